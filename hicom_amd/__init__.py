@@ -1,0 +1,8 @@
+"""hicom_amd -- MI355X-native (gfx950) implementation of HICom's hybrid-level, instruction-injected
+video-token compressor behind the reference's projector API."""
+from .projector import (GlobalCompressor, GuideInjector, HIComProjector, IdentityMap, LocalCompressor,  # noqa: F401
+                        MultiheadAttention, build_mlp, build_vision_projector)
+from .mm_utils import post_process_visual_feature  # noqa: F401
+
+__all__ = ["build_vision_projector", "HIComProjector", "LocalCompressor", "GlobalCompressor", "GuideInjector",
+           "MultiheadAttention", "IdentityMap", "build_mlp", "post_process_visual_feature"]

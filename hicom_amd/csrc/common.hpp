@@ -1,0 +1,74 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) HICom kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hicom_hip.h"
+
+namespace hicom {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one 16x16x32 A/B fragment
+typedef __attribute__((ext_vector_type(4))) short bf16x4;   // 4 bf16 = one 16x16x16 A/B fragment
+typedef __attribute__((ext_vector_type(4))) float f32x4;    // one 16x16 f32 accumulator fragment
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(3))) unsigned int u32x3;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ float bf16lo_to_f32(uint32_t packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(uint32_t packed) { return __uint_as_float(packed & 0xFFFF0000u); }
+
+// round-to-nearest-even f32 -> bf16 bits (plain cast: hipcc emits v_cvt_pk_bf16_f32, NaN-safe)
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+
+// x ~= hi + lo, both bf16; |x - hi - lo| <= 2^-17 |x|
+__device__ __forceinline__ void split_bf16(float x, uint16_t& hi, uint16_t& lo) {
+    hi = f32_to_bf16(x);
+    lo = f32_to_bf16(x - bf16_to_f32(hi));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// start of window i along an axis (projector.py:501-522 restated in closed form)
+__device__ __host__ __forceinline__ int axis_start(const hicom_axis& a, int i) {
+    return i < a.nfull ? i * a.k : a.nfull * a.k + (i - a.nfull) * (a.k - 1) - 1;
+}
+
+// raw workgroup barrier that orders LDS traffic only (leaves global loads / LDS-DMA in flight)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+}  // namespace hicom
+
+// host-side error plumbing shared by the C-ABI translation units
+namespace hicom_host {
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+}  // namespace hicom_host
+
+#define HICOM_REQUIRE(cond, code, ...)            \
+    do {                                          \
+        if (!(cond)) {                            \
+            hicom_host::set_error(__VA_ARGS__);   \
+            return (code);                        \
+        }                                         \
+    } while (0)

@@ -1,0 +1,314 @@
+// Global compressor: streaming multi-query cross-attention over ALL visual tokens, K = V = x.
+//
+// Replaces MultiheadAttention.forward (reference projector.py:166-228) as used by
+// GlobalCompressor.forward (:634-646).  k_proj / v_proj are folded into the queries on the
+// host side of the ABI (hicom_fold_query_fwd), so this kernel consumes the RAW bf16 tokens:
+//     S[r, n]   = qt[r, :] . x[n, :]  (+ separable positional terms a_t + a_y + a_x)
+//     ACC[r, :] = sum_n exp(S[r, n] - m_r) x[n, :]          (online softmax, fp32)
+// and never materialises K, V or x + pos.  x is read from HBM exactly once per row group.
+//
+// CDNA4 mapping
+//   * workgroup = 4 waves, 2 workgroups per CU (80 KiB LDS, <=256 VGPR each); a workgroup walks
+//     a contiguous range of 16-token tiles with running (m, l, ACC) in registers.
+//   * tile staging: global_load_lds_dwordx4 (LDS-DMA, 1 KiB per wave instruction, whole 256-B
+//     row segments) into a double-buffered [E/128][16 rows][256 B] image with the
+//     chunk ^ rot(row) swizzle, so that BOTH the row read (ds_read_b128: B operand of the
+//     score MFMA) and the transposed read (ds_read_b64_tr_b16: B operand of the P.x MFMA)
+//     of the same image are bank-conflict free / 2-way.
+//   * scores: v_mfma_f32_16x16x32_bf16, A = folded queries as bf16 hi + lo pairs (two MFMAs
+//     into one accumulator -> fp32-grade logits), each wave contracts its own E/4 channel
+//     slice and the four partial 16x16 tiles are summed through LDS.
+//   * softmax fused at wavefront level: lane (row, token-quad) owns 4 logits, row max / row sum
+//     are two cross-lane shuffles; P is split hi/lo and is already in A-fragment order.
+//   * P.x: v_mfma_f32_16x16x16_bf16, each wave owns E/4 output channels (72 accumulator VGPRs).
+#include "common.hpp"
+
+namespace hicom {
+
+struct StreamParams {
+    const uint16_t* x;
+    long N;
+    const uint16_t* qhi;
+    const uint16_t* qlo;
+    const float* pos_a;
+    int pos_stride;
+    int H, W, HW;
+    int t0i, y0i, x0i;
+    float* scores;
+    long score_stride;
+    float* part_m;
+    float* part_l;
+    float* part_acc;
+    int rows_pad;
+    int ntiles;
+};
+
+// bit rotation of the row index used as the 16-byte-chunk swizzle (bijective on 0..15)
+__device__ __forceinline__ int swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+// token-quad permutation: MFMA k-group g <-> tile rows 4*sig(g)..4*sig(g)+3, so that the two
+// 4-row blocks a 32-lane half reads with ds_read_b64_tr_b16 sit 8 rows apart (conflict-free)
+__device__ __forceinline__ int sig(int g) { return ((g & 1) << 1) | (g >> 1); }
+
+template <int NB>
+__global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
+    constexpr int E = NB * 128;
+    constexpr int SLICE = E / 4;          // channels owned by one wave
+    constexpr int KSTEPS = SLICE / 32;    // score MFMAs (K = 32 channels) per wave per pass
+    constexpr int CBLK = SLICE / 16;      // 16-channel output blocks per wave
+    constexpr int TILE_BYTES = NB * 4096;
+    constexpr int PIECES = NB * 4;        // 1 KiB LDS-DMA pieces per tile
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* tilebuf = smem;                                           // [2][TILE_BYTES]
+    float* red = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);  // [4 waves][16 rows][16 tokens]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int part = blockIdx.x, rg = blockIdx.y, nparts = gridDim.x;
+    const int tb = (int)(((long)p.ntiles * part) / nparts);
+    const int te = (int)(((long)p.ntiles * (part + 1)) / nparts);
+    const long row_glob = (long)rg * 16 + r16;
+
+    // ---- A operand: folded queries, this wave's channel slice, hi and lo parts ----------------
+    bf16x8 ahi[KSTEPS], alo[KSTEPS];
+    {
+        const long off = row_glob * E + SLICE * wave + 8 * kg;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            ahi[s] = *reinterpret_cast<const bf16x8*>(p.qhi + off + 32 * s);
+            alo[s] = *reinterpret_cast<const bf16x8*>(p.qlo + off + 32 * s);
+        }
+    }
+
+    f32x4 acc[CBLK];
+#pragma unroll
+    for (int cb = 0; cb < CBLK; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -1.0e30f, l_run = 0.f;   // online-softmax state of row r16 (replicated over kg, waves)
+
+    // ---- LDS-DMA staging of one 16-token tile ------------------------------------------------
+    auto stage = [&](int tile, int buf) {
+        const int r = lane >> 4, cpos = lane & 15;
+        static_assert(PIECES % 4 == 0, "pieces are dealt round-robin to the 4 waves");
+#pragma unroll
+        for (int i = 0; i < PIECES / 4; ++i) {
+            const int pi = wave + 4 * i;
+            const int blk = pi >> 2, row = 4 * (pi & 3) + r;
+            long tok = (long)tile * 16 + row;
+            tok = tok < p.N ? tok : p.N - 1;   // tail tile: re-read a valid row (masked later)
+            const char* src = reinterpret_cast<const char*>(p.x) + tok * (long)(E * 2) + blk * 256 +
+                              16 * (cpos ^ swz(row));
+            char* dst = tilebuf + buf * TILE_BYTES + pi * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
+                                             (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+        }
+    };
+
+    // per-lane LDS byte offsets inside a tile image
+    const int q4 = (lane >> 2) & 3, pp = lane & 3;
+    const int trow = 4 * sig(kg) + q4;                // row this lane addresses in transposed reads
+    const int rd_row_off = r16 * 256, rd_swz = swz(r16);
+    const int tr_row_off = trow * 256 + 8 * (pp & 1), tr_swz = swz(trow);
+    const float* pa = p.pos_a ? p.pos_a + row_glob * p.pos_stride : nullptr;
+
+    // positional logit terms are fetched ONE TILE AHEAD: vmcnt retires in order, so consuming an
+    // ordinary load issued after the LDS-DMA of the next tile would drain that prefetch.
+    float pt[4] = {0.f, 0.f, 0.f, 0.f}, py[4] = {0.f, 0.f, 0.f, 0.f}, px[4] = {0.f, 0.f, 0.f, 0.f};
+    auto fetch_pos = [&](int tile) {
+        if (pa) {
+            const long nb = (long)tile * 16 + 4 * sig(kg);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                long n = nb + j;
+                n = n < p.N ? n : p.N - 1;
+                const unsigned un = (unsigned)n;
+                const unsigned t = un / (unsigned)p.HW, rem = un - t * (unsigned)p.HW;
+                const unsigned y = rem / (unsigned)p.W, xx = rem - y * (unsigned)p.W;
+                pt[j] = pa[p.t0i + t];
+                py[j] = pa[p.y0i + y];
+                px[j] = pa[p.x0i + xx];
+            }
+        }
+    };
+
+    if (tb < te) {
+        fetch_pos(tb);
+        stage(tb, 0);
+    }
+
+    for (int tile = tb; tile < te; ++tile) {
+        const int cur = (tile - tb) & 1;
+        // [A] every wave's LDS-DMA pieces of tile `tile` have landed (explicit drain: hipcc does
+        //     not order LDS-DMA against the barrier by itself), and every wave is done reading the
+        //     other buffer and the reduction scratch
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float padd[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) padd[j] = pt[j] + py[j] + px[j];
+        if (tile + 1 < te) {
+            fetch_pos(tile + 1);
+            stage(tile + 1, cur ^ 1);
+        }
+        const char* img = tilebuf + cur * TILE_BYTES;
+
+        // ---- partial scores over this wave's channel slice: S = qt_hi.x^T + qt_lo.x^T -------
+        f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const int ch0 = SLICE * wave + 32 * s;
+            const int blk = ch0 >> 7, cbase = (ch0 & 127) >> 3;
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(img + blk * 4096 + rd_row_off +
+                                                              16 * ((cbase + kg) ^ rd_swz));
+            s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[s], b, s4, 0, 0, 0);
+            s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[s], b, s4, 0, 0, 0);
+        }
+        // C layout: lane holds rows 4*kg + j (j = 0..3) of token column r16
+        float* rw = red + wave * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rw[(4 * kg + j) * 16 + r16] = s4[j];
+        lds_barrier();   // [B] LDS only: the next tile's LDS-DMA stays in flight
+
+        // ---- full logits of (row r16, tokens 4*sig(kg) .. +3) -----------------------------------
+        const float* rb = red + r16 * 16 + 4 * sig(kg);
+        f32x4 lg = *reinterpret_cast<const f32x4*>(rb);
+        lg += *reinterpret_cast<const f32x4*>(rb + 256);
+        lg += *reinterpret_cast<const f32x4*>(rb + 512);
+        lg += *reinterpret_cast<const f32x4*>(rb + 768);
+        const long n0 = (long)tile * 16 + 4 * sig(kg);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lg[j] += padd[j];
+        if (wave == 0) *reinterpret_cast<f32x4*>(p.scores + row_glob * p.score_stride + n0) = lg;
+
+        // ---- online softmax for row r16 (lanes r16, r16+16, r16+32, r16+48 share the row) -------
+        float tmax = -1.0e30f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tmax = (n0 + j < p.N) ? fmaxf(tmax, lg[j]) : tmax;
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = expf(m_run - m_new);
+        float pr[4], lsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pr[j] = (n0 + j < p.N) ? expf(lg[j] - m_new) : 0.f;
+            lsum += pr[j];
+        }
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+        bf16x4 phi, plo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint16_t h, l;
+            split_bf16(pr[j], h, l);
+            phi[j] = (short)h;
+            plo[j] = (short)l;
+        }
+        // rescale the running context when any row's max moved (wave-uniform branch)
+        if (__any(alpha != 1.0f)) {
+            const float a0 = __shfl(alpha, 4 * kg + 0, 64), a1 = __shfl(alpha, 4 * kg + 1, 64);
+            const float a2 = __shfl(alpha, 4 * kg + 2, 64), a3 = __shfl(alpha, 4 * kg + 3, 64);
+#pragma unroll
+            for (int cb = 0; cb < CBLK; ++cb) {
+                acc[cb][0] *= a0; acc[cb][1] *= a1; acc[cb][2] *= a2; acc[cb][3] *= a3;
+            }
+        }
+
+        // ---- ACC += P . x over this wave's output channels ----------------------------------------
+#pragma unroll
+        for (int cb = 0; cb < CBLK; ++cb) {
+            const int ch0 = SLICE * wave + 16 * cb;
+            const int blk = ch0 >> 7, c2 = (ch0 & 127) >> 3;
+            const char* a = img + blk * 4096 + tr_row_off + 16 * ((c2 + (pp >> 1)) ^ tr_swz);
+            const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(phi, b, acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(plo, b, acc[cb], 0, 0, 0);
+        }
+    }
+
+    // ---- partial results of this token chunk ----------------------------------------------------
+    const long prow = (long)part * p.rows_pad + rg * 16;
+    if (wave == 0 && kg == 0) {
+        p.part_m[prow + r16] = m_run;
+        p.part_l[prow + r16] = l_run;
+    }
+#pragma unroll
+    for (int cb = 0; cb < CBLK; ++cb) {
+        float* o = p.part_acc + (prow + 4 * kg) * E + SLICE * wave + 16 * cb + r16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[(long)j * E] = acc[cb][j];
+    }
+}
+
+static int g_num_cus = 0;
+static int num_cus() {
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_num_cus = prop.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+}  // namespace hicom
+
+using namespace hicom;
+
+extern "C" int hicom_global_stream_nparts(int64_t N, int32_t rows_pad) {
+    if (N <= 0 || rows_pad <= 0) return HICOM_EINVAL;
+    const long ntiles = (N + 15) / 16;
+    const int groups = rows_pad / 16;
+    long want = 2L * num_cus() / (groups > 0 ? groups : 1);   // 2 resident workgroups per CU
+    if (want < 1) want = 1;
+    // keep >= 4 tiles per chunk so the per-chunk partial write stays a small fraction of the stream
+    long cap = ntiles / 4;
+    if (cap < 1) cap = 1;
+    return (int)(want < cap ? want : cap);
+}
+
+extern "C" int hicom_global_stream_fwd(const void* x, int64_t N, int32_t E,
+                                       const void* qt_hi, const void* qt_lo, int32_t rows_pad,
+                                       const float* pos_a, int32_t pos_stride,
+                                       int32_t H, int32_t W, int32_t t_index0, int32_t y_index0, int32_t x_index0,
+                                       float* scores, int64_t score_stride,
+                                       float* part_m, float* part_l, float* part_acc, int32_t nparts,
+                                       void* stream) {
+    HICOM_REQUIRE(x && qt_hi && qt_lo && scores && part_m && part_l && part_acc, HICOM_EINVAL, "global_stream: NULL pointer");
+    HICOM_REQUIRE(E == 1152 || E == 768, HICOM_EUNSUP, "global_stream: E=%d (only 1152 / 768)", E);
+    HICOM_REQUIRE(N > 0 && N < (1L << 31), HICOM_EINVAL, "global_stream: N out of range");
+    HICOM_REQUIRE(rows_pad > 0 && rows_pad % 16 == 0, HICOM_EINVAL, "global_stream: rows_pad must be a multiple of 16");
+    HICOM_REQUIRE(nparts > 0, HICOM_EINVAL, "global_stream: nparts");
+    HICOM_REQUIRE(score_stride >= ((N + 15) / 16) * 16 && score_stride % 4 == 0, HICOM_EINVAL,
+                  "global_stream: score_stride must be >= roundup(N,16)");
+    HICOM_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)qt_hi % 16 == 0) && ((uintptr_t)qt_lo % 16 == 0) &&
+                      ((uintptr_t)scores % 16 == 0),
+                  HICOM_EINVAL, "global_stream: pointers must be 16-byte aligned");
+    if (pos_a) HICOM_REQUIRE(H > 0 && W > 0 && pos_stride > 0, HICOM_EINVAL, "global_stream: pos geometry");
+    StreamParams p;
+    p.x = (const uint16_t*)x; p.N = N; p.qhi = (const uint16_t*)qt_hi; p.qlo = (const uint16_t*)qt_lo;
+    p.pos_a = pos_a; p.pos_stride = pos_stride; p.H = H; p.W = W; p.HW = H * W;
+    p.t0i = t_index0; p.y0i = y_index0; p.x0i = x_index0;
+    p.scores = scores; p.score_stride = score_stride;
+    p.part_m = part_m; p.part_l = part_l; p.part_acc = part_acc; p.rows_pad = rows_pad;
+    p.ntiles = (int)((N + 15) / 16);
+    dim3 grid((unsigned)nparts, (unsigned)(rows_pad / 16));
+    hipStream_t s = (hipStream_t)stream;
+    if (E == 1152) {
+        constexpr int smem = 2 * 9 * 4096 + 4096;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(global_stream_kernel<9>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(global_stream_kernel<9>, grid, dim3(256), smem, s, p);
+    } else {
+        constexpr int smem = 2 * 6 * 4096 + 4096;
+        hipLaunchKernelGGL(global_stream_kernel<6>, grid, dim3(256), smem, s, p);
+    }
+    return hicom_host::check_launch("global_stream");
+}

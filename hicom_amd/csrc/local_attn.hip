@@ -1,0 +1,241 @@
+// Local compressor: windowed single-head cross-attention as ONE streaming pass.
+//
+// Replaces LocalCompressor.forward's divide_feature x3 + bmm + softmax + bmm + un-window
+// (reference projector.py:544-558).  The window regroup is pure address arithmetic here
+// (zero bytes moved); every key row and every value row is read from HBM exactly once.
+//
+// Mapping: one 256-thread workgroup (4 waves) per window.  A token row of D bf16 channels is
+// spread over the 64 lanes of a wave as NV segments of 64 x 12 B (global_load_dwordx3, fully
+// coalesced 768-B runs; the 3 tokens of a window row are contiguous in HBM).  Wave w scores
+// tokens w, w+4, ... with a 64-lane shuffle reduction, the softmax over the <= few-hundred
+// window scores is done in LDS, then the same wave->token assignment accumulates p * value in
+// fp32 registers and the four partial rows are summed through LDS.
+//
+// Roofline: HBM-bound streaming (4*D flop per 4*D bytes); no MFMA on purpose -- one query row
+// per window with private keys is a block-diagonal M=1 product (SURVEY.md §7 "Where MFMA applies").
+#include "common.hpp"
+
+namespace hicom {
+
+struct __attribute__((packed, aligned(4))) Seg12 { uint32_t a, b, c; };
+
+struct LocalParams {
+    const uint16_t* key;
+    const uint16_t* value;
+    const void* query;
+    int query_f32;
+    long query_stride;
+    hicom_axis at, ay, ax;
+    float scale, bias;
+    int l2norm;
+    float* ctx;
+};
+
+template <int NV>
+__device__ __forceinline__ void load_row(const uint16_t* row, int lane, float (&v)[NV][6]) {
+#pragma unroll
+    for (int s = 0; s < NV; ++s) {
+        const Seg12 g = *reinterpret_cast<const Seg12*>(row + 384 * s + 6 * lane);
+        v[s][0] = bf16lo_to_f32(g.a); v[s][1] = bf16hi_to_f32(g.a);
+        v[s][2] = bf16lo_to_f32(g.b); v[s][3] = bf16hi_to_f32(g.b);
+        v[s][4] = bf16lo_to_f32(g.c); v[s][5] = bf16hi_to_f32(g.c);
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void local_attn_kernel(LocalParams p) {
+    constexpr int D = NV * 384;
+    extern __shared__ __attribute__((aligned(16))) float lsm[];
+    const int ks2 = p.ay.k * p.ax.k;
+    const int WIN = p.at.k * ks2;
+    float* sc = lsm;                              // [WIN] scores
+    float* part = lsm + ((WIN + 3) & ~3);         // [4][D] partial contexts
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int win = blockIdx.x;
+    const int w1 = win % p.ax.nwin;
+    const int h1 = (win / p.ax.nwin) % p.ay.nwin;
+    const int t1 = win / (p.ax.nwin * p.ay.nwin);
+    const int t0 = axis_start(p.at, t1), y0 = axis_start(p.ay, h1), x0 = axis_start(p.ax, w1);
+    const int H = p.ay.n, W = p.ax.n;
+
+    // query fragment of this lane (fp32)
+    float q[NV][6];
+    if (p.query_f32) {
+        const float* qp = reinterpret_cast<const float*>(p.query) + (long)win * p.query_stride;
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) q[s][j] = qp[384 * s + 6 * lane + j];
+    } else {
+        load_row<NV>(reinterpret_cast<const uint16_t*>(p.query) + (long)win * p.query_stride, lane, q);
+    }
+    if (p.l2norm & 2) {   // clip-scale variant: guide / ||guide||  (projector.py:529)
+        float qq = 0.f;
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) qq += q[s][j] * q[s][j];
+        const float inv = 1.0f / sqrtf(wave_sum(qq));
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) q[s][j] *= inv;
+    }
+
+    auto token_of = [&](int i) -> long {
+        const int t2 = i / ks2, r = i - t2 * ks2;
+        const int h2 = r / p.ax.k, w2 = r - h2 * p.ax.k;
+        return ((long)(t0 + t2) * H + (y0 + h2)) * W + (x0 + w2);
+    };
+
+    // ---- phase 1: scores ---------------------------------------------------------------
+    for (int i0 = wave; i0 < WIN; i0 += 12) {     // up to 3 tokens in flight per wave
+        float k[3][NV][6];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int i = i0 + 4 * u;
+            if (i < WIN) load_row<NV>(p.key + token_of(i) * D, lane, k[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int i = i0 + 4 * u;
+            if (i < WIN) {
+                float dot = 0.f, kk = 0.f;
+#pragma unroll
+                for (int s = 0; s < NV; ++s)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        dot = fmaf(q[s][j], k[u][s][j], dot);
+                        kk = fmaf(k[u][s][j], k[u][s][j], kk);
+                    }
+                dot = wave_sum(dot);
+                if (p.l2norm & 1) dot /= sqrtf(wave_sum(kk));   // frames_embed / ||.||  (:528)
+                if (lane == 0) sc[i] = dot * p.scale + p.bias;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- softmax statistics (every wave redundantly; WIN is tiny) -------------------------
+    float mx = -3.0e38f;
+    for (int i = lane; i < WIN; i += 64) mx = fmaxf(mx, sc[i]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int i = lane; i < WIN; i += 64) sum += expf(sc[i] - mx);
+    const float inv_sum = 1.0f / wave_sum(sum);
+
+    // ---- phase 2: context = sum_i p_i * value_i ---------------------------------------------
+    float acc[NV][6];
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[s][j] = 0.f;
+    for (int i0 = wave; i0 < WIN; i0 += 12) {
+        float v[3][NV][6];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int i = i0 + 4 * u;
+            if (i < WIN) load_row<NV>(p.value + token_of(i) * D, lane, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int i = i0 + 4 * u;
+            if (i < WIN) {
+                const float pi = expf(sc[i] - mx) * inv_sum;
+#pragma unroll
+                for (int s = 0; s < NV; ++s)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc[s][j] = fmaf(pi, v[u][s][j], acc[s][j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) part[wave * D + 384 * s + 6 * lane + j] = acc[s][j];
+    __syncthreads();
+    float* out = p.ctx + (long)win * D;
+    for (int c = tid; c < D; c += 256) out[c] = (part[c] + part[D + c]) + (part[2 * D + c] + part[3 * D + c]);
+}
+
+// ---- pooled per-window query (trilinear, align_corners=False; projector.py:539-540) ----------
+struct PoolParams {
+    const uint16_t* x;
+    int T, H, W, D, To, Ho, Wo;
+    float* out;
+};
+
+__device__ __forceinline__ void lerp_tap(int i, int n_in, int n_out, int& i0, int& i1, float& lam) {
+    // src = (i + 0.5) * n_in / n_out - 0.5 clamped at 0 (PyTorch area_pixel_compute_source_index)
+    const float scale = (float)n_in / (float)n_out;
+    float src = ((float)i + 0.5f) * scale - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)floorf(src);
+    if (i0 > n_in - 1) i0 = n_in - 1;
+    i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
+    lam = src - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void trilinear_pool_kernel(PoolParams p) {
+    const int o = blockIdx.x;
+    const int wo = o % p.Wo, ho = (o / p.Wo) % p.Ho, to = o / (p.Wo * p.Ho);
+    int t0, t1, y0, y1, x0, x1;
+    float lt, ly, lx;
+    lerp_tap(to, p.T, p.To, t0, t1, lt);
+    lerp_tap(ho, p.H, p.Ho, y0, y1, ly);
+    lerp_tap(wo, p.W, p.Wo, x0, x1, lx);
+    auto at = [&](int t, int y, int x, int c) -> float {
+        return bf16_to_f32(p.x[(((long)t * p.H + y) * p.W + x) * p.D + c]);
+    };
+    for (int c = threadIdx.x; c < p.D; c += blockDim.x) {
+        // same nesting as the separable restatement in the oracle: t, then h, then w
+        const float a00 = at(t0, y0, x0, c) * (1.f - lt) + at(t1, y0, x0, c) * lt;
+        const float a01 = at(t0, y0, x1, c) * (1.f - lt) + at(t1, y0, x1, c) * lt;
+        const float a10 = at(t0, y1, x0, c) * (1.f - lt) + at(t1, y1, x0, c) * lt;
+        const float a11 = at(t0, y1, x1, c) * (1.f - lt) + at(t1, y1, x1, c) * lt;
+        const float b0 = a00 * (1.f - ly) + a10 * ly;
+        const float b1 = a01 * (1.f - ly) + a11 * ly;
+        p.out[(long)o * p.D + c] = b0 * (1.f - lx) + b1 * lx;
+    }
+}
+
+}  // namespace hicom
+
+using namespace hicom;
+
+extern "C" int hicom_local_attn_fwd(const void* key, const void* value, int32_t D,
+                                    hicom_axis at, hicom_axis ay, hicom_axis ax,
+                                    const void* query, int32_t query_dt, int64_t query_stride,
+                                    float scale, float bias, int32_t l2norm,
+                                    float* ctx, void* stream) {
+    HICOM_REQUIRE(key && value && query && ctx, HICOM_EINVAL, "local_attn: NULL pointer");
+    HICOM_REQUIRE(D == 1152 || D == 768, HICOM_EUNSUP, "local_attn: D=%d (only 1152 / 768)", D);
+    HICOM_REQUIRE(query_dt == HICOM_DT_BF16 || query_dt == HICOM_DT_F32, HICOM_EINVAL, "local_attn: query dtype");
+    for (const hicom_axis* a : {&at, &ay, &ax}) {
+        HICOM_REQUIRE(a->n > 0 && a->k > 0 && a->nwin > 0 && a->nfull >= 0 && a->nfull <= a->nwin && a->k <= a->n,
+                      HICOM_EINVAL, "local_attn: bad axis n=%d k=%d nwin=%d nfull=%d", a->n, a->k, a->nwin, a->nfull);
+        const int last = axis_start(*a, a->nwin - 1);
+        HICOM_REQUIRE(last >= 0 && last + a->k <= a->n, HICOM_EINVAL, "local_attn: window runs off the axis");
+    }
+    const long win = (long)at.k * ay.k * ax.k;
+    HICOM_REQUIRE(win <= 4096, HICOM_EUNSUP, "local_attn: window of %ld tokens is too large", win);
+    const long nwin = (long)at.nwin * ay.nwin * ax.nwin;
+    HICOM_REQUIRE(nwin < (1L << 31), HICOM_EINVAL, "local_attn: too many windows");
+    LocalParams p{(const uint16_t*)key, (const uint16_t*)value, query, query_dt == HICOM_DT_F32,
+                  (long)query_stride, at, ay, ax, scale, bias, l2norm, ctx};
+    const size_t smem = (((size_t)win + 3) & ~(size_t)3) * 4 + 4 * (size_t)D * 4;
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 1152) hipLaunchKernelGGL(local_attn_kernel<3>, dim3((unsigned)nwin), dim3(256), smem, s, p);
+    else hipLaunchKernelGGL(local_attn_kernel<2>, dim3((unsigned)nwin), dim3(256), smem, s, p);
+    return hicom_host::check_launch("local_attn");
+}
+
+extern "C" int hicom_trilinear_pool_fwd(const void* x, int32_t T, int32_t H, int32_t W, int32_t D,
+                                        int32_t To, int32_t Ho, int32_t Wo, float* out, void* stream) {
+    HICOM_REQUIRE(x && out, HICOM_EINVAL, "trilinear_pool: NULL pointer");
+    HICOM_REQUIRE(T > 0 && H > 0 && W > 0 && D > 0 && To > 0 && Ho > 0 && Wo > 0, HICOM_EINVAL, "trilinear_pool: bad shape");
+    PoolParams p{(const uint16_t*)x, T, H, W, D, To, Ho, Wo, out};
+    hipLaunchKernelGGL(trilinear_pool_kernel, dim3((unsigned)((long)To * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, p);
+    return hicom_host::check_launch("trilinear_pool");
+}

@@ -1,0 +1,213 @@
+// Small per-call operators around the two streaming kernels: few-row linears (GEMV class),
+// the k_proj fold, the hi/lo bf16 split and row scatter.  All are latency/HBM-bound on a few MB
+// of weights; they use plain fp32 FMAs on wave64 with 16-byte coalesced weight reads.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.hpp"
+
+namespace hicom_host {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return HICOM_ELAUNCH;
+    }
+    return HICOM_OK;
+}
+}  // namespace hicom_host
+
+extern "C" int hicom_abi_version(void) { return HICOM_ABI_VERSION; }
+extern "C" const char* hicom_last_error(void) { return hicom_host::g_err; }
+
+namespace hicom {
+
+// ---------------------------------------------------------------------------------------------
+// y[m, n] = act(sum_k x[row(m,n), k] * w[n, k] + b[n]) + res[m, n]
+// one wave per output column n, up to MR rows per workgroup pass; lanes stride K in 8-element
+// chunks (16 B of bf16 weights / 32 B of f32), 64-lane shuffle reduction per row.
+// ---------------------------------------------------------------------------------------------
+struct LinearParams {
+    const void* x;
+    const void* w;
+    const void* b;
+    const float* res;
+    float* y;
+    int x_f32, w_f32, b_f32, res_bcast;
+    int M, N, K;
+    int head_rows, head_dim;
+    int act;
+};
+
+template <bool F32>
+__device__ __forceinline__ void load8(const void* base, long off, float (&v)[8]) {
+    if constexpr (F32) {
+        const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+        const float4 c = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+    } else {
+        const u32x4 g = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(base) + off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = bf16lo_to_f32(g[i]);
+            v[2 * i + 1] = bf16hi_to_f32(g[i]);
+        }
+    }
+}
+
+template <bool XF32, bool WF32, int MR>
+__global__ __launch_bounds__(256) void linear_rows_kernel(LinearParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wave;
+    const int m0 = blockIdx.y * MR;
+    if (n >= p.N) return;
+    float acc[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) acc[r] = 0.f;
+    const int head = p.head_dim > 0 ? n / p.head_dim : 0;
+    for (int k = lane * 8; k < p.K; k += 512) {
+        float wv[8];
+        load8<WF32>(p.w, (long)n * p.K + k, wv);
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            const int m = m0 + r;
+            if (m < p.M) {
+                const long xr = p.head_dim > 0 ? (long)m * p.head_rows + head : m;
+                float xv[8];
+                load8<XF32>(p.x, xr * p.K + k, xv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[r] = fmaf(xv[i], wv[i], acc[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        const float s = wave_sum(acc[r]);
+        const int m = m0 + r;
+        if (lane == 0 && m < p.M) {
+            float v = s;
+            if (p.b) v += p.b_f32 ? reinterpret_cast<const float*>(p.b)[n]
+                                  : bf16_to_f32(reinterpret_cast<const uint16_t*>(p.b)[n]);
+            if (p.act == HICOM_ACT_GELU) v = gelu_erf(v);
+            if (p.res) v += p.res[(p.res_bcast ? 0 : (long)m * p.N) + n];
+            p.y[(long)m * p.N + n] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// qt[q*nh + h, c] = scale * sum_j w_k[h*hd + j, c] * qp[q, h*hd + j]      (hd = E / nh)
+// thread per output channel c (coalesced w_k rows), QB queries per pass held in registers.
+// ---------------------------------------------------------------------------------------------
+template <int QB>
+__global__ __launch_bounds__(128) void fold_query_kernel(const float* qp, const uint16_t* wk, int nq, int nh, int E,
+                                                         float scale, float* qt) {
+    const int c = blockIdx.x * 128 + threadIdx.x;
+    const int h = blockIdx.y, q0 = blockIdx.z * QB;
+    const int hd = E / nh;
+    __shared__ float qs[QB][128];   // hd <= 128
+    for (int i = threadIdx.x; i < QB * hd; i += 128) {
+        const int q = i / hd, j = i - q * hd;
+        qs[q][j] = (q0 + q < nq) ? qp[(long)(q0 + q) * E + h * hd + j] : 0.f;
+    }
+    __syncthreads();
+    if (c >= E) return;
+    float acc[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) acc[q] = 0.f;
+    for (int j = 0; j < hd; ++j) {
+        const float w = bf16_to_f32(wk[(long)(h * hd + j) * E + c]);
+#pragma unroll
+        for (int q = 0; q < QB; ++q) acc[q] = fmaf(w, qs[q][j], acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q)
+        if (q0 + q < nq) qt[((long)(q0 + q) * nh + h) * E + c] = acc[q] * scale;
+}
+
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* x, int rows, int rows_pad, int E,
+                                                         uint16_t* hi, uint16_t* lo) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows_pad * E) return;
+    const long r = i / E;
+    uint16_t h = 0, l = 0;
+    if (r < rows) split_bf16(x[i], h, l);
+    hi[i] = h;
+    lo[i] = l;
+}
+
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const void* src, int src_f32, int src_rows, int ncols,
+                                                           void* dst, int dst_f32, long ldd, long row0, long row_step,
+                                                           int nl_group, int count) {
+    const int i = blockIdx.x;
+    const long sr = i % src_rows, dr = row0 + (long)i * row_step + (nl_group > 0 ? i / nl_group : 0);
+    for (int c = threadIdx.x; c < ncols; c += 256) {
+        const float v = src_f32 ? reinterpret_cast<const float*>(src)[sr * ncols + c]
+                                : bf16_to_f32(reinterpret_cast<const uint16_t*>(src)[sr * ncols + c]);
+        if (dst_f32) reinterpret_cast<float*>(dst)[dr * ldd + c] = v;
+        else reinterpret_cast<uint16_t*>(dst)[dr * ldd + c] = f32_to_bf16(v);
+    }
+}
+
+}  // namespace hicom
+
+using namespace hicom;
+
+extern "C" int hicom_linear_fwd(const void* x, int32_t x_dt, const void* w, int32_t w_dt,
+                                const void* b, int32_t b_dt, const float* res, int32_t res_bcast,
+                                int32_t M, int32_t N, int32_t K, int32_t head_rows, int32_t head_dim,
+                                int32_t act, float* y, void* stream) {
+    HICOM_REQUIRE(x && w && y, HICOM_EINVAL, "linear: NULL pointer");
+    HICOM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0, HICOM_EINVAL, "linear: bad shape M=%d N=%d K=%d (K %% 8)", M, N, K);
+    HICOM_REQUIRE(head_dim == 0 || (head_dim > 0 && head_rows > 0), HICOM_EINVAL, "linear: head mode");
+    LinearParams p{x, w, b, res, y, x_dt == HICOM_DT_F32, w_dt == HICOM_DT_F32, b_dt == HICOM_DT_F32, res_bcast,
+                   M, N, K, head_rows, head_dim, act};
+    constexpr int MR = 8;
+    dim3 grid((unsigned)((N + 3) / 4), (unsigned)((M + MR - 1) / MR));
+    hipStream_t s = (hipStream_t)stream;
+    if (p.x_f32 && p.w_f32) hipLaunchKernelGGL((linear_rows_kernel<true, true, MR>), grid, dim3(256), 0, s, p);
+    else if (p.x_f32) hipLaunchKernelGGL((linear_rows_kernel<true, false, MR>), grid, dim3(256), 0, s, p);
+    else if (p.w_f32) hipLaunchKernelGGL((linear_rows_kernel<false, true, MR>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((linear_rows_kernel<false, false, MR>), grid, dim3(256), 0, s, p);
+    return hicom_host::check_launch("linear");
+}
+
+extern "C" int hicom_fold_query_fwd(const float* qp, const void* w_k, int32_t nq, int32_t nh, int32_t E,
+                                    float scale, float* qt, void* stream) {
+    HICOM_REQUIRE(qp && w_k && qt, HICOM_EINVAL, "fold_query: NULL pointer");
+    HICOM_REQUIRE(nq > 0 && nh > 0 && E > 0 && E % nh == 0 && E / nh <= 128, HICOM_EINVAL, "fold_query: bad shape");
+    constexpr int QB = 8;
+    dim3 grid((unsigned)((E + 127) / 128), (unsigned)nh, (unsigned)((nq + QB - 1) / QB));
+    hipLaunchKernelGGL(fold_query_kernel<QB>, grid, dim3(128), 0, (hipStream_t)stream, qp, (const uint16_t*)w_k, nq, nh, E,
+                       scale, qt);
+    return hicom_host::check_launch("fold_query");
+}
+
+extern "C" int hicom_split_bf16_fwd(const float* x, int32_t rows, int32_t rows_pad, int32_t E,
+                                    void* hi, void* lo, void* stream) {
+    HICOM_REQUIRE(x && hi && lo, HICOM_EINVAL, "split_bf16: NULL pointer");
+    HICOM_REQUIRE(rows > 0 && rows_pad >= rows && E > 0, HICOM_EINVAL, "split_bf16: bad shape");
+    const long n = (long)rows_pad * E;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, rows,
+                       rows_pad, E, (uint16_t*)hi, (uint16_t*)lo);
+    return hicom_host::check_launch("split_bf16");
+}
+
+extern "C" int hicom_scatter_rows_fwd(const void* src, int32_t src_dt, int32_t src_rows, int32_t ncols,
+                                      void* dst, int32_t dst_dt, int64_t ldd, int64_t row0, int64_t row_step,
+                                      int32_t nl_group, int32_t count, void* stream) {
+    HICOM_REQUIRE(src && dst, HICOM_EINVAL, "scatter_rows: NULL pointer");
+    HICOM_REQUIRE(src_rows > 0 && ncols > 0 && count >= 0 && ldd >= ncols && nl_group >= 0, HICOM_EINVAL, "scatter_rows: bad shape");
+    if (count == 0) return HICOM_OK;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)count), dim3(256), 0, (hipStream_t)stream, src,
+                       src_dt == HICOM_DT_F32, src_rows, ncols, dst, dst_dt == HICOM_DT_F32, (long)ldd, (long)row0,
+                       (long)row_step, nl_group, count);
+    return hicom_host::check_launch("scatter_rows");
+}

@@ -1,0 +1,454 @@
+"""MI355X-native drop-in for the reference's `hicom/model/projector.py` (HICom's hybrid-level,
+instruction-injected video-token compressor).
+
+Same public surface as the reference, so `hicom/model/hicom_arch.py:44,97,212` can use it unchanged:
+
+    build_vision_projector(config, delay_load=False, **kw) -> nn.Module         (ref :231-304)
+    HIComProjector.forward(frames_feature, frames_embed, guide_embed, modal,
+                           image_newline=None) -> Tensor[n_tok, hidden]          (ref :676-708)
+    LocalCompressor / GlobalCompressor / GuideInjector / MultiheadAttention      (ref :133-646)
+
+and the same sub-module / parameter names, i.e. the same state-dict schema, so `mm_projector.bin`
+and full checkpoints load with `load_state_dict` exactly as before (ref hicom_arch.py:107-128).
+
+What differs is everything below the signatures: the modules are parameter containers, and the
+forward pass is a short sequence of hand-written HIP kernels for gfx950, called
+through the C ABI in include/hicom_hip.h.  There is no PyTorch compute fallback: without
+libhicom_hip.so, or on CPU tensors, forward raises.
+"""
+from __future__ import annotations
+
+import math
+import re
+from functools import partial
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.init import trunc_normal_
+
+from . import geometry as geo
+from . import native as nv
+
+_NATIVE_GUIDE_MODES = (None, "off", "direct")
+
+
+def _init_like_reference(m: nn.Module):
+    """Linear: trunc_normal(std=.02), zero bias; LayerNorm: (1, 0)  (ref :155-164, 462-471, 623-632)."""
+    if isinstance(m, nn.Linear):
+        trunc_normal_(m.weight, std=.02)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+    elif isinstance(m, nn.LayerNorm):
+        nn.init.constant_(m.bias, 0)
+        nn.init.constant_(m.weight, 1.0)
+
+
+def build_mlp(depth: int, hidden_size: int, output_hidden_size: int) -> nn.Sequential:
+    """Linear -> (GELU -> Linear)*  with the reference's Sequential indices 0, 2, ... (ref :307-312)."""
+    layers = [nn.Linear(hidden_size, output_hidden_size)]
+    for _ in range(1, depth):
+        layers += [nn.GELU(), nn.Linear(output_hidden_size, output_hidden_size)]
+    return nn.Sequential(*layers)
+
+
+class IdentityMap(nn.Module):
+    def forward(self, x, *args, **kwargs):
+        return x
+
+
+class MultiheadAttention(nn.Module):
+    """Parameter container for q/k/v/out projections (ref :133-153).  The attention itself runs in
+    hicom_global_stream_fwd with k_proj / v_proj folded around the raw tokens."""
+
+    def __init__(self, embed_dim: int, num_heads: int, dropout: float = 0.):
+        super().__init__()
+        if embed_dim % num_heads:
+            raise ValueError(f"embed_dim must be divisible by num_heads (got `embed_dim`: {embed_dim} and "
+                             f"`num_heads`: {num_heads}).")
+        self.embed_dim, self.num_heads, self.head_dim = embed_dim, num_heads, embed_dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.dropout = dropout
+        self.k_proj = nn.Linear(embed_dim, embed_dim)
+        self.v_proj = nn.Linear(embed_dim, embed_dim)
+        self.q_proj = nn.Linear(embed_dim, embed_dim)
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        self.apply(_init_like_reference)
+
+
+class GuideInjector(nn.Module):
+    """Parameters of the instruction injector (ref :315-342).  'direct' has none."""
+
+    def __init__(self, use_guide, text_dim, qk_dim, adapt_guide=False,
+                 norm_layer=partial(nn.LayerNorm, eps=1e-6), mlp_depth=2):
+        super().__init__()
+        self.use_guide = use_guide
+        self.text2qk_proj = build_mlp(mlp_depth, text_dim, qk_dim) if text_dim != qk_dim else nn.Identity()
+        if adapt_guide:
+            self.guide_proj = build_mlp(mlp_depth, qk_dim, qk_dim)
+            self.guide_norm = norm_layer(qk_dim)
+            self.guide_alpha = nn.Parameter(torch.zeros(1))
+        else:
+            self.guide_proj, self.guide_norm, self.guide_alpha = nn.Identity(), nn.Identity(), 0
+        if use_guide == "coarse":
+            self.coarse_proj = build_mlp(mlp_depth, qk_dim, qk_dim * 2)
+            self.coarse_norm = norm_layer(qk_dim)
+        elif use_guide == "fine":
+            self.fine_proj = MultiheadAttention(qk_dim, num_heads=qk_dim // 128)
+            self.fine_norm = norm_layer(qk_dim)
+        elif use_guide != "direct":
+            raise NotImplementedError(f"use_guide={use_guide!r}")
+
+
+def _f32(shape, device):
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def _require_bf16_cuda(name: str, t: torch.Tensor):
+    if not t.is_cuda:
+        raise nv.HicomNativeError(f"{name}: hicom_amd runs on the GPU only (got a CPU tensor)")
+    if t.dtype != torch.bfloat16:
+        raise NotImplementedError(f"{name}: dtype {t.dtype}; the HIP path takes bfloat16 tokens and weights "
+                                  "(cast the projector and its inputs to torch.bfloat16)")
+
+
+def _linear_params(lin: nn.Linear):
+    _require_bf16_cuda("weight", lin.weight)
+    return lin.weight.detach(), (lin.bias.detach() if lin.bias is not None else None)
+
+
+class LocalCompressor(nn.Module):
+    """Windowed (t x s x s) single-head cross-attention + 2-layer readout (ref :399-559)."""
+
+    def __init__(self, config, temporal_kernel_size=4, spatial_kernel_size=2,
+                 adapt_q=False, adapt_k=False, adapt_v=False, adapt_guide=False,
+                 norm_layer=partial(nn.LayerNorm, eps=1e-6), mlp_depth=2, force_use_guide=False):
+        super().__init__()
+        qk_dim, _ = geo.tower_dims(config.mm_vision_tower)
+        enc, out = config.mm_hidden_size, config.hidden_size
+        self.qk_dim = qk_dim
+        self.spatial_kernel_size, self.temporal_kernel_size = spatial_kernel_size, temporal_kernel_size
+        self.use_guide = getattr(config, "use_guide", None) if force_use_guide is False else force_use_guide
+        if self.use_guide in (None, "off"):
+            self.guide_injector = IdentityMap()
+        else:
+            self.guide_injector = GuideInjector(self.use_guide, qk_dim, qk_dim, adapt_guide, norm_layer, mlp_depth)
+        if self.use_guide == "direct":
+            adapt_q = False                     # ref :428-429
+        self.adapt_q, self.adapt_k, self.adapt_v, self.adapt_guide = adapt_q, adapt_k, adapt_v, adapt_guide
+        if adapt_q:
+            self.q_proj = nn.Linear(qk_dim, qk_dim, bias=False)
+            self.q_norm = norm_layer(qk_dim)
+            self.q_alpha = nn.Parameter(torch.zeros(1))
+        else:
+            self.q_proj, self.q_norm, self.q_alpha = nn.Identity(), nn.Identity(), 0
+        if adapt_k:
+            self.k_proj = build_mlp(mlp_depth, qk_dim, qk_dim)
+            self.k_norm = norm_layer(qk_dim)
+            self.k_alpha = nn.Parameter(torch.zeros(1))
+        else:
+            self.k_proj, self.k_norm, self.k_alpha = nn.Identity(), nn.Identity(), 0
+        if adapt_v:
+            self.v_proj = build_mlp(mlp_depth, enc, enc)
+            self.v_norm = norm_layer(enc)
+            self.v_alpha = nn.Parameter(torch.zeros(1))
+        else:
+            self.v_proj, self.v_norm, self.v_alpha = nn.Identity(), nn.Identity(), 0
+        self.readout = build_mlp(mlp_depth, enc, out)
+        self.apply(_init_like_reference)
+
+    # -- geometry -------------------------------------------------------------------------
+    def tilings(self, T: int, H: int, W: int, modal: str):
+        kt = 1 if (modal == "image" or T == 1) else self.temporal_kernel_size      # ref :536
+        ks = self.spatial_kernel_size
+        return geo.axis_tiling(T, kt), geo.axis_tiling(H, ks), geo.axis_tiling(W, ks)
+
+    def _check_native(self):
+        if self.use_guide not in _NATIVE_GUIDE_MODES:
+            raise NotImplementedError(f"LocalCompressor: use_guide={self.use_guide!r} has no HIP path yet "
+                                      "(native modes: direct, off)")
+        if self.adapt_q or self.adapt_k or self.adapt_v or self.adapt_guide:
+            raise NotImplementedError("LocalCompressor: adapt{q,k,v,g} variants have no HIP path yet")
+
+    # -- attention context: [Nw, D] fp32 -----------------------------------------------------
+    def window_context(self, frames_feature, frames_embed, guide_embed, modal, logit_scale, logit_bias):
+        self._check_native()
+        _require_bf16_cuda("frames_feature", frames_feature)
+        ff = frames_feature.contiguous()
+        T, H, W, D = ff.shape
+        key = ff if frames_embed is None else frames_embed.contiguous()
+        if key is not ff:
+            _require_bf16_cuda("frames_embed", key)
+            if key.shape != ff.shape:
+                raise ValueError("frames_embed must have the shape of frames_feature")
+        at, ay, ax = self.tilings(T, H, W, modal)
+        axes = tuple(nv.Axis(a.n, a.k, a.nwin, a.nfull) for a in (at, ay, ax))
+        grid = (at.nwin, ay.nwin, ax.nwin)
+        nw = grid[0] * grid[1] * grid[2]
+        l2norm = 0
+        if logit_scale is not None:                                   # ref :527-529, :549
+            scale, bias = float(torch.exp(logit_scale.float())), float(logit_bias)
+            if frames_embed is not None:
+                l2norm = 1 | (2 if self.use_guide == "direct" else 0)
+        else:
+            scale, bias = 1.0 / math.sqrt(self.qk_dim), 0.0            # ref :551
+        ctx = _f32((nw, D), ff.device)
+        if self.use_guide == "direct":                                 # query := guide for every window
+            g = guide_embed.contiguous()
+            _require_bf16_cuda("guide_embed", g)
+            if g.ndim != 1 or g.shape[0] != D:
+                raise ValueError("direct guide injection takes a [D] guide embedding")
+            nv.local_attn(key, ff, axes, g, 0, scale, bias, l2norm, ctx)
+        else:                                                          # pooled per-window query (ref :539-540)
+            q = _f32((*grid, D), ff.device)
+            nv.trilinear_pool(ff, q)
+            nv.local_attn(key, ff, axes, q, D, scale, bias, l2norm, ctx)
+        return ctx, grid
+
+    def readout_into(self, ctx, out, row0: int, nl_group: int):
+        """out[row0 + packed(m), :] = readout(ctx[m, :]) -- both Linear layers on matrix cores."""
+        w0, b0 = _linear_params(self.readout[0])
+        w2, b2 = _linear_params(self.readout[2])
+        hid = _f32((ctx.shape[0], w0.shape[0]), ctx.device)
+        nv.readout_gemm(ctx, w0, b0, hid, act=nv.ACT_GELU)
+        nv.readout_gemm(hid, w2, b2, out, row0=row0, nl_group=nl_group)
+
+    def forward(self, frames_feature, frames_embed, guide_embed, modal, logit_scale=None, logit_bias=None):
+        ctx, grid = self.window_context(frames_feature, frames_embed, guide_embed, modal, logit_scale, logit_bias)
+        out = torch.empty((ctx.shape[0], self.readout[2].out_features), dtype=_out_dtype(self), device=ctx.device)
+        self.readout_into(ctx, out, 0, 0)
+        return out.view(*grid, -1)
+
+
+def _out_dtype(module: nn.Module) -> torch.dtype:
+    return torch.float32 if getattr(module, "return_fp32", False) else torch.bfloat16
+
+
+class GlobalCompressor(nn.Module):
+    """num_queries x 9-head cross-attention over all T*h*w tokens + readout (ref :562-646)."""
+
+    def __init__(self, config, num_queries, use_pos_emb=True, adapt_guide=False,
+                 norm_layer=partial(nn.LayerNorm, eps=1e-6), mlp_depth=2, force_use_guide=False):
+        super().__init__()
+        text_dim, hw = geo.tower_dims(config.mm_vision_tower)
+        self.embed_dim = embed_dim = config.mm_hidden_size
+        self.num_queries = num_queries
+        self.use_pos_emb = use_pos_emb
+        self.max_size = [getattr(config, "max_num_frames", 256), hw, hw]
+        self.query = nn.Parameter(torch.zeros(num_queries, embed_dim))
+        self.use_guide = getattr(config, "use_guide", None) if force_use_guide is False else force_use_guide
+        self.adapt_guide = adapt_guide
+        if self.use_guide in (None, "off"):
+            self.guide_injector = IdentityMap()
+        else:
+            self.guide_injector = GuideInjector(self.use_guide, text_dim, embed_dim, adapt_guide, norm_layer, mlp_depth)
+        self.attn_layer = MultiheadAttention(embed_dim, embed_dim // 128)
+        self.readout = build_mlp(mlp_depth, embed_dim, config.hidden_size)
+        self.apply(_init_like_reference)
+        self._pe_cache: Dict[Tuple, torch.Tensor] = {}
+
+    # per-axis sinusoid tables [t_cap + H + W, E] fp32 on the device (ref :57-101, :603-621: the
+    # reference caches the full [T,27,27,E] sum; we keep the three separable factors)
+    def pos_tables(self, t_cap: int, H: int, W: int, device) -> Tuple[torch.Tensor, int]:
+        t_cap = max(t_cap, 1)
+        key = (H, W, str(device))
+        hit = self._pe_cache.get(key)
+        if hit is None or hit[1] < t_cap:
+            cap = max(t_cap, min(self.max_size[0], 4096))
+            tab = torch.from_numpy(geo.stacked_pos_tables(cap, H, W, self.embed_dim)).to(device)
+            hit = (tab, cap)
+            self._pe_cache[key] = hit
+        return hit
+
+    def _check_native(self, logit_scale):
+        if self.use_guide not in _NATIVE_GUIDE_MODES:
+            raise NotImplementedError(f"GlobalCompressor: use_guide={self.use_guide!r} has no HIP path yet "
+                                      "(native modes: direct, off)")
+        if self.adapt_guide:
+            raise NotImplementedError("GlobalCompressor: adaptg has no HIP path yet")
+        if logit_scale is not None:
+            raise NotImplementedError("GlobalCompressor: the clip-scale variant normalises the PROJECTED keys "
+                                      "(ref :184-186), which does not fold into the queries; no HIP path yet")
+
+    def injected_queries(self, guide_embed) -> Tuple[torch.Tensor, int]:
+        """bf16 [nq_eff, E] distinct query rows and how many output rows they stand for.
+        direct: the 32 queries are 32 copies of the guide (ref :352-368, :642) -> one row."""
+        if self.use_guide == "direct":
+            g = guide_embed.contiguous()
+            _require_bf16_cuda("guide_embed", g)
+            if g.ndim != 1 or g.shape[0] != self.embed_dim:
+                raise ValueError("direct guide injection takes a [D] guide embedding")
+            return g.view(1, -1), self.num_queries
+        _require_bf16_cuda("global_compressor.query", self.query)
+        return self.query.detach(), self.num_queries
+
+    def partial_context(self, frames_feature, q_in, t_offset: int = 0):
+        """Streams this call's frames once: returns (ml [R,2], acc [R,E]) un-normalised online-softmax
+        state for R = nq_eff * num_heads folded query rows (ref :180-215 restated)."""
+        att = self.attn_layer
+        E, nh = self.embed_dim, att.num_heads
+        ff = frames_feature.contiguous()
+        _require_bf16_cuda("frames_feature", ff)
+        T, H, W, _ = ff.shape
+        N = T * H * W
+        dev = ff.device
+        nq = q_in.shape[0]
+        R = nq * nh
+        rows_pad = (R + 15) // 16 * 16
+        wq, bq = _linear_params(att.q_proj)
+        wk, _ = _linear_params(att.k_proj)      # b_k only shifts every logit of a row: softmax cancels it
+        qp = _f32((nq, E), dev)
+        nv.linear(q_in, wq, bq, qp)
+        qt = _f32((R, E), dev)
+        nv.fold_query(qp, wk, nh, att.scale, qt)
+        qhi = torch.empty((rows_pad, E), dtype=torch.bfloat16, device=dev)
+        qlo = torch.empty_like(qhi)
+        nv.split_bf16(qt, rows_pad, qhi, qlo)
+        pos_a = pe = None
+        t0i = y0i = x0i = 0
+        if self.use_pos_emb:
+            pe, cap = self.pos_tables(t_offset + T, H, W, dev)
+            t0i, y0i, x0i = t_offset, cap, cap + H
+            pos_a = torch.zeros((rows_pad, pe.shape[0]), dtype=torch.float32, device=dev)
+            nv.linear(qt, pe, None, pos_a, M=R)                     # a[r, p] = qt[r] . PE[p]
+        nparts = nv.global_stream_nparts(N, rows_pad)
+        stride = (N + 15) // 16 * 16
+        scores = _f32((rows_pad, stride), dev)
+        part_m, part_l = _f32((nparts, rows_pad), dev), _f32((nparts, rows_pad), dev)
+        part_acc = _f32((nparts, rows_pad, E), dev)
+        nv.global_stream(ff, N, qhi, qlo, pos_a, H, W, t0i, y0i, x0i, scores, part_m, part_l, part_acc)
+        ml, acc = _f32((R, 2), dev), _f32((R, E), dev)
+        scratch = _f32((R * T * (H + W + 1),), dev) if pe is not None else None
+        nv.global_merge(part_m, part_l, part_acc, R, scores, N, H, W, pe, t0i, y0i, x0i, scratch, ml, acc)
+        return ml, acc, scores
+
+    def finish(self, ml_sets, acc_sets, q_in, out, row0: int, n_rows: int):
+        """Combine shard states, apply v_proj per head, out_proj + residual, readout, and write
+        n_rows output rows (broadcast when the queries are identical) at out[row0:]."""
+        att = self.attn_layer
+        E, nh = self.embed_dim, att.num_heads
+        dev = out.device
+        nq = q_in.shape[0]
+        R = nq * nh
+        ctx = _f32((R, E), dev)
+        nv.global_combine(ml_sets, acc_sets, ctx)
+        wv, bv = _linear_params(att.v_proj)
+        wo, bo = _linear_params(att.out_proj)
+        o = _f32((nq, E), dev)
+        nv.linear(ctx, wv, bv, o, head_rows=nh, head_dim=att.head_dim)   # sum(p) = 1 carries b_v through
+        qres = _f32((nq, E), dev)
+        nv.scatter_rows(q_in, qres, 0, nq)                                # bf16 -> f32 residual (ref :646)
+        pre = _f32((nq, E), dev)
+        nv.linear(o, wo, bo, pre, res=qres)
+        w0, b0 = _linear_params(self.readout[0])
+        w2, b2 = _linear_params(self.readout[2])
+        hid = _f32((nq, w0.shape[0]), dev)
+        nv.linear(pre, w0, b0, hid, act=nv.ACT_GELU)
+        tok = _f32((nq, w2.shape[0]), dev)
+        nv.linear(hid, w2, b2, tok)
+        nv.scatter_rows(tok, out, row0, n_rows)
+
+    def forward_into(self, frames_feature, guide_embed, logit_scale, out, row0: int):
+        self._check_native(logit_scale)
+        q_in, n_rows = self.injected_queries(guide_embed)
+        ml, acc, _ = self.partial_context(frames_feature, q_in)
+        self.finish(ml.unsqueeze(0), acc.unsqueeze(0), q_in, out, row0, n_rows)
+
+    def forward(self, frames_feature, frames_embed, guide_embed, modal, logit_scale=None, logit_bias=None):
+        out = torch.empty((self.num_queries, self.readout[2].out_features), dtype=_out_dtype(self),
+                          device=frames_feature.device)
+        self.forward_into(frames_feature, guide_embed, logit_scale, out, 0)
+        return out
+
+
+class HIComProjector(nn.Module):
+    """[local tokens (+ newline rows) ; global tokens] for one video / image (ref :649-708)."""
+
+    def __init__(self, config, local_compressor=None, global_compressor=None):
+        super().__init__()
+        self.config = config
+        use_clip_scale = getattr(config, "use_clip_scale", "").split(",")
+        self.local_use_clip_scale = "local" in use_clip_scale
+        self.global_use_clip_scale = "global" in use_clip_scale
+        self.local_logit_scale = self.local_logit_bias = None
+        self.global_logit_scale = self.global_logit_bias = None
+        if self.local_use_clip_scale or self.global_use_clip_scale:
+            # the reference copies SigLIP's logit_scale / logit_bias out of the checkpoint here
+            # (ref :660-670); this build takes them from set_clip_logits() instead of the hub.
+            raise NotImplementedError("use_clip_scale: call set_clip_logits() on a projector built without it")
+        self.local_compressor = local_compressor
+        self.global_compressor = global_compressor
+        assert local_compressor is not None or global_compressor is not None, \
+            "At least one compressor should be provided."
+        self.return_fp32 = False     # True: fp32 result (parity tests); default = weight dtype (bf16)
+
+    def set_clip_logits(self, local=None, glob=None):
+        if local is not None:
+            self.local_logit_scale, self.local_logit_bias = local
+        if glob is not None:
+            self.global_logit_scale, self.global_logit_bias = glob
+
+    def _layout(self, grid, modal, has_newline, is_anyres):
+        return geo.pack_layout(getattr(self.config, "mm_patch_merge_type", "flat"),
+                               getattr(self.config, "mm_newline_position", "one_token"),
+                               modal, grid[0], grid[1], grid[2], has_newline, is_anyres)
+
+    def forward(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None):
+        lc, gc = self.local_compressor, self.global_compressor
+        segments = []        # (ctx, layout) per local segment, in output order
+        if lc is not None:
+            if isinstance(frames_feature, dict):                                 # anyres image (ref :679-689)
+                if frames_feature["base"] is not None:
+                    fe = frames_embed["base"].unsqueeze(0) if frames_embed is not None else None
+                    ctx, grid = lc.window_context(frames_feature["base"].unsqueeze(0), fe, guide_embed, modal,
+                                                  self.local_logit_scale, self.local_logit_bias)
+                    segments.append((ctx, self._layout(grid, modal, image_newline is not None, False)))
+                fe = frames_embed["patch"].unsqueeze(0) if frames_embed is not None else None
+                ctx, grid = lc.window_context(frames_feature["patch"].unsqueeze(0), fe, guide_embed, modal,
+                                              self.local_logit_scale, self.local_logit_bias)
+                segments.append((ctx, self._layout(grid, modal, image_newline is not None, True)))
+            else:
+                ctx, grid = lc.window_context(frames_feature, frames_embed, guide_embed, modal,
+                                              self.local_logit_scale, self.local_logit_bias)
+                segments.append((ctx, self._layout(grid, modal, image_newline is not None, False)))
+        n_local = sum(lay.n_rows for _, lay in segments)
+        n_global = gc.num_queries if gc is not None else 0
+        some = segments[0][0] if segments else (frames_feature["patch"] if isinstance(frames_feature, dict)
+                                                else frames_feature)
+        hidden = (lc or gc).readout[2].out_features
+        out = torch.empty((n_local + n_global, hidden), dtype=_out_dtype(self), device=some.device)
+        row = 0
+        for ctx, lay in segments:
+            lc.readout_into(ctx, out, row, lay.nl_group)
+            if lay.newline_rows:
+                nl = image_newline.contiguous()
+                first = lay.newline_rows[0]
+                step = lay.newline_rows[1] - first if len(lay.newline_rows) > 1 else 1
+                nv.scatter_rows(nl.view(1, -1), out, row + first, len(lay.newline_rows), row_step=step)
+            row += lay.n_rows
+        if gc is not None:
+            gff = frames_feature["patch"].unsqueeze(0) if isinstance(frames_feature, dict) else frames_feature
+            gc.forward_into(gff, guide_embed, self.global_logit_scale, out, row)
+        return out
+
+
+def build_vision_projector(config, delay_load=False, **kwargs):
+    """Factory with the reference's type-string grammar (ref :231-304).  'mlpNx_gelu' / 'linear'
+    are plain PyTorch modules in the reference too and are returned as such."""
+    projector_type = getattr(config, "mm_projector_type", "linear")
+    m = re.match(r"^mlp(\d+)x_gelu$", projector_type)
+    if m:
+        return build_mlp(int(m.group(1)), config.mm_hidden_size, config.hidden_size)
+    if projector_type == "linear":
+        return nn.Linear(config.mm_hidden_size, config.hidden_size)
+    lspec, gspec = geo.parse_mm_projector_type(projector_type)
+    local = glob = None
+    if lspec is not None:
+        local = LocalCompressor(config, lspec.temporal_kernel_size, lspec.spatial_kernel_size,
+                                lspec.adapt_q, lspec.adapt_k, lspec.adapt_v, lspec.adapt_guide,
+                                force_use_guide=lspec.force_use_guide)
+    if gspec is not None:
+        glob = GlobalCompressor(config, gspec.num_queries, True, gspec.adapt_guide,
+                                force_use_guide=gspec.force_use_guide)
+    return HIComProjector(config, local, glob)

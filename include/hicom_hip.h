@@ -1,0 +1,167 @@
+/*
+ * hicom_hip.h -- C ABI of libhicom_hip.so: MI355X (gfx950 / CDNA4) kernels for the HICom
+ * hybrid-level video-token compressor.
+ *
+ * The reference (lntzm/HICom) is pure Python and has no FFI; each entry point below replaces
+ * a chain of stock PyTorch ops on the path
+ *     hicom/model/projector.py:676-708   HIComProjector.forward
+ * and is cited to the reference lines it stands in for.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into memory owned by the caller (torch on the Python
+ *     side); the library allocates nothing and keeps no state between calls;
+ *   - dense row-major layouts, no strides; "bf16" = uint16_t bit patterns; f32 = float;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is
+ *     enqueued asynchronously on it and nothing synchronises the host (graph-capturable);
+ *   - return 0 on success, a negative HICOM_E* code otherwise; never throws.
+ *     hicom_last_error() returns a thread-local description of the last failure.
+ */
+#ifndef HICOM_HIP_H
+#define HICOM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HICOM_ABI_VERSION 1
+
+#define HICOM_OK         0
+#define HICOM_EINVAL    -1   /* bad argument (shape, alignment, NULL)        */
+#define HICOM_EUNSUP    -2   /* configuration not supported by the kernels   */
+#define HICOM_ELAUNCH   -3   /* HIP launch / runtime error                   */
+
+#define HICOM_DT_BF16 0
+#define HICOM_DT_F32  1
+
+/* activation / epilogue flags for the linear + GEMM entry points */
+#define HICOM_ACT_NONE 0
+#define HICOM_ACT_GELU 1     /* exact erf GELU (nn.GELU() default, projector.py:310) */
+
+int hicom_abi_version(void);
+const char* hicom_last_error(void);
+
+/* One axis of the window tiling of LocalCompressor.divide_feature /
+ * balance_divide_feature (projector.py:473-522): `nwin` windows of length `k` over `n`
+ * elements; the first `nfull` start at i*k, the rest at nfull*k + (i-nfull)*(k-1) - 1
+ * (one-element overlap).  Divisible axes have nfull == nwin. */
+typedef struct hicom_axis {
+    int32_t n, k, nwin, nfull;
+} hicom_axis;
+
+/* ---- local compressor: windowed single-head cross-attention ------------------------------
+ * Replaces projector.py:544-558 (divide_feature x3, bmm, softmax, bmm, un-window) and, with
+ * l2norm != 0, the clip-scale normalisation at :527-529,549.
+ *   key, value : bf16 [T,H,W,D]   (frames_embed / frames_feature; key may alias value)
+ *   query      : [D] shared by every window (query_stride == 0, GuideInjector "direct",
+ *                projector.py:352-368) or [Nw, D] with row stride query_stride elements;
+ *                dtype query_dt
+ *   logits     : (q.k) * scale + bias        (scale = 1/sqrt(D) or exp(logit_scale))
+ *   ctx        : f32 [Nw, D], window order (t1,h1,w1) row-major, Nw = at.nwin*ay.nwin*ax.nwin
+ *   l2norm     : bit 0 = L2-normalise every key row, bit 1 = L2-normalise the query
+ *                (clip-scale variant, projector.py:527-529)
+ * D must be 1152 or 768 (projector.py:407-414). */
+int hicom_local_attn_fwd(const void* key, const void* value, int32_t D,
+                         hicom_axis at, hicom_axis ay, hicom_axis ax,
+                         const void* query, int32_t query_dt, int64_t query_stride,
+                         float scale, float bias, int32_t l2norm,
+                         float* ctx, void* stream);
+
+/* ---- pooled per-window query: F.interpolate(..., 'trilinear', align_corners=False) --------
+ * Replaces projector.py:539-540.  x bf16 [T,H,W,D] -> out f32 [t',h',w',D]. */
+int hicom_trilinear_pool_fwd(const void* x, int32_t T, int32_t H, int32_t W, int32_t D,
+                             int32_t To, int32_t Ho, int32_t Wo, float* out, void* stream);
+
+/* ---- small-M linear: y[M,N] = act(x[M,K] . w[N,K]^T + b) + res ---------------------------
+ * nn.Linear on a handful of rows (q_proj / out_proj / readout of the global tokens,
+ * projector.py:180,226,646; also the score-side positional table q~.PE^T).
+ *   head_dim > 0 selects "per-head rows": column n reads x row m*head_rows + n/head_dim
+ *   (v_proj applied to the per-head context, projector.py:182,215 after folding).
+ *   b, res may be NULL.  res is f32 [M,N] (res_stride0 == 0 broadcasts row 0). */
+int hicom_linear_fwd(const void* x, int32_t x_dt, const void* w, int32_t w_dt,
+                     const void* b, int32_t b_dt, const float* res, int32_t res_bcast,
+                     int32_t M, int32_t N, int32_t K, int32_t head_rows, int32_t head_dim,
+                     int32_t act, float* y, void* stream);
+
+/* ---- fold k_proj into the queries ---------------------------------------------------------
+ * qt[(q*nh + h), c] = scale * sum_j w_k[h*hd + j, c] * qp[q, h*hd + j]
+ * so that score_h(n) = qt_h . x_n (+ a key-independent constant that softmax cancels):
+ * replaces k_proj over all T*729 tokens (projector.py:181,193-197).  qp f32 [nq,E],
+ * w_k bf16 [E,E] (nn.Linear layout [out,in]), qt f32 [nq*nh, E]. */
+int hicom_fold_query_fwd(const float* qp, const void* w_k, int32_t nq, int32_t nh, int32_t E,
+                         float scale, float* qt, void* stream);
+
+/* Split f32 rows into bf16 hi + lo parts (x ~= hi + lo to 2^-16), zero-padding the row count
+ * to rows_pad: the MFMA operand format for fp32 intermediates (SURVEY.md §7 strategy B). */
+int hicom_split_bf16_fwd(const float* x, int32_t rows, int32_t rows_pad, int32_t E,
+                         void* hi, void* lo, void* stream);
+
+/* ---- global compressor: streaming multi-query attention over all tokens -------------------
+ * One pass over x = frames_feature[n0 : n0+N) (bf16 [N,E], E = 1152 | 768) computing, for a
+ * block of `rows_pad` folded queries (multiple of 16), the raw scores and the online-softmax
+ * partial sums of attn . x.  Replaces projector.py:193-215 for K = V = x (pos-emb handled
+ * separably: `pos_a` holds qt . PE for the t / y / x axes).
+ *   qt_hi, qt_lo : bf16 [rows_pad, E]
+ *   pos_a        : f32 [rows_pad, pos_stride] or NULL; token (t,y,x) adds
+ *                  pos_a[r, t_index0 + t] + pos_a[r, y_index0 + y] + pos_a[r, x_index0 + x]
+ *   geometry     : token n -> t = n / (H*W), y = (n / W) % H, x = n % W  (n relative to n0 = 0
+ *                  of THIS call's x pointer; t_index0 carries the shard's frame offset)
+ *   scores       : f32 [rows_pad, score_stride]  (score_stride >= roundup(N,16))
+ *   part_m/l     : f32 [nparts, rows_pad]; part_acc : f32 [nparts, rows_pad, E]
+ *   nparts       : number of token chunks (= workgroups per row group); returned layout is
+ *                  consumed by hicom_global_merge_fwd.
+ */
+int hicom_global_stream_fwd(const void* x, int64_t N, int32_t E,
+                            const void* qt_hi, const void* qt_lo, int32_t rows_pad,
+                            const float* pos_a, int32_t pos_stride,
+                            int32_t H, int32_t W, int32_t t_index0, int32_t y_index0, int32_t x_index0,
+                            float* scores, int64_t score_stride,
+                            float* part_m, float* part_l, float* part_acc, int32_t nparts,
+                            void* stream);
+
+/* Suggested nparts for N tokens (fills the chip: 2 workgroups per CU). */
+int hicom_global_stream_nparts(int64_t N, int32_t rows_pad);
+
+/* ---- merge the partials (+ the value-side positional term) --------------------------------
+ * out_acc[r,:] = sum_p e^(m_p - M_r) acc_p[r,:] + sum_n e^(s_n - M_r) pos(n)   (un-normalised)
+ * out_ml[r]   = (M_r, L_r).  pos(n) = pe[t_index0+t] + pe[y_index0+y] + pe[x_index0+x] with
+ * pe f32 [*, E] the per-axis sinusoid tables (projector.py:57-101), or NULL for no pos-emb.
+ * scratch: f32 [rows * (T*(H+W+1))] work area.  T = N / (H*W). */
+int hicom_global_merge_fwd(const float* part_m, const float* part_l, const float* part_acc,
+                           int32_t nparts, int32_t rows, int32_t rows_pad, int32_t E,
+                           const float* scores, int64_t score_stride, int64_t N,
+                           int32_t H, int32_t W, const float* pe,
+                           int32_t t_index0, int32_t y_index0, int32_t x_index0,
+                           float* scratch, float* out_ml, float* out_acc, void* stream);
+
+/* Combine `nsets` (M,L,ACC) triples (one per GPU after the all-gather, or one) and normalise:
+ * ctx[r,:] = sum_k e^(M_k - M) ACC_k[r,:] / sum_k e^(M_k - M) L_k.
+ * ml f32 [nsets, rows, 2]; acc f32 [nsets, rows, E]; ctx f32 [rows, E]. */
+int hicom_global_combine_fwd(const float* ml, const float* acc, int32_t nsets, int32_t rows,
+                             int32_t E, float* ctx, void* stream);
+
+/* ---- readout MLP GEMM on matrix cores -------------------------------------------------------
+ * y[out_row(m), :] = act(x[m,:] . w^T + b),  x f32 [M,K] (split hi/lo on the fly), w bf16 [N,K],
+ * b bf16|f32 [N].  out_row(m) = row0 + m + (nl_group ? m / nl_group : 0) implements the
+ * newline-interleaved packing of post_process_visual_feature (mm_utils.py:100-135).
+ * Replaces build_mlp's Linear/GELU/Linear (projector.py:307-312,559,646).
+ * K % 32 == 0; y dtype y_dt, row length ldy elements. */
+int hicom_readout_gemm_fwd(const float* x, const void* w, const void* b, int32_t b_dt,
+                           int32_t M, int32_t N, int32_t K, int32_t act,
+                           void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group,
+                           void* stream);
+
+/* Row copy / broadcast with dtype conversion into the packed output:
+ *   dst[row0 + i*row_step + (nl_group ? i / nl_group : 0), :] = src[(i % src_rows), :],  i in [0,count)
+ * (newline tokens, the 32 identical global rows of "direct" mode, and the standalone
+ * post_process_visual_feature packing of mm_utils.py:92-140). */
+int hicom_scatter_rows_fwd(const void* src, int32_t src_dt, int32_t src_rows, int32_t ncols,
+                           void* dst, int32_t dst_dt, int64_t ldd, int64_t row0, int64_t row_step,
+                           int32_t nl_group, int32_t count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HICOM_HIP_H */

@@ -209,16 +209,18 @@ def guide_inject(mode, visual: Tensor, guide: Optional[Tensor], sd, prefix: str,
 # --------------------------------------------------------------------------
 # window geometry                                 (projector.py:473-522)
 # --------------------------------------------------------------------------
-def window_starts(n: int, k: int) -> List[int]:
-    """Start index of each length-k group along an axis of n elements.
+def window_starts(n: int, k: int) -> Tuple[List[int], int]:
+    """(start index of each group, group length) along an axis of n elements.
 
     n % k == 0: plain tiling (:476-477).  Otherwise `balance_divide_feature` (:501-522):
     ceil(n/k) groups, the first n % split (or all) are full, each remaining group starts
-    one element early (overlap).  When that produces groups of unequal length the reference's
-    torch.stack raises RuntimeError (e.g. n=5,6,9 with k=4) -- reproduced here.
+    one element early (overlap).  n < k gives ONE group holding all n elements (the slice
+    x[0:k] is simply short, and a one-element torch.stack cannot fail).  When the groups come out
+    with unequal lengths the reference's torch.stack raises RuntimeError (e.g.
+    n=5,6,9 with k=4) -- reproduced here.
     """
     if n % k == 0:
-        return [i * k for i in range(n // k)]
+        return [i * k for i in range(n // k)], k
     split = math.ceil(n / k)
     no_rep = n % split
     if no_rep == 0:
@@ -230,22 +232,22 @@ def window_starts(n: int, k: int) -> List[int]:
         if lens[i] < k:
             s -= 1
         starts.append(s)
-        sizes.append(min(e, n) - max(s, 0) if s >= 0 else -1)
+        sizes.append(len(range(n)[s:e]))          # python slice semantics, like x[s:e]
         s = e
-    if any(sz != sizes[0] for sz in sizes) or sizes[0] != k or starts[0] < 0 or starts[-1] + k > n:
+    if any(sz != sizes[0] for sz in sizes):
         raise RuntimeError("stack expects each tensor to be equal size")
-    return starts
+    return starts, sizes[0]
 
 
 def window_token_index(T: int, H: int, W: int, kt: int, ks: int) -> Tensor:
-    """Flat token ids [Nw, kt*ks*ks]; window order (t1,h1,w1), in-window order (t2,h2,w2)
+    """Flat token ids [Nw, win]; window order (t1,h1,w1), in-window order (t2,h2,w2)
     row-major (divide_feature's final rearrange, :493)."""
-    ts, hs, ws = window_starts(T, kt), window_starts(H, ks), window_starts(W, ks)
+    (ts, kt), (hs, kh), (ws, kw) = window_starts(T, kt), window_starts(H, ks), window_starts(W, ks)
     t = torch.tensor(ts).view(-1, 1, 1, 1, 1, 1) + torch.arange(kt).view(1, 1, 1, -1, 1, 1)
-    y = torch.tensor(hs).view(1, -1, 1, 1, 1, 1) + torch.arange(ks).view(1, 1, 1, 1, -1, 1)
-    x = torch.tensor(ws).view(1, 1, -1, 1, 1, 1) + torch.arange(ks).view(1, 1, 1, 1, 1, -1)
+    y = torch.tensor(hs).view(1, -1, 1, 1, 1, 1) + torch.arange(kh).view(1, 1, 1, 1, -1, 1)
+    x = torch.tensor(ws).view(1, 1, -1, 1, 1, 1) + torch.arange(kw).view(1, 1, 1, 1, 1, -1)
     idx = (t * H + y) * W + x
-    return idx.reshape(len(ts) * len(hs) * len(ws), kt * ks * ks)
+    return idx.reshape(len(ts) * len(hs) * len(ws), kt * kh * kw)
 
 
 def _lerp_taps(n_in: int, n_out: int):

@@ -19,6 +19,8 @@ CASES = {
     # non-divisible T: overlapping windows (T=7) / reference raises (T=5)
     "G3_direct_T7": dict(cfg=dict(), T=7, h=6, w=6),
     "G3b_direct_T5_raises": dict(cfg=dict(), T=5, h=6, w=6, expect_raises="RuntimeError"),
+    "G3d_direct_T2": dict(cfg=dict(), T=2, h=6, w=6),
+    "G3e_off_T3_h2": dict(cfg=dict(use_guide=None), T=3, h=2, w=6),
     "G3c_off_T10_hw75": dict(cfg=dict(use_guide=None), T=10, h=7, w=5),
     # t-kernel 1: single frame video, image modality with a newline token
     "G4_direct_T1": dict(cfg=dict(), T=1, h=6, w=6),

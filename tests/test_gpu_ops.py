@@ -1,0 +1,239 @@
+"""Operator-level parity (GPU): every C-ABI entry point against the oracle's math on small seeded
+inputs.  fp tolerances are written next to each check; integer/index behaviour is exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from hicom_amd import geometry as geo
+from hicom_amd import native as nv
+from hicom_amd import synth
+from oracle import hicom_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+D = 1152
+
+
+def bf(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).cuda()
+
+
+def f32(shape):
+    return torch.empty(shape, dtype=torch.float32, device="cuda")
+
+
+def maxabs(a, b):
+    return float((a.float().cpu() - b.float().cpu()).abs().max())
+
+
+@pytest.mark.parametrize("T,H,W,kt,ks", [(8, 6, 6, 4, 3), (7, 7, 5, 4, 3), (1, 6, 6, 1, 3), (4, 27, 27, 4, 3), (4, 7, 7, 4, 2), (3, 2, 6, 4, 3)])
+@pytest.mark.parametrize("shared_query", [True, False])
+def test_local_attn_matches_oracle(T, H, W, kt, ks, shared_query):
+    x = synth.synth_inputs(T, H, W, D, tag=f"loc{T}{H}{W}")
+    ff, fe, g = x["ff"], x["fe"], x["g"]
+    spec = dict(kt=kt, ks=ks, adapt_q=False, adapt_k=False, adapt_v=False, adapt_guide=False)
+    mode = "direct" if shared_query else None
+    tff, tfe, tg = (torch.from_numpy(a) for a in (ff, fe, g))
+    want, _ = orc.local_context(spec, mode, {}, "lc", tff, tfe, tg, "video", None, None)
+    at, ay, ax = geo.axis_tiling(T, 1 if T == 1 else kt), geo.axis_tiling(H, ks), geo.axis_tiling(W, ks)
+    axes = tuple(nv.Axis(a.n, a.k, a.nwin, a.nfull) for a in (at, ay, ax))
+    nw = at.nwin * ay.nwin * ax.nwin
+    ctx = f32((nw, D))
+    dff, dfe = bf(ff), bf(fe)
+    if shared_query:
+        nv.local_attn(dfe, dff, axes, bf(g), 0, 1 / math.sqrt(D), 0.0, 0, ctx)
+    else:
+        q = f32((at.nwin, ay.nwin, ax.nwin, D))
+        nv.trilinear_pool(dff, q)
+        want_q = orc.pooled_query(tff, (at.nwin, ay.nwin, ax.nwin))
+        assert maxabs(q, want_q) <= 1e-6
+        nv.local_attn(dfe, dff, axes, q, D, 1 / math.sqrt(D), 0.0, 0, ctx)
+    torch.cuda.synchronize()
+    assert maxabs(ctx, want.reshape(nw, D)) <= 2e-5          # fp32 accumulation-order noise only
+
+
+def test_local_attn_clip_scale_and_uniform():
+    T, H, W = 4, 6, 6
+    x = synth.synth_inputs(T, H, W, D, tag="clip")
+    spec = dict(kt=4, ks=3, adapt_q=False, adapt_k=False, adapt_v=False, adapt_guide=False)
+    ls, lb = torch.tensor(2.0), torch.tensor(-3.0)
+    tff, tfe, tg = (torch.from_numpy(x[k]) for k in ("ff", "fe", "g"))
+    want, _ = orc.local_context(spec, "direct", {}, "lc", tff, tfe, tg, "video", ls, lb)
+    axes = tuple(nv.Axis(a.n, a.k, a.nwin, a.nfull) for a in (geo.axis_tiling(T, 4), geo.axis_tiling(H, 3), geo.axis_tiling(W, 3)))
+    ctx = f32((4, D))
+    nv.local_attn(bf(x["fe"]), bf(x["ff"]), axes, bf(x["g"]), 0, math.exp(2.0), -3.0, 3, ctx)
+    assert maxabs(ctx, want.reshape(4, D)) <= 2e-5
+    # known answer: zero query -> uniform attention -> plain window mean of the value stream
+    nv.local_attn(bf(x["fe"]), bf(x["ff"]), axes, bf(np.zeros(D, np.float32)), 0, 1.0, 0.0, 0, ctx)
+    idx = orc.window_token_index(T, H, W, 4, 3)
+    mean = tff.reshape(-1, D)[idx].mean(dim=1)
+    assert maxabs(ctx, mean) <= 2e-6
+
+
+@pytest.mark.parametrize("M,N,K,xdt,wdt", [(1, 1152, 1152, "bf16", "bf16"), (32, 1152, 1152, "f32", "bf16"),
+                                           (9, 118, 1152, "f32", "f32"), (3, 64, 1152, "f32", "bf16"), (32, 896, 896, "f32", "bf16")])
+def test_linear_matches_torch(M, N, K, xdt, wdt):
+    x = synth.normal_like((M, K), 11)
+    w = synth.normal_like((N, K), 12, 0.05)
+    b = synth.normal_like((N,), 13, 0.1)
+    res = synth.normal_like((M, N), 14)
+    want = torch.from_numpy(x).double() @ torch.from_numpy(w).double().t() + torch.from_numpy(b).double()
+    want_g = (0.5 * want * (1 + torch.erf(want / math.sqrt(2)))) + torch.from_numpy(res).double()
+    dx = bf(x) if xdt == "bf16" else torch.from_numpy(x).cuda()
+    dw = bf(w) if wdt == "bf16" else torch.from_numpy(w).cuda()
+    y = f32((M, N))
+    nv.linear(dx, dw, bf(b), y)
+    assert maxabs(y, want) <= 2e-5 * max(1.0, float(want.abs().max()))
+    nv.linear(dx, dw, bf(b), y, res=torch.from_numpy(res).cuda(), act=nv.ACT_GELU)
+    assert maxabs(y, want_g) <= 2e-5 * max(1.0, float(want_g.abs().max()))
+
+
+def test_fold_split_headproj():
+    nq, nh, E = 5, 9, 1152
+    hd = E // nh
+    qp = synth.normal_like((nq, E), 21)
+    wk = synth.normal_like((E, E), 22, 0.02)
+    qt = f32((nq * nh, E))
+    nv.fold_query(torch.from_numpy(qp).cuda(), bf(wk), nh, hd ** -0.5, qt)
+    tq, tw = torch.from_numpy(qp).double(), torch.from_numpy(wk).double()
+    want = torch.stack([tq[q, h * hd:(h + 1) * hd] @ tw[h * hd:(h + 1) * hd, :] for q in range(nq) for h in range(nh)]) * hd ** -0.5
+    assert maxabs(qt, want) <= 1e-6
+    hi = torch.empty((48, E), dtype=torch.bfloat16, device="cuda")
+    lo = torch.empty_like(hi)
+    nv.split_bf16(qt, 48, hi, lo)
+    rec = hi.float() + lo.float()
+    assert float((rec[:45] - qt).abs().max()) <= 2 ** -16 * float(qt.abs().max())
+    assert float(rec[45:].abs().max()) == 0.0
+    assert torch.equal(hi[:45], qt.to(torch.bfloat16))              # hi is the RNE bf16 of the value
+    # per-head v_proj: o[q, f] = w_v[f] . ctx[q*nh + f // hd] + b_v[f]
+    ctx = synth.normal_like((nq * nh, E), 23)
+    bv = synth.normal_like((E,), 24, 0.1)
+    o = f32((nq, E))
+    nv.linear(torch.from_numpy(ctx).cuda(), bf(wk), bf(bv), o, head_rows=nh, head_dim=hd)
+    tc = torch.from_numpy(ctx).double().reshape(nq, nh, E)
+    want_o = torch.stack([torch.cat([tw[h * hd:(h + 1) * hd] @ tc[q, h] for h in range(nh)]) for q in range(nq)]) + torch.from_numpy(bv).double()
+    assert maxabs(o, want_o) <= 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,act", [(8, 64, 1152, 1), (81, 896, 1152, 1), (130, 64, 64, 0), (1296, 896, 896, 0)])
+def test_readout_gemm_matches_torch(M, N, K, act):
+    x = synth.normal_like((M, K), 31)
+    x = (x + synth.normal_like((M, K), 35) * 2.0 ** -10).astype(np.float32)   # NOT bf16-representable
+    w = synth.normal_like((N, K), 32, 0.03)
+    b = synth.normal_like((N,), 33, 0.1)
+    want = torch.from_numpy(x).double() @ torch.from_numpy(w).double().t() + torch.from_numpy(b).double()
+    if act:
+        want = 0.5 * want * (1 + torch.erf(want / math.sqrt(2)))
+    y = f32((M, N))
+    nv.readout_gemm(torch.from_numpy(x).cuda(), bf(w), bf(b), y, act=act)
+    assert maxabs(y, want) <= 5e-5 * max(1.0, float(want.abs().max()))        # hi+lo split: ~2^-16 relative
+    # packed store: newline gap after every 9 rows, offset 3, bf16 output
+    rows = 3 + M + M // 9 + 1
+    yp = torch.zeros((rows, N), dtype=torch.bfloat16, device="cuda")
+    nv.readout_gemm(torch.from_numpy(x).cuda(), bf(w), bf(b), yp, act=act, row0=3, nl_group=9)
+    got = yp.float().cpu()
+    for m in (0, 8, 9, M - 1):
+        r = 3 + m + m // 9
+        assert torch.equal(got[r], want[m].float().to(torch.bfloat16).float()) or maxabs(got[r], want[m]) <= 2 ** -8 * float(want.abs().max())
+    assert float(got[:3].abs().max()) == 0.0 and float(got[3 + 9].abs().max()) == 0.0   # gap rows untouched
+
+
+def test_scatter_rows():
+    src = synth.normal_like((6, 64), 41)
+    dst = torch.zeros((20, 64), dtype=torch.float32, device="cuda")
+    nv.scatter_rows(bf(src), dst, 1, 6, nl_group=2)             # rows 1,2,_,4,5,_,7,8
+    got = dst.cpu().numpy()
+    for i, r in enumerate((1, 2, 4, 5, 7, 8)):
+        assert np.array_equal(got[r], src[i])
+    assert not got[[0, 3, 6, 9]].any()
+    nv.scatter_rows(bf(src[:1]), dst, 10, 5, row_step=2)        # broadcast one row to 10,12,..,18
+    got = dst.cpu().numpy()
+    for r in (10, 12, 14, 16, 18):
+        assert np.array_equal(got[r], src[0])
+    assert not got[[11, 13]].any()
+
+
+def _global_reference(T, H, W, nq, seed_tag, peaky=1.0, in_scale=1.0):
+    """fp64 oracle pieces of the global attention for nq distinct queries."""
+    E, nh = D, 9
+    x = synth.synth_inputs(T, H, W, D, tag=seed_tag, scale=in_scale)
+    q = synth.normal_like((nq, E), synth.seed_of(seed_tag + ":q"))
+    shapes = {f"a.{p}.{k}": s for p in ("q_proj", "k_proj", "v_proj", "out_proj") for k, s in (("weight", (E, E)), ("bias", (E,)))}
+    sd = synth.synth_state_dict(shapes, tag=seed_tag, peaky=peaky)
+    tsd = {k: torch.from_numpy(v).double() for k, v in sd.items()}
+    xp = torch.from_numpy(x["ff"]).double().reshape(-1, E) + orc.pos_table(T, H, W, E).double().reshape(-1, E)
+    # note: the oracle proper adds the float32 pos table; float64 here isolates kernel error
+    _, scores = orc.mha(torch.from_numpy(q).double(), xp, xp, tsd, "a", nh, return_scores=True)   # [nh,nq,N]
+    p = torch.softmax(scores, dim=-1)
+    ctx = torch.einsum("hqn,ne->qhe", p, xp).reshape(nq * nh, E)
+    return x, q, sd, scores.permute(1, 0, 2).reshape(nq * nh, -1), ctx
+
+
+@pytest.mark.parametrize("T,H,W,nq,peaky,in_scale", [(8, 6, 6, 1, 1.0, 1.0), (4, 7, 5, 3, 1.0, 1.0), (8, 6, 6, 2, 12.0, 2.0), (2, 27, 27, 1, 1.0, 1.0)])
+def test_global_stream_merge_combine(T, H, W, nq, peaky, in_scale):
+    E, nh = D, 9
+    x, q, sd, want_scores, want_ctx = _global_reference(T, H, W, nq, f"glob{T}{H}{W}{nq}", peaky, in_scale)
+    N, R = T * H * W, nq * nh
+    rows_pad = (R + 15) // 16 * 16
+    dq = bf(q)
+    qp, qt = f32((nq, E)), f32((R, E))
+    nv.linear(dq, bf(sd["a.q_proj.weight"]), bf(sd["a.q_proj.bias"]), qp)
+    nv.fold_query(qp, bf(sd["a.k_proj.weight"]), nh, (E // nh) ** -0.5, qt)
+    qhi = torch.empty((rows_pad, E), dtype=torch.bfloat16, device="cuda")
+    qlo = torch.empty_like(qhi)
+    nv.split_bf16(qt, rows_pad, qhi, qlo)
+    cap = T + 3
+    pe = torch.from_numpy(geo.stacked_pos_tables(cap, H, W, E)).cuda()
+    pos_a = torch.zeros((rows_pad, pe.shape[0]), dtype=torch.float32, device="cuda")
+    nv.linear(qt, pe, None, pos_a, M=R)
+    ff = bf(x["ff"])
+    for nparts in (1, 3, nv.global_stream_nparts(N, rows_pad)):
+        stride = (N + 15) // 16 * 16
+        scores = f32((rows_pad, stride))
+        pm, pl, pacc = f32((nparts, rows_pad)), f32((nparts, rows_pad)), f32((nparts, rows_pad, E))
+        nv.global_stream(ff, N, qhi, qlo, pos_a, H, W, 0, cap, cap + H, scores, pm, pl, pacc)
+        ml, acc = f32((R, 2)), f32((R, E))
+        scratch = f32((R * T * (H + W + 1),))
+        nv.global_merge(pm, pl, pacc, R, scores, N, H, W, pe, 0, cap, cap + H, scratch, ml, acc)
+        ctx = f32((R, E))
+        nv.global_combine(ml.unsqueeze(0), acc.unsqueeze(0), ctx)
+        torch.cuda.synchronize()
+        # logits agree up to the per-row constant q_h . b_k that softmax cancels
+        diff = scores[:R, :N].double().cpu() - want_scores
+        diff = diff - diff.mean(dim=1, keepdim=True)
+        assert float(diff.abs().max()) <= 2e-4 * max(1.0, float(want_scores.abs().max())), nparts
+        assert maxabs(ctx, want_ctx) <= 1e-4 * max(1.0, float(want_ctx.abs().max())), nparts
+
+
+def test_global_frame_shard_merge_equals_unsharded():
+    """Two frame shards with absolute frame offsets, combined, equal the single pass."""
+    E, nh, T, H, W = D, 9, 8, 6, 6
+    x, q, sd, _, want_ctx = _global_reference(T, H, W, 1, "shard")
+    R, rows_pad = nh, 16
+    qp, qt = f32((1, E)), f32((R, E))
+    nv.linear(bf(q), bf(sd["a.q_proj.weight"]), bf(sd["a.q_proj.bias"]), qp)
+    nv.fold_query(qp, bf(sd["a.k_proj.weight"]), nh, (E // nh) ** -0.5, qt)
+    qhi = torch.empty((rows_pad, E), dtype=torch.bfloat16, device="cuda")
+    qlo = torch.empty_like(qhi)
+    nv.split_bf16(qt, rows_pad, qhi, qlo)
+    cap = 16
+    pe = torch.from_numpy(geo.stacked_pos_tables(cap, H, W, E)).cuda()
+    pos_a = torch.zeros((rows_pad, pe.shape[0]), dtype=torch.float32, device="cuda")
+    nv.linear(qt, pe, None, pos_a, M=R)
+    ff = bf(x["ff"])
+    mls, accs = [], []
+    for t0, t1 in ((0, 4), (4, 8)):
+        shard = ff[t0:t1].contiguous()
+        n = (t1 - t0) * H * W
+        scores = f32((rows_pad, (n + 15) // 16 * 16))
+        pm, pl, pacc = f32((2, rows_pad)), f32((2, rows_pad)), f32((2, rows_pad, E))
+        nv.global_stream(shard, n, qhi, qlo, pos_a, H, W, t0, cap, cap + H, scores, pm, pl, pacc)
+        ml, acc = f32((R, 2)), f32((R, E))
+        nv.global_merge(pm, pl, pacc, R, scores, n, H, W, pe, t0, cap, cap + H, f32((R * 4 * (H + W + 1),)), ml, acc)
+        mls.append(ml), accs.append(acc)
+    ctx = f32((R, E))
+    nv.global_combine(torch.stack(mls), torch.stack(accs), ctx)
+    assert maxabs(ctx, want_ctx) <= 1e-4 * max(1.0, float(want_ctx.abs().max()))
