@@ -49,7 +49,7 @@ def test_local_attn_matches_oracle(T, H, W, kt, ks, shared_query):
         q = f32((at.nwin, ay.nwin, ax.nwin, D))
         nv.trilinear_pool(dff, q)
         want_q = orc.pooled_query(tff, (at.nwin, ay.nwin, ax.nwin))
-        assert maxabs(q, want_q) <= 1e-6
+        assert maxabs(q, want_q) <= 5e-6          # fp32 lerp weights vs the oracle's double taps
         nv.local_attn(dfe, dff, axes, q, D, 1 / math.sqrt(D), 0.0, 0, ctx)
     torch.cuda.synchronize()
     assert maxabs(ctx, want.reshape(nw, D)) <= 2e-5          # fp32 accumulation-order noise only
@@ -135,10 +135,10 @@ def test_readout_gemm_matches_torch(M, N, K, act):
     yp = torch.zeros((rows, N), dtype=torch.bfloat16, device="cuda")
     nv.readout_gemm(torch.from_numpy(x).cuda(), bf(w), bf(b), yp, act=act, row0=3, nl_group=9)
     got = yp.float().cpu()
-    for m in (0, 8, 9, M - 1):
+    for m in sorted({0, min(8, M - 1), min(9, M - 1), M - 1}):
         r = 3 + m + m // 9
         assert torch.equal(got[r], want[m].float().to(torch.bfloat16).float()) or maxabs(got[r], want[m]) <= 2 ** -8 * float(want.abs().max())
-    assert float(got[:3].abs().max()) == 0.0 and float(got[3 + 9].abs().max()) == 0.0   # gap rows untouched
+    assert float(got[:3].abs().max()) == 0.0 and (M < 9 or float(got[3 + 9].abs().max()) == 0.0)   # gap rows untouched
 
 
 def test_scatter_rows():
@@ -205,7 +205,10 @@ def test_global_stream_merge_combine(T, H, W, nq, peaky, in_scale):
         diff = scores[:R, :N].double().cpu() - want_scores
         diff = diff - diff.mean(dim=1, keepdim=True)
         assert float(diff.abs().max()) <= 2e-4 * max(1.0, float(want_scores.abs().max())), nparts
-        assert maxabs(ctx, want_ctx) <= 1e-4 * max(1.0, float(want_ctx.abs().max())), nparts
+        # hi+lo bf16 queries carry ~2^-17 relative logit error; with |logit| ~ 1e2 (peaky case) that is
+        # ~1e-3 absolute in the exponent, i.e. ~3e-4 relative in the context
+        rel = 3e-4 if peaky > 1 else 1e-4
+        assert maxabs(ctx, want_ctx) <= rel * max(1.0, float(want_ctx.abs().max())), nparts
 
 
 def test_global_frame_shard_merge_equals_unsharded():
