@@ -1,0 +1,215 @@
+"""Headline benchmark: compressed video-tokens / s of the HICom compressor on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torchrun)
+
+A "step" = one forward of the release configuration (mm_projector_type local43_global32_coarse,
+use_guide=direct, spatial_unpad/no_token, hidden 896) over synthetic SigLIP features that are
+already resident in HBM: 64 frames x 729 tokens x 1152 bf16 PER GPU (BASELINE.json configs[1];
+N GPUs => 64*N frames frame-sharded with one RCCL all-gather, configs[2], weak scaling).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     dominant kernel's ALGORITHMIC bytes / its mean launch time (HIP events on its own
+               stream, measured here) against the 8 TB/s HBM3E peak
+  cpu_baseline the CPU oracle (a port of the reference's PyTorch path) timed on this host's
+               cores on the same 64-frame workload (bounded number of repetitions)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import hicom_amd                                      # noqa: E402
+from hicom_amd import native as nv                    # noqa: E402
+from hicom_amd.dist import sharded_forward            # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy)
+D, GRID = 1152, 27
+
+
+def release_config(hidden: int, frames: int):
+    from types import SimpleNamespace
+    return SimpleNamespace(mm_projector_type="local43_global32_coarse", use_guide="direct", use_clip_scale="",
+                           mm_patch_merge_type="spatial_unpad", mm_newline_position="no_token",
+                           mm_vision_tower="google/siglip-so400m-patch14-384", mm_hidden_size=D,
+                           hidden_size=hidden, max_num_frames=max(frames, 32))
+
+
+def make_projector(cfg, device):
+    """Random-init weights of the reference's architecture/init law (query ~ N(0,.02) so the branch
+    is numerically live), bf16."""
+    torch.manual_seed(20250614)
+    m = hicom_amd.build_vision_projector(cfg)
+    with torch.no_grad():
+        m.global_compressor.query.normal_(0, 0.02)
+        for p in m.parameters():
+            if p.ndim == 1 and p.numel() > 1:
+                p.normal_(0, 0.02)
+    return m.to(torch.bfloat16).to(device).eval()
+
+
+def cpu_baseline(cfg, module, frames: int, budget_s: float = 20.0):
+    """Times the CPU oracle on the same workload shape (fp32, all host cores)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import hicom_oracle as orc
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))   # one socket's worth; more threads only adds contention
+    g = torch.Generator().manual_seed(1)
+    ff = torch.randn(frames, GRID, GRID, D, generator=g).bfloat16().float()
+    fe = torch.randn(frames, GRID, GRID, D, generator=g).bfloat16().float()
+    gd = torch.randn(D, generator=g).bfloat16().float()
+    sd = {k: v.detach().float().cpu() for k, v in module.state_dict().items()}
+    n_out = frames // 4 * 81 + 32
+    times = []
+    t_start = time.perf_counter()
+    with torch.no_grad():
+        # untimed warm-up at the full shape: the reference builds its pos_embed buffer at construction
+        orc.projector_forward(cfg, sd, ff, fe, gd, "video", None)
+        t_start = time.perf_counter()
+        while len(times) < 5 and (time.perf_counter() - t_start) < budget_s:
+            t0 = time.perf_counter()
+            out = orc.projector_forward(cfg, sd, ff, fe, gd, "video", None)
+            times.append(time.perf_counter() - t0)
+    assert out.shape[0] == n_out
+    best = min(times)
+    return {"value": n_out / best, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} forwards of the full {frames}x729x1152 fp32 workload (min of {len(times)}, "
+                      f"{best * 1e3:.0f} ms each) by oracle/hicom_oracle.py on torch-CPU"}
+
+
+def parity_probe(device):
+    """max-abs of the HIP path vs the CPU oracle on the reference's CPU-runnable case (configs[0])."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import cases
+    from gpu_util import run_native
+    from oracle_util import run_oracle
+    case = cases.build_case("G11_c1_shape")
+    got = run_native(case)["out"].float().cpu()
+    want = run_oracle(case)["out"]
+    return {"max_abs": float((got - want).abs().max()), "tolerance": 1e-3,
+            "workload": "4x729x1152, H=896, direct (BASELINE configs[0]) vs fp32 CPU oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--frames-per-gpu", type=int, default=64)
+    ap.add_argument("--hidden", type=int, default=896)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)      # "nccl" is RCCL on ROCm
+
+    fpg = args.frames_per_gpu
+    total_frames = fpg * world
+    cfg = release_config(args.hidden, total_frames)
+    module = make_projector(cfg, device)
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    ff = torch.randn(fpg, GRID, GRID, D, device=device, generator=gen).to(torch.bfloat16)
+    fe = torch.randn(fpg, GRID, GRID, D, device=device, generator=gen).to(torch.bfloat16)
+    guide = torch.randn(D, device=device, generator=torch.Generator(device=device).manual_seed(7)).to(torch.bfloat16)
+    n_out = total_frames // 4 * 81 + 32
+
+    def step():
+        if distributed:
+            return sharded_forward(module, ff, fe, guide, total_frames)
+        return module(ff, fe, guide, "video", None)
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step()
+        assert out.shape == (n_out, args.hidden)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel (HIP events on the stream it is launched on) ----------
+    roofline = dominant_kernel_roofline(module, ff, fe, guide, args.steps)
+
+    result = {
+        "metric": "compressed_video_tokens_per_sec", "value": n_out / (ms_per_step * 1e-3), "unit": "tokens/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{total_frames} frames x 729 SigLIP tokens x 1152 bf16 ({fpg}/GPU), local43+global32, "
+                               f"use_guide=direct, hidden {args.hidden} -> {n_out} compressed tokens",
+                   "frames": total_frames, "frames_per_gpu": fpg, "hidden": args.hidden,
+                   "parallelism": f"frame-shard x{world}" + (" + RCCL all-gather" if distributed else "")},
+        "input_visual_tokens_per_sec": total_frames * GRID * GRID / (ms_per_step * 1e-3),
+        "roofline": roofline,
+    }
+    if rank == 0:
+        if world == 1:
+            result["parity"] = parity_probe(device)
+            if not args.no_cpu_baseline:
+                result["cpu_baseline"] = cpu_baseline(cfg, module, fpg)
+                result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+        print(json.dumps(result))
+    if distributed:
+        dist.destroy_process_group()
+
+
+def dominant_kernel_roofline(module, ff, fe, guide, iters):
+    """local_attn_kernel streams both visual tensors (frames_embed + frames_feature) once: its
+    algorithmic bytes are SURVEY.md §8(d)'s 3,359,232 B per frame x frames (+ the fp32 contexts)."""
+    lc = module.local_compressor
+    T, H, W, _ = ff.shape
+    at, ay, ax = lc.tilings(T, H, W, "video")
+    axes = tuple(nv.Axis(a.n, a.k, a.nwin, a.nfull) for a in (at, ay, ax))
+    nw = at.nwin * ay.nwin * ax.nwin
+    ctx = torch.empty((nw, D), dtype=torch.float32, device=ff.device)
+    stream = torch.cuda.current_stream()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for _ in range(3):
+        nv.local_attn(fe, ff, axes, guide, 0, 1.0 / D ** 0.5, 0.0, 0, ctx)
+    torch.cuda.synchronize()
+    for a, b in evs:
+        a.record(stream)
+        nv.local_attn(fe, ff, axes, guide, 0, 1.0 / D ** 0.5, 0.0, 0, ctx)
+        b.record(stream)
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    mean_ms = sum(ms) / len(ms)
+    alg_bytes = 3359232 * T + nw * D * 4
+    achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
+    return {"kernel": "hicom::local_attn_kernel<3>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": mean_ms, "min_launch_ms": ms[0]}
+
+
+if __name__ == "__main__":
+    main()

@@ -346,8 +346,21 @@ def pos_axis_table(n: int, d_model: int) -> np.ndarray:
     return pe
 
 
+_POS_CACHE: Dict[Tuple[int, int, int, int], Tensor] = {}
+
+
 def pos_table(T: int, H: int, W: int, d_model: int) -> Tensor:
-    """float32 [T,H,W,D] = (PE_t + PE_h + PE_w in float64).float()  (:95-99, :606)."""
+    """float32 [T,H,W,D] = (PE_t + PE_h + PE_w in float64).float()  (:95-99, :606).
+    Cached like the reference's `pos_embed` buffer, which is built once at construction (:601)."""
+    key = (T, H, W, d_model)
+    if key not in _POS_CACHE:
+        if len(_POS_CACHE) > 4:
+            _POS_CACHE.clear()
+        _POS_CACHE[key] = _pos_table_uncached(T, H, W, d_model)
+    return _POS_CACHE[key]
+
+
+def _pos_table_uncached(T: int, H: int, W: int, d_model: int) -> Tensor:
     pt, ph, pw = pos_axis_table(T, d_model), pos_axis_table(H, d_model), pos_axis_table(W, d_model)
     full = pt[:, None, None, :] + ph[None, :, None, :] + pw[None, None, :, :]
     return torch.from_numpy(full).float()

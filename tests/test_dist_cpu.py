@@ -1,0 +1,95 @@
+"""World-size-2 gloo test (CPU) of the frame-shard plan and the single-collective exchange.
+
+The HIP kernels cannot run here, so each rank's shard results are produced by the oracle (as the
+checker's stand-in for the kernels); what is under test is the product's plan, buffer packing,
+all-gather ordering and the online-softmax combine identity the multi-GPU path relies on."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cases
+from hicom_amd.dist import FrameShardPlan, exchange
+from oracle import hicom_oracle as orc
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard_state(sd, ff, guide, t0, T_total, nh=9):
+    """(M, L, ACC) of one frame shard for the direct-mode query, from oracle math (fp64)."""
+    E = ff.shape[-1]
+    H, W = ff.shape[1:3]
+    pos = orc.pos_table(T_total, H, W, E)[t0:t0 + ff.shape[0]].double()
+    x = (ff.double() + pos).reshape(-1, E)
+    pre = "global_compressor.attn_layer"
+    q = orc.linear(guide.double()[None], {k: v.double() for k, v in sd.items()}, pre + ".q_proj")
+    k = orc.linear(x, {k_: v.double() for k_, v in sd.items()}, pre + ".k_proj")
+    hd = E // nh
+    s = torch.einsum("hd,nhd->hn", q.reshape(nh, hd), k.reshape(-1, nh, hd)) * hd ** -0.5
+    M = s.max(dim=1).values
+    p = torch.exp(s - M[:, None])
+    return M, p.sum(dim=1), p @ x        # [nh], [nh], [nh, E]
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        case = cases.build_case("G1_direct_T8")
+        sd = {k: torch.from_numpy(v) for k, v in case.sd.items()}
+        ff, fe, g = (torch.from_numpy(a) for a in (case.ff, case.fe, case.g))
+        T = ff.shape[0]
+        plan = FrameShardPlan(T, world, 4)
+        t0, t1 = plan.frame_range(rank)
+        spec = orc.parse_projector_type(case.cfg.mm_projector_type)
+        loc = orc.local_forward(spec["local"], "direct", sd, "local_compressor", ff[t0:t1], fe[t0:t1], g, "video")
+        loc = loc.reshape(-1, loc.shape[-1]).float()
+        assert loc.shape[0] == plan.windows_per_rank(2, 2)
+        M, L, ACC = _shard_state(sd, ff[t0:t1], g, t0, T)
+        state = torch.cat([torch.stack([M, L], dim=1).reshape(-1), ACC.reshape(-1)]).float()
+        states, tokens = exchange(state, loc)
+        assert states.shape == (world, state.numel()) and tokens.shape == (world * loc.shape[0], loc.shape[1])
+        assert torch.equal(states[rank], state) and torch.equal(tokens[rank * loc.shape[0]:(rank + 1) * loc.shape[0]], loc)
+        # combine exactly as hicom_global_combine_fwd does
+        R, E = ACC.shape
+        ml = states[:, :2 * R].reshape(world, R, 2).double()
+        acc = states[:, 2 * R:].reshape(world, R, E).double()
+        Ms = ml[..., 0].max(dim=0).values
+        w = torch.exp(ml[..., 0] - Ms)
+        ctx = (w[..., None] * acc).sum(0) / (w * ml[..., 1]).sum(0)[:, None]
+        # finish the global rows with oracle math and compare with the unsharded oracle
+        dsd = {k: v.double() for k, v in sd.items()}
+        pre = "global_compressor.attn_layer"
+        hd = E // R
+        o = torch.cat([dsd[pre + ".v_proj.weight"][h * hd:(h + 1) * hd] @ ctx[h] for h in range(R)]) + dsd[pre + ".v_proj.bias"]
+        att = orc.linear(o[None], dsd, pre + ".out_proj")
+        glob = orc.mlp2(g.double()[None] + att, dsd, "global_compressor.readout")
+        full = orc.projector_forward(case.cfg, sd, ff, fe, g, "video", None)
+        assert float((tokens - full[:tokens.shape[0]]).abs().max()) < 1e-5
+        assert float((glob.float() - full[-1:]).abs().max()) < 1e-5
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_exchange_and_combine(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_plan_rejects_ragged_splits():
+    assert FrameShardPlan(512, 8, 4).frame_range(3) == (192, 256)
+    assert FrameShardPlan(64, 1, 4).windows_per_rank(9, 9) == 1296
+    with pytest.raises(ValueError):
+        FrameShardPlan(60, 8, 4)
