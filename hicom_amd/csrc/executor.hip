@@ -1,0 +1,198 @@
+// Native executor: ONE C call enqueues the whole compressor forward for a dense [T,H,W,E] input.
+//
+// The reference runs HIComProjector.forward (projector.py:676-708) as ~60 eager PyTorch ops on
+// one stream.  Here the forward is a fixed plan of <= 14 kernel launches over a caller-owned
+// workspace, issued from C++ (no per-op Python/ctypes/allocator cost) on TWO HIP streams:
+//
+//   main stream : local windowed attention -> readout GEMM 1 (GELU) -> readout GEMM 2 -> newline rows
+//   side stream : q_proj -> fold(+pos table, hi/lo split) -> MFMA token stream -> marginals -> merge
+//                 [-> combine of gathered shard states] -> per-head v_proj -> out_proj(+residual)
+//                 -> readout 1 (GELU) -> readout 2 -> 32 global rows
+//
+// fork/join uses two caller-provided events, so the whole thing is hipGraph-capturable and keeps
+// no state inside the library.  Phases can be run separately (HICOM_PHASE_*) so that the
+// frame-sharded multi-GPU path can place its RCCL all-gather between them.
+#include <string.h>
+
+#include "common.hpp"
+
+using namespace hicom;
+
+namespace {
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct WsLayout {
+    size_t ctx_local, hid_local, pooled_q, qp, qhi, qlo, pos_a, scores, part_m, part_l, part_acc, scratch, ml, acc,
+        ctx_g, o, qres, pre, hid_g, tok, total;
+    int nw, R, rows_pad, nparts, P;
+    long N, score_stride;
+};
+
+WsLayout make_layout(const hicom_compressor_args& a) {
+    WsLayout w;
+    memset(&w, 0, sizeof(w));
+    w.nw = a.at.nwin * a.ay.nwin * a.ax.nwin;
+    w.N = (long)a.T * a.H * a.W;
+    w.R = a.nq * a.nh;
+    w.rows_pad = (w.R + 15) / 16 * 16;
+    w.P = a.P;
+    w.score_stride = (w.N + 15) / 16 * 16;
+    w.nparts = a.has_global ? hicom_global_stream_nparts(w.N, w.rows_pad) : 0;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align256(off + bytes); return o; };
+    // zero-initialised-once region first (padding rows that no kernel ever writes)
+    w.qhi = take((size_t)w.rows_pad * a.E * 2);
+    w.qlo = take((size_t)w.rows_pad * a.E * 2);
+    w.pos_a = take((size_t)w.rows_pad * (a.P > 0 ? a.P : 1) * 4);
+    if (a.has_local) {
+        w.ctx_local = take((size_t)w.nw * a.E * 4);
+        w.hid_local = take((size_t)w.nw * a.hidden * 4);
+        w.pooled_q = take(a.lq ? 0 : (size_t)w.nw * a.E * 4);
+    }
+    if (a.has_global) {
+        w.qp = take((size_t)a.nq * a.E * 4);
+        w.scores = take((size_t)w.rows_pad * w.score_stride * 4);
+        w.part_m = take((size_t)w.nparts * w.rows_pad * 4);
+        w.part_l = take((size_t)w.nparts * w.rows_pad * 4);
+        w.part_acc = take((size_t)w.nparts * w.rows_pad * a.E * 4);
+        w.scratch = take((size_t)w.R * a.T * (a.H + a.W + 2) * 4);
+        w.ml = take((size_t)w.R * 2 * 4);
+        w.acc = take((size_t)w.R * a.E * 4);
+        w.ctx_g = take((size_t)w.R * a.E * 4);
+        w.o = take((size_t)a.nq * a.E * 4);
+        w.qres = take((size_t)a.nq * a.E * 4);
+        w.pre = take((size_t)a.nq * a.E * 4);
+        w.hid_g = take((size_t)a.nq * a.hidden * 4);
+        w.tok = take((size_t)a.nq * a.hidden * 4);
+    }
+    w.total = off;
+    return w;
+}
+
+#define CHK(call)                  \
+    do {                           \
+        int rc_ = (call);          \
+        if (rc_ != HICOM_OK) return rc_; \
+    } while (0)
+
+int check_args(const hicom_compressor_args& a) {
+    HICOM_REQUIRE(a.has_local || a.has_global, HICOM_EINVAL, "compressor: nothing to do");
+    HICOM_REQUIRE(a.ff && a.out && a.ws, HICOM_EINVAL, "compressor: NULL pointer");
+    HICOM_REQUIRE(a.T > 0 && a.H > 0 && a.W > 0 && (a.E == 1152 || a.E == 768), HICOM_EINVAL, "compressor: bad input shape");
+    HICOM_REQUIRE(a.hidden > 0 && a.hidden % 64 == 0, HICOM_EUNSUP, "compressor: hidden size %d must be a multiple of 64", a.hidden);
+    if (a.has_local) HICOM_REQUIRE(a.lw0 && a.lw2, HICOM_EINVAL, "compressor: local readout weights");
+    if (a.has_global) {
+        HICOM_REQUIRE(a.gq && a.nq > 0 && a.nh > 0 && a.wq && a.wk && a.wv && a.wo && a.gw0 && a.gw2, HICOM_EINVAL,
+                      "compressor: global weights");
+        HICOM_REQUIRE(a.n_global_rows >= a.nq && a.n_global_rows % a.nq == 0, HICOM_EINVAL, "compressor: global row count");
+        HICOM_REQUIRE((a.pe == nullptr) == (a.kpe == nullptr), HICOM_EINVAL, "compressor: pe and kpe go together");
+    }
+    if (a.has_local && a.has_global && (a.phases & HICOM_PHASE_STREAM))
+        HICOM_REQUIRE(a.stream_side && a.ev_fork && a.ev_join, HICOM_EINVAL, "compressor: side stream and events required");
+    return HICOM_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t hicom_compressor_workspace_bytes(const hicom_compressor_args* a) {
+    if (!a) return HICOM_EINVAL;
+    return (int64_t)make_layout(*a).total;
+}
+
+extern "C" int64_t hicom_compressor_zero_prefix_bytes(const hicom_compressor_args* a) {
+    if (!a) return HICOM_EINVAL;
+    const WsLayout w = make_layout(*a);
+    return (int64_t)(a->has_local ? w.ctx_local : w.qp);
+}
+
+extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
+    HICOM_REQUIRE(ap, HICOM_EINVAL, "compressor: NULL args");
+    const hicom_compressor_args& a = *ap;
+    CHK(check_args(a));
+    const WsLayout w = make_layout(a);
+    HICOM_REQUIRE(a.ws_bytes >= (int64_t)w.total, HICOM_EINVAL, "compressor: workspace too small (%lld < %zu)",
+                  (long long)a.ws_bytes, w.total);
+    char* ws = (char*)a.ws;
+    auto F = [&](size_t off) { return (float*)(ws + off); };
+    hipStream_t sm = (hipStream_t)a.stream_main, ss = (hipStream_t)a.stream_side;
+    const bool both = a.has_local && a.has_global;
+    const bool do_stream = a.phases & HICOM_PHASE_STREAM, do_finish = a.phases & HICOM_PHASE_FINISH;
+    // the global chain runs on the side stream only when there is local work to overlap it with
+    hipStream_t sg = (both && do_stream) ? ss : sm;
+
+    if (both && do_stream) {
+        HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_fork, sm) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
+        HICOM_REQUIRE(hipStreamWaitEvent(ss, (hipEvent_t)a.ev_fork, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
+    }
+
+    // ------------------------------------------------------------------ global chain, part 1
+    if (a.has_global && do_stream) {
+        CHK(hicom_scatter_rows_fwd(a.gq, HICOM_DT_BF16, a.nq, a.E, F(w.qres), HICOM_DT_F32, a.E, 0, 1, 0, a.nq, sg));
+        CHK(hicom_linear_fwd(a.gq, HICOM_DT_BF16, a.wq, HICOM_DT_BF16, a.bq, HICOM_DT_BF16, nullptr, 0, a.nq, a.E, a.E,
+                             0, 0, HICOM_ACT_NONE, F(w.qp), sg));
+        const float scale = 1.0f / sqrtf((float)(a.E / a.nh));
+        CHK(hicom_fold_query_split_fwd(F(w.qp), a.wk, a.kpe, a.nq, a.nh, a.E, a.P, scale, ws + w.qhi, ws + w.qlo,
+                                       F(w.pos_a), a.P, sg));
+        CHK(hicom_global_stream_fwd(a.ff, w.N, a.E, ws + w.qhi, ws + w.qlo, w.R, w.rows_pad,
+                                    a.pe ? F(w.pos_a) : nullptr, a.P, a.H, a.W, a.t_index0, a.y_index0, a.x_index0,
+                                    F(w.scores), w.score_stride, F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, sg));
+        // single shard: the merge normalises in place and no combine is needed
+        const bool solo = a.state_out == nullptr;
+        float* ml = solo ? F(w.ml) : (float*)a.state_out;
+        float* acc = solo ? F(w.ctx_g) : (float*)a.state_out + 2 * w.R;
+        CHK(hicom_global_merge_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E,
+                                   F(w.scores), w.score_stride, w.N, a.H, a.W, a.pe, a.t_index0, a.y_index0, a.x_index0,
+                                   F(w.scratch), ml, acc, solo ? 1 : 0, sg));
+    }
+
+    // ------------------------------------------------------------------ local chain
+    if (a.has_local && do_stream) {
+        const void* q = a.lq;
+        int q_dt = a.lq_dt;
+        int64_t q_stride = a.lq_stride;
+        if (!q) {   // guide off: per-window pooled query
+            CHK(hicom_trilinear_pool_fwd(a.ff, a.T, a.H, a.W, a.E, a.at.nwin, a.ay.nwin, a.ax.nwin, F(w.pooled_q), sm));
+            q = F(w.pooled_q);
+            q_dt = HICOM_DT_F32;
+            q_stride = a.E;
+        }
+        CHK(hicom_local_attn_fwd(a.fe ? a.fe : a.ff, a.ff, a.E, a.at, a.ay, a.ax, q, q_dt, q_stride, a.l_scale, a.l_bias,
+                                 a.l2norm, F(w.ctx_local), sm));
+        CHK(hicom_readout_gemm_fwd(F(w.ctx_local), a.lw0, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E, HICOM_ACT_GELU,
+                                   F(w.hid_local), HICOM_DT_F32, a.hidden, 0, 0, sm));
+        CHK(hicom_readout_gemm_fwd(F(w.hid_local), a.lw2, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden, HICOM_ACT_NONE,
+                                   a.local_out ? a.local_out : a.out, a.out_dt, a.local_out ? a.hidden : a.ldo,
+                                   a.local_out ? 0 : a.local_row0, a.local_out ? 0 : a.nl_group, sm));
+        if (a.nl_count > 0 && !a.local_out)
+            CHK(hicom_scatter_rows_fwd(a.newline, a.newline_dt, 1, a.hidden, a.out, a.out_dt, a.ldo, a.nl_first, a.nl_step,
+                                       0, a.nl_count, sm));
+    }
+
+    // ------------------------------------------------------------------ global chain, part 2
+    if (a.has_global && do_finish) {
+        const float* ctx = F(w.ctx_g);
+        if (a.state_sets) {   // gathered (M, L, ACC) states of all shards: [nsets][2R + R*E]
+            HICOM_REQUIRE(a.nsets > 0 && a.state_set_stride >= (int64_t)(2 * w.R + (long)w.R * a.E), HICOM_EINVAL,
+                          "compressor: state set layout");
+            CHK(hicom_global_combine_strided_fwd((const float*)a.state_sets, (const float*)a.state_sets + 2 * w.R,
+                                                 a.state_set_stride, a.nsets, w.R, a.E, F(w.ctx_g), sg));
+        }
+        CHK(hicom_linear_fwd(ctx, HICOM_DT_F32, a.wv, HICOM_DT_BF16, a.bv, HICOM_DT_BF16, nullptr, 0, a.nq, a.E, a.E,
+                             a.nh, a.E / a.nh, HICOM_ACT_NONE, F(w.o), sg));
+        CHK(hicom_linear_fwd(F(w.o), HICOM_DT_F32, a.wo, HICOM_DT_BF16, a.bo, HICOM_DT_BF16, F(w.qres), 0, a.nq, a.E, a.E,
+                             0, 0, HICOM_ACT_NONE, F(w.pre), sg));
+        CHK(hicom_linear_fwd(F(w.pre), HICOM_DT_F32, a.gw0, HICOM_DT_BF16, a.gb0, HICOM_DT_BF16, nullptr, 0, a.nq, a.hidden,
+                             a.E, 0, 0, HICOM_ACT_GELU, F(w.hid_g), sg));
+        CHK(hicom_linear_fwd(F(w.hid_g), HICOM_DT_F32, a.gw2, HICOM_DT_BF16, a.gb2, HICOM_DT_BF16, nullptr, 0, a.nq,
+                             a.hidden, a.hidden, 0, 0, HICOM_ACT_NONE, F(w.tok), sg));
+        CHK(hicom_scatter_rows_fwd(F(w.tok), HICOM_DT_F32, a.nq, a.hidden, a.out, a.out_dt, a.ldo, a.global_row0, 1, 0,
+                                   a.n_global_rows, sg));
+    }
+
+    if (both && do_stream) {
+        HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_join, ss) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
+        HICOM_REQUIRE(hipStreamWaitEvent(sm, (hipEvent_t)a.ev_join, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
+    }
+    return HICOM_OK;
+}

@@ -40,6 +40,7 @@ struct StreamParams {
     float* part_l;
     float* part_acc;
     int rows_pad;
+    int rows;      // rows < rows_pad that carry real queries; padded rows are never stored
     int ntiles;
 };
 
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
 
     // ---- partial results of this token chunk ----------------------------------------------------
     const long prow = (long)part * p.rows_pad + rg * 16;
-    if (wave == 0 && kg == 0) {
+    if (wave == 0 && kg == 0 && rg * 16 + r16 < p.rows) {
         p.part_m[prow + r16] = m_run;
         p.part_l[prow + r16] = l_run;
     }
@@ -238,7 +239,8 @@ __global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
     for (int cb = 0; cb < CBLK; ++cb) {
         float* o = p.part_acc + (prow + 4 * kg) * E + SLICE * wave + 16 * cb + r16;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[(long)j * E] = acc[cb][j];
+        for (int j = 0; j < 4; ++j)
+            if (rg * 16 + 4 * kg + j < p.rows) o[(long)j * E] = acc[cb][j];
     }
 }
 
@@ -271,7 +273,7 @@ extern "C" int hicom_global_stream_nparts(int64_t N, int32_t rows_pad) {
 }
 
 extern "C" int hicom_global_stream_fwd(const void* x, int64_t N, int32_t E,
-                                       const void* qt_hi, const void* qt_lo, int32_t rows_pad,
+                                       const void* qt_hi, const void* qt_lo, int32_t rows, int32_t rows_pad,
                                        const float* pos_a, int32_t pos_stride,
                                        int32_t H, int32_t W, int32_t t_index0, int32_t y_index0, int32_t x_index0,
                                        float* scores, int64_t score_stride,
@@ -280,7 +282,8 @@ extern "C" int hicom_global_stream_fwd(const void* x, int64_t N, int32_t E,
     HICOM_REQUIRE(x && qt_hi && qt_lo && scores && part_m && part_l && part_acc, HICOM_EINVAL, "global_stream: NULL pointer");
     HICOM_REQUIRE(E == 1152 || E == 768, HICOM_EUNSUP, "global_stream: E=%d (only 1152 / 768)", E);
     HICOM_REQUIRE(N > 0 && N < (1L << 31), HICOM_EINVAL, "global_stream: N out of range");
-    HICOM_REQUIRE(rows_pad > 0 && rows_pad % 16 == 0, HICOM_EINVAL, "global_stream: rows_pad must be a multiple of 16");
+    HICOM_REQUIRE(rows_pad > 0 && rows_pad % 16 == 0 && rows > 0 && rows <= rows_pad, HICOM_EINVAL,
+                  "global_stream: rows_pad must be a multiple of 16 and 0 < rows <= rows_pad");
     HICOM_REQUIRE(nparts > 0, HICOM_EINVAL, "global_stream: nparts");
     HICOM_REQUIRE(score_stride >= ((N + 15) / 16) * 16 && score_stride % 4 == 0, HICOM_EINVAL,
                   "global_stream: score_stride must be >= roundup(N,16)");
@@ -293,7 +296,7 @@ extern "C" int hicom_global_stream_fwd(const void* x, int64_t N, int32_t E,
     p.pos_a = pos_a; p.pos_stride = pos_stride; p.H = H; p.W = W; p.HW = H * W;
     p.t0i = t_index0; p.y0i = y_index0; p.x0i = x_index0;
     p.scores = scores; p.score_stride = score_stride;
-    p.part_m = part_m; p.part_l = part_l; p.part_acc = part_acc; p.rows_pad = rows_pad;
+    p.part_m = part_m; p.part_l = part_l; p.part_acc = part_acc; p.rows_pad = rows_pad; p.rows = rows;
     p.ntiles = (int)((N + 15) / 16);
     dim3 grid((unsigned)nparts, (unsigned)(rows_pad / 16));
     hipStream_t s = (hipStream_t)stream;

@@ -8,9 +8,11 @@
 // bf16 hi + lo and contracted with two v_mfma_f32_16x16x32_bf16 into the same fp32 accumulator.
 // Weights are exact bf16.
 //
-// Tiling: 64x64 output tile per 256-thread workgroup (2x2 waves, each 32x32 = 2x2 MFMA tiles),
-// BK = 32; operands are register-staged (next k-step's global loads fly under the MFMAs) into
-// 80-byte-stride LDS rows, which makes every ds_read_b128 fragment read conflict-free.
+// Tiling: 64x64 output tile per 256-thread workgroup (2x2 waves, each 32x32 = 2x2 MFMA tiles).
+// The K loop runs in stages of 64: operands are register-staged TWO stages ahead (global-load
+// latency of ~1 us is several stage-times long at these small sizes), converted/split while being
+// written into a double-buffered LDS image with 144-byte rows (conflict-free ds_read_b128
+// fragment reads), one workgroup barrier per stage.
 // The store applies the packing row map of post_process_visual_feature (mm_utils.py:100-135).
 #include "common.hpp"
 
@@ -28,25 +30,59 @@ struct GemmParams {
     int nl_group;
 };
 
-constexpr int kLdsRow = 80;   // bytes per 32-element bf16 row (64 B data + 16 B pad)
+constexpr int kRowB = 144;                 // bytes per 64-element bf16 row (128 B data + 16 B pad)
+constexpr int kMatB = 64 * kRowB;          // one 64x64 bf16 operand image
+constexpr int kBufB = 3 * kMatB;           // A_hi | A_lo | B
 
-__global__ __launch_bounds__(256) void readout_gemm_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[3 * 64 * kLdsRow];
-    char* Ahi = lds;
-    char* Alo = lds + 64 * kLdsRow;
-    char* Bs = lds + 2 * 64 * kLdsRow;
+struct Stage {
+    float4 a[4];     // 16 consecutive k of one A row (fp32)
+    u32x4 b[2];      // 16 consecutive k of one W row (bf16)
+};
+
+__device__ __forceinline__ void stage_load(Stage& st, const float* xa, const uint16_t* wb, int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st.a[i] = *reinterpret_cast<const float4*>(xa + k0 + 4 * i);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) st.b[i] = *reinterpret_cast<const u32x4*>(wb + k0 + 8 * i);
+}
+
+__device__ __forceinline__ void stage_store(const Stage& st, char* buf, int srow, int skq) {
+    char* ahi = buf + srow * kRowB + 32 * skq;
+    char* alo = ahi + kMatB;
+    char* bs = ahi + 2 * kMatB;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const float v[8] = {st.a[2 * half].x, st.a[2 * half].y, st.a[2 * half].z, st.a[2 * half].w,
+                            st.a[2 * half + 1].x, st.a[2 * half + 1].y, st.a[2 * half + 1].z, st.a[2 * half + 1].w};
+        u32x4 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint16_t h0, l0, h1, l1;
+            split_bf16(v[2 * i], h0, l0);
+            split_bf16(v[2 * i + 1], h1, l1);
+            hi[i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+            lo[i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+        }
+        *reinterpret_cast<u32x4*>(ahi + 16 * half) = hi;
+        *reinterpret_cast<u32x4*>(alo + 16 * half) = lo;
+        *reinterpret_cast<u32x4*>(bs + 16 * half) = st.b[half];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void readout_gemm_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // [2][kBufB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int r16 = lane & 15, kg = lane >> 4;
 
-    // staging assignment: thread -> (row, 8-element k chunk)
-    const int srow = tid >> 2, skc = tid & 3;
+    // staging assignment: thread -> (row, 16-element k quarter of the 64-wide stage)
+    const int srow = tid >> 2, skq = tid & 3;
     int am = m0 + srow; am = am < p.M ? am : p.M - 1;
     int bn = n0 + srow; bn = bn < p.N ? bn : p.N - 1;
-    const float* xa = p.x + (long)am * p.K + 8 * skc;
-    const uint16_t* wb = p.w + (long)bn * p.K + 8 * skc;
+    const float* xa = p.x + (long)am * p.K + 16 * skq;
+    const uint16_t* wb = p.w + (long)bn * p.K + 16 * skq;
 
     f32x4 acc[2][2];
 #pragma unroll
@@ -54,50 +90,46 @@ __global__ __launch_bounds__(256) void readout_gemm_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float4 a0 = *reinterpret_cast<const float4*>(xa);
-    float4 a1 = *reinterpret_cast<const float4*>(xa + 4);
-    u32x4 bw = *reinterpret_cast<const u32x4*>(wb);
+    const int ns = p.K / 64;
+    Stage st[2];
+    stage_load(st[0], xa, wb, 0);
+    if (ns > 1) stage_load(st[1], xa, wb, 64);
+    stage_store(st[0], lds, srow, skq);
+    __syncthreads();
 
-    const int nk = p.K / 32;
-    for (int ks = 0; ks < nk; ++ks) {
-        __syncthreads();
-        {
-            const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            u32x4 hi, lo;
+    auto compute = [&](const char* buf) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint16_t h0, l0, h1, l1;
-                split_bf16(v[2 * i], h0, l0);
-                split_bf16(v[2 * i + 1], h1, l1);
-                hi[i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-                lo[i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa_hi[2], fa_lo[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* ap = buf + (32 * wm + 16 * i + r16) * kRowB + 64 * kk + 16 * kg;
+                fa_hi[i] = *reinterpret_cast<const bf16x8*>(ap);
+                fa_lo[i] = *reinterpret_cast<const bf16x8*>(ap + kMatB);
+                fb[i] = *reinterpret_cast<const bf16x8*>(buf + 2 * kMatB + (32 * wn + 16 * i + r16) * kRowB + 64 * kk + 16 * kg);
             }
-            *reinterpret_cast<u32x4*>(Ahi + srow * kLdsRow + 16 * skc) = hi;
-            *reinterpret_cast<u32x4*>(Alo + srow * kLdsRow + 16 * skc) = lo;
-            *reinterpret_cast<u32x4*>(Bs + srow * kLdsRow + 16 * skc) = bw;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_lo[i], fb[j], acc[i][j], 0, 0, 0);
+                }
         }
+    };
+
+    // stage s: LDS buf[s&1] holds it; register set (s+1)&1 holds stage s+1 in flight;
+    // register set s&1 is free and receives stage s+2.
+    for (int s = 0; s < ns; s += 2) {
+        if (s + 2 < ns) stage_load(st[0], xa, wb, 64 * (s + 2));
+        compute(lds);
+        if (s + 1 < ns) stage_store(st[1], lds + kBufB, srow, skq);
         __syncthreads();
-        if (ks + 1 < nk) {
-            a0 = *reinterpret_cast<const float4*>(xa + 32 * (ks + 1));
-            a1 = *reinterpret_cast<const float4*>(xa + 32 * (ks + 1) + 4);
-            bw = *reinterpret_cast<const u32x4*>(wb + 32 * (ks + 1));
-        }
-        bf16x8 fa_hi[2], fa_lo[2], fb[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ar = 32 * wm + 16 * i + r16;
-            fa_hi[i] = *reinterpret_cast<const bf16x8*>(Ahi + ar * kLdsRow + 16 * kg);
-            fa_lo[i] = *reinterpret_cast<const bf16x8*>(Alo + ar * kLdsRow + 16 * kg);
-            const int br = 32 * wn + 16 * i + r16;
-            fb[i] = *reinterpret_cast<const bf16x8*>(Bs + br * kLdsRow + 16 * kg);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[i], fb[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_lo[i], fb[j], acc[i][j], 0, 0, 0);
-            }
+        if (s + 1 >= ns) break;
+        if (s + 3 < ns) stage_load(st[1], xa, wb, 64 * (s + 3));
+        compute(lds + kBufB);
+        if (s + 2 < ns) stage_store(st[0], lds, srow, skq);
+        __syncthreads();
     }
 
     // epilogue: bias, activation, packed-row store.  C layout: col = lane & 15, rows 4*kg + j.
@@ -132,12 +164,18 @@ extern "C" int hicom_readout_gemm_fwd(const float* x, const void* w, const void*
                                       void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group,
                                       void* stream) {
     HICOM_REQUIRE(x && w && y, HICOM_EINVAL, "readout_gemm: NULL pointer");
-    HICOM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 32 == 0, HICOM_EINVAL, "readout_gemm: bad shape M=%d N=%d K=%d (K %% 32)", M, N, K);
+    HICOM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, HICOM_EINVAL, "readout_gemm: bad shape M=%d N=%d K=%d (K %% 64)", M, N, K);
     HICOM_REQUIRE(ldy >= N && row0 >= 0 && nl_group >= 0, HICOM_EINVAL, "readout_gemm: bad output layout");
     HICOM_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0), HICOM_EINVAL, "readout_gemm: alignment");
     GemmParams p{x, (const uint16_t*)w, b, b_dt == HICOM_DT_F32, M, N, K, act, y, y_dt == HICOM_DT_F32,
                  (long)ldy, (long)row0, nl_group};
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
-    hipLaunchKernelGGL(readout_gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(readout_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * kBufB);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(readout_gemm_kernel, grid, dim3(256), 2 * kBufB, (hipStream_t)stream, p);
     return hicom_host::check_launch("readout_gemm");
 }

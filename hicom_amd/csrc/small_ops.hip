@@ -103,33 +103,99 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(LinearParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// qt[q*nh + h, c] = scale * sum_j w_k[h*hd + j, c] * qp[q, h*hd + j]      (hd = E / nh)
-// thread per output channel c (coalesced w_k rows), QB queries per pass held in registers.
+// Query fold.  For head h (hd = E / nh rows of k_proj) and query q:
+//   qt[q*nh + h, c]    = scale * sum_j w_k[h*hd + j, c] * qp[q, h*hd + j]          c in [0, E)
+//   pos_a[q*nh + h, p] = scale * sum_j kpe[h*hd + j, p] * qp[q, h*hd + j]          p in [0, P)
+// where kpe = w_k . PE^T is a weight-only constant cached by the caller, so the score-side
+// positional table qt . PE^T needs no second pass over qt.  qt is emitted as fp32 (optional)
+// and as the bf16 hi/lo pair the MFMA stream kernel consumes.
+// 256 threads = 4 j-groups x 64 lanes; lane owns 2 adjacent w_k columns (one 4-byte load per j)
+// or 1 kpe column; partial sums of the 4 j-groups meet in LDS.
 // ---------------------------------------------------------------------------------------------
+struct FoldParams {
+    const float* qp;
+    const uint16_t* wk;
+    const float* kpe;
+    int nq, nh, E, P;
+    float scale;
+    float* qt;
+    uint16_t* qhi;
+    uint16_t* qlo;
+    float* pos_a;
+    int pos_stride;
+    int nbE;
+};
+
 template <int QB>
-__global__ __launch_bounds__(128) void fold_query_kernel(const float* qp, const uint16_t* wk, int nq, int nh, int E,
-                                                         float scale, float* qt) {
-    const int c = blockIdx.x * 128 + threadIdx.x;
+__global__ __launch_bounds__(256) void fold_query_kernel(FoldParams p) {
+    const int tid = threadIdx.x, jg = tid >> 6, cl = tid & 63;
     const int h = blockIdx.y, q0 = blockIdx.z * QB;
-    const int hd = E / nh;
-    __shared__ float qs[QB][128];   // hd <= 128
-    for (int i = threadIdx.x; i < QB * hd; i += 128) {
+    const int hd = p.E / p.nh, jn = (hd + 3) / 4;
+    __shared__ float qs[QB][128];          // hd <= 128
+    __shared__ float red[4][QB][128];
+    for (int i = tid; i < QB * hd; i += 256) {
         const int q = i / hd, j = i - q * hd;
-        qs[q][j] = (q0 + q < nq) ? qp[(long)(q0 + q) * E + h * hd + j] : 0.f;
+        qs[q][j] = (q0 + q < p.nq) ? p.qp[(long)(q0 + q) * p.E + h * hd + j] : 0.f;
     }
     __syncthreads();
-    if (c >= E) return;
-    float acc[QB];
+    const bool is_w = (int)blockIdx.x < p.nbE;
+    float a0[QB], a1[QB];
 #pragma unroll
-    for (int q = 0; q < QB; ++q) acc[q] = 0.f;
-    for (int j = 0; j < hd; ++j) {
-        const float w = bf16_to_f32(wk[(long)(h * hd + j) * E + c]);
+    for (int q = 0; q < QB; ++q) a0[q] = a1[q] = 0.f;
+    const int j0 = jg * jn, j1 = min(hd, j0 + jn);
+    if (is_w) {
+        const int c = blockIdx.x * 128 + 2 * cl;
+        if (c < p.E) {
+#pragma unroll 8
+            for (int j = j0; j < j1; ++j) {
+                const uint32_t w2 = *reinterpret_cast<const uint32_t*>(p.wk + (long)(h * hd + j) * p.E + c);
+                const float w0 = bf16lo_to_f32(w2), w1 = bf16hi_to_f32(w2);
 #pragma unroll
-        for (int q = 0; q < QB; ++q) acc[q] = fmaf(w, qs[q][j], acc[q]);
+                for (int q = 0; q < QB; ++q) {
+                    a0[q] = fmaf(w0, qs[q][j], a0[q]);
+                    a1[q] = fmaf(w1, qs[q][j], a1[q]);
+                }
+            }
+        }
+    } else {
+        const int pc = (blockIdx.x - p.nbE) * 64 + cl;
+        if (pc < p.P) {
+#pragma unroll 8
+            for (int j = j0; j < j1; ++j) {
+                const float w0 = p.kpe[(long)(h * hd + j) * p.P + pc];
+#pragma unroll
+                for (int q = 0; q < QB; ++q) a0[q] = fmaf(w0, qs[q][j], a0[q]);
+            }
+        }
     }
 #pragma unroll
-    for (int q = 0; q < QB; ++q)
-        if (q0 + q < nq) qt[((long)(q0 + q) * nh + h) * E + c] = acc[q] * scale;
+    for (int q = 0; q < QB; ++q) {
+        red[jg][q][2 * cl] = a0[q];
+        red[jg][q][2 * cl + 1] = a1[q];
+    }
+    __syncthreads();
+    // 256 threads finish QB x 128 outputs
+    for (int o = tid; o < QB * 128; o += 256) {
+        const int q = o >> 7, i = o & 127;
+        if (q0 + q >= p.nq) continue;
+        const float v = ((red[0][q][i] + red[1][q][i]) + (red[2][q][i] + red[3][q][i])) * p.scale;
+        const long row = (long)(q0 + q) * p.nh + h;
+        if (is_w) {
+            const int c = blockIdx.x * 128 + i;
+            if (c < p.E) {
+                if (p.qt) p.qt[row * p.E + c] = v;
+                if (p.qhi) {
+                    uint16_t hi, lo;
+                    split_bf16(v, hi, lo);
+                    p.qhi[row * p.E + c] = hi;
+                    p.qlo[row * p.E + c] = lo;
+                }
+            }
+        } else if ((i & 1) == 0) {
+            const int pc = (blockIdx.x - p.nbE) * 64 + (i >> 1);
+            if (pc < p.P) p.pos_a[row * p.pos_stride + pc] = v;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* x, int rows, int rows_pad, int E,
@@ -179,15 +245,30 @@ extern "C" int hicom_linear_fwd(const void* x, int32_t x_dt, const void* w, int3
     return hicom_host::check_launch("linear");
 }
 
+static int launch_fold(const float* qp, const void* w_k, const float* kpe, int nq, int nh, int E, int P, float scale,
+                       float* qt, void* hi, void* lo, float* pos_a, int pos_stride, void* stream) {
+    constexpr int QB = 8;
+    FoldParams p{qp, (const uint16_t*)w_k, kpe, nq, nh, E, kpe ? P : 0, scale, qt, (uint16_t*)hi, (uint16_t*)lo,
+                 pos_a, pos_stride, (E + 127) / 128};
+    dim3 grid((unsigned)(p.nbE + (p.P + 63) / 64), (unsigned)nh, (unsigned)((nq + QB - 1) / QB));
+    hipLaunchKernelGGL(fold_query_kernel<QB>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return hicom_host::check_launch("fold_query");
+}
+
 extern "C" int hicom_fold_query_fwd(const float* qp, const void* w_k, int32_t nq, int32_t nh, int32_t E,
                                     float scale, float* qt, void* stream) {
     HICOM_REQUIRE(qp && w_k && qt, HICOM_EINVAL, "fold_query: NULL pointer");
-    HICOM_REQUIRE(nq > 0 && nh > 0 && E > 0 && E % nh == 0 && E / nh <= 128, HICOM_EINVAL, "fold_query: bad shape");
-    constexpr int QB = 8;
-    dim3 grid((unsigned)((E + 127) / 128), (unsigned)nh, (unsigned)((nq + QB - 1) / QB));
-    hipLaunchKernelGGL(fold_query_kernel<QB>, grid, dim3(128), 0, (hipStream_t)stream, qp, (const uint16_t*)w_k, nq, nh, E,
-                       scale, qt);
-    return hicom_host::check_launch("fold_query");
+    HICOM_REQUIRE(nq > 0 && nh > 0 && E > 0 && E % nh == 0 && E / nh <= 128 && E % 2 == 0, HICOM_EINVAL, "fold_query: bad shape");
+    return launch_fold(qp, w_k, nullptr, nq, nh, E, 0, scale, qt, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int hicom_fold_query_split_fwd(const float* qp, const void* w_k, const float* kpe, int32_t nq, int32_t nh,
+                                          int32_t E, int32_t P, float scale, void* qt_hi, void* qt_lo,
+                                          float* pos_a, int32_t pos_stride, void* stream) {
+    HICOM_REQUIRE(qp && w_k && qt_hi && qt_lo, HICOM_EINVAL, "fold_query_split: NULL pointer");
+    HICOM_REQUIRE(nq > 0 && nh > 0 && E > 0 && E % nh == 0 && E / nh <= 128 && E % 2 == 0, HICOM_EINVAL, "fold_query_split: bad shape");
+    HICOM_REQUIRE(!kpe || (pos_a && P > 0 && pos_stride >= P), HICOM_EINVAL, "fold_query_split: positional outputs");
+    return launch_fold(qp, w_k, kpe, nq, nh, E, P, scale, nullptr, qt_hi, qt_lo, pos_a, pos_stride, stream);
 }
 
 extern "C" int hicom_split_bf16_fwd(const float* x, int32_t rows, int32_t rows_pad, int32_t E,

@@ -52,26 +52,44 @@ class FrameShardPlan:
 def exchange(state: torch.Tensor, local_tokens: torch.Tensor, group=None):
     """All-gathers (state f32 [S], local tokens [Nw_rank, H]) of every rank with ONE collective.
 
-    Returns (states [world, S] f32, tokens [world * Nw_rank, H]) in rank order = frame order."""
+    Returns (states [world, S] f32, tokens [world * Nw_rank, H]) in rank order = frame order.
+    (Copying reference form used by the CPU/gloo test; the HIP path below gathers a pre-packed
+    send buffer that the kernels wrote in place.)"""
     world = dist.get_world_size(group)
-    s_bytes = state.numel() * 4
-    t_bytes = local_tokens.numel() * local_tokens.element_size()
-    pad = (-s_bytes) % 16
-    mine = torch.empty(s_bytes + pad + t_bytes, dtype=torch.uint8, device=state.device)
+    mine, s_bytes, pad = pack_buffer(state.numel(), local_tokens.shape, local_tokens.dtype, state.device)
     mine[:s_bytes].view(torch.float32).copy_(state.reshape(-1))
     mine[s_bytes + pad:].view(local_tokens.dtype).copy_(local_tokens.reshape(-1))
-    flat = torch.empty(world * mine.numel(), dtype=torch.uint8, device=state.device)
-    dist.all_gather_into_tensor(flat, mine, group=group)      # rank-major concatenation
-    everyone = flat.view(world, mine.numel())
+    everyone = gather_buffers(mine, group)
     states = everyone[:, :s_bytes].contiguous().view(torch.float32).view(world, -1)
     tokens = everyone[:, s_bytes + pad:].contiguous().view(local_tokens.dtype).view(world * local_tokens.shape[0], -1)
     return states, tokens
 
 
+def pack_buffer(state_floats: int, token_shape, token_dtype, device):
+    """Per-rank send buffer [state f32 | pad to 16 B | local tokens]; returns (buffer, state bytes, pad)."""
+    s_bytes = state_floats * 4
+    pad = (-s_bytes) % 16
+    t_bytes = token_shape[0] * token_shape[1] * torch.empty((), dtype=token_dtype).element_size()
+    tail = (-(s_bytes + pad + t_bytes)) % 16
+    return torch.empty(s_bytes + pad + t_bytes + tail, dtype=torch.uint8, device=device), s_bytes, pad
+
+
+def gather_buffers(mine: torch.Tensor, group=None) -> torch.Tensor:
+    world = dist.get_world_size(group)
+    flat = torch.empty(world * mine.numel(), dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(flat, mine, group=group)      # rank-major concatenation
+    return flat.view(world, mine.numel())
+
+
 def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: int,
                     image_newline: Optional[torch.Tensor] = None, group=None) -> torch.Tensor:
     """HIComProjector.forward for modal='video' with the frames split evenly over the ranks of
-    `group`; every rank passes ITS frames and receives the full [n_tok, hidden] result."""
+    `group`; every rank passes ITS frames and receives the full [n_tok, hidden] result.
+
+    STREAM phase of the native executor writes this rank's local tokens and global softmax state
+    straight into the send buffer; one RCCL all-gather; FINISH phase combines the states and writes
+    the global rows; one row-scatter places the gathered local tokens."""
+    from . import engine
     from . import native as nv
     from .projector import _out_dtype
     lc, gc = projector.local_compressor, projector.global_compressor
@@ -83,30 +101,35 @@ def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: in
     if ff_shard.shape[0] != t1 - t0:
         raise ValueError(f"rank {rank} must hold frames [{t0},{t1})")
     dev = ff_shard.device
+    ff_shard = ff_shard.contiguous()
+    fe_shard = fe_shard.contiguous() if fe_shard is not None else None
+    T, H, W, E = ff_shard.shape
     hidden = lc.readout[2].out_features
     odt = _out_dtype(projector)
-    # local tokens of this shard (unpacked; packing happens after the gather)
-    ctx, grid = lc.window_context(ff_shard, fe_shard, guide_embed, "video",
-                                  projector.local_logit_scale, projector.local_logit_bias)
-    loc = torch.empty((ctx.shape[0], hidden), dtype=odt, device=dev)
-    lc.readout_into(ctx, loc, 0, 0)
-    # global online-softmax state of this shard
-    gc._check_native(projector.global_logit_scale)
+    at, ay, ax = lc.tilings(T, H, W, "video")
+    nw = at.nwin * ay.nwin * ax.nwin
     q_in, n_rows = gc.injected_queries(guide_embed)
-    ml, acc, _ = gc.partial_context(ff_shard, q_in, t_offset=t0)
-    R, E = acc.shape
-    state = torch.cat([ml.reshape(-1), acc.reshape(-1)])
-    states, tokens = exchange(state, loc, group)
-    ml_sets = states[:, :2 * R].contiguous().view(world, R, 2)
-    acc_sets = states[:, 2 * R:].contiguous().view(world, R, E)
-    lay = projector._layout((grid[0] * world, grid[1], grid[2]), "video", image_newline is not None, False)
+    R = q_in.shape[0] * gc.attn_layer.num_heads
+    mine, s_bytes, pad = pack_buffer(2 * R + R * E, (nw, hidden), odt, dev)
+    lay = projector._layout((at.nwin * world, ay.nwin, ax.nwin), "video", image_newline is not None, False)
     out = torch.empty((lay.n_rows + n_rows, hidden), dtype=odt, device=dev)
-    if lay.n_rows == lay.n_tokens:
-        out[:lay.n_tokens].copy_(tokens)
-    else:
-        nv.scatter_rows(tokens, out, 0, lay.n_tokens, nl_group=lay.nl_group)
+    a = engine.build_args(projector, ff_shard, fe_shard, guide_embed, "video", None, out, None, t_offset=t0,
+                          phases=nv.PHASE_STREAM, local_out=mine[s_bytes + pad:], state_out=mine[:s_bytes],
+                          global_row0=lay.n_rows)
+    engine.attach_execution(a, dev, key_extra=("shard",))
+    nv.compressor_fwd(a)
+    everyone = gather_buffers(mine, group)
+    a.phases = nv.PHASE_FINISH
+    a.state_sets, a.nsets, a.state_set_stride = everyone.data_ptr(), world, mine.numel() // 4
+    nv.compressor_fwd(a)
+    tokens = everyone[:, s_bytes + pad:]
+    # gathered local tokens -> packed rows (one strided row-scatter per rank block keeps this a kernel)
+    for r in range(world):
+        blk = tokens[r, :nw * hidden * out.element_size()].view(odt).view(nw, hidden)
+        m0 = r * nw                   # shard boundaries coincide with newline-group boundaries
+        nv.scatter_rows(blk, out, m0 + (m0 // lay.nl_group if lay.nl_group else 0), nw, nl_group=lay.nl_group)
+    if lay.newline_rows:
         first = lay.newline_rows[0]
         step = lay.newline_rows[1] - first if len(lay.newline_rows) > 1 else 1
         nv.scatter_rows(image_newline.contiguous().view(1, -1), out, first, len(lay.newline_rows), row_step=step)
-    gc.finish(ml_sets, acc_sets, q_in, out, lay.n_rows, n_rows)
     return out

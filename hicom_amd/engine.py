@@ -1,0 +1,168 @@
+"""Host side of the native executor (hicom_compressor_fwd): fills `hicom_compressor_args` from a
+HIComProjector and its inputs, and owns the per-shape workspace, the side stream and the two
+fork/join events.  All compute happens in libhicom_hip.so; torch is used for device memory,
+streams and events only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import native as nv
+
+
+class _DeviceResources:
+    def __init__(self, device):
+        self.side = torch.cuda.Stream(device=device)
+        self.ev_fork = torch.cuda.Event()
+        self.ev_join = torch.cuda.Event()
+        # hipEventRecord needs created events: torch creates them lazily on first record
+        cur = torch.cuda.current_stream(device)
+        self.ev_fork.record(cur)
+        self.ev_join.record(cur)
+
+
+_RES: Dict[int, _DeviceResources] = {}
+_WS: Dict[Tuple, torch.Tensor] = {}
+
+
+def _resources(device) -> _DeviceResources:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _RES:
+        _RES[idx] = _DeviceResources(device)
+    return _RES[idx]
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _w(lin) -> Tuple[int, Optional[int]]:
+    w = lin.weight
+    if not w.is_cuda or w.dtype != torch.bfloat16:
+        raise NotImplementedError("hicom_amd: projector weights must be bfloat16 on the GPU "
+                                  "(cast the projector with .to(torch.bfloat16).cuda())")
+    return w.data_ptr(), (lin.bias.data_ptr() if lin.bias is not None else None)
+
+
+def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, t_offset=0,
+               phases=nv.PHASE_STREAM | nv.PHASE_FINISH, local_out=None, state_out=None,
+               state_sets=None, state_set_stride=0, nsets=0, global_row0=None) -> nv.CompressorArgs:
+    from .projector import _require_bf16_cuda
+    lc, gc = proj.local_compressor, proj.global_compressor
+    a = nv.CompressorArgs()
+    _require_bf16_cuda("frames_feature", ff)
+    T, H, W, E = ff.shape
+    a.ff, a.T, a.H, a.W, a.E = ff.data_ptr(), T, H, W, E
+    a.fe = None
+    a.phases = phases
+    a.has_local, a.has_global = int(lc is not None), int(gc is not None)
+    a.hidden = (lc or gc).readout[2].out_features
+    keep = [ff]
+    if lc is not None:
+        lc._check_native()
+        if fe is not None:
+            _require_bf16_cuda("frames_embed", fe)
+            if fe.shape != ff.shape:
+                raise ValueError("frames_embed must have the shape of frames_feature")
+            a.fe = fe.data_ptr()
+            keep.append(fe)
+        at, ay, ax = lc.tilings(T, H, W, modal)
+        a.at, a.ay, a.ax = (nv.Axis(t.n, t.k, t.nwin, t.nfull) for t in (at, ay, ax))
+        ls, lb = proj.local_logit_scale, proj.local_logit_bias
+        a.l2norm = 0
+        if ls is not None:                                            # ref :527-529, :549
+            a.l_scale, a.l_bias = float(torch.exp(ls.float())), float(lb)
+            if fe is not None:
+                a.l2norm = 1 | (2 if lc.use_guide == "direct" else 0)
+        else:
+            a.l_scale, a.l_bias = 1.0 / math.sqrt(lc.qk_dim), 0.0      # ref :551
+        if lc.use_guide == "direct":
+            g = guide_embed.contiguous()
+            _require_bf16_cuda("guide_embed", g)
+            if g.ndim != 1 or g.shape[0] != E:
+                raise ValueError("direct guide injection takes a [D] guide embedding")
+            a.lq, a.lq_dt, a.lq_stride = g.data_ptr(), nv.DT_BF16, 0
+            keep.append(g)
+        else:
+            a.lq = None                                               # pooled per-window query, made natively
+        a.lw0, a.lb0 = _w(lc.readout[0])
+        a.lw2, a.lb2 = _w(lc.readout[2])
+    if gc is not None:
+        gc._check_native(proj.global_logit_scale)
+        q_in, n_rows = gc.injected_queries(guide_embed)
+        keep.append(q_in)
+        att = gc.attn_layer
+        a.gq, a.nq, a.nh, a.n_global_rows = q_in.data_ptr(), q_in.shape[0], att.num_heads, n_rows
+        a.wq, a.bq = _w(att.q_proj)
+        a.wk, _ = _w(att.k_proj)
+        a.wv, a.bv = _w(att.v_proj)
+        a.wo, a.bo = _w(att.out_proj)
+        a.gw0, a.gb0 = _w(gc.readout[0])
+        a.gw2, a.gb2 = _w(gc.readout[2])
+        if gc.use_pos_emb:
+            pe, kpe, cap = gc.pos_and_kpe(t_offset + T, H, W, ff.device)
+            a.pe, a.kpe, a.P = pe.data_ptr(), kpe.data_ptr(), pe.shape[0]
+            a.t_index0, a.y_index0, a.x_index0 = t_offset, cap, cap + H
+            keep += [pe, kpe]
+        else:
+            a.pe = a.kpe = None
+            a.P = 0
+    a.out, a.out_dt, a.ldo = out.data_ptr(), nv._dt(out), out.shape[-1]
+    a.local_row0 = 0
+    a.nl_group = layout.nl_group if layout is not None else 0
+    a.global_row0 = global_row0 if global_row0 is not None else (layout.n_rows if layout is not None else 0)
+    a.nl_count = 0
+    if layout is not None and layout.newline_rows:
+        nl = image_newline.contiguous()
+        keep.append(nl)
+        a.newline, a.newline_dt = nl.data_ptr(), nv._dt(nl)
+        a.nl_first = layout.newline_rows[0]
+        a.nl_step = layout.newline_rows[1] - layout.newline_rows[0] if len(layout.newline_rows) > 1 else 1
+        a.nl_count = len(layout.newline_rows)
+    a.local_out, a.state_out = _p(local_out), _p(state_out)
+    a.state_sets, a.state_set_stride, a.nsets = _p(state_sets), state_set_stride, nsets
+    a._keep = keep                      # keeps borrowed tensors alive until the call is enqueued
+    return a
+
+
+def attach_execution(a: nv.CompressorArgs, device, key_extra=()):
+    """Workspace (zero-prefixed once, cached per problem shape) + streams/events."""
+    res = _resources(device)
+    total, prefix = nv.compressor_workspace(a)
+    key = (device.index, a.T, a.H, a.W, a.E, a.hidden, a.nq, a.P, a.has_local, a.has_global,
+           a.at.nwin, a.ay.nwin, a.ax.nwin, bool(a.lq), *key_extra)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < total:
+        ws = torch.empty(total, dtype=torch.uint8, device=device)
+        ws[:prefix].zero_()
+        _WS[key] = ws
+    a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+    a.stream_main = torch.cuda.current_stream(device).cuda_stream
+    a.stream_side = res.side.cuda_stream
+    a.ev_fork, a.ev_join = res.ev_fork.cuda_event, res.ev_join.cuda_event
+    return a
+
+
+def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype) -> torch.Tensor:
+    """HIComProjector.forward for a dense [T,H,W,E] input through hicom_compressor_fwd."""
+    lc, gc = proj.local_compressor, proj.global_compressor
+    ff = ff.contiguous()
+    fe = fe.contiguous() if fe is not None else None
+    T, H, W, _ = ff.shape
+    layout = None
+    n_local = 0
+    if lc is not None:
+        at, ay, ax = lc.tilings(T, H, W, modal)
+        layout = proj._layout((at.nwin, ay.nwin, ax.nwin), modal, image_newline is not None, False)
+        n_local = layout.n_rows
+    n_global = gc.num_queries if gc is not None else 0
+    hidden = (lc or gc).readout[2].out_features
+    out = torch.empty((n_local + n_global, hidden), dtype=out_dtype, device=ff.device)
+    a = build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, global_row0=n_local)
+    attach_execution(a, ff.device)
+    nv.compressor_fwd(a)
+    return out

@@ -23,8 +23,12 @@ EXPORTS = (
     "hicom_abi_version", "hicom_last_error", "hicom_local_attn_fwd", "hicom_trilinear_pool_fwd",
     "hicom_linear_fwd", "hicom_fold_query_fwd", "hicom_split_bf16_fwd", "hicom_global_stream_fwd",
     "hicom_global_stream_nparts", "hicom_global_merge_fwd", "hicom_global_combine_fwd",
-    "hicom_readout_gemm_fwd", "hicom_scatter_rows_fwd",
+    "hicom_readout_gemm_fwd", "hicom_scatter_rows_fwd", "hicom_fold_query_split_fwd",
+    "hicom_global_combine_strided_fwd", "hicom_compressor_workspace_bytes", "hicom_compressor_zero_prefix_bytes",
+    "hicom_compressor_fwd",
 )
+
+PHASE_STREAM, PHASE_FINISH = 1, 2
 
 
 class HicomNativeError(RuntimeError):
@@ -34,6 +38,33 @@ class HicomNativeError(RuntimeError):
 class Axis(C.Structure):
     """hicom_axis: one axis of the window tiling (include/hicom_hip.h)."""
     _fields_ = [("n", C.c_int32), ("k", C.c_int32), ("nwin", C.c_int32), ("nfull", C.c_int32)]
+
+
+class CompressorArgs(C.Structure):
+    """hicom_compressor_args (include/hicom_hip.h) -- field order and types must match the header."""
+    _fields_ = [
+        ("ff", C.c_void_p), ("fe", C.c_void_p),
+        ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("E", C.c_int32),
+        ("has_local", C.c_int32), ("has_global", C.c_int32), ("phases", C.c_int32), ("hidden", C.c_int32),
+        ("at", Axis), ("ay", Axis), ("ax", Axis),
+        ("lq", C.c_void_p), ("lq_dt", C.c_int32), ("l2norm", C.c_int32), ("lq_stride", C.c_int64),
+        ("l_scale", C.c_float), ("l_bias", C.c_float),
+        ("lw0", C.c_void_p), ("lb0", C.c_void_p), ("lw2", C.c_void_p), ("lb2", C.c_void_p),
+        ("gq", C.c_void_p), ("nq", C.c_int32), ("nh", C.c_int32), ("n_global_rows", C.c_int32), ("P", C.c_int32),
+        ("wq", C.c_void_p), ("bq", C.c_void_p), ("wk", C.c_void_p), ("wv", C.c_void_p), ("bv", C.c_void_p),
+        ("wo", C.c_void_p), ("bo", C.c_void_p),
+        ("gw0", C.c_void_p), ("gb0", C.c_void_p), ("gw2", C.c_void_p), ("gb2", C.c_void_p),
+        ("pe", C.c_void_p), ("kpe", C.c_void_p),
+        ("t_index0", C.c_int32), ("y_index0", C.c_int32), ("x_index0", C.c_int32), ("nsets", C.c_int32),
+        ("out", C.c_void_p), ("out_dt", C.c_int32), ("nl_group", C.c_int32),
+        ("ldo", C.c_int64), ("local_row0", C.c_int64), ("global_row0", C.c_int64),
+        ("newline", C.c_void_p), ("newline_dt", C.c_int32), ("nl_count", C.c_int32),
+        ("nl_first", C.c_int64), ("nl_step", C.c_int64),
+        ("local_out", C.c_void_p), ("state_out", C.c_void_p), ("state_sets", C.c_void_p),
+        ("state_set_stride", C.c_int64),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+        ("stream_main", C.c_void_p), ("stream_side", C.c_void_p), ("ev_fork", C.c_void_p), ("ev_join", C.c_void_p),
+    ]
 
 
 _LIB: Optional[C.CDLL] = None
@@ -61,16 +92,24 @@ def lib() -> C.CDLL:
     L.hicom_linear_fwd.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.hicom_fold_query_fwd.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp]
     L.hicom_split_bf16_fwd.argtypes = [vp, i32, i32, i32, vp, vp, vp]
-    L.hicom_global_stream_fwd.argtypes = [vp, i64, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i64,
+    L.hicom_global_stream_fwd.argtypes = [vp, i64, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i64,
                                           vp, vp, vp, i32, vp]
     L.hicom_global_stream_nparts.argtypes = [i64, i32]
     L.hicom_global_merge_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, i64, i64, i32, i32, vp, i32, i32, i32,
-                                         vp, vp, vp, vp]
+                                         vp, vp, vp, i32, vp]
+    L.hicom_fold_query_split_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, i32, vp]
+    L.hicom_global_combine_strided_fwd.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
+    ap = C.POINTER(CompressorArgs)
+    L.hicom_compressor_workspace_bytes.argtypes = [ap]
+    L.hicom_compressor_zero_prefix_bytes.argtypes = [ap]
+    L.hicom_compressor_fwd.argtypes = [ap]
     L.hicom_global_combine_fwd.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     L.hicom_readout_gemm_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i64, i64, i32, vp]
     L.hicom_scatter_rows_fwd.argtypes = [vp, i32, i32, i32, vp, i32, i64, i64, i64, i32, i32, vp]
     for name in EXPORTS[2:]:
         getattr(L, name).restype = C.c_int
+    L.hicom_compressor_workspace_bytes.restype = C.c_int64
+    L.hicom_compressor_zero_prefix_bytes.restype = C.c_int64
     _LIB = L
     return L
 
@@ -144,22 +183,25 @@ def global_stream_nparts(N, rows_pad) -> int:
     return n
 
 
-def global_stream(x, N, qhi, qlo, pos_a, H, W, t0i, y0i, x0i, scores, part_m, part_l, part_acc):
+def global_stream(x, N, qhi, qlo, pos_a, H, W, t0i, y0i, x0i, scores, part_m, part_l, part_acc, rows=None):
     E = x.shape[-1]
     rows_pad = qhi.shape[0]
+    rows = rows_pad if rows is None else rows
     nparts = part_m.shape[0]
-    _check(lib().hicom_global_stream_fwd(_ptr(x), N, E, _ptr(qhi), _ptr(qlo), rows_pad, _ptr(pos_a),
+    _check(lib().hicom_global_stream_fwd(_ptr(x), N, E, _ptr(qhi), _ptr(qlo), rows, rows_pad, _ptr(pos_a),
                                          pos_a.shape[1] if pos_a is not None else 0, H, W, t0i, y0i, x0i,
                                          _ptr(scores), scores.shape[1], _ptr(part_m), _ptr(part_l), _ptr(part_acc),
                                          nparts, _stream()), "hicom_global_stream_fwd")
 
 
-def global_merge(part_m, part_l, part_acc, rows, scores, N, H, W, pe, t0i, y0i, x0i, scratch, out_ml, out_acc):
+def global_merge(part_m, part_l, part_acc, rows, scores, N, H, W, pe, t0i, y0i, x0i, scratch, out_ml, out_acc,
+                 normalize=False):
     nparts, rows_pad = part_m.shape
     E = part_acc.shape[-1]
     _check(lib().hicom_global_merge_fwd(_ptr(part_m), _ptr(part_l), _ptr(part_acc), nparts, rows, rows_pad, E,
                                         _ptr(scores), scores.shape[1], N, H, W, _ptr(pe), t0i, y0i, x0i,
-                                        _ptr(scratch), _ptr(out_ml), _ptr(out_acc), _stream()), "hicom_global_merge_fwd")
+                                        _ptr(scratch), _ptr(out_ml), _ptr(out_acc), int(normalize), _stream()),
+           "hicom_global_merge_fwd")
 
 
 def global_combine(ml, acc, ctx):
@@ -179,3 +221,28 @@ def scatter_rows(src, dst, row0, count, row_step=1, nl_group=0):
     src2 = src.reshape(-1, src.shape[-1])
     _check(lib().hicom_scatter_rows_fwd(_ptr(src2), _dt(src2), src2.shape[0], src2.shape[1], _ptr(dst), _dt(dst),
                                         dst.shape[-1], row0, row_step, nl_group, count, _stream()), "hicom_scatter_rows_fwd")
+
+
+def fold_query_split(qp, w_k, kpe, nh, scale, qhi, qlo, pos_a):
+    nq, E = qp.shape
+    P = kpe.shape[1] if kpe is not None else 0
+    _check(lib().hicom_fold_query_split_fwd(_ptr(qp), _ptr(w_k), _ptr(kpe), nq, nh, E, P, scale, _ptr(qhi), _ptr(qlo),
+                                            _ptr(pos_a), pos_a.shape[1] if pos_a is not None else 0, _stream()),
+           "hicom_fold_query_split_fwd")
+
+
+def global_combine_strided(ml, acc, set_stride, nsets, rows, E, ctx):
+    _check(lib().hicom_global_combine_strided_fwd(_ptr(ml), _ptr(acc), set_stride, nsets, rows, E, _ptr(ctx), _stream()),
+           "hicom_global_combine_strided_fwd")
+
+
+def compressor_workspace(args: CompressorArgs):
+    L = lib()
+    total, prefix = L.hicom_compressor_workspace_bytes(C.byref(args)), L.hicom_compressor_zero_prefix_bytes(C.byref(args))
+    if total <= 0 or prefix < 0:
+        raise HicomNativeError("hicom_compressor_workspace_bytes: bad arguments")
+    return total, prefix
+
+
+def compressor_fwd(args: CompressorArgs):
+    _check(lib().hicom_compressor_fwd(C.byref(args)), "hicom_compressor_fwd")

@@ -261,6 +261,22 @@ class GlobalCompressor(nn.Module):
             self._pe_cache[key] = hit
         return hit
 
+    def pos_and_kpe(self, t_cap: int, H: int, W: int, device):
+        """(pe [P,E], kpe [E,P] = k_proj.weight . pe^T, cap).  kpe depends on the weights only and is
+        rebuilt when k_proj.weight is replaced or modified in place (tensor version counter)."""
+        pe, cap = self.pos_tables(t_cap, H, W, device)
+        wk = self.attn_layer.k_proj.weight
+        _require_bf16_cuda("k_proj.weight", wk)
+        key = ("kpe", H, W, cap, str(device))
+        stamp = (wk.data_ptr(), wk._version)
+        hit = self._pe_cache.get(key)
+        if hit is None or hit[1] != stamp:
+            kpe = _f32((self.embed_dim, pe.shape[0]), device)
+            nv.linear(wk.detach(), pe, None, kpe)
+            hit = (kpe, stamp)
+            self._pe_cache[key] = hit
+        return pe, hit[0], cap
+
     def _check_native(self, logit_scale):
         if self.use_guide not in _NATIVE_GUIDE_MODES:
             raise NotImplementedError(f"GlobalCompressor: use_guide={self.use_guide!r} has no HIP path yet "
@@ -317,9 +333,9 @@ class GlobalCompressor(nn.Module):
         scores = _f32((rows_pad, stride), dev)
         part_m, part_l = _f32((nparts, rows_pad), dev), _f32((nparts, rows_pad), dev)
         part_acc = _f32((nparts, rows_pad, E), dev)
-        nv.global_stream(ff, N, qhi, qlo, pos_a, H, W, t0i, y0i, x0i, scores, part_m, part_l, part_acc)
+        nv.global_stream(ff, N, qhi, qlo, pos_a, H, W, t0i, y0i, x0i, scores, part_m, part_l, part_acc, rows=R)
         ml, acc = _f32((R, 2), dev), _f32((R, E), dev)
-        scratch = _f32((R * T * (H + W + 1),), dev) if pe is not None else None
+        scratch = _f32((R * T * (H + W + 2),), dev) if pe is not None else None
         nv.global_merge(part_m, part_l, part_acc, R, scores, N, H, W, pe, t0i, y0i, x0i, scratch, ml, acc)
         return ml, acc, scores
 
@@ -382,6 +398,7 @@ class HIComProjector(nn.Module):
         assert local_compressor is not None or global_compressor is not None, \
             "At least one compressor should be provided."
         self.return_fp32 = False     # True: fp32 result (parity tests); default = weight dtype (bf16)
+        self.use_executor = True     # dense inputs go through the one-call native executor (engine.py)
 
     def set_clip_logits(self, local=None, glob=None):
         if local is not None:
@@ -395,6 +412,15 @@ class HIComProjector(nn.Module):
                                modal, grid[0], grid[1], grid[2], has_newline, is_anyres)
 
     def forward(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None):
+        if self.use_executor and not isinstance(frames_feature, dict):
+            from . import engine
+            return engine.run_dense(self, frames_feature, frames_embed, guide_embed, modal, image_newline,
+                                    _out_dtype(self))
+        return self.forward_stepwise(frames_feature, frames_embed, guide_embed, modal, image_newline)
+
+    def forward_stepwise(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None):
+        """Same result, one C-ABI call per operator (anyres dict inputs; also the cross-check of the
+        executor in the tests)."""
         lc, gc = self.local_compressor, self.global_compressor
         segments = []        # (ctx, layout) per local segment, in output order
         if lc is not None:

@@ -93,6 +93,16 @@ int hicom_linear_fwd(const void* x, int32_t x_dt, const void* w, int32_t w_dt,
 int hicom_fold_query_fwd(const float* qp, const void* w_k, int32_t nq, int32_t nh, int32_t E,
                          float scale, float* qt, void* stream);
 
+/* Fused form used on the hot path: emits qt directly as the bf16 hi/lo pair of the stream kernel
+ * and, when kpe != NULL, the score-side positional table
+ *   pos_a[(q*nh + h), p] = scale * sum_j kpe[h*hd + j, p] * qp[q, h*hd + j]  ( = qt . PE[p] )
+ * from kpe = w_k . PE^T (f32 [E, P]; depends on the weights only -- the caller caches it, the way
+ * the reference caches its pos_embed buffer, projector.py:603-607).  Rows >= nq*nh of qt_hi /
+ * qt_lo / pos_a are not written (callers keep them zero). */
+int hicom_fold_query_split_fwd(const float* qp, const void* w_k, const float* kpe, int32_t nq, int32_t nh,
+                               int32_t E, int32_t P, float scale, void* qt_hi, void* qt_lo,
+                               float* pos_a, int32_t pos_stride, void* stream);
+
 /* Split f32 rows into bf16 hi + lo parts (x ~= hi + lo to 2^-16), zero-padding the row count
  * to rows_pad: the MFMA operand format for fp32 intermediates (SURVEY.md §7 strategy B). */
 int hicom_split_bf16_fwd(const float* x, int32_t rows, int32_t rows_pad, int32_t E,
@@ -103,7 +113,7 @@ int hicom_split_bf16_fwd(const float* x, int32_t rows, int32_t rows_pad, int32_t
  * block of `rows_pad` folded queries (multiple of 16), the raw scores and the online-softmax
  * partial sums of attn . x.  Replaces projector.py:193-215 for K = V = x (pos-emb handled
  * separably: `pos_a` holds qt . PE for the t / y / x axes).
- *   qt_hi, qt_lo : bf16 [rows_pad, E]
+ *   qt_hi, qt_lo : bf16 [rows_pad, E]; rows >= `rows` are zero padding and produce no output
  *   pos_a        : f32 [rows_pad, pos_stride] or NULL; token (t,y,x) adds
  *                  pos_a[r, t_index0 + t] + pos_a[r, y_index0 + y] + pos_a[r, x_index0 + x]
  *   geometry     : token n -> t = n / (H*W), y = (n / W) % H, x = n % W  (n relative to n0 = 0
@@ -114,7 +124,7 @@ int hicom_split_bf16_fwd(const float* x, int32_t rows, int32_t rows_pad, int32_t
  *                  consumed by hicom_global_merge_fwd.
  */
 int hicom_global_stream_fwd(const void* x, int64_t N, int32_t E,
-                            const void* qt_hi, const void* qt_lo, int32_t rows_pad,
+                            const void* qt_hi, const void* qt_lo, int32_t rows, int32_t rows_pad,
                             const float* pos_a, int32_t pos_stride,
                             int32_t H, int32_t W, int32_t t_index0, int32_t y_index0, int32_t x_index0,
                             float* scores, int64_t score_stride,
@@ -128,13 +138,14 @@ int hicom_global_stream_nparts(int64_t N, int32_t rows_pad);
  * out_acc[r,:] = sum_p e^(m_p - M_r) acc_p[r,:] + sum_n e^(s_n - M_r) pos(n)   (un-normalised)
  * out_ml[r]   = (M_r, L_r).  pos(n) = pe[t_index0+t] + pe[y_index0+y] + pe[x_index0+x] with
  * pe f32 [*, E] the per-axis sinusoid tables (projector.py:57-101), or NULL for no pos-emb.
- * scratch: f32 [rows * (T*(H+W+1))] work area.  T = N / (H*W). */
+ * scratch: f32 [rows * T * (H+W+2)] work area.  T = N / (H*W).  normalize != 0 divides by L_r
+ * (single-shard case: out_acc is then the final context and no combine is needed). */
 int hicom_global_merge_fwd(const float* part_m, const float* part_l, const float* part_acc,
                            int32_t nparts, int32_t rows, int32_t rows_pad, int32_t E,
                            const float* scores, int64_t score_stride, int64_t N,
                            int32_t H, int32_t W, const float* pe,
                            int32_t t_index0, int32_t y_index0, int32_t x_index0,
-                           float* scratch, float* out_ml, float* out_acc, void* stream);
+                           float* scratch, float* out_ml, float* out_acc, int32_t normalize, void* stream);
 
 /* Combine `nsets` (M,L,ACC) triples (one per GPU after the all-gather, or one) and normalise:
  * ctx[r,:] = sum_k e^(M_k - M) ACC_k[r,:] / sum_k e^(M_k - M) L_k.
@@ -147,7 +158,7 @@ int hicom_global_combine_fwd(const float* ml, const float* acc, int32_t nsets, i
  * b bf16|f32 [N].  out_row(m) = row0 + m + (nl_group ? m / nl_group : 0) implements the
  * newline-interleaved packing of post_process_visual_feature (mm_utils.py:100-135).
  * Replaces build_mlp's Linear/GELU/Linear (projector.py:307-312,559,646).
- * K % 32 == 0; y dtype y_dt, row length ldy elements. */
+ * K % 64 == 0; y dtype y_dt, row length ldy elements. */
 int hicom_readout_gemm_fwd(const float* x, const void* w, const void* b, int32_t b_dt,
                            int32_t M, int32_t N, int32_t K, int32_t act,
                            void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group,
@@ -160,6 +171,72 @@ int hicom_readout_gemm_fwd(const float* x, const void* w, const void* b, int32_t
 int hicom_scatter_rows_fwd(const void* src, int32_t src_dt, int32_t src_rows, int32_t ncols,
                            void* dst, int32_t dst_dt, int64_t ldd, int64_t row0, int64_t row_step,
                            int32_t nl_group, int32_t count, void* stream);
+
+/* Same, with the per-set (M,L) pairs and ACC blocks `set_stride` floats apart (the layout of the
+ * all-gathered per-rank buffers): ml_k = ml + k*set_stride, acc_k = acc + k*set_stride. */
+int hicom_global_combine_strided_fwd(const float* ml, const float* acc, int64_t set_stride, int32_t nsets,
+                                     int32_t rows, int32_t E, float* ctx, void* stream);
+
+/* ---- whole-forward executor ------------------------------------------------------------------
+ * hicom_compressor_fwd enqueues HIComProjector.forward (projector.py:676-708) for one dense
+ * [T,H,W,E] input as a fixed plan of kernel launches over a caller-owned workspace: the local
+ * chain on stream_main, the global chain on stream_side (fork/join through ev_fork / ev_join),
+ * so the two streaming kernels and the two small-kernel tails overlap.
+ *
+ * phases: HICOM_PHASE_STREAM = everything that touches the frames (local tokens, and the
+ *         global online-softmax state); HICOM_PHASE_FINISH = the 32 global rows from the state.
+ *         A single GPU passes both.  The frame-sharded path runs STREAM with local_out /
+ *         state_out pointing into its send buffer, all-gathers, then runs FINISH with state_sets.
+ * workspace: hicom_compressor_workspace_bytes(args) bytes, 256-B aligned; its first
+ *         hicom_compressor_zero_prefix_bytes(args) bytes must be zeroed ONCE by the caller
+ *         (padding rows the kernels never write) and the buffer must not be shared between
+ *         concurrently running forwards. */
+#define HICOM_PHASE_STREAM 1
+#define HICOM_PHASE_FINISH 2
+
+typedef struct hicom_compressor_args {
+    /* inputs: frames_feature (values; keys/values of the global stage), frames_embed (local keys, may be NULL) */
+    const void* ff;
+    const void* fe;
+    int32_t T, H, W, E;
+    int32_t has_local, has_global, phases, hidden;
+    /* local compressor */
+    hicom_axis at, ay, ax;
+    const void* lq;            /* shared [E] (stride 0) or per-window query; NULL = pooled (guide off) */
+    int32_t lq_dt;
+    int32_t l2norm;
+    int64_t lq_stride;
+    float l_scale, l_bias;
+    const void *lw0, *lb0, *lw2, *lb2;          /* readout Linear(E,hidden), Linear(hidden,hidden): bf16 */
+    /* global compressor */
+    const void* gq;            /* bf16 [nq, E] injected queries (1 row in "direct" mode) */
+    int32_t nq, nh, n_global_rows, P;
+    const void *wq, *bq, *wk, *wv, *bv, *wo, *bo;
+    const void *gw0, *gb0, *gw2, *gb2;
+    const float* pe;           /* f32 [P, E] stacked per-axis sinusoid tables, or NULL (no pos-emb) */
+    const float* kpe;          /* f32 [E, P] = w_k . pe^T (weight-only cache) */
+    int32_t t_index0, y_index0, x_index0, nsets;
+    /* output [rows, ldo] of dtype out_dt */
+    void* out;
+    int32_t out_dt, nl_group;
+    int64_t ldo, local_row0, global_row0;
+    const void* newline;       /* newline token [hidden] or NULL */
+    int32_t newline_dt, nl_count;
+    int64_t nl_first, nl_step;
+    /* frame-sharded operation (all NULL / 0 on a single GPU) */
+    void* local_out;           /* dense [Nw, hidden] (out_dt) instead of packed rows of `out` */
+    void* state_out;           /* f32 [2R + R*E]: un-normalised (M,L) pairs then ACC of this shard */
+    const void* state_sets;    /* gathered states, nsets blocks state_set_stride floats apart */
+    int64_t state_set_stride;
+    /* execution resources */
+    void* ws;
+    int64_t ws_bytes;
+    void *stream_main, *stream_side, *ev_fork, *ev_join;
+} hicom_compressor_args;
+
+int64_t hicom_compressor_workspace_bytes(const hicom_compressor_args* args);
+int64_t hicom_compressor_zero_prefix_bytes(const hicom_compressor_args* args);
+int hicom_compressor_fwd(const hicom_compressor_args* args);
 
 #ifdef __cplusplus
 }

@@ -194,9 +194,9 @@ def test_global_stream_merge_combine(T, H, W, nq, peaky, in_scale):
         stride = (N + 15) // 16 * 16
         scores = f32((rows_pad, stride))
         pm, pl, pacc = f32((nparts, rows_pad)), f32((nparts, rows_pad)), f32((nparts, rows_pad, E))
-        nv.global_stream(ff, N, qhi, qlo, pos_a, H, W, 0, cap, cap + H, scores, pm, pl, pacc)
+        nv.global_stream(ff, N, qhi, qlo, pos_a, H, W, 0, cap, cap + H, scores, pm, pl, pacc, rows=R)
         ml, acc = f32((R, 2)), f32((R, E))
-        scratch = f32((R * T * (H + W + 1),))
+        scratch = f32((R * T * (H + W + 2),))
         nv.global_merge(pm, pl, pacc, R, scores, N, H, W, pe, 0, cap, cap + H, scratch, ml, acc)
         ctx = f32((R, E))
         nv.global_combine(ml.unsqueeze(0), acc.unsqueeze(0), ctx)
@@ -233,10 +233,50 @@ def test_global_frame_shard_merge_equals_unsharded():
         n = (t1 - t0) * H * W
         scores = f32((rows_pad, (n + 15) // 16 * 16))
         pm, pl, pacc = f32((2, rows_pad)), f32((2, rows_pad)), f32((2, rows_pad, E))
-        nv.global_stream(shard, n, qhi, qlo, pos_a, H, W, t0, cap, cap + H, scores, pm, pl, pacc)
+        nv.global_stream(shard, n, qhi, qlo, pos_a, H, W, t0, cap, cap + H, scores, pm, pl, pacc, rows=R)
         ml, acc = f32((R, 2)), f32((R, E))
-        nv.global_merge(pm, pl, pacc, R, scores, n, H, W, pe, t0, cap, cap + H, f32((R * 4 * (H + W + 1),)), ml, acc)
+        nv.global_merge(pm, pl, pacc, R, scores, n, H, W, pe, t0, cap, cap + H, f32((R * 4 * (H + W + 2),)), ml, acc)
         mls.append(ml), accs.append(acc)
     ctx = f32((R, E))
     nv.global_combine(torch.stack(mls), torch.stack(accs), ctx)
     assert maxabs(ctx, want_ctx) <= 1e-4 * max(1.0, float(want_ctx.abs().max()))
+
+
+def test_fold_query_split_matches_unfused_chain():
+    """hicom_fold_query_split_fwd (hot path) == fold -> split -> qt . PE^T (reference chain of ops)."""
+    nq, nh, E, H, W, cap = 3, 9, 1152, 6, 5, 12
+    hd = E // nh
+    qp = torch.from_numpy(synth.normal_like((nq, E), 51)).cuda()
+    wk = bf(synth.normal_like((E, E), 52, 0.02))
+    pe = torch.from_numpy(geo.stacked_pos_tables(cap, H, W, E)).cuda()
+    P, R, rows_pad = pe.shape[0], nq * nh, 32
+    qt = f32((R, E))
+    nv.fold_query(qp, wk, nh, hd ** -0.5, qt)
+    hi0 = torch.empty((rows_pad, E), dtype=torch.bfloat16, device="cuda")
+    lo0 = torch.empty_like(hi0)
+    nv.split_bf16(qt, rows_pad, hi0, lo0)
+    pa0 = torch.zeros((rows_pad, P), dtype=torch.float32, device="cuda")
+    nv.linear(qt, pe, None, pa0, M=R)
+    kpe = f32((E, P))
+    nv.linear(wk, pe, None, kpe)
+    hi1 = torch.zeros_like(hi0)
+    lo1 = torch.zeros_like(lo0)
+    pa1 = torch.zeros_like(pa0)
+    nv.fold_query_split(qp, wk, kpe, nh, hd ** -0.5, hi1, lo1, pa1)
+    rec0, rec1 = hi0.float() + lo0.float(), hi1.float() + lo1.float()
+    assert float((rec0 - rec1).abs().max()) <= 2e-6 * max(1.0, float(rec0.abs().max()))
+    assert float((pa0 - pa1).abs().max()) <= 2e-5 * max(1.0, float(pa0.abs().max()))
+    assert float(rec1[R:].abs().max()) == 0.0 and float(pa1[R:].abs().max()) == 0.0
+
+
+def test_combine_strided_equals_dense():
+    nsets, R, E = 3, 9, 1152
+    stride = 2 * R + R * E + 40
+    buf = torch.from_numpy(synth.normal_like((nsets, stride), 61)).cuda()
+    buf[:, 1:2 * R:2] = buf[:, 1:2 * R:2].abs() + 0.5                 # L > 0
+    ml = buf[:, :2 * R].contiguous().view(nsets, R, 2)
+    acc = buf[:, 2 * R:2 * R + R * E].contiguous().view(nsets, R, E)
+    a, b = f32((R, E)), f32((R, E))
+    nv.global_combine(ml, acc, a)
+    nv.global_combine_strided(buf, buf.view(-1)[2 * R:], stride, nsets, R, E, b)
+    assert torch.equal(a, b)
