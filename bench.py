@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=64)
     ap.add_argument("--hidden", type=int, default=896)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay of the plan")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,6 +126,7 @@ def main():
     total_frames = fpg * world
     cfg = release_config(args.hidden, total_frames)
     module = make_projector(cfg, device)
+    module.graph_replay = not args.no_graph and not distributed
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     ff = torch.randn(fpg, GRID, GRID, D, device=device, generator=gen).to(torch.bfloat16)
     fe = torch.randn(fpg, GRID, GRID, D, device=device, generator=gen).to(torch.bfloat16)
@@ -168,7 +170,8 @@ def main():
         "config": {"workload": f"{total_frames} frames x 729 SigLIP tokens x 1152 bf16 ({fpg}/GPU), local43+global32, "
                                f"use_guide=direct, hidden {args.hidden} -> {n_out} compressed tokens",
                    "frames": total_frames, "frames_per_gpu": fpg, "hidden": args.hidden,
-                   "parallelism": f"frame-shard x{world}" + (" + RCCL all-gather" if distributed else "")},
+                   "parallelism": f"frame-shard x{world}" + (" + RCCL all-gather" if distributed else ""),
+                   "launch": "hipGraph replay" if module.graph_replay else "eager (one C call per step)"},
         "input_visual_tokens_per_sec": total_frames * GRID * GRID / (ms_per_step * 1e-3),
         "roofline": roofline,
     }

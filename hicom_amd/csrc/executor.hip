@@ -126,9 +126,25 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         HICOM_REQUIRE(hipStreamWaitEvent(ss, (hipEvent_t)a.ev_fork, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
     }
 
+    // Host enqueue order matters (each launch costs a few us of host time): the long local
+    // attention kernel goes first so that the side chain is enqueued while it runs.
+    // ------------------------------------------------------------------ local chain: attention
+    if (a.has_local && do_stream) {
+        const void* q = a.lq;
+        int q_dt = a.lq_dt;
+        int64_t q_stride = a.lq_stride;
+        if (!q) {   // guide off: per-window pooled query
+            CHK(hicom_trilinear_pool_fwd(a.ff, a.T, a.H, a.W, a.E, a.at.nwin, a.ay.nwin, a.ax.nwin, F(w.pooled_q), sm));
+            q = F(w.pooled_q);
+            q_dt = HICOM_DT_F32;
+            q_stride = a.E;
+        }
+        CHK(hicom_local_attn_fwd(a.fe ? a.fe : a.ff, a.ff, a.E, a.at, a.ay, a.ax, q, q_dt, q_stride, a.l_scale, a.l_bias,
+                                 a.l2norm, F(w.ctx_local), sm));
+    }
+
     // ------------------------------------------------------------------ global chain, part 1
     if (a.has_global && do_stream) {
-        CHK(hicom_scatter_rows_fwd(a.gq, HICOM_DT_BF16, a.nq, a.E, F(w.qres), HICOM_DT_F32, a.E, 0, 1, 0, a.nq, sg));
         CHK(hicom_linear_fwd(a.gq, HICOM_DT_BF16, a.wq, HICOM_DT_BF16, a.bq, HICOM_DT_BF16, nullptr, 0, a.nq, a.E, a.E,
                              0, 0, HICOM_ACT_NONE, F(w.qp), sg));
         const float scale = 1.0f / sqrtf((float)(a.E / a.nh));
@@ -146,19 +162,8 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                                    F(w.scratch), ml, acc, solo ? 1 : 0, sg));
     }
 
-    // ------------------------------------------------------------------ local chain
+    // ------------------------------------------------------------------ local chain: readout
     if (a.has_local && do_stream) {
-        const void* q = a.lq;
-        int q_dt = a.lq_dt;
-        int64_t q_stride = a.lq_stride;
-        if (!q) {   // guide off: per-window pooled query
-            CHK(hicom_trilinear_pool_fwd(a.ff, a.T, a.H, a.W, a.E, a.at.nwin, a.ay.nwin, a.ax.nwin, F(w.pooled_q), sm));
-            q = F(w.pooled_q);
-            q_dt = HICOM_DT_F32;
-            q_stride = a.E;
-        }
-        CHK(hicom_local_attn_fwd(a.fe ? a.fe : a.ff, a.ff, a.E, a.at, a.ay, a.ax, q, q_dt, q_stride, a.l_scale, a.l_bias,
-                                 a.l2norm, F(w.ctx_local), sm));
         CHK(hicom_readout_gemm_fwd(F(w.ctx_local), a.lw0, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E, HICOM_ACT_GELU,
                                    F(w.hid_local), HICOM_DT_F32, a.hidden, 0, 0, sm));
         CHK(hicom_readout_gemm_fwd(F(w.hid_local), a.lw2, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden, HICOM_ACT_NONE,
@@ -180,7 +185,8 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         }
         CHK(hicom_linear_fwd(ctx, HICOM_DT_F32, a.wv, HICOM_DT_BF16, a.bv, HICOM_DT_BF16, nullptr, 0, a.nq, a.E, a.E,
                              a.nh, a.E / a.nh, HICOM_ACT_NONE, F(w.o), sg));
-        CHK(hicom_linear_fwd(F(w.o), HICOM_DT_F32, a.wo, HICOM_DT_BF16, a.bo, HICOM_DT_BF16, F(w.qres), 0, a.nq, a.E, a.E,
+        // residual with the injected query (projector.py:646), read as bf16 directly
+        CHK(hicom_linear_fwd(F(w.o), HICOM_DT_F32, a.wo, HICOM_DT_BF16, a.bo, HICOM_DT_BF16, a.gq, 2, a.nq, a.E, a.E,
                              0, 0, HICOM_ACT_NONE, F(w.pre), sg));
         CHK(hicom_linear_fwd(F(w.pre), HICOM_DT_F32, a.gw0, HICOM_DT_BF16, a.gb0, HICOM_DT_BF16, nullptr, 0, a.nq, a.hidden,
                              a.E, 0, 0, HICOM_ACT_GELU, F(w.hid_g), sg));

@@ -79,16 +79,20 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+constexpr int kTC = 32;   // frames of marginals staged in LDS per pass
+
 __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
-    extern __shared__ float wsm[];   // [nparts] | [T] frame weights | [T+H+W] positional weights | [4*64] | [4]
+    // LDS: [16*64] column partials | [4] | [nparts] partial weights | [T] frame weights |
+    //      [T+H+W] positional weights | [kTC * S] staged marginals
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int r = blockIdx.x, tid = threadIdx.x;
-    const int pg = tid >> 6, cl = tid & 63, c = blockIdx.y * 64 + cl;
-    float* wp = wsm;
+    const int S = p.H + p.W + 2, HW2 = p.H + p.W;
+    float* cred = wsm;                                   // 16-byte aligned: float4 stores
+    float* red = cred + 16 * 64;
+    float* wp = red + 4;
     float* wt = wp + p.nparts;
     float* wpos = wt + p.T;
-    float* cred = wpos + (p.T + p.H + p.W);
-    float* red = cred + 256;
-    const int S = p.H + p.W + 2;
+    float* tile = wpos + (p.T + HW2);
     const float* sc = p.scratch ? p.scratch + (long)r * p.T * S : nullptr;
 
     // (M, L) of this row from the partials
@@ -102,34 +106,77 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
         l += w * p.part_l[(long)i * p.rows_pad + r];
     }
     const float L = block_reduce_sum(l, red);
+
+    // positional weights: w_t = e^(m_t - M) * total_t ; w_y = sum_t e^(m_t - M) fy[t][y] ; w_x likewise.
+    // The [T][S] marginal table is streamed through LDS in coalesced chunks of kTC frames.
     if (sc) {
-        for (int t = tid; t < p.T; t += 256) wt[t] = expf(sc[(long)t * S + p.H + p.W + 1] - M);
-        __syncthreads();
-        for (int j = tid; j < p.T + p.H + p.W; j += 256) {
-            float a = 0.f;
-            if (j < p.T) a = wt[j] * sc[(long)j * S + p.H + p.W];
-            else for (int t = 0; t < p.T; ++t) a = fmaf(wt[t], sc[(long)t * S + (j - p.T)], a);
-            wpos[j] = a;
+        for (int t = tid; t < p.T; t += 256) wt[t] = expf(sc[(long)t * S + HW2 + 1] - M);
+        float ay[4] = {0.f, 0.f, 0.f, 0.f};      // up to 4 * 256 spatial marginals per thread
+        for (int t0 = 0; t0 < p.T; t0 += kTC) {
+            const int nt = min(kTC, p.T - t0);
+            __syncthreads();
+            for (int i = tid; i < nt * S; i += 256) tile[i] = sc[(long)t0 * S + i];
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = tid + 256 * u;
+                if (j < HW2)
+                    for (int tt = 0; tt < nt; ++tt) ay[u] = fmaf(wt[t0 + tt], tile[tt * S + j], ay[u]);
+            }
+            if (tid < nt) wpos[t0 + tid] = wt[t0 + tid] * tile[tid * S + HW2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = tid + 256 * u;
+            if (j < HW2) wpos[p.T + j] = ay[u];
         }
     }
     __syncthreads();
 
-    float a = 0.f;
-    if (c < p.E) {
-        for (int i = pg; i < p.nparts; i += 4) a = fmaf(wp[i], p.part_acc[((long)i * p.rows_pad + r) * p.E + c], a);
+    // context columns: 16 partial-groups x 16 lanes x float4 (one 256-B row segment per group-load),
+    // 8 independent loads in flight per thread
+    const int pgp = tid >> 4, l4 = tid & 15;
+    const int c4 = blockIdx.y * 64 + 4 * l4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < p.E) {
+        const float* base = p.part_acc + (long)r * p.E + c4;
+        const long pstride = (long)p.rows_pad * p.E;
+        int i = pgp;
+        for (; i + 16 * 7 < p.nparts; i += 16 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(base + (long)(i + 16 * u) * pstride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float w = wp[i + 16 * u];
+                a.x = fmaf(w, v[u].x, a.x); a.y = fmaf(w, v[u].y, a.y); a.z = fmaf(w, v[u].z, a.z); a.w = fmaf(w, v[u].w, a.w);
+            }
+        }
+        for (; i < p.nparts; i += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (long)i * pstride);
+            const float w = wp[i];
+            a.x = fmaf(w, v.x, a.x); a.y = fmaf(w, v.y, a.y); a.z = fmaf(w, v.z, a.z); a.w = fmaf(w, v.w, a.w);
+        }
         if (sc) {
-            for (int j = pg; j < p.T + p.H + p.W; j += 4) {
+            for (int j = pgp; j < p.T + HW2; j += 16) {
                 const int row = j < p.T ? p.t0i + j : (j < p.T + p.H ? p.y0i + (j - p.T) : p.x0i + (j - p.T - p.H));
-                a = fmaf(wpos[j], p.pe[(long)row * p.E + c], a);
+                const float4 v = *reinterpret_cast<const float4*>(p.pe + (long)row * p.E + c4);
+                const float w = wpos[j];
+                a.x = fmaf(w, v.x, a.x); a.y = fmaf(w, v.y, a.y); a.z = fmaf(w, v.z, a.z); a.w = fmaf(w, v.w, a.w);
             }
         }
     }
-    cred[pg * 64 + cl] = a;
+    *reinterpret_cast<float4*>(cred + pgp * 64 + 4 * l4) = a;
     __syncthreads();
-    if (pg == 0 && c < p.E) {
-        float v = (cred[cl] + cred[64 + cl]) + (cred[128 + cl] + cred[192 + cl]);
-        if (p.normalize) v /= L;
-        p.out_acc[(long)r * p.E + c] = v;
+    if (tid < 64) {
+        const int c = blockIdx.y * 64 + tid;
+        if (c < p.E) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) v += cred[g * 64 + tid];
+            if (p.normalize) v /= L;
+            p.out_acc[(long)r * p.E + c] = v;
+        }
     }
     if (blockIdx.y == 0 && tid == 0) {
         p.out_ml[2 * r] = M;
@@ -178,7 +225,8 @@ extern "C" int hicom_global_merge_fwd(const float* part_m, const float* part_l, 
     }
     MergeCtxParams p{part_m, part_l, part_acc, nparts, rows_pad, E, pe ? scratch : nullptr, pe,
                      T, H, W, t_index0, y_index0, x_index0, out_ml, out_acc, normalize};
-    const size_t smem2 = ((size_t)nparts + (pe ? (size_t)2 * T + H + W : 0) + 256 + 4) * 4;
+    HICOM_REQUIRE(E % 4 == 0 && (!pe || H + W <= 1024), HICOM_EUNSUP, "global_merge: E %% 4 and H + W <= 1024");
+    const size_t smem2 = ((size_t)nparts + (pe ? (size_t)2 * T + H + W + (size_t)kTC * (H + W + 2) : 0) + 16 * 64 + 4) * 4;
     HICOM_REQUIRE(smem2 <= 60000, HICOM_EUNSUP, "global_merge: too many partials/frames for one pass");
     hipLaunchKernelGGL(merge_ctx_kernel, dim3((unsigned)rows, (unsigned)((E + 63) / 64)), dim3(256), smem2, s, p);
     return hicom_host::check_launch("global_merge");

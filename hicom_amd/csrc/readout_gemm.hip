@@ -35,38 +35,41 @@ constexpr int kMatB = 64 * kRowB;          // one 64x64 bf16 operand image
 constexpr int kBufB = 3 * kMatB;           // A_hi | A_lo | B
 
 struct Stage {
-    float4 a[4];     // 16 consecutive k of one A row (fp32)
-    u32x4 b[2];      // 16 consecutive k of one W row (bf16)
+    float4 a[4];     // 4 passes x (one 16-byte chunk of an A row): rows r, r+16, r+32, r+48
+    u32x4 b[2];      // 2 passes x (one 16-byte chunk of a W row): rows r, r+32
 };
 
-__device__ __forceinline__ void stage_load(Stage& st, const float* xa, const uint16_t* wb, int k0) {
+// Global loads are issued so that consecutive lanes read consecutive 16-byte chunks of a row
+// (a wave covers 4 full 256-B A-row segments / 8 full 128-B W-row segments per instruction).
+__device__ __forceinline__ void stage_load(Stage& st, const float* const (&xa)[4], const uint16_t* const (&wb)[2], int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) st.a[i] = *reinterpret_cast<const float4*>(xa + k0 + 4 * i);
+    for (int i = 0; i < 4; ++i) st.a[i] = *reinterpret_cast<const float4*>(xa[i] + k0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) st.b[i] = *reinterpret_cast<const u32x4*>(wb + k0 + 8 * i);
+    for (int i = 0; i < 2; ++i) st.b[i] = *reinterpret_cast<const u32x4*>(wb[i] + k0);
 }
 
-__device__ __forceinline__ void stage_store(const Stage& st, char* buf, int srow, int skq) {
-    char* ahi = buf + srow * kRowB + 32 * skq;
-    char* alo = ahi + kMatB;
-    char* bs = ahi + 2 * kMatB;
+__device__ __forceinline__ void stage_store(const Stage& st, char* buf, int tid) {
+    const int ra = tid >> 4, ca = tid & 15;      // A: row within pass, 4-float chunk
+    const int rb = tid >> 3, cb = tid & 7;       // B: row within pass, 8-bf16 chunk
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const float v[8] = {st.a[2 * half].x, st.a[2 * half].y, st.a[2 * half].z, st.a[2 * half].w,
-                            st.a[2 * half + 1].x, st.a[2 * half + 1].y, st.a[2 * half + 1].z, st.a[2 * half + 1].w};
-        u32x4 hi, lo;
+    for (int i = 0; i < 4; ++i) {
+        const float v[4] = {st.a[i].x, st.a[i].y, st.a[i].z, st.a[i].w};
+        u32x2 hi, lo;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 2; ++j) {
             uint16_t h0, l0, h1, l1;
-            split_bf16(v[2 * i], h0, l0);
-            split_bf16(v[2 * i + 1], h1, l1);
-            hi[i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-            lo[i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+            split_bf16(v[2 * j], h0, l0);
+            split_bf16(v[2 * j + 1], h1, l1);
+            hi[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+            lo[j] = (uint32_t)l0 | ((uint32_t)l1 << 16);
         }
-        *reinterpret_cast<u32x4*>(ahi + 16 * half) = hi;
-        *reinterpret_cast<u32x4*>(alo + 16 * half) = lo;
-        *reinterpret_cast<u32x4*>(bs + 16 * half) = st.b[half];
+        char* d = buf + (ra + 16 * i) * kRowB + 8 * ca;
+        *reinterpret_cast<u32x2*>(d) = hi;
+        *reinterpret_cast<u32x2*>(d + kMatB) = lo;
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        *reinterpret_cast<u32x4*>(buf + 2 * kMatB + (rb + 32 * i) * kRowB + 16 * cb) = st.b[i];
 }
 
 __global__ __launch_bounds__(256, 2) void readout_gemm_kernel(GemmParams p) {
@@ -77,12 +80,21 @@ __global__ __launch_bounds__(256, 2) void readout_gemm_kernel(GemmParams p) {
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int r16 = lane & 15, kg = lane >> 4;
 
-    // staging assignment: thread -> (row, 16-element k quarter of the 64-wide stage)
-    const int srow = tid >> 2, skq = tid & 3;
-    int am = m0 + srow; am = am < p.M ? am : p.M - 1;
-    int bn = n0 + srow; bn = bn < p.N ? bn : p.N - 1;
-    const float* xa = p.x + (long)am * p.K + 16 * skq;
-    const uint16_t* wb = p.w + (long)bn * p.K + 16 * skq;
+    // staging assignment (see stage_load): clamp tail rows to a valid row, masked at the store
+    const float* xa[4];
+    const uint16_t* wb[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int am = m0 + (tid >> 4) + 16 * i;
+        am = am < p.M ? am : p.M - 1;
+        xa[i] = p.x + (long)am * p.K + 4 * (tid & 15);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int bn = n0 + (tid >> 3) + 32 * i;
+        bn = bn < p.N ? bn : p.N - 1;
+        wb[i] = p.w + (long)bn * p.K + 8 * (tid & 7);
+    }
 
     f32x4 acc[2][2];
 #pragma unroll
@@ -94,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void readout_gemm_kernel(GemmParams p) {
     Stage st[2];
     stage_load(st[0], xa, wb, 0);
     if (ns > 1) stage_load(st[1], xa, wb, 64);
-    stage_store(st[0], lds, srow, skq);
+    stage_store(st[0], lds, tid);
     __syncthreads();
 
     auto compute = [&](const char* buf) {
@@ -123,12 +135,12 @@ __global__ __launch_bounds__(256, 2) void readout_gemm_kernel(GemmParams p) {
     for (int s = 0; s < ns; s += 2) {
         if (s + 2 < ns) stage_load(st[0], xa, wb, 64 * (s + 2));
         compute(lds);
-        if (s + 1 < ns) stage_store(st[1], lds + kBufB, srow, skq);
+        if (s + 1 < ns) stage_store(st[1], lds + kBufB, tid);
         __syncthreads();
         if (s + 1 >= ns) break;
         if (s + 3 < ns) stage_load(st[1], xa, wb, 64 * (s + 3));
         compute(lds + kBufB);
-        if (s + 2 < ns) stage_store(st[0], lds, srow, skq);
+        if (s + 2 < ns) stage_store(st[0], lds, tid);
         __syncthreads();
     }
 

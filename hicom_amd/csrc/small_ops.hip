@@ -38,9 +38,9 @@ struct LinearParams {
     const void* x;
     const void* w;
     const void* b;
-    const float* res;
+    const void* res;
     float* y;
-    int x_f32, w_f32, b_f32, res_bcast;
+    int x_f32, w_f32, b_f32, res_flags;   // res_flags: bit0 = broadcast row 0, bit1 = res is bf16
     int M, N, K;
     int head_rows, head_dim;
     int act;
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(LinearParams p) {
 #pragma unroll
     for (int r = 0; r < MR; ++r) acc[r] = 0.f;
     const int head = p.head_dim > 0 ? n / p.head_dim : 0;
+#pragma unroll 3
     for (int k = lane * 8; k < p.K; k += 512) {
         float wv[8];
         load8<WF32>(p.w, (long)n * p.K + k, wv);
@@ -96,7 +97,10 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(LinearParams p) {
             if (p.b) v += p.b_f32 ? reinterpret_cast<const float*>(p.b)[n]
                                   : bf16_to_f32(reinterpret_cast<const uint16_t*>(p.b)[n]);
             if (p.act == HICOM_ACT_GELU) v = gelu_erf(v);
-            if (p.res) v += p.res[(p.res_bcast ? 0 : (long)m * p.N) + n];
+            if (p.res) {
+                const long ri = ((p.res_flags & 1) ? 0 : (long)m * p.N) + n;
+                v += (p.res_flags & 2) ? bf16_to_f32(reinterpret_cast<const uint16_t*>(p.res)[ri]) : reinterpret_cast<const float*>(p.res)[ri];
+            }
             p.y[(long)m * p.N + n] = v;
         }
     }
@@ -227,21 +231,26 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const void* src, int 
 using namespace hicom;
 
 extern "C" int hicom_linear_fwd(const void* x, int32_t x_dt, const void* w, int32_t w_dt,
-                                const void* b, int32_t b_dt, const float* res, int32_t res_bcast,
+                                const void* b, int32_t b_dt, const void* res, int32_t res_flags,
                                 int32_t M, int32_t N, int32_t K, int32_t head_rows, int32_t head_dim,
                                 int32_t act, float* y, void* stream) {
     HICOM_REQUIRE(x && w && y, HICOM_EINVAL, "linear: NULL pointer");
     HICOM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0, HICOM_EINVAL, "linear: bad shape M=%d N=%d K=%d (K %% 8)", M, N, K);
     HICOM_REQUIRE(head_dim == 0 || (head_dim > 0 && head_rows > 0), HICOM_EINVAL, "linear: head mode");
-    LinearParams p{x, w, b, res, y, x_dt == HICOM_DT_F32, w_dt == HICOM_DT_F32, b_dt == HICOM_DT_F32, res_bcast,
+    LinearParams p{x, w, b, res, y, x_dt == HICOM_DT_F32, w_dt == HICOM_DT_F32, b_dt == HICOM_DT_F32, res_flags,
                    M, N, K, head_rows, head_dim, act};
-    constexpr int MR = 8;
-    dim3 grid((unsigned)((N + 3) / 4), (unsigned)((M + MR - 1) / MR));
     hipStream_t s = (hipStream_t)stream;
-    if (p.x_f32 && p.w_f32) hipLaunchKernelGGL((linear_rows_kernel<true, true, MR>), grid, dim3(256), 0, s, p);
-    else if (p.x_f32) hipLaunchKernelGGL((linear_rows_kernel<true, false, MR>), grid, dim3(256), 0, s, p);
-    else if (p.w_f32) hipLaunchKernelGGL((linear_rows_kernel<false, true, MR>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((linear_rows_kernel<false, false, MR>), grid, dim3(256), 0, s, p);
+#define HICOM_LAUNCH_LINEAR(MR)                                                                                        \
+    do {                                                                                                               \
+        dim3 grid((unsigned)((N + 3) / 4), (unsigned)((M + (MR)-1) / (MR)));                                            \
+        if (p.x_f32 && p.w_f32) hipLaunchKernelGGL((linear_rows_kernel<true, true, MR>), grid, dim3(256), 0, s, p);     \
+        else if (p.x_f32) hipLaunchKernelGGL((linear_rows_kernel<true, false, MR>), grid, dim3(256), 0, s, p);          \
+        else if (p.w_f32) hipLaunchKernelGGL((linear_rows_kernel<false, true, MR>), grid, dim3(256), 0, s, p);          \
+        else hipLaunchKernelGGL((linear_rows_kernel<false, false, MR>), grid, dim3(256), 0, s, p);                      \
+    } while (0)
+    if (M == 1) HICOM_LAUNCH_LINEAR(1);     // GEMV: one shuffle reduction per column instead of eight
+    else HICOM_LAUNCH_LINEAR(8);
+#undef HICOM_LAUNCH_LINEAR
     return hicom_host::check_launch("linear");
 }
 

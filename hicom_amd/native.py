@@ -159,10 +159,11 @@ def trilinear_pool(x, out):
 
 
 def linear(x, w, b, y, res=None, res_bcast=False, act=ACT_NONE, head_rows=0, head_dim=0, M=None):
+    res_flags = (1 if res_bcast else 0) | (2 if (res is not None and res.dtype == torch.bfloat16) else 0)
     N, K = w.shape
     M = y.shape[0] if M is None else M
     _check(lib().hicom_linear_fwd(_ptr(x), _dt(x), _ptr(w), _dt(w), _ptr(b), _dt(b) if b is not None else 0,
-                                  _ptr(res), int(res_bcast), M, N, K, head_rows, head_dim, act, _ptr(y), _stream()),
+                                  _ptr(res), res_flags, M, N, K, head_rows, head_dim, act, _ptr(y), _stream()),
            "hicom_linear_fwd")
 
 

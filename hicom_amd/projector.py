@@ -247,6 +247,7 @@ class GlobalCompressor(nn.Module):
         self.readout = build_mlp(mlp_depth, embed_dim, config.hidden_size)
         self.apply(_init_like_reference)
         self._pe_cache: Dict[Tuple, torch.Tensor] = {}
+        self._cache_gen = 0          # bumped whenever a cached device table is (re)built: invalidates engine plans
 
     # per-axis sinusoid tables [t_cap + H + W, E] fp32 on the device (ref :57-101, :603-621: the
     # reference caches the full [T,27,27,E] sum; we keep the three separable factors)
@@ -259,6 +260,7 @@ class GlobalCompressor(nn.Module):
             tab = torch.from_numpy(geo.stacked_pos_tables(cap, H, W, self.embed_dim)).to(device)
             hit = (tab, cap)
             self._pe_cache[key] = hit
+            self._cache_gen += 1
         return hit
 
     def pos_and_kpe(self, t_cap: int, H: int, W: int, device):
@@ -275,6 +277,7 @@ class GlobalCompressor(nn.Module):
             nv.linear(wk.detach(), pe, None, kpe)
             hit = (kpe, stamp)
             self._pe_cache[key] = hit
+            self._cache_gen += 1
         return pe, hit[0], cap
 
     def _check_native(self, logit_scale):
@@ -399,6 +402,7 @@ class HIComProjector(nn.Module):
             "At least one compressor should be provided."
         self.return_fp32 = False     # True: fp32 result (parity tests); default = weight dtype (bf16)
         self.use_executor = True     # dense inputs go through the one-call native executor (engine.py)
+        self.graph_replay = False    # True: capture each cached plan into a hipGraph and replay it
 
     def set_clip_logits(self, local=None, glob=None):
         if local is not None:

@@ -79,9 +79,10 @@ int hicom_trilinear_pool_fwd(const void* x, int32_t T, int32_t H, int32_t W, int
  * projector.py:180,226,646; also the score-side positional table q~.PE^T).
  *   head_dim > 0 selects "per-head rows": column n reads x row m*head_rows + n/head_dim
  *   (v_proj applied to the per-head context, projector.py:182,215 after folding).
- *   b, res may be NULL.  res is f32 [M,N] (res_stride0 == 0 broadcasts row 0). */
+ *   b, res may be NULL.  res is [M,N]; res_flags bit 0 = broadcast row 0, bit 1 = res is bf16
+ *   (otherwise f32). */
 int hicom_linear_fwd(const void* x, int32_t x_dt, const void* w, int32_t w_dt,
-                     const void* b, int32_t b_dt, const float* res, int32_t res_bcast,
+                     const void* b, int32_t b_dt, const void* res, int32_t res_flags,
                      int32_t M, int32_t N, int32_t K, int32_t head_rows, int32_t head_dim,
                      int32_t act, float* y, void* stream);
 
