@@ -190,10 +190,8 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                              0, 0, HICOM_ACT_NONE, F(w.pre), sg));
         CHK(hicom_linear_fwd(F(w.pre), HICOM_DT_F32, a.gw0, HICOM_DT_BF16, a.gb0, HICOM_DT_BF16, nullptr, 0, a.nq, a.hidden,
                              a.E, 0, 0, HICOM_ACT_GELU, F(w.hid_g), sg));
-        CHK(hicom_linear_fwd(F(w.hid_g), HICOM_DT_F32, a.gw2, HICOM_DT_BF16, a.gb2, HICOM_DT_BF16, nullptr, 0, a.nq,
-                             a.hidden, a.hidden, 0, 0, HICOM_ACT_NONE, F(w.tok), sg));
-        CHK(hicom_scatter_rows_fwd(F(w.tok), HICOM_DT_F32, a.nq, a.hidden, a.out, a.out_dt, a.ldo, a.global_row0, 1, 0,
-                                   a.n_global_rows, sg));
+        CHK(hicom_linear_to_rows_fwd(F(w.hid_g), HICOM_DT_F32, a.gw2, HICOM_DT_BF16, a.gb2, HICOM_DT_BF16, a.nq, a.hidden,
+                                     a.hidden, HICOM_ACT_NONE, a.out, a.out_dt, a.ldo, a.global_row0, a.n_global_rows, sg));
     }
 
     if (both && do_stream) {

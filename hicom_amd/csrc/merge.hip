@@ -133,32 +133,32 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
     }
     __syncthreads();
 
-    // context columns: 16 partial-groups x 16 lanes x float4 (one 256-B row segment per group-load),
-    // 8 independent loads in flight per thread
-    const int pgp = tid >> 4, l4 = tid & 15;
-    const int c4 = blockIdx.y * 64 + 4 * l4;
+    // context columns: 32 partial-groups x 8 lanes x float4 (32-column slab -> R * E/32 workgroups fill
+    // the chip), 8 independent loads in flight per thread
+    const int pgp = tid >> 3, l4 = tid & 7;
+    const int c4 = blockIdx.y * 32 + 4 * l4;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < p.E) {
         const float* base = p.part_acc + (long)r * p.E + c4;
         const long pstride = (long)p.rows_pad * p.E;
         int i = pgp;
-        for (; i + 16 * 7 < p.nparts; i += 16 * 8) {
+        for (; i + 32 * 7 < p.nparts; i += 32 * 8) {
             float4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(base + (long)(i + 16 * u) * pstride);
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(base + (long)(i + 32 * u) * pstride);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float w = wp[i + 16 * u];
+                const float w = wp[i + 32 * u];
                 a.x = fmaf(w, v[u].x, a.x); a.y = fmaf(w, v[u].y, a.y); a.z = fmaf(w, v[u].z, a.z); a.w = fmaf(w, v[u].w, a.w);
             }
         }
-        for (; i < p.nparts; i += 16) {
+        for (; i < p.nparts; i += 32) {
             const float4 v = *reinterpret_cast<const float4*>(base + (long)i * pstride);
             const float w = wp[i];
             a.x = fmaf(w, v.x, a.x); a.y = fmaf(w, v.y, a.y); a.z = fmaf(w, v.z, a.z); a.w = fmaf(w, v.w, a.w);
         }
         if (sc) {
-            for (int j = pgp; j < p.T + HW2; j += 16) {
+            for (int j = pgp; j < p.T + HW2; j += 32) {
                 const int row = j < p.T ? p.t0i + j : (j < p.T + p.H ? p.y0i + (j - p.T) : p.x0i + (j - p.T - p.H));
                 const float4 v = *reinterpret_cast<const float4*>(p.pe + (long)row * p.E + c4);
                 const float w = wpos[j];
@@ -166,14 +166,14 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
             }
         }
     }
-    *reinterpret_cast<float4*>(cred + pgp * 64 + 4 * l4) = a;
+    *reinterpret_cast<float4*>(cred + pgp * 32 + 4 * l4) = a;
     __syncthreads();
-    if (tid < 64) {
-        const int c = blockIdx.y * 64 + tid;
+    if (tid < 32) {
+        const int c = blockIdx.y * 32 + tid;
         if (c < p.E) {
             float v = 0.f;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) v += cred[g * 64 + tid];
+            for (int g = 0; g < 32; ++g) v += cred[g * 32 + tid];
             if (p.normalize) v /= L;
             p.out_acc[(long)r * p.E + c] = v;
         }
@@ -228,7 +228,7 @@ extern "C" int hicom_global_merge_fwd(const float* part_m, const float* part_l, 
     HICOM_REQUIRE(E % 4 == 0 && (!pe || H + W <= 1024), HICOM_EUNSUP, "global_merge: E %% 4 and H + W <= 1024");
     const size_t smem2 = ((size_t)nparts + (pe ? (size_t)2 * T + H + W + (size_t)kTC * (H + W + 2) : 0) + 16 * 64 + 4) * 4;
     HICOM_REQUIRE(smem2 <= 60000, HICOM_EUNSUP, "global_merge: too many partials/frames for one pass");
-    hipLaunchKernelGGL(merge_ctx_kernel, dim3((unsigned)rows, (unsigned)((E + 63) / 64)), dim3(256), smem2, s, p);
+    hipLaunchKernelGGL(merge_ctx_kernel, dim3((unsigned)rows, (unsigned)((E + 31) / 32)), dim3(256), smem2, s, p);
     return hicom_host::check_launch("global_merge");
 }
 

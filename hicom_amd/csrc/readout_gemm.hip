@@ -10,7 +10,7 @@
 //
 // Tiling: 64x64 output tile per 256-thread workgroup (2x2 waves, each 32x32 = 2x2 MFMA tiles).
 // The K loop runs in stages of 64: operands are register-staged TWO stages ahead (global-load
-// latency of ~1 us is several stage-times long at these small sizes), converted/split while being
+// latency of ~1 us is several stage-times long at these small sizes; THREE stages in flight), converted/split while being
 // written into a double-buffered LDS image with 144-byte rows (conflict-free ds_read_b128
 // fragment reads), one workgroup barrier per stage.
 // The store applies the packing row map of post_process_visual_feature (mm_utils.py:100-135).
@@ -103,9 +103,10 @@ __global__ __launch_bounds__(256, 2) void readout_gemm_kernel(GemmParams p) {
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ns = p.K / 64;
-    Stage st[2];
+    Stage st[3];
     stage_load(st[0], xa, wb, 0);
     if (ns > 1) stage_load(st[1], xa, wb, 64);
+    if (ns > 2) stage_load(st[2], xa, wb, 128);
     stage_store(st[0], lds, tid);
     __syncthreads();
 
@@ -130,19 +131,34 @@ __global__ __launch_bounds__(256, 2) void readout_gemm_kernel(GemmParams p) {
         }
     };
 
-    // stage s: LDS buf[s&1] holds it; register set (s+1)&1 holds stage s+1 in flight;
-    // register set s&1 is free and receives stage s+2.
-    for (int s = 0; s < ns; s += 2) {
-        if (s + 2 < ns) stage_load(st[0], xa, wb, 64 * (s + 2));
-        compute(lds);
-        if (s + 1 < ns) stage_store(st[1], lds + kBufB, tid);
-        __syncthreads();
+    // Stage i lives in register set i % 3 while in flight and in LDS buffer i % 2 once staged.
+    // Step S: issue the loads of stage S+3 (into the set stage S just vacated), compute stage S from
+    // LDS, then convert + store stage S+1 (loaded two steps ago) into the other LDS buffer.  The
+    // sched_barriers pin that order: without them hipcc hoists the wait-and-convert of stage S+1
+    // above the MFMAs and the prefetch distance collapses to zero.
+#define HICOM_GEMM_STEP(S, CUR, NXT, FREE)                                            \
+    do {                                                                              \
+        if ((S) + 3 < ns) stage_load(st[FREE], xa, wb, 64 * ((S) + 3));               \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        compute(lds + (CUR)*kBufB);                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        if ((S) + 1 < ns) stage_store(st[NXT], lds + ((CUR) ^ 1) * kBufB, tid);       \
+        __syncthreads();                                                              \
+    } while (0)
+    for (int s = 0; s < ns; s += 6) {
+        HICOM_GEMM_STEP(s, 0, 1, 0);
         if (s + 1 >= ns) break;
-        if (s + 3 < ns) stage_load(st[1], xa, wb, 64 * (s + 3));
-        compute(lds + kBufB);
-        if (s + 2 < ns) stage_store(st[0], lds, tid);
-        __syncthreads();
+        HICOM_GEMM_STEP(s + 1, 1, 2, 1);
+        if (s + 2 >= ns) break;
+        HICOM_GEMM_STEP(s + 2, 0, 0, 2);
+        if (s + 3 >= ns) break;
+        HICOM_GEMM_STEP(s + 3, 1, 1, 0);
+        if (s + 4 >= ns) break;
+        HICOM_GEMM_STEP(s + 4, 0, 2, 1);
+        if (s + 5 >= ns) break;
+        HICOM_GEMM_STEP(s + 5, 1, 0, 2);
     }
+#undef HICOM_GEMM_STEP
 
     // epilogue: bias, activation, packed-row store.  C layout: col = lane & 15, rows 4*kg + j.
 #pragma unroll

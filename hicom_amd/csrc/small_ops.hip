@@ -44,6 +44,11 @@ struct LinearParams {
     int M, N, K;
     int head_rows, head_dim;
     int act;
+    // optional second destination: row m is replicated to rows row0 + m + k*M (k < reps) of a packed
+    // [*, ldd] tensor of dtype dst (the 32 global rows of the output, projector.py:646,707)
+    void* dst;
+    int dst_f32, reps;
+    long ldd, row0;
 };
 
 template <bool F32>
@@ -101,7 +106,14 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(LinearParams p) {
                 const long ri = ((p.res_flags & 1) ? 0 : (long)m * p.N) + n;
                 v += (p.res_flags & 2) ? bf16_to_f32(reinterpret_cast<const uint16_t*>(p.res)[ri]) : reinterpret_cast<const float*>(p.res)[ri];
             }
-            p.y[(long)m * p.N + n] = v;
+            if (p.y) p.y[(long)m * p.N + n] = v;
+            if (p.dst) {
+                for (int k = 0; k < p.reps; ++k) {
+                    const long o = (p.row0 + m + (long)k * p.M) * p.ldd + n;
+                    if (p.dst_f32) reinterpret_cast<float*>(p.dst)[o] = v;
+                    else reinterpret_cast<uint16_t*>(p.dst)[o] = f32_to_bf16(v);
+                }
+            }
         }
     }
 }
@@ -230,15 +242,8 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const void* src, int 
 
 using namespace hicom;
 
-extern "C" int hicom_linear_fwd(const void* x, int32_t x_dt, const void* w, int32_t w_dt,
-                                const void* b, int32_t b_dt, const void* res, int32_t res_flags,
-                                int32_t M, int32_t N, int32_t K, int32_t head_rows, int32_t head_dim,
-                                int32_t act, float* y, void* stream) {
-    HICOM_REQUIRE(x && w && y, HICOM_EINVAL, "linear: NULL pointer");
-    HICOM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0, HICOM_EINVAL, "linear: bad shape M=%d N=%d K=%d (K %% 8)", M, N, K);
-    HICOM_REQUIRE(head_dim == 0 || (head_dim > 0 && head_rows > 0), HICOM_EINVAL, "linear: head mode");
-    LinearParams p{x, w, b, res, y, x_dt == HICOM_DT_F32, w_dt == HICOM_DT_F32, b_dt == HICOM_DT_F32, res_flags,
-                   M, N, K, head_rows, head_dim, act};
+static int launch_linear(const LinearParams& p, void* stream) {
+    const int M = p.M, N = p.N;
     hipStream_t s = (hipStream_t)stream;
 #define HICOM_LAUNCH_LINEAR(MR)                                                                                        \
     do {                                                                                                               \
@@ -253,6 +258,33 @@ extern "C" int hicom_linear_fwd(const void* x, int32_t x_dt, const void* w, int3
 #undef HICOM_LAUNCH_LINEAR
     return hicom_host::check_launch("linear");
 }
+
+extern "C" int hicom_linear_fwd(const void* x, int32_t x_dt, const void* w, int32_t w_dt,
+                                const void* b, int32_t b_dt, const void* res, int32_t res_flags,
+                                int32_t M, int32_t N, int32_t K, int32_t head_rows, int32_t head_dim,
+                                int32_t act, float* y, void* stream) {
+    HICOM_REQUIRE(x && w && y, HICOM_EINVAL, "linear: NULL pointer");
+    HICOM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0, HICOM_EINVAL, "linear: bad shape M=%d N=%d K=%d (K %% 8)", M, N, K);
+    HICOM_REQUIRE(head_dim == 0 || (head_dim > 0 && head_rows > 0), HICOM_EINVAL, "linear: head mode");
+    LinearParams p{x, w, b, res, y, x_dt == HICOM_DT_F32, w_dt == HICOM_DT_F32, b_dt == HICOM_DT_F32, res_flags,
+                   M, N, K, head_rows, head_dim, act, nullptr, 0, 0, 0, 0};
+    return launch_linear(p, stream);
+}
+
+extern "C" int hicom_linear_to_rows_fwd(const void* x, int32_t x_dt, const void* w, int32_t w_dt,
+                                        const void* b, int32_t b_dt, int32_t M, int32_t N, int32_t K, int32_t act,
+                                        void* dst, int32_t dst_dt, int64_t ldd, int64_t row0, int32_t n_rows,
+                                        void* stream) {
+    HICOM_REQUIRE(x && w && dst, HICOM_EINVAL, "linear_to_rows: NULL pointer");
+    HICOM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && n_rows >= M && n_rows % M == 0 && ldd >= N, HICOM_EINVAL,
+                  "linear_to_rows: bad shape M=%d N=%d K=%d rows=%d", M, N, K, n_rows);
+    LinearParams p{x, w, b, nullptr, nullptr, x_dt == HICOM_DT_F32, w_dt == HICOM_DT_F32, b_dt == HICOM_DT_F32, 0,
+                   M, N, K, 0, 0, act, dst, dst_dt == HICOM_DT_F32, n_rows / M, (long)ldd, (long)row0};
+    return launch_linear(p, stream);
+}
+
+
+
 
 static int launch_fold(const float* qp, const void* w_k, const float* kpe, int nq, int nh, int E, int P, float scale,
                        float* qt, void* hi, void* lo, float* pos_a, int pos_stride, void* stream) {

@@ -16,7 +16,9 @@ from . import native as nv
 
 class _DeviceResources:
     def __init__(self, device):
-        self.side = torch.cuda.Stream(device=device)
+        # high priority: the global chain is a string of small kernels that must not queue behind the
+        # thousands of workgroups of the local streaming kernel
+        self.side = torch.cuda.Stream(device=device, priority=-1)
         self.ev_fork = torch.cuda.Event()
         self.ev_join = torch.cuda.Event()
         # hipEventRecord needs created events: torch creates them lazily on first record
@@ -159,16 +161,23 @@ class _Plan:
         self.hits = 0
 
 
-_PLANS: Dict[Tuple, _Plan] = {}
-_MAX_PLANS = 16
+_MAX_PLANS = 16      # per projector; plans live ON the module (they point into its cached device tables)
 
 
 def _param_stamp(proj):
-    return tuple((p.data_ptr(), p._version) for p in proj.parameters())
+    """(pointer, version) of every parameter.  The parameter LIST is cached on the module (walking
+    nn.Module.parameters() costs tens of microseconds) and refreshed whenever the module is moved /
+    cast (_apply) or reloaded (load_state_dict); in-place updates bump `_version`."""
+    gen = proj.__dict__.get("_engine_params_gen", 0)
+    cached = proj.__dict__.get("_engine_params")
+    if cached is None or cached[0] != gen:
+        cached = (gen, [p for p in proj.parameters()])
+        proj.__dict__["_engine_params"] = cached
+    return tuple([(p.data_ptr(), p._version) for p in cached[1]])
 
 
 def _plan_key(proj, ff, fe, guide_embed, modal, image_newline, out_dtype):
-    return (id(proj), ff.data_ptr(), tuple(ff.shape), None if fe is None else fe.data_ptr(),
+    return (ff.data_ptr(), tuple(ff.shape), None if fe is None else fe.data_ptr(),
             None if guide_embed is None else guide_embed.data_ptr(), modal,
             None if image_newline is None else image_newline.data_ptr(), out_dtype,
             torch.cuda.current_stream(ff.device).cuda_stream,
@@ -192,7 +201,8 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype) -> tor
     ff = ff.contiguous()
     fe = fe.contiguous() if fe is not None else None
     key = _plan_key(proj, ff, fe, guide_embed, modal, image_newline, out_dtype) if cacheable else None
-    plan = _PLANS.get(key) if cacheable else None
+    plans = proj.__dict__.setdefault("_engine_plans", {})
+    plan = plans.get(key) if cacheable else None
     if plan is None:
         T, H, W, _ = ff.shape
         layout = None
@@ -209,9 +219,9 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype) -> tor
         nv.compressor_fwd(a)
         if cacheable:
             a._keep = None             # do not pin the caller's feature tensors
-            if len(_PLANS) >= _MAX_PLANS:
-                _PLANS.pop(next(iter(_PLANS)))
-            _PLANS[key] = _Plan(a, n_local + n_global, hidden)
+            if len(plans) >= _MAX_PLANS:
+                plans.pop(next(iter(plans)))
+            plans[key] = _Plan(a, n_local + n_global, hidden)
         return out
     plan.hits += 1
     a = plan.args

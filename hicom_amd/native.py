@@ -25,7 +25,7 @@ EXPORTS = (
     "hicom_global_stream_nparts", "hicom_global_merge_fwd", "hicom_global_combine_fwd",
     "hicom_readout_gemm_fwd", "hicom_scatter_rows_fwd", "hicom_fold_query_split_fwd",
     "hicom_global_combine_strided_fwd", "hicom_compressor_workspace_bytes", "hicom_compressor_zero_prefix_bytes",
-    "hicom_compressor_fwd",
+    "hicom_compressor_fwd", "hicom_linear_to_rows_fwd",
 )
 
 PHASE_STREAM, PHASE_FINISH = 1, 2
@@ -97,6 +97,7 @@ def lib() -> C.CDLL:
     L.hicom_global_stream_nparts.argtypes = [i64, i32]
     L.hicom_global_merge_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, i64, i64, i32, i32, vp, i32, i32, i32,
                                          vp, vp, vp, i32, vp]
+    L.hicom_linear_to_rows_fwd.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i64, i64, i32, vp]
     L.hicom_fold_query_split_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, i32, vp]
     L.hicom_global_combine_strided_fwd.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
     ap = C.POINTER(CompressorArgs)
@@ -247,3 +248,10 @@ def compressor_workspace(args: CompressorArgs):
 
 def compressor_fwd(args: CompressorArgs):
     _check(lib().hicom_compressor_fwd(C.byref(args)), "hicom_compressor_fwd")
+
+
+def linear_to_rows(x, w, b, dst, row0, n_rows, act=ACT_NONE):
+    N, K = w.shape
+    _check(lib().hicom_linear_to_rows_fwd(_ptr(x), _dt(x), _ptr(w), _dt(w), _ptr(b), _dt(b) if b is not None else 0,
+                                          x.shape[0], N, K, act, _ptr(dst), _dt(dst), dst.shape[-1], row0, n_rows,
+                                          _stream()), "hicom_linear_to_rows_fwd")

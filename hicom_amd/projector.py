@@ -404,6 +404,18 @@ class HIComProjector(nn.Module):
         self.use_executor = True     # dense inputs go through the one-call native executor (engine.py)
         self.graph_replay = False    # True: capture each cached plan into a hipGraph and replay it
 
+    def _invalidate_plans(self):
+        self.__dict__["_engine_params_gen"] = self.__dict__.get("_engine_params_gen", 0) + 1
+        self.__dict__.pop("_engine_plans", None)
+
+    def _apply(self, fn, *args, **kwargs):           # .to() / .cuda() / .bfloat16() ...
+        self._invalidate_plans()
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._invalidate_plans()
+        return super().load_state_dict(*args, **kwargs)
+
     def set_clip_logits(self, local=None, glob=None):
         if local is not None:
             self.local_logit_scale, self.local_logit_bias = local

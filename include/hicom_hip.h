@@ -86,6 +86,15 @@ int hicom_linear_fwd(const void* x, int32_t x_dt, const void* w, int32_t w_dt,
                      int32_t M, int32_t N, int32_t K, int32_t head_rows, int32_t head_dim,
                      int32_t act, float* y, void* stream);
 
+/* Same product, written straight into a packed output: row m of y goes to rows
+ * row0 + m + k*M, k < n_rows / M, of dst [*, ldd] (dtype dst_dt) -- the last Linear of the global
+ * readout filling the 32 global rows (projector.py:646,707; in "direct" mode M == 1 and the 32 rows
+ * are 32 copies). */
+int hicom_linear_to_rows_fwd(const void* x, int32_t x_dt, const void* w, int32_t w_dt,
+                             const void* b, int32_t b_dt, int32_t M, int32_t N, int32_t K, int32_t act,
+                             void* dst, int32_t dst_dt, int64_t ldd, int64_t row0, int32_t n_rows,
+                             void* stream);
+
 /* ---- fold k_proj into the queries ---------------------------------------------------------
  * qt[(q*nh + h), c] = scale * sum_j w_k[h*hd + j, c] * qp[q, h*hd + j]
  * so that score_h(n) = qt_h . x_n (+ a key-independent constant that softmax cancels):

@@ -280,3 +280,17 @@ def test_combine_strided_equals_dense():
     nv.global_combine(ml, acc, a)
     nv.global_combine_strided(buf, buf.view(-1)[2 * R:], stride, nsets, R, E, b)
     assert torch.equal(a, b)
+
+
+def test_linear_to_rows_replicates_and_casts():
+    M, N, K = 2, 64, 128
+    x = synth.normal_like((M, K), 71)
+    w = synth.normal_like((N, K), 72, 0.1)
+    b = synth.normal_like((N,), 73, 0.1)
+    y = f32((M, N))
+    nv.linear(torch.from_numpy(x).cuda(), bf(w), bf(b), y)
+    dst = torch.zeros((12, N), dtype=torch.bfloat16, device="cuda")
+    nv.linear_to_rows(torch.from_numpy(x).cuda(), bf(w), bf(b), dst, 3, 6)
+    for k in range(3):
+        assert torch.equal(dst[3 + 2 * k:5 + 2 * k], y.to(torch.bfloat16))
+    assert float(dst[:3].float().abs().max()) == 0.0 and float(dst[9:].float().abs().max()) == 0.0
