@@ -14,6 +14,8 @@
 // written into a double-buffered LDS image with 144-byte rows (conflict-free ds_read_b128
 // fragment reads), one workgroup barrier per stage.
 // The store applies the packing row map of post_process_visual_feature (mm_utils.py:100-135).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace hicom {
@@ -28,6 +30,7 @@ struct GemmParams {
     int y_f32;
     long ldy, row0;
     int nl_group;
+    int dbg;   // developer ablation switches (HICOM_GEMM_DBG): 1 skip MFMA phase, 2 skip LDS staging, 4 skip global loads
 };
 
 constexpr int kRowB = 144;                 // bytes per 64-element bf16 row (128 B data + 16 B pad)
@@ -77,7 +80,15 @@ __global__ __launch_bounds__(256, 2) void readout_gemm_kernel(GemmParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (id % 8), each with
+    // a private 4 MiB L2: all column tiles of one 64-row block of x run on ONE XCD, so that block
+    // (295 KB fp32) is fetched from the Infinity Cache once per XCD pass and the weight matrix
+    // (<= 2-25 MB) streams through; a plain (x,y) grid makes every XCD touch all of x AND w.
+    const int nbx = (p.N + 63) >> 6, nby = (p.M + 63) >> 6;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int by = xcd + 8 * (slot / nbx), bx = slot - (slot / nbx) * nbx;
+    if (by >= nby) return;
+    const int m0 = by * 64, n0 = bx * 64;
     const int r16 = lane & 15, kg = lane >> 4;
 
     // staging assignment (see stage_load): clamp tail rows to a valid row, masked at the store
@@ -105,8 +116,8 @@ __global__ __launch_bounds__(256, 2) void readout_gemm_kernel(GemmParams p) {
     const int ns = p.K / 64;
     Stage st[3];
     stage_load(st[0], xa, wb, 0);
-    if (ns > 1) stage_load(st[1], xa, wb, 64);
-    if (ns > 2) stage_load(st[2], xa, wb, 128);
+    stage_load(st[1], xa, wb, ns > 1 ? 64 : 0);
+    stage_load(st[2], xa, wb, ns > 2 ? 128 : 64 * (ns - 1));
     stage_store(st[0], lds, tid);
     __syncthreads();
 
@@ -133,30 +144,26 @@ __global__ __launch_bounds__(256, 2) void readout_gemm_kernel(GemmParams p) {
 
     // Stage i lives in register set i % 3 while in flight and in LDS buffer i % 2 once staged.
     // Step S: issue the loads of stage S+3 (into the set stage S just vacated), compute stage S from
-    // LDS, then convert + store stage S+1 (loaded two steps ago) into the other LDS buffer.  The
-    // sched_barriers pin that order: without them hipcc hoists the wait-and-convert of stage S+1
-    // above the MFMAs and the prefetch distance collapses to zero.
-#define HICOM_GEMM_STEP(S, CUR, NXT, FREE)                                            \
-    do {                                                                              \
-        if ((S) + 3 < ns) stage_load(st[FREE], xa, wb, 64 * ((S) + 3));               \
-        __builtin_amdgcn_sched_barrier(0);                                            \
-        compute(lds + (CUR)*kBufB);                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                            \
-        if ((S) + 1 < ns) stage_store(st[NXT], lds + ((CUR) ^ 1) * kBufB, tid);       \
-        __syncthreads();                                                              \
+    // LDS, then convert + store stage S+1 (loaded two steps ago) into the other LDS buffer.
+    // The loop body is deliberately BRANCH-FREE around the loads and stores (tail stages re-load
+    // the last stage and store it where nobody reads): with conditional loads hipcc's waitcnt
+    // pass loses count at the merge points and drains vmcnt(0) before every barrier, which
+    // collapses the prefetch distance to zero.  The sched_barriers pin load / MFMA / store order.
+    const int last_k = 64 * (ns - 1);
+#define HICOM_GEMM_STEP(S, NXT, FREE)                                                     \
+    do {                                                                                  \
+        const int kl = 64 * ((S) + 3);                                                    \
+        if (!(p.dbg & 4)) stage_load(st[FREE], xa, wb, kl < last_k ? kl : last_k);        \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        if ((S) < ns && !(p.dbg & 1)) compute(lds + ((S)&1) * kBufB);                     \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        if (!(p.dbg & 2)) stage_store(st[NXT], lds + (((S) + 1) & 1) * kBufB, tid);       \
+        __syncthreads();                                                                  \
     } while (0)
-    for (int s = 0; s < ns; s += 6) {
-        HICOM_GEMM_STEP(s, 0, 1, 0);
-        if (s + 1 >= ns) break;
-        HICOM_GEMM_STEP(s + 1, 1, 2, 1);
-        if (s + 2 >= ns) break;
-        HICOM_GEMM_STEP(s + 2, 0, 0, 2);
-        if (s + 3 >= ns) break;
-        HICOM_GEMM_STEP(s + 3, 1, 1, 0);
-        if (s + 4 >= ns) break;
-        HICOM_GEMM_STEP(s + 4, 0, 2, 1);
-        if (s + 5 >= ns) break;
-        HICOM_GEMM_STEP(s + 5, 1, 0, 2);
+    for (int s = 0; s < ns; s += 3) {
+        HICOM_GEMM_STEP(s, 1, 0);
+        HICOM_GEMM_STEP(s + 1, 2, 1);
+        HICOM_GEMM_STEP(s + 2, 0, 2);
     }
 #undef HICOM_GEMM_STEP
 
@@ -196,8 +203,9 @@ extern "C" int hicom_readout_gemm_fwd(const float* x, const void* w, const void*
     HICOM_REQUIRE(ldy >= N && row0 >= 0 && nl_group >= 0, HICOM_EINVAL, "readout_gemm: bad output layout");
     HICOM_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0), HICOM_EINVAL, "readout_gemm: alignment");
     GemmParams p{x, (const uint16_t*)w, b, b_dt == HICOM_DT_F32, M, N, K, act, y, y_dt == HICOM_DT_F32,
-                 (long)ldy, (long)row0, nl_group};
-    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
+                 (long)ldy, (long)row0, nl_group, getenv("HICOM_GEMM_DBG") ? atoi(getenv("HICOM_GEMM_DBG")) : 0};
+    const int nbx = (N + 63) / 64, nby = (M + 63) / 64;
+    dim3 grid((unsigned)(8 * nbx * ((nby + 7) / 8)));
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(readout_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -1,0 +1,36 @@
+"""Dev tool: per-kernel timings (HIP events, back-to-back launches) at the C2 shape."""
+import math, sys, torch
+sys.path.insert(0, ".")
+from hicom_amd import native as nv, geometry as geo
+dev = "cuda"
+T, H, W, E, HID = 64, 27, 27, 1152, 896
+ff = torch.randn(T, H, W, E, device=dev).bfloat16(); fe = torch.randn_like(ff); g = torch.randn(E, device=dev).bfloat16()
+def timeit(fn, n=50):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+which = sys.argv[1:] or ["gemm", "local", "stream", "merge", "lin"]
+if "gemm" in which:
+    x = torch.randn(1296, E, device=dev); w0 = torch.randn(HID, E, device=dev).bfloat16() * 0.02; b0 = torch.zeros(HID, device=dev).bfloat16()
+    w2 = torch.randn(HID, HID, device=dev).bfloat16() * 0.02
+    hid = torch.empty(1296, HID, device=dev); out = torch.empty(1296, HID, device=dev, dtype=torch.bfloat16)
+    t1 = timeit(lambda: nv.readout_gemm(x, w0, b0, hid, act=1)); t2 = timeit(lambda: nv.readout_gemm(hid, w2, b0, out))
+    print("gemm1 %.1f us (%.0f TF incl hi/lo)  gemm2 %.1f us" % (t1, 2 * 2 * 1296 * HID * E / t1 / 1e6, t2))
+if "local" in which:
+    axes = tuple(nv.Axis(a.n, a.k, a.nwin, a.nfull) for a in (geo.axis_tiling(T, 4), geo.axis_tiling(H, 3), geo.axis_tiling(W, 3)))
+    ctx = torch.empty(1296, E, device=dev)
+    t = timeit(lambda: nv.local_attn(fe, ff, axes, g, 0, 1 / math.sqrt(E), 0.0, 0, ctx))
+    print("local_attn %.1f us  %.2f TB/s" % (t, 2 * ff.numel() * 2 / t / 1e6))
+if "stream" in which:
+    N = T * H * W
+    qhi = (torch.randn(16, E, device=dev) * 0.05).bfloat16(); qlo = (qhi.float() * 1e-3).bfloat16(); qhi[9:] = 0; qlo[9:] = 0
+    pos_a = torch.randn(16, 64 + 54, device=dev) * 0.1
+    for nparts in (256, 512, 768):
+        scores = torch.empty(16, (N + 15) // 16 * 16, device=dev)
+        pm, pl, pacc = torch.empty(nparts, 16, device=dev), torch.empty(nparts, 16, device=dev), torch.empty(nparts, 16, E, device=dev)
+        t = timeit(lambda: nv.global_stream(ff, N, qhi, qlo, pos_a, H, W, 0, 64, 64 + H, scores, pm, pl, pacc, rows=9))
+        print("global_stream nparts=%d %.1f us  %.2f TB/s" % (nparts, t, ff.numel() * 2 / t / 1e6))
