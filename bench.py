@@ -8,8 +8,8 @@ already resident in HBM: 64 frames x 729 tokens x 1152 bf16 PER GPU (BASELINE.js
 N GPUs => 64*N frames frame-sharded with one RCCL all-gather, configs[2], weak scaling).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     dominant kernel's ALGORITHMIC bytes / its mean launch time (HIP events on its own
-               stream, measured here) against the 8 TB/s HBM3E peak
+  roofline     dominant kernel (the fused local+global stream): ALGORITHMIC bytes / its mean launch
+               time (HIP events on its own stream, measured here) against the 8 TB/s HBM3E peak
   cpu_baseline the CPU oracle (a port of the reference's PyTorch path) timed on this host's
                cores on the same 64-frame workload (bounded number of repetitions)
 """
@@ -187,30 +187,52 @@ def main():
 
 
 def dominant_kernel_roofline(module, ff, fe, guide, iters):
-    """local_attn_kernel streams both visual tensors (frames_embed + frames_feature) once: its
-    algorithmic bytes are SURVEY.md §8(d)'s 3,359,232 B per frame x frames (+ the fp32 contexts)."""
-    lc = module.local_compressor
+    """fused_stream_kernel reads both visual tensors (frames_embed + frames_feature) exactly once and
+    produces the local contexts and the global partial state: its algorithmic bytes are SURVEY.md
+    §8(d)'s 3,359,232 B per frame x frames (+ the fp32 local contexts it writes)."""
+    lc, gc = module.local_compressor, module.global_compressor
     T, H, W, _ = ff.shape
+    dev = ff.device
     at, ay, ax = lc.tilings(T, H, W, "video")
-    axes = tuple(nv.Axis(a.n, a.k, a.nwin, a.nfull) for a in (at, ay, ax))
     nw = at.nwin * ay.nwin * ax.nwin
-    ctx = torch.empty((nw, D), dtype=torch.float32, device=ff.device)
+    R = gc.attn_layer.num_heads
+    qhi = (torch.randn(16, D, device=dev) * 0.05).to(torch.bfloat16)
+    qlo = (torch.randn(16, D, device=dev) * 1e-4).to(torch.bfloat16)
+    qhi[R:] = guide
+    qlo[R:] = 0
+    pos_a = torch.randn(16, T + H + W, device=dev) * 0.1
+    nparts = nv.fused_stream_nparts(nw)
+    scores = torch.empty(16, T * H * W, device=dev)
+    pm, pl = torch.empty(nparts, 16, device=dev), torch.empty(nparts, 16, device=dev)
+    pacc = torch.empty(nparts, 16, D, device=dev)
+    ctx = torch.empty(nw, D, device=dev)
+
+    def launch():
+        nv.fused_stream(ff, fe, at.k, ay.k, qhi, qlo, R, 1.0 / D ** 0.5, 0.0, pos_a, 0, T, T + H, scores, pm, pl, pacc, ctx)
+
     stream = torch.cuda.current_stream()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for _ in range(3):
-        nv.local_attn(fe, ff, axes, guide, 0, 1.0 / D ** 0.5, 0.0, 0, ctx)
+        launch()
     torch.cuda.synchronize()
     for a, b in evs:
         a.record(stream)
-        nv.local_attn(fe, ff, axes, guide, 0, 1.0 / D ** 0.5, 0.0, 0, ctx)
+        launch()
         b.record(stream)
     torch.cuda.synchronize()
     ms = sorted(a.elapsed_time(b) for a, b in evs)
     mean_ms = sum(ms) / len(ms)
     alg_bytes = 3359232 * T + nw * D * 4
     achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
-    return {"kernel": "hicom::local_attn_kernel<3>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+    traffic = None
+    try:   # HBM bytes per launch from the committed PMC pass of this same workload (profiles/)
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic.json")))
+        if prof.get("frames") == T:
+            traffic = prof["kernels"]["fused_stream_kernel"]["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        pass
+    return {"kernel": "hicom::fused_stream_kernel<9>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": mean_ms, "min_launch_ms": ms[0]}
 
 

@@ -29,6 +29,24 @@ struct WsLayout {
     long N, score_stride;
 };
 
+// The fused local+global stream kernel applies to the release recipe: shared bf16 local query
+// ("direct"), plain 1/sqrt(d) logits, windows that partition the grid, <= 14 folded global rows.
+bool can_fuse(const hicom_compressor_args& a) {
+    if (!(a.has_local && a.has_global) || !a.lq || a.lq_stride != 0 || a.lq_dt != HICOM_DT_BF16 || a.l2norm != 0) return false;
+    if (a.E != 1152 || a.nq * a.nh > 14) return false;
+    for (const hicom_axis* x : {&a.at, &a.ay, &a.ax})
+        if (x->n % x->k != 0 || x->nfull != x->nwin) return false;
+    if (a.ay.k != a.ax.k) return false;
+    const int wsz = a.at.k * a.ay.k * a.ax.k;
+    if (wsz < 16 || wsz > 64 || a.H >= 256 || a.W >= 256) return false;
+    const int R = a.nq * a.nh;
+    if (2 * 9 * 4096 + 4096 + (64 + 64 + 64) * 4 + R * (16 + a.H + a.W) * 4 > 81920) return false;
+    const int nw = a.at.nwin * a.ay.nwin * a.ax.nwin, per_t = a.ay.nwin * a.ax.nwin;
+    const int nparts = hicom_fused_stream_nparts(nw);
+    const int wpw = (nw + nparts - 1) / nparts;
+    return ((wpw + per_t - 2) / per_t + 1) * a.at.k <= 16;
+}
+
 WsLayout make_layout(const hicom_compressor_args& a) {
     WsLayout w;
     memset(&w, 0, sizeof(w));
@@ -38,7 +56,7 @@ WsLayout make_layout(const hicom_compressor_args& a) {
     w.rows_pad = (w.R + 15) / 16 * 16;
     w.P = a.P;
     w.score_stride = (w.N + 15) / 16 * 16;
-    w.nparts = a.has_global ? hicom_global_stream_nparts(w.N, w.rows_pad) : 0;
+    w.nparts = !a.has_global ? 0 : (can_fuse(a) ? hicom_fused_stream_nparts(w.nw) : hicom_global_stream_nparts(w.N, w.rows_pad));
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align256(off + bytes); return o; };
     // zero-initialised-once region first (padding rows that no kernel ever writes)
@@ -118,60 +136,80 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
     hipStream_t sm = (hipStream_t)a.stream_main, ss = (hipStream_t)a.stream_side;
     const bool both = a.has_local && a.has_global;
     const bool do_stream = a.phases & HICOM_PHASE_STREAM, do_finish = a.phases & HICOM_PHASE_FINISH;
+    const bool fused = do_stream && can_fuse(a);
     // the global chain runs on the side stream only when there is local work to overlap it with
     hipStream_t sg = (both && do_stream) ? ss : sm;
+    const float qscale = a.has_global ? 1.0f / sqrtf((float)(a.E / a.nh)) : 0.f;
+    const bool solo = a.state_out == nullptr;   // single shard: the merge normalises, no combine needed
+    float* ml_out = solo ? F(w.ml) : (float*)a.state_out;
+    float* acc_out = solo ? F(w.ctx_g) : (float*)a.state_out + 2 * w.R;
 
-    if (both && do_stream) {
+    auto fork = [&]() -> int {
         HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_fork, sm) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
         HICOM_REQUIRE(hipStreamWaitEvent(ss, (hipEvent_t)a.ev_fork, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
-    }
-
-    // Host enqueue order matters (each launch costs a few us of host time): the long local
-    // attention kernel goes first so that the side chain is enqueued while it runs.
-    // ------------------------------------------------------------------ local chain: attention
-    if (a.has_local && do_stream) {
-        const void* q = a.lq;
-        int q_dt = a.lq_dt;
-        int64_t q_stride = a.lq_stride;
-        if (!q) {   // guide off: per-window pooled query
-            CHK(hicom_trilinear_pool_fwd(a.ff, a.T, a.H, a.W, a.E, a.at.nwin, a.ay.nwin, a.ax.nwin, F(w.pooled_q), sm));
-            q = F(w.pooled_q);
-            q_dt = HICOM_DT_F32;
-            q_stride = a.E;
-        }
-        CHK(hicom_local_attn_fwd(a.fe ? a.fe : a.ff, a.ff, a.E, a.at, a.ay, a.ax, q, q_dt, q_stride, a.l_scale, a.l_bias,
-                                 a.l2norm, F(w.ctx_local), sm));
-    }
-
-    // ------------------------------------------------------------------ global chain, part 1
-    if (a.has_global && do_stream) {
+        return HICOM_OK;
+    };
+    auto query_prep = [&](hipStream_t st) -> int {
         CHK(hicom_linear_fwd(a.gq, HICOM_DT_BF16, a.wq, HICOM_DT_BF16, a.bq, HICOM_DT_BF16, nullptr, 0, a.nq, a.E, a.E,
-                             0, 0, HICOM_ACT_NONE, F(w.qp), sg));
-        const float scale = 1.0f / sqrtf((float)(a.E / a.nh));
-        CHK(hicom_fold_query_split_fwd(F(w.qp), a.wk, a.kpe, a.nq, a.nh, a.E, a.P, scale, ws + w.qhi, ws + w.qlo,
-                                       F(w.pos_a), a.P, sg));
-        CHK(hicom_global_stream_fwd(a.ff, w.N, a.E, ws + w.qhi, ws + w.qlo, w.R, w.rows_pad,
-                                    a.pe ? F(w.pos_a) : nullptr, a.P, a.H, a.W, a.t_index0, a.y_index0, a.x_index0,
-                                    F(w.scores), w.score_stride, F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, sg));
-        // single shard: the merge normalises in place and no combine is needed
-        const bool solo = a.state_out == nullptr;
-        float* ml = solo ? F(w.ml) : (float*)a.state_out;
-        float* acc = solo ? F(w.ctx_g) : (float*)a.state_out + 2 * w.R;
-        CHK(hicom_global_merge_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E,
-                                   F(w.scores), w.score_stride, w.N, a.H, a.W, a.pe, a.t_index0, a.y_index0, a.x_index0,
-                                   F(w.scratch), ml, acc, solo ? 1 : 0, sg));
-    }
-
-    // ------------------------------------------------------------------ local chain: readout
-    if (a.has_local && do_stream) {
+                             0, 0, HICOM_ACT_NONE, F(w.qp), st));
+        return hicom_fold_query_split_fwd(F(w.qp), a.wk, a.kpe, a.nq, a.nh, a.E, a.P, qscale, ws + w.qhi, ws + w.qlo,
+                                          F(w.pos_a), a.P, st);
+    };
+    auto merge = [&](hipStream_t st) -> int {
+        return hicom_global_merge_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E,
+                                      F(w.scores), w.score_stride, w.N, a.H, a.W, a.pe, a.t_index0, a.y_index0,
+                                      a.x_index0, F(w.scratch), ml_out, acc_out, solo ? 1 : 0, st);
+    };
+    auto local_readout = [&](hipStream_t st) -> int {
         CHK(hicom_readout_gemm_fwd(F(w.ctx_local), a.lw0, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E, HICOM_ACT_GELU,
-                                   F(w.hid_local), HICOM_DT_F32, a.hidden, 0, 0, sm));
+                                   F(w.hid_local), HICOM_DT_F32, a.hidden, 0, 0, st));
         CHK(hicom_readout_gemm_fwd(F(w.hid_local), a.lw2, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden, HICOM_ACT_NONE,
                                    a.local_out ? a.local_out : a.out, a.out_dt, a.local_out ? a.hidden : a.ldo,
-                                   a.local_out ? 0 : a.local_row0, a.local_out ? 0 : a.nl_group, sm));
+                                   a.local_out ? 0 : a.local_row0, a.local_out ? 0 : a.nl_group, st));
         if (a.nl_count > 0 && !a.local_out)
             CHK(hicom_scatter_rows_fwd(a.newline, a.newline_dt, 1, a.hidden, a.out, a.out_dt, a.ldo, a.nl_first, a.nl_step,
-                                       0, a.nl_count, sm));
+                                       0, a.nl_count, st));
+        return HICOM_OK;
+    };
+
+    if (fused) {
+        // ---- release recipe: ONE streaming kernel reads frames_embed and frames_feature once ------
+        // main: guide -> local rows of the A operand, q_proj, fold, fused stream | fork |
+        // main: readout GEMMs            side: merge -> (finish)                 | join |
+        CHK(hicom_scatter_rows_fwd(a.lq, HICOM_DT_BF16, 1, a.E, ws + w.qhi, HICOM_DT_BF16, a.E, w.R, 1, 0, 16 - w.R, sm));
+        CHK(query_prep(sm));
+        CHK(hicom_fused_stream_fwd(a.ff, a.fe ? a.fe : a.ff, a.T, a.H, a.W, a.E, a.at.k, a.ay.k, ws + w.qhi, ws + w.qlo,
+                                   w.R, a.l_scale, a.l_bias, a.pe ? F(w.pos_a) : nullptr, a.P, a.t_index0, a.y_index0,
+                                   a.x_index0, F(w.scores), w.score_stride, F(w.part_m), F(w.part_l), F(w.part_acc),
+                                   w.nparts, F(w.ctx_local), sm));
+        CHK(fork());
+        CHK(merge(ss));
+        CHK(local_readout(sm));
+    } else if (do_stream) {
+        if (both) CHK(fork());
+        // Host enqueue order matters (each launch costs a few us of host time): the long local
+        // attention kernel goes first so that the side chain is enqueued while it runs.
+        if (a.has_local) {
+            const void* q = a.lq;
+            int q_dt = a.lq_dt;
+            int64_t q_stride = a.lq_stride;
+            if (!q) {   // guide off: per-window pooled query
+                CHK(hicom_trilinear_pool_fwd(a.ff, a.T, a.H, a.W, a.E, a.at.nwin, a.ay.nwin, a.ax.nwin, F(w.pooled_q), sm));
+                q = F(w.pooled_q);
+                q_dt = HICOM_DT_F32;
+                q_stride = a.E;
+            }
+            CHK(hicom_local_attn_fwd(a.fe ? a.fe : a.ff, a.ff, a.E, a.at, a.ay, a.ax, q, q_dt, q_stride, a.l_scale,
+                                     a.l_bias, a.l2norm, F(w.ctx_local), sm));
+        }
+        if (a.has_global) {
+            CHK(query_prep(sg));
+            CHK(hicom_global_stream_fwd(a.ff, w.N, a.E, ws + w.qhi, ws + w.qlo, w.R, w.rows_pad,
+                                        a.pe ? F(w.pos_a) : nullptr, a.P, a.H, a.W, a.t_index0, a.y_index0, a.x_index0,
+                                        F(w.scores), w.score_stride, F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, sg));
+            CHK(merge(sg));
+        }
+        if (a.has_local) CHK(local_readout(sm));
     }
 
     // ------------------------------------------------------------------ global chain, part 2

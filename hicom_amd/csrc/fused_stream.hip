@@ -1,0 +1,370 @@
+// Fused hybrid-level compressor stream: LOCAL windowed attention + GLOBAL multi-head attention in
+// ONE pass over the visual tokens -- frames_embed and frames_feature are each read from HBM
+// exactly once ("local + global share the value stream").
+//
+// Replaces, for the release recipe (use_guide = direct, exact window partition), both
+//   LocalCompressor.forward  windows/bmm/softmax/bmm   (reference projector.py:544-558) and
+//   MultiheadAttention.forward QK^T/softmax/PV          (reference projector.py:193-215).
+//
+// One 16-row MFMA operand carries BOTH problems:
+//   rows 0 .. R-1   : folded global queries qt_h (bf16 hi + lo), scored against frames_feature
+//   rows R .. 15    : the local query (guide), scored against frames_embed; row R + (w mod NLOC)
+//                     belongs to window w, other windows' tokens are masked out of that row
+// so the P.x product (v_mfma_f32_16x16x16_bf16 against the frames_feature tile) accumulates the 9
+// global head contexts AND the open windows' local contexts in the same 72 accumulator VGPRs.
+//
+// Token order: a workgroup walks a contiguous range of windows in window-major order (the 36
+// tokens of a window, then the next window), 16 tokens per tile.  A window spans <= 4 tiles and
+// at most 2 windows are open per tile, so NLOC = 16 - R >= 2 local rows suffice; when a window's
+// last token has been accumulated its row is normalised, written to ctx_local and recycled.
+//
+// Per tile: frames_feature rows -> LDS by LDS-DMA (same swizzled image as global_stream.hip:
+// row reads for the score B operand, transposed reads for the P.x B operand); frames_embed goes
+// straight from HBM into B-fragment registers (it is only needed once, by the local score).
+// Positional logit terms come from small per-workgroup LDS tables (a_t for the <= 16 frames a
+// workgroup touches, a_y, a_x), so the tile loop contains no ordinary global load whose in-order
+// vmcnt would drain the LDS-DMA prefetch.
+#include "common.hpp"
+
+namespace hicom {
+
+constexpr int kMaxWinPerWg = 32;
+constexpr int kMaxFramesPerWg = 16;
+
+struct FusedParams {
+    const uint16_t* ff;
+    const uint16_t* fe;
+    int T, H, W;
+    int kt, ks, nwy, nwx, NW, WSZ;
+    const uint16_t* qhi;   // [16][E]  rows < R: qt hi ; rows >= R: local query (exact bf16)
+    const uint16_t* qlo;   // [16][E]  rows < R: qt lo ; rows >= R: zero
+    int R;
+    float l_scale, l_bias;
+    const float* pos_a;    // [16][pos_stride] or NULL
+    int pos_stride, t0i, y0i, x0i;
+    float* scores;         // [16][score_stride], token-indexed, rows < R
+    long score_stride;
+    float* part_m;
+    float* part_l;
+    float* part_acc;       // [nparts][16][E], rows < R
+    float* ctx_local;      // [NW][E]
+    int wpw;               // windows per workgroup
+};
+
+__device__ __forceinline__ int fswz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+__device__ __forceinline__ int fsig(int g) { return ((g & 1) << 1) | (g >> 1); }
+
+template <int NB>
+__global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
+    constexpr int E = NB * 128;
+    constexpr int SLICE = E / 4;
+    constexpr int KSTEPS = SLICE / 32;
+    constexpr int CBLK = SLICE / 16;
+    constexpr int TILE_BYTES = NB * 4096;
+    constexpr int PIECES = NB * 4;
+    static_assert(PIECES % 4 == 0, "pieces are dealt round-robin to the 4 waves");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* tilebuf = smem;                                              // [2][TILE_BYTES]
+    float* red = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);     // [4][16][16]
+    int* win_off = reinterpret_cast<int*>(red + 1024);                 // [64] token offset of in-window index
+    int* win_txy = win_off + 64;                                       // [64] packed (t2 << 16 | h2 << 8 | w2)
+    int* worg = win_txy + 64;                                          // [kMaxWinPerWg] window origin token
+    int* wtxy = worg + kMaxWinPerWg;                                   // [kMaxWinPerWg] packed (t0 << 16 | y0 << 8 | x0) window base coords
+    float* a_t = reinterpret_cast<float*>(wtxy + kMaxWinPerWg);        // [R][kMaxFramesPerWg]
+    float* a_y = a_t + p.R * kMaxFramesPerWg;                          // [R][H]
+    float* a_x = a_y + p.R * p.H;                                      // [R][W]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int part = blockIdx.x;
+    const int wb = part * p.wpw;
+    const int we = min(p.NW, wb + p.wpw);
+    const int nwin = we - wb;
+    const int total = nwin * p.WSZ;                 // tokens of this workgroup's stream
+    const int ntile = (total + 15) >> 4;
+    const int R = p.R, NLOC = 16 - R;
+    const int HW = p.H * p.W, ks2 = p.ks * p.ks;
+
+    // ---- per-workgroup tables -----------------------------------------------------------------
+    if (tid < p.WSZ) {
+        const int t2 = tid / ks2, r = tid - t2 * ks2, h2 = r / p.ks, w2 = r - h2 * p.ks;
+        win_off[tid] = (t2 * p.H + h2) * p.W + w2;
+        win_txy[tid] = (t2 << 16) | (h2 << 8) | w2;
+    }
+    const int t1_first = wb / (p.nwy * p.nwx);
+    if (tid < nwin) {
+        const int w = wb + tid;
+        const int t1 = w / (p.nwy * p.nwx), r = w - t1 * (p.nwy * p.nwx), h1 = r / p.nwx, w1 = r - h1 * p.nwx;
+        worg[tid] = (t1 * p.kt * p.H + h1 * p.ks) * p.W + w1 * p.ks;
+        wtxy[tid] = (((t1 - t1_first) * p.kt) << 16) | ((h1 * p.ks) << 8) | (w1 * p.ks);
+    }
+    if (p.pos_a) {
+        for (int i = tid; i < R * kMaxFramesPerWg; i += 256) {
+            const int r = i / kMaxFramesPerWg, f = i - r * kMaxFramesPerWg;
+            const int t = t1_first * p.kt + f;
+            a_t[r * kMaxFramesPerWg + f] = t < p.T ? p.pos_a[(long)r * p.pos_stride + p.t0i + t] : 0.f;
+        }
+        for (int i = tid; i < R * p.H; i += 256) a_y[i] = p.pos_a[(long)(i / p.H) * p.pos_stride + p.y0i + (i % p.H)];
+        for (int i = tid; i < R * p.W; i += 256) a_x[i] = p.pos_a[(long)(i / p.W) * p.pos_stride + p.x0i + (i % p.W)];
+    }
+
+    // ---- A operand (hi / lo) of this wave's channel slice ----------------------------------------
+    bf16x8 ahi[KSTEPS], alo[KSTEPS];
+    {
+        const long off = (long)r16 * E + SLICE * wave + 8 * kg;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            ahi[s] = *reinterpret_cast<const bf16x8*>(p.qhi + off + 32 * s);
+            alo[s] = *reinterpret_cast<const bf16x8*>(p.qlo + off + 32 * s);
+        }
+    }
+    f32x4 acc[CBLK];
+#pragma unroll
+    for (int cb = 0; cb < CBLK; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -1.0e30f, l_run = 0.f;
+
+    __syncthreads();   // tables ready
+
+    // stream slot -> token index (clamped to the last valid slot of this workgroup)
+    auto token_of = [&](int s) -> long {
+        s = s < total ? s : total - 1;
+        const int wr = s / p.WSZ, i = s - wr * p.WSZ;
+        return (long)worg[wr] + win_off[i];
+    };
+
+    auto stage = [&](int tile, int buf) {
+        const int row = 4 * wave + (lane >> 4), cpos = lane & 15;      // pieces of wave w cover rows 4w..4w+3
+        const long tok = token_of(tile * 16 + row);
+        const char* src = reinterpret_cast<const char*>(p.ff) + tok * (long)(E * 2) + 16 * (cpos ^ fswz(row));
+#pragma unroll
+        for (int i = 0; i < PIECES / 4; ++i) {
+            const int pi = wave + 4 * i;                                // pi & 3 == wave, blk = i
+            char* dst = tilebuf + buf * TILE_BYTES + pi * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 256),
+                                             (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+        }
+    };
+
+    const int q4 = (lane >> 2) & 3, pp = lane & 3;
+    const int trow = 4 * fsig(kg) + q4;
+    const int rd_row_off = r16 * 256, rd_swz = fswz(r16);
+    const int tr_row_off = trow * 256 + 8 * (pp & 1), tr_swz = fswz(trow);
+
+    if (ntile > 0) stage(0, 0);
+
+    for (int tile = 0; tile < ntile; ++tile) {
+        const int cur = tile & 1;
+        const int s0 = tile * 16;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                               // [A]
+        // frames_embed B fragments of this tile: token slot r16, this wave's channel slice
+        bf16x8 bfe[KSTEPS];
+        {
+            const uint16_t* src = p.fe + token_of(s0 + r16) * E + SLICE * wave + 8 * kg;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) bfe[s] = *reinterpret_cast<const bf16x8*>(src + 32 * s);
+        }
+        if (tile + 1 < ntile) stage(tile + 1, cur ^ 1);
+        const char* img = tilebuf + cur * TILE_BYTES;
+
+        // ---- global logits (rows < R) from the frames_feature tile in LDS -----------------------
+        f32x4 sff = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const int ch0 = SLICE * wave + 32 * s;
+            const int blk = ch0 >> 7, cbase = (ch0 & 127) >> 3;
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(img + blk * 4096 + rd_row_off + 16 * ((cbase + kg) ^ rd_swz));
+            sff = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[s], b, sff, 0, 0, 0);
+            sff = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[s], b, sff, 0, 0, 0);
+        }
+        // ---- local logits (rows >= R) from the frames_embed fragments -------------------------------
+        f32x4 sfe = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) sfe = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[s], bfe[s], sfe, 0, 0, 0);
+
+        float* rw = red + wave * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rw[(4 * kg + j) * 16 + r16] = (4 * kg + j < R) ? sff[j] : sfe[j];
+        lds_barrier();                                                 // [B]
+
+        const float* rb = red + r16 * 16 + 4 * fsig(kg);
+        f32x4 lg = *reinterpret_cast<const f32x4*>(rb);
+        lg += *reinterpret_cast<const f32x4*>(rb + 256);
+        lg += *reinterpret_cast<const f32x4*>(rb + 512);
+        lg += *reinterpret_cast<const f32x4*>(rb + 768);
+
+        // window bookkeeping of this tile (wave-uniform): slot 0 is token i0 of window wr0
+        const int wr0 = s0 / p.WSZ, i0 = s0 - wr0 * p.WSZ;
+        const int q0 = 4 * fsig(kg);
+        const bool is_glob = r16 < R;
+        bool valid[4];
+        float tmax = -1.0e30f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int s = s0 + q0 + j;
+            int i = i0 + q0 + j, wr = wr0;
+            if (i >= p.WSZ) { i -= p.WSZ; wr += 1; }
+            const bool in = s < total;
+            const int wsafe = in ? wr : 0;
+            if (is_glob) {
+                valid[j] = in;
+                if (p.pos_a) {
+                    const int txy = win_txy[i], base = wtxy[wsafe];
+                    const int f = (base >> 16) + (txy >> 16), y = ((base >> 8) & 255) + ((txy >> 8) & 255), x = (base & 255) + (txy & 255);
+                    lg[j] += a_t[r16 * kMaxFramesPerWg + f] + a_y[r16 * p.H + y] + a_x[r16 * p.W + x];
+                }
+                if (wave == 0 && in) p.scores[(long)r16 * p.score_stride + worg[wsafe] + win_off[i]] = lg[j];
+            } else {
+                valid[j] = in && ((wb + wr) % NLOC == r16 - R);
+                lg[j] = lg[j] * p.l_scale + p.l_bias;
+            }
+            tmax = valid[j] ? fmaxf(tmax, lg[j]) : tmax;
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = expf(m_run - m_new);
+        float pr[4], lsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pr[j] = valid[j] ? expf(lg[j] - m_new) : 0.f;
+            lsum += pr[j];
+        }
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+        bf16x4 phi, plo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint16_t h, l;
+            split_bf16(pr[j], h, l);
+            phi[j] = (short)h;
+            plo[j] = (short)l;
+        }
+        if (__any(alpha != 1.0f)) {
+            const float a0 = __shfl(alpha, 4 * kg + 0, 64), a1 = __shfl(alpha, 4 * kg + 1, 64);
+            const float a2 = __shfl(alpha, 4 * kg + 2, 64), a3 = __shfl(alpha, 4 * kg + 3, 64);
+#pragma unroll
+            for (int cb = 0; cb < CBLK; ++cb) {
+                acc[cb][0] *= a0; acc[cb][1] *= a1; acc[cb][2] *= a2; acc[cb][3] *= a3;
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < CBLK; ++cb) {
+            const int ch0 = SLICE * wave + 16 * cb;
+            const int blk = ch0 >> 7, c2 = (ch0 & 127) >> 3;
+            const char* a = img + blk * 4096 + tr_row_off + 16 * ((c2 + (pp >> 1)) ^ tr_swz);
+            const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(phi, b, acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(plo, b, acc[cb], 0, 0, 0);
+        }
+
+        // ---- a window completed in this tile: emit its local context, recycle its row ------------
+        if (i0 + 16 >= p.WSZ) {
+            const int w = wb + wr0;
+            const int row = R + w % NLOC;                  // wave-uniform
+            const float linv = 1.0f / __shfl(l_run, row, 64);
+            float* out = p.ctx_local + (long)w * E + SLICE * wave + r16;
+            const int rk = row >> 2, rj = row & 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j == rj) {
+                    if (kg == rk) {
+#pragma unroll
+                        for (int cb = 0; cb < CBLK; ++cb) {
+                            out[16 * cb] = acc[cb][j] * linv;
+                            acc[cb][j] = 0.f;
+                        }
+                    }
+                }
+            }
+            if (r16 == row) { m_run = -1.0e30f; l_run = 0.f; }
+        }
+    }
+
+    // ---- partial global state of this workgroup --------------------------------------------------
+    const long prow = (long)part * 16;
+    if (wave == 0 && kg == 0 && r16 < R) {
+        p.part_m[prow + r16] = m_run;
+        p.part_l[prow + r16] = l_run;
+    }
+#pragma unroll
+    for (int cb = 0; cb < CBLK; ++cb) {
+        float* o = p.part_acc + (prow + 4 * kg) * E + SLICE * wave + 16 * cb + r16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * kg + j < R) o[(long)j * E] = acc[cb][j];
+    }
+}
+
+}  // namespace hicom
+
+using namespace hicom;
+
+static int fused_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+extern "C" int hicom_fused_stream_nparts(int32_t n_windows) {
+    if (n_windows <= 0) return HICOM_EINVAL;
+    const int slots = 2 * fused_num_cus();                       // 2 resident workgroups per CU
+    int wpw = (n_windows + slots - 1) / slots;                   // equal windows per workgroup
+    if (wpw > kMaxWinPerWg) wpw = kMaxWinPerWg;
+    return (n_windows + wpw - 1) / wpw;
+}
+
+extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T, int32_t H, int32_t W, int32_t E,
+                                      int32_t kt, int32_t ks, const void* q_hi, const void* q_lo, int32_t rows,
+                                      float l_scale, float l_bias, const float* pos_a, int32_t pos_stride,
+                                      int32_t t_index0, int32_t y_index0, int32_t x_index0,
+                                      float* scores, int64_t score_stride, float* part_m, float* part_l,
+                                      float* part_acc, int32_t nparts, float* ctx_local, void* stream) {
+    HICOM_REQUIRE(ff && fe && q_hi && q_lo && scores && part_m && part_l && part_acc && ctx_local, HICOM_EINVAL,
+                  "fused_stream: NULL pointer");
+    HICOM_REQUIRE(E == 1152, HICOM_EUNSUP, "fused_stream: E=%d (only 1152)", E);
+    HICOM_REQUIRE(T > 0 && H > 0 && W > 0 && kt > 0 && ks > 0 && T % kt == 0 && H % ks == 0 && W % ks == 0, HICOM_EUNSUP,
+                  "fused_stream: windows must partition the [%d,%d,%d] grid exactly", T, H, W);
+    const int wsz = kt * ks * ks;
+    HICOM_REQUIRE(wsz >= 16 && wsz <= 64, HICOM_EUNSUP, "fused_stream: window of %d tokens (16..64 supported)", wsz);
+    HICOM_REQUIRE(rows > 0 && rows <= 14, HICOM_EUNSUP, "fused_stream: %d global rows (<= 14: >= 2 local rows needed)", rows);
+    HICOM_REQUIRE(H < 256 && W < 256 && (long)T * H * W < (1L << 31), HICOM_EUNSUP, "fused_stream: grid too large");
+    const int NW = (T / kt) * (H / ks) * (W / ks);
+    HICOM_REQUIRE(nparts > 0 && nparts <= NW, HICOM_EINVAL, "fused_stream: nparts");
+    const int wpw = (NW + nparts - 1) / nparts;
+    HICOM_REQUIRE(wpw <= kMaxWinPerWg && (long)(nparts - 1) * wpw < NW, HICOM_EINVAL,
+                  "fused_stream: nparts=%d gives %d windows per workgroup (max %d, no empty workgroup)", nparts, wpw, kMaxWinPerWg);
+    // frames a workgroup may touch: the t-groups its windows span
+    const int per_t = (H / ks) * (W / ks);
+    const int span = (wpw + per_t - 2) / per_t + 1;
+    HICOM_REQUIRE(span * kt <= kMaxFramesPerWg, HICOM_EUNSUP, "fused_stream: a workgroup would span %d frames", span * kt);
+    const size_t smem = 2 * 9 * 4096 + 4096 + (64 + 64 + 2 * kMaxWinPerWg) * 4 +
+                        (size_t)rows * (kMaxFramesPerWg + H + W) * 4;
+    HICOM_REQUIRE(smem <= 81920, HICOM_EUNSUP, "fused_stream: H + W = %d does not fit the LDS budget", H + W);
+    HICOM_REQUIRE(score_stride >= (long)T * H * W, HICOM_EINVAL, "fused_stream: score_stride");
+    FusedParams p;
+    p.ff = (const uint16_t*)ff; p.fe = (const uint16_t*)fe; p.T = T; p.H = H; p.W = W;
+    p.kt = kt; p.ks = ks; p.nwy = H / ks; p.nwx = W / ks; p.NW = NW; p.WSZ = wsz;
+    p.qhi = (const uint16_t*)q_hi; p.qlo = (const uint16_t*)q_lo; p.R = rows;
+    p.l_scale = l_scale; p.l_bias = l_bias;
+    p.pos_a = pos_a; p.pos_stride = pos_stride; p.t0i = t_index0; p.y0i = y_index0; p.x0i = x_index0;
+    p.scores = scores; p.score_stride = score_stride;
+    p.part_m = part_m; p.part_l = part_l; p.part_acc = part_acc; p.ctx_local = ctx_local; p.wpw = wpw;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(fused_stream_kernel<9>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fused_stream_kernel<9>, dim3((unsigned)nparts), dim3(256), smem, (hipStream_t)stream, p);
+    return hicom_host::check_launch("fused_stream");
+}

@@ -25,7 +25,7 @@ EXPORTS = (
     "hicom_global_stream_nparts", "hicom_global_merge_fwd", "hicom_global_combine_fwd",
     "hicom_readout_gemm_fwd", "hicom_scatter_rows_fwd", "hicom_fold_query_split_fwd",
     "hicom_global_combine_strided_fwd", "hicom_compressor_workspace_bytes", "hicom_compressor_zero_prefix_bytes",
-    "hicom_compressor_fwd", "hicom_linear_to_rows_fwd",
+    "hicom_compressor_fwd", "hicom_linear_to_rows_fwd", "hicom_fused_stream_fwd", "hicom_fused_stream_nparts",
 )
 
 PHASE_STREAM, PHASE_FINISH = 1, 2
@@ -98,6 +98,9 @@ def lib() -> C.CDLL:
     L.hicom_global_merge_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, i64, i64, i32, i32, vp, i32, i32, i32,
                                          vp, vp, vp, i32, vp]
     L.hicom_linear_to_rows_fwd.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i64, i64, i32, vp]
+    L.hicom_fused_stream_fwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, f32, vp, i32, i32, i32, i32,
+                                         vp, i64, vp, vp, vp, i32, vp, vp]
+    L.hicom_fused_stream_nparts.argtypes = [i32]
     L.hicom_fold_query_split_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, i32, vp]
     L.hicom_global_combine_strided_fwd.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
     ap = C.POINTER(CompressorArgs)
@@ -255,3 +258,19 @@ def linear_to_rows(x, w, b, dst, row0, n_rows, act=ACT_NONE):
     _check(lib().hicom_linear_to_rows_fwd(_ptr(x), _dt(x), _ptr(w), _dt(w), _ptr(b), _dt(b) if b is not None else 0,
                                           x.shape[0], N, K, act, _ptr(dst), _dt(dst), dst.shape[-1], row0, n_rows,
                                           _stream()), "hicom_linear_to_rows_fwd")
+
+
+def fused_stream_nparts(n_windows: int) -> int:
+    n = lib().hicom_fused_stream_nparts(n_windows)
+    if n <= 0:
+        raise HicomNativeError("hicom_fused_stream_nparts: bad arguments")
+    return n
+
+
+def fused_stream(ff, fe, kt, ks, qhi, qlo, rows, l_scale, l_bias, pos_a, t0i, y0i, x0i, scores, part_m, part_l,
+                 part_acc, ctx_local):
+    T, H, W, E = ff.shape
+    _check(lib().hicom_fused_stream_fwd(_ptr(ff), _ptr(fe), T, H, W, E, kt, ks, _ptr(qhi), _ptr(qlo), rows, l_scale,
+                                        l_bias, _ptr(pos_a), pos_a.shape[1] if pos_a is not None else 0, t0i, y0i, x0i,
+                                        _ptr(scores), scores.shape[1], _ptr(part_m), _ptr(part_l), _ptr(part_acc),
+                                        part_m.shape[0], _ptr(ctx_local), _stream()), "hicom_fused_stream_fwd")

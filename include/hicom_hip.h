@@ -144,6 +144,26 @@ int hicom_global_stream_fwd(const void* x, int64_t N, int32_t E,
 /* Suggested nparts for N tokens (fills the chip: 2 workgroups per CU). */
 int hicom_global_stream_nparts(int64_t N, int32_t rows_pad);
 
+/* ---- fused local + global stream (release recipe) -------------------------------------------
+ * ONE pass over frames_embed and frames_feature computing BOTH the local window contexts
+ * (projector.py:544-558, guide as the shared query) and the global online-softmax partial state
+ * (projector.py:193-215): each visual tensor is read from HBM exactly once.
+ * Requirements: windows partition the grid exactly (T % kt == H % ks == W % ks == 0), 16 <= kt*ks*ks
+ * <= 64, rows <= 14 global folded rows, E == 1152.
+ *   q_hi / q_lo : bf16 [16, E]; rows < `rows` = folded global queries (hi / lo), rows >= `rows` =
+ *                 the local query in q_hi (exact bf16) and zeros in q_lo
+ *   scores      : f32 [16, score_stride >= T*H*W], indexed by the token's position in the grid
+ *   part_*      : as hicom_global_stream_fwd with rows_pad = 16; nparts from
+ *                 hicom_fused_stream_nparts(number of windows)
+ *   ctx_local   : f32 [Nw, E], window order (t1,h1,w1) */
+int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T, int32_t H, int32_t W, int32_t E,
+                           int32_t kt, int32_t ks, const void* q_hi, const void* q_lo, int32_t rows,
+                           float l_scale, float l_bias, const float* pos_a, int32_t pos_stride,
+                           int32_t t_index0, int32_t y_index0, int32_t x_index0,
+                           float* scores, int64_t score_stride, float* part_m, float* part_l,
+                           float* part_acc, int32_t nparts, float* ctx_local, void* stream);
+int hicom_fused_stream_nparts(int32_t n_windows);
+
 /* ---- merge the partials (+ the value-side positional term) --------------------------------
  * out_acc[r,:] = sum_p e^(m_p - M_r) acc_p[r,:] + sum_n e^(s_n - M_r) pos(n)   (un-normalised)
  * out_ml[r]   = (M_r, L_r).  pos(n) = pe[t_index0+t] + pe[y_index0+y] + pe[x_index0+x] with

@@ -294,3 +294,50 @@ def test_linear_to_rows_replicates_and_casts():
     for k in range(3):
         assert torch.equal(dst[3 + 2 * k:5 + 2 * k], y.to(torch.bfloat16))
     assert float(dst[:3].float().abs().max()) == 0.0 and float(dst[9:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("T,H,W,kt,ks", [(8, 6, 6, 4, 3), (4, 27, 27, 4, 3), (16, 27, 27, 4, 3), (8, 6, 6, 2, 3), (8, 6, 6, 4, 2), (12, 9, 6, 4, 3)])
+def test_fused_stream_matches_separate_kernels(T, H, W, kt, ks):
+    """The fused local+global kernel reproduces hicom_local_attn_fwd and hicom_global_stream_fwd."""
+    E, nh, R = D, 9, 9
+    x = synth.synth_inputs(T, H, W, D, tag=f"fused{T}{H}{W}{kt}{ks}")
+    ff, fe, g = bf(x["ff"]), bf(x["fe"]), bf(x["g"])
+    N = T * H * W
+    # global operand: random folded queries (hi/lo), positional table
+    qt = torch.from_numpy(synth.normal_like((R, E), 81, 0.05)).cuda()
+    qhi = torch.zeros((16, E), dtype=torch.bfloat16, device="cuda")
+    qlo = torch.zeros_like(qhi)
+    nv.split_bf16(qt, 16, qhi, qlo)
+    cap = T + 2
+    pe = torch.from_numpy(geo.stacked_pos_tables(cap, H, W, E)).cuda()
+    pos_a = torch.zeros((16, pe.shape[0]), dtype=torch.float32, device="cuda")
+    nv.linear(qt, pe, None, pos_a, M=R)
+    # reference: the two separate kernels
+    axes = tuple(nv.Axis(a.n, a.k, a.nwin, a.nfull) for a in (geo.axis_tiling(T, kt), geo.axis_tiling(H, ks), geo.axis_tiling(W, ks)))
+    nw = (T // kt) * (H // ks) * (W // ks)
+    ctx_ref = f32((nw, E))
+    nv.local_attn(fe, ff, axes, g, 0, 1 / math.sqrt(E), 0.0, 0, ctx_ref)
+    stride = (N + 15) // 16 * 16
+    def merged(pm, pl, pacc, scores):
+        ml, acc = f32((R, 2)), f32((R, E))
+        nv.global_merge(pm, pl, pacc, R, scores, N, H, W, pe, 0, cap, cap + H, f32((R * T * (H + W + 2),)), ml, acc, normalize=True)
+        return acc
+    np0 = nv.global_stream_nparts(N, 16)
+    s0 = f32((16, stride)); pm0, pl0, pa0 = f32((np0, 16)), f32((np0, 16)), f32((np0, 16, E))
+    nv.global_stream(ff, N, qhi, qlo, pos_a, H, W, 0, cap, cap + H, s0, pm0, pl0, pa0, rows=R)
+    g_ref = merged(pm0, pl0, pa0, s0)
+    # fused: local query rows R..15 = guide
+    qhi_f = qhi.clone()
+    qhi_f[R:] = g
+    for nparts in sorted({nv.fused_stream_nparts(nw), max(1, (nw + 31) // 32), min(nw, 3)}):
+        wpw = (nw + nparts - 1) // nparts
+        if wpw > 32 or (nparts - 1) * wpw >= nw:
+            continue
+        s1 = torch.zeros((16, stride), dtype=torch.float32, device="cuda")
+        pm1, pl1, pa1 = f32((nparts, 16)), f32((nparts, 16)), f32((nparts, 16, E))
+        ctx = torch.full((nw, E), float("nan"), dtype=torch.float32, device="cuda")
+        nv.fused_stream(ff, fe, kt, ks, qhi_f, qlo, R, 1 / math.sqrt(E), 0.0, pos_a, 0, cap, cap + H, s1, pm1, pl1, pa1, ctx)
+        torch.cuda.synchronize()
+        assert maxabs(ctx, ctx_ref) <= 5e-5 * max(1.0, float(ctx_ref.abs().max())), (nparts, "local")
+        assert maxabs(s1[:R, :N], s0[:R, :N]) <= 1e-5 * max(1.0, float(s0[:R, :N].abs().max())), (nparts, "scores")
+        assert maxabs(merged(pm1, pl1, pa1, s1), g_ref) <= 2e-5 * max(1.0, float(g_ref.abs().max())), (nparts, "global")
