@@ -40,11 +40,11 @@ bool can_fuse(const hicom_compressor_args& a) {
     const int wsz = a.at.k * a.ay.k * a.ax.k;
     if (wsz < 16 || wsz > 64 || a.H >= 256 || a.W >= 256) return false;
     const int R = a.nq * a.nh;
-    if (2 * 9 * 4096 + 4096 + (64 + 64 + 64) * 4 + R * (16 + a.H + a.W) * 4 > 81920) return false;
+    if (2 * 9 * 4096 + 4096 + 1024 + 128 + (64 + 64 + 32) * 4 + R * (8 + a.H + a.W) * 4 > 81920) return false;
     const int nw = a.at.nwin * a.ay.nwin * a.ax.nwin, per_t = a.ay.nwin * a.ax.nwin;
     const int nparts = hicom_fused_stream_nparts(nw);
     const int wpw = (nw + nparts - 1) / nparts;
-    return ((wpw + per_t - 2) / per_t + 1) * a.at.k <= 16;
+    return wpw <= 16 && ((wpw + per_t - 2) / per_t + 1) * a.at.k <= 8;
 }
 
 WsLayout make_layout(const hicom_compressor_args& a) {

@@ -24,12 +24,14 @@
 // Positional logit terms come from small per-workgroup LDS tables (a_t for the <= 16 frames a
 // workgroup touches, a_y, a_x), so the tile loop contains no ordinary global load whose in-order
 // vmcnt would drain the LDS-DMA prefetch.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace hicom {
 
-constexpr int kMaxWinPerWg = 32;
-constexpr int kMaxFramesPerWg = 16;
+constexpr int kMaxWinPerWg = 16;
+constexpr int kMaxFramesPerWg = 8;
 
 struct FusedParams {
     const uint16_t* ff;
@@ -49,6 +51,7 @@ struct FusedParams {
     float* part_acc;       // [nparts][16][E], rows < R
     float* ctx_local;      // [NW][E]
     int wpw;               // windows per workgroup
+    int dbg;               // developer ablation mask (HICOM_FUSED_DBG): 1 no P.x, 2 no score MFMAs, 8 no fe loads, 16 no LDS-DMA after tile 0
 };
 
 __device__ __forceinline__ int fswz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
@@ -67,7 +70,11 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* tilebuf = smem;                                              // [2][TILE_BYTES]
     float* red = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);     // [4][16][16]
-    int* win_off = reinterpret_cast<int*>(red + 1024);                 // [64] token offset of in-window index
+    uint16_t* p_hi = reinterpret_cast<uint16_t*>(red + 1024);          // [16 rows][16 slots] softmax weights, bf16 hi
+    uint16_t* p_lo = p_hi + 256;                                       // [16][16] bf16 lo
+    float* alpha_s = reinterpret_cast<float*>(p_lo + 256);             // [16] rescale factor of each row (this tile)
+    float* lrun_s = alpha_s + 16;                                      // [16] running normaliser of each row
+    int* win_off = reinterpret_cast<int*>(lrun_s + 16);                // [64] token offset of in-window index
     int* win_txy = win_off + 64;                                       // [64] packed (t2 << 16 | h2 << 8 | w2)
     int* worg = win_txy + 64;                                          // [kMaxWinPerWg] window origin token
     int* wtxy = worg + kMaxWinPerWg;                                   // [kMaxWinPerWg] packed (t0 << 16 | y0 << 8 | x0) window base coords
@@ -123,14 +130,18 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
     f32x4 acc[CBLK];
 #pragma unroll
     for (int cb = 0; cb < CBLK; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -1.0e30f, l_run = 0.f;
+    float m_run = -1.0e30f, l_run = 0.f;   // online-softmax state of row 4*wave + lane/16 (owner lanes)
 
     __syncthreads();   // tables ready
 
     // stream slot -> token index (clamped to the last valid slot of this workgroup)
+    // (s / WSZ by multiply-shift: exact for s < 2^16, i.e. <= kMaxWinPerWg * 64 tokens per workgroup)
+    const unsigned wsz_magic = (65536u + p.WSZ - 1) / p.WSZ;
     auto token_of = [&](int s) -> long {
         s = s < total ? s : total - 1;
-        const int wr = s / p.WSZ, i = s - wr * p.WSZ;
+        int wr = (int)(((unsigned)s * wsz_magic) >> 16);
+        int i = s - wr * p.WSZ;
+        if (i < 0) { i += p.WSZ; wr -= 1; }
         return (long)worg[wr] + win_off[i];
     };
 
@@ -152,25 +163,31 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
     const int rd_row_off = r16 * 256, rd_swz = fswz(r16);
     const int tr_row_off = trow * 256 + 8 * (pp & 1), tr_swz = fswz(trow);
 
-    if (ntile > 0) stage(0, 0);
+    // frames_embed B fragments (token slot r16, this wave's channel slice), fetched ONE TILE AHEAD
+    // into the registers the previous tile's local-score MFMAs have just released
+    bf16x8 bfe[KSTEPS];
+    auto load_fe = [&](int tile) {
+        const uint16_t* src = p.fe + token_of(tile * 16 + r16) * E + SLICE * wave + 8 * kg;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) bfe[s] = *reinterpret_cast<const bf16x8*>(src + 32 * s);
+    };
+
+    if (ntile > 0) {
+        stage(0, 0);
+        load_fe(0);
+    }
 
     for (int tile = 0; tile < ntile; ++tile) {
         const int cur = tile & 1;
         const int s0 = tile * 16;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                               // [A]
-        // frames_embed B fragments of this tile: token slot r16, this wave's channel slice
-        bf16x8 bfe[KSTEPS];
-        {
-            const uint16_t* src = p.fe + token_of(s0 + r16) * E + SLICE * wave + 8 * kg;
-#pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) bfe[s] = *reinterpret_cast<const bf16x8*>(src + 32 * s);
-        }
-        if (tile + 1 < ntile) stage(tile + 1, cur ^ 1);
+        if (tile + 1 < ntile && !(p.dbg & 16)) stage(tile + 1, cur ^ 1);
         const char* img = tilebuf + cur * TILE_BYTES;
 
         // ---- global logits (rows < R) from the frames_feature tile in LDS -----------------------
         f32x4 sff = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(p.dbg & 2))
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             const int ch0 = SLICE * wave + 32 * s;
@@ -183,90 +200,107 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
         f32x4 sfe = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) sfe = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[s], bfe[s], sfe, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);          // keep the refill below the MFMAs that read bfe
+        if (tile + 1 < ntile && !(p.dbg & 8)) load_fe(tile + 1);
 
         float* rw = red + wave * 256;
 #pragma unroll
         for (int j = 0; j < 4; ++j) rw[(4 * kg + j) * 16 + r16] = (4 * kg + j < R) ? sff[j] : sfe[j];
         lds_barrier();                                                 // [B]
 
-        const float* rb = red + r16 * 16 + 4 * fsig(kg);
-        f32x4 lg = *reinterpret_cast<const f32x4*>(rb);
-        lg += *reinterpret_cast<const f32x4*>(rb + 256);
-        lg += *reinterpret_cast<const f32x4*>(rb + 512);
-        lg += *reinterpret_cast<const f32x4*>(rb + 768);
-
-        // window bookkeeping of this tile (wave-uniform): slot 0 is token i0 of window wr0
-        const int wr0 = s0 / p.WSZ, i0 = s0 - wr0 * p.WSZ;
-        const int q0 = 4 * fsig(kg);
-        const bool is_glob = r16 < R;
-        bool valid[4];
-        float tmax = -1.0e30f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int s = s0 + q0 + j;
-            int i = i0 + q0 + j, wr = wr0;
+        // ---- softmax: each wave owns 4 of the 16 rows; lane = (row 4*wave + lane/16, token slot lane%16).
+        // (One logit per lane instead of four replicated in every wave; P, alpha and l are shared
+        // through 1.2 KB of LDS.)
+        int wr0 = (int)(((unsigned)s0 * wsz_magic) >> 16), i0 = s0 - wr0 * p.WSZ;
+        if (i0 < 0) { i0 += p.WSZ; wr0 -= 1; }
+        // local rows of the (at most two) windows this tile touches -- wave-uniform
+        const int rowA = R + (wb + wr0) % NLOC;
+        const int rowB = (rowA + 1 < 16) ? rowA + 1 : R;
+        {
+            const int row = 4 * wave + (lane >> 4), tk = lane & 15;
+            const float* rb = red + row * 16 + tk;
+            float lgt = (rb[0] + rb[256]) + (rb[512] + rb[768]);
+            const int s = s0 + tk;
+            int i = i0 + tk, wr = wr0;
             if (i >= p.WSZ) { i -= p.WSZ; wr += 1; }
             const bool in = s < total;
             const int wsafe = in ? wr : 0;
-            if (is_glob) {
-                valid[j] = in;
+            bool valid;
+            if (row < R) {
+                valid = in;
                 if (p.pos_a) {
                     const int txy = win_txy[i], base = wtxy[wsafe];
                     const int f = (base >> 16) + (txy >> 16), y = ((base >> 8) & 255) + ((txy >> 8) & 255), x = (base & 255) + (txy & 255);
-                    lg[j] += a_t[r16 * kMaxFramesPerWg + f] + a_y[r16 * p.H + y] + a_x[r16 * p.W + x];
+                    lgt += a_t[row * kMaxFramesPerWg + f] + a_y[row * p.H + y] + a_x[row * p.W + x];
                 }
-                if (wave == 0 && in) p.scores[(long)r16 * p.score_stride + worg[wsafe] + win_off[i]] = lg[j];
+                if (in) p.scores[(long)row * p.score_stride + worg[wsafe] + win_off[i]] = lgt;
             } else {
-                valid[j] = in && ((wb + wr) % NLOC == r16 - R);
-                lg[j] = lg[j] * p.l_scale + p.l_bias;
+                valid = in && (row == (wr == wr0 ? rowA : rowB));
+                lgt = lgt * p.l_scale + p.l_bias;
             }
-            tmax = valid[j] ? fmaxf(tmax, lg[j]) : tmax;
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = expf(m_run - m_new);
-        float pr[4], lsum = 0.f;
+            float tmax = valid ? lgt : -1.0e30f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            pr[j] = valid[j] ? expf(lg[j] - m_new) : 0.f;
-            lsum += pr[j];
-        }
-        lsum += __shfl_xor(lsum, 16, 64);
-        lsum += __shfl_xor(lsum, 32, 64);
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
-        bf16x4 phi, plo;
+            for (int o = 8; o > 0; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64));
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = fast_exp(m_run - m_new);
+            const float pr = valid ? fast_exp(lgt - m_new) : 0.f;
+            float lsum = pr;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+            for (int o = 8; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o, 64);
+            l_run = l_run * alpha + lsum;
+            m_run = m_new;
             uint16_t h, l;
-            split_bf16(pr[j], h, l);
-            phi[j] = (short)h;
-            plo[j] = (short)l;
+            split_bf16(pr, h, l);
+            p_hi[row * 16 + tk] = h;
+            p_lo[row * 16 + tk] = l;
+            if (tk == 0) {
+                alpha_s[row] = alpha;
+                lrun_s[row] = l_run;
+            }
         }
-        if (__any(alpha != 1.0f)) {
-            const float a0 = __shfl(alpha, 4 * kg + 0, 64), a1 = __shfl(alpha, 4 * kg + 1, 64);
-            const float a2 = __shfl(alpha, 4 * kg + 2, 64), a3 = __shfl(alpha, 4 * kg + 3, 64);
+        lds_barrier();                                                 // [C] P / alpha / l visible to every wave
+
+        const bf16x4 phi = *reinterpret_cast<const bf16x4*>(p_hi + r16 * 16 + 4 * fsig(kg));
+        const bf16x4 plo = *reinterpret_cast<const bf16x4*>(p_lo + r16 * 16 + 4 * fsig(kg));
+        const f32x4 al = *reinterpret_cast<const f32x4*>(alpha_s + 4 * kg);
+        if (__any(al[0] != 1.0f || al[1] != 1.0f || al[2] != 1.0f || al[3] != 1.0f)) {
 #pragma unroll
             for (int cb = 0; cb < CBLK; ++cb) {
-                acc[cb][0] *= a0; acc[cb][1] *= a1; acc[cb][2] *= a2; acc[cb][3] *= a3;
+                acc[cb][0] *= al[0]; acc[cb][1] *= al[1]; acc[cb][2] *= al[2]; acc[cb][3] *= al[3];
             }
         }
+        // ACC += P . x.  The transposed LDS reads are issued as inline asm with our own lgkmcnt wait:
+        // through the builtin, hipcc orders them behind ALL outstanding vector-memory traffic
+        // (s_waitcnt vmcnt(0)), which would drain the next tile's LDS-DMA and frames_embed prefetch.
+        if (!(p.dbg & 1)) {
+            const unsigned img_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(img);
+            constexpr int G = 3;                     // reads in flight per group (register budget: 256 VGPRs)
+            static_assert(CBLK % G == 0, "column blocks per group");
 #pragma unroll
-        for (int cb = 0; cb < CBLK; ++cb) {
-            const int ch0 = SLICE * wave + 16 * cb;
-            const int blk = ch0 >> 7, c2 = (ch0 & 127) >> 3;
-            const char* a = img + blk * 4096 + tr_row_off + 16 * ((c2 + (pp >> 1)) ^ tr_swz);
-            const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
-            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(phi, b, acc[cb], 0, 0, 0);
-            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(plo, b, acc[cb], 0, 0, 0);
+            for (int g0 = 0; g0 < CBLK; g0 += G) {
+                bf16x4 bv[G];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int ch0 = SLICE * wave + 16 * (g0 + u);
+                    const int blk = ch0 >> 7, c2 = (ch0 & 127) >> 3;
+                    const unsigned addr = img_lds + blk * 4096 + tr_row_off + 16 * ((c2 + (pp >> 1)) ^ tr_swz);
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(bv[u]) : "v"(addr));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    acc[g0 + u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(phi, bv[u], acc[g0 + u], 0, 0, 0);
+                    acc[g0 + u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(plo, bv[u], acc[g0 + u], 0, 0, 0);
+                }
+            }
         }
 
         // ---- a window completed in this tile: emit its local context, recycle its row ------------
         if (i0 + 16 >= p.WSZ) {
             const int w = wb + wr0;
-            const int row = R + w % NLOC;                  // wave-uniform
-            const float linv = 1.0f / __shfl(l_run, row, 64);
+            const int row = rowA;                          // wave-uniform
+            const float linv = 1.0f / lrun_s[row];
             float* out = p.ctx_local + (long)w * E + SLICE * wave + r16;
             const int rk = row >> 2, rj = row & 3;
 #pragma unroll
@@ -281,15 +315,18 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
                     }
                 }
             }
-            if (r16 == row) { m_run = -1.0e30f; l_run = 0.f; }
+            if (4 * wave + (lane >> 4) == row) { m_run = -1.0e30f; l_run = 0.f; }   // owner lanes recycle the row
         }
     }
 
     // ---- partial global state of this workgroup --------------------------------------------------
     const long prow = (long)part * 16;
-    if (wave == 0 && kg == 0 && r16 < R) {
-        p.part_m[prow + r16] = m_run;
-        p.part_l[prow + r16] = l_run;
+    {
+        const int row = 4 * wave + (lane >> 4);
+        if ((lane & 15) == 0 && row < R) {
+            p.part_m[prow + row] = m_run;
+            p.part_l[prow + row] = l_run;
+        }
     }
 #pragma unroll
     for (int cb = 0; cb < CBLK; ++cb) {
@@ -347,7 +384,7 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T,
     const int per_t = (H / ks) * (W / ks);
     const int span = (wpw + per_t - 2) / per_t + 1;
     HICOM_REQUIRE(span * kt <= kMaxFramesPerWg, HICOM_EUNSUP, "fused_stream: a workgroup would span %d frames", span * kt);
-    const size_t smem = 2 * 9 * 4096 + 4096 + (64 + 64 + 2 * kMaxWinPerWg) * 4 +
+    const size_t smem = 2 * 9 * 4096 + 4096 + 1024 + 128 + (64 + 64 + 2 * kMaxWinPerWg) * 4 +
                         (size_t)rows * (kMaxFramesPerWg + H + W) * 4;
     HICOM_REQUIRE(smem <= 81920, HICOM_EUNSUP, "fused_stream: H + W = %d does not fit the LDS budget", H + W);
     HICOM_REQUIRE(score_stride >= (long)T * H * W, HICOM_EINVAL, "fused_stream: score_stride");
@@ -359,6 +396,7 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T,
     p.pos_a = pos_a; p.pos_stride = pos_stride; p.t0i = t_index0; p.y0i = y_index0; p.x0i = x_index0;
     p.scores = scores; p.score_stride = score_stride;
     p.part_m = part_m; p.part_l = part_l; p.part_acc = part_acc; p.ctx_local = ctx_local; p.wpw = wpw;
+    p.dbg = getenv("HICOM_FUSED_DBG") ? atoi(getenv("HICOM_FUSED_DBG")) : 0;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(fused_stream_kernel<9>),

@@ -144,7 +144,8 @@ def test_c2_frame_shards_compose(c2):
         ctx, grid = lc.window_context(ff[16:32], fe[16:32], g, "video", None, None)
         loc = torch.empty((ctx.shape[0], 896), dtype=torch.float32, device="cuda")
         lc.readout_into(ctx, loc, 0, 0)
-        assert torch.equal(loc, full[4 * 81:8 * 81])
+        # stepwise local path = VALU window kernel, forward = fused MFMA kernel: same math, fp32 noise
+        assert float((loc - full[4 * 81:8 * 81]).abs().max()) <= 2e-5
 
 
 def test_c2_uniform_attention_known_answer(c2):

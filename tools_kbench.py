@@ -34,3 +34,15 @@ if "stream" in which:
         pm, pl, pacc = torch.empty(nparts, 16, device=dev), torch.empty(nparts, 16, device=dev), torch.empty(nparts, 16, E, device=dev)
         t = timeit(lambda: nv.global_stream(ff, N, qhi, qlo, pos_a, H, W, 0, 64, 64 + H, scores, pm, pl, pacc, rows=9))
         print("global_stream nparts=%d %.1f us  %.2f TB/s" % (nparts, t, ff.numel() * 2 / t / 1e6))
+
+if "fused" in which or len(sys.argv) == 1:
+    N = T * H * W
+    qhi = (torch.randn(16, E, device=dev) * 0.05).bfloat16(); qlo = (qhi.float() * 1e-3).bfloat16(); qhi[9:] = g; qlo[9:] = 0
+    pos_a = torch.randn(16, 64 + 54, device=dev) * 0.1
+    nw = 1296
+    for nparts in sorted({nv.fused_stream_nparts(nw)}):
+        scores = torch.empty(16, N, device=dev)
+        pm, pl, pacc = torch.empty(nparts, 16, device=dev), torch.empty(nparts, 16, device=dev), torch.empty(nparts, 16, E, device=dev)
+        ctx = torch.empty(nw, E, device=dev)
+        t = timeit(lambda: nv.fused_stream(ff, fe, 4, 3, qhi, qlo, 9, 1 / math.sqrt(E), 0.0, pos_a, 0, 64, 64 + H, scores, pm, pl, pacc, ctx))
+        print("fused_stream nparts=%d %.1f us  %.2f TB/s (inputs only)" % (nparts, t, 2 * ff.numel() * 2 / t / 1e6))
