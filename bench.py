@@ -205,10 +205,11 @@ def dominant_kernel_roofline(module, ff, fe, guide, iters):
     scores = torch.empty(16, T * H * W, device=dev)
     pm, pl = torch.empty(nparts, 16, device=dev), torch.empty(nparts, 16, device=dev)
     pacc = torch.empty(nparts, 16, D, device=dev)
-    ctx = torch.empty(nw, D, device=dev)
+    chi = torch.empty(nw, D, device=dev, dtype=torch.bfloat16)
+    clo = torch.empty_like(chi)
 
     def launch():
-        nv.fused_stream(ff, fe, at.k, ay.k, qhi, qlo, R, 1.0 / D ** 0.5, 0.0, pos_a, 0, T, T + H, scores, pm, pl, pacc, ctx)
+        nv.fused_stream(ff, fe, at.k, ay.k, qhi, qlo, R, 1.0 / D ** 0.5, 0.0, pos_a, 0, T, T + H, scores, pm, pl, pacc, None, chi, clo)
 
     stream = torch.cuda.current_stream()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]

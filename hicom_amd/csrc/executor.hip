@@ -23,7 +23,7 @@ namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct WsLayout {
-    size_t ctx_local, hid_local, pooled_q, qp, qhi, qlo, pos_a, scores, part_m, part_l, part_acc, scratch, ml, acc,
+    size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, qp, qhi, qlo, pos_a, scores, part_m, part_l, part_acc, scratch, ml, acc,
         ctx_g, o, qres, pre, hid_g, tok, total;
     int nw, R, rows_pad, nparts, P;
     long N, score_stride;
@@ -64,8 +64,12 @@ WsLayout make_layout(const hicom_compressor_args& a) {
     w.qlo = take((size_t)w.rows_pad * a.E * 2);
     w.pos_a = take((size_t)w.rows_pad * (a.P > 0 ? a.P : 1) * 4);
     if (a.has_local) {
-        w.ctx_local = take((size_t)w.nw * a.E * 4);
+        w.ctx_local = take((size_t)w.nw * a.E * 4);          // fp32 form (two-kernel path) ...
         w.hid_local = take((size_t)w.nw * a.hidden * 4);
+        w.ctx_hi = w.ctx_local;                               // ... or bf16 hi/lo planes in the same bytes (fused path)
+        w.ctx_lo = w.ctx_local + (size_t)w.nw * a.E * 2;
+        w.hid_hi = w.hid_local;
+        w.hid_lo = w.hid_local + (size_t)w.nw * a.hidden * 2;
         w.pooled_q = take(a.lq ? 0 : (size_t)w.nw * a.E * 4);
     }
     if (a.has_global) {
@@ -181,10 +185,19 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         CHK(hicom_fused_stream_fwd(a.ff, a.fe ? a.fe : a.ff, a.T, a.H, a.W, a.E, a.at.k, a.ay.k, ws + w.qhi, ws + w.qlo,
                                    w.R, a.l_scale, a.l_bias, a.pe ? F(w.pos_a) : nullptr, a.P, a.t_index0, a.y_index0,
                                    a.x_index0, F(w.scores), w.score_stride, F(w.part_m), F(w.part_l), F(w.part_acc),
-                                   w.nparts, F(w.ctx_local), sm));
+                                   w.nparts, nullptr, ws + w.ctx_hi, ws + w.ctx_lo, sm));
         CHK(fork());
         CHK(merge(ss));
-        CHK(local_readout(sm));
+        // readout MLP on bf16 planes: contexts (hi/lo) -> hidden (hi/lo) -> packed output rows
+        CHK(hicom_planes_gemm_fwd(ws + w.ctx_hi, ws + w.ctx_lo, a.lw0, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E,
+                                  HICOM_ACT_GELU, ws + w.hid_hi, ws + w.hid_lo, nullptr, 0, 0, 0, 0, sm));
+        CHK(hicom_planes_gemm_fwd(ws + w.hid_hi, ws + w.hid_lo, a.lw2, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden,
+                                  HICOM_ACT_NONE, nullptr, nullptr, a.local_out ? a.local_out : a.out, a.out_dt,
+                                  a.local_out ? a.hidden : a.ldo, a.local_out ? 0 : a.local_row0,
+                                  a.local_out ? 0 : a.nl_group, sm));
+        if (a.nl_count > 0 && !a.local_out)
+            CHK(hicom_scatter_rows_fwd(a.newline, a.newline_dt, 1, a.hidden, a.out, a.out_dt, a.ldo, a.nl_first, a.nl_step,
+                                       0, a.nl_count, sm));
     } else if (do_stream) {
         if (both) CHK(fork());
         // Host enqueue order matters (each launch costs a few us of host time): the long local

@@ -49,7 +49,9 @@ struct FusedParams {
     float* part_m;
     float* part_l;
     float* part_acc;       // [nparts][16][E], rows < R
-    float* ctx_local;      // [NW][E]
+    float* ctx_local;      // [NW][E] fp32 window contexts (may be NULL)
+    uint16_t* ctx_hi;      // [NW][E] the same as bf16 hi / lo planes for hicom_planes_gemm_fwd (may be NULL)
+    uint16_t* ctx_lo;
     int wpw;               // windows per workgroup
     int dbg;               // developer ablation mask (HICOM_FUSED_DBG): 1 no P.x, 2 no score MFMAs, 8 no fe loads, 16 no LDS-DMA after tile 0
 };
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
             const int w = wb + wr0;
             const int row = rowA;                          // wave-uniform
             const float linv = 1.0f / lrun_s[row];
-            float* out = p.ctx_local + (long)w * E + SLICE * wave + r16;
+            const long obase = (long)w * E + SLICE * wave + r16;
             const int rk = row >> 2, rj = row & 3;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -309,7 +311,14 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
                     if (kg == rk) {
 #pragma unroll
                         for (int cb = 0; cb < CBLK; ++cb) {
-                            out[16 * cb] = acc[cb][j] * linv;
+                            const float v = acc[cb][j] * linv;
+                            if (p.ctx_local) p.ctx_local[obase + 16 * cb] = v;
+                            if (p.ctx_hi) {
+                                uint16_t h, l;
+                                split_bf16(v, h, l);
+                                p.ctx_hi[obase + 16 * cb] = h;
+                                p.ctx_lo[obase + 16 * cb] = l;
+                            }
                             acc[cb][j] = 0.f;
                         }
                     }
@@ -365,9 +374,11 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T,
                                       float l_scale, float l_bias, const float* pos_a, int32_t pos_stride,
                                       int32_t t_index0, int32_t y_index0, int32_t x_index0,
                                       float* scores, int64_t score_stride, float* part_m, float* part_l,
-                                      float* part_acc, int32_t nparts, float* ctx_local, void* stream) {
-    HICOM_REQUIRE(ff && fe && q_hi && q_lo && scores && part_m && part_l && part_acc && ctx_local, HICOM_EINVAL,
+                                      float* part_acc, int32_t nparts, float* ctx_local, void* ctx_hi, void* ctx_lo,
+                                      void* stream) {
+    HICOM_REQUIRE(ff && fe && q_hi && q_lo && scores && part_m && part_l && part_acc, HICOM_EINVAL,
                   "fused_stream: NULL pointer");
+    HICOM_REQUIRE(ctx_local || (ctx_hi && ctx_lo), HICOM_EINVAL, "fused_stream: no local output");
     HICOM_REQUIRE(E == 1152, HICOM_EUNSUP, "fused_stream: E=%d (only 1152)", E);
     HICOM_REQUIRE(T > 0 && H > 0 && W > 0 && kt > 0 && ks > 0 && T % kt == 0 && H % ks == 0 && W % ks == 0, HICOM_EUNSUP,
                   "fused_stream: windows must partition the [%d,%d,%d] grid exactly", T, H, W);
@@ -395,7 +406,7 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T,
     p.l_scale = l_scale; p.l_bias = l_bias;
     p.pos_a = pos_a; p.pos_stride = pos_stride; p.t0i = t_index0; p.y0i = y_index0; p.x0i = x_index0;
     p.scores = scores; p.score_stride = score_stride;
-    p.part_m = part_m; p.part_l = part_l; p.part_acc = part_acc; p.ctx_local = ctx_local; p.wpw = wpw;
+    p.part_m = part_m; p.part_l = part_l; p.part_acc = part_acc; p.ctx_local = ctx_local; p.ctx_hi = (uint16_t*)ctx_hi; p.ctx_lo = (uint16_t*)ctx_lo; p.wpw = wpw;
     p.dbg = getenv("HICOM_FUSED_DBG") ? atoi(getenv("HICOM_FUSED_DBG")) : 0;
     static bool attr_set = false;
     if (!attr_set) {

@@ -26,6 +26,7 @@ EXPORTS = (
     "hicom_readout_gemm_fwd", "hicom_scatter_rows_fwd", "hicom_fold_query_split_fwd",
     "hicom_global_combine_strided_fwd", "hicom_compressor_workspace_bytes", "hicom_compressor_zero_prefix_bytes",
     "hicom_compressor_fwd", "hicom_linear_to_rows_fwd", "hicom_fused_stream_fwd", "hicom_fused_stream_nparts",
+    "hicom_planes_gemm_fwd",
 )
 
 PHASE_STREAM, PHASE_FINISH = 1, 2
@@ -99,8 +100,9 @@ def lib() -> C.CDLL:
                                          vp, vp, vp, i32, vp]
     L.hicom_linear_to_rows_fwd.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i64, i64, i32, vp]
     L.hicom_fused_stream_fwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, f32, vp, i32, i32, i32, i32,
-                                         vp, i64, vp, vp, vp, i32, vp, vp]
+                                         vp, i64, vp, vp, vp, i32, vp, vp, vp, vp]
     L.hicom_fused_stream_nparts.argtypes = [i32]
+    L.hicom_planes_gemm_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i64, i64, i32, vp]
     L.hicom_fold_query_split_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, i32, vp]
     L.hicom_global_combine_strided_fwd.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
     ap = C.POINTER(CompressorArgs)
@@ -268,9 +270,19 @@ def fused_stream_nparts(n_windows: int) -> int:
 
 
 def fused_stream(ff, fe, kt, ks, qhi, qlo, rows, l_scale, l_bias, pos_a, t0i, y0i, x0i, scores, part_m, part_l,
-                 part_acc, ctx_local):
+                 part_acc, ctx_local, ctx_hi=None, ctx_lo=None):
     T, H, W, E = ff.shape
     _check(lib().hicom_fused_stream_fwd(_ptr(ff), _ptr(fe), T, H, W, E, kt, ks, _ptr(qhi), _ptr(qlo), rows, l_scale,
                                         l_bias, _ptr(pos_a), pos_a.shape[1] if pos_a is not None else 0, t0i, y0i, x0i,
                                         _ptr(scores), scores.shape[1], _ptr(part_m), _ptr(part_l), _ptr(part_acc),
-                                        part_m.shape[0], _ptr(ctx_local), _stream()), "hicom_fused_stream_fwd")
+                                        part_m.shape[0], _ptr(ctx_local), _ptr(ctx_hi), _ptr(ctx_lo), _stream()),
+           "hicom_fused_stream_fwd")
+
+
+def planes_gemm(a_hi, a_lo, w, b, act=ACT_NONE, out_hi=None, out_lo=None, y=None, row0=0, nl_group=0):
+    N, K = w.shape
+    M = a_hi.shape[0]
+    _check(lib().hicom_planes_gemm_fwd(_ptr(a_hi), _ptr(a_lo), _ptr(w), _ptr(b), _dt(b) if b is not None else 0, M, N, K,
+                                       act, _ptr(out_hi), _ptr(out_lo), _ptr(y), _dt(y) if y is not None else 0,
+                                       y.shape[-1] if y is not None else 0, row0, nl_group, _stream()),
+           "hicom_planes_gemm_fwd")

@@ -155,13 +155,15 @@ int hicom_global_stream_nparts(int64_t N, int32_t rows_pad);
  *   scores      : f32 [16, score_stride >= T*H*W], indexed by the token's position in the grid
  *   part_*      : as hicom_global_stream_fwd with rows_pad = 16; nparts from
  *                 hicom_fused_stream_nparts(number of windows)
- *   ctx_local   : f32 [Nw, E], window order (t1,h1,w1) */
+ *   ctx_local   : f32 [Nw, E], window order (t1,h1,w1), and/or ctx_hi + ctx_lo: the same contexts as
+ *                 bf16 planes (hi + lo) for hicom_planes_gemm_fwd; unused outputs NULL */
 int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T, int32_t H, int32_t W, int32_t E,
                            int32_t kt, int32_t ks, const void* q_hi, const void* q_lo, int32_t rows,
                            float l_scale, float l_bias, const float* pos_a, int32_t pos_stride,
                            int32_t t_index0, int32_t y_index0, int32_t x_index0,
                            float* scores, int64_t score_stride, float* part_m, float* part_l,
-                           float* part_acc, int32_t nparts, float* ctx_local, void* stream);
+                           float* part_acc, int32_t nparts, float* ctx_local, void* ctx_hi, void* ctx_lo,
+                           void* stream);
 int hicom_fused_stream_nparts(int32_t n_windows);
 
 /* ---- merge the partials (+ the value-side positional term) --------------------------------
@@ -193,6 +195,14 @@ int hicom_readout_gemm_fwd(const float* x, const void* w, const void* b, int32_t
                            int32_t M, int32_t N, int32_t K, int32_t act,
                            void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group,
                            void* stream);
+
+/* Same GEMM on bf16 PLANES (the hot path): the activation arrives already split as a_hi + a_lo
+ * (bf16 [M,K] each, written by the producing kernel), so all three operands go HBM -> LDS by LDS-DMA.
+ * Outputs (either or both): out_hi/out_lo = bf16 planes [M,N] of the result (feeds the next GEMM);
+ * y = packed rows as in hicom_readout_gemm_fwd. */
+int hicom_planes_gemm_fwd(const void* a_hi, const void* a_lo, const void* w, const void* b, int32_t b_dt,
+                          int32_t M, int32_t N, int32_t K, int32_t act, void* out_hi, void* out_lo,
+                          void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group, void* stream);
 
 /* Row copy / broadcast with dtype conversion into the packed output:
  *   dst[row0 + i*row_step + (nl_group ? i / nl_group : 0), :] = src[(i % src_rows), :],  i in [0,count)

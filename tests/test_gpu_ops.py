@@ -346,3 +346,27 @@ def test_fused_stream_matches_separate_kernels(T, H, W, kt, ks):
         assert maxabs(s1[:R, :N], s0[:R, :N]) <= 1e-5 * max(1.0, float(s0[:R, :N].abs().max())), (nparts, "scores")
         assert maxabs(merged(pm1, pl1, pa1, s1), g_ref) <= 2e-5 * max(1.0, float(g_ref.abs().max())), (nparts, "global")
     assert ran
+
+
+@pytest.mark.parametrize("M,N,K,act", [(8, 64, 1152, 1), (81, 896, 1152, 1), (130, 64, 64, 0), (1296, 896, 896, 0), (1296, 896, 1152, 1)])
+def test_planes_gemm_matches_torch(M, N, K, act):
+    x = synth.normal_like((M, K), 91)
+    x = (x + synth.normal_like((M, K), 95) * 2.0 ** -10).astype(np.float32)   # NOT bf16-representable
+    w = synth.normal_like((N, K), 92, 0.03)
+    b = synth.normal_like((N,), 93, 0.1)
+    want = torch.from_numpy(x).double() @ torch.from_numpy(w).double().t() + torch.from_numpy(b).double()
+    if act:
+        want = 0.5 * want * (1 + torch.erf(want / math.sqrt(2)))
+    a_hi = torch.empty((M, K), dtype=torch.bfloat16, device="cuda")
+    a_lo = torch.empty_like(a_hi)
+    nv.split_bf16(torch.from_numpy(x).cuda(), M, a_hi, a_lo)
+    o_hi = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    o_lo = torch.empty_like(o_hi)
+    y = f32((M + M // 9 + 4, N))
+    y.zero_()
+    nv.planes_gemm(a_hi, a_lo, bf(w), bf(b), act=act, out_hi=o_hi, out_lo=o_lo, y=y, row0=2, nl_group=9)
+    tol = 5e-5 * max(1.0, float(want.abs().max()))
+    assert maxabs(o_hi.float() + o_lo.float(), want) <= tol
+    rows = torch.tensor([2 + m + m // 9 for m in range(M)])
+    assert maxabs(y.cpu()[rows], want) <= tol
+    assert float(y[:2].abs().max()) == 0.0

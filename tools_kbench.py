@@ -46,3 +46,11 @@ if "fused" in which or len(sys.argv) == 1:
         ctx = torch.empty(nw, E, device=dev)
         t = timeit(lambda: nv.fused_stream(ff, fe, 4, 3, qhi, qlo, 9, 1 / math.sqrt(E), 0.0, pos_a, 0, 64, 64 + H, scores, pm, pl, pacc, ctx))
         print("fused_stream nparts=%d %.1f us  %.2f TB/s (inputs only)" % (nparts, t, 2 * ff.numel() * 2 / t / 1e6))
+
+if "pgemm" in which or len(sys.argv) == 1:
+    x = torch.randn(1296, E, device=dev); w0 = (torch.randn(HID, E, device=dev) * 0.02).bfloat16(); b0 = torch.zeros(HID, device=dev).bfloat16()
+    w2 = (torch.randn(HID, HID, device=dev) * 0.02).bfloat16()
+    ah = torch.empty(1296, E, device=dev, dtype=torch.bfloat16); al = torch.empty_like(ah); nv.split_bf16(x, 1296, ah, al)
+    hh = torch.empty(1296, HID, device=dev, dtype=torch.bfloat16); hl = torch.empty_like(hh); out = torch.empty(1296, HID, device=dev, dtype=torch.bfloat16)
+    t1 = timeit(lambda: nv.planes_gemm(ah, al, w0, b0, act=1, out_hi=hh, out_lo=hl)); t2 = timeit(lambda: nv.planes_gemm(hh, hl, w2, b0, y=out))
+    print("planes gemm1 %.1f us (%.0f TF incl hi/lo)  gemm2 %.1f us" % (t1, 2 * 2 * 1296 * HID * E / t1 / 1e6, t2))
