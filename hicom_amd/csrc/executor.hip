@@ -153,11 +153,11 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         HICOM_REQUIRE(hipStreamWaitEvent(ss, (hipEvent_t)a.ev_fork, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
         return HICOM_OK;
     };
-    auto query_prep = [&](hipStream_t st) -> int {
+    auto query_prep = [&](hipStream_t st, bool with_local_rows) -> int {
         CHK(hicom_linear_fwd(a.gq, HICOM_DT_BF16, a.wq, HICOM_DT_BF16, a.bq, HICOM_DT_BF16, nullptr, 0, a.nq, a.E, a.E,
                              0, 0, HICOM_ACT_NONE, F(w.qp), st));
         return hicom_fold_query_split_fwd(F(w.qp), a.wk, a.kpe, a.nq, a.nh, a.E, a.P, qscale, ws + w.qhi, ws + w.qlo,
-                                          F(w.pos_a), a.P, st);
+                                          F(w.pos_a), a.P, with_local_rows ? a.lq : nullptr, w.R, 16 - w.R, st);
     };
     auto merge = [&](hipStream_t st) -> int {
         return hicom_global_merge_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E,
@@ -178,10 +178,9 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
 
     if (fused) {
         // ---- release recipe: ONE streaming kernel reads frames_embed and frames_feature once ------
-        // main: guide -> local rows of the A operand, q_proj, fold, fused stream | fork |
+        // main: q_proj, fold (+ guide -> local rows of the A operand), fused stream      | fork |
         // main: readout GEMMs            side: merge -> (finish)                 | join |
-        CHK(hicom_scatter_rows_fwd(a.lq, HICOM_DT_BF16, 1, a.E, ws + w.qhi, HICOM_DT_BF16, a.E, w.R, 1, 0, 16 - w.R, sm));
-        CHK(query_prep(sm));
+        CHK(query_prep(sm, true));
         CHK(hicom_fused_stream_fwd(a.ff, a.fe ? a.fe : a.ff, a.T, a.H, a.W, a.E, a.at.k, a.ay.k, ws + w.qhi, ws + w.qlo,
                                    w.R, a.l_scale, a.l_bias, a.pe ? F(w.pos_a) : nullptr, a.P, a.t_index0, a.y_index0,
                                    a.x_index0, F(w.scores), w.score_stride, F(w.part_m), F(w.part_l), F(w.part_acc),
@@ -216,7 +215,7 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                                      a.l_bias, a.l2norm, F(w.ctx_local), sm));
         }
         if (a.has_global) {
-            CHK(query_prep(sg));
+            CHK(query_prep(sg, false));
             CHK(hicom_global_stream_fwd(a.ff, w.N, a.E, ws + w.qhi, ws + w.qlo, w.R, w.rows_pad,
                                         a.pe ? F(w.pos_a) : nullptr, a.P, a.H, a.W, a.t_index0, a.y_index0, a.x_index0,
                                         F(w.scores), w.score_stride, F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, sg));

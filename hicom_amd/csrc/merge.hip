@@ -79,7 +79,7 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-constexpr int kTC = 32;   // frames of marginals staged in LDS per pass
+constexpr int kTC = 64;   // frames of marginals staged in LDS per pass (one pass for T <= 64)
 
 __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
     // LDS: [16*64] column partials | [4] | [nparts] partial weights | [T] frame weights |
@@ -94,6 +94,25 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
     float* wpos = wt + p.T;
     float* tile = wpos + (p.T + HW2);
     const float* sc = p.scratch ? p.scratch + (long)r * p.T * S : nullptr;
+
+    // Everything that does not depend on M is requested first, so the dependent chain below is
+    // M -> weights -> sums instead of one memory round trip per step:
+    //   (a) the first batch of partial-context rows of this thread's column group (raw values)
+    //   (b) the first chunk of the frame-marginal table -> LDS
+    const int pgp = tid >> 3, l4 = tid & 7;
+    const int c4 = blockIdx.y * 32 + 4 * l4;
+    const float* base = p.part_acc + (long)r * p.E + c4;
+    const long pstride = (long)p.rows_pad * p.E;
+    float4 v0[8];
+    const bool have0 = c4 < p.E && pgp + 32 * 7 < p.nparts;
+    if (have0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v0[u] = *reinterpret_cast<const float4*>(base + (long)(pgp + 32 * u) * pstride);
+    }
+    if (sc) {
+        const int nt = min(kTC, p.T);
+        for (int i = tid; i < nt * S; i += 256) tile[i] = sc[i];
+    }
 
     // (M, L) of this row from the partials
     float mx = -1.0e30f;
@@ -110,12 +129,19 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
     // positional weights: w_t = e^(m_t - M) * total_t ; w_y = sum_t e^(m_t - M) fy[t][y] ; w_x likewise.
     // The [T][S] marginal table is streamed through LDS in coalesced chunks of kTC frames.
     if (sc) {
-        for (int t = tid; t < p.T; t += 256) wt[t] = expf(sc[(long)t * S + HW2 + 1] - M);
         float ay[4] = {0.f, 0.f, 0.f, 0.f};      // up to 4 * 256 spatial marginals per thread
         for (int t0 = 0; t0 < p.T; t0 += kTC) {
             const int nt = min(kTC, p.T - t0);
-            __syncthreads();
-            for (int i = tid; i < nt * S; i += 256) tile[i] = sc[(long)t0 * S + i];
+            if (t0 > 0) {
+                __syncthreads();
+                for (int i = tid; i < nt * S; i += 256) tile[i] = sc[(long)t0 * S + i];
+                __syncthreads();
+            }
+            if (tid < nt) {
+                const float w = expf(tile[tid * S + HW2 + 1] - M);
+                wt[t0 + tid] = w;
+                wpos[t0 + tid] = w * tile[tid * S + HW2];
+            }
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -123,7 +149,6 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
                 if (j < HW2)
                     for (int tt = 0; tt < nt; ++tt) ay[u] = fmaf(wt[t0 + tt], tile[tt * S + j], ay[u]);
             }
-            if (tid < nt) wpos[t0 + tid] = wt[t0 + tid] * tile[tid * S + HW2];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -135,13 +160,17 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
 
     // context columns: 32 partial-groups x 8 lanes x float4 (32-column slab -> R * E/32 workgroups fill
     // the chip), 8 independent loads in flight per thread
-    const int pgp = tid >> 3, l4 = tid & 7;
-    const int c4 = blockIdx.y * 32 + 4 * l4;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < p.E) {
-        const float* base = p.part_acc + (long)r * p.E + c4;
-        const long pstride = (long)p.rows_pad * p.E;
         int i = pgp;
+        if (have0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float w = wp[i + 32 * u];
+                a.x = fmaf(w, v0[u].x, a.x); a.y = fmaf(w, v0[u].y, a.y); a.z = fmaf(w, v0[u].z, a.z); a.w = fmaf(w, v0[u].w, a.w);
+            }
+            i += 32 * 8;
+        }
         for (; i + 32 * 7 < p.nparts; i += 32 * 8) {
             float4 v[8];
 #pragma unroll

@@ -140,15 +140,26 @@ struct FoldParams {
     float* pos_a;
     int pos_stride;
     int nbE;
+    // optional: broadcast one bf16 row (the local query of the fused stream kernel) into rows
+    // [fill_row0, fill_row0 + fill_rows) of qhi -- saves a separate launch on the critical path
+    const uint16_t* fill;
+    int fill_row0, fill_rows;
 };
 
+// 256 threads = 16 j-groups x 16 lanes; a workgroup owns 32 w_k columns (2 per lane, one 4-byte load
+// per j) or 16 kpe columns of one head: hd/16 = 8 serial steps per thread, E/32 * nh workgroups.
 template <int QB>
 __global__ __launch_bounds__(256) void fold_query_kernel(FoldParams p) {
-    const int tid = threadIdx.x, jg = tid >> 6, cl = tid & 63;
+    const int tid = threadIdx.x, jg = tid >> 4, cl = tid & 15;
     const int h = blockIdx.y, q0 = blockIdx.z * QB;
-    const int hd = p.E / p.nh, jn = (hd + 3) / 4;
+    if (h == p.nh) {   // fill blocks
+        for (int i = blockIdx.x * 256 + tid; i < p.fill_rows * p.E; i += gridDim.x * 256)
+            p.qhi[(long)p.fill_row0 * p.E + i] = p.fill[i % p.E];
+        return;
+    }
+    const int hd = p.E / p.nh, jn = (hd + 15) / 16;
     __shared__ float qs[QB][128];          // hd <= 128
-    __shared__ float red[4][QB][128];
+    __shared__ float red[16][QB][32];
     for (int i = tid; i < QB * hd; i += 256) {
         const int q = i / hd, j = i - q * hd;
         qs[q][j] = (q0 + q < p.nq) ? p.qp[(long)(q0 + q) * p.E + h * hd + j] : 0.f;
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(256) void fold_query_kernel(FoldParams p) {
     for (int q = 0; q < QB; ++q) a0[q] = a1[q] = 0.f;
     const int j0 = jg * jn, j1 = min(hd, j0 + jn);
     if (is_w) {
-        const int c = blockIdx.x * 128 + 2 * cl;
+        const int c = blockIdx.x * 32 + 2 * cl;
         if (c < p.E) {
 #pragma unroll 8
             for (int j = j0; j < j1; ++j) {
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(256) void fold_query_kernel(FoldParams p) {
             }
         }
     } else {
-        const int pc = (blockIdx.x - p.nbE) * 64 + cl;
+        const int pc = (blockIdx.x - p.nbE) * 16 + cl;
         if (pc < p.P) {
 #pragma unroll 8
             for (int j = j0; j < j1; ++j) {
@@ -190,14 +201,16 @@ __global__ __launch_bounds__(256) void fold_query_kernel(FoldParams p) {
         red[jg][q][2 * cl + 1] = a1[q];
     }
     __syncthreads();
-    // 256 threads finish QB x 128 outputs
-    for (int o = tid; o < QB * 128; o += 256) {
-        const int q = o >> 7, i = o & 127;
+    for (int o = tid; o < QB * 32; o += 256) {
+        const int q = o >> 5, i = o & 31;
         if (q0 + q >= p.nq) continue;
-        const float v = ((red[0][q][i] + red[1][q][i]) + (red[2][q][i] + red[3][q][i])) * p.scale;
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) v += red[g][q][i];
+        v *= p.scale;
         const long row = (long)(q0 + q) * p.nh + h;
         if (is_w) {
-            const int c = blockIdx.x * 128 + i;
+            const int c = blockIdx.x * 32 + i;
             if (c < p.E) {
                 if (p.qt) p.qt[row * p.E + c] = v;
                 if (p.qhi) {
@@ -208,7 +221,7 @@ __global__ __launch_bounds__(256) void fold_query_kernel(FoldParams p) {
                 }
             }
         } else if ((i & 1) == 0) {
-            const int pc = (blockIdx.x - p.nbE) * 64 + (i >> 1);
+            const int pc = (blockIdx.x - p.nbE) * 16 + (i >> 1);
             if (pc < p.P) p.pos_a[row * p.pos_stride + pc] = v;
         }
     }
@@ -287,12 +300,13 @@ extern "C" int hicom_linear_to_rows_fwd(const void* x, int32_t x_dt, const void*
 
 
 static int launch_fold(const float* qp, const void* w_k, const float* kpe, int nq, int nh, int E, int P, float scale,
-                       float* qt, void* hi, void* lo, float* pos_a, int pos_stride, void* stream) {
-    constexpr int QB = 8;
+                       float* qt, void* hi, void* lo, float* pos_a, int pos_stride, const void* fill, int fill_row0,
+                       int fill_rows, void* stream) {
     FoldParams p{qp, (const uint16_t*)w_k, kpe, nq, nh, E, kpe ? P : 0, scale, qt, (uint16_t*)hi, (uint16_t*)lo,
-                 pos_a, pos_stride, (E + 127) / 128};
-    dim3 grid((unsigned)(p.nbE + (p.P + 63) / 64), (unsigned)nh, (unsigned)((nq + QB - 1) / QB));
-    hipLaunchKernelGGL(fold_query_kernel<QB>, grid, dim3(256), 0, (hipStream_t)stream, p);
+                 pos_a, pos_stride, (E + 31) / 32, (const uint16_t*)fill, fill_row0, fill ? fill_rows : 0};
+    const unsigned gx = (unsigned)(p.nbE + (p.P + 15) / 16), gy = (unsigned)(nh + (p.fill_rows > 0 ? 1 : 0));
+    if (nq == 1) hipLaunchKernelGGL(fold_query_kernel<1>, dim3(gx, gy, 1), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(fold_query_kernel<8>, dim3(gx, gy, (unsigned)((nq + 7) / 8)), dim3(256), 0, (hipStream_t)stream, p);
     return hicom_host::check_launch("fold_query");
 }
 
@@ -300,16 +314,19 @@ extern "C" int hicom_fold_query_fwd(const float* qp, const void* w_k, int32_t nq
                                     float scale, float* qt, void* stream) {
     HICOM_REQUIRE(qp && w_k && qt, HICOM_EINVAL, "fold_query: NULL pointer");
     HICOM_REQUIRE(nq > 0 && nh > 0 && E > 0 && E % nh == 0 && E / nh <= 128 && E % 2 == 0, HICOM_EINVAL, "fold_query: bad shape");
-    return launch_fold(qp, w_k, nullptr, nq, nh, E, 0, scale, qt, nullptr, nullptr, nullptr, 0, stream);
+    return launch_fold(qp, w_k, nullptr, nq, nh, E, 0, scale, qt, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, stream);
 }
 
 extern "C" int hicom_fold_query_split_fwd(const float* qp, const void* w_k, const float* kpe, int32_t nq, int32_t nh,
                                           int32_t E, int32_t P, float scale, void* qt_hi, void* qt_lo,
-                                          float* pos_a, int32_t pos_stride, void* stream) {
+                                          float* pos_a, int32_t pos_stride, const void* fill_row, int32_t fill_row0,
+                                          int32_t fill_rows, void* stream) {
     HICOM_REQUIRE(qp && w_k && qt_hi && qt_lo, HICOM_EINVAL, "fold_query_split: NULL pointer");
     HICOM_REQUIRE(nq > 0 && nh > 0 && E > 0 && E % nh == 0 && E / nh <= 128 && E % 2 == 0, HICOM_EINVAL, "fold_query_split: bad shape");
     HICOM_REQUIRE(!kpe || (pos_a && P > 0 && pos_stride >= P), HICOM_EINVAL, "fold_query_split: positional outputs");
-    return launch_fold(qp, w_k, kpe, nq, nh, E, P, scale, nullptr, qt_hi, qt_lo, pos_a, pos_stride, stream);
+    HICOM_REQUIRE(!fill_row || (fill_row0 >= nq * nh && fill_rows > 0), HICOM_EINVAL, "fold_query_split: fill rows overlap the queries");
+    return launch_fold(qp, w_k, kpe, nq, nh, E, P, scale, nullptr, qt_hi, qt_lo, pos_a, pos_stride, fill_row, fill_row0,
+                       fill_rows, stream);
 }
 
 extern "C" int hicom_split_bf16_fwd(const float* x, int32_t rows, int32_t rows_pad, int32_t E,

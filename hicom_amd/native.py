@@ -103,7 +103,7 @@ def lib() -> C.CDLL:
                                          vp, i64, vp, vp, vp, i32, vp, vp, vp, vp]
     L.hicom_fused_stream_nparts.argtypes = [i32]
     L.hicom_planes_gemm_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i64, i64, i32, vp]
-    L.hicom_fold_query_split_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, i32, vp]
+    L.hicom_fold_query_split_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, i32, vp, i32, i32, vp]
     L.hicom_global_combine_strided_fwd.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
     ap = C.POINTER(CompressorArgs)
     L.hicom_compressor_workspace_bytes.argtypes = [ap]
@@ -230,12 +230,12 @@ def scatter_rows(src, dst, row0, count, row_step=1, nl_group=0):
                                         dst.shape[-1], row0, row_step, nl_group, count, _stream()), "hicom_scatter_rows_fwd")
 
 
-def fold_query_split(qp, w_k, kpe, nh, scale, qhi, qlo, pos_a):
+def fold_query_split(qp, w_k, kpe, nh, scale, qhi, qlo, pos_a, fill_row=None, fill_row0=0, fill_rows=0):
     nq, E = qp.shape
     P = kpe.shape[1] if kpe is not None else 0
     _check(lib().hicom_fold_query_split_fwd(_ptr(qp), _ptr(w_k), _ptr(kpe), nq, nh, E, P, scale, _ptr(qhi), _ptr(qlo),
-                                            _ptr(pos_a), pos_a.shape[1] if pos_a is not None else 0, _stream()),
-           "hicom_fold_query_split_fwd")
+                                            _ptr(pos_a), pos_a.shape[1] if pos_a is not None else 0, _ptr(fill_row),
+                                            fill_row0, fill_rows, _stream()), "hicom_fold_query_split_fwd")
 
 
 def global_combine_strided(ml, acc, set_stride, nsets, rows, E, ctx):

@@ -108,10 +108,13 @@ int hicom_fold_query_fwd(const float* qp, const void* w_k, int32_t nq, int32_t n
  *   pos_a[(q*nh + h), p] = scale * sum_j kpe[h*hd + j, p] * qp[q, h*hd + j]  ( = qt . PE[p] )
  * from kpe = w_k . PE^T (f32 [E, P]; depends on the weights only -- the caller caches it, the way
  * the reference caches its pos_embed buffer, projector.py:603-607).  Rows >= nq*nh of qt_hi /
- * qt_lo / pos_a are not written (callers keep them zero). */
+ * qt_lo / pos_a are not written (callers keep them zero), except that fill_row (bf16 [E], may be
+ * NULL) is broadcast into rows [fill_row0, fill_row0 + fill_rows) of qt_hi: the local query rows of
+ * hicom_fused_stream_fwd's operand. */
 int hicom_fold_query_split_fwd(const float* qp, const void* w_k, const float* kpe, int32_t nq, int32_t nh,
                                int32_t E, int32_t P, float scale, void* qt_hi, void* qt_lo,
-                               float* pos_a, int32_t pos_stride, void* stream);
+                               float* pos_a, int32_t pos_stride, const void* fill_row, int32_t fill_row0,
+                               int32_t fill_rows, void* stream);
 
 /* Split f32 rows into bf16 hi + lo parts (x ~= hi + lo to 2^-16), zero-padding the row count
  * to rows_pad: the MFMA operand format for fp32 intermediates (SURVEY.md §7 strategy B). */
