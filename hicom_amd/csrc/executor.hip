@@ -211,7 +211,7 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                 q_dt = HICOM_DT_F32;
                 q_stride = a.E;
             }
-            CHK(hicom_local_attn_fwd(a.fe ? a.fe : a.ff, a.ff, a.E, a.at, a.ay, a.ax, q, q_dt, q_stride, a.l_scale,
+            CHK(hicom_local_attn_fwd(a.fe ? a.fe : a.ff, HICOM_DT_BF16, a.ff, HICOM_DT_BF16, a.E, a.at, a.ay, a.ax, q, q_dt, q_stride, a.l_scale,
                                      a.l_bias, a.l2norm, F(w.ctx_local), sm));
         }
         if (a.has_global) {

@@ -1,0 +1,137 @@
+// Row-wise operators of the instruction injector and the q/k/v adaptors
+// (reference projector.py:315-397 GuideInjector, :431-457 / :533-541 adaptors):
+//
+//   hicom_row_ln_fwd   out = (1 - alpha) * src + alpha * (LayerNorm(x * (1 + mul) + add) * gamma + beta)
+//       coarse   : x = visual query, mul/add = FiLM scale/shift (one broadcast row), alpha = 1      (:369-372)
+//       fine     : x = query, add = attention output per row, alpha = 1                             (:392)
+//       adapt_*  : x = proj(src), src = un-adapted tensor, alpha = learned scalar                   (:365,:533-541)
+//   hicom_small_mha_fwd  per-row multi-head attention over a short key list (the L = 64 text tokens
+//       of "fine" injection, :391): projected q [M,E], k/v [L,E] -> [M,E]
+//
+// One wave per row (E <= 4096), values kept in registers; LayerNorm statistics in fp32, eps = 1e-6.
+#include "common.hpp"
+
+namespace hicom {
+
+struct RowLnParams {
+    const void* x; int x_dt; long x_stride;
+    const float* mul; long mul_stride;     // NULL or [*,E]; stride 0 = broadcast row
+    const float* add; long add_stride;
+    const void* gamma; const void* beta; int gb_dt;
+    const void* src; int src_dt; long src_stride;   // blend source (NULL => alpha must be 1)
+    const void* alpha_ptr; int alpha_dt;             // device scalar or NULL (=> alpha = 1)
+    float eps;
+    void* out; int out_dt; long out_stride;
+    int M, E;
+};
+
+__device__ __forceinline__ float ld(const void* p, int dt, long i) {
+    return dt == HICOM_DT_F32 ? reinterpret_cast<const float*>(p)[i] : bf16_to_f32(reinterpret_cast<const uint16_t*>(p)[i]);
+}
+
+constexpr int kMaxPerLane = 64;   // E <= 4096
+
+// NPL = channels per lane, compile-time so the row stays in registers (18 for E = 1152, 12 for 768)
+template <int NPL>
+__global__ __launch_bounds__(256) void row_ln_kernel(RowLnParams p) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= p.M) return;
+    constexpr int n = NPL;
+    float v[NPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+        const int c = lane + 64 * i;
+        float t = 0.f;
+        if (c < p.E) {
+            t = ld(p.x, p.x_dt, m * p.x_stride + c);
+            if (p.mul) t *= 1.0f + p.mul[m * p.mul_stride + c];
+            if (p.add) t += p.add[m * p.add_stride + c];
+        }
+        v[i] = t;
+        sum += t;
+    }
+    const float mean = wave_sum(sum) / (float)p.E;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+        const int c = lane + 64 * i;
+        const float d = c < p.E ? v[i] - mean : 0.f;
+        var += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)p.E + p.eps);
+    const float alpha = p.alpha_ptr ? ld(p.alpha_ptr, p.alpha_dt, 0) : 1.0f;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+        const int c = lane + 64 * i;
+        if (c >= p.E) continue;
+        float y = (v[i] - mean) * rstd * ld(p.gamma, p.gb_dt, c) + ld(p.beta, p.gb_dt, c);
+        if (p.src) y = (1.0f - alpha) * ld(p.src, p.src_dt, m * p.src_stride + c) + alpha * y;
+        if (p.out_dt == HICOM_DT_F32) reinterpret_cast<float*>(p.out)[m * p.out_stride + c] = y;
+        else reinterpret_cast<uint16_t*>(p.out)[m * p.out_stride + c] = f32_to_bf16(y);
+    }
+}
+
+// ---- small MHA: one wave per (row, head); lane = key token (L <= 64) for the scores, lane = channel
+// pair for the weighted sum; fp32 softmax (reference projector.py:197-215 with scale = hd^-1/2).
+__global__ __launch_bounds__(256) void small_mha_kernel(const float* q, const float* k, const float* v, int M, int L,
+                                                        int nh, int hd, float scale, float* out) {
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (long)M * nh) return;
+    const long m = wid / nh;
+    const int h = (int)(wid - m * nh), E = nh * hd;
+    const float* qh = q + m * E + h * hd;
+    float s = -1.0e30f;
+    if (lane < L) {
+        const float* kh = k + (long)lane * E + h * hd;
+        float d = 0.f;
+        for (int c = 0; c < hd; ++c) d = fmaf(qh[c], kh[c], d);
+        s = d * scale;
+    }
+    const float mx = wave_max(s);
+    const float e = lane < L ? expf(s - mx) : 0.f;
+    const float pr = e / wave_sum(e);
+    for (int c0 = 0; c0 < hd; c0 += 64) {
+        const int c = c0 + lane;
+        float a = 0.f;
+        for (int t = 0; t < L; ++t) {
+            const float pt = __shfl(pr, t, 64);
+            if (c < hd) a = fmaf(pt, v[(long)t * E + h * hd + c], a);
+        }
+        if (c < hd) out[m * E + h * hd + c] = a;
+    }
+}
+
+}  // namespace hicom
+
+using namespace hicom;
+
+extern "C" int hicom_row_ln_fwd(const void* x, int32_t x_dt, int64_t x_stride,
+                                const float* mul, int64_t mul_stride, const float* add, int64_t add_stride,
+                                const void* gamma, const void* beta, int32_t gb_dt,
+                                const void* src, int32_t src_dt, int64_t src_stride,
+                                const void* alpha, int32_t alpha_dt, float eps,
+                                void* out, int32_t out_dt, int64_t out_stride, int32_t M, int32_t E, void* stream) {
+    HICOM_REQUIRE(x && gamma && beta && out, HICOM_EINVAL, "row_ln: NULL pointer");
+    HICOM_REQUIRE(M > 0 && E > 0 && E <= 64 * kMaxPerLane, HICOM_EINVAL, "row_ln: bad shape M=%d E=%d", M, E);
+    HICOM_REQUIRE(src || !alpha, HICOM_EINVAL, "row_ln: alpha without a blend source");
+    RowLnParams p{x, x_dt, (long)x_stride, mul, (long)mul_stride, add, (long)add_stride, gamma, beta, gb_dt,
+                  src, src_dt, (long)src_stride, alpha, alpha_dt, eps, out, out_dt, (long)out_stride, M, E};
+    const dim3 grid((unsigned)((M + 3) / 4));
+    if (E <= 768) hipLaunchKernelGGL(row_ln_kernel<12>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (E <= 1152) hipLaunchKernelGGL(row_ln_kernel<18>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(row_ln_kernel<kMaxPerLane>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return hicom_host::check_launch("row_ln");
+}
+
+extern "C" int hicom_small_mha_fwd(const float* q, const float* k, const float* v, int32_t M, int32_t L,
+                                   int32_t nh, int32_t hd, float* out, void* stream) {
+    HICOM_REQUIRE(q && k && v && out, HICOM_EINVAL, "small_mha: NULL pointer");
+    HICOM_REQUIRE(M > 0 && L > 0 && L <= 64 && nh > 0 && hd > 0, HICOM_EUNSUP, "small_mha: L=%d (<= 64 keys supported)", L);
+    const long waves = (long)M * nh;
+    hipLaunchKernelGGL(small_mha_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, k, v, M, L,
+                       nh, hd, 1.0f / sqrtf((float)hd), out);
+    return hicom_host::check_launch("small_mha");
+}

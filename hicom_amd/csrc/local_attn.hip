@@ -20,8 +20,9 @@ namespace hicom {
 struct __attribute__((packed, aligned(4))) Seg12 { uint32_t a, b, c; };
 
 struct LocalParams {
-    const uint16_t* key;
-    const uint16_t* value;
+    const void* key;
+    const void* value;
+    int key_f32, value_f32;      // adapted (alpha-blended) streams arrive as fp32, raw tokens as bf16
     const void* query;
     int query_f32;
     long query_stride;
@@ -40,6 +41,24 @@ __device__ __forceinline__ void load_row(const uint16_t* row, int lane, float (&
         v[s][2] = bf16lo_to_f32(g.b); v[s][3] = bf16hi_to_f32(g.b);
         v[s][4] = bf16lo_to_f32(g.c); v[s][5] = bf16hi_to_f32(g.c);
     }
+}
+
+template <int NV>
+__device__ __forceinline__ void load_row_f32(const float* row, int lane, float (&v)[NV][6]) {
+#pragma unroll
+    for (int s = 0; s < NV; ++s) {
+        const Seg12 a = *reinterpret_cast<const Seg12*>(row + 384 * s + 6 * lane);
+        const Seg12 b = *reinterpret_cast<const Seg12*>(row + 384 * s + 6 * lane + 3);
+        v[s][0] = __uint_as_float(a.a); v[s][1] = __uint_as_float(a.b); v[s][2] = __uint_as_float(a.c);
+        v[s][3] = __uint_as_float(b.a); v[s][4] = __uint_as_float(b.b); v[s][5] = __uint_as_float(b.c);
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ void load_stream_row(const void* base, int is_f32, long token, int lane, float (&v)[NV][6]) {
+    constexpr int D = NV * 384;
+    if (is_f32) load_row_f32<NV>(reinterpret_cast<const float*>(base) + token * D, lane, v);
+    else load_row<NV>(reinterpret_cast<const uint16_t*>(base) + token * D, lane, v);
 }
 
 template <int NV>
@@ -95,7 +114,7 @@ __global__ __launch_bounds__(256) void local_attn_kernel(LocalParams p) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int i = i0 + 4 * u;
-            if (i < WIN) load_row<NV>(p.key + token_of(i) * D, lane, k[u]);
+            if (i < WIN) load_stream_row<NV>(p.key, p.key_f32, token_of(i), lane, k[u]);
         }
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
@@ -136,7 +155,7 @@ __global__ __launch_bounds__(256) void local_attn_kernel(LocalParams p) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int i = i0 + 4 * u;
-            if (i < WIN) load_row<NV>(p.value + token_of(i) * D, lane, v[u]);
+            if (i < WIN) load_stream_row<NV>(p.value, p.value_f32, token_of(i), lane, v[u]);
         }
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
@@ -204,7 +223,7 @@ __global__ __launch_bounds__(256) void trilinear_pool_kernel(PoolParams p) {
 
 using namespace hicom;
 
-extern "C" int hicom_local_attn_fwd(const void* key, const void* value, int32_t D,
+extern "C" int hicom_local_attn_fwd(const void* key, int32_t key_dt, const void* value, int32_t value_dt, int32_t D,
                                     hicom_axis at, hicom_axis ay, hicom_axis ax,
                                     const void* query, int32_t query_dt, int64_t query_stride,
                                     float scale, float bias, int32_t l2norm,
@@ -222,7 +241,7 @@ extern "C" int hicom_local_attn_fwd(const void* key, const void* value, int32_t 
     HICOM_REQUIRE(win <= 4096, HICOM_EUNSUP, "local_attn: window of %ld tokens is too large", win);
     const long nwin = (long)at.nwin * ay.nwin * ax.nwin;
     HICOM_REQUIRE(nwin < (1L << 31), HICOM_EINVAL, "local_attn: too many windows");
-    LocalParams p{(const uint16_t*)key, (const uint16_t*)value, query, query_dt == HICOM_DT_F32,
+    LocalParams p{key, value, key_dt == HICOM_DT_F32, value_dt == HICOM_DT_F32, query, query_dt == HICOM_DT_F32,
                   (long)query_stride, at, ay, ax, scale, bias, l2norm, ctx};
     const size_t smem = (((size_t)win + 3) & ~(size_t)3) * 4 + 4 * (size_t)D * 4;
     hipStream_t s = (hipStream_t)stream;

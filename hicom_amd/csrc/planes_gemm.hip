@@ -38,6 +38,9 @@ struct PlanesGemmParams {
 constexpr int kPStage = 3 * 8192;     // bytes per ring stage: A_hi, A_lo, W images of 64 x 128 B
 constexpr int kPRing = 3;
 
+// HAS_LO = false: the activation is exactly bf16 (raw visual tokens feeding the k/v adaptor MLPs): no
+// lo plane is fetched and half the MFMAs are issued.
+template <bool HAS_LO>
 __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(PlanesGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [kPRing][kPStage]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(PlanesGemmParams p)
         if (op < 2) {
             int m = m0 + row;
             m = m < p.M ? m : p.M - 1;
-            src[i] = (op == 0 ? p.a_hi : p.a_lo) + (long)m * p.K + 8 * chunk;
+            src[i] = ((op == 0 || !HAS_LO) ? p.a_hi : p.a_lo) + (long)m * p.K + 8 * chunk;
         } else {
             int n = n0 + row;
             n = n < p.N ? n : p.N - 1;
@@ -76,9 +79,12 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(PlanesGemmParams p)
     auto issue = [&](int s) {
         char* base = lds + (s % kPRing) * kPStage;
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < 6; ++i) {
+            // pieces 8..15 are the lo plane (i = 2, 3 of every wave: pi = wave + 4*i in [8, 16))
+            if (!HAS_LO && (i == 2 || i == 3)) continue;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + 64 * s),
                                              (__attribute__((address_space(3))) void*)(base + dst_off[i]), 16, 0, 0);
+        }
     };
 
     f32x4 acc[2][2];
@@ -92,8 +98,12 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(PlanesGemmParams p)
 
     for (int s = 0; s < ns; ++s) {
         // stage s has landed for every wave; stage s+1 may still be in flight
-        if (s + 1 < ns) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (s + 1 < ns) {
+            if (HAS_LO) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // every wave is past compute(s-1): its ring slot is free for stage s+2
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(PlanesGemmParams p)
                 const int ar = 32 * wm + 16 * i + r16;
                 const int aoff = ar * 128 + 16 * ((4 * kk + kg) ^ (ar & 7));
                 fa_hi[i] = *reinterpret_cast<const bf16x8*>(st + aoff);
-                fa_lo[i] = *reinterpret_cast<const bf16x8*>(st + 8192 + aoff);
+                if (HAS_LO) fa_lo[i] = *reinterpret_cast<const bf16x8*>(st + 8192 + aoff);
                 const int br = 32 * wn + 16 * i + r16;
                 fb[i] = *reinterpret_cast<const bf16x8*>(st + 16384 + br * 128 + 16 * ((4 * kk + kg) ^ (br & 7)));
             }
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(PlanesGemmParams p)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[i], fb[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_lo[i], fb[j], acc[i][j], 0, 0, 0);
+                    if (HAS_LO) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_lo[i], fb[j], acc[i][j], 0, 0, 0);
                 }
         }
     }
@@ -160,11 +170,11 @@ extern "C" int hicom_planes_gemm_fwd(const void* a_hi, const void* a_lo, const v
                                      int32_t M, int32_t N, int32_t K, int32_t act,
                                      void* out_hi, void* out_lo,
                                      void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group, void* stream) {
-    HICOM_REQUIRE(a_hi && a_lo && w, HICOM_EINVAL, "planes_gemm: NULL pointer");
+    HICOM_REQUIRE(a_hi && w, HICOM_EINVAL, "planes_gemm: NULL pointer");
     HICOM_REQUIRE((out_hi && out_lo) || y, HICOM_EINVAL, "planes_gemm: no output");
     HICOM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, HICOM_EINVAL, "planes_gemm: bad shape M=%d N=%d K=%d (K %% 64)", M, N, K);
     HICOM_REQUIRE(!y || (ldy >= N && row0 >= 0 && nl_group >= 0), HICOM_EINVAL, "planes_gemm: bad output layout");
-    HICOM_REQUIRE(((uintptr_t)a_hi % 16 == 0) && ((uintptr_t)a_lo % 16 == 0) && ((uintptr_t)w % 16 == 0), HICOM_EINVAL,
+    HICOM_REQUIRE(((uintptr_t)a_hi % 16 == 0) && ((uintptr_t)a_lo % 16 == 0) && ((uintptr_t)w % 16 == 0) && M < (1 << 30), HICOM_EINVAL,
                   "planes_gemm: alignment");
     PlanesGemmParams p{(const uint16_t*)a_hi, (const uint16_t*)a_lo, (const uint16_t*)w, b, b_dt == HICOM_DT_F32,
                        M, N, K, act, (uint16_t*)out_hi, (uint16_t*)out_lo, y, y_dt == HICOM_DT_F32, (long)ldy, (long)row0,
@@ -172,11 +182,14 @@ extern "C" int hicom_planes_gemm_fwd(const void* a_hi, const void* a_lo, const v
     const int nbx = (N + 63) / 64, nby = (M + 63) / 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(planes_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(planes_gemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kPRing * kPStage);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(planes_gemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kPRing * kPStage);
         attr_set = true;
     }
-    hipLaunchKernelGGL(planes_gemm_kernel, dim3((unsigned)(8 * nbx * ((nby + 7) / 8))), dim3(256), kPRing * kPStage,
-                       (hipStream_t)stream, p);
+    const dim3 grid((unsigned)(8 * nbx * ((nby + 7) / 8)));
+    if (a_lo) hipLaunchKernelGGL(planes_gemm_kernel<true>, grid, dim3(256), kPRing * kPStage, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(planes_gemm_kernel<false>, grid, dim3(256), kPRing * kPStage, (hipStream_t)stream, p);
     return hicom_host::check_launch("planes_gemm");
 }

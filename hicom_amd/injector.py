@@ -1,0 +1,116 @@
+"""Host orchestration of the instruction injector and the q/k/v adaptors on the HIP kernels
+(reference projector.py:315-397 GuideInjector, :431-457 + :533-541 adaptors).
+
+Every function enqueues C-ABI kernels on the current stream and returns device tensors; there is no
+PyTorch arithmetic here.  Small row counts use the wave-per-column linear kernel, token-sized row
+counts use the MFMA GEMMs.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import native as nv
+
+
+def _f32(shape, device):
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def _wb(lin):
+    w = lin.weight.detach()
+    if not w.is_cuda or w.dtype != torch.bfloat16:
+        raise NotImplementedError("hicom_amd: projector weights must be bfloat16 on the GPU")
+    return w, (lin.bias.detach() if lin.bias is not None else None)
+
+
+def linear_rows(x, lin, act=nv.ACT_NONE, res=None):
+    """y = act(x @ W^T + b) (+ res) for x [M, K] (bf16 or f32) -> f32 [M, N]; any M."""
+    w, b = _wb(lin)
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    M = x2.shape[0]
+    y = _f32((M, w.shape[0]), x2.device)
+    if M <= 64 or x2.dtype != torch.float32 or res is not None or w.shape[1] % 64:
+        nv.linear(x2, w, b, y, res=res, act=act)
+    else:
+        nv.readout_gemm(x2, w, b, y, act=act)            # MFMA path, fp32 activations split on the fly
+    return y
+
+
+def mlp2_rows(x, mlp, out_features=None):
+    """build_mlp(depth 2): Linear -> GELU -> Linear on a few rows (ref :307-312)."""
+    return linear_rows(linear_rows(x, mlp[0], act=nv.ACT_GELU), mlp[2])
+
+
+def adapted_guide(inj, guide):
+    """(1 - a) g + a LN(MLP(g)) when the injector has adapt_guide (ref :365 / :389); else the guide."""
+    if isinstance(inj.guide_alpha, (int, float)):
+        return guide
+    g = guide.reshape(-1, guide.shape[-1]).contiguous()
+    h = mlp2_rows(g, inj.guide_proj)
+    out = _f32(g.shape, g.device)
+    nv.row_ln(h, inj.guide_norm, out, src=g, alpha=inj.guide_alpha.detach())
+    return out.reshape(guide.shape)
+
+
+def inject(inj, mode, visual, guide):
+    """GuideInjector.forward for `visual` [M, D] (the pooled / learnable queries).
+
+    Returns (query, shared): shared=True means one row that every position uses ("direct")."""
+    if mode in (None, "off"):
+        return visual, False
+    if mode == "direct":
+        if guide.ndim != 1:
+            raise ValueError("direct guide injection takes a [D] guide embedding")
+        return adapted_guide(inj, guide).reshape(1, -1), True
+    D = visual.shape[-1]
+    vis = visual.reshape(-1, D).contiguous()
+    out = _f32(vis.shape, vis.device)
+    if mode == "coarse":
+        if guide.ndim != 1:
+            raise ValueError("coarse guide injection takes a [D] guide embedding")
+        g = adapted_guide(inj, guide).reshape(1, -1)
+        cs = mlp2_rows(g, inj.coarse_proj)                      # [1, 2D]: FiLM (scale | shift)  (ref :370-371)
+        nv.row_ln(vis, inj.coarse_norm, out, mul=cs[:, :D], add=cs[:, D:])      # LN(v * (1 + scale) + shift)  (:372)
+        return out, False
+    if mode == "fine":
+        if guide.ndim != 2:
+            raise ValueError("fine guide injection takes an [L, D] guide embedding")
+        g = adapted_guide(inj, guide)
+        att = inj.fine_proj
+        qp = linear_rows(vis, att.q_proj)
+        kp = linear_rows(g, att.k_proj)
+        vp = linear_rows(g, att.v_proj)
+        ao = _f32(vis.shape, vis.device)
+        nv.small_mha(qp, kp, vp, att.num_heads, ao)             # softmax(q k^T / sqrt(hd)) v over the L tokens (:391)
+        o = linear_rows(ao, att.out_proj)
+        nv.row_ln(vis, inj.fine_norm, out, add=o)               # LN(q + attn)  (:392)
+        return out, False
+    raise NotImplementedError(f"use_guide={mode!r}")
+
+
+def adapt_stream(x, mlp, norm, alpha):
+    """(1 - a) x + a LN(MLP(x)) over ALL tokens (adapt_k / adapt_v, ref :533-534): x bf16 [T,h,w,D] ->
+    f32 [T,h,w,D].  Two MFMA GEMMs on bf16 planes (the raw tokens are exact bf16: no lo plane for the
+    first one) and a row-wise LayerNorm blend."""
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D).contiguous()
+    N = x2.shape[0]
+    w0, b0 = _wb(mlp[0])
+    w2, b2 = _wb(mlp[2])
+    hid_hi = torch.empty((N, w0.shape[0]), dtype=torch.bfloat16, device=x.device)
+    hid_lo = torch.empty_like(hid_hi)
+    nv.planes_gemm(x2, None, w0, b0, act=nv.ACT_GELU, out_hi=hid_hi, out_lo=hid_lo)
+    y = _f32((N, w2.shape[0]), x.device)
+    nv.planes_gemm(hid_hi, hid_lo, w2, b2, y=y)
+    out = _f32((N, D), x.device)
+    nv.row_ln(y, norm, out, src=x2, alpha=alpha.detach())
+    return out.reshape(x.shape)
+
+
+def adapt_query(q, proj, norm, alpha):
+    """(1 - a) q + a LN(q W^T)  (adapt_q, Linear without bias, ref :433,:541)."""
+    q2 = q.reshape(-1, q.shape[-1]).contiguous()
+    h = linear_rows(q2, proj)
+    out = _f32(q2.shape, q2.device)
+    nv.row_ln(h, norm, out, src=q2, alpha=alpha.detach())
+    return out.reshape(q.shape)

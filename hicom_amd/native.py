@@ -26,7 +26,7 @@ EXPORTS = (
     "hicom_readout_gemm_fwd", "hicom_scatter_rows_fwd", "hicom_fold_query_split_fwd",
     "hicom_global_combine_strided_fwd", "hicom_compressor_workspace_bytes", "hicom_compressor_zero_prefix_bytes",
     "hicom_compressor_fwd", "hicom_linear_to_rows_fwd", "hicom_fused_stream_fwd", "hicom_fused_stream_nparts",
-    "hicom_planes_gemm_fwd",
+    "hicom_planes_gemm_fwd", "hicom_row_ln_fwd", "hicom_small_mha_fwd",
 )
 
 PHASE_STREAM, PHASE_FINISH = 1, 2
@@ -88,7 +88,7 @@ def lib() -> C.CDLL:
     if L.hicom_abi_version() != ABI_VERSION:
         raise HicomNativeError(f"ABI mismatch: library {L.hicom_abi_version()} vs binding {ABI_VERSION}; rebuild")
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
-    L.hicom_local_attn_fwd.argtypes = [vp, vp, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32, i32, vp, vp]
+    L.hicom_local_attn_fwd.argtypes = [vp, i32, vp, i32, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32, i32, vp, vp]
     L.hicom_trilinear_pool_fwd.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.hicom_linear_fwd.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.hicom_fold_query_fwd.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp]
@@ -103,6 +103,9 @@ def lib() -> C.CDLL:
                                          vp, i64, vp, vp, vp, i32, vp, vp, vp, vp]
     L.hicom_fused_stream_nparts.argtypes = [i32]
     L.hicom_planes_gemm_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i64, i64, i32, vp]
+    L.hicom_row_ln_fwd.argtypes = [vp, i32, i64, vp, i64, vp, i64, vp, vp, i32, vp, i32, i64, vp, i32, f32, vp, i32, i64,
+                                   i32, i32, vp]
+    L.hicom_small_mha_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
     L.hicom_fold_query_split_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, i32, vp, i32, i32, vp]
     L.hicom_global_combine_strided_fwd.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
     ap = C.POINTER(CompressorArgs)
@@ -153,7 +156,7 @@ def _stream():
 # ------------------------------------------------------------------------------------------
 def local_attn(key, value, axes, query, query_stride, scale, bias, l2norm, ctx):
     D = value.shape[-1]
-    _check(lib().hicom_local_attn_fwd(_ptr(key), _ptr(value), D, axes[0], axes[1], axes[2], _ptr(query), _dt(query),
+    _check(lib().hicom_local_attn_fwd(_ptr(key), _dt(key), _ptr(value), _dt(value), D, axes[0], axes[1], axes[2], _ptr(query), _dt(query),
                                       query_stride, scale, bias, l2norm, _ptr(ctx), _stream()), "hicom_local_attn_fwd")
 
 
@@ -286,3 +289,24 @@ def planes_gemm(a_hi, a_lo, w, b, act=ACT_NONE, out_hi=None, out_lo=None, y=None
                                        act, _ptr(out_hi), _ptr(out_lo), _ptr(y), _dt(y) if y is not None else 0,
                                        y.shape[-1] if y is not None else 0, row0, nl_group, _stream()),
            "hicom_planes_gemm_fwd")
+
+
+def row_ln(x, norm, out, mul=None, add=None, src=None, alpha=None, eps=1e-6):
+    """out = (1-alpha)*src + alpha*LN(x*(1+mul)+add); mul/add rows broadcast when they have one row."""
+    x2, o2 = x.reshape(-1, x.shape[-1]), out.reshape(-1, out.shape[-1])
+    M, E = x2.shape
+    bstride = lambda t: 0 if (t is None or t.reshape(-1, E).shape[0] == 1) else E
+    s2 = src.reshape(-1, E) if src is not None else None
+    if s2 is not None and s2.shape[0] == 1 and M > 1:
+        raise HicomNativeError("row_ln: blend source must have one row per output row")
+    _check(lib().hicom_row_ln_fwd(_ptr(x2), _dt(x2), E, _ptr(mul), bstride(mul), _ptr(add), bstride(add),
+                                  _ptr(norm.weight.detach()), _ptr(norm.bias.detach()), _dt(norm.weight),
+                                  _ptr(s2), _dt(s2) if s2 is not None else 0, E,
+                                  _ptr(alpha), _dt(alpha) if alpha is not None else 0, eps,
+                                  _ptr(o2), _dt(o2), E, M, E, _stream()), "hicom_row_ln_fwd")
+
+
+def small_mha(q, k, v, nh, out):
+    M, E = q.shape
+    _check(lib().hicom_small_mha_fwd(_ptr(q), _ptr(k), _ptr(v), M, k.shape[0], nh, E // nh, _ptr(out), _stream()),
+           "hicom_small_mha_fwd")

@@ -164,15 +164,20 @@ class LocalCompressor(nn.Module):
         ks = self.spatial_kernel_size
         return geo.axis_tiling(T, kt), geo.axis_tiling(H, ks), geo.axis_tiling(W, ks)
 
+    @property
+    def is_plain(self) -> bool:
+        """True for the configurations the one-call executor covers: guide direct / off, no adaptors."""
+        return self.use_guide in _NATIVE_GUIDE_MODES and not (self.adapt_q or self.adapt_k or self.adapt_v
+                                                             or self.adapt_guide)
+
     def _check_native(self):
-        if self.use_guide not in _NATIVE_GUIDE_MODES:
-            raise NotImplementedError(f"LocalCompressor: use_guide={self.use_guide!r} has no HIP path yet "
-                                      "(native modes: direct, off)")
-        if self.adapt_q or self.adapt_k or self.adapt_v or self.adapt_guide:
-            raise NotImplementedError("LocalCompressor: adapt{q,k,v,g} variants have no HIP path yet")
+        if self.use_guide not in (None, "off", "direct", "coarse", "fine"):
+            raise NotImplementedError(f"LocalCompressor: use_guide={self.use_guide!r}")
 
     # -- attention context: [Nw, D] fp32 -----------------------------------------------------
     def window_context(self, frames_feature, frames_embed, guide_embed, modal, logit_scale, logit_bias):
+        """Operator-by-operator form of ref :524-558 (everything before the readout), all variants."""
+        from . import injector as inj
         self._check_native()
         _require_bf16_cuda("frames_feature", frames_feature)
         ff = frames_feature.contiguous()
@@ -190,20 +195,31 @@ class LocalCompressor(nn.Module):
         if logit_scale is not None:                                   # ref :527-529, :549
             scale, bias = float(torch.exp(logit_scale.float())), float(logit_bias)
             if frames_embed is not None:
+                if self.adapt_k or self.use_guide not in (None, "off", "direct"):
+                    raise NotImplementedError("LocalCompressor: clip-scale together with adapt_k / coarse / fine "
+                                              "normalises BEFORE the adaptor (ref :527-533); no HIP path yet")
                 l2norm = 1 | (2 if self.use_guide == "direct" else 0)
         else:
             scale, bias = 1.0 / math.sqrt(self.qk_dim), 0.0            # ref :551
+        value = ff
+        if self.adapt_k:                                               # ref :533
+            key = inj.adapt_stream(key, self.k_proj, self.k_norm, self.k_alpha)
+        if self.adapt_v:                                               # ref :534
+            value = inj.adapt_stream(ff, self.v_proj, self.v_norm, self.v_alpha)
         ctx = _f32((nw, D), ff.device)
-        if self.use_guide == "direct":                                 # query := guide for every window
-            g = guide_embed.contiguous()
-            _require_bf16_cuda("guide_embed", g)
-            if g.ndim != 1 or g.shape[0] != D:
-                raise ValueError("direct guide injection takes a [D] guide embedding")
-            nv.local_attn(key, ff, axes, g, 0, scale, bias, l2norm, ctx)
-        else:                                                          # pooled per-window query (ref :539-540)
-            q = _f32((*grid, D), ff.device)
-            nv.trilinear_pool(ff, q)
-            nv.local_attn(key, ff, axes, q, D, scale, bias, l2norm, ctx)
+        if self.use_guide == "direct":                                 # query := guide for every window (:352-368)
+            _require_bf16_cuda("guide_embed", guide_embed)
+            q, _ = inj.inject(self.guide_injector, "direct", None, guide_embed.contiguous())
+            nv.local_attn(key, value, axes, q.reshape(-1).contiguous(), 0, scale, bias, l2norm, ctx)
+            return ctx, grid
+        q = _f32((*grid, D), ff.device)                                # pooled per-window query (ref :539-540)
+        nv.trilinear_pool(ff, q)
+        if self.adapt_q:                                               # ref :541
+            q = inj.adapt_query(q, self.q_proj, self.q_norm, self.q_alpha)
+        if self.use_guide in ("coarse", "fine"):
+            _require_bf16_cuda("guide_embed", guide_embed)
+            q, _ = inj.inject(self.guide_injector, self.use_guide, q.reshape(nw, D), guide_embed.contiguous())
+        nv.local_attn(key, value, axes, q.reshape(nw, D), D, scale, bias, l2norm, ctx)
         return ctx, grid
 
     def readout_into(self, ctx, out, row0: int, nl_group: int):
@@ -280,27 +296,33 @@ class GlobalCompressor(nn.Module):
             self._cache_gen += 1
         return pe, hit[0], cap
 
+    @property
+    def is_plain(self) -> bool:
+        return self.use_guide in _NATIVE_GUIDE_MODES and not self.adapt_guide
+
     def _check_native(self, logit_scale):
-        if self.use_guide not in _NATIVE_GUIDE_MODES:
-            raise NotImplementedError(f"GlobalCompressor: use_guide={self.use_guide!r} has no HIP path yet "
-                                      "(native modes: direct, off)")
-        if self.adapt_guide:
-            raise NotImplementedError("GlobalCompressor: adaptg has no HIP path yet")
+        if self.use_guide not in (None, "off", "direct", "coarse", "fine"):
+            raise NotImplementedError(f"GlobalCompressor: use_guide={self.use_guide!r}")
         if logit_scale is not None:
             raise NotImplementedError("GlobalCompressor: the clip-scale variant normalises the PROJECTED keys "
                                       "(ref :184-186), which does not fold into the queries; no HIP path yet")
 
     def injected_queries(self, guide_embed) -> Tuple[torch.Tensor, int]:
-        """bf16 [nq_eff, E] distinct query rows and how many output rows they stand for.
-        direct: the 32 queries are 32 copies of the guide (ref :352-368, :642) -> one row."""
+        """[nq_eff, E] distinct injected query rows (bf16 or f32) and how many output rows they stand for.
+        direct: the 32 queries are 32 copies of the (adapted) guide (ref :352-368, :642) -> one row."""
+        from . import injector as inj
+        if guide_embed is not None:
+            _require_bf16_cuda("guide_embed", guide_embed)
+            guide_embed = guide_embed.contiguous()
+        if self.use_guide in (None, "off"):
+            _require_bf16_cuda("global_compressor.query", self.query)
+            return self.query.detach(), self.num_queries
         if self.use_guide == "direct":
-            g = guide_embed.contiguous()
-            _require_bf16_cuda("guide_embed", g)
-            if g.ndim != 1 or g.shape[0] != self.embed_dim:
+            if guide_embed.ndim != 1 or guide_embed.shape[0] != self.embed_dim:
                 raise ValueError("direct guide injection takes a [D] guide embedding")
-            return g.view(1, -1), self.num_queries
         _require_bf16_cuda("global_compressor.query", self.query)
-        return self.query.detach(), self.num_queries
+        q, shared = inj.inject(self.guide_injector, self.use_guide, self.query.detach(), guide_embed)
+        return q.reshape(-1, self.embed_dim).contiguous(), self.num_queries
 
     def partial_context(self, frames_feature, q_in, t_offset: int = 0):
         """Streams this call's frames once: returns (ml [R,2], acc [R,E]) un-normalised online-softmax
@@ -428,7 +450,8 @@ class HIComProjector(nn.Module):
                                modal, grid[0], grid[1], grid[2], has_newline, is_anyres)
 
     def forward(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None):
-        if self.use_executor and not isinstance(frames_feature, dict):
+        plain = all(c is None or c.is_plain for c in (self.local_compressor, self.global_compressor))
+        if self.use_executor and plain and not isinstance(frames_feature, dict):
             from . import engine
             return engine.run_dense(self, frames_feature, frames_embed, guide_embed, modal, image_newline,
                                     _out_dtype(self))

@@ -54,7 +54,8 @@ typedef struct hicom_axis {
 /* ---- local compressor: windowed single-head cross-attention ------------------------------
  * Replaces projector.py:544-558 (divide_feature x3, bmm, softmax, bmm, un-window) and, with
  * l2norm != 0, the clip-scale normalisation at :527-529,549.
- *   key, value : bf16 [T,H,W,D]   (frames_embed / frames_feature; key may alias value)
+ *   key, value : [T,H,W,D] bf16 (frames_embed / frames_feature; key may alias value) or f32 (the
+ *                alpha-blended adaptor outputs of projector.py:533-534); dtype key_dt / value_dt
  *   query      : [D] shared by every window (query_stride == 0, GuideInjector "direct",
  *                projector.py:352-368) or [Nw, D] with row stride query_stride elements;
  *                dtype query_dt
@@ -63,7 +64,7 @@ typedef struct hicom_axis {
  *   l2norm     : bit 0 = L2-normalise every key row, bit 1 = L2-normalise the query
  *                (clip-scale variant, projector.py:527-529)
  * D must be 1152 or 768 (projector.py:407-414). */
-int hicom_local_attn_fwd(const void* key, const void* value, int32_t D,
+int hicom_local_attn_fwd(const void* key, int32_t key_dt, const void* value, int32_t value_dt, int32_t D,
                          hicom_axis at, hicom_axis ay, hicom_axis ax,
                          const void* query, int32_t query_dt, int64_t query_stride,
                          float scale, float bias, int32_t l2norm,
@@ -201,6 +202,7 @@ int hicom_readout_gemm_fwd(const float* x, const void* w, const void* b, int32_t
 
 /* Same GEMM on bf16 PLANES (the hot path): the activation arrives already split as a_hi + a_lo
  * (bf16 [M,K] each, written by the producing kernel), so all three operands go HBM -> LDS by LDS-DMA.
+ * a_lo may be NULL when the activation is exactly bf16 (raw visual tokens).
  * Outputs (either or both): out_hi/out_lo = bf16 planes [M,N] of the result (feeds the next GEMM);
  * y = packed rows as in hicom_readout_gemm_fwd. */
 int hicom_planes_gemm_fwd(const void* a_hi, const void* a_lo, const void* w, const void* b, int32_t b_dt,
@@ -219,6 +221,25 @@ int hicom_scatter_rows_fwd(const void* src, int32_t src_dt, int32_t src_rows, in
  * all-gathered per-rank buffers): ml_k = ml + k*set_stride, acc_k = acc + k*set_stride. */
 int hicom_global_combine_strided_fwd(const float* ml, const float* acc, int64_t set_stride, int32_t nsets,
                                      int32_t rows, int32_t E, float* ctx, void* stream);
+
+/* ---- instruction injector / adaptor row operators -------------------------------------------
+ * out = (1 - alpha) * src + alpha * (LayerNorm_eps(x * (1 + mul) + add) * gamma + beta), row-wise over E.
+ * Covers GuideInjector "coarse" (FiLM + LayerNorm, projector.py:369-372: mul/add = one broadcast
+ * row, stride 0), "fine" (LayerNorm(q + attn), :392: add per row), and the alpha-blended adaptors
+ * (adapt_guide :365, adapt_q :541, adapt_k / adapt_v :533-534).  mul / add / src / alpha may be NULL
+ * (alpha == NULL means 1 and needs no src); alpha is a 1-element DEVICE tensor (the nn.Parameter). */
+int hicom_row_ln_fwd(const void* x, int32_t x_dt, int64_t x_stride,
+                     const float* mul, int64_t mul_stride, const float* add, int64_t add_stride,
+                     const void* gamma, const void* beta, int32_t gb_dt,
+                     const void* src, int32_t src_dt, int64_t src_stride,
+                     const void* alpha, int32_t alpha_dt, float eps,
+                     void* out, int32_t out_dt, int64_t out_stride, int32_t M, int32_t E, void* stream);
+
+/* Multi-head attention of M query rows over L <= 64 keys (the text tokens of "fine" injection,
+ * projector.py:391 -> :193-215): q [M,E], k, v [L,E] are the PROJECTED states (f32), heads of hd
+ * channels, scale hd^-1/2, fp32 softmax; out [M,E] f32 (before out_proj). */
+int hicom_small_mha_fwd(const float* q, const float* k, const float* v, int32_t M, int32_t L,
+                        int32_t nh, int32_t hd, float* out, void* stream);
 
 /* ---- whole-forward executor ------------------------------------------------------------------
  * hicom_compressor_fwd enqueues HIComProjector.forward (projector.py:676-708) for one dense

@@ -370,3 +370,54 @@ def test_planes_gemm_matches_torch(M, N, K, act):
     rows = torch.tensor([2 + m + m // 9 for m in range(M)])
     assert maxabs(y.cpu()[rows], want) <= tol
     assert float(y[:2].abs().max()) == 0.0
+
+
+def test_row_ln_variants_match_torch():
+    M, E = 37, 1152
+    x = torch.from_numpy(synth.normal_like((M, E), 101)).cuda()
+    mul = torch.from_numpy(synth.normal_like((1, E), 102, 0.3)).cuda()
+    add = torch.from_numpy(synth.normal_like((M, E), 103)).cuda()
+    src = bf(synth.normal_like((M, E), 104))
+    norm = torch.nn.LayerNorm(E, eps=1e-6)
+    with torch.no_grad():
+        norm.weight.copy_(torch.from_numpy(1 + synth.normal_like((E,), 105, 0.1)))
+        norm.bias.copy_(torch.from_numpy(synth.normal_like((E,), 106, 0.1)))
+    norm_d = torch.nn.LayerNorm(E, eps=1e-6).to(torch.bfloat16).cuda()
+    norm_d.load_state_dict(norm.state_dict())
+    alpha = torch.tensor([0.5], dtype=torch.bfloat16, device="cuda")
+    ln = lambda t: torch.nn.functional.layer_norm(t.double(), (E,), norm_d.weight.double().cpu(), norm_d.bias.double().cpu(), 1e-6)
+    out = f32((M, E))
+    nv.row_ln(x, norm_d, out, mul=mul, add=add[:1].contiguous())             # coarse: broadcast FiLM rows
+    want = ln(x.cpu() * (1 + mul.cpu()) + add[:1].cpu())
+    assert maxabs(out, want) <= 2e-5
+    nv.row_ln(x, norm_d, out, add=add)                                         # fine: per-row residual
+    assert maxabs(out, ln(x.cpu() + add.cpu())) <= 2e-5
+    nv.row_ln(x, norm_d, out, src=src, alpha=alpha)                            # adaptor blend
+    assert maxabs(out, 0.5 * src.double().cpu() + 0.5 * ln(x.cpu())) <= 2e-5
+
+
+def test_small_mha_matches_torch():
+    M, L, nh, hd = 21, 64, 9, 128
+    E = nh * hd
+    q, k, v = (torch.from_numpy(synth.normal_like(s, sd, 0.3)).cuda() for s, sd in (((M, E), 111), ((L, E), 112), ((L, E), 113)))
+    out = f32((M, E))
+    nv.small_mha(q, k, v, nh, out)
+    qh, kh, vh = (t.double().cpu().reshape(-1, nh, hd).permute(1, 0, 2) for t in (q, k, v))
+    p = torch.softmax(qh @ kh.transpose(1, 2) * hd ** -0.5, dim=-1)
+    want = (p @ vh).permute(1, 0, 2).reshape(M, E)
+    assert maxabs(out, want) <= 1e-5
+
+
+def test_local_attn_fp32_streams():
+    """adapt_k / adapt_v hand the local kernel fp32 key / value streams."""
+    T, H, W = 4, 6, 6
+    x = synth.synth_inputs(T, H, W, D, tag="f32s")
+    key = (x["fe"] + synth.normal_like(x["fe"].shape, 121) * 2.0 ** -10).astype(np.float32)
+    val = (x["ff"] + synth.normal_like(x["ff"].shape, 122) * 2.0 ** -10).astype(np.float32)
+    spec = dict(kt=4, ks=3, adapt_q=False, adapt_k=False, adapt_v=False, adapt_guide=False)
+    want, _ = orc.local_context(spec, "direct", {}, "lc", torch.from_numpy(val), torch.from_numpy(key), torch.from_numpy(x["g"]),
+                                "video", None, None)
+    axes = tuple(nv.Axis(a.n, a.k, a.nwin, a.nfull) for a in (geo.axis_tiling(T, 4), geo.axis_tiling(H, 3), geo.axis_tiling(W, 3)))
+    ctx = f32((4, D))
+    nv.local_attn(torch.from_numpy(key).cuda(), torch.from_numpy(val).cuda(), axes, bf(x["g"]), 0, 1 / math.sqrt(D), 0.0, 0, ctx)
+    assert maxabs(ctx, want.reshape(4, D)) <= 2e-5

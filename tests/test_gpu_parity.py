@@ -20,8 +20,9 @@ TOL = 1e-3
 NATIVE_CASES = ["G1_direct_T8", "G2_off_T8", "G2b_off_string", "G3_direct_T7", "G3d_direct_T2", "G3e_off_T3_h2",
                 "G3c_off_T10_hw75", "G4_direct_T1", "G4b_image_newline", "G9_grid", "G9_frame", "G9_one_token",
                 "G9_flat", "G9_anyres", "G9_anyres_nobase", "G9_local_only", "G9_global_only", "G9_local22",
-                "G10_peaky_direct", "G10b_peaky_off", "G11_c1_shape"]
-NOT_YET_NATIVE = ["G5_adaptkv", "G5b_adaptqkvg_off", "G6_coarse", "G7_fine", "G7b_guide_override"]
+                "G10_peaky_direct", "G10b_peaky_off", "G11_c1_shape",
+                # injector / adaptor variants: FiLM+LN, 64-token MHA, alpha-blended q/k/v/guide adaptors
+                "G5_adaptkv", "G5b_adaptqkvg_off", "G6_coarse", "G7_fine", "G7b_guide_override"]
 
 
 @pytest.mark.parametrize("name", NATIVE_CASES)
@@ -48,12 +49,15 @@ def test_clip_scale_local_matches_golden(golden):
     assert got.shape == ref.shape and np.abs(got - ref).max() <= TOL
 
 
-@pytest.mark.parametrize("name", NOT_YET_NATIVE)
-def test_unsupported_variants_fail_loudly(name):
-    """No silent fallback: variants without a HIP path raise instead of computing with PyTorch."""
-    case = cases.build_case(name)
+def test_unsupported_variant_fails_loudly():
+    """No silent fallback: the one variant without a HIP path (clip-scale on the GLOBAL stage, which
+    normalises the projected keys) raises instead of computing with PyTorch."""
+    case = cases.build_case("G1_direct_T8")
+    m = build_module(case)
+    m.set_clip_logits(glob=(torch.tensor(1.5, device="cuda"), torch.tensor(-2.0, device="cuda")))
+    ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
     with pytest.raises(NotImplementedError):
-        run_native(case)
+        m(ff, fe, g, "video", None)
 
 
 @pytest.mark.parametrize("name", ["G3b_direct_T5_raises", "G4c_image_T2_raises"])
