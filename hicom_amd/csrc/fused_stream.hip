@@ -53,7 +53,7 @@ struct FusedParams {
     uint16_t* ctx_hi;      // [NW][E] the same as bf16 hi / lo planes for hicom_planes_gemm_fwd (may be NULL)
     uint16_t* ctx_lo;
     int wpw;               // windows per workgroup
-    int dbg;               // developer ablation mask (HICOM_FUSED_DBG): 1 no P.x, 2 no score MFMAs, 8 no fe loads, 16 no LDS-DMA after tile 0
+    int dbg;               // developer ablation mask (HICOM_FUSED_DBG): 1 no P.x, 2 no score MFMAs, 8 no fe loads, 16 no LDS-DMA after tile 0, 64 no partial write-out, 128 no score stores, 256 one tile only
 };
 
 __device__ __forceinline__ int fswz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
     float* a_y = a_t + p.R * kMaxFramesPerWg;                          // [R][H]
     float* a_x = a_y + p.R * p.H;                                      // [R][W]
 
+    if (p.dbg & 512) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kg = lane >> 4;
@@ -92,9 +93,45 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
     const int we = min(p.NW, wb + p.wpw);
     const int nwin = we - wb;
     const int total = nwin * p.WSZ;                 // tokens of this workgroup's stream
-    const int ntile = (total + 15) >> 4;
+    const int ntile = (p.dbg & 256) ? 1 : (total + 15) >> 4;
     const int R = p.R, NLOC = 16 - R;
     const int HW = p.H * p.W, ks2 = p.ks * p.ks;
+
+    // ---- A operand (hi / lo) of this wave's channel slice ----------------------------------------
+    bf16x8 ahi[KSTEPS], alo[KSTEPS];
+    {
+        const long off = (long)r16 * E + SLICE * wave + 8 * kg;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            ahi[s] = *reinterpret_cast<const bf16x8*>(p.qhi + off + 32 * s);
+            alo[s] = *reinterpret_cast<const bf16x8*>(p.qlo + off + 32 * s);
+        }
+    }
+    // ---- tile 0 is requested BEFORE the LDS tables exist (token index by plain arithmetic), so the
+    // table set-up below overlaps the first HBM round trip instead of preceding it
+    const unsigned wsz_magic = (65536u + p.WSZ - 1) / p.WSZ;
+    auto token_direct = [&](int s) -> long {
+        s = s < total ? s : total - 1;
+        int wr = (int)(((unsigned)s * wsz_magic) >> 16);
+        int i = s - wr * p.WSZ;
+        if (i < 0) { i += p.WSZ; wr -= 1; }
+        const int w = wb + wr, per_t = p.nwy * p.nwx;
+        const int t1 = w / per_t, r = w - t1 * per_t, h1 = r / p.nwx, w1 = r - h1 * p.nwx;
+        const int t2 = i / ks2, ri = i - t2 * ks2, h2 = ri / p.ks, w2 = ri - h2 * p.ks;
+        return ((long)(t1 * p.kt + t2) * p.H + (h1 * p.ks + h2)) * p.W + (w1 * p.ks + w2);
+    };
+    bf16x8 bfe[KSTEPS];
+    if (ntile > 0) {
+        const int row = 4 * wave + (lane >> 4), cpos = lane & 15;
+        const char* src = reinterpret_cast<const char*>(p.ff) + token_direct(row) * (long)(E * 2) + 16 * (cpos ^ fswz(row));
+#pragma unroll
+        for (int i = 0; i < PIECES / 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 256),
+                                             (__attribute__((address_space(3))) void*)(tilebuf + (wave + 4 * i) * 1024), 16, 0, 0);
+        const uint16_t* fsrc = p.fe + token_direct(r16) * E + SLICE * wave + 8 * kg;
+#pragma unroll
+        for (int k = 0; k < KSTEPS; ++k) bfe[k] = *reinterpret_cast<const bf16x8*>(fsrc + 32 * k);
+    }
 
     // ---- per-workgroup tables -----------------------------------------------------------------
     if (tid < p.WSZ) {
@@ -119,16 +156,6 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
         for (int i = tid; i < R * p.W; i += 256) a_x[i] = p.pos_a[(long)(i / p.W) * p.pos_stride + p.x0i + (i % p.W)];
     }
 
-    // ---- A operand (hi / lo) of this wave's channel slice ----------------------------------------
-    bf16x8 ahi[KSTEPS], alo[KSTEPS];
-    {
-        const long off = (long)r16 * E + SLICE * wave + 8 * kg;
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            ahi[s] = *reinterpret_cast<const bf16x8*>(p.qhi + off + 32 * s);
-            alo[s] = *reinterpret_cast<const bf16x8*>(p.qlo + off + 32 * s);
-        }
-    }
     f32x4 acc[CBLK];
 #pragma unroll
     for (int cb = 0; cb < CBLK; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -138,7 +165,6 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
 
     // stream slot -> token index (clamped to the last valid slot of this workgroup)
     // (s / WSZ by multiply-shift: exact for s < 2^16, i.e. <= kMaxWinPerWg * 64 tokens per workgroup)
-    const unsigned wsz_magic = (65536u + p.WSZ - 1) / p.WSZ;
     auto token_of = [&](int s) -> long {
         s = s < total ? s : total - 1;
         int wr = (int)(((unsigned)s * wsz_magic) >> 16);
@@ -167,18 +193,13 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
 
     // frames_embed B fragments (token slot r16, this wave's channel slice), fetched ONE TILE AHEAD
     // into the registers the previous tile's local-score MFMAs have just released
-    bf16x8 bfe[KSTEPS];
     auto load_fe = [&](int tile) {
         const uint16_t* src = p.fe + token_of(tile * 16 + r16) * E + SLICE * wave + 8 * kg;
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) bfe[s] = *reinterpret_cast<const bf16x8*>(src + 32 * s);
     };
 
-    if (ntile > 0) {
-        stage(0, 0);
-        load_fe(0);
-    }
-
+    if (p.dbg & 1024) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (ahi[0][0] == 12345 && bfe[0][0] == 1) p.part_m[0] = 1.f; return; }
     for (int tile = 0; tile < ntile; ++tile) {
         const int cur = tile & 1;
         const int s0 = tile * 16;
@@ -235,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
                     const int f = (base >> 16) + (txy >> 16), y = ((base >> 8) & 255) + ((txy >> 8) & 255), x = (base & 255) + (txy & 255);
                     lgt += a_t[row * kMaxFramesPerWg + f] + a_y[row * p.H + y] + a_x[row * p.W + x];
                 }
-                if (in) p.scores[(long)row * p.score_stride + worg[wsafe] + win_off[i]] = lgt;
+                if (in && !(p.dbg & 128)) p.scores[(long)row * p.score_stride + worg[wsafe] + win_off[i]] = lgt;
             } else {
                 valid = in && (row == (wr == wr0 ? rowA : rowB));
                 lgt = lgt * p.l_scale + p.l_bias;
@@ -329,6 +350,7 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
     }
 
     // ---- partial global state of this workgroup --------------------------------------------------
+    if (p.dbg & 64) return;
     const long prow = (long)part * 16;
     {
         const int row = 4 * wave + (lane >> 4);

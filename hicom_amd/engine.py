@@ -27,15 +27,18 @@ class _DeviceResources:
         self.ev_join.record(cur)
 
 
-_RES: Dict[int, _DeviceResources] = {}
+_RES: Dict[Tuple[int, int], _DeviceResources] = {}
 _WS: Dict[Tuple, torch.Tensor] = {}
 
 
 def _resources(device) -> _DeviceResources:
+    """Side stream + fork/join events, one set per (device, caller stream): forwards issued on two
+    different caller streams must not share events or the side queue."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    if idx not in _RES:
-        _RES[idx] = _DeviceResources(device)
-    return _RES[idx]
+    key = (idx, torch.cuda.current_stream(device).cuda_stream)
+    if key not in _RES:
+        _RES[key] = _DeviceResources(device)
+    return _RES[key]
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -135,8 +138,9 @@ def attach_execution(a: nv.CompressorArgs, device, key_extra=()):
     """Workspace (zero-prefixed once, cached per problem shape) + streams/events."""
     res = _resources(device)
     total, prefix = nv.compressor_workspace(a)
-    key = (device.index, a.T, a.H, a.W, a.E, a.hidden, a.nq, a.P, a.has_local, a.has_global,
-           a.at.nwin, a.ay.nwin, a.ax.nwin, bool(a.lq), *key_extra)
+    # one workspace per problem shape AND caller stream (two streams may run the same shape concurrently)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, a.T, a.H, a.W, a.E, a.hidden, a.nq, a.P,
+           a.has_local, a.has_global, a.at.nwin, a.ay.nwin, a.ax.nwin, bool(a.lq), *key_extra)
     ws = _WS.get(key)
     if ws is None or ws.numel() < total:
         ws = torch.empty(total, dtype=torch.uint8, device=device)

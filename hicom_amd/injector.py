@@ -43,6 +43,8 @@ def mlp2_rows(x, mlp, out_features=None):
 
 def adapted_guide(inj, guide):
     """(1 - a) g + a LN(MLP(g)) when the injector has adapt_guide (ref :365 / :389); else the guide."""
+    if not isinstance(inj.text2qk_proj, torch.nn.Identity):      # text_dim != qk_dim (ref :323-326, :364)
+        guide = mlp2_rows(guide, inj.text2qk_proj).reshape(*guide.shape[:-1], -1)
     if isinstance(inj.guide_alpha, (int, float)):
         return guide
     g = guide.reshape(-1, guide.shape[-1]).contiguous()

@@ -105,6 +105,11 @@ def _f32(shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
+def _plain_injector(inj) -> bool:
+    """No text2qk projection in front of the guide (text width == query width, ref :323-326)."""
+    return not isinstance(inj, GuideInjector) or isinstance(inj.text2qk_proj, nn.Identity)
+
+
 def _require_bf16_cuda(name: str, t: torch.Tensor):
     if not t.is_cuda:
         raise nv.HicomNativeError(f"{name}: hicom_amd runs on the GPU only (got a CPU tensor)")
@@ -167,8 +172,8 @@ class LocalCompressor(nn.Module):
     @property
     def is_plain(self) -> bool:
         """True for the configurations the one-call executor covers: guide direct / off, no adaptors."""
-        return self.use_guide in _NATIVE_GUIDE_MODES and not (self.adapt_q or self.adapt_k or self.adapt_v
-                                                             or self.adapt_guide)
+        return (self.use_guide in _NATIVE_GUIDE_MODES and _plain_injector(self.guide_injector)
+                and not (self.adapt_q or self.adapt_k or self.adapt_v or self.adapt_guide))
 
     def _check_native(self):
         if self.use_guide not in (None, "off", "direct", "coarse", "fine"):
@@ -186,7 +191,9 @@ class LocalCompressor(nn.Module):
         if key is not ff:
             _require_bf16_cuda("frames_embed", key)
             if key.shape != ff.shape:
-                raise ValueError("frames_embed must have the shape of frames_feature")
+                # e.g. the real CLIP-L tower: 768-d projected keys against 1024-d hidden-state values
+                raise NotImplementedError("LocalCompressor: key width != value width (frames_embed "
+                                          f"{tuple(key.shape)} vs frames_feature {tuple(ff.shape)}) has no HIP path")
         at, ay, ax = self.tilings(T, H, W, modal)
         axes = tuple(nv.Axis(a.n, a.k, a.nwin, a.nfull) for a in (at, ay, ax))
         grid = (at.nwin, ay.nwin, ax.nwin)
@@ -298,7 +305,7 @@ class GlobalCompressor(nn.Module):
 
     @property
     def is_plain(self) -> bool:
-        return self.use_guide in _NATIVE_GUIDE_MODES and not self.adapt_guide
+        return self.use_guide in _NATIVE_GUIDE_MODES and _plain_injector(self.guide_injector) and not self.adapt_guide
 
     def _check_native(self, logit_scale):
         if self.use_guide not in (None, "off", "direct", "coarse", "fine"):

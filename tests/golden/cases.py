@@ -52,6 +52,10 @@ CASES = {
     # peaky softmax: exercises online-softmax merging
     "G10_peaky_direct": dict(cfg=dict(), T=8, h=6, w=6, peaky=12.0, in_scale=2.0),
     "G10b_peaky_off": dict(cfg=dict(use_guide=None), T=8, h=6, w=6, peaky=12.0, in_scale=2.0),
+    # CLIP tower branch (projector.py:410-412,572-574): qk_dim = 768, 24x24 grid side, 6 heads
+    "G12_clip768_direct": dict(cfg=dict(mm_vision_tower="openai/clip-vit-large-patch14-336", mm_hidden_size=768), T=4, h=6, w=6, dim=768),
+    "G12b_clip768_off": dict(cfg=dict(mm_vision_tower="openai/clip-vit-large-patch14-336", mm_hidden_size=768, use_guide=None),
+                             T=8, h=6, w=6, dim=768),
     # C1 shape: 27x27 grid, T=4, H=896 -- stored as sampled outputs + checksum only
     "G11_c1_shape": dict(cfg=dict(hidden_size=896), T=4, h=27, w=27, sampled=True),
 }
@@ -90,13 +94,14 @@ def build_case(name: str):
     shapes = orc.param_shapes(cfg)
     sd = synth.synth_state_dict(shapes, tag=name, peaky=c.get("peaky", 1.0))
     T, h, w = c["T"], c["h"], c["w"]
-    x = synth.synth_inputs(T, h, w, D, tag=name, guide_len=c.get("guide_len", 0),
+    dim = c.get("dim", D)
+    x = synth.synth_inputs(T, h, w, dim, tag=name, guide_len=c.get("guide_len", 0),
                            scale=c.get("in_scale", 1.0))
     newline = synth.normal_like((cfg.hidden_size,), synth.seed_of(name + ":newline")) if c.get("newline") else None
     anyres = None
     if c.get("anyres"):
         a = c["anyres"]
-        p = synth.synth_inputs(1, a["ph"], a["pw"], D, tag=name + ":patch")
+        p = synth.synth_inputs(1, a["ph"], a["pw"], dim, tag=name + ":patch")
         anyres = dict(patch_ff=p["ff"][0], patch_fe=p["fe"][0], no_base=a.get("no_base", False))
     return SimpleNamespace(name=name, cfg=cfg, sd=sd, ff=x["ff"], fe=x["fe"], g=x["g"],
                            modal=c.get("modal", "video"), newline=newline, anyres=anyres,

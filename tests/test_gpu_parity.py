@@ -22,7 +22,9 @@ NATIVE_CASES = ["G1_direct_T8", "G2_off_T8", "G2b_off_string", "G3_direct_T7", "
                 "G9_flat", "G9_anyres", "G9_anyres_nobase", "G9_local_only", "G9_global_only", "G9_local22",
                 "G10_peaky_direct", "G10b_peaky_off", "G11_c1_shape",
                 # injector / adaptor variants: FiLM+LN, 64-token MHA, alpha-blended q/k/v/guide adaptors
-                "G5_adaptkv", "G5b_adaptqkvg_off", "G6_coarse", "G7_fine", "G7b_guide_override"]
+                "G5_adaptkv", "G5b_adaptqkvg_off", "G6_coarse", "G7_fine", "G7b_guide_override",
+                # CLIP-tower branch: every width-768 kernel instantiation
+                "G12_clip768_direct", "G12b_clip768_off"]
 
 
 @pytest.mark.parametrize("name", NATIVE_CASES)

@@ -1,6 +1,6 @@
 """Dev tool: host-side cost of one projector call (no device sync inside the loop)."""
-import sys, time, torch
-sys.path.insert(0, ".")
+import os, sys, time, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
 cfg = bench.release_config(896, 64)
 dev = torch.device("cuda", 0)

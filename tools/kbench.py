@@ -1,6 +1,6 @@
 """Dev tool: per-kernel timings (HIP events, back-to-back launches) at the C2 shape."""
-import math, sys, torch
-sys.path.insert(0, ".")
+import math, os, sys, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from hicom_amd import native as nv, geometry as geo
 dev = "cuda"
 T, H, W, E, HID = 64, 27, 27, 1152, 896

@@ -1,6 +1,6 @@
 """Dev tool: whole-forward time of the non-release recipes at the C2 shape."""
-import sys, time, torch
-sys.path.insert(0, ".")
+import os, sys, time, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench, hicom_amd
 from types import SimpleNamespace
 dev = torch.device("cuda", 0)
