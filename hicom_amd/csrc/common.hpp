@@ -32,6 +32,25 @@ __device__ __forceinline__ void split_bf16(float x, uint16_t& hi, uint16_t& lo) 
     lo = f32_to_bf16(x - bf16_to_f32(hi));
 }
 
+// Reductions over the 16 lanes of a DPP row (lanes 16k..16k+15) by row rotations: four VALU ops, every
+// lane ends up with the result.  (__shfl_xor compiles to ds_bpermute_b32: an LDS round trip per step.)
+template <int ROR>
+__device__ __forceinline__ float dpp_row_ror(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + ROR, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_row_ror<8>(v));
+    v = fmaxf(v, dpp_row_ror<4>(v));
+    v = fmaxf(v, dpp_row_ror<2>(v));
+    return fmaxf(v, dpp_row_ror<1>(v));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_row_ror<8>(v);
+    v += dpp_row_ror<4>(v);
+    v += dpp_row_ror<2>(v);
+    return v + dpp_row_ror<1>(v);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -56,6 +75,14 @@ __device__ __host__ __forceinline__ int axis_start(const hicom_axis& a, int i) {
 }
 
 // raw workgroup barrier that orders LDS traffic only (leaves global loads / LDS-DMA in flight)
+// LDS float add without return, issued as inline asm: through atomicAdd hipcc orders it behind ALL
+// outstanding vector-memory traffic (s_waitcnt vmcnt(0)), which drains LDS-DMA prefetches in flight.
+// Completion is covered by the next lds_barrier() (lgkmcnt(0)); same-wave LDS ops stay in issue order.
+__device__ __forceinline__ void lds_add_f32(float* lds_ptr, float v) {
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)(lds_ptr);
+    asm volatile("ds_add_f32 %0, %1" : : "v"(addr), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

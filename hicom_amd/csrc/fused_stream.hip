@@ -30,8 +30,19 @@
 
 namespace hicom {
 
+// Dev-only phase timeline (tools/fused_trace.py builds a second library with -DHICOM_TRACE): lane 0 of
+// every workgroup stamps s_memtime at the phase boundaries.  Compiled out of the product.
+#ifdef HICOM_TRACE
+__device__ unsigned long long g_fused_trace[1024 * 128];
+#define HICOM_TR() do { if (tid == 0 && tr_n < 128) g_fused_trace[blockIdx.x * 128 + tr_n] = __builtin_readcyclecounter(); ++tr_n; } while (0)
+#else
+#define HICOM_TR() do {} while (0)
+#endif
+
 constexpr int kMaxWinPerWg = 16;
 constexpr int kMaxFramesPerWg = 8;
+constexpr int kPStride = 32;        // halfwords between rows of the softmax-weight planes (they share red[0]'s rows)
+constexpr int kMargW = 12;         // per (row, window): kt + 2 * ks <= 11 marginal bins + the reference max in slot 11
 
 struct FusedParams {
     const uint16_t* ff;
@@ -44,16 +55,16 @@ struct FusedParams {
     float l_scale, l_bias;
     const float* pos_a;    // [16][pos_stride] or NULL
     int pos_stride, t0i, y0i, x0i;
-    float* scores;         // [16][score_stride], token-indexed, rows < R
-    long score_stride;
     float* part_m;
     float* part_l;
     float* part_acc;       // [nparts][16][E], rows < R
+    float* part_marg;      // [nparts][R][wpw][kMargW]: per-window t / y / x marginals of the global softmax weights
+                           // (relative to part_m), or NULL
     float* ctx_local;      // [NW][E] fp32 window contexts (may be NULL)
     uint16_t* ctx_hi;      // [NW][E] the same as bf16 hi / lo planes for hicom_planes_gemm_fwd (may be NULL)
     uint16_t* ctx_lo;
     int wpw;               // windows per workgroup
-    int dbg;               // developer ablation mask (HICOM_FUSED_DBG): 1 no P.x, 2 no score MFMAs, 8 no fe loads, 16 no LDS-DMA after tile 0, 64 no partial write-out, 128 no score stores, 256 one tile only
+               // developer ablation mask (HICOM_FUSED_DBG): 1 no P.x, 2 no score MFMAs, 8 no fe loads, 16 no LDS-DMA after tile 0, 64 no partial write-out, 128 no score stores, 256 one tile only
 };
 
 __device__ __forceinline__ int fswz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
@@ -67,14 +78,19 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
     constexpr int CBLK = SLICE / 16;
     constexpr int TILE_BYTES = NB * 4096;
     constexpr int PIECES = NB * 4;
+    static_assert(KSTEPS % 3 == 0, "three score accumulators");
     static_assert(PIECES % 4 == 0, "pieces are dealt round-robin to the 4 waves");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* tilebuf = smem;                                              // [2][TILE_BYTES]
-    float* red = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);     // [4][16][16]
-    uint16_t* p_hi = reinterpret_cast<uint16_t*>(red + 1024);          // [16 rows][16 slots] softmax weights, bf16 hi
-    uint16_t* p_lo = p_hi + 256;                                       // [16][16] bf16 lo
-    float* alpha_s = reinterpret_cast<float*>(p_lo + 256);             // [16] rescale factor of each row (this tile)
+    float* red = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);     // [4 waves][16][16] logit partials (channel slices)
+    // The softmax weights (bf16 hi / lo, [16 rows][16 slots] each) live INSIDE red[0]: row r's 64 bytes hold
+    // p_hi[r] | p_lo[r].  Only the wave that owns row r reads red[*][r] (after [B]) and it writes P[r] after
+    // those reads; red is rewritten after the next [A], when every wave is done reading P.
+    uint16_t* p_hi = reinterpret_cast<uint16_t*>(red);                 // row stride kPStride halfwords
+    uint16_t* p_lo = p_hi + 16;
+    float* mbin = red + 4 * 256;                                       // [2 parities][R][kMargW] marginals of the windows in flight
+    float* alpha_s = mbin + (p.part_marg ? 2 * p.R * kMargW : 0);             // [16] rescale factor of each row (this tile)
     float* lrun_s = alpha_s + 16;                                      // [16] running normaliser of each row
     int* win_off = reinterpret_cast<int*>(lrun_s + 16);                // [64] token offset of in-window index
     int* win_txy = win_off + 64;                                       // [64] packed (t2 << 16 | h2 << 8 | w2)
@@ -84,8 +100,9 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
     float* a_y = a_t + p.R * kMaxFramesPerWg;                          // [R][H]
     float* a_x = a_y + p.R * p.H;                                      // [R][W]
 
-    if (p.dbg & 512) return;
     const int tid = threadIdx.x, lane = tid & 63;
+    int tr_n = 0; (void)tr_n;
+    HICOM_TR();   // 0: start
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kg = lane >> 4;
     const int part = blockIdx.x;
@@ -93,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
     const int we = min(p.NW, wb + p.wpw);
     const int nwin = we - wb;
     const int total = nwin * p.WSZ;                 // tokens of this workgroup's stream
-    const int ntile = (p.dbg & 256) ? 1 : (total + 15) >> 4;
+    const int ntile = (total + 15) >> 4;
     const int R = p.R, NLOC = 16 - R;
     const int HW = p.H * p.W, ks2 = p.ks * p.ks;
 
@@ -133,7 +150,10 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
         for (int k = 0; k < KSTEPS; ++k) bfe[k] = *reinterpret_cast<const bf16x8*>(fsrc + 32 * k);
     }
 
+    HICOM_TR();   // prologue: A operand + tile 0 requested
     // ---- per-workgroup tables -----------------------------------------------------------------
+    if (p.part_marg)
+        for (int i = tid; i < 2 * R * kMargW; i += 256) mbin[i] = 0.f;
     if (tid < p.WSZ) {
         const int t2 = tid / ks2, r = tid - t2 * ks2, h2 = r / p.ks, w2 = r - h2 * p.ks;
         win_off[tid] = (t2 * p.H + h2) * p.W + w2;
@@ -160,8 +180,11 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
 #pragma unroll
     for (int cb = 0; cb < CBLK; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -1.0e30f, l_run = 0.f;   // online-softmax state of row 4*wave + lane/16 (owner lanes)
+    const unsigned ks2_magic = (65536u + ks2 - 1) / ks2, ks_magic = (65536u + p.ks - 1) / p.ks;
 
+    HICOM_TR();   // prologue: tables written (this wave)
     __syncthreads();   // tables ready
+    HICOM_TR();   // 1: prologue done
 
     // stream slot -> token index (clamped to the last valid slot of this workgroup)
     // (s / WSZ by multiply-shift: exact for s < 2^16, i.e. <= kMaxWinPerWg * 64 tokens per workgroup)
@@ -186,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
         }
     };
 
+    const int orow = 4 * wave + (lane >> 4), tk = lane & 15;   // softmax ownership: (row, token slot) of this lane
     const int q4 = (lane >> 2) & 3, pp = lane & 3;
     const int trow = 4 * fsig(kg) + q4;
     const int rd_row_off = r16 * 256, rd_swz = fswz(r16);
@@ -199,92 +223,108 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
         for (int s = 0; s < KSTEPS; ++s) bfe[s] = *reinterpret_cast<const bf16x8*>(src + 32 * s);
     };
 
-    if (p.dbg & 1024) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (ahi[0][0] == 12345 && bfe[0][0] == 1) p.part_m[0] = 1.f; return; }
     for (int tile = 0; tile < ntile; ++tile) {
         const int cur = tile & 1;
         const int s0 = tile * 16;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                               // [A]
-        if (tile + 1 < ntile && !(p.dbg & 16)) stage(tile + 1, cur ^ 1);
+        HICOM_TR();   // tile: past [A] (data landed)
         const char* img = tilebuf + cur * TILE_BYTES;
 
-        // ---- global logits (rows < R) from the frames_feature tile in LDS -----------------------
-        f32x4 sff = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!(p.dbg & 2))
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            const int ch0 = SLICE * wave + 32 * s;
-            const int blk = ch0 >> 7, cbase = (ch0 & 127) >> 3;
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(img + blk * 4096 + rd_row_off + 16 * ((cbase + kg) ^ rd_swz));
-            sff = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[s], b, sff, 0, 0, 0);
-            sff = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[s], b, sff, 0, 0, 0);
-        }
-        // ---- local logits (rows >= R) from the frames_embed fragments -------------------------------
-        f32x4 sfe = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) sfe = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[s], bfe[s], sfe, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);          // keep the refill below the MFMAs that read bfe
-        if (tile + 1 < ntile && !(p.dbg & 8)) load_fe(tile + 1);
-
-        float* rw = red + wave * 256;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) rw[(4 * kg + j) * 16 + r16] = (4 * kg + j < R) ? sff[j] : sfe[j];
-        lds_barrier();                                                 // [B]
-
-        // ---- softmax: each wave owns 4 of the 16 rows; lane = (row 4*wave + lane/16, token slot lane%16).
-        // (One logit per lane instead of four replicated in every wave; P, alpha and l are shared
-        // through 1.2 KB of LDS.)
+        // window bookkeeping of this tile and the score-side pos-emb of this lane's (row, token slot): its
+        // two dependent LDS lookups are issued here, under the score MFMAs, not in the serial softmax section
         int wr0 = (int)(((unsigned)s0 * wsz_magic) >> 16), i0 = s0 - wr0 * p.WSZ;
         if (i0 < 0) { i0 += p.WSZ; wr0 -= 1; }
         // local rows of the (at most two) windows this tile touches -- wave-uniform
         const int rowA = R + (wb + wr0) % NLOC;
         const int rowB = (rowA + 1 < 16) ? rowA + 1 : R;
+        int oi = i0 + tk, owr = wr0;
+        if (oi >= p.WSZ) { oi -= p.WSZ; owr += 1; }
+        const bool in = s0 + tk < total;
+        float posb = 0.f;
+        if (p.pos_a && orow < R) {
+            const int txy = win_txy[oi], base = wtxy[in ? owr : 0];
+            const int f = (base >> 16) + (txy >> 16), y = ((base >> 8) & 255) + ((txy >> 8) & 255), x = (base & 255) + (txy & 255);
+            posb = a_t[orow * kMaxFramesPerWg + f] + a_y[orow * p.H + y] + a_x[orow * p.W + x];
+        }
+
+        // ---- local logits (rows >= R) from the frames_embed fragments (landed with [A]) -------------
+        // These MFMAs come BEFORE the next tile's requests are issued: hipcc guards the use of `bfe` with
+        // s_waitcnt vmcnt(0), and placed after the LDS-DMA issue that wait would drain the prefetch it
+        // has just started (zero lookahead).  Here nothing is outstanding yet, so it is free.
+        // Three accumulators: a single one would serialise the 9 MFMAs on their own latency.
+        f32x4 e0 = f32x4{0.f, 0.f, 0.f, 0.f}, e1 = e0, e2 = e0;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; s += 3) {
+            e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[s], bfe[s], e0, 0, 0, 0);
+            e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[s + 1], bfe[s + 1], e1, 0, 0, 0);
+            e2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[s + 2], bfe[s + 2], e2, 0, 0, 0);
+        }
+        const f32x4 sfe = (e0 + e1) + e2;
+        __builtin_amdgcn_sched_barrier(0);
+        stage(tile + 1, cur ^ 1);                   // branch-free: past the end it re-requests the last tokens (clamped)
+
+        // ---- global logits (rows < R) from the frames_feature tile in LDS -----------------------
+        // All 9 fragment reads are in flight together (in the registers `bfe` has just released; its refill
+        // is issued after these MFMAs), then 18 MFMAs on three accumulators: one LDS round trip per tile
+        // instead of nine.
+        bf16x8 bff[KSTEPS];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const int ch0 = SLICE * wave + 32 * s;
+            const int blk = ch0 >> 7, cbase = (ch0 & 127) >> 3;
+            bff[s] = *reinterpret_cast<const bf16x8*>(img + blk * 4096 + rd_row_off + 16 * ((cbase + kg) ^ rd_swz));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 f0 = f32x4{0.f, 0.f, 0.f, 0.f}, f1 = f0;   // hi-plane and lo-plane chains, interleaved
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            f0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[s], bff[s], f0, 0, 0, 0);
+            f1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[s], bff[s], f1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // keep the refill below the MFMAs that read the shared registers
+        load_fe(tile + 1);                          // unconditional, so the registers are dead across the score phase
+        const f32x4 sff = f0 + f1;
+
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[wave * 256 + (4 * kg + j) * 16 + r16] = (4 * kg + j < R) ? sff[j] : sfe[j];
+        lds_barrier();                                                 // [B]
+        HICOM_TR();   // tile: past [B] (scores done)
+
+        // ---- softmax: each wave owns 4 of the 16 rows; lane = (row 4*wave + lane/16, token slot lane%16).
+        // (One logit per lane instead of four replicated in every wave; P, alpha and l are shared
+        // through 1.2 KB of LDS.)
         {
-            const int row = 4 * wave + (lane >> 4), tk = lane & 15;
-            const float* rb = red + row * 16 + tk;
-            float lgt = (rb[0] + rb[256]) + (rb[512] + rb[768]);
-            const int s = s0 + tk;
-            int i = i0 + tk, wr = wr0;
-            if (i >= p.WSZ) { i -= p.WSZ; wr += 1; }
-            const bool in = s < total;
-            const int wsafe = in ? wr : 0;
+            const int row = orow;
+            float lgt = (red[row * 16 + tk] + red[256 + row * 16 + tk]) + (red[512 + row * 16 + tk] + red[768 + row * 16 + tk]);
             bool valid;
             if (row < R) {
                 valid = in;
-                if (p.pos_a) {
-                    const int txy = win_txy[i], base = wtxy[wsafe];
-                    const int f = (base >> 16) + (txy >> 16), y = ((base >> 8) & 255) + ((txy >> 8) & 255), x = (base & 255) + (txy & 255);
-                    lgt += a_t[row * kMaxFramesPerWg + f] + a_y[row * p.H + y] + a_x[row * p.W + x];
-                }
-                if (in && !(p.dbg & 128)) p.scores[(long)row * p.score_stride + worg[wsafe] + win_off[i]] = lgt;
+                lgt += posb;
             } else {
-                valid = in && (row == (wr == wr0 ? rowA : rowB));
+                valid = in && (row == (owr == wr0 ? rowA : rowB));
                 lgt = lgt * p.l_scale + p.l_bias;
             }
-            float tmax = valid ? lgt : -1.0e30f;
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64));
+            const float tmax = row16_max(valid ? lgt : -1.0e30f);
             const float m_new = fmaxf(m_run, tmax);
             const float alpha = fast_exp(m_run - m_new);
             const float pr = valid ? fast_exp(lgt - m_new) : 0.f;
-            float lsum = pr;
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o, 64);
-            l_run = l_run * alpha + lsum;
+            l_run = l_run * alpha + row16_sum(pr);
             m_run = m_new;
             uint16_t h, l;
             split_bf16(pr, h, l);
-            p_hi[row * 16 + tk] = h;
-            p_lo[row * 16 + tk] = l;
+            p_hi[row * kPStride + tk] = h;
+            p_lo[row * kPStride + tk] = l;
             if (tk == 0) {
                 alpha_s[row] = alpha;
                 lrun_s[row] = l_run;
             }
         }
         lds_barrier();                                                 // [C] P / alpha / l visible to every wave
+        HICOM_TR();   // tile: past [C] (softmax done)
 
-        const bf16x4 phi = *reinterpret_cast<const bf16x4*>(p_hi + r16 * 16 + 4 * fsig(kg));
-        const bf16x4 plo = *reinterpret_cast<const bf16x4*>(p_lo + r16 * 16 + 4 * fsig(kg));
+        const bf16x4 phi = *reinterpret_cast<const bf16x4*>(p_hi + r16 * kPStride + 4 * fsig(kg));
+        const bf16x4 plo = *reinterpret_cast<const bf16x4*>(p_lo + r16 * kPStride + 4 * fsig(kg));
         const f32x4 al = *reinterpret_cast<const f32x4*>(alpha_s + 4 * kg);
         if (__any(al[0] != 1.0f || al[1] != 1.0f || al[2] != 1.0f || al[3] != 1.0f)) {
 #pragma unroll
@@ -292,10 +332,39 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
                 acc[cb][0] *= al[0]; acc[cb][1] *= al[1]; acc[cb][2] *= al[2]; acc[cb][3] *= al[3];
             }
         }
+        // ---- t / y / x marginals of the global weights, per window, as ONE more 16x16 MFMA tile:
+        // MG += P . onehot(bin of each token).  A tile touches at most two consecutive windows: wave 0
+        // accumulates the even-numbered one, wave 1 the odd one.  Rescaled by alpha like ACC, so a window's
+        // bins end up relative to the running max at its last tile, which is stored next to them.  The
+        // accumulators stay in LDS (the register file is full); each is touched by one wave only.
+        // (LDS float atomics were measured at ~4 clk per lane: 3x slower than this.)
+        if (p.part_marg && wave < 2) {
+            bf16x4 bm;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int i = i0 + 4 * fsig(kg) + u;
+                const int second = i >= p.WSZ ? 1 : 0;
+                i -= second * p.WSZ;
+                const int t2 = (int)(((unsigned)i * ks2_magic) >> 16), rem = i - t2 * ks2;
+                const int h2 = (int)(((unsigned)rem * ks_magic) >> 16), w2 = rem - h2 * p.ks;
+                const bool hit = r16 == t2 || r16 == p.kt + h2 || r16 == p.kt + p.ks + w2;
+                bm[u] = (hit && ((wr0 + second) & 1) == wave) ? (short)0x3F80 : (short)0;
+            }
+            f32x4 mg = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(phi, bm, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            mg = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(plo, bm, mg, 0, 0, 0);
+            if (r16 < kMargW) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * kg + j < R) {
+                        float* a = mbin + (wave * R + 4 * kg + j) * kMargW + r16;
+                        *a = fmaf(*a, al[j], mg[j]);
+                    }
+            }
+        }
         // ACC += P . x.  The transposed LDS reads are issued as inline asm with our own lgkmcnt wait:
         // through the builtin, hipcc orders them behind ALL outstanding vector-memory traffic
         // (s_waitcnt vmcnt(0)), which would drain the next tile's LDS-DMA and frames_embed prefetch.
-        if (!(p.dbg & 1)) {
+        {
             const unsigned img_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(img);
             constexpr int G = 3;                     // reads in flight per group (register budget: 256 VGPRs)
             static_assert(CBLK % G == 0, "column blocks per group");
@@ -319,6 +388,7 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
             }
         }
 
+        HICOM_TR();   // tile: P.x issued
         // ---- a window completed in this tile: emit its local context, recycle its row ------------
         if (i0 + 16 >= p.WSZ) {
             const int w = wb + wr0;
@@ -345,12 +415,29 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
                     }
                 }
             }
+            if (p.part_marg) {
+                // the completed window's marginals (wave 0) and its reference max (owner lanes of the rows)
+                float* o = p.part_marg + ((long)part * R * p.wpw + wr0) * kMargW;
+                if (wave == (wr0 & 1) && r16 < kMargW - 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * kg + j < R) {
+                            float* a = mbin + (wave * R + 4 * kg + j) * kMargW + r16;
+                            o[(long)(4 * kg + j) * p.wpw * kMargW + r16] = *a;
+                            *a = 0.f;
+                        }
+                }
+                const int orow = 4 * wave + (lane >> 4);
+                if (orow < R && (lane & 15) == kMargW - 1) o[(long)orow * p.wpw * kMargW + kMargW - 1] = m_run;
+            }
             if (4 * wave + (lane >> 4) == row) { m_run = -1.0e30f; l_run = 0.f; }   // owner lanes recycle the row
         }
+        HICOM_TR();   // tile: window completion (if any) issued
     }
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped requests of the last iteration
+    HICOM_TR();   // loop done
     // ---- partial global state of this workgroup --------------------------------------------------
-    if (p.dbg & 64) return;
     const long prow = (long)part * 16;
     {
         const int row = 4 * wave + (lane >> 4);
@@ -366,6 +453,7 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
         for (int j = 0; j < 4; ++j)
             if (4 * kg + j < R) o[(long)j * E] = acc[cb][j];
     }
+    HICOM_TR();   // epilogue issued
 }
 
 }  // namespace hicom
@@ -383,6 +471,12 @@ static int fused_num_cus() {
     return n;
 }
 
+#ifdef HICOM_TRACE
+extern "C" int hicom_debug_fused_trace(void* dst, int64_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(hicom::g_fused_trace), (size_t)bytes) == hipSuccess ? HICOM_OK : HICOM_ELAUNCH;
+}
+#endif
+
 extern "C" int hicom_fused_stream_nparts(int32_t n_windows) {
     if (n_windows <= 0) return HICOM_EINVAL;
     const int slots = 2 * fused_num_cus();                       // 2 resident workgroups per CU
@@ -395,10 +489,10 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T,
                                       int32_t kt, int32_t ks, const void* q_hi, const void* q_lo, int32_t rows,
                                       float l_scale, float l_bias, const float* pos_a, int32_t pos_stride,
                                       int32_t t_index0, int32_t y_index0, int32_t x_index0,
-                                      float* scores, int64_t score_stride, float* part_m, float* part_l,
-                                      float* part_acc, int32_t nparts, float* ctx_local, void* ctx_hi, void* ctx_lo,
-                                      void* stream) {
-    HICOM_REQUIRE(ff && fe && q_hi && q_lo && scores && part_m && part_l && part_acc, HICOM_EINVAL,
+                                      float* part_m, float* part_l,
+                                      float* part_acc, float* part_marg, int32_t nparts, float* ctx_local, void* ctx_hi,
+                                      void* ctx_lo, void* stream) {
+    HICOM_REQUIRE(ff && fe && q_hi && q_lo && part_m && part_l && part_acc && (part_marg || !pos_a), HICOM_EINVAL,
                   "fused_stream: NULL pointer");
     HICOM_REQUIRE(ctx_local || (ctx_hi && ctx_lo), HICOM_EINVAL, "fused_stream: no local output");
     HICOM_REQUIRE(E == 1152, HICOM_EUNSUP, "fused_stream: E=%d (only 1152)", E);
@@ -417,19 +511,17 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T,
     const int per_t = (H / ks) * (W / ks);
     const int span = (wpw + per_t - 2) / per_t + 1;
     HICOM_REQUIRE(span * kt <= kMaxFramesPerWg, HICOM_EUNSUP, "fused_stream: a workgroup would span %d frames", span * kt);
-    const size_t smem = 2 * 9 * 4096 + 4096 + 1024 + 128 + (64 + 64 + 2 * kMaxWinPerWg) * 4 +
-                        (size_t)rows * (kMaxFramesPerWg + H + W) * 4;
+    HICOM_REQUIRE(kt + 2 * ks <= kMargW - 1, HICOM_EUNSUP, "fused_stream: window %dx%dx%d exceeds the marginal bin width", kt, ks, ks);
+    const size_t smem = 2 * 9 * 4096 + 4096 + (part_marg ? (size_t)2 * rows * kMargW * 4 : 0) + 128 +
+                        (64 + 64 + 2 * kMaxWinPerWg) * 4 + (size_t)rows * (kMaxFramesPerWg + H + W) * 4;
     HICOM_REQUIRE(smem <= 81920, HICOM_EUNSUP, "fused_stream: H + W = %d does not fit the LDS budget", H + W);
-    HICOM_REQUIRE(score_stride >= (long)T * H * W, HICOM_EINVAL, "fused_stream: score_stride");
     FusedParams p;
     p.ff = (const uint16_t*)ff; p.fe = (const uint16_t*)fe; p.T = T; p.H = H; p.W = W;
     p.kt = kt; p.ks = ks; p.nwy = H / ks; p.nwx = W / ks; p.NW = NW; p.WSZ = wsz;
     p.qhi = (const uint16_t*)q_hi; p.qlo = (const uint16_t*)q_lo; p.R = rows;
     p.l_scale = l_scale; p.l_bias = l_bias;
     p.pos_a = pos_a; p.pos_stride = pos_stride; p.t0i = t_index0; p.y0i = y_index0; p.x0i = x_index0;
-    p.scores = scores; p.score_stride = score_stride;
-    p.part_m = part_m; p.part_l = part_l; p.part_acc = part_acc; p.ctx_local = ctx_local; p.ctx_hi = (uint16_t*)ctx_hi; p.ctx_lo = (uint16_t*)ctx_lo; p.wpw = wpw;
-    p.dbg = getenv("HICOM_FUSED_DBG") ? atoi(getenv("HICOM_FUSED_DBG")) : 0;
+    p.part_m = part_m; p.part_l = part_l; p.part_acc = part_acc; p.part_marg = part_marg; p.ctx_local = ctx_local; p.ctx_hi = (uint16_t*)ctx_hi; p.ctx_lo = (uint16_t*)ctx_lo; p.wpw = wpw;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(fused_stream_kernel<9>),

@@ -56,7 +56,9 @@ struct MergeCtxParams {
     const float* part_l;
     const float* part_acc;
     int nparts, rows_pad, E;
-    const float* scratch;   // frame marginals or NULL
+    const float* scratch;   // frame marginals (two-kernel path) or NULL
+    const float* part_marg; // [nparts][rows][wpw][kMargW] per-window marginals from the fused kernel, or NULL
+    int wpw, kt, ks, nwy, nwx, NW;
     const float* pe;
     int T, H, W, t0i, y0i, x0i;
     float* out_ml;
@@ -79,6 +81,7 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+constexpr int kMargW = 12;   // must match fused_stream.hip
 constexpr int kTC = 64;   // frames of marginals staged in LDS per pass (one pass for T <= 64)
 
 __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
@@ -126,9 +129,47 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
     }
     const float L = block_reduce_sum(l, red);
 
-    // positional weights: w_t = e^(m_t - M) * total_t ; w_y = sum_t e^(m_t - M) fy[t][y] ; w_x likewise.
-    // The [T][S] marginal table is streamed through LDS in coalesced chunks of kTC frames.
-    if (sc) {
+    const bool has_pos = sc != nullptr || p.part_marg != nullptr;
+    if (p.part_marg) {
+        // positional weights from the per-workgroup, per-window marginals of the fused kernel.  Every
+        // window's bins are relative to its own reference max (slot kMargW-1): ew[w] = e^(ref_w - M).
+        // Each t / y / x slot then sums its windows in a fixed order (SUB threads per slot, combined in
+        // order), so the result is run-to-run deterministic.
+        float* ew = tile;                       // [NW]
+        float* psum = tile + p.NW;              // [nslots * SUB]
+        const int per_part = p.wpw * kMargW, per_t = p.nwy * p.nwx, nt = p.T / p.kt;
+        const long rstride = (long)gridDim.x * per_part;
+        const float* mrow = p.part_marg + (long)r * per_part;
+        for (int w = tid; w < p.NW; w += 256) {
+            const int i = w / p.wpw, wr = w - i * p.wpw;
+            ew[w] = expf(mrow[i * rstride + wr * kMargW + (kMargW - 1)] - M);
+        }
+        __syncthreads();
+        const int nslots = p.T + HW2, SUB = nslots < 256 ? 256 / nslots : 1;
+        for (int item = tid; item < nslots * SUB; item += 256) {
+            const int j = item / SUB, k = item - j * SUB;
+            int cnt, b, fixed, mode;
+            if (j < p.T) { mode = 0; fixed = (j / p.kt) * per_t; b = j % p.kt; cnt = per_t; }
+            else if (j < p.T + p.H) { const int y = j - p.T; mode = 1; fixed = (y / p.ks) * p.nwx; b = p.kt + y % p.ks; cnt = nt * p.nwx; }
+            else { const int x = j - p.T - p.H; mode = 2; fixed = x / p.ks; b = p.kt + p.ks + x % p.ks; cnt = nt * p.nwy; }
+            float a = 0.f;
+            for (int q = k; q < cnt; q += SUB) {
+                int w;
+                if (mode == 0) w = fixed + q;
+                else if (mode == 1) { const int t1 = q / p.nwx; w = t1 * per_t + fixed + (q - t1 * p.nwx); }
+                else { const int t1 = q / p.nwy; w = t1 * per_t + (q - t1 * p.nwy) * p.nwx + fixed; }
+                const int i = w / p.wpw, wr = w - i * p.wpw;
+                a = fmaf(ew[w], mrow[i * rstride + wr * kMargW + b], a);
+            }
+            psum[item] = a;
+        }
+        __syncthreads();
+        for (int j = tid; j < nslots; j += 256) {
+            float a = 0.f;
+            for (int k = 0; k < SUB; ++k) a += psum[j * SUB + k];
+            wpos[j] = a;
+        }
+    } else if (sc) {
         float ay[4] = {0.f, 0.f, 0.f, 0.f};      // up to 4 * 256 spatial marginals per thread
         for (int t0 = 0; t0 < p.T; t0 += kTC) {
             const int nt = min(kTC, p.T - t0);
@@ -186,7 +227,7 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
             const float w = wp[i];
             a.x = fmaf(w, v.x, a.x); a.y = fmaf(w, v.y, a.y); a.z = fmaf(w, v.z, a.z); a.w = fmaf(w, v.w, a.w);
         }
-        if (sc) {
+        if (has_pos) {
             for (int j = pgp; j < p.T + HW2; j += 32) {
                 const int row = j < p.T ? p.t0i + j : (j < p.T + p.H ? p.y0i + (j - p.T) : p.x0i + (j - p.T - p.H));
                 const float4 v = *reinterpret_cast<const float4*>(p.pe + (long)row * p.E + c4);
@@ -252,13 +293,32 @@ extern "C" int hicom_global_merge_fwd(const float* part_m, const float* part_l, 
         hipLaunchKernelGGL(frame_marginals_kernel, dim3((unsigned)rows, (unsigned)T), dim3(256), smem, s, scores,
                            (long)score_stride, T, H, W, scratch);
     }
-    MergeCtxParams p{part_m, part_l, part_acc, nparts, rows_pad, E, pe ? scratch : nullptr, pe,
+    MergeCtxParams p{part_m, part_l, part_acc, nparts, rows_pad, E, pe ? scratch : nullptr, nullptr, 0, 0, 0, 0, 0, 0, pe,
                      T, H, W, t_index0, y_index0, x_index0, out_ml, out_acc, normalize};
     HICOM_REQUIRE(E % 4 == 0 && (!pe || H + W <= 1024), HICOM_EUNSUP, "global_merge: E %% 4 and H + W <= 1024");
     const size_t smem2 = ((size_t)nparts + (pe ? (size_t)2 * T + H + W + (size_t)kTC * (H + W + 2) : 0) + 16 * 64 + 4) * 4;
     HICOM_REQUIRE(smem2 <= 60000, HICOM_EUNSUP, "global_merge: too many partials/frames for one pass");
     hipLaunchKernelGGL(merge_ctx_kernel, dim3((unsigned)rows, (unsigned)((E + 31) / 32)), dim3(256), smem2, s, p);
     return hicom_host::check_launch("global_merge");
+}
+
+extern "C" int hicom_global_merge_windows_fwd(const float* part_m, const float* part_l, const float* part_acc,
+                                              const float* part_marg, int32_t nparts, int32_t rows, int32_t E,
+                                              int32_t T, int32_t H, int32_t W, int32_t kt, int32_t ks,
+                                              const float* pe, int32_t t_index0, int32_t y_index0, int32_t x_index0,
+                                              float* out_ml, float* out_acc, int32_t normalize, void* stream) {
+    HICOM_REQUIRE(part_m && part_l && part_acc && out_ml && out_acc, HICOM_EINVAL, "global_merge_windows: NULL pointer");
+    HICOM_REQUIRE((pe == nullptr) == (part_marg == nullptr), HICOM_EINVAL, "global_merge_windows: pe and part_marg go together");
+    HICOM_REQUIRE(nparts > 0 && rows > 0 && rows <= 16 && E > 0 && E % 4 == 0 && kt > 0 && ks > 0 && T % kt == 0 && H % ks == 0 &&
+                      W % ks == 0 && kt + 2 * ks <= kMargW - 1,
+                  HICOM_EINVAL, "global_merge_windows: bad shape");
+    const int NW = (T / kt) * (H / ks) * (W / ks), wpw = (NW + nparts - 1) / nparts;
+    MergeCtxParams p{part_m, part_l, part_acc, nparts, 16, E, nullptr, part_marg, wpw, kt, ks, H / ks, W / ks, NW, pe,
+                     T, H, W, t_index0, y_index0, x_index0, out_ml, out_acc, normalize};
+    const size_t smem2 = ((size_t)nparts + (pe ? (size_t)2 * T + H + W + NW + (T + H + W < 256 ? 256 : T + H + W) : 0) + 16 * 64 + 4) * 4;
+    HICOM_REQUIRE(smem2 <= 60000, HICOM_EUNSUP, "global_merge_windows: too many partials/windows for one pass");
+    hipLaunchKernelGGL(merge_ctx_kernel, dim3((unsigned)rows, (unsigned)((E + 31) / 32)), dim3(256), smem2, (hipStream_t)stream, p);
+    return hicom_host::check_launch("global_merge_windows");
 }
 
 extern "C" int hicom_global_combine_fwd(const float* ml, const float* acc, int32_t nsets, int32_t rows,

@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhicom_hip.so")
+# HICOM_NATIVE_LIB: dev override (instrumented builds from tools/); the product loads the in-tree library
+LIB_PATH = os.environ.get("HICOM_NATIVE_LIB") or os.path.join(HERE, "libhicom_hip.so")
 ABI_VERSION = 1
 
 DT_BF16, DT_F32 = 0, 1
@@ -26,6 +27,7 @@ EXPORTS = (
     "hicom_readout_gemm_fwd", "hicom_scatter_rows_fwd", "hicom_fold_query_split_fwd",
     "hicom_global_combine_strided_fwd", "hicom_compressor_workspace_bytes", "hicom_compressor_zero_prefix_bytes",
     "hicom_compressor_fwd", "hicom_linear_to_rows_fwd", "hicom_fused_stream_fwd", "hicom_fused_stream_nparts",
+    "hicom_global_merge_windows_fwd",
     "hicom_planes_gemm_fwd", "hicom_row_ln_fwd", "hicom_small_mha_fwd",
 )
 
@@ -100,8 +102,10 @@ def lib() -> C.CDLL:
                                          vp, vp, vp, i32, vp]
     L.hicom_linear_to_rows_fwd.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i64, i64, i32, vp]
     L.hicom_fused_stream_fwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, f32, vp, i32, i32, i32, i32,
-                                         vp, i64, vp, vp, vp, i32, vp, vp, vp, vp]
+                                         vp, vp, vp, vp, i32, vp, vp, vp, vp]
     L.hicom_fused_stream_nparts.argtypes = [i32]
+    L.hicom_global_merge_windows_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32,
+                                                 vp, vp, i32, vp]
     L.hicom_planes_gemm_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i64, i64, i32, vp]
     L.hicom_row_ln_fwd.argtypes = [vp, i32, i64, vp, i64, vp, i64, vp, vp, i32, vp, i32, i64, vp, i32, f32, vp, i32, i64,
                                    i32, i32, vp]
@@ -272,14 +276,22 @@ def fused_stream_nparts(n_windows: int) -> int:
     return n
 
 
-def fused_stream(ff, fe, kt, ks, qhi, qlo, rows, l_scale, l_bias, pos_a, t0i, y0i, x0i, scores, part_m, part_l,
-                 part_acc, ctx_local, ctx_hi=None, ctx_lo=None):
+def fused_stream(ff, fe, kt, ks, qhi, qlo, rows, l_scale, l_bias, pos_a, t0i, y0i, x0i, part_m, part_l,
+                 part_acc, part_marg, ctx_local, ctx_hi=None, ctx_lo=None):
+    """part_marg: f32 [nparts, rows, ceil(Nw / nparts), 12] (None iff pos_a is None)."""
     T, H, W, E = ff.shape
     _check(lib().hicom_fused_stream_fwd(_ptr(ff), _ptr(fe), T, H, W, E, kt, ks, _ptr(qhi), _ptr(qlo), rows, l_scale,
                                         l_bias, _ptr(pos_a), pos_a.shape[1] if pos_a is not None else 0, t0i, y0i, x0i,
-                                        _ptr(scores), scores.shape[1], _ptr(part_m), _ptr(part_l), _ptr(part_acc),
-                                        part_m.shape[0], _ptr(ctx_local), _ptr(ctx_hi), _ptr(ctx_lo), _stream()),
+                                        _ptr(part_m), _ptr(part_l), _ptr(part_acc), _ptr(part_marg), part_m.shape[0], _ptr(ctx_local), _ptr(ctx_hi), _ptr(ctx_lo), _stream()),
            "hicom_fused_stream_fwd")
+
+
+def global_merge_windows(part_m, part_l, part_acc, part_marg, rows, T, H, W, kt, ks, pe, t0i, y0i, x0i, out_ml, out_acc,
+                         normalize=True):
+    _check(lib().hicom_global_merge_windows_fwd(_ptr(part_m), _ptr(part_l), _ptr(part_acc), _ptr(part_marg),
+                                                part_m.shape[0], rows, part_acc.shape[-1], T, H, W, kt, ks, _ptr(pe),
+                                                t0i, y0i, x0i, _ptr(out_ml), _ptr(out_acc), int(normalize), _stream()),
+           "hicom_global_merge_windows_fwd")
 
 
 def planes_gemm(a_hi, a_lo, w, b, act=ACT_NONE, out_hi=None, out_lo=None, y=None, row0=0, nl_group=0):

@@ -156,7 +156,11 @@ int hicom_global_stream_nparts(int64_t N, int32_t rows_pad);
  * <= 64, rows <= 14 global folded rows, E == 1152.
  *   q_hi / q_lo : bf16 [16, E]; rows < `rows` = folded global queries (hi / lo), rows >= `rows` =
  *                 the local query in q_hi (exact bf16) and zeros in q_lo
- *   scores      : f32 [16, score_stride >= T*H*W], indexed by the token's position in the grid
+ *   part_marg   : f32 [nparts, rows, wpw, 12] (NULL iff pos_a is NULL): per workgroup, per window the t / y / x
+ *                 marginals of the global softmax weights, bins [0,kt) frames,
+ *                 [kt,kt+ks) rows, [kt+ks,kt+2ks) columns; wpw = ceil(Nw / nparts).  Consumed by
+ *                 hicom_global_merge_windows_fwd for the value-side pos-emb (projector.py:57-101,
+ *                 :176-179); slot 11 = the window's reference max.  Needs kt + 2 ks <= 11.
  *   part_*      : as hicom_global_stream_fwd with rows_pad = 16; nparts from
  *                 hicom_fused_stream_nparts(number of windows)
  *   ctx_local   : f32 [Nw, E], window order (t1,h1,w1), and/or ctx_hi + ctx_lo: the same contexts as
@@ -165,9 +169,8 @@ int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T, int32_t H,
                            int32_t kt, int32_t ks, const void* q_hi, const void* q_lo, int32_t rows,
                            float l_scale, float l_bias, const float* pos_a, int32_t pos_stride,
                            int32_t t_index0, int32_t y_index0, int32_t x_index0,
-                           float* scores, int64_t score_stride, float* part_m, float* part_l,
-                           float* part_acc, int32_t nparts, float* ctx_local, void* ctx_hi, void* ctx_lo,
-                           void* stream);
+                           float* part_m, float* part_l, float* part_acc, float* part_marg, int32_t nparts, float* ctx_local,
+                           void* ctx_hi, void* ctx_lo, void* stream);
 int hicom_fused_stream_nparts(int32_t n_windows);
 
 /* ---- merge the partials (+ the value-side positional term) --------------------------------
@@ -182,6 +185,15 @@ int hicom_global_merge_fwd(const float* part_m, const float* part_l, const float
                            int32_t H, int32_t W, const float* pe,
                            int32_t t_index0, int32_t y_index0, int32_t x_index0,
                            float* scratch, float* out_ml, float* out_acc, int32_t normalize, void* stream);
+
+/* Same merge fed by the fused kernel's per-window marginals (`part_marg`, see
+ * hicom_fused_stream_fwd) instead of the score buffer: one launch, no scratch.  nparts must be the
+ * value the fused kernel ran with; pe == NULL <=> part_marg == NULL (no pos-emb). */
+int hicom_global_merge_windows_fwd(const float* part_m, const float* part_l, const float* part_acc,
+                                   const float* part_marg, int32_t nparts, int32_t rows, int32_t E,
+                                   int32_t T, int32_t H, int32_t W, int32_t kt, int32_t ks,
+                                   const float* pe, int32_t t_index0, int32_t y_index0, int32_t x_index0,
+                                   float* out_ml, float* out_acc, int32_t normalize, void* stream);
 
 /* Combine `nsets` (M,L,ACC) triples (one per GPU after the all-gather, or one) and normalise:
  * ctx[r,:] = sum_k e^(M_k - M) ACC_k[r,:] / sum_k e^(M_k - M) L_k.

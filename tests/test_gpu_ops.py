@@ -334,17 +334,31 @@ def test_fused_stream_matches_separate_kernels(T, H, W, kt, ks):
         wpw = (nw + nparts - 1) // nparts
         per_t = (H // ks) * (W // ks)
         span_frames = ((wpw + per_t - 2) // per_t + 1) * kt          # frames one workgroup may touch
-        if wpw > 16 or span_frames > 8 or (nparts - 1) * wpw >= nw:
+        lds = 2 * 9 * 4096 + 4096 + 2 * R * 48 + 128 + (64 + 64 + 32) * 4 + R * (8 + H + W) * 4
+        if wpw > 16 or span_frames > 8 or (nparts - 1) * wpw >= nw or lds > 81920:
             continue                                                  # outside the kernel's LDS-table limits
         ran = True
-        s1 = torch.zeros((16, stride), dtype=torch.float32, device="cuda")
         pm1, pl1, pa1 = f32((nparts, 16)), f32((nparts, 16)), f32((nparts, 16, E))
+        marg = torch.full((nparts, R, wpw, 12), float("nan"), dtype=torch.float32, device="cuda")
         ctx = torch.full((nw, E), float("nan"), dtype=torch.float32, device="cuda")
-        nv.fused_stream(ff, fe, kt, ks, qhi_f, qlo, R, 1 / math.sqrt(E), 0.0, pos_a, 0, cap, cap + H, s1, pm1, pl1, pa1, ctx)
+        nv.fused_stream(ff, fe, kt, ks, qhi_f, qlo, R, 1 / math.sqrt(E), 0.0, pos_a, 0, cap, cap + H, pm1, pl1, pa1, marg, ctx)
+        ml, acc = f32((R, 2)), f32((R, E))
+        nv.global_merge_windows(pm1, pl1, pa1, marg, R, T, H, W, kt, ks, pe, 0, cap, cap + H, ml, acc, normalize=True)
         torch.cuda.synchronize()
         assert maxabs(ctx, ctx_ref) <= 5e-5 * max(1.0, float(ctx_ref.abs().max())), (nparts, "local")
-        assert maxabs(s1[:R, :N], s0[:R, :N]) <= 1e-5 * max(1.0, float(s0[:R, :N].abs().max())), (nparts, "scores")
-        assert maxabs(merged(pm1, pl1, pa1, s1), g_ref) <= 2e-5 * max(1.0, float(g_ref.abs().max())), (nparts, "global")
+        # the per-window marginals are the t / y / x sums of the softmax weights the score buffer implies
+        sc = s0[:R, :N].double().cpu().reshape(R, T // kt, kt, H // ks, ks, W // ks, ks).permute(0, 1, 3, 5, 2, 4, 6)
+        mg = marg.double().cpu().reshape(R, -1, 12) if nparts == 1 else marg.double().cpu().permute(1, 0, 2, 3).reshape(R, -1, 12)
+        mg = mg[:, :nw]
+        wts = torch.exp(sc.reshape(R, nw, kt, ks, ks) - mg[:, :, 11].reshape(R, nw, 1, 1, 1))
+        want_bins = torch.cat([wts.sum((3, 4)), wts.sum((2, 4)), wts.sum((2, 3))], dim=2)
+        assert maxabs(mg[:, :, :kt + 2 * ks], want_bins) <= 2e-4 * max(1.0, float(want_bins.abs().max())), (nparts, "marginals")
+        assert maxabs(acc, g_ref) <= 2e-5 * max(1.0, float(g_ref.abs().max())), (nparts, "global")
+        # run-to-run determinism of the LDS-atomic reductions
+        pa2, acc2 = torch.empty_like(pa1), f32((R, E))
+        nv.fused_stream(ff, fe, kt, ks, qhi_f, qlo, R, 1 / math.sqrt(E), 0.0, pos_a, 0, cap, cap + H, pm1, pl1, pa2, marg, ctx)
+        nv.global_merge_windows(pm1, pl1, pa2, marg, R, T, H, W, kt, ks, pe, 0, cap, cap + H, ml, acc2, normalize=True)
+        assert torch.equal(pa1[:, :R], pa2[:, :R]) and torch.equal(acc, acc2), (nparts, "determinism")
     assert ran
 
 
