@@ -34,13 +34,16 @@ namespace hicom {
 // every workgroup stamps s_memtime at the phase boundaries.  Compiled out of the product.
 #ifdef HICOM_TRACE
 __device__ unsigned long long g_fused_trace[1024 * 128];
+constexpr int kTraceStores = 1;   // trace stores between the pos requests and their counted wait
 #define HICOM_TR() do { if (tid == 0 && tr_n < 128) g_fused_trace[blockIdx.x * 128 + tr_n] = __builtin_readcyclecounter(); ++tr_n; } while (0)
 #else
+constexpr int kTraceStores = 0;
 #define HICOM_TR() do {} while (0)
 #endif
 
 constexpr int kMaxWinPerWg = 16;
 constexpr int kMaxFramesPerWg = 8;
+constexpr int kPosPerThread = 3;     // score-side pos-emb table entries fetched per thread: rows * (8 + H + W) <= 768
 constexpr int kPStride = 32;        // halfwords between rows of the softmax-weight planes (they share red[0]'s rows)
 constexpr int kMargW = 12;         // per (row, window): kt + 2 * ks <= 11 marginal bins + the reference max in slot 11
 
@@ -96,9 +99,7 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
     int* win_txy = win_off + 64;                                       // [64] packed (t2 << 16 | h2 << 8 | w2)
     int* worg = win_txy + 64;                                          // [kMaxWinPerWg] window origin token
     int* wtxy = worg + kMaxWinPerWg;                                   // [kMaxWinPerWg] packed (t0 << 16 | y0 << 8 | x0) window base coords
-    float* a_t = reinterpret_cast<float*>(wtxy + kMaxWinPerWg);        // [R][kMaxFramesPerWg]
-    float* a_y = a_t + p.R * kMaxFramesPerWg;                          // [R][H]
-    float* a_x = a_y + p.R * p.H;                                      // [R][W]
+    float* a_pos = reinterpret_cast<float*>(wtxy + kMaxWinPerWg);      // [R][kMaxFramesPerWg | H | W] score-side pos-emb per row
 
     const int tid = threadIdx.x, lane = tid & 63;
     int tr_n = 0; (void)tr_n;
@@ -114,18 +115,33 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
     const int R = p.R, NLOC = 16 - R;
     const int HW = p.H * p.W, ks2 = p.ks * p.ks;
 
-    // ---- A operand (hi / lo) of this wave's channel slice ----------------------------------------
-    bf16x8 ahi[KSTEPS], alo[KSTEPS];
+    // ---- request order of the prologue: (1) the score-side pos-emb table entries (three per thread,
+    // L2-resident, tiny), (2) tile 0 of frames_feature by LDS-DMA, (3) its frames_embed fragments, (4) the
+    // A operand.  The counted wait below then releases the table build while (2)-(4) are still in
+    // flight, instead of the tables waiting behind the first HBM round trip (vmcnt returns in order).
+    const int t1_first = wb / (p.nwy * p.nwx);
+    float posv[kPosPerThread];
+    bool pos_ok[kPosPerThread];
     {
-        const long off = (long)r16 * E + SLICE * wave + 8 * kg;
+        // branch-free (selects + unconditional loads from a valid address), so the waits stay counted
+        const int S = kMaxFramesPerWg + p.H + p.W;                    // entries per row: frames | rows | columns
+        const float inv_s = 1.0f / (float)S;
+        const float* pa = p.pos_a ? p.pos_a : reinterpret_cast<const float*>(p.qhi);
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            ahi[s] = *reinterpret_cast<const bf16x8*>(p.qhi + off + 32 * s);
-            alo[s] = *reinterpret_cast<const bf16x8*>(p.qlo + off + 32 * s);
+        for (int u = 0; u < kPosPerThread; ++u) {
+            const int e = tid + 256 * u;
+            const int r = (int)(((float)e + 0.5f) * inv_s), c = e - r * S;
+            const int t = t1_first * p.kt + c;
+            const int col = c < kMaxFramesPerWg ? p.t0i + t : (c < kMaxFramesPerWg + p.H ? p.y0i + (c - kMaxFramesPerWg) : p.x0i + (c - kMaxFramesPerWg - p.H));
+            const bool ok = p.pos_a != nullptr && r < R && (c >= kMaxFramesPerWg || t < p.T);
+            // inline asm: hipcc would guard a tracked load's first use with s_waitcnt vmcnt(0) here (the
+            // code in between has branches), i.e. behind the whole first HBM round trip
+            const float* src = pa + (ok ? (long)r * p.pos_stride + col : 0);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(posv[u]) : "v"(src) : "memory");
+            pos_ok[u] = ok;
         }
     }
-    // ---- tile 0 is requested BEFORE the LDS tables exist (token index by plain arithmetic), so the
-    // table set-up below overlaps the first HBM round trip instead of preceding it
+    // tile 0 is requested BEFORE the LDS tables exist (token index by plain arithmetic)
     const unsigned wsz_magic = (65536u + p.WSZ - 1) / p.WSZ;
     auto token_direct = [&](int s) -> long {
         s = s < total ? s : total - 1;
@@ -138,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
         return ((long)(t1 * p.kt + t2) * p.H + (h1 * p.ks + h2)) * p.W + (w1 * p.ks + w2);
     };
     bf16x8 bfe[KSTEPS];
-    if (ntile > 0) {
+    {
         const int row = 4 * wave + (lane >> 4), cpos = lane & 15;
         const char* src = reinterpret_cast<const char*>(p.ff) + token_direct(row) * (long)(E * 2) + 16 * (cpos ^ fswz(row));
 #pragma unroll
@@ -149,8 +165,19 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
 #pragma unroll
         for (int k = 0; k < KSTEPS; ++k) bfe[k] = *reinterpret_cast<const bf16x8*>(fsrc + 32 * k);
     }
+    // ---- A operand (hi / lo) of this wave's channel slice ----------------------------------------
+    bf16x8 ahi[KSTEPS], alo[KSTEPS];
+    {
+        const long off = (long)r16 * E + SLICE * wave + 8 * kg;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            ahi[s] = *reinterpret_cast<const bf16x8*>(p.qhi + off + 32 * s);
+            alo[s] = *reinterpret_cast<const bf16x8*>(p.qlo + off + 32 * s);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
-    HICOM_TR();   // prologue: A operand + tile 0 requested
+    HICOM_TR();   // prologue: everything requested
     // ---- per-workgroup tables -----------------------------------------------------------------
     if (p.part_marg)
         for (int i = tid; i < 2 * R * kMargW; i += 256) mbin[i] = 0.f;
@@ -159,21 +186,23 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
         win_off[tid] = (t2 * p.H + h2) * p.W + w2;
         win_txy[tid] = (t2 << 16) | (h2 << 8) | w2;
     }
-    const int t1_first = wb / (p.nwy * p.nwx);
     if (tid < nwin) {
         const int w = wb + tid;
         const int t1 = w / (p.nwy * p.nwx), r = w - t1 * (p.nwy * p.nwx), h1 = r / p.nwx, w1 = r - h1 * p.nwx;
         worg[tid] = (t1 * p.kt * p.H + h1 * p.ks) * p.W + w1 * p.ks;
         wtxy[tid] = (((t1 - t1_first) * p.kt) << 16) | ((h1 * p.ks) << 8) | (w1 * p.ks);
     }
-    if (p.pos_a) {
-        for (int i = tid; i < R * kMaxFramesPerWg; i += 256) {
-            const int r = i / kMaxFramesPerWg, f = i - r * kMaxFramesPerWg;
-            const int t = t1_first * p.kt + f;
-            a_t[r * kMaxFramesPerWg + f] = t < p.T ? p.pos_a[(long)r * p.pos_stride + p.t0i + t] : 0.f;
+    {
+        // the pos entries were the first requests of this wave (in-order return): wait until only the
+        // later ones -- tile 0, its frames_embed fragments, the A operand -- are still in flight
+        static_assert(kPosPerThread == 3, "operands of the counted wait");
+        asm volatile("s_waitcnt vmcnt(%3)" : "+v"(posv[0]), "+v"(posv[1]), "+v"(posv[2]) : "n"(PIECES / 4 + 3 * KSTEPS + kTraceStores) : "memory");
+        const int n_all = R * (kMaxFramesPerWg + p.H + p.W);
+#pragma unroll
+        for (int u = 0; u < kPosPerThread; ++u) {
+            const int e = tid + 256 * u;
+            if (e < n_all) a_pos[e] = pos_ok[u] ? posv[u] : 0.f;
         }
-        for (int i = tid; i < R * p.H; i += 256) a_y[i] = p.pos_a[(long)(i / p.H) * p.pos_stride + p.y0i + (i % p.H)];
-        for (int i = tid; i < R * p.W; i += 256) a_x[i] = p.pos_a[(long)(i / p.W) * p.pos_stride + p.x0i + (i % p.W)];
     }
 
     f32x4 acc[CBLK];
@@ -182,9 +211,7 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
     float m_run = -1.0e30f, l_run = 0.f;   // online-softmax state of row 4*wave + lane/16 (owner lanes)
     const unsigned ks2_magic = (65536u + ks2 - 1) / ks2, ks_magic = (65536u + p.ks - 1) / p.ks;
 
-    HICOM_TR();   // prologue: tables written (this wave)
-    __syncthreads();   // tables ready
-    HICOM_TR();   // 1: prologue done
+    HICOM_TR();   // prologue: tables written (this wave); barrier [A] of tile 0 publishes them
 
     // stream slot -> token index (clamped to the last valid slot of this workgroup)
     // (s / WSZ by multiply-shift: exact for s < 2^16, i.e. <= kMaxWinPerWg * 64 tokens per workgroup)
@@ -245,7 +272,10 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
         if (p.pos_a && orow < R) {
             const int txy = win_txy[oi], base = wtxy[in ? owr : 0];
             const int f = (base >> 16) + (txy >> 16), y = ((base >> 8) & 255) + ((txy >> 8) & 255), x = (base & 255) + (txy & 255);
-            posb = a_t[orow * kMaxFramesPerWg + f] + a_y[orow * p.H + y] + a_x[orow * p.W + x];
+            int orow_c = orow;                           // opaque: recomputed per tile instead of held in a register
+            asm volatile("" : "+v"(orow_c));
+            const float* ap = a_pos + orow_c * (kMaxFramesPerWg + p.H + p.W);
+            posb = ap[f] + ap[kMaxFramesPerWg + y] + ap[kMaxFramesPerWg + p.H + x];
         }
 
         // ---- local logits (rows >= R) from the frames_embed fragments (landed with [A]) -------------
@@ -352,11 +382,14 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
             }
             f32x4 mg = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(phi, bm, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             mg = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(plo, bm, mg, 0, 0, 0);
-            if (r16 < kMargW) {
+            int lane_m = lane;                           // opaque: this block's addresses are not loop invariants
+            asm volatile("" : "+v"(lane_m));
+            const int r16m = lane_m & 15, kgm = lane_m >> 4;
+            if (r16m < kMargW) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (4 * kg + j < R) {
-                        float* a = mbin + (wave * R + 4 * kg + j) * kMargW + r16;
+                    if (4 * kgm + j < R) {
+                        float* a = mbin + (wave * R + 4 * kgm + j) * kMargW + r16m;
                         *a = fmaf(*a, al[j], mg[j]);
                     }
             }
@@ -394,41 +427,57 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
             const int w = wb + wr0;
             const int row = rowA;                          // wave-uniform
             const float linv = 1.0f / lrun_s[row];
-            const long obase = (long)w * E + SLICE * wave + r16;
             const int rk = row >> 2, rj = row & 3;
+            // The row sits in 16 lanes as 18 values 16 channels apart: stored from there it would be 36
+            // 2-byte store instructions per wave (each a full pass of the address unit).  Two hops through a
+            // wave-private scratch inside red[1..3] (idle between [C] and the next [A]) regroup it so that
+            // 36 lanes hold 4 consecutive channels each: 2 wide stores per plane instead.
+            int lane_c = lane;                           // opaque copy: keeps this block's address math out of the loop-invariant registers
+            asm volatile("" : "+v"(lane_c));
+            float* wsc = red + 256 + wave * (SLICE / 2);
+            static_assert(CBLK % 2 == 0 && 4 * (SLICE / 2) <= 3 * 256 && SLICE / 8 <= 64, "scratch of the row regroup");
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j == rj) {
-                    if (kg == rk) {
+            for (int half = 0; half < 2; ++half) {
 #pragma unroll
-                        for (int cb = 0; cb < CBLK; ++cb) {
-                            const float v = acc[cb][j] * linv;
-                            if (p.ctx_local) p.ctx_local[obase + 16 * cb] = v;
-                            if (p.ctx_hi) {
-                                uint16_t h, l;
-                                split_bf16(v, h, l);
-                                p.ctx_hi[obase + 16 * cb] = h;
-                                p.ctx_lo[obase + 16 * cb] = l;
+                for (int j = 0; j < 4; ++j) {
+                    if (j == rj) {
+                        if (kg == rk) {
+#pragma unroll
+                            for (int c = 0; c < CBLK / 2; ++c) {
+                                wsc[16 * c + r16] = acc[half * (CBLK / 2) + c][j] * linv;
+                                acc[half * (CBLK / 2) + c][j] = 0.f;
                             }
-                            acc[cb][j] = 0.f;
                         }
+                    }
+                }
+                if (lane_c < SLICE / 8) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(wsc + 4 * lane_c);
+                    const long o = (long)w * E + SLICE * wave + half * (SLICE / 2) + 4 * lane_c;
+                    if (p.ctx_local) *reinterpret_cast<f32x4*>(p.ctx_local + o) = v;
+                    if (p.ctx_hi) {
+                        uint16_t h[4], l[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) split_bf16(v[u], h[u], l[u]);
+                        *reinterpret_cast<uint2*>(p.ctx_hi + o) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+                        *reinterpret_cast<uint2*>(p.ctx_lo + o) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
                     }
                 }
             }
             if (p.part_marg) {
                 // the completed window's marginals (wave 0) and its reference max (owner lanes of the rows)
                 float* o = p.part_marg + ((long)part * R * p.wpw + wr0) * kMargW;
-                if (wave == (wr0 & 1) && r16 < kMargW - 1) {
+                const int r16c = lane_c & 15, kgc = lane_c >> 4;
+                if (wave == (wr0 & 1) && r16c < kMargW - 1) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (4 * kg + j < R) {
-                            float* a = mbin + (wave * R + 4 * kg + j) * kMargW + r16;
-                            o[(long)(4 * kg + j) * p.wpw * kMargW + r16] = *a;
+                        if (4 * kgc + j < R) {
+                            float* a = mbin + (wave * R + 4 * kgc + j) * kMargW + r16c;
+                            o[(4 * kgc + j) * p.wpw * kMargW + r16c] = *a;
                             *a = 0.f;
                         }
                 }
-                const int orow = 4 * wave + (lane >> 4);
-                if (orow < R && (lane & 15) == kMargW - 1) o[(long)orow * p.wpw * kMargW + kMargW - 1] = m_run;
+                const int orow2 = 4 * wave + kgc;
+                if (orow2 < R && r16c == kMargW - 1) o[orow2 * p.wpw * kMargW + kMargW - 1] = m_run;
             }
             if (4 * wave + (lane >> 4) == row) { m_run = -1.0e30f; l_run = 0.f; }   // owner lanes recycle the row
         }
@@ -446,12 +495,21 @@ __global__ __launch_bounds__(256, 2) void fused_stream_kernel(FusedParams p) {
             p.part_l[prow + row] = l_run;
         }
     }
+    // The accumulator rows go out through the (now idle) tile buffers, regrouped so that every lane stores
+    // 16 contiguous bytes: 11 store instructions per wave instead of 72 four-byte ones.
+    __syncthreads();                                   // every wave is done with the last tile image
+    {
+        float* est = reinterpret_cast<float*>(tilebuf) + wave * (R * SLICE);       // wave-private [R][SLICE]
 #pragma unroll
-    for (int cb = 0; cb < CBLK; ++cb) {
-        float* o = p.part_acc + (prow + 4 * kg) * E + SLICE * wave + 16 * cb + r16;
+        for (int cb = 0; cb < CBLK; ++cb)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (4 * kg + j < R) o[(long)j * E] = acc[cb][j];
+            for (int j = 0; j < 4; ++j)
+                if (4 * kg + j < R) est[(4 * kg + j) * SLICE + 16 * cb + r16] = acc[cb][j];
+        const int n4 = R * (SLICE / 4);
+        for (int it = lane; it < n4; it += 64) {
+            const int row = it / (SLICE / 4), c4 = it - row * (SLICE / 4);
+            *reinterpret_cast<f32x4*>(p.part_acc + (prow + row) * E + SLICE * wave + 4 * c4) = *reinterpret_cast<const f32x4*>(est + 4 * it);
+        }
     }
     HICOM_TR();   // epilogue issued
 }

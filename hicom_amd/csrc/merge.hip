@@ -82,16 +82,18 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
 }
 
 constexpr int kMargW = 12;   // must match fused_stream.hip
+constexpr int kMergeChunk = 16128;   // floats of marginals staged in LDS per pass (63 KiB; a multiple of 12 * 4)
 constexpr int kTC = 64;   // frames of marginals staged in LDS per pass (one pass for T <= 64)
 
 __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
-    // LDS: [16*64] column partials | [4] | [nparts] partial weights | [T] frame weights |
+    // LDS: [16*64] column partials | [marginal chunk] | [4] | [nparts] partial weights | [T] frame weights |
     //      [T+H+W] positional weights | [kTC * S] staged marginals
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int r = blockIdx.x, tid = threadIdx.x;
     const int S = p.H + p.W + 2, HW2 = p.H + p.W;
     float* cred = wsm;                                   // 16-byte aligned: float4 stores
-    float* red = cred + 16 * 64;
+    float* chunk = cred + 16 * 64;                       // [kMergeChunk] staged window marginals (fused path only), 16-byte aligned
+    float* red = chunk + (p.part_marg ? kMergeChunk : 0);
     float* wp = red + 4;
     float* wt = wp + p.nparts;
     float* wpos = wt + p.T;
@@ -131,37 +133,53 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
 
     const bool has_pos = sc != nullptr || p.part_marg != nullptr;
     if (p.part_marg) {
-        // positional weights from the per-workgroup, per-window marginals of the fused kernel.  Every
-        // window's bins are relative to its own reference max (slot kMargW-1): ew[w] = e^(ref_w - M).
-        // Each t / y / x slot then sums its windows in a fixed order (SUB threads per slot, combined in
-        // order), so the result is run-to-run deterministic.
-        float* ew = tile;                       // [NW]
-        float* psum = tile + p.NW;              // [nslots * SUB]
-        const int per_part = p.wpw * kMargW, per_t = p.nwy * p.nwx, nt = p.T / p.kt;
-        const long rstride = (long)gridDim.x * per_part;
-        const float* mrow = p.part_marg + (long)r * per_part;
-        for (int w = tid; w < p.NW; w += 256) {
-            const int i = w / p.wpw, wr = w - i * p.wpw;
-            ew[w] = expf(mrow[i * rstride + wr * kMargW + (kMargW - 1)] - M);
-        }
-        __syncthreads();
+        // positional weights from the per-window marginals of the fused kernel.  Row r's marginals are
+        // copied to LDS in coalesced chunks (window-major: partial i holds windows i*wpw ..), each window's
+        // bins are relative to its own reference max (slot kMargW-1), which becomes e^(ref - M) in place.
+        // Every t / y / x slot then sums its windows in a fixed order (SUB threads per slot, combined in
+        // order): run-to-run deterministic, no atomics.
+        float* psum = tile;                              // [max(256, nslots)]
+        const int per_part = p.wpw * kMargW, nt = p.T / p.kt;
+        const int parts_per_chunk = kMergeChunk / per_part;
         const int nslots = p.T + HW2, SUB = nslots < 256 ? 256 / nslots : 1;
-        for (int item = tid; item < nslots * SUB; item += 256) {
-            const int j = item / SUB, k = item - j * SUB;
-            int cnt, b, fixed, mode;
-            if (j < p.T) { mode = 0; fixed = (j / p.kt) * per_t; b = j % p.kt; cnt = per_t; }
-            else if (j < p.T + p.H) { const int y = j - p.T; mode = 1; fixed = (y / p.ks) * p.nwx; b = p.kt + y % p.ks; cnt = nt * p.nwx; }
-            else { const int x = j - p.T - p.H; mode = 2; fixed = x / p.ks; b = p.kt + p.ks + x % p.ks; cnt = nt * p.nwy; }
-            float a = 0.f;
-            for (int q = k; q < cnt; q += SUB) {
-                int w;
-                if (mode == 0) w = fixed + q;
-                else if (mode == 1) { const int t1 = q / p.nwx; w = t1 * per_t + fixed + (q - t1 * p.nwx); }
-                else { const int t1 = q / p.nwy; w = t1 * per_t + (q - t1 * p.nwy) * p.nwx + fixed; }
-                const int i = w / p.wpw, wr = w - i * p.wpw;
-                a = fmaf(ew[w], mrow[i * rstride + wr * kMargW + b], a);
+        const unsigned q4_magic = ((1u << 24) + per_part / 4 - 1) / (per_part / 4);
+        for (int item = tid; item < nslots * SUB; item += 256) psum[item] = 0.f;
+        for (int i_lo = 0; i_lo < p.nparts; i_lo += parts_per_chunk) {
+            const int i_hi = min(p.nparts, i_lo + parts_per_chunk);
+            const int w_lo = i_lo * p.wpw, w_hi = min(p.NW, i_hi * p.wpw);
+            __syncthreads();
+            // coalesced copy: partial i contributes per_part contiguous floats (16-byte aligned)
+            const int n4 = (i_hi - i_lo) * (per_part / 4);
+            for (int e = tid; e < n4; e += 256) {
+                const int i = (int)(((unsigned long long)(unsigned)e * q4_magic) >> 24), k4 = e - i * (per_part / 4);
+                reinterpret_cast<float4*>(chunk)[e] =
+                    *reinterpret_cast<const float4*>(p.part_marg + ((long)(i_lo + i) * gridDim.x + r) * per_part + 4 * k4);
             }
-            psum[item] = a;
+            __syncthreads();
+            for (int w = w_lo + tid; w < w_hi; w += 256) {
+                float* ref = chunk + (w - w_lo) * kMargW + (kMargW - 1);
+                *ref = expf(*ref - M);
+            }
+            __syncthreads();
+            for (int item = tid; item < nslots * SUB; item += 256) {
+                const int j = item / SUB, k = item - j * SUB;
+                int base, so, no, si, ni, b;        // w = base + o * so + i * si, o = k, k+SUB, .. < no, i < ni
+                if (j < p.T) { base = (j / p.kt) * p.nwy * p.nwx; b = j % p.kt; so = p.nwx; no = p.nwy; si = 1; ni = p.nwx; }
+                else if (j < p.T + p.H) { const int y = j - p.T; base = (y / p.ks) * p.nwx; b = p.kt + y % p.ks; so = p.nwy * p.nwx; no = nt; si = 1; ni = p.nwx; }
+                else { const int x = j - p.T - p.H; base = x / p.ks; b = p.kt + p.ks + x % p.ks; so = p.nwy * p.nwx; no = nt; si = p.nwx; ni = p.nwy; }
+                float a = psum[item];
+                for (int o = k; o < no; o += SUB) {
+                    const int w0 = base + o * so;
+                    for (int i = 0; i < ni; ++i) {
+                        const int w = w0 + i * si;
+                        if (w >= w_lo && w < w_hi) {
+                            const float* c = chunk + (w - w_lo) * kMargW;
+                            a = fmaf(c[kMargW - 1], c[b], a);
+                        }
+                    }
+                }
+                psum[item] = a;
+            }
         }
         __syncthreads();
         for (int j = tid; j < nslots; j += 256) {
@@ -315,8 +333,13 @@ extern "C" int hicom_global_merge_windows_fwd(const float* part_m, const float* 
     const int NW = (T / kt) * (H / ks) * (W / ks), wpw = (NW + nparts - 1) / nparts;
     MergeCtxParams p{part_m, part_l, part_acc, nparts, 16, E, nullptr, part_marg, wpw, kt, ks, H / ks, W / ks, NW, pe,
                      T, H, W, t_index0, y_index0, x_index0, out_ml, out_acc, normalize};
-    const size_t smem2 = ((size_t)nparts + (pe ? (size_t)2 * T + H + W + NW + (T + H + W < 256 ? 256 : T + H + W) : 0) + 16 * 64 + 4) * 4;
-    HICOM_REQUIRE(smem2 <= 60000, HICOM_EUNSUP, "global_merge_windows: too many partials/windows for one pass");
+    const size_t smem2 = ((size_t)nparts + (pe ? (size_t)2 * T + H + W + kMergeChunk + (T + H + W < 256 ? 256 : T + H + W) : 0) + 16 * 64 + 4) * 4;
+    HICOM_REQUIRE(smem2 <= 81920 && wpw * kMargW <= kMergeChunk, HICOM_EUNSUP, "global_merge_windows: too many partials/frames for one pass");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(merge_ctx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+        attr_set = true;
+    }
     hipLaunchKernelGGL(merge_ctx_kernel, dim3((unsigned)rows, (unsigned)((E + 31) / 32)), dim3(256), smem2, (hipStream_t)stream, p);
     return hicom_host::check_launch("global_merge_windows");
 }

@@ -247,3 +247,51 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype) -> tor
     a.out = out.data_ptr()
     nv.compressor_fwd(a)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Pipelined submission: consecutive, independent forwards on alternating "lanes" (a lane = its own
+# main stream, side stream, events, workspace and plans -- everything above is keyed by the stream
+# it runs on).  The tail of one video (readout GEMMs, merge, the small global chain: latency-bound)
+# then overlaps the query prep and the HBM-bound stream kernel of the next one.
+class _Lane:
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.ev_in = torch.cuda.Event()
+
+
+class Pending:
+    """Result handle of forward_async.  wait() orders the caller's current stream after the lane's
+    work and returns the tensor; the inputs are kept alive until then."""
+    __slots__ = ("_out", "_done", "_inputs")
+
+    def __init__(self, out, done, inputs):
+        self._out, self._done, self._inputs = out, done, inputs
+
+    def wait(self) -> torch.Tensor:
+        cur = torch.cuda.current_stream(self._out.device)
+        cur.wait_event(self._done)
+        self._out.record_stream(cur)           # allocated on the lane stream, consumed on the caller's
+        self._inputs = None
+        return self._out
+
+
+def submit(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, n_lanes: int = 2) -> Pending:
+    from .projector import _require_bf16_cuda
+    _require_bf16_cuda("frames_feature", ff)
+    dev = ff.device
+    state = proj.__dict__.setdefault("_engine_lanes", {})
+    key = (dev.index, n_lanes)
+    if key not in state:
+        state[key] = [[_Lane(dev) for _ in range(n_lanes)], 0]
+    lanes, rr = state[key]
+    lane = lanes[rr % n_lanes]
+    state[key][1] = rr + 1
+    cur = torch.cuda.current_stream(dev)
+    lane.ev_in.record(cur)                     # inputs are ready where the caller stands now
+    lane.stream.wait_event(lane.ev_in)
+    with torch.cuda.stream(lane.stream):
+        out = run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype)
+        done = torch.cuda.Event()
+        done.record(lane.stream)
+    return Pending(out, done, (ff, fe, guide_embed, image_newline))

@@ -464,6 +464,16 @@ class HIComProjector(nn.Module):
                                     _out_dtype(self))
         return self.forward_stepwise(frames_feature, frames_embed, guide_embed, modal, image_newline)
 
+    def forward_async(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None, lanes: int = 2):
+        """forward() for serving loops: the call is enqueued on one of `lanes` internal stream sets and a
+        handle is returned at once; handle.wait() yields the tensor (ordered on the caller's stream).
+        Independent videos submitted back to back overlap on the GPU.  Dense plain inputs only."""
+        plain = all(c is None or c.is_plain for c in (self.local_compressor, self.global_compressor))
+        if not plain or isinstance(frames_feature, dict):
+            raise NotImplementedError("forward_async: dense inputs of the plain recipes only (use forward())")
+        from . import engine
+        return engine.submit(self, frames_feature, frames_embed, guide_embed, modal, image_newline, _out_dtype(self), lanes)
+
     def forward_stepwise(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None):
         """Same result, one C-ABI call per operator (anyres dict inputs; also the cross-check of the
         executor in the tests)."""

@@ -38,7 +38,7 @@ L.hicom_debug_fused_trace.argtypes = [ctypes.c_void_p, ctypes.c_int64]
 assert L.hicom_debug_fused_trace(buf.ctypes.data, buf.nbytes) == 0
 tr = buf.reshape(1024, 128)[:nparts].astype(np.int64)
 ntile = (wpw * 36 + 15) // 16
-n = 4 + 5 * ntile + 2
+n = 3 + 5 * ntile + 2
 t0 = tr[:, 0].min()
 span = tr[:, n - 1].max() - t0
 print("stamps per wg %d (tiles %d); span first start -> last end: %d ticks" % (n, ntile, span))
@@ -48,11 +48,10 @@ def stat(name, d):
           np.percentile(d, 50) * tick_us, np.percentile(d, 90) * tick_us, d.max() * tick_us))
 full = tr[(tr[:, n - 1] > 0)]
 stat("wg start (after first wg)", full[:, 0] - t0)
-stat("prologue: issue A + tile 0", full[:, 1] - full[:, 0])
+stat("prologue: issue requests", full[:, 1] - full[:, 0])
 stat("prologue: tables", full[:, 2] - full[:, 1])
-stat("prologue: barrier", full[:, 3] - full[:, 2])
 for t in range(ntile):
-    base = 4 + 5 * t
+    base = 3 + 5 * t
     prev = full[:, base - 1]
     stat("tile %d wait data  (-> [A])" % t, full[:, base] - prev)
     stat("tile %d scores     ([A]->[B])" % t, full[:, base + 1] - full[:, base])
