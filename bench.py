@@ -232,7 +232,7 @@ def dominant_kernel_roofline(module, ff, fe, guide, iters):
             traffic = prof["kernels"]["fused_stream_kernel"]["hbm_bytes_per_launch_corrected"]
     except Exception:
         pass
-    return {"kernel": "hicom::fused_stream_kernel<9>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+    return {"kernel": "hicom::fused_ring_kernel<9>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": mean_ms, "min_launch_ms": ms[0]}
 

@@ -44,8 +44,11 @@ bool can_fuse(const hicom_compressor_args& a) {
     const int nw = a.at.nwin * a.ay.nwin * a.ax.nwin, per_t = a.ay.nwin * a.ax.nwin;
     const int nparts = hicom_fused_stream_nparts(nw);
     const int wpw = (nw + nparts - 1) / nparts;
-    if (2 * 9 * 4096 + 4096 + 2 * R * 12 * 4 + 128 + (64 + 64 + 32) * 4 + R * (8 + a.H + a.W) * 4 > 81920) return false;
-    return wpw <= 16 && ((wpw + per_t - 2) / per_t + 1) * a.at.k <= 8;
+    // limits of fused_ring.hip: 160 KiB of LDS (ring 4 x 36 KiB + logit partials + tables), <= 32 windows
+    // and <= 8 frames per workgroup, <= 1024 pos-emb table entries
+    if (4 * 9 * 4096 + 9 * 1024 + 8 * 80 * 4 + 8 * 64 + (128 + 32) * 4 + R * (8 + a.H + a.W) * 4 > 163840) return false;
+    if (R * (8 + a.H + a.W) > 1024) return false;
+    return wpw <= 32 && ((wpw + per_t - 2) / per_t + 1) * a.at.k <= 8;
 }
 
 WsLayout make_layout(const hicom_compressor_args& a) {

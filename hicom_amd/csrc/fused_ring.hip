@@ -1,0 +1,572 @@
+// Fused hybrid-level compressor stream: LOCAL windowed attention + GLOBAL multi-head attention in
+// ONE pass over the visual tokens -- frames_embed and frames_feature are each read from HBM
+// exactly once ("local + global share the value stream").
+//
+// Replaces, for the release recipe (use_guide = direct, exact window partition), both
+//   LocalCompressor.forward  windows/bmm/softmax/bmm   (reference projector.py:544-558) and
+//   MultiheadAttention.forward QK^T/softmax/PV          (reference projector.py:193-215).
+//
+// One 16-row MFMA operand carries BOTH problems:
+//   rows 0 .. R-1   : folded global queries qt_h (bf16 hi + lo), scored against frames_feature
+//   rows R .. 15    : the local query (guide), scored against frames_embed; row R + (w mod NLOC)
+//                     belongs to window w, other windows' tokens are masked out of that row
+// so the P.x product accumulates the global head contexts AND the open windows' local contexts in
+// the same accumulator registers.
+//
+// Token order: a workgroup walks a contiguous range of windows in window-major order (the kt*ks*ks
+// tokens of a window, then the next window), 16 tokens per tile.  At most 2 windows are open per
+// tile, so NLOC = 16 - R >= 2 local rows suffice; when a window's last token has been accumulated its
+// row is normalised, written out and recycled.
+//
+// Execution model: ONE 768-thread workgroup per CU with fixed roles.
+//   4 LOADER waves  own every vector-memory request of the tile loop: both visual tensors travel
+//                   HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction) into a
+//                   2 + 2 slot ring of swizzled tile images ([E/128][16 tokens][256 B]).  Issuing a DMA
+//                   piece costs the issuing wave 60-185 cycles (MI355X_MICROARCH.md), which in the
+//                   previous 4-wave design sat in front of the MFMAs of every tile; here it is paid by
+//                   waves that have nothing else to do.  The loaders wait on their own counted vmcnt
+//                   and publish a tile at barrier [A] (two barriers per tile in all); frames_embed of tile t+2 is requested as soon as
+//                   the local scores of tile t have consumed its slot (barrier [B]), frames_feature of
+//                   tile t+1 when the P.x of tile t-1 has released its slot (barrier [A]).
+//   8 COMPUTE waves each own a 144-channel slice: score B fragments by ds_read_b64 (rows), P.x B
+//                   fragments by ds_read_b64_tr_b16 (columns) from the same image, v_mfma_f32_16x16x16_bf16
+//                   throughout, fp32 online softmax (2 rows per wave, DPP row reductions).
+// The positional marginals of the global weights (value-side pos-emb) are one more 16x16 MFMA tile
+// per tile (P x one-hot bins), kept in LDS and written out per window.
+#include <stdlib.h>
+
+#include "common.hpp"
+
+namespace hicom {
+
+// Dev-only phase timeline (tools/fused_trace.py builds a second library with -DHICOM_TRACE): lane 0 of
+// compute waves 0 / 2 and of loader 0 stamp s_memtime at the phase boundaries.  Compiled out of the product.
+#ifdef HICOM_TRACE
+__device__ unsigned long long g_fused_trace[1024 * 3 * 256];
+#define HICOM_TR(who) do { if (lane == 0 && wave == (who == 0 ? 0 : who == 1 ? 2 : kRingC) && tr_n < 256) g_fused_trace[(blockIdx.x * 3 + who) * 256 + tr_n] = __builtin_readcyclecounter(); ++tr_n; } while (0)
+#else
+#define HICOM_TR(who) do {} while (0)
+#endif
+
+constexpr int kRingC = 8;                 // compute waves
+constexpr int kRingL = 4;                 // loader waves
+constexpr int kRingThreads = 64 * (kRingC + kRingL);
+constexpr int kMaxWinPerWg = 32;
+constexpr int kMaxFramesPerWg = 8;
+constexpr int kPosPerThread = 2;          // score-side pos-emb entries fetched per compute thread: rows * (8 + H + W) <= 1024
+constexpr int kPStride = 32;              // halfwords between rows of the softmax-weight planes (they live in red[0]'s rows)
+constexpr int kRegroup = 80;               // channels per hop of the completed-row regroup (multiple of 16)
+constexpr int kMargW = 12;                // per (row, window): kt + 2 ks <= 11 marginal bins + the reference max in slot 11
+
+struct RingParams {
+    const uint16_t* ff;
+    const uint16_t* fe;
+    int T, H, W;
+    int kt, ks, nwy, nwx, NW, WSZ;
+    const uint16_t* qhi;   // [16][E]  rows < R: qt hi ; rows >= R: local query (exact bf16)
+    const uint16_t* qlo;   // [16][E]  rows < R: qt lo ; rows >= R: zero
+    int R;
+    float l_scale, l_bias;
+    const float* pos_a;    // [16][pos_stride] or NULL
+    int pos_stride, t0i, y0i, x0i;
+    float* part_m;
+    float* part_l;
+    float* part_acc;       // [nparts][16][E], rows < R
+    float* part_marg;      // [nparts][R][wpw][kMargW] per-window t / y / x marginals of the global weights, or NULL
+    float* ctx_local;      // [NW][E] fp32 window contexts (may be NULL)
+    uint16_t* ctx_hi;      // [NW][E] the same as bf16 hi / lo planes for hicom_planes_gemm_fwd (may be NULL)
+    uint16_t* ctx_lo;
+    int wpw;               // windows per workgroup
+};
+
+__device__ __forceinline__ int fswz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+__device__ __forceinline__ int fsig(int g) { return ((g & 1) << 1) | (g >> 1); }
+
+template <int NB>
+__global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams p) {
+    constexpr int E = NB * 128;
+    constexpr int SLICE = E / kRingC;              // channels per compute wave
+    constexpr int KS = SLICE / 16;                 // 16-column blocks of the P.x product per wave
+    constexpr int K32 = SLICE / 32;                // score K-steps of 32 channels
+    constexpr bool KTAIL = (SLICE % 32) != 0;      // + one K-step of 16 channels
+    constexpr int TILE_BYTES = NB * 4096;          // one 16-token image
+    constexpr int PIECES = NB * 4;                 // 1-KiB DMA pieces per image: (128-channel block, 4-token row group)
+    constexpr int PPL = PIECES / kRingL;           // pieces per loader wave and image
+    static_assert(E % (16 * kRingC) == 0 && PIECES % kRingL == 0 && kRingL == 4, "slice / piece split");
+    static_assert(SLICE % 4 == 0 && SLICE / 4 <= 64, "row regroup: one float4 per lane");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ffbuf = smem;                                                // [2][TILE_BYTES] frames_feature ring
+    char* febuf = smem + 2 * TILE_BYTES;                               // [2][TILE_BYTES] frames_embed ring
+    float* red = reinterpret_cast<float*>(smem + 4 * TILE_BYTES);     // [kRingC + 1][16][16] logit partials (channel slices) + the score-side pos-emb
+    float* cscr = red + (kRingC + 1) * 256;                                  // [kRingC][kRegroup] wave-private regroup scratch of a completed row
+    float* alpha_s = cscr + kRingC * kRegroup;                            // [kRingC][16] wave-private rescale factors in accumulator-row order
+    int* win_txy = reinterpret_cast<int*>(alpha_s + kRingC * 16);   // [64] packed in-window coords (t2 << 16 | h2 << 8 | w2)
+    int* win_bins = win_txy + 64;                                      // [64] marginal bins of an in-window token: bit t2 | bit kt+h2 | bit kt+ks+w2
+    int* wtxy = win_bins + 64;                                          // [kMaxWinPerWg] packed window base coords (frame offset << 16 | y0 << 8 | x0)
+    float* a_pos = reinterpret_cast<float*>(wtxy + kMaxWinPerWg);      // [R][kMaxFramesPerWg | H | W] score-side pos-emb per row
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tr_n = 0; (void)tr_n;
+    const int part = blockIdx.x;
+    const int wb = part * p.wpw;
+    const int we = min(p.NW, wb + p.wpw);
+    const int nwin = we - wb;
+    const int total = nwin * p.WSZ;                 // tokens of this workgroup's stream
+    const int ntile = (total + 15) >> 4;
+    const int R = p.R, NLOC = 16 - R;
+    const int ks2 = p.ks * p.ks, per_t = p.nwy * p.nwx;
+    const unsigned wsz_magic = (65536u + p.WSZ - 1) / p.WSZ;    // s / WSZ by multiply-shift: exact for s < 2^16
+
+    // =========================================================================================
+    // LOADER waves
+    // =========================================================================================
+    if (wave >= kRingC) {
+        const int l = wave - kRingC;
+        const int row = 4 * l + (lane >> 4), cpos = lane & 15;          // token slot of this lane, 16-byte chunk in the row
+        const int lane_off = 16 * (cpos ^ fswz(row));
+        // stream slot -> byte offset of the token row (clamped past the end: harmless re-requests)
+        auto src_off = [&](int tile) -> long {
+            int s = tile * 16 + row;
+            s = s < total ? s : total - 1;
+            int wr = (int)(((unsigned)s * wsz_magic) >> 16);
+            int i = s - wr * p.WSZ;
+            if (i < 0) { i += p.WSZ; wr -= 1; }
+            const int w = wb + wr;
+            const int t1 = w / per_t, r = w - t1 * per_t, h1 = r / p.nwx, w1 = r - h1 * p.nwx;
+            const int t2 = i / ks2, ri = i - t2 * ks2, h2 = ri / p.ks, w2 = ri - h2 * p.ks;
+            const long tok = ((long)(t1 * p.kt + t2) * p.H + (h1 * p.ks + h2)) * p.W + (w1 * p.ks + w2);
+            return tok * (long)(E * 2) + lane_off;
+        };
+        auto issue = [&](const uint16_t* base, long off, char* img) {
+            const char* src = reinterpret_cast<const char*>(base) + off;
+#pragma unroll
+            for (int i = 0; i < PPL; ++i)                               // piece (block i, row group l)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 256),
+                                                 (__attribute__((address_space(3))) void*)(img + (4 * i + l) * 1024), 16, 0, 0);
+        };
+        const long o0 = src_off(0);
+        long o_ff = src_off(1);
+        issue(p.ff, o0, ffbuf);
+        issue(p.fe, o0, febuf);
+        issue(p.fe, o_ff, febuf + TILE_BYTES);
+        HICOM_TR(2);   // prologue requests issued
+        __builtin_amdgcn_s_barrier();                                  // [P] (the compute waves' tables)
+        for (int t = 0; t < ntile; ++t) {
+            const long o_fe = src_off(t + 2);                          // address math ahead of the wait
+            // in flight, oldest first: fe(t) | ff(t) | fe(t+1): everything but the youngest image has to land
+            HICOM_TR(2);   // tile: addresses ready
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PPL) : "memory");
+            HICOM_TR(2);   // tile: data landed
+            __builtin_amdgcn_s_barrier();                              // [A] tile t published; ff slot of tile t-1 released
+            HICOM_TR(2);   // tile: past [A]
+            issue(p.ff, o_ff, ffbuf + ((t + 1) & 1) * TILE_BYTES);
+            HICOM_TR(2);   // tile: ff issued
+            __builtin_amdgcn_s_barrier();                              // [B] fe slot of tile t released
+            HICOM_TR(2);   // tile: past [B]
+            issue(p.fe, o_fe, febuf + (t & 1) * TILE_BYTES);
+            HICOM_TR(2);   // tile: fe issued
+            o_ff = o_fe;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the clamped requests past the end
+        __builtin_amdgcn_s_barrier();                                  // [E] ring idle
+        return;
+    }
+
+    // =========================================================================================
+    // COMPUTE waves
+    // =========================================================================================
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int ctid = tid;                                              // compute threads are 0 .. 511
+
+    // ---- A operand (hi / lo) of this wave's channel slice: lane (query row r16, k group kg) -------
+    // SLICE = K32 steps of 32 channels (v_mfma_f32_16x16x32_bf16, the full-rate instruction) + an optional
+    // 16-channel tail (v_mfma_f32_16x16x16_bf16 runs at half the rate per flop).
+    bf16x8 ahi[K32], alo[K32];
+    bf16x4 ahi_t = bf16x4{0, 0, 0, 0}, alo_t = bf16x4{0, 0, 0, 0};
+    {
+        const long off = (long)r16 * E + SLICE * wave;
+#pragma unroll
+        for (int s = 0; s < K32; ++s) {
+            ahi[s] = *reinterpret_cast<const bf16x8*>(p.qhi + off + 32 * s + 8 * kg);
+            alo[s] = *reinterpret_cast<const bf16x8*>(p.qlo + off + 32 * s + 8 * kg);
+        }
+        if (KTAIL) {
+            ahi_t = *reinterpret_cast<const bf16x4*>(p.qhi + off + 32 * K32 + 4 * kg);
+            alo_t = *reinterpret_cast<const bf16x4*>(p.qlo + off + 32 * K32 + 4 * kg);
+        }
+    }
+    // ---- per-workgroup tables ---------------------------------------------------------------------
+    const int t1_first = wb / per_t;
+    if (ctid < p.WSZ) {
+        const int t2 = ctid / ks2, r = ctid - t2 * ks2, h2 = r / p.ks, w2 = r - h2 * p.ks;
+        win_txy[ctid] = (t2 << 16) | (h2 << 8) | w2;
+        win_bins[ctid] = (1 << t2) | (1 << (p.kt + h2)) | (1 << (p.kt + p.ks + w2));
+    }
+    if (ctid < nwin) {
+        const int w = wb + ctid;
+        const int t1 = w / per_t, r = w - t1 * per_t, h1 = r / p.nwx, w1 = r - h1 * p.nwx;
+        wtxy[ctid] = (((t1 - t1_first) * p.kt) << 16) | ((h1 * p.ks) << 8) | (w1 * p.ks);
+    }
+    if (p.pos_a) {
+        const int S = kMaxFramesPerWg + p.H + p.W, n_all = R * S;
+#pragma unroll
+        for (int u = 0; u < kPosPerThread; ++u) {
+            const int e = ctid + 64 * kRingC * u;
+            if (e < n_all) {
+                const int r = e / S, c = e - r * S;
+                const int t = t1_first * p.kt + c;
+                const int col = c < kMaxFramesPerWg ? p.t0i + t
+                                                    : (c < kMaxFramesPerWg + p.H ? p.y0i + (c - kMaxFramesPerWg) : p.x0i + (c - kMaxFramesPerWg - p.H));
+                a_pos[e] = (c >= kMaxFramesPerWg || t < p.T) ? p.pos_a[(long)r * p.pos_stride + col] : 0.f;
+            }
+        }
+    }
+
+    f32x4 acc[KS];
+#pragma unroll
+    for (int cb = 0; cb < KS; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Online-softmax state of query row r16, replicated in the four lanes (kg = 0..3) that hold its tokens
+    // and in every compute wave: the scores are computed TRANSPOSED (S^T = x . q^T), which leaves each lane
+    // with (row r16, token slots 4*sig(kg) .. +3) -- exactly the A-operand layout of P for the P.x MFMAs.
+    // The softmax therefore runs in registers in all waves at once: no shared P, no third barrier.
+    float m_run = -1.0e30f, l_run = 0.f;
+    f32x4 mgacc = f32x4{0.f, 0.f, 0.f, 0.f};   // waves 0 / 1: marginals (rows 4 kg + j, bin r16) of the even / odd window in flight
+
+    const int q4 = (lane >> 2) & 3, pp = lane & 3;
+    const int trow = 4 * fsig(kg) + q4;
+    const int prow16 = 4 * fsig(r16 >> 2) + (r16 & 3);                      // token slot read as A-row r16 of the score MFMA
+    const int rd_row = prow16 * 256, rd_swz = fswz(prow16);                 // row read: chunk c of the row sits at position c ^ swz
+    const int tr_row_off = trow * 256 + 8 * (pp & 1), tr_swz = fswz(trow);
+    const int ch_base = SLICE * wave;
+    const int ts0 = 4 * fsig(kg);                                            // first token slot of this lane
+    float* ascr = alpha_s + 16 * wave;                                       // wave-private: alpha in accumulator-row order
+
+    HICOM_TR(0); HICOM_TR(1);   // prologue done (this wave)
+    lds_barrier();                                                     // [P] tables ready
+
+    for (int tile = 0; tile < ntile; ++tile) {
+        const int cur = tile & 1;
+        const int s0 = tile * 16;
+        HICOM_TR(0); HICOM_TR(1);   // tile: arrive [A]
+        lds_barrier();                                                 // [A] images of this tile landed; red free
+        HICOM_TR(0); HICOM_TR(1);   // tile: past [A]
+        const char* ffimg = ffbuf + cur * TILE_BYTES;
+        const char* feimg = febuf + cur * TILE_BYTES;
+
+        // window bookkeeping of this tile (wave-uniform)
+        int wr0 = (int)(((unsigned)s0 * wsz_magic) >> 16), i0 = s0 - wr0 * p.WSZ;
+        if (i0 < 0) { i0 += p.WSZ; wr0 -= 1; }
+        const int rowA = R + (wb + wr0) % NLOC;                        // local rows of the (at most two) windows in this tile
+        const int rowB = (rowA + 1 < 16) ? rowA + 1 : R;
+
+        // ---- logits, transposed: A = token rows of both images, B = the query fragments ---------------
+        bf16x8 bfe[K32], bff[K32];
+        bf16x4 bfe_t, bff_t;
+#pragma unroll
+        for (int s = 0; s < K32; ++s) {
+            const int cc = ((ch_base + 32 * s) >> 3) + kg;              // 16-byte chunk of this lane over the whole row
+            const int off = (cc >> 4) * 4096 + rd_row + 16 * ((cc & 15) ^ rd_swz);
+            bfe[s] = *reinterpret_cast<const bf16x8*>(feimg + off);
+            bff[s] = *reinterpret_cast<const bf16x8*>(ffimg + off);
+        }
+        if (KTAIL) {
+            const int cc = ((ch_base + 32 * K32) >> 3) + (kg >> 1);
+            const int off = (cc >> 4) * 4096 + rd_row + 16 * ((cc & 15) ^ rd_swz) + 8 * (kg & 1);
+            bfe_t = *reinterpret_cast<const bf16x4*>(feimg + off);
+            bff_t = *reinterpret_cast<const bf16x4*>(ffimg + off);
+        }
+        // score-side pos-emb of the R x 16 (row, token) pairs of this tile: a ninth "partial" of the exchange,
+        // two pairs per... one pair per lane on 2R lanes of every wave
+        if (p.pos_a && lane < 2 * R) {
+            const int q = wave * 2 * R + lane;                          // 0 .. 16 R - 1
+            const int row = q >> 4, pos = q & 15;
+            const int slot = 4 * fsig(pos >> 2) + (pos & 3);            // token slot held at exchange position `pos`
+            int oi = i0 + slot, owr = wr0;
+            if (oi >= p.WSZ) { oi -= p.WSZ; owr += 1; }
+            const int txy = win_txy[oi], base = wtxy[(s0 + slot < total) ? owr : 0];
+            const int f = (base >> 16) + (txy >> 16), y = ((base >> 8) & 255) + ((txy >> 8) & 255), x = (base & 255) + (txy & 255);
+            const float* ap = a_pos + row * (kMaxFramesPerWg + p.H + p.W);
+            red[kRingC * 256 + q] = ap[f] + ap[kMaxFramesPerWg + y] + ap[kMaxFramesPerWg + p.H + x];
+        }
+        f32x4 e0 = f32x4{0.f, 0.f, 0.f, 0.f}, f0 = e0, f1 = e0;
+#pragma unroll
+        for (int s = 0; s < K32; ++s) {
+            e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfe[s], ahi[s], e0, 0, 0, 0);
+            f0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bff[s], ahi[s], f0, 0, 0, 0);
+            f1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bff[s], alo[s], f1, 0, 0, 0);
+        }
+        if (KTAIL) {
+            e0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bfe_t, ahi_t, e0, 0, 0, 0);
+            f0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bff_t, ahi_t, f0, 0, 0, 0);
+            f1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bff_t, alo_t, f1, 0, 0, 0);
+        }
+        {
+            const f32x4 part_logit = (r16 < R) ? (f0 + f1) : e0;
+            *reinterpret_cast<f32x4*>(red + wave * 256 + r16 * 16 + 4 * kg) = part_logit;
+        }
+        HICOM_TR(0); HICOM_TR(1);   // tile: arrive [B]
+        lds_barrier();                                                 // [B] channel-slice partials exchanged
+        HICOM_TR(0); HICOM_TR(1);   // tile: past [B]
+
+        // ---- softmax of (row r16, 4 token slots) in registers, identically in every wave ---------------
+        f32x4 lg = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < kRingC; ++k) lg += *reinterpret_cast<const f32x4*>(red + k * 256 + r16 * 16 + 4 * kg);
+        if (p.pos_a && r16 < R) lg += *reinterpret_cast<const f32x4*>(red + kRingC * 256 + r16 * 16 + 4 * kg);
+        float pr[4];
+        float tmax = -1.0e30f;
+        bool valid[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = s0 + ts0 + j < total;
+            if (r16 < R) {
+                valid[j] = in;
+            } else {
+                const int row_of = (i0 + ts0 + j >= p.WSZ) ? rowB : rowA;
+                valid[j] = in && r16 == row_of;
+                lg[j] = lg[j] * p.l_scale + p.l_bias;
+            }
+            tmax = fmaxf(tmax, valid[j] ? lg[j] : -1.0e30f);
+        }
+        tmax = xrow4_max(tmax);
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = fast_exp(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pr[j] = valid[j] ? fast_exp(lg[j] - m_new) : 0.f;
+            psum += pr[j];
+        }
+        l_run = l_run * alpha + xrow4_sum(psum);
+        m_run = m_new;
+        // P as ONE K=32 A operand: k = 8 kg + u carries the hi plane of this lane's token u, k = 8 kg + 4 + u its
+        // lo plane; the B operand then holds the lane's 4 transposed x values twice.  One full-rate
+        // v_mfma_f32_16x16x32_bf16 per 16-channel block instead of two half-rate 16x16x16.
+        bf16x8 pw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint16_t h, l;
+            split_bf16(pr[j], h, l);
+            pw[j] = (short)h;
+            pw[4 + j] = (short)l;
+        }
+        // accumulator rows are indexed 4 kg + j: fetch their rescale factors through a wave-private LDS hop,
+        // only in the (rare, after the first tiles) case that some running max moved
+        f32x4 al = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (__any(alpha != 1.0f)) {
+            if (kg == 0) ascr[r16] = alpha;
+            al = *reinterpret_cast<const f32x4*>(ascr + 4 * kg);
+#pragma unroll
+            for (int cb = 0; cb < KS; ++cb) {
+                acc[cb][0] *= al[0]; acc[cb][1] *= al[1]; acc[cb][2] *= al[2]; acc[cb][3] *= al[3];
+            }
+        }
+        // ---- t / y / x marginals of the global weights, per window, as ONE more 16x16 MFMA tile:
+        // MG += P . onehot(bin of each token).  A tile touches at most two consecutive windows: wave 0
+        // accumulates the even-numbered one, wave 1 the odd one.  Rescaled by alpha like ACC, so a window's
+        // bins end up relative to the running max at its last tile, which is stored next to them.
+        if (p.part_marg && wave < 2) {
+            bf16x4 bm;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int i = i0 + ts0 + u;
+                const int second = i >= p.WSZ ? 1 : 0;
+                i -= second * p.WSZ;
+                const bool hit = ((win_bins[i] >> r16) & 1) != 0;
+                bm[u] = (hit && ((wr0 + second) & 1) == wave) ? (short)0x3F80 : (short)0;
+            }
+            const bf16x8 bm2 = bf16x8{bm[0], bm[1], bm[2], bm[3], bm[0], bm[1], bm[2], bm[3]};
+            const f32x4 mg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pw, bm2, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mgacc[j] = fmaf(mgacc[j], al[j], mg[j]);
+        }
+        // ---- ACC += P . x: all transposed fragment reads of the slice in flight, then the MFMAs ------------
+        {
+            const unsigned img_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(ffimg);
+            bf16x4 bv[KS];
+#pragma unroll
+            for (int u = 0; u < KS; ++u) {
+                const int ch0 = ch_base + 16 * u;
+                const unsigned addr = img_lds + (ch0 >> 7) * 4096 + tr_row_off + 16 * ((((ch0 & 127) >> 3) + (pp >> 1)) ^ tr_swz);
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(bv[u]) : "v"(addr));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < KS; ++u) {
+                const bf16x8 b2 = bf16x8{bv[u][0], bv[u][1], bv[u][2], bv[u][3], bv[u][0], bv[u][1], bv[u][2], bv[u][3]};
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pw, b2, acc[u], 0, 0, 0);
+            }
+        }
+
+        HICOM_TR(0); HICOM_TR(1);   // tile: P.x issued
+        // ---- a window completed in this tile: emit its local context, recycle its row ------------
+        if (i0 + 16 >= p.WSZ) {
+            const int w = wb + wr0;
+            const int row = __builtin_amdgcn_readfirstlane(rowA);
+            const float linv = 1.0f / __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l_run), row));
+            const int rk = row >> 2, rj = row & 3;
+            // The row sits in 16 lanes as KS values 16 channels apart.  A hop through a wave-private scratch
+            // inside red (idle between the softmax reads and the next [A]... see the barrier below) regroups it
+            // so that SLICE/4 lanes hold 4 consecutive channels each: one 16-byte (fp32) or 8-byte (bf16 plane)
+            // store per lane.
+            int lane_c = lane;                           // opaque copy: keeps this block's address math out of the loop-invariant registers
+            asm volatile("" : "+v"(lane_c));
+            // (two hops of <= kRegroup channels: the scratch has to fit beside the ring)
+            float* wsc = cscr + wave * kRegroup;
+#pragma unroll
+            for (int c0 = 0; c0 < KS; c0 += kRegroup / 16) {
+                constexpr int NBLK = kRegroup / 16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j == rj) {
+                        if (kg == rk) {
+#pragma unroll
+                            for (int c = 0; c < NBLK; ++c)
+                                if (c0 + c < KS) {
+                                    wsc[16 * c + r16] = acc[c0 + c][j] * linv;
+                                    acc[c0 + c][j] = 0.f;
+                                }
+                        }
+                    }
+                }
+                const int nch = (KS - c0 < NBLK ? KS - c0 : NBLK) * 16;        // channels of this hop
+                if (4 * lane_c < nch) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(wsc + 4 * lane_c);
+                    const long o = (long)w * E + ch_base + 16 * c0 + 4 * lane_c;
+                    if (p.ctx_local) *reinterpret_cast<f32x4*>(p.ctx_local + o) = v;
+                    if (p.ctx_hi) {
+                        uint16_t h[4], l[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) split_bf16(v[u], h[u], l[u]);
+                        *reinterpret_cast<uint2*>(p.ctx_hi + o) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+                        *reinterpret_cast<uint2*>(p.ctx_lo + o) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+                    }
+                }
+            }
+            if (p.part_marg) {
+                // the completed window's marginals (wave = its parity) and its reference max (wave 0, one lane per row)
+                float* o = p.part_marg + ((long)part * R * p.wpw + wr0) * kMargW;
+                const int r16c = lane_c & 15, kgc = lane_c >> 4;
+                if (wave == (wr0 & 1)) {
+                    if (r16c < kMargW - 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (4 * kgc + j < R) o[(4 * kgc + j) * p.wpw * kMargW + r16c] = mgacc[j];
+                    }
+                    mgacc = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                if (wave == 0 && kgc == 0 && r16c < R) o[r16c * p.wpw * kMargW + kMargW - 1] = m_run;
+            }
+            if (r16 == row) { m_run = -1.0e30f; l_run = 0.f; }   // every copy of the row's state is recycled
+        }
+    }
+
+    lds_barrier();                                                     // [E] loaders drained, every wave done with the ring
+    // ---- partial global state of this workgroup --------------------------------------------------
+    const long prow = (long)part * 16;
+    if (wave == 0 && kg == 0 && r16 < R) {
+        p.part_m[prow + r16] = m_run;
+        p.part_l[prow + r16] = l_run;
+    }
+    // The accumulator rows go out through the (now idle) ring, regrouped so that every lane stores 16
+    // contiguous bytes.
+    {
+        float* est = reinterpret_cast<float*>(smem) + wave * (R * SLICE);          // wave-private [R][SLICE]
+#pragma unroll
+        for (int cb = 0; cb < KS; ++cb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * kg + j < R) est[(4 * kg + j) * SLICE + 16 * cb + r16] = acc[cb][j];
+        const int n4 = R * (SLICE / 4);
+        for (int it = lane; it < n4; it += 64) {
+            const int row = it / (SLICE / 4), c4 = it - row * (SLICE / 4);
+            *reinterpret_cast<f32x4*>(p.part_acc + (prow + row) * E + ch_base + 4 * c4) = *reinterpret_cast<const f32x4*>(est + 4 * it);
+        }
+    }
+}
+
+}  // namespace hicom
+
+using namespace hicom;
+
+static int fused_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+#ifdef HICOM_TRACE
+extern "C" int hicom_debug_fused_trace(void* dst, int64_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(hicom::g_fused_trace), (size_t)bytes) == hipSuccess ? HICOM_OK : HICOM_ELAUNCH;
+}
+#endif
+
+extern "C" int hicom_fused_stream_nparts(int32_t n_windows) {
+    if (n_windows <= 0) return HICOM_EINVAL;
+    const int slots = fused_num_cus();                           // one resident workgroup per CU
+    int wpw = (n_windows + slots - 1) / slots;                   // equal windows per workgroup
+    if (wpw > kMaxWinPerWg) wpw = kMaxWinPerWg;
+    return (n_windows + wpw - 1) / wpw;
+}
+
+static size_t ring_lds_bytes(int rows, int H, int W) {
+    return (size_t)4 * 9 * 4096 + (size_t)(kRingC + 1) * 1024 + (size_t)kRingC * kRegroup * 4 + (size_t)kRingC * 64 +
+           (128 + kMaxWinPerWg) * 4 + (size_t)rows * (kMaxFramesPerWg + H + W) * 4;
+}
+
+extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T, int32_t H, int32_t W, int32_t E,
+                                      int32_t kt, int32_t ks, const void* q_hi, const void* q_lo, int32_t rows,
+                                      float l_scale, float l_bias, const float* pos_a, int32_t pos_stride,
+                                      int32_t t_index0, int32_t y_index0, int32_t x_index0,
+                                      float* part_m, float* part_l,
+                                      float* part_acc, float* part_marg, int32_t nparts, float* ctx_local, void* ctx_hi,
+                                      void* ctx_lo, void* stream) {
+    HICOM_REQUIRE(ff && fe && q_hi && q_lo && part_m && part_l && part_acc && (part_marg || !pos_a), HICOM_EINVAL,
+                  "fused_stream: NULL pointer");
+    HICOM_REQUIRE(ctx_local || (ctx_hi && ctx_lo), HICOM_EINVAL, "fused_stream: no local output");
+    HICOM_REQUIRE(E == 1152, HICOM_EUNSUP, "fused_stream: E=%d (only 1152)", E);
+    HICOM_REQUIRE(T > 0 && H > 0 && W > 0 && kt > 0 && ks > 0 && T % kt == 0 && H % ks == 0 && W % ks == 0, HICOM_EUNSUP,
+                  "fused_stream: windows must partition the [%d,%d,%d] grid exactly", T, H, W);
+    const int wsz = kt * ks * ks;
+    HICOM_REQUIRE(wsz >= 16 && wsz <= 64, HICOM_EUNSUP, "fused_stream: window of %d tokens (16..64 supported)", wsz);
+    HICOM_REQUIRE(rows > 0 && rows <= 14, HICOM_EUNSUP, "fused_stream: %d global rows (<= 14: >= 2 local rows needed)", rows);
+    HICOM_REQUIRE(H < 256 && W < 256 && (long)T * H * W < (1L << 31), HICOM_EUNSUP, "fused_stream: grid too large");
+    const int NW = (T / kt) * (H / ks) * (W / ks);
+    HICOM_REQUIRE(nparts > 0 && nparts <= NW, HICOM_EINVAL, "fused_stream: nparts");
+    const int wpw = (NW + nparts - 1) / nparts;
+    HICOM_REQUIRE(wpw <= kMaxWinPerWg && (long)(nparts - 1) * wpw < NW, HICOM_EINVAL,
+                  "fused_stream: nparts=%d gives %d windows per workgroup (max %d, no empty workgroup)", nparts, wpw, kMaxWinPerWg);
+    // frames a workgroup may touch: the t-groups its windows span
+    const int per_t = (H / ks) * (W / ks);
+    const int span = (wpw + per_t - 2) / per_t + 1;
+    HICOM_REQUIRE(span * kt <= kMaxFramesPerWg, HICOM_EUNSUP, "fused_stream: a workgroup would span %d frames", span * kt);
+    HICOM_REQUIRE(kt + 2 * ks <= kMargW - 1, HICOM_EUNSUP, "fused_stream: window %dx%dx%d exceeds the marginal bin width", kt, ks, ks);
+    HICOM_REQUIRE(rows * (kMaxFramesPerWg + H + W) <= 64 * kRingC * kPosPerThread, HICOM_EUNSUP, "fused_stream: pos-emb table too large");
+    const size_t smem = ring_lds_bytes(rows, H, W);
+    HICOM_REQUIRE(smem <= 163840, HICOM_EUNSUP, "fused_stream: H + W = %d does not fit the LDS budget", H + W);
+    RingParams p;
+    p.ff = (const uint16_t*)ff; p.fe = (const uint16_t*)fe; p.T = T; p.H = H; p.W = W;
+    p.kt = kt; p.ks = ks; p.nwy = H / ks; p.nwx = W / ks; p.NW = NW; p.WSZ = wsz;
+    p.qhi = (const uint16_t*)q_hi; p.qlo = (const uint16_t*)q_lo; p.R = rows;
+    p.l_scale = l_scale; p.l_bias = l_bias;
+    p.pos_a = pos_a; p.pos_stride = pos_stride; p.t0i = t_index0; p.y0i = y_index0; p.x0i = x_index0;
+    p.part_m = part_m; p.part_l = part_l; p.part_acc = part_acc; p.part_marg = part_marg;
+    p.ctx_local = ctx_local; p.ctx_hi = (uint16_t*)ctx_hi; p.ctx_lo = (uint16_t*)ctx_lo; p.wpw = wpw;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HICOM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_ring_kernel<9>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 163840) == hipSuccess,
+                      HICOM_ELAUNCH, "fused_stream: 160 KiB of LDS per workgroup not available");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fused_ring_kernel<9>, dim3((unsigned)nparts), dim3(kRingThreads), smem, (hipStream_t)stream, p);
+    return hicom_host::check_launch("fused_stream");
+}

@@ -1,7 +1,8 @@
-"""Dev tool: phase timeline of fused_stream_kernel from in-kernel s_memtime stamps.
+"""Dev tool: phase timeline of fused_ring_kernel from in-kernel s_memtime stamps.
 
 Builds a second library with -DHICOM_TRACE (never the product one), runs the C2 shape, and prints for every
-phase the distribution over workgroups.  Usage on the GPU box:  python tools/fused_trace.py
+phase the distribution over workgroups (ticks = shader cycles; clocks of different CUs are not synchronised).
+Usage on the GPU box:  python tools/fused_trace.py
 """
 import ctypes, math, os, subprocess, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -32,33 +33,42 @@ torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record(); run(); b.record(); torch.cuda.synchronize()
 print("kernel (events, incl. launch) %.1f us, nparts %d, windows/wg %d" % (a.elapsed_time(b) * 1e3, nparts, wpw))
-buf = np.zeros(1024 * 128, dtype=np.uint64)
+buf = np.zeros(1024 * 3 * 256, dtype=np.uint64)
 L = nv.lib()
 L.hicom_debug_fused_trace.argtypes = [ctypes.c_void_p, ctypes.c_int64]
 assert L.hicom_debug_fused_trace(buf.ctypes.data, buf.nbytes) == 0
-tr = buf.reshape(1024, 128)[:nparts].astype(np.int64)
+tr = buf.reshape(1024, 3, 256)[:nparts].astype(np.int64)
 ntile = (wpw * 36 + 15) // 16
-n = 3 + 5 * ntile + 2
-t0 = tr[:, 0].min()
-span = tr[:, n - 1].max() - t0
-print("stamps per wg %d (tiles %d); span first start -> last end: %d ticks" % (n, ntile, span))
-tick_us = float(os.environ.get("TICK_US", 1.0))      # printed in raw s_memtime ticks (~core clock cycles; not synchronised across CUs)
 def stat(name, d):
-    print("%-34s mean %7.0f  p10 %7.0f  p50 %7.0f  p90 %7.0f  max %7.0f ticks" % (name, d.mean() * tick_us, np.percentile(d, 10) * tick_us,
-          np.percentile(d, 50) * tick_us, np.percentile(d, 90) * tick_us, d.max() * tick_us))
-full = tr[(tr[:, n - 1] > 0)]
-stat("wg start (after first wg)", full[:, 0] - t0)
-stat("prologue: issue requests", full[:, 1] - full[:, 0])
-stat("prologue: tables", full[:, 2] - full[:, 1])
+    print("%-40s mean %7.0f  p10 %7.0f  p50 %7.0f  p90 %7.0f  max %7.0f" % (name, d.mean(), np.percentile(d, 10), np.percentile(d, 50), np.percentile(d, 90), d.max()))
+for who, label in ((0, "compute wave 0 (marginals)"), (1, "compute wave 2")):
+    c = tr[:, who, who::2]          # both stamp macros advance the slot counter: wave 0 owns the even slots, wave 2 the odd ones
+    print("---- %s: 1 + 5 stamps per tile" % label)
+    names = ["wait at [A]", "reads+scores ([A]->arrive B)", "wait at [B]", "softmax+marg+P.x", "completion -> arrive next [A]"]
+    agg = {n: [] for n in names}
+    for t in range(ntile):
+        b0 = 1 + 5 * t
+        seg = [c[:, b0 + 1] - c[:, b0], c[:, b0 + 2] - c[:, b0 + 1], c[:, b0 + 3] - c[:, b0 + 2], c[:, b0 + 4] - c[:, b0 + 3]]
+        if t + 1 < ntile:
+            seg.append(c[:, b0 + 5] - c[:, b0 + 4])
+        for n, d in zip(names, seg):
+            agg[n].append(d)
+    for n in names:
+        stat(n + " (all tiles)", np.concatenate(agg[n]))
+    stat("tile 0: wait at [A] (first data)", c[:, 2] - c[:, 1])
+    stat("loop total (first [A] arrive -> last P.x)", c[:, 1 + 5 * (ntile - 1) + 4] - c[:, 1])
+c = tr[:, 2]
+print("---- loader 0: 1 + 6 stamps per tile")
+names = ["addr -> landed (vmcnt wait)", "wait at [A]", "issue ff(t+1)", "wait at [B]", "issue fe(t+2)", "next addr math"]
+agg = {n: [] for n in names}
 for t in range(ntile):
-    base = 3 + 5 * t
-    prev = full[:, base - 1]
-    stat("tile %d wait data  (-> [A])" % t, full[:, base] - prev)
-    stat("tile %d scores     ([A]->[B])" % t, full[:, base + 1] - full[:, base])
-    stat("tile %d softmax    ([B]->[C])" % t, full[:, base + 2] - full[:, base + 1])
-    stat("tile %d P.x        ([C]->   )" % t, full[:, base + 3] - full[:, base + 2])
-    stat("tile %d completion          " % t, full[:, base + 4] - full[:, base + 3])
-stat("final drain", full[:, n - 2] - full[:, n - 3])
-stat("epilogue issue", full[:, n - 1] - full[:, n - 2])
-stat("wg total", full[:, n - 1] - full[:, 0])
-stat("wg end (after first start)", full[:, n - 1] - t0)
+    b0 = 1 + 6 * t
+    seg = [c[:, b0 + 1] - c[:, b0], c[:, b0 + 2] - c[:, b0 + 1], c[:, b0 + 3] - c[:, b0 + 2], c[:, b0 + 4] - c[:, b0 + 3], c[:, b0 + 5] - c[:, b0 + 4]]
+    if t + 1 < ntile:
+        seg.append(c[:, b0 + 6] - c[:, b0 + 5])
+    for n, d in zip(names, seg):
+        agg[n].append(d)
+for n in names:
+    stat(n + " (all tiles)", np.concatenate(agg[n]))
+stat("tile 0: vmcnt wait (first data)", c[:, 2] - c[:, 1])
+stat("loader total", c[:, 1 + 6 * (ntile - 1) + 5] - c[:, 0])
