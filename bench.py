@@ -202,14 +202,16 @@ def dominant_kernel_roofline(module, ff, fe, guide, iters):
     qlo[R:] = 0
     pos_a = torch.randn(16, T + H + W, device=dev) * 0.1
     nparts = nv.fused_stream_nparts(nw)
-    marg = torch.empty(nparts, R, (nw + nparts - 1) // nparts, 12, device=dev)
+    pe = torch.randn(T + H + W, D, device=dev)
+    pe_hi = pe.to(torch.bfloat16)
+    pe_lo = (pe - pe_hi.float()).to(torch.bfloat16)
     pm, pl = torch.empty(nparts, 16, device=dev), torch.empty(nparts, 16, device=dev)
     pacc = torch.empty(nparts, 16, D, device=dev)
     chi = torch.empty(nw, D, device=dev, dtype=torch.bfloat16)
     clo = torch.empty_like(chi)
 
     def launch():
-        nv.fused_stream(ff, fe, at.k, ay.k, qhi, qlo, R, 1.0 / D ** 0.5, 0.0, pos_a, 0, T, T + H, pm, pl, pacc, marg, None, chi, clo)
+        nv.fused_stream(ff, fe, at.k, ay.k, qhi, qlo, R, 1.0 / D ** 0.5, 0.0, pos_a, pe_hi, pe_lo, 0, T, T + H, pm, pl, pacc, None, chi, clo)
 
     stream = torch.cuda.current_stream()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]

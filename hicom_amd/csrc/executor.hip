@@ -23,7 +23,7 @@ namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct WsLayout {
-    size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, qp, qhi, qlo, pos_a, scores, part_m, part_l, part_acc, part_marg, scratch, ml, acc,
+    size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, qp, qhi, qlo, pos_a, scores, part_m, part_l, part_acc, scratch, ml, acc,
         ctx_g, o, qres, pre, hid_g, tok, total;
     int nw, R, rows_pad, nparts, P;
     long N, score_stride;
@@ -40,7 +40,7 @@ bool can_fuse(const hicom_compressor_args& a) {
     const int wsz = a.at.k * a.ay.k * a.ax.k;
     if (wsz < 16 || wsz > 64 || a.H >= 256 || a.W >= 256) return false;
     const int R = a.nq * a.nh;
-    if (a.at.k + 2 * a.ay.k > 11) return false;              // marginal bins of the fused kernel
+    if (8 + a.H + a.W > 64) return false;                    // pos-emb slots of the fused kernel (4 tiles of 16)
     const int nw = a.at.nwin * a.ay.nwin * a.ax.nwin, per_t = a.ay.nwin * a.ax.nwin;
     const int nparts = hicom_fused_stream_nparts(nw);
     const int wpw = (nw + nparts - 1) / nparts;
@@ -82,7 +82,6 @@ WsLayout make_layout(const hicom_compressor_args& a) {
         w.part_m = take((size_t)w.nparts * w.rows_pad * 4);
         w.part_l = take((size_t)w.nparts * w.rows_pad * 4);
         w.part_acc = take((size_t)w.nparts * w.rows_pad * a.E * 4);
-        w.part_marg = take(can_fuse(a) ? (size_t)w.nparts * w.R * ((w.nw + w.nparts - 1) / w.nparts) * 12 * 4 : 0);
         w.scratch = take((size_t)w.R * a.T * (a.H + a.W + 2) * 4);
         w.ml = take((size_t)w.R * 2 * 4);
         w.acc = take((size_t)w.R * a.E * 4);
@@ -187,14 +186,13 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         // main: readout GEMMs            side: merge -> (finish)                 | join |
         CHK(query_prep(sm, true));
         CHK(hicom_fused_stream_fwd(a.ff, a.fe ? a.fe : a.ff, a.T, a.H, a.W, a.E, a.at.k, a.ay.k, ws + w.qhi, ws + w.qlo,
-                                   w.R, a.l_scale, a.l_bias, a.pe ? F(w.pos_a) : nullptr, a.P, a.t_index0, a.y_index0,
+                                   w.R, a.l_scale, a.l_bias, a.pe ? F(w.pos_a) : nullptr, a.P, a.pe ? a.pe_hi : nullptr, a.pe ? a.pe_lo : nullptr, a.t_index0, a.y_index0,
                                    a.x_index0, F(w.part_m), F(w.part_l), F(w.part_acc),
-                                   a.pe ? F(w.part_marg) : nullptr, w.nparts, nullptr, ws + w.ctx_hi, ws + w.ctx_lo, sm));
+                                   w.nparts, nullptr, ws + w.ctx_hi, ws + w.ctx_lo, sm));
         CHK(fork());
-        // value-side pos-emb from the kernel's own per-window marginals: one merge launch, no score buffer
-        CHK(hicom_global_merge_windows_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), a.pe ? F(w.part_marg) : nullptr,
-                                           w.nparts, w.R, a.E, a.T, a.H, a.W, a.at.k, a.ay.k, a.pe, a.t_index0,
-                                           a.y_index0, a.x_index0, ml_out, acc_out, solo ? 1 : 0, ss));
+        // the value-side pos-emb is already inside the partial contexts: a plain merge, one launch
+        CHK(hicom_global_merge_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E, nullptr, 0, w.N,
+                                   a.H, a.W, nullptr, 0, 0, 0, nullptr, ml_out, acc_out, solo ? 1 : 0, ss));
         // readout MLP on bf16 planes: contexts (hi/lo) -> hidden (hi/lo) -> packed output rows
         CHK(hicom_planes_gemm_fwd(ws + w.ctx_hi, ws + w.ctx_lo, a.lw0, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E,
                                   HICOM_ACT_GELU, ws + w.hid_hi, ws + w.hid_lo, nullptr, 0, 0, 0, 0, sm));

@@ -56,7 +56,7 @@ constexpr int kMaxFramesPerWg = 8;
 constexpr int kPosPerThread = 2;          // score-side pos-emb entries fetched per compute thread: rows * (8 + H + W) <= 1024
 constexpr int kPStride = 32;              // halfwords between rows of the softmax-weight planes (they live in red[0]'s rows)
 constexpr int kRegroup = 80;               // channels per hop of the completed-row regroup (multiple of 16)
-constexpr int kMargW = 12;                // per (row, window): kt + 2 ks <= 11 marginal bins + the reference max in slot 11
+constexpr int kPosImages = 8;              // ring images of the value-side pos-emb pass: up to 4 slot tiles x (hi, lo) planes
 
 struct RingParams {
     const uint16_t* ff;
@@ -72,7 +72,8 @@ struct RingParams {
     float* part_m;
     float* part_l;
     float* part_acc;       // [nparts][16][E], rows < R
-    float* part_marg;      // [nparts][R][wpw][kMargW] per-window t / y / x marginals of the global weights, or NULL
+    const uint16_t* pe_hi; // [P][E] bf16 hi / lo planes of the per-axis sinusoid tables (value-side pos-emb), or NULL
+    const uint16_t* pe_lo;
     float* ctx_local;      // [NW][E] fp32 window contexts (may be NULL)
     uint16_t* ctx_hi;      // [NW][E] the same as bf16 hi / lo planes for hicom_planes_gemm_fwd (may be NULL)
     uint16_t* ctx_lo;
@@ -102,8 +103,7 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
     float* cscr = red + (kRingC + 1) * 256;                                  // [kRingC][kRegroup] wave-private regroup scratch of a completed row
     float* alpha_s = cscr + kRingC * kRegroup;                            // [kRingC][16] wave-private rescale factors in accumulator-row order
     int* win_txy = reinterpret_cast<int*>(alpha_s + kRingC * 16);   // [64] packed in-window coords (t2 << 16 | h2 << 8 | w2)
-    int* win_bins = win_txy + 64;                                      // [64] marginal bins of an in-window token: bit t2 | bit kt+h2 | bit kt+ks+w2
-    int* wtxy = win_bins + 64;                                          // [kMaxWinPerWg] packed window base coords (frame offset << 16 | y0 << 8 | x0)
+    int* wtxy = win_txy + 64;                                          // [kMaxWinPerWg] packed window base coords (frame offset << 16 | y0 << 8 | x0)
     float* a_pos = reinterpret_cast<float*>(wtxy + kMaxWinPerWg);      // [R][kMaxFramesPerWg | H | W] score-side pos-emb per row
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -118,6 +118,7 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
     const int R = p.R, NLOC = 16 - R;
     const int ks2 = p.ks * p.ks, per_t = p.nwy * p.nwx;
     const unsigned wsz_magic = (65536u + p.WSZ - 1) / p.WSZ;    // s / WSZ by multiply-shift: exact for s < 2^16
+    const int nslot_tiles = (kMaxFramesPerWg + p.H + p.W + 15) >> 4;   // 16-slot tiles of the pos-emb marginals (<= kPosImages / 2)
 
     // =========================================================================================
     // LOADER waves
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
         const int l = wave - kRingC;
         const int row = 4 * l + (lane >> 4), cpos = lane & 15;          // token slot of this lane, 16-byte chunk in the row
         const int lane_off = 16 * (cpos ^ fswz(row));
+        const int t1_first_l = wb / per_t;
         // stream slot -> byte offset of the token row (clamped past the end: harmless re-requests)
         auto src_off = [&](int tile) -> long {
             int s = tile * 16 + row;
@@ -170,6 +172,35 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
             o_ff = o_fe;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the clamped requests past the end
+        __builtin_amdgcn_s_barrier();                                  // [M] ring idle, marginals tabled
+        if (p.pe_hi) {
+            // value-side pos-emb pass: the pe rows of slot tile b travel through the 4 ring slots exactly like
+            // token rows (image n = 2 b + plane); up to three images run ahead of the one being consumed.
+            auto pe_off = [&](int n) -> long {
+                const int s = 16 * (n >> 1) + row;                      // slot: frame | grid row | grid column | padding
+                const int t = t1_first_l * p.kt + s;
+                int prow = s < kMaxFramesPerWg ? p.t0i + (t < p.T ? t : p.T - 1)
+                                               : (s < kMaxFramesPerWg + p.H ? p.y0i + (s - kMaxFramesPerWg)
+                                                                            : p.x0i + min(s - kMaxFramesPerWg - p.H, p.W - 1));
+                return (long)prow * (long)(E * 2) + lane_off;
+            };
+            const int nimg = 2 * nslot_tiles;
+#pragma unroll
+            for (int n = 0; n < 3; ++n)
+                if (n < nimg) issue((n & 1) ? p.pe_lo : p.pe_hi, pe_off(n), smem + n * TILE_BYTES);
+#pragma unroll
+            for (int n = 0; n < kPosImages; ++n) {
+                if (n < nimg) {
+                    // issued so far: images 0 .. min(nimg - 1, n + 2); the younger ones may stay in flight
+                    const int younger = min(nimg - 1, n + 2) - n;
+                    if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * PPL) : "memory");
+                    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PPL) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                      // [X_n] image n published; slot of image n-1 released
+                    if (n + 3 < nimg) issue(((n + 3) & 1) ? p.pe_lo : p.pe_hi, pe_off(n + 3), smem + ((n + 3) & 3) * TILE_BYTES);
+                }
+            }
+        }
         __builtin_amdgcn_s_barrier();                                  // [E] ring idle
         return;
     }
@@ -202,7 +233,6 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
     if (ctid < p.WSZ) {
         const int t2 = ctid / ks2, r = ctid - t2 * ks2, h2 = r / p.ks, w2 = r - h2 * p.ks;
         win_txy[ctid] = (t2 << 16) | (h2 << 8) | w2;
-        win_bins[ctid] = (1 << t2) | (1 << (p.kt + h2)) | (1 << (p.kt + p.ks + w2));
     }
     if (ctid < nwin) {
         const int w = wb + ctid;
@@ -232,7 +262,7 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
     // with (row r16, token slots 4*sig(kg) .. +3) -- exactly the A-operand layout of P for the P.x MFMAs.
     // The softmax therefore runs in registers in all waves at once: no shared P, no third barrier.
     float m_run = -1.0e30f, l_run = 0.f;
-    f32x4 mgacc = f32x4{0.f, 0.f, 0.f, 0.f};   // waves 0 / 1: marginals (rows 4 kg + j, bin r16) of the even / odd window in flight
+    f32x4 mgacc = f32x4{0.f, 0.f, 0.f, 0.f};   // waves < nslot_tiles: marginals (rows 4 kg + j, slot 16 wave + r16) of the global weights
 
     const int q4 = (lane >> 2) & 3, pp = lane & 3;
     const int trow = 4 * fsig(kg) + q4;
@@ -363,19 +393,22 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
                 acc[cb][0] *= al[0]; acc[cb][1] *= al[1]; acc[cb][2] *= al[2]; acc[cb][3] *= al[3];
             }
         }
-        // ---- t / y / x marginals of the global weights, per window, as ONE more 16x16 MFMA tile:
-        // MG += P . onehot(bin of each token).  A tile touches at most two consecutive windows: wave 0
-        // accumulates the even-numbered one, wave 1 the odd one.  Rescaled by alpha like ACC, so a window's
-        // bins end up relative to the running max at its last tile, which is stored next to them.
-        if (p.part_marg && wave < 2) {
+        // ---- value-side pos-emb, part 1 (reference projector.py:57-101 with :176-179): the context of a row is
+        // sum_n p_n (x_n + pe_t[t_n] + pe_y[y_n] + pe_x[x_n]).  The pe part only needs the t / y / x MARGINALS of
+        // the weights: MG += P . onehot(slot of each token) over the slots  frame (relative to this workgroup's
+        // first frame) | grid row | grid column -- one more MFMA per tile on the wave that owns the 16-slot
+        // block.  Rescaled by alpha like ACC.  Part 2 (after the stream) multiplies MG by the pe rows.
+        if (p.pe_hi && wave < nslot_tiles) {
+            const int col = 16 * wave + r16;
             bf16x4 bm;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                int i = i0 + ts0 + u;
-                const int second = i >= p.WSZ ? 1 : 0;
-                i -= second * p.WSZ;
-                const bool hit = ((win_bins[i] >> r16) & 1) != 0;
-                bm[u] = (hit && ((wr0 + second) & 1) == wave) ? (short)0x3F80 : (short)0;
+                int i = i0 + ts0 + u, wr = wr0;
+                if (i >= p.WSZ) { i -= p.WSZ; wr += 1; }
+                const int txy = win_txy[i], base = wtxy[(s0 + ts0 + u < total) ? wr : 0];
+                const int f = (base >> 16) + (txy >> 16), y = ((base >> 8) & 255) + ((txy >> 8) & 255), x = (base & 255) + (txy & 255);
+                const bool hit = col == f || col == kMaxFramesPerWg + y || col == kMaxFramesPerWg + p.H + x;
+                bm[u] = hit ? (short)0x3F80 : (short)0;
             }
             const bf16x8 bm2 = bf16x8{bm[0], bm[1], bm[2], bm[3], bm[0], bm[1], bm[2], bm[3]};
             const f32x4 mg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pw, bm2, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -446,25 +479,55 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
                     }
                 }
             }
-            if (p.part_marg) {
-                // the completed window's marginals (wave = its parity) and its reference max (wave 0, one lane per row)
-                float* o = p.part_marg + ((long)part * R * p.wpw + wr0) * kMargW;
-                const int r16c = lane_c & 15, kgc = lane_c >> 4;
-                if (wave == (wr0 & 1)) {
-                    if (r16c < kMargW - 1) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (4 * kgc + j < R) o[(4 * kgc + j) * p.wpw * kMargW + r16c] = mgacc[j];
-                    }
-                    mgacc = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-                if (wave == 0 && kgc == 0 && r16c < R) o[r16c * p.wpw * kMargW + kMargW - 1] = m_run;
-            }
             if (r16 == row) { m_run = -1.0e30f; l_run = 0.f; }   // every copy of the row's state is recycled
         }
     }
 
-    lds_barrier();                                                     // [E] loaders drained, every wave done with the ring
+    lds_barrier();                                                     // [M] loaders drained, every wave done with the ring
+    if (p.pe_hi) {
+        // ---- value-side pos-emb, part 2: ACC += MG . pe, as P.x steps over images of pe rows.  MG (fp32, in the
+        // accumulator layout of the waves that own the slot blocks) is tabled in LDS ([slot][row], in `red`) and
+        // re-read in the A-operand layout; hi + lo planes of MG against hi and lo planes of pe.
+        float* mgs = red;                                              // [64 slots][16 rows]  (red: 9 x 256 floats)
+        if (wave < nslot_tiles) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mgs[(16 * wave + r16) * 16 + 4 * kg + j] = (4 * kg + j < R) ? mgacc[j] : 0.f;
+        }
+        lds_barrier();                                                 // [X_0] table complete, image 0 landed
+        const int nimg = 2 * nslot_tiles;
+        bf16x8 pwp = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int n = 0; n < kPosImages; ++n) {
+            if (n < nimg) {
+                if (n > 0) lds_barrier();                              // [X_n]
+                if ((n & 1) == 0) {                                    // new slot tile: its marginals as the A operand
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        uint16_t h, l;
+                        split_bf16(mgs[(16 * (n >> 1) + ts0 + u) * 16 + r16], h, l);
+                        pwp[u] = (short)h;
+                        pwp[4 + u] = (short)l;
+                    }
+                }
+                const unsigned img_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(smem + (n & 3) * TILE_BYTES);
+                bf16x4 bv[KS];
+#pragma unroll
+                for (int u = 0; u < KS; ++u) {
+                    const int ch0 = ch_base + 16 * u;
+                    const unsigned addr = img_lds + (ch0 >> 7) * 4096 + tr_row_off + 16 * ((((ch0 & 127) >> 3) + (pp >> 1)) ^ tr_swz);
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(bv[u]) : "v"(addr));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < KS; ++u) {
+                    const bf16x8 b2 = bf16x8{bv[u][0], bv[u][1], bv[u][2], bv[u][3], bv[u][0], bv[u][1], bv[u][2], bv[u][3]};
+                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pwp, b2, acc[u], 0, 0, 0);
+                }
+            }
+        }
+    }
+    lds_barrier();                                                     // [E] every wave done with the ring
     // ---- partial global state of this workgroup --------------------------------------------------
     const long prow = (long)part * 16;
     if (wave == 0 && kg == 0 && r16 < R) {
@@ -525,11 +588,12 @@ static size_t ring_lds_bytes(int rows, int H, int W) {
 extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T, int32_t H, int32_t W, int32_t E,
                                       int32_t kt, int32_t ks, const void* q_hi, const void* q_lo, int32_t rows,
                                       float l_scale, float l_bias, const float* pos_a, int32_t pos_stride,
+                                      const void* pe_hi, const void* pe_lo,
                                       int32_t t_index0, int32_t y_index0, int32_t x_index0,
                                       float* part_m, float* part_l,
-                                      float* part_acc, float* part_marg, int32_t nparts, float* ctx_local, void* ctx_hi,
+                                      float* part_acc, int32_t nparts, float* ctx_local, void* ctx_hi,
                                       void* ctx_lo, void* stream) {
-    HICOM_REQUIRE(ff && fe && q_hi && q_lo && part_m && part_l && part_acc && (part_marg || !pos_a), HICOM_EINVAL,
+    HICOM_REQUIRE(ff && fe && q_hi && q_lo && part_m && part_l && part_acc && ((pe_hi && pe_lo) || !pos_a) && (pos_a || !pe_hi), HICOM_EINVAL,
                   "fused_stream: NULL pointer");
     HICOM_REQUIRE(ctx_local || (ctx_hi && ctx_lo), HICOM_EINVAL, "fused_stream: no local output");
     HICOM_REQUIRE(E == 1152, HICOM_EUNSUP, "fused_stream: E=%d (only 1152)", E);
@@ -548,7 +612,7 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T,
     const int per_t = (H / ks) * (W / ks);
     const int span = (wpw + per_t - 2) / per_t + 1;
     HICOM_REQUIRE(span * kt <= kMaxFramesPerWg, HICOM_EUNSUP, "fused_stream: a workgroup would span %d frames", span * kt);
-    HICOM_REQUIRE(kt + 2 * ks <= kMargW - 1, HICOM_EUNSUP, "fused_stream: window %dx%dx%d exceeds the marginal bin width", kt, ks, ks);
+    HICOM_REQUIRE(kMaxFramesPerWg + H + W <= 16 * (kPosImages / 2), HICOM_EUNSUP, "fused_stream: H + W = %d exceeds the pos-emb slots", H + W);
     HICOM_REQUIRE(rows * (kMaxFramesPerWg + H + W) <= 64 * kRingC * kPosPerThread, HICOM_EUNSUP, "fused_stream: pos-emb table too large");
     const size_t smem = ring_lds_bytes(rows, H, W);
     HICOM_REQUIRE(smem <= 163840, HICOM_EUNSUP, "fused_stream: H + W = %d does not fit the LDS budget", H + W);
@@ -558,7 +622,7 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T,
     p.qhi = (const uint16_t*)q_hi; p.qlo = (const uint16_t*)q_lo; p.R = rows;
     p.l_scale = l_scale; p.l_bias = l_bias;
     p.pos_a = pos_a; p.pos_stride = pos_stride; p.t0i = t_index0; p.y0i = y_index0; p.x0i = x_index0;
-    p.part_m = part_m; p.part_l = part_l; p.part_acc = part_acc; p.part_marg = part_marg;
+    p.part_m = part_m; p.part_l = part_l; p.part_acc = part_acc; p.pe_hi = (const uint16_t*)pe_hi; p.pe_lo = (const uint16_t*)pe_lo;
     p.ctx_local = ctx_local; p.ctx_hi = (uint16_t*)ctx_hi; p.ctx_lo = (uint16_t*)ctx_lo; p.wpw = wpw;
     static bool attr_set = false;
     if (!attr_set) {

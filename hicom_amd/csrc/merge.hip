@@ -57,8 +57,6 @@ struct MergeCtxParams {
     const float* part_acc;
     int nparts, rows_pad, E;
     const float* scratch;   // frame marginals (two-kernel path) or NULL
-    const float* part_marg; // [nparts][rows][wpw][kMargW] per-window marginals from the fused kernel, or NULL
-    int wpw, kt, ks, nwy, nwx, NW;
     const float* pe;
     int T, H, W, t0i, y0i, x0i;
     float* out_ml;
@@ -81,19 +79,16 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-constexpr int kMargW = 12;   // must match fused_stream.hip
-constexpr int kMergeChunk = 16128;   // floats of marginals staged in LDS per pass (63 KiB; a multiple of 12 * 4)
 constexpr int kTC = 64;   // frames of marginals staged in LDS per pass (one pass for T <= 64)
 
 __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
-    // LDS: [16*64] column partials | [marginal chunk] | [4] | [nparts] partial weights | [T] frame weights |
+    // LDS: [16*64] column partials | [4] | [nparts] partial weights | [T] frame weights |
     //      [T+H+W] positional weights | [kTC * S] staged marginals
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int r = blockIdx.x, tid = threadIdx.x;
     const int S = p.H + p.W + 2, HW2 = p.H + p.W;
     float* cred = wsm;                                   // 16-byte aligned: float4 stores
-    float* chunk = cred + 16 * 64;                       // [kMergeChunk] staged window marginals (fused path only), 16-byte aligned
-    float* red = chunk + (p.part_marg ? kMergeChunk : 0);
+    float* red = cred + 16 * 64;
     float* wp = red + 4;
     float* wt = wp + p.nparts;
     float* wpos = wt + p.T;
@@ -131,63 +126,8 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
     }
     const float L = block_reduce_sum(l, red);
 
-    const bool has_pos = sc != nullptr || p.part_marg != nullptr;
-    if (p.part_marg) {
-        // positional weights from the per-window marginals of the fused kernel.  Row r's marginals are
-        // copied to LDS in coalesced chunks (window-major: partial i holds windows i*wpw ..), each window's
-        // bins are relative to its own reference max (slot kMargW-1), which becomes e^(ref - M) in place.
-        // Every t / y / x slot then sums its windows in a fixed order (SUB threads per slot, combined in
-        // order): run-to-run deterministic, no atomics.
-        float* psum = tile;                              // [max(256, nslots)]
-        const int per_part = p.wpw * kMargW, nt = p.T / p.kt;
-        const int parts_per_chunk = kMergeChunk / per_part;
-        const int nslots = p.T + HW2, SUB = nslots < 256 ? 256 / nslots : 1;
-        const unsigned q4_magic = ((1u << 24) + per_part / 4 - 1) / (per_part / 4);
-        for (int item = tid; item < nslots * SUB; item += 256) psum[item] = 0.f;
-        for (int i_lo = 0; i_lo < p.nparts; i_lo += parts_per_chunk) {
-            const int i_hi = min(p.nparts, i_lo + parts_per_chunk);
-            const int w_lo = i_lo * p.wpw, w_hi = min(p.NW, i_hi * p.wpw);
-            __syncthreads();
-            // coalesced copy: partial i contributes per_part contiguous floats (16-byte aligned)
-            const int n4 = (i_hi - i_lo) * (per_part / 4);
-            for (int e = tid; e < n4; e += 256) {
-                const int i = (int)(((unsigned long long)(unsigned)e * q4_magic) >> 24), k4 = e - i * (per_part / 4);
-                reinterpret_cast<float4*>(chunk)[e] =
-                    *reinterpret_cast<const float4*>(p.part_marg + ((long)(i_lo + i) * gridDim.x + r) * per_part + 4 * k4);
-            }
-            __syncthreads();
-            for (int w = w_lo + tid; w < w_hi; w += 256) {
-                float* ref = chunk + (w - w_lo) * kMargW + (kMargW - 1);
-                *ref = expf(*ref - M);
-            }
-            __syncthreads();
-            for (int item = tid; item < nslots * SUB; item += 256) {
-                const int j = item / SUB, k = item - j * SUB;
-                int base, so, no, si, ni, b;        // w = base + o * so + i * si, o = k, k+SUB, .. < no, i < ni
-                if (j < p.T) { base = (j / p.kt) * p.nwy * p.nwx; b = j % p.kt; so = p.nwx; no = p.nwy; si = 1; ni = p.nwx; }
-                else if (j < p.T + p.H) { const int y = j - p.T; base = (y / p.ks) * p.nwx; b = p.kt + y % p.ks; so = p.nwy * p.nwx; no = nt; si = 1; ni = p.nwx; }
-                else { const int x = j - p.T - p.H; base = x / p.ks; b = p.kt + p.ks + x % p.ks; so = p.nwy * p.nwx; no = nt; si = p.nwx; ni = p.nwy; }
-                float a = psum[item];
-                for (int o = k; o < no; o += SUB) {
-                    const int w0 = base + o * so;
-                    for (int i = 0; i < ni; ++i) {
-                        const int w = w0 + i * si;
-                        if (w >= w_lo && w < w_hi) {
-                            const float* c = chunk + (w - w_lo) * kMargW;
-                            a = fmaf(c[kMargW - 1], c[b], a);
-                        }
-                    }
-                }
-                psum[item] = a;
-            }
-        }
-        __syncthreads();
-        for (int j = tid; j < nslots; j += 256) {
-            float a = 0.f;
-            for (int k = 0; k < SUB; ++k) a += psum[j * SUB + k];
-            wpos[j] = a;
-        }
-    } else if (sc) {
+    const bool has_pos = sc != nullptr;
+    if (sc) {
         float ay[4] = {0.f, 0.f, 0.f, 0.f};      // up to 4 * 256 spatial marginals per thread
         for (int t0 = 0; t0 < p.T; t0 += kTC) {
             const int nt = min(kTC, p.T - t0);
@@ -311,37 +251,13 @@ extern "C" int hicom_global_merge_fwd(const float* part_m, const float* part_l, 
         hipLaunchKernelGGL(frame_marginals_kernel, dim3((unsigned)rows, (unsigned)T), dim3(256), smem, s, scores,
                            (long)score_stride, T, H, W, scratch);
     }
-    MergeCtxParams p{part_m, part_l, part_acc, nparts, rows_pad, E, pe ? scratch : nullptr, nullptr, 0, 0, 0, 0, 0, 0, pe,
+    MergeCtxParams p{part_m, part_l, part_acc, nparts, rows_pad, E, pe ? scratch : nullptr, pe,
                      T, H, W, t_index0, y_index0, x_index0, out_ml, out_acc, normalize};
     HICOM_REQUIRE(E % 4 == 0 && (!pe || H + W <= 1024), HICOM_EUNSUP, "global_merge: E %% 4 and H + W <= 1024");
     const size_t smem2 = ((size_t)nparts + (pe ? (size_t)2 * T + H + W + (size_t)kTC * (H + W + 2) : 0) + 16 * 64 + 4) * 4;
     HICOM_REQUIRE(smem2 <= 60000, HICOM_EUNSUP, "global_merge: too many partials/frames for one pass");
     hipLaunchKernelGGL(merge_ctx_kernel, dim3((unsigned)rows, (unsigned)((E + 31) / 32)), dim3(256), smem2, s, p);
     return hicom_host::check_launch("global_merge");
-}
-
-extern "C" int hicom_global_merge_windows_fwd(const float* part_m, const float* part_l, const float* part_acc,
-                                              const float* part_marg, int32_t nparts, int32_t rows, int32_t E,
-                                              int32_t T, int32_t H, int32_t W, int32_t kt, int32_t ks,
-                                              const float* pe, int32_t t_index0, int32_t y_index0, int32_t x_index0,
-                                              float* out_ml, float* out_acc, int32_t normalize, void* stream) {
-    HICOM_REQUIRE(part_m && part_l && part_acc && out_ml && out_acc, HICOM_EINVAL, "global_merge_windows: NULL pointer");
-    HICOM_REQUIRE((pe == nullptr) == (part_marg == nullptr), HICOM_EINVAL, "global_merge_windows: pe and part_marg go together");
-    HICOM_REQUIRE(nparts > 0 && rows > 0 && rows <= 16 && E > 0 && E % 4 == 0 && kt > 0 && ks > 0 && T % kt == 0 && H % ks == 0 &&
-                      W % ks == 0 && kt + 2 * ks <= kMargW - 1,
-                  HICOM_EINVAL, "global_merge_windows: bad shape");
-    const int NW = (T / kt) * (H / ks) * (W / ks), wpw = (NW + nparts - 1) / nparts;
-    MergeCtxParams p{part_m, part_l, part_acc, nparts, 16, E, nullptr, part_marg, wpw, kt, ks, H / ks, W / ks, NW, pe,
-                     T, H, W, t_index0, y_index0, x_index0, out_ml, out_acc, normalize};
-    const size_t smem2 = ((size_t)nparts + (pe ? (size_t)2 * T + H + W + kMergeChunk + (T + H + W < 256 ? 256 : T + H + W) : 0) + 16 * 64 + 4) * 4;
-    HICOM_REQUIRE(smem2 <= 81920 && wpw * kMargW <= kMergeChunk, HICOM_EUNSUP, "global_merge_windows: too many partials/frames for one pass");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(merge_ctx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(merge_ctx_kernel, dim3((unsigned)rows, (unsigned)((E + 31) / 32)), dim3(256), smem2, (hipStream_t)stream, p);
-    return hicom_host::check_launch("global_merge_windows");
 }
 
 extern "C" int hicom_global_combine_fwd(const float* ml, const float* acc, int32_t nsets, int32_t rows,

@@ -110,11 +110,13 @@ def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, 
         a.gw2, a.gb2 = _w(gc.readout[2])
         if gc.use_pos_emb:
             pe, kpe, cap = gc.pos_and_kpe(t_offset + T, H, W, ff.device)
+            pe_hi, pe_lo = gc.pos_planes(t_offset + T, H, W, ff.device)
             a.pe, a.kpe, a.P = pe.data_ptr(), kpe.data_ptr(), pe.shape[0]
+            a.pe_hi, a.pe_lo = pe_hi.data_ptr(), pe_lo.data_ptr()
             a.t_index0, a.y_index0, a.x_index0 = t_offset, cap, cap + H
-            keep += [pe, kpe]
+            keep += [pe, kpe, pe_hi, pe_lo]
         else:
-            a.pe = a.kpe = None
+            a.pe = a.kpe = a.pe_hi = a.pe_lo = None
             a.P = 0
     a.out, a.out_dt, a.ldo = out.data_ptr(), nv._dt(out), out.shape[-1]
     a.local_row0 = 0

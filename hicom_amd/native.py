@@ -27,7 +27,6 @@ EXPORTS = (
     "hicom_readout_gemm_fwd", "hicom_scatter_rows_fwd", "hicom_fold_query_split_fwd",
     "hicom_global_combine_strided_fwd", "hicom_compressor_workspace_bytes", "hicom_compressor_zero_prefix_bytes",
     "hicom_compressor_fwd", "hicom_linear_to_rows_fwd", "hicom_fused_stream_fwd", "hicom_fused_stream_nparts",
-    "hicom_global_merge_windows_fwd",
     "hicom_planes_gemm_fwd", "hicom_row_ln_fwd", "hicom_small_mha_fwd",
 )
 
@@ -57,7 +56,7 @@ class CompressorArgs(C.Structure):
         ("wq", C.c_void_p), ("bq", C.c_void_p), ("wk", C.c_void_p), ("wv", C.c_void_p), ("bv", C.c_void_p),
         ("wo", C.c_void_p), ("bo", C.c_void_p),
         ("gw0", C.c_void_p), ("gb0", C.c_void_p), ("gw2", C.c_void_p), ("gb2", C.c_void_p),
-        ("pe", C.c_void_p), ("kpe", C.c_void_p),
+        ("pe", C.c_void_p), ("kpe", C.c_void_p), ("pe_hi", C.c_void_p), ("pe_lo", C.c_void_p),
         ("t_index0", C.c_int32), ("y_index0", C.c_int32), ("x_index0", C.c_int32), ("nsets", C.c_int32),
         ("out", C.c_void_p), ("out_dt", C.c_int32), ("nl_group", C.c_int32),
         ("ldo", C.c_int64), ("local_row0", C.c_int64), ("global_row0", C.c_int64),
@@ -101,11 +100,9 @@ def lib() -> C.CDLL:
     L.hicom_global_merge_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, i64, i64, i32, i32, vp, i32, i32, i32,
                                          vp, vp, vp, i32, vp]
     L.hicom_linear_to_rows_fwd.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i64, i64, i32, vp]
-    L.hicom_fused_stream_fwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, f32, vp, i32, i32, i32, i32,
-                                         vp, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.hicom_fused_stream_fwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, f32, vp, i32, vp, vp, i32, i32, i32,
+                                         vp, vp, vp, i32, vp, vp, vp, vp]
     L.hicom_fused_stream_nparts.argtypes = [i32]
-    L.hicom_global_merge_windows_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32,
-                                                 vp, vp, i32, vp]
     L.hicom_planes_gemm_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i64, i64, i32, vp]
     L.hicom_row_ln_fwd.argtypes = [vp, i32, i64, vp, i64, vp, i64, vp, vp, i32, vp, i32, i64, vp, i32, f32, vp, i32, i64,
                                    i32, i32, vp]
@@ -213,7 +210,7 @@ def global_merge(part_m, part_l, part_acc, rows, scores, N, H, W, pe, t0i, y0i, 
     nparts, rows_pad = part_m.shape
     E = part_acc.shape[-1]
     _check(lib().hicom_global_merge_fwd(_ptr(part_m), _ptr(part_l), _ptr(part_acc), nparts, rows, rows_pad, E,
-                                        _ptr(scores), scores.shape[1], N, H, W, _ptr(pe), t0i, y0i, x0i,
+                                        _ptr(scores), scores.shape[1] if scores is not None else 0, N, H, W, _ptr(pe), t0i, y0i, x0i,
                                         _ptr(scratch), _ptr(out_ml), _ptr(out_acc), int(normalize), _stream()),
            "hicom_global_merge_fwd")
 
@@ -276,22 +273,17 @@ def fused_stream_nparts(n_windows: int) -> int:
     return n
 
 
-def fused_stream(ff, fe, kt, ks, qhi, qlo, rows, l_scale, l_bias, pos_a, t0i, y0i, x0i, part_m, part_l,
-                 part_acc, part_marg, ctx_local, ctx_hi=None, ctx_lo=None):
-    """part_marg: f32 [nparts, rows, ceil(Nw / nparts), 12] (None iff pos_a is None)."""
+def fused_stream(ff, fe, kt, ks, qhi, qlo, rows, l_scale, l_bias, pos_a, pe_hi, pe_lo, t0i, y0i, x0i, part_m, part_l,
+                 part_acc, ctx_local, ctx_hi=None, ctx_lo=None):
+    """pos_a f32 [16, P] + pe_hi / pe_lo bf16 [P, E] (all three or none): the kernel folds the value-side
+    pos-emb into part_acc."""
     T, H, W, E = ff.shape
     _check(lib().hicom_fused_stream_fwd(_ptr(ff), _ptr(fe), T, H, W, E, kt, ks, _ptr(qhi), _ptr(qlo), rows, l_scale,
-                                        l_bias, _ptr(pos_a), pos_a.shape[1] if pos_a is not None else 0, t0i, y0i, x0i,
-                                        _ptr(part_m), _ptr(part_l), _ptr(part_acc), _ptr(part_marg), part_m.shape[0], _ptr(ctx_local), _ptr(ctx_hi), _ptr(ctx_lo), _stream()),
+                                        l_bias, _ptr(pos_a), pos_a.shape[1] if pos_a is not None else 0,
+                                        _ptr(pe_hi), _ptr(pe_lo), t0i, y0i, x0i,
+                                        _ptr(part_m), _ptr(part_l), _ptr(part_acc), part_m.shape[0], _ptr(ctx_local),
+                                        _ptr(ctx_hi), _ptr(ctx_lo), _stream()),
            "hicom_fused_stream_fwd")
-
-
-def global_merge_windows(part_m, part_l, part_acc, part_marg, rows, T, H, W, kt, ks, pe, t0i, y0i, x0i, out_ml, out_acc,
-                         normalize=True):
-    _check(lib().hicom_global_merge_windows_fwd(_ptr(part_m), _ptr(part_l), _ptr(part_acc), _ptr(part_marg),
-                                                part_m.shape[0], rows, part_acc.shape[-1], T, H, W, kt, ks, _ptr(pe),
-                                                t0i, y0i, x0i, _ptr(out_ml), _ptr(out_acc), int(normalize), _stream()),
-           "hicom_global_merge_windows_fwd")
 
 
 def planes_gemm(a_hi, a_lo, w, b, act=ACT_NONE, out_hi=None, out_lo=None, y=None, row0=0, nl_group=0):

@@ -303,6 +303,20 @@ class GlobalCompressor(nn.Module):
             self._cache_gen += 1
         return pe, hit[0], cap
 
+    def pos_planes(self, t_cap: int, H: int, W: int, device):
+        """bf16 hi / lo planes of the pe table (the fused kernel multiplies them on matrix cores), cached with it."""
+        pe, cap = self.pos_tables(t_cap, H, W, device)
+        key = ("planes", H, W, cap, str(device))
+        hit = self._pe_cache.get(key)
+        if hit is None or hit[2] != pe.data_ptr():
+            hi = torch.empty(pe.shape, dtype=torch.bfloat16, device=device)
+            lo = torch.empty_like(hi)
+            nv.split_bf16(pe, pe.shape[0], hi, lo)
+            hit = (hi, lo, pe.data_ptr())
+            self._pe_cache[key] = hit
+            self._cache_gen += 1
+        return hit[0], hit[1]
+
     @property
     def is_plain(self) -> bool:
         return self.use_guide in _NATIVE_GUIDE_MODES and _plain_injector(self.guide_injector) and not self.adapt_guide

@@ -156,11 +156,13 @@ int hicom_global_stream_nparts(int64_t N, int32_t rows_pad);
  * <= 64, rows <= 14 global folded rows, E == 1152.
  *   q_hi / q_lo : bf16 [16, E]; rows < `rows` = folded global queries (hi / lo), rows >= `rows` =
  *                 the local query in q_hi (exact bf16) and zeros in q_lo
- *   part_marg   : f32 [nparts, rows, wpw, 12] (NULL iff pos_a is NULL): per workgroup, per window the t / y / x
- *                 marginals of the global softmax weights, bins [0,kt) frames,
- *                 [kt,kt+ks) rows, [kt+ks,kt+2ks) columns; wpw = ceil(Nw / nparts).  Consumed by
- *                 hicom_global_merge_windows_fwd for the value-side pos-emb (projector.py:57-101,
- *                 :176-179); slot 11 = the window's reference max.  Needs kt + 2 ks <= 11.
+ *   pos_a       : f32 [16, pos_stride] score-side pos-emb  a[r, p] = qt_r . pe[p]  (hicom_fold_query_split_fwd),
+ *                 or NULL (no pos-emb)
+ *   pe_hi/pe_lo : bf16 [P, E] hi / lo planes of the per-axis sinusoid table pe (hicom_split_bf16_fwd of the f32
+ *                 table, projector.py:57-101); NULL iff pos_a is NULL.  The value-side pos-emb term
+ *                 sum_n p_n (pe[t_index0 + t_n] + pe[y_index0 + y_n] + pe[x_index0 + x_n])  (:176-179) is folded into
+ *                 part_acc by the kernel itself (marginals of the weights x pe rows, as extra P.x steps), so the
+ *                 partials merge with hicom_global_merge_fwd(pe = NULL).
  *   part_*      : as hicom_global_stream_fwd with rows_pad = 16; nparts from
  *                 hicom_fused_stream_nparts(number of windows)
  *   ctx_local   : f32 [Nw, E], window order (t1,h1,w1), and/or ctx_hi + ctx_lo: the same contexts as
@@ -168,8 +170,9 @@ int hicom_global_stream_nparts(int64_t N, int32_t rows_pad);
 int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T, int32_t H, int32_t W, int32_t E,
                            int32_t kt, int32_t ks, const void* q_hi, const void* q_lo, int32_t rows,
                            float l_scale, float l_bias, const float* pos_a, int32_t pos_stride,
+                           const void* pe_hi, const void* pe_lo,
                            int32_t t_index0, int32_t y_index0, int32_t x_index0,
-                           float* part_m, float* part_l, float* part_acc, float* part_marg, int32_t nparts, float* ctx_local,
+                           float* part_m, float* part_l, float* part_acc, int32_t nparts, float* ctx_local,
                            void* ctx_hi, void* ctx_lo, void* stream);
 int hicom_fused_stream_nparts(int32_t n_windows);
 
@@ -185,15 +188,6 @@ int hicom_global_merge_fwd(const float* part_m, const float* part_l, const float
                            int32_t H, int32_t W, const float* pe,
                            int32_t t_index0, int32_t y_index0, int32_t x_index0,
                            float* scratch, float* out_ml, float* out_acc, int32_t normalize, void* stream);
-
-/* Same merge fed by the fused kernel's per-window marginals (`part_marg`, see
- * hicom_fused_stream_fwd) instead of the score buffer: one launch, no scratch.  nparts must be the
- * value the fused kernel ran with; pe == NULL <=> part_marg == NULL (no pos-emb). */
-int hicom_global_merge_windows_fwd(const float* part_m, const float* part_l, const float* part_acc,
-                                   const float* part_marg, int32_t nparts, int32_t rows, int32_t E,
-                                   int32_t T, int32_t H, int32_t W, int32_t kt, int32_t ks,
-                                   const float* pe, int32_t t_index0, int32_t y_index0, int32_t x_index0,
-                                   float* out_ml, float* out_acc, int32_t normalize, void* stream);
 
 /* Combine `nsets` (M,L,ACC) triples (one per GPU after the all-gather, or one) and normalise:
  * ctx[r,:] = sum_k e^(M_k - M) ACC_k[r,:] / sum_k e^(M_k - M) L_k.
@@ -291,6 +285,7 @@ typedef struct hicom_compressor_args {
     const void *gw0, *gb0, *gw2, *gb2;
     const float* pe;           /* f32 [P, E] stacked per-axis sinusoid tables, or NULL (no pos-emb) */
     const float* kpe;          /* f32 [E, P] = w_k . pe^T (weight-only cache) */
+    const void *pe_hi, *pe_lo; /* bf16 [P, E] hi / lo planes of pe (hicom_split_bf16_fwd; cached with pe) */
     int32_t t_index0, y_index0, x_index0, nsets;
     /* output [rows, ldo] of dtype out_dt */
     void* out;

@@ -312,6 +312,9 @@ def test_fused_stream_matches_separate_kernels(T, H, W, kt, ks):
     pe = torch.from_numpy(geo.stacked_pos_tables(cap, H, W, E)).cuda()
     pos_a = torch.zeros((16, pe.shape[0]), dtype=torch.float32, device="cuda")
     nv.linear(qt, pe, None, pos_a, M=R)
+    pe_hi = torch.empty(pe.shape, dtype=torch.bfloat16, device="cuda")
+    pe_lo = torch.empty_like(pe_hi)
+    nv.split_bf16(pe, pe.shape[0], pe_hi, pe_lo)
     # reference: the two separate kernels
     axes = tuple(nv.Axis(a.n, a.k, a.nwin, a.nfull) for a in (geo.axis_tiling(T, kt), geo.axis_tiling(H, ks), geo.axis_tiling(W, ks)))
     nw = (T // kt) * (H // ks) * (W // ks)
@@ -334,30 +337,23 @@ def test_fused_stream_matches_separate_kernels(T, H, W, kt, ks):
         wpw = (nw + nparts - 1) // nparts
         per_t = (H // ks) * (W // ks)
         span_frames = ((wpw + per_t - 2) // per_t + 1) * kt          # frames one workgroup may touch
-        lds = 4 * 9 * 4096 + 9 * 1024 + 8 * 80 * 4 + 8 * 64 + (128 + 32) * 4 + R * (8 + H + W) * 4
-        if wpw > 32 or span_frames > 8 or (nparts - 1) * wpw >= nw or lds > 163840 or R * (8 + H + W) > 1024:
+        lds = 4 * 9 * 4096 + 9 * 1024 + 8 * 80 * 4 + 8 * 64 + (64 + 32) * 4 + R * (8 + H + W) * 4
+        if wpw > 32 or span_frames > 8 or (nparts - 1) * wpw >= nw or lds > 163840 or R * (8 + H + W) > 1024 or 8 + H + W > 64:
             continue                                                  # outside the kernel's LDS-table limits
         ran = True
         pm1, pl1, pa1 = f32((nparts, 16)), f32((nparts, 16)), f32((nparts, 16, E))
-        marg = torch.full((nparts, R, wpw, 12), float("nan"), dtype=torch.float32, device="cuda")
         ctx = torch.full((nw, E), float("nan"), dtype=torch.float32, device="cuda")
-        nv.fused_stream(ff, fe, kt, ks, qhi_f, qlo, R, 1 / math.sqrt(E), 0.0, pos_a, 0, cap, cap + H, pm1, pl1, pa1, marg, ctx)
+        nv.fused_stream(ff, fe, kt, ks, qhi_f, qlo, R, 1 / math.sqrt(E), 0.0, pos_a, pe_hi, pe_lo, 0, cap, cap + H, pm1, pl1, pa1, ctx)
+        # the kernel folds the value-side pos-emb into its partial contexts: a plain merge finishes the job
         ml, acc = f32((R, 2)), f32((R, E))
-        nv.global_merge_windows(pm1, pl1, pa1, marg, R, T, H, W, kt, ks, pe, 0, cap, cap + H, ml, acc, normalize=True)
+        nv.global_merge(pm1, pl1, pa1, R, None, N, H, W, None, 0, 0, 0, None, ml, acc, normalize=True)
         torch.cuda.synchronize()
         assert maxabs(ctx, ctx_ref) <= 5e-5 * max(1.0, float(ctx_ref.abs().max())), (nparts, "local")
-        # the per-window marginals are the t / y / x sums of the softmax weights the score buffer implies
-        sc = s0[:R, :N].double().cpu().reshape(R, T // kt, kt, H // ks, ks, W // ks, ks).permute(0, 1, 3, 5, 2, 4, 6)
-        mg = marg.double().cpu().reshape(R, -1, 12) if nparts == 1 else marg.double().cpu().permute(1, 0, 2, 3).reshape(R, -1, 12)
-        mg = mg[:, :nw]
-        wts = torch.exp(sc.reshape(R, nw, kt, ks, ks) - mg[:, :, 11].reshape(R, nw, 1, 1, 1))
-        want_bins = torch.cat([wts.sum((3, 4)), wts.sum((2, 4)), wts.sum((2, 3))], dim=2)
-        assert maxabs(mg[:, :, :kt + 2 * ks], want_bins) <= 2e-4 * max(1.0, float(want_bins.abs().max())), (nparts, "marginals")
         assert maxabs(acc, g_ref) <= 2e-5 * max(1.0, float(g_ref.abs().max())), (nparts, "global")
-        # run-to-run determinism of the LDS-atomic reductions
+        # run-to-run determinism (no atomics anywhere)
         pa2, acc2 = torch.empty_like(pa1), f32((R, E))
-        nv.fused_stream(ff, fe, kt, ks, qhi_f, qlo, R, 1 / math.sqrt(E), 0.0, pos_a, 0, cap, cap + H, pm1, pl1, pa2, marg, ctx)
-        nv.global_merge_windows(pm1, pl1, pa2, marg, R, T, H, W, kt, ks, pe, 0, cap, cap + H, ml, acc2, normalize=True)
+        nv.fused_stream(ff, fe, kt, ks, qhi_f, qlo, R, 1 / math.sqrt(E), 0.0, pos_a, pe_hi, pe_lo, 0, cap, cap + H, pm1, pl1, pa2, ctx)
+        nv.global_merge(pm1, pl1, pa2, R, None, N, H, W, None, 0, 0, 0, None, ml, acc2, normalize=True)
         assert torch.equal(pa1[:, :R], pa2[:, :R]) and torch.equal(acc, acc2), (nparts, "determinism")
     assert ran
 

@@ -20,7 +20,7 @@ for nparts in sorted({nv.fused_stream_nparts(nw), max(1, (nw + 15) // 16), min(n
     if ((wpw + per_t - 2) // per_t + 1) * kt > 8 or wpw > 32: continue
     pm, pl, pa = torch.empty(nparts, 16, device="cuda"), torch.empty(nparts, 16, device="cuda"), torch.empty(nparts, 16, E, device="cuda")
     ctx = torch.full((nw, E), float("nan"), device="cuda")
-    nv.fused_stream(ff, fe, kt, ks, qhi, qlo, R, 1 / math.sqrt(E), 0.0, None, 0, T, T + H, pm, pl, pa, None, ctx)
+    nv.fused_stream(ff, fe, kt, ks, qhi, qlo, R, 1 / math.sqrt(E), 0.0, None, None, None, 0, T, T + H, pm, pl, pa, ctx)
     torch.cuda.synchronize()
     err = (ctx - ref).abs().amax(dim=1).cpu().numpy()
     print("nparts", nparts, "wpw", wpw, "per-window max err:", np.array2string(err, precision=3))

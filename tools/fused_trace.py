@@ -24,10 +24,10 @@ pos_a = torch.randn(16, T + 54, device=dev) * 0.1
 nw = (T // 4) * 81
 nparts = nv.fused_stream_nparts(nw)
 wpw = (nw + nparts - 1) // nparts
-marg = torch.empty(nparts, 9, wpw, 12, device=dev)
+pe = torch.randn(T + 54, E, device=dev); pe_hi = pe.bfloat16(); pe_lo = (pe - pe_hi.float()).bfloat16()
 pm, pl, pacc = torch.empty(nparts, 16, device=dev), torch.empty(nparts, 16, device=dev), torch.empty(nparts, 16, E, device=dev)
 chi = torch.empty(nw, E, device=dev, dtype=torch.bfloat16); clo = torch.empty_like(chi)
-run = lambda: nv.fused_stream(ff, fe, 4, 3, qhi, qlo, 9, 1 / math.sqrt(E), 0.0, pos_a, 0, T, T + H, pm, pl, pacc, marg, None, chi, clo)
+run = lambda: nv.fused_stream(ff, fe, 4, 3, qhi, qlo, 9, 1 / math.sqrt(E), 0.0, pos_a, pe_hi, pe_lo, 0, T, T + H, pm, pl, pacc, None, chi, clo)
 for _ in range(5): run()
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

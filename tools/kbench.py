@@ -41,12 +41,12 @@ if "fused" in which or len(sys.argv) == 1:
     pos_a = torch.randn(16, 64 + 54, device=dev) * 0.1
     nw = 1296
     for nparts in sorted({nv.fused_stream_nparts(nw)}):
-        marg = torch.empty(nparts, 9, (nw + nparts - 1) // nparts, 12, device=dev)
+        pe = torch.randn(64 + 54, E, device=dev); pe_hi = pe.bfloat16(); pe_lo = (pe - pe_hi.float()).bfloat16()
         pm, pl, pacc = torch.empty(nparts, 16, device=dev), torch.empty(nparts, 16, device=dev), torch.empty(nparts, 16, E, device=dev)
         ctx = torch.empty(nw, E, device=dev)
-        t = timeit(lambda: nv.fused_stream(ff, fe, 4, 3, qhi, qlo, 9, 1 / math.sqrt(E), 0.0, pos_a, 0, 64, 64 + H, pm, pl, pacc, marg, ctx))
+        t = timeit(lambda: nv.fused_stream(ff, fe, 4, 3, qhi, qlo, 9, 1 / math.sqrt(E), 0.0, pos_a, pe_hi, pe_lo, 0, 64, 64 + H, pm, pl, pacc, ctx))
         print("fused_stream nparts=%d %.1f us  %.2f TB/s (inputs only)" % (nparts, t, 2 * ff.numel() * 2 / t / 1e6))
-        t = timeit(lambda: nv.fused_stream(ff, fe, 4, 3, qhi, qlo, 9, 1 / math.sqrt(E), 0.0, None, 0, 64, 64 + H, pm, pl, pacc, None, ctx))
+        t = timeit(lambda: nv.fused_stream(ff, fe, 4, 3, qhi, qlo, 9, 1 / math.sqrt(E), 0.0, None, None, None, 0, 64, 64 + H, pm, pl, pacc, ctx))
         print("fused_stream (no pos) nparts=%d %.1f us" % (nparts, t))
 
 if "pgemm" in which or len(sys.argv) == 1:
