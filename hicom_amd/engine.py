@@ -136,20 +136,25 @@ def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, 
     return a
 
 
-def attach_execution(a: nv.CompressorArgs, device, key_extra=()):
-    """Workspace (zero-prefixed once, cached per problem shape) + streams/events."""
-    res = _resources(device)
+def attach_execution(a: nv.CompressorArgs, device, key_extra=(), main_stream=None, res=None):
+    """Workspace (zero-prefixed once, cached per problem shape) + streams/events.  `main_stream` / `res`
+    default to torch's current stream and its resource set; the pipelined lanes pass their own."""
+    if main_stream is None:
+        main_stream = torch.cuda.current_stream(device)
+    if res is None:
+        res = _resources(device)
     total, prefix = nv.compressor_workspace(a)
-    # one workspace per problem shape AND caller stream (two streams may run the same shape concurrently)
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream, a.T, a.H, a.W, a.E, a.hidden, a.nq, a.P,
+    # one workspace per problem shape AND main stream (two streams may run the same shape concurrently)
+    key = (device.index, main_stream.cuda_stream, a.T, a.H, a.W, a.E, a.hidden, a.nq, a.P,
            a.has_local, a.has_global, a.at.nwin, a.ay.nwin, a.ax.nwin, bool(a.lq), *key_extra)
     ws = _WS.get(key)
     if ws is None or ws.numel() < total:
-        ws = torch.empty(total, dtype=torch.uint8, device=device)
-        ws[:prefix].zero_()
+        with torch.cuda.stream(main_stream):
+            ws = torch.empty(total, dtype=torch.uint8, device=device)
+            ws[:prefix].zero_()
         _WS[key] = ws
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
-    a.stream_main = torch.cuda.current_stream(device).cuda_stream
+    a.stream_main = main_stream.cuda_stream
     a.stream_side = res.side.cuda_stream
     a.ev_fork, a.ev_join = res.ev_fork.cuda_event, res.ev_join.cuda_event
     return a
@@ -253,13 +258,21 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype) -> tor
 
 # ---------------------------------------------------------------------------------------------
 # Pipelined submission: consecutive, independent forwards on alternating "lanes" (a lane = its own
-# main stream, side stream, events, workspace and plans -- everything above is keyed by the stream
-# it runs on).  The tail of one video (readout GEMMs, merge, the small global chain: latency-bound)
-# then overlaps the query prep and the HBM-bound stream kernel of the next one.
+# main stream, side stream, events, workspace and plans).  The latency-bound tail of one video (readout
+# GEMMs, merge, the small global chain) then overlaps the query prep and the HBM-bound stream kernel
+# of the next one.  The host path is kept as short as the synchronous one: no stream context switch,
+# the lane's stream handles are baked into its cached argument blocks.
 class _Lane:
     def __init__(self, device):
         self.stream = torch.cuda.Stream(device=device)
         self.ev_in = torch.cuda.Event()
+        cur = torch.cuda.current_stream(device)
+        with torch.cuda.stream(self.stream):
+            self.res = _DeviceResources(device)      # side stream + fork/join events of this lane
+        self.ev_in.record(cur)
+        self.done = [torch.cuda.Event() for _ in range(8)]
+        self.n = 0
+        self.plans = {}
 
 
 class Pending:
@@ -273,7 +286,6 @@ class Pending:
     def wait(self) -> torch.Tensor:
         cur = torch.cuda.current_stream(self._out.device)
         cur.wait_event(self._done)
-        self._out.record_stream(cur)           # allocated on the lane stream, consumed on the caller's
         self._inputs = None
         return self._out
 
@@ -282,6 +294,8 @@ def submit(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, n_lanes: 
     from .projector import _require_bf16_cuda
     _require_bf16_cuda("frames_feature", ff)
     dev = ff.device
+    if not all(t is None or t.is_contiguous() for t in (ff, fe, guide_embed, image_newline)):
+        raise ValueError("forward_async: contiguous inputs only")
     state = proj.__dict__.setdefault("_engine_lanes", {})
     key = (dev.index, n_lanes)
     if key not in state:
@@ -292,8 +306,33 @@ def submit(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, n_lanes: 
     cur = torch.cuda.current_stream(dev)
     lane.ev_in.record(cur)                     # inputs are ready where the caller stands now
     lane.stream.wait_event(lane.ev_in)
-    with torch.cuda.stream(lane.stream):
-        out = run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype)
-        done = torch.cuda.Event()
-        done.record(lane.stream)
+    lc, gc = proj.local_compressor, proj.global_compressor
+    pkey = _plan_key(proj, ff, fe, guide_embed, modal, image_newline, out_dtype)
+    plan = lane.plans.get(pkey)
+    if plan is None:
+        T, H, W, _ = ff.shape
+        layout, n_local = None, 0
+        if lc is not None:
+            at, ay, ax = lc.tilings(T, H, W, modal)
+            layout = proj._layout((at.nwin, ay.nwin, ax.nwin), modal, image_newline is not None, False)
+            n_local = layout.n_rows
+        n_global = gc.num_queries if gc is not None else 0
+        hidden = (lc or gc).readout[2].out_features
+        out = torch.empty((n_local + n_global, hidden), dtype=out_dtype, device=dev)
+        with torch.cuda.stream(lane.stream):   # one-time table builds (pos planes, kpe, ...) go to the lane
+            a = build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, global_row0=n_local)
+        attach_execution(a, dev, main_stream=lane.stream, res=lane.res)
+        a._keep = None
+        if len(lane.plans) >= _MAX_PLANS:
+            lane.plans.pop(next(iter(lane.plans)))
+        plan = lane.plans[pkey] = _Plan(a, n_local + n_global, hidden)
+    else:
+        out = torch.empty((plan.rows, plan.hidden), dtype=out_dtype, device=dev)
+    a = plan.args
+    a.out = out.data_ptr()
+    out.record_stream(lane.stream)             # allocated on the caller's stream, written on the lane's
+    nv.compressor_fwd(a)
+    done = lane.done[lane.n % len(lane.done)]
+    lane.n += 1
+    done.record(lane.stream)
     return Pending(out, done, (ff, fe, guide_embed, image_newline))

@@ -450,6 +450,7 @@ class HIComProjector(nn.Module):
     def _invalidate_plans(self):
         self.__dict__["_engine_params_gen"] = self.__dict__.get("_engine_params_gen", 0) + 1
         self.__dict__.pop("_engine_plans", None)
+        self.__dict__.pop("_engine_lanes", None)
 
     def _apply(self, fn, *args, **kwargs):           # .to() / .cuda() / .bfloat16() ...
         self._invalidate_plans()

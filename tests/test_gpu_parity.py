@@ -180,6 +180,21 @@ def test_executor_equals_stepwise(name):
     assert torch.equal(a, a2)
 
 
+def test_forward_async_lanes_equal_forward(c2):
+    """forward_async (alternating stream lanes) returns, for a stream of DIFFERENT videos submitted back to
+    back, exactly the bits of the synchronous forward of each."""
+    m, ff, fe, g, _ = c2
+    vids = [(ff, fe), (fe, ff), (ff.flip(0).contiguous(), fe), (ff, fe)]
+    with torch.no_grad():
+        want = [m(a, b, g, "video", None).clone() for a, b in vids]
+        for lanes in (2, 3):
+            handles = [m.forward_async(a, b, g, "video", None, lanes=lanes) for a, b in vids for _ in range(2)]
+            got = [h.wait() for h in handles]
+            torch.cuda.synchronize()
+            for k, o in enumerate(got):
+                assert torch.equal(o, want[k // 2]), (lanes, k)
+
+
 def test_sharded_forward_world1_equals_forward(c2):
     """sharded_forward with a 1-rank RCCL group (STREAM phase -> all-gather -> FINISH phase) reproduces
     the single-call forward at the full C2 size."""
