@@ -40,14 +40,16 @@ bool can_fuse(const hicom_compressor_args& a) {
     const int wsz = a.at.k * a.ay.k * a.ax.k;
     if (wsz < 16 || wsz > 64 || a.H >= 256 || a.W >= 256) return false;
     const int R = a.nq * a.nh;
-    if (8 + a.H + a.W > 64) return false;                    // pos-emb slots of the fused kernel (4 tiles of 16)
     const int nw = a.at.nwin * a.ay.nwin * a.ax.nwin, per_t = a.ay.nwin * a.ax.nwin;
     const int nparts = hicom_fused_stream_nparts(nw);
     const int wpw = (nw + nparts - 1) / nparts;
     // limits of fused_ring.hip: 160 KiB of LDS (ring 4 x 36 KiB + logit partials + tables), <= 32 windows
     // and <= 8 frames per workgroup, <= 1024 pos-emb table entries
-    if (4 * 9 * 4096 + 9 * 1024 + 8 * 80 * 4 + 8 * 64 + (128 + 32) * 4 + R * (8 + a.H + a.W) * 4 > 163840) return false;
+    if (4 * 9 * 4096 + 9 * 1024 + 8 * 80 * 4 + 8 * 64 + (64 + 32 + 65 + 32 + 16) * 4 + R * (8 + a.H + a.W) * 4 > 163840) return false;
     if (R * (8 + a.H + a.W) > 1024) return false;
+    // compact pos-emb slots a workgroup can touch: 8 frames + the grid rows and columns of its windows (<= 64)
+    const int rows_t = ((wpw + a.ax.nwin - 2) / a.ax.nwin + 1) * a.ay.k, cols_t = wpw * a.ax.k;
+    if (a.H > 64 || a.W > 64 || 8 + (rows_t < a.H ? rows_t : a.H) + (cols_t < a.W ? cols_t : a.W) > 64) return false;
     return wpw <= 32 && ((wpw + per_t - 2) / per_t + 1) * a.at.k <= 8;
 }
 

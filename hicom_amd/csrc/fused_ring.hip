@@ -56,7 +56,6 @@ constexpr int kMaxFramesPerWg = 8;
 constexpr int kPosPerThread = 2;          // score-side pos-emb entries fetched per compute thread: rows * (8 + H + W) <= 1024
 constexpr int kPStride = 32;              // halfwords between rows of the softmax-weight planes (they live in red[0]'s rows)
 constexpr int kRegroup = 80;               // channels per hop of the completed-row regroup (multiple of 16)
-constexpr int kPosImages = 8;              // ring images of the value-side pos-emb pass: up to 4 slot tiles x (hi, lo) planes
 
 struct RingParams {
     const uint16_t* ff;
@@ -104,7 +103,11 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
     float* alpha_s = cscr + kRingC * kRegroup;                            // [kRingC][16] wave-private rescale factors in accumulator-row order
     int* win_txy = reinterpret_cast<int*>(alpha_s + kRingC * 16);   // [64] packed in-window coords (t2 << 16 | h2 << 8 | w2)
     int* wtxy = win_txy + 64;                                          // [kMaxWinPerWg] packed window base coords (frame offset << 16 | y0 << 8 | x0)
-    float* a_pos = reinterpret_cast<float*>(wtxy + kMaxWinPerWg);      // [R][kMaxFramesPerWg | H | W] score-side pos-emb per row
+    int* slot_row = wtxy + kMaxWinPerWg;                               // [64] pe row of a compact pos-emb slot; [64] = number of slots
+    unsigned char* ymap = reinterpret_cast<unsigned char*>(slot_row + 65);   // [64] grid row -> compact slot (255: not touched by this workgroup)
+    unsigned char* xmap = ymap + 64;                                   // [64] grid column -> compact slot
+    int* tokslot = reinterpret_cast<int*>(xmap + 64);                  // [16] compact pos-emb slots (frame | row << 8 | column << 16) of this tile's tokens
+    float* a_pos = reinterpret_cast<float*>(tokslot + 16);            // [R][kMaxFramesPerWg | H | W] score-side pos-emb per row
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,7 +121,6 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
     const int R = p.R, NLOC = 16 - R;
     const int ks2 = p.ks * p.ks, per_t = p.nwy * p.nwx;
     const unsigned wsz_magic = (65536u + p.WSZ - 1) / p.WSZ;    // s / WSZ by multiply-shift: exact for s < 2^16
-    const int nslot_tiles = (kMaxFramesPerWg + p.H + p.W + 15) >> 4;   // 16-slot tiles of the pos-emb marginals (<= kPosImages / 2)
 
     // =========================================================================================
     // LOADER waves
@@ -127,8 +129,7 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
         const int l = wave - kRingC;
         const int row = 4 * l + (lane >> 4), cpos = lane & 15;          // token slot of this lane, 16-byte chunk in the row
         const int lane_off = 16 * (cpos ^ fswz(row));
-        const int t1_first_l = wb / per_t;
-        // stream slot -> byte offset of the token row (clamped past the end: harmless re-requests)
+        // stream slot -> byte offset of the token row (slots past the end of the last tile re-read its last token)
         auto src_off = [&](int tile) -> long {
             int s = tile * 16 + row;
             s = s < total ? s : total - 1;
@@ -148,60 +149,61 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 256),
                                                  (__attribute__((address_space(3))) void*)(img + (4 * i + l) * 1024), 16, 0, 0);
         };
+        // Past the token stream the ring carries the value-side pos-emb: "tile" ntile + b holds the pe rows of
+        // compact slot tile b -- hi plane where frames_embed goes, lo plane where frames_feature goes -- so the
+        // request cadence, the slots and the counted waits stay exactly those of the stream, and the first pe
+        // images are already in flight while the last token tiles are being consumed.
+        int ntot = ntile, nsl = 0;
+        // byte offset of this lane's source row for image `tile`, computed ahead of the barrier it is issued after
+        auto off_of = [&](int tile) -> long {
+            if (tile < ntile) return src_off(tile);
+            const int s = 16 * (tile - ntile) + row;                    // compact pos-emb slot
+            return (long)slot_row[s < nsl ? s : 0] * (long)(E * 2) + lane_off;
+        };
         const long o0 = src_off(0);
-        long o_ff = src_off(1);
-        issue(p.ff, o0, ffbuf);
         issue(p.fe, o0, febuf);
-        issue(p.fe, o_ff, febuf + TILE_BYTES);
+        issue(p.ff, o0, ffbuf);
         HICOM_TR(2);   // prologue requests issued
         __builtin_amdgcn_s_barrier();                                  // [P] (the compute waves' tables)
-        for (int t = 0; t < ntile; ++t) {
-            const long o_fe = src_off(t + 2);                          // address math ahead of the wait
-            // in flight, oldest first: fe(t) | ff(t) | fe(t+1): everything but the youngest image has to land
+        if (p.pe_hi) {
+            nsl = slot_row[64];
+            ntot = ntile + ((nsl + 15) >> 4);
+        }
+        long o_ff = ntot > 1 ? off_of(1) : 0;                          // offset of tile t+1 (fe, then ff)
+        if (ntot > 1) issue(1 < ntile ? p.fe : p.pe_hi, o_ff, febuf + TILE_BYTES);
+        for (int t = 0; t < ntot; ++t) {
+            const long o_fe = t + 2 < ntot ? off_of(t + 2) : 0;         // address math ahead of the wait
             HICOM_TR(2);   // tile: addresses ready
-            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PPL) : "memory");
+            // in flight, oldest first: fe(t) | ff(t) | fe(t+1): everything but the youngest image has to land
+            if (t + 1 < ntot) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PPL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             HICOM_TR(2);   // tile: data landed
             __builtin_amdgcn_s_barrier();                              // [A] tile t published; ff slot of tile t-1 released
+            if (t == ntile) __builtin_amdgcn_s_barrier();              // [A'] (the compute waves table their marginals)
             HICOM_TR(2);   // tile: past [A]
-            issue(p.ff, o_ff, ffbuf + ((t + 1) & 1) * TILE_BYTES);
+            if (t + 1 < ntot) issue(t + 1 < ntile ? p.ff : p.pe_lo, o_ff, ffbuf + ((t + 1) & 1) * TILE_BYTES);
             HICOM_TR(2);   // tile: ff issued
+            if (p.pe_hi && l == 0 && t < ntile && lane < 16) {
+                // compact pos-emb slots of this tile's 16 tokens, for the marginal MFMA of the compute waves (read
+                // after [B]): the table walk costs a loader lane nothing that matters
+                const int s = t * 16 + lane;
+                int wr = (int)(((unsigned)s * wsz_magic) >> 16), i = s - wr * p.WSZ;
+                if (i < 0) { i += p.WSZ; wr -= 1; }
+                int v = 0xFFFFFF;
+                if (s < total) {
+                    const int txy = win_txy[i], base = wtxy[wr];
+                    const int f = (base >> 16) + (txy >> 16), y = ((base >> 8) & 255) + ((txy >> 8) & 255), x = (base & 255) + (txy & 255);
+                    v = f | ((int)ymap[y] << 8) | ((int)xmap[x] << 16);
+                }
+                tokslot[lane] = v;
+            }
             __builtin_amdgcn_s_barrier();                              // [B] fe slot of tile t released
             HICOM_TR(2);   // tile: past [B]
-            issue(p.fe, o_fe, febuf + (t & 1) * TILE_BYTES);
+            if (t + 2 < ntot) issue(t + 2 < ntile ? p.fe : p.pe_hi, o_fe, febuf + (t & 1) * TILE_BYTES);
             HICOM_TR(2);   // tile: fe issued
             o_ff = o_fe;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the clamped requests past the end
-        __builtin_amdgcn_s_barrier();                                  // [M] ring idle, marginals tabled
-        if (p.pe_hi) {
-            // value-side pos-emb pass: the pe rows of slot tile b travel through the 4 ring slots exactly like
-            // token rows (image n = 2 b + plane); up to three images run ahead of the one being consumed.
-            auto pe_off = [&](int n) -> long {
-                const int s = 16 * (n >> 1) + row;                      // slot: frame | grid row | grid column | padding
-                const int t = t1_first_l * p.kt + s;
-                int prow = s < kMaxFramesPerWg ? p.t0i + (t < p.T ? t : p.T - 1)
-                                               : (s < kMaxFramesPerWg + p.H ? p.y0i + (s - kMaxFramesPerWg)
-                                                                            : p.x0i + min(s - kMaxFramesPerWg - p.H, p.W - 1));
-                return (long)prow * (long)(E * 2) + lane_off;
-            };
-            const int nimg = 2 * nslot_tiles;
-#pragma unroll
-            for (int n = 0; n < 3; ++n)
-                if (n < nimg) issue((n & 1) ? p.pe_lo : p.pe_hi, pe_off(n), smem + n * TILE_BYTES);
-#pragma unroll
-            for (int n = 0; n < kPosImages; ++n) {
-                if (n < nimg) {
-                    // issued so far: images 0 .. min(nimg - 1, n + 2); the younger ones may stay in flight
-                    const int younger = min(nimg - 1, n + 2) - n;
-                    if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * PPL) : "memory");
-                    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PPL) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();                      // [X_n] image n published; slot of image n-1 released
-                    if (n + 3 < nimg) issue(((n + 3) & 1) ? p.pe_lo : p.pe_hi, pe_off(n + 3), smem + ((n + 3) & 3) * TILE_BYTES);
-                }
-            }
-        }
-        __builtin_amdgcn_s_barrier();                                  // [E] ring idle
+        __builtin_amdgcn_s_barrier();                                  // [E] ring idle (nothing is in flight any more)
         return;
     }
 
@@ -239,6 +241,30 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
         const int t1 = w / per_t, r = w - t1 * per_t, h1 = r / p.nwx, w1 = r - h1 * p.nwx;
         wtxy[ctid] = (((t1 - t1_first) * p.kt) << 16) | ((h1 * p.ks) << 8) | (w1 * p.ks);
     }
+    if (p.pe_hi && wave == 0) {
+        // Compact pos-emb slots of this workgroup: the 8 frames from its first frame group, then only the grid
+        // rows and columns its windows touch (a few of the H + W): fewer pe rows to multiply after the stream.
+        ymap[lane] = 0;
+        xmap[lane] = 0;
+        if (lane < nwin) {
+            const int w = wb + lane;
+            const int t1 = w / per_t, r = w - t1 * per_t, h1 = r / p.nwx, w1 = r - h1 * p.nwx;
+            for (int j = 0; j < p.ks; ++j) {
+                ymap[h1 * p.ks + j] = 1;
+                xmap[w1 * p.ks + j] = 1;
+            }
+        }
+        const bool yu = lane < p.H && ymap[lane] != 0, xu = lane < p.W && xmap[lane] != 0;
+        const unsigned long long ym = __ballot(yu), xm = __ballot(xu), below = (1ull << lane) - 1ull;
+        const int ny = __popcll(ym);
+        const int cy = kMaxFramesPerWg + __popcll(ym & below), cx = kMaxFramesPerWg + ny + __popcll(xm & below);
+        ymap[lane] = yu ? (unsigned char)cy : (unsigned char)255;
+        xmap[lane] = xu ? (unsigned char)cx : (unsigned char)255;
+        if (lane < kMaxFramesPerWg) slot_row[lane] = p.t0i + min(t1_first * p.kt + lane, p.T - 1);
+        if (yu) slot_row[cy] = p.y0i + lane;
+        if (xu) slot_row[cx] = p.x0i + lane;
+        if (lane == 0) slot_row[64] = kMaxFramesPerWg + ny + __popcll(xm);
+    }
     if (p.pos_a) {
         const int S = kMaxFramesPerWg + p.H + p.W, n_all = R * S;
 #pragma unroll
@@ -275,6 +301,7 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
 
     HICOM_TR(0); HICOM_TR(1);   // prologue done (this wave)
     lds_barrier();                                                     // [P] tables ready
+    const int nslot_tiles = p.pe_hi ? (__builtin_amdgcn_readfirstlane(slot_row[64]) + 15) >> 4 : 0;   // 16-slot tiles of the compact pos-emb slots
 
     for (int tile = 0; tile < ntile; ++tile) {
         const int cur = tile & 1;
@@ -398,16 +425,15 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
         // the weights: MG += P . onehot(slot of each token) over the slots  frame (relative to this workgroup's
         // first frame) | grid row | grid column -- one more MFMA per tile on the wave that owns the 16-slot
         // block.  Rescaled by alpha like ACC.  Part 2 (after the stream) multiplies MG by the pe rows.
+#ifndef X_NO_MARG
         if (p.pe_hi && wave < nslot_tiles) {
             const int col = 16 * wave + r16;
             bf16x4 bm;
+            const int4 tsl = *reinterpret_cast<const int4*>(tokslot + ts0);   // slots of this lane's 4 tokens (tabled by a loader wave)
+            const int tsv[4] = {tsl.x, tsl.y, tsl.z, tsl.w};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                int i = i0 + ts0 + u, wr = wr0;
-                if (i >= p.WSZ) { i -= p.WSZ; wr += 1; }
-                const int txy = win_txy[i], base = wtxy[(s0 + ts0 + u < total) ? wr : 0];
-                const int f = (base >> 16) + (txy >> 16), y = ((base >> 8) & 255) + ((txy >> 8) & 255), x = (base & 255) + (txy & 255);
-                const bool hit = col == f || col == kMaxFramesPerWg + y || col == kMaxFramesPerWg + p.H + x;
+                const bool hit = col == (tsv[u] & 255) || col == ((tsv[u] >> 8) & 255) || col == (tsv[u] >> 16);
                 bm[u] = hit ? (short)0x3F80 : (short)0;
             }
             const bf16x8 bm2 = bf16x8{bm[0], bm[1], bm[2], bm[3], bm[0], bm[1], bm[2], bm[3]};
@@ -415,6 +441,7 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
 #pragma unroll
             for (int j = 0; j < 4; ++j) mgacc[j] = fmaf(mgacc[j], al[j], mg[j]);
         }
+#endif
         // ---- ACC += P . x: all transposed fragment reads of the slice in flight, then the MFMAs ------------
         {
             const unsigned img_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(ffimg);
@@ -483,33 +510,35 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
         }
     }
 
-    lds_barrier();                                                     // [M] loaders drained, every wave done with the ring
     if (p.pe_hi) {
-        // ---- value-side pos-emb, part 2: ACC += MG . pe, as P.x steps over images of pe rows.  MG (fp32, in the
-        // accumulator layout of the waves that own the slot blocks) is tabled in LDS ([slot][row], in `red`) and
-        // re-read in the A-operand layout; hi + lo planes of MG against hi and lo planes of pe.
+        // ---- value-side pos-emb, part 2: ACC += MG . pe, as P.x steps over the pe tiles that follow the token
+        // stream in the ring.  MG (fp32, in the accumulator layout of the waves that own the slot blocks) is
+        // tabled in LDS ([slot][row], in `red`) and re-read in the A-operand layout; hi + lo planes of MG in one
+        // K = 32 operand against the hi plane (frames_embed slot), then the lo plane (frames_feature slot).
         float* mgs = red;                                              // [64 slots][16 rows]  (red: 9 x 256 floats)
-        if (wave < nslot_tiles) {
+        for (int b = 0; b < nslot_tiles; ++b) {
+            const int t = ntile + b;
+            lds_barrier();                                             // [A] pe tile b landed; red idle
+            if (b == 0) {
+                if (wave < nslot_tiles) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) mgs[(16 * wave + r16) * 16 + 4 * kg + j] = (4 * kg + j < R) ? mgacc[j] : 0.f;
-        }
-        lds_barrier();                                                 // [X_0] table complete, image 0 landed
-        const int nimg = 2 * nslot_tiles;
-        bf16x8 pwp = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int n = 0; n < kPosImages; ++n) {
-            if (n < nimg) {
-                if (n > 0) lds_barrier();                              // [X_n]
-                if ((n & 1) == 0) {                                    // new slot tile: its marginals as the A operand
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        uint16_t h, l;
-                        split_bf16(mgs[(16 * (n >> 1) + ts0 + u) * 16 + r16], h, l);
-                        pwp[u] = (short)h;
-                        pwp[4 + u] = (short)l;
-                    }
+                    for (int j = 0; j < 4; ++j) mgs[(16 * wave + r16) * 16 + 4 * kg + j] = (4 * kg + j < R) ? mgacc[j] : 0.f;
                 }
-                const unsigned img_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(smem + (n & 3) * TILE_BYTES);
+                lds_barrier();                                         // [A'] table complete
+            }
+            bf16x8 pwp;                                                // marginals of slot tile b as the A operand (hi | lo)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                uint16_t h, l;
+                split_bf16(mgs[(16 * b + ts0 + u) * 16 + r16], h, l);
+                pwp[u] = (short)h;
+                pwp[4 + u] = (short)l;
+            }
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane) {
+                if (plane == 1) lds_barrier();                         // [B] hi-plane slot released
+                const char* img = (plane == 0 ? febuf : ffbuf) + (t & 1) * TILE_BYTES;
+                const unsigned img_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(img);
                 bf16x4 bv[KS];
 #pragma unroll
                 for (int u = 0; u < KS; ++u) {
@@ -582,7 +611,7 @@ extern "C" int hicom_fused_stream_nparts(int32_t n_windows) {
 
 static size_t ring_lds_bytes(int rows, int H, int W) {
     return (size_t)4 * 9 * 4096 + (size_t)(kRingC + 1) * 1024 + (size_t)kRingC * kRegroup * 4 + (size_t)kRingC * 64 +
-           (128 + kMaxWinPerWg) * 4 + (size_t)rows * (kMaxFramesPerWg + H + W) * 4;
+           (64 + kMaxWinPerWg + 65 + 32 + 16) * 4 + (size_t)rows * (kMaxFramesPerWg + H + W) * 4;   // = the carve-out at the top of the kernel
 }
 
 extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T, int32_t H, int32_t W, int32_t E,
@@ -612,7 +641,12 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T,
     const int per_t = (H / ks) * (W / ks);
     const int span = (wpw + per_t - 2) / per_t + 1;
     HICOM_REQUIRE(span * kt <= kMaxFramesPerWg, HICOM_EUNSUP, "fused_stream: a workgroup would span %d frames", span * kt);
-    HICOM_REQUIRE(kMaxFramesPerWg + H + W <= 16 * (kPosImages / 2), HICOM_EUNSUP, "fused_stream: H + W = %d exceeds the pos-emb slots", H + W);
+    HICOM_REQUIRE(H <= 64 && W <= 64, HICOM_EUNSUP, "fused_stream: grid %dx%d exceeds the pos-emb slot maps", H, W);
+    {   // compact slots a workgroup can touch: 8 frames + the rows and columns of its windows
+        const int rows_t = ((wpw + (W / ks) - 2) / (W / ks) + 1) * ks, cols_t = wpw * ks;
+        HICOM_REQUIRE(kMaxFramesPerWg + (rows_t < H ? rows_t : H) + (cols_t < W ? cols_t : W) <= 64, HICOM_EUNSUP,
+                      "fused_stream: %d windows per workgroup touch too many pos-emb slots", wpw);
+    }
     HICOM_REQUIRE(rows * (kMaxFramesPerWg + H + W) <= 64 * kRingC * kPosPerThread, HICOM_EUNSUP, "fused_stream: pos-emb table too large");
     const size_t smem = ring_lds_bytes(rows, H, W);
     HICOM_REQUIRE(smem <= 163840, HICOM_EUNSUP, "fused_stream: H + W = %d does not fit the LDS budget", H + W);

@@ -337,8 +337,9 @@ def test_fused_stream_matches_separate_kernels(T, H, W, kt, ks):
         wpw = (nw + nparts - 1) // nparts
         per_t = (H // ks) * (W // ks)
         span_frames = ((wpw + per_t - 2) // per_t + 1) * kt          # frames one workgroup may touch
-        lds = 4 * 9 * 4096 + 9 * 1024 + 8 * 80 * 4 + 8 * 64 + (64 + 32) * 4 + R * (8 + H + W) * 4
-        if wpw > 32 or span_frames > 8 or (nparts - 1) * wpw >= nw or lds > 163840 or R * (8 + H + W) > 1024 or 8 + H + W > 64:
+        lds = 4 * 9 * 4096 + 9 * 1024 + 8 * 80 * 4 + 8 * 64 + (64 + 32 + 65 + 32 + 16) * 4 + R * (8 + H + W) * 4
+        if wpw > 32 or span_frames > 8 or (nparts - 1) * wpw >= nw or lds > 163840 or R * (8 + H + W) > 1024 \
+                or 8 + min(H, ((wpw + W // ks - 2) // (W // ks) + 1) * ks) + min(W, wpw * ks) > 64:
             continue                                                  # outside the kernel's LDS-table limits
         ran = True
         pm1, pl1, pa1 = f32((nparts, 16)), f32((nparts, 16)), f32((nparts, 16, E))

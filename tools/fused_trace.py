@@ -72,3 +72,11 @@ for n in names:
     stat(n + " (all tiles)", np.concatenate(agg[n]))
 stat("tile 0: vmcnt wait (first data)", c[:, 2] - c[:, 1])
 stat("loader total", c[:, 1 + 6 * (ntile - 1) + 5] - c[:, 0])
+
+print("---- loader 0, per tile (incl. the pe tiles that follow the %d token tiles): landed-wait | wait[A] | issue ff | wait[B] | issue fe" % ntile)
+for t in range(ntile - 3, ntile + 3):
+    b0 = 1 + 6 * t
+    if (c[:, b0 + 5] <= 0).all():
+        break
+    seg = [c[:, b0 + 1] - c[:, b0], c[:, b0 + 2] - c[:, b0 + 1], c[:, b0 + 3] - c[:, b0 + 2], c[:, b0 + 4] - c[:, b0 + 3], c[:, b0 + 5] - c[:, b0 + 4]]
+    print("tile %2d: " % t + "  ".join("%6.0f" % np.median(x) for x in seg) + ("   next-addr %6.0f" % np.median(c[:, b0 + 6] - c[:, b0 + 5]) if (c[:, b0 + 6] > 0).all() else ""))
