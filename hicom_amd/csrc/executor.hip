@@ -33,7 +33,7 @@ struct WsLayout {
 // ("direct"), plain 1/sqrt(d) logits, windows that partition the grid, <= 14 folded global rows.
 bool can_fuse(const hicom_compressor_args& a) {
     if (!(a.has_local && a.has_global) || !a.lq || a.lq_stride != 0 || a.lq_dt != HICOM_DT_BF16 || a.l2norm != 0) return false;
-    if (a.E != 1152 || a.nq * a.nh > 14) return false;
+    if (a.E != 1152 || a.nq * a.nh > 12) return false;
     for (const hicom_axis* x : {&a.at, &a.ay, &a.ax})
         if (x->n % x->k != 0 || x->nfull != x->nwin) return false;
     if (a.ay.k != a.ax.k) return false;

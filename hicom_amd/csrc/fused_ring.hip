@@ -197,7 +197,23 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
                 }
                 tokslot[lane] = v;
             }
-            __builtin_amdgcn_s_barrier();                              // [B] fe slot of tile t released
+            if (p.pos_a && l >= 1 && t < ntile) {
+                // score-side pos-emb of the R x 16 (row, token) pairs of this tile: the ninth "partial" of the
+                // logit exchange, tabled here (three loader waves) so that no compute wave walks the tables
+                const int q = (l - 1) * 64 + lane;                      // 0 .. 16 R - 1
+                if (q < 16 * R) {
+                    const int prow = q >> 4, pos = q & 15;
+                    const int slot = 4 * fsig(pos >> 2) + (pos & 3);    // token slot held at exchange position `pos`
+                    const int s = t * 16 + slot;
+                    int wr = (int)(((unsigned)s * wsz_magic) >> 16), i = s - wr * p.WSZ;
+                    if (i < 0) { i += p.WSZ; wr -= 1; }
+                    const int txy = win_txy[i], base = wtxy[s < total ? wr : 0];
+                    const int f = (base >> 16) + (txy >> 16), y = ((base >> 8) & 255) + ((txy >> 8) & 255), x = (base & 255) + (txy & 255);
+                    const float* ap = a_pos + prow * (kMaxFramesPerWg + p.H + p.W);
+                    red[kRingC * 256 + q] = ap[f] + ap[kMaxFramesPerWg + y] + ap[kMaxFramesPerWg + p.H + x];
+                }
+            }
+            lds_barrier();                                             // [B] fe slot of tile t released; the tables written above are visible
             HICOM_TR(2);   // tile: past [B]
             if (t + 2 < ntot) issue(t + 2 < ntile ? p.fe : p.pe_hi, o_fe, febuf + (t & 1) * TILE_BYTES);
             HICOM_TR(2);   // tile: fe issued
@@ -334,19 +350,6 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
             bfe_t = *reinterpret_cast<const bf16x4*>(feimg + off);
             bff_t = *reinterpret_cast<const bf16x4*>(ffimg + off);
         }
-        // score-side pos-emb of the R x 16 (row, token) pairs of this tile: a ninth "partial" of the exchange,
-        // two pairs per... one pair per lane on 2R lanes of every wave
-        if (p.pos_a && lane < 2 * R) {
-            const int q = wave * 2 * R + lane;                          // 0 .. 16 R - 1
-            const int row = q >> 4, pos = q & 15;
-            const int slot = 4 * fsig(pos >> 2) + (pos & 3);            // token slot held at exchange position `pos`
-            int oi = i0 + slot, owr = wr0;
-            if (oi >= p.WSZ) { oi -= p.WSZ; owr += 1; }
-            const int txy = win_txy[oi], base = wtxy[(s0 + slot < total) ? owr : 0];
-            const int f = (base >> 16) + (txy >> 16), y = ((base >> 8) & 255) + ((txy >> 8) & 255), x = (base & 255) + (txy & 255);
-            const float* ap = a_pos + row * (kMaxFramesPerWg + p.H + p.W);
-            red[kRingC * 256 + q] = ap[f] + ap[kMaxFramesPerWg + y] + ap[kMaxFramesPerWg + p.H + x];
-        }
         f32x4 e0 = f32x4{0.f, 0.f, 0.f, 0.f}, f0 = e0, f1 = e0;
 #pragma unroll
         for (int s = 0; s < K32; ++s) {
@@ -359,6 +362,11 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
             f0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bff_t, ahi_t, f0, 0, 0, 0);
             f1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bff_t, alo_t, f1, 0, 0, 0);
         }
+        // The accumulators are read by VALU right away.  hipcc pads an MFMA -> VALU read with the wait states of
+        // its own latency table, and for the K = 16 tail (v_mfma_f32_16x16x16_bf16 on gfx950) that padding proved
+        // too short under load: logits of a tile came out stale whenever a co-resident wave delayed the matrix
+        // pipe (timing-dependent corruption of single tiles).  Sixteen explicit wait states close the hazard.
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
         {
             const f32x4 part_logit = (r16 < R) ? (f0 + f1) : e0;
             *reinterpret_cast<f32x4*>(red + wave * 256 + r16 * 16 + 4 * kg) = part_logit;
@@ -425,7 +433,6 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
         // the weights: MG += P . onehot(slot of each token) over the slots  frame (relative to this workgroup's
         // first frame) | grid row | grid column -- one more MFMA per tile on the wave that owns the 16-slot
         // block.  Rescaled by alpha like ACC.  Part 2 (after the stream) multiplies MG by the pe rows.
-#ifndef X_NO_MARG
         if (p.pe_hi && wave < nslot_tiles) {
             const int col = 16 * wave + r16;
             bf16x4 bm;
@@ -438,10 +445,10 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
             }
             const bf16x8 bm2 = bf16x8{bm[0], bm[1], bm[2], bm[3], bm[0], bm[1], bm[2], bm[3]};
             const f32x4 mg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pw, bm2, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");             // MFMA -> VALU read, as above
 #pragma unroll
             for (int j = 0; j < 4; ++j) mgacc[j] = fmaf(mgacc[j], al[j], mg[j]);
         }
-#endif
         // ---- ACC += P . x: all transposed fragment reads of the slice in flight, then the MFMAs ------------
         {
             const unsigned img_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(ffimg);
@@ -630,7 +637,7 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T,
                   "fused_stream: windows must partition the [%d,%d,%d] grid exactly", T, H, W);
     const int wsz = kt * ks * ks;
     HICOM_REQUIRE(wsz >= 16 && wsz <= 64, HICOM_EUNSUP, "fused_stream: window of %d tokens (16..64 supported)", wsz);
-    HICOM_REQUIRE(rows > 0 && rows <= 14, HICOM_EUNSUP, "fused_stream: %d global rows (<= 14: >= 2 local rows needed)", rows);
+    HICOM_REQUIRE(rows > 0 && rows <= 12, HICOM_EUNSUP, "fused_stream: %d global rows (<= 12 supported)", rows);
     HICOM_REQUIRE(H < 256 && W < 256 && (long)T * H * W < (1L << 31), HICOM_EUNSUP, "fused_stream: grid too large");
     const int NW = (T / kt) * (H / ks) * (W / ks);
     HICOM_REQUIRE(nparts > 0 && nparts <= NW, HICOM_EINVAL, "fused_stream: nparts");

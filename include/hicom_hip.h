@@ -153,7 +153,7 @@ int hicom_global_stream_nparts(int64_t N, int32_t rows_pad);
  * (projector.py:544-558, guide as the shared query) and the global online-softmax partial state
  * (projector.py:193-215): each visual tensor is read from HBM exactly once.
  * Requirements: windows partition the grid exactly (T % kt == H % ks == W % ks == 0), 16 <= kt*ks*ks
- * <= 64, rows <= 14 global folded rows, E == 1152.
+ * <= 64, rows <= 12 global folded rows, E == 1152.
  *   q_hi / q_lo : bf16 [16, E]; rows < `rows` = folded global queries (hi / lo), rows >= `rows` =
  *                 the local query in q_hi (exact bf16) and zeros in q_lo
  *   pos_a       : f32 [16, pos_stride] score-side pos-emb  a[r, p] = qt_r . pe[p]  (hicom_fold_query_split_fwd),
