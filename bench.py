@@ -105,7 +105,8 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=64)
     ap.add_argument("--hidden", type=int, default=896)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay of the plan")
+    ap.add_argument("--graph", action="store_true", help="hipGraph replay of the cached plan (measured slower than the C launch loop on ROCm 7.2)")
+    ap.add_argument("--no-graph", action="store_true", help="(default) eager launches: one C call per step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,7 +127,7 @@ def main():
     total_frames = fpg * world
     cfg = release_config(args.hidden, total_frames)
     module = make_projector(cfg, device)
-    module.graph_replay = not args.no_graph and not distributed
+    module.graph_replay = args.graph and not args.no_graph and not distributed
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     ff = torch.randn(fpg, GRID, GRID, D, device=device, generator=gen).to(torch.bfloat16)
     fe = torch.randn(fpg, GRID, GRID, D, device=device, generator=gen).to(torch.bfloat16)
