@@ -79,8 +79,18 @@ struct RingParams {
     int wpw;               // windows per workgroup
 };
 
-__device__ __forceinline__ int fswz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+// Position of 16-byte chunk c of image row r inside the row: c ^ fswz(r).  The row -> XOR map is chosen so that
+//  * the score fragment reads (ds_read_b128; the hardware services lanes in four 16-lane groups, each mixing the
+//    rows {0-3, 12-15} at chunk c with the rows {4-11} at chunk c ^ 1, c even) hit 16 distinct slots: both row
+//    sets map to whole {2m, 2m+1} pairs; and
+//  * the transposed reads (ds_read_b64_tr_b16; 32-lane groups, rows {0-3, 8-11} or {4-7, 12-15}, chunks c and
+//    c ^ 1) hit 32 distinct bank pairs: the 8 rows of a group fall into 8 different pairs.
+// rows 0-3 -> 0,2,4,6   4-7 -> 8,10,12,14   8-11 -> 9,11,13,15   12-15 -> 1,3,5,7
+__device__ __forceinline__ int fswz(int r) { return ((r & 3) << 1) | ((r >> 3) & 1) | ((((r >> 2) ^ (r >> 3)) & 1) << 3); }
 __device__ __forceinline__ int fsig(int g) { return ((g & 1) << 1) | (g >> 1); }
+// float4 group of (row, k-group) inside a row of the logit exchange: rows 8-15 store their groups in reverse
+// pairing so that the four 16-lane service groups of a ds_read/write_b128 hit 16 distinct slots
+__device__ __forceinline__ int fxg(int row, int kg) { return kg ^ (((row >> 3) & 1) * 3); }
 
 template <int NB>
 __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams p) {
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
     constexpr int PIECES = NB * 4;                 // 1-KiB DMA pieces per image: (128-channel block, 4-token row group)
     constexpr int PPL = PIECES / kRingL;           // pieces per loader wave and image
     static_assert(E % (16 * kRingC) == 0 && PIECES % kRingL == 0 && kRingL == 4, "slice / piece split");
-    static_assert(SLICE % 4 == 0 && SLICE / 4 <= 64, "row regroup: one float4 per lane");
+    static_assert(SLICE % 16 == 0 && kRegroup % 16 == 0 && kRegroup / 4 <= 64, "row regroup: hops of kRegroup channels, one float4 per lane");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ffbuf = smem;                                                // [2][TILE_BYTES] frames_feature ring
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
                 const int q = (l - 1) * 64 + lane;                      // 0 .. 16 R - 1
                 if (q < 16 * R) {
                     const int prow = q >> 4, pos = q & 15;
-                    const int slot = 4 * fsig(pos >> 2) + (pos & 3);    // token slot held at exchange position `pos`
+                    const int slot = 4 * fsig(fxg(prow, pos >> 2)) + (pos & 3);   // token slot held at exchange position `pos`
                     const int s = t * 16 + slot;
                     int wr = (int)(((unsigned)s * wsz_magic) >> 16), i = s - wr * p.WSZ;
                     if (i < 0) { i += p.WSZ; wr -= 1; }
@@ -315,6 +325,27 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
     const int ts0 = 4 * fsig(kg);                                            // first token slot of this lane
     float* ascr = alpha_s + 16 * wave;                                       // wave-private: alpha in accumulator-row order
 
+    // one P.x step over a 16-row image: ACC[u] += A(16 rows x [hi | lo of 16 rows' weights]) . [x ; x] per 16-channel block
+    constexpr int PG = (KS % 6 == 0 && KS > 9) ? 6 : KS;               // blocks whose fragments are in flight together
+    auto px_step = [&](unsigned img_lds, const bf16x8& a_op, f32x4 (&accr)[KS]) {
+#pragma unroll
+        for (int g0 = 0; g0 < KS; g0 += PG) {
+            bf16x4 bv[PG];
+#pragma unroll
+            for (int u = 0; u < PG; ++u) {
+                const int ch0 = ch_base + 16 * (g0 + u);
+                const unsigned addr = img_lds + (ch0 >> 7) * 4096 + tr_row_off + 16 * ((((ch0 & 127) >> 3) + (pp >> 1)) ^ tr_swz);
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(bv[u]) : "v"(addr));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < PG; ++u) {
+                const bf16x8 b2 = bf16x8{bv[u][0], bv[u][1], bv[u][2], bv[u][3], bv[u][0], bv[u][1], bv[u][2], bv[u][3]};
+                accr[g0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_op, b2, accr[g0 + u], 0, 0, 0);
+            }
+        }
+    };
     HICOM_TR(0); HICOM_TR(1);   // prologue done (this wave)
     lds_barrier();                                                     // [P] tables ready
     const int nslot_tiles = p.pe_hi ? (__builtin_amdgcn_readfirstlane(slot_row[64]) + 15) >> 4 : 0;   // 16-slot tiles of the compact pos-emb slots
@@ -335,15 +366,10 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
         const int rowB = (rowA + 1 < 16) ? rowA + 1 : R;
 
         // ---- logits, transposed: A = token rows of both images, B = the query fragments ---------------
-        bf16x8 bfe[K32], bff[K32];
+        // fragment reads in groups of KG K-steps (both images), each group's reads in flight together: bounds the
+        // registers the fragments hold (fat slices) while keeping one LDS round trip per group
+        constexpr int KG = (K32 % 3 == 0 && K32 > 4) ? 3 : K32;
         bf16x4 bfe_t, bff_t;
-#pragma unroll
-        for (int s = 0; s < K32; ++s) {
-            const int cc = ((ch_base + 32 * s) >> 3) + kg;              // 16-byte chunk of this lane over the whole row
-            const int off = (cc >> 4) * 4096 + rd_row + 16 * ((cc & 15) ^ rd_swz);
-            bfe[s] = *reinterpret_cast<const bf16x8*>(feimg + off);
-            bff[s] = *reinterpret_cast<const bf16x8*>(ffimg + off);
-        }
         if (KTAIL) {
             const int cc = ((ch_base + 32 * K32) >> 3) + (kg >> 1);
             const int off = (cc >> 4) * 4096 + rd_row + 16 * ((cc & 15) ^ rd_swz) + 8 * (kg & 1);
@@ -352,10 +378,23 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
         }
         f32x4 e0 = f32x4{0.f, 0.f, 0.f, 0.f}, f0 = e0, f1 = e0;
 #pragma unroll
-        for (int s = 0; s < K32; ++s) {
-            e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfe[s], ahi[s], e0, 0, 0, 0);
-            f0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bff[s], ahi[s], f0, 0, 0, 0);
-            f1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bff[s], alo[s], f1, 0, 0, 0);
+        for (int g0 = 0; g0 < K32; g0 += KG) {
+            bf16x8 bfe[KG], bff[KG];
+#pragma unroll
+            for (int u = 0; u < KG; ++u) {
+                const int cc = ((ch_base + 32 * (g0 + u)) >> 3) + kg;   // 16-byte chunk of this lane over the whole row
+                const int off = (cc >> 4) * 4096 + rd_row + 16 * ((cc & 15) ^ rd_swz);
+                bfe[u] = *reinterpret_cast<const bf16x8*>(feimg + off);
+                bff[u] = *reinterpret_cast<const bf16x8*>(ffimg + off);
+            }
+            if (KG < K32) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < KG; ++u) {
+                e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfe[u], ahi[g0 + u], e0, 0, 0, 0);
+                f0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bff[u], ahi[g0 + u], f0, 0, 0, 0);
+                f1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bff[u], alo[g0 + u], f1, 0, 0, 0);
+            }
+            if (KG < K32) __builtin_amdgcn_sched_barrier(0);
         }
         if (KTAIL) {
             e0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bfe_t, ahi_t, e0, 0, 0, 0);
@@ -369,7 +408,7 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
         {
             const f32x4 part_logit = (r16 < R) ? (f0 + f1) : e0;
-            *reinterpret_cast<f32x4*>(red + wave * 256 + r16 * 16 + 4 * kg) = part_logit;
+            *reinterpret_cast<f32x4*>(red + wave * 256 + r16 * 16 + 4 * fxg(r16, kg)) = part_logit;
         }
         HICOM_TR(0); HICOM_TR(1);   // tile: arrive [B]
         lds_barrier();                                                 // [B] channel-slice partials exchanged
@@ -378,8 +417,8 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
         // ---- softmax of (row r16, 4 token slots) in registers, identically in every wave ---------------
         f32x4 lg = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < kRingC; ++k) lg += *reinterpret_cast<const f32x4*>(red + k * 256 + r16 * 16 + 4 * kg);
-        if (p.pos_a && r16 < R) lg += *reinterpret_cast<const f32x4*>(red + kRingC * 256 + r16 * 16 + 4 * kg);
+        for (int k = 0; k < kRingC; ++k) lg += *reinterpret_cast<const f32x4*>(red + k * 256 + r16 * 16 + 4 * fxg(r16, kg));
+        if (p.pos_a && r16 < R) lg += *reinterpret_cast<const f32x4*>(red + kRingC * 256 + r16 * 16 + 4 * fxg(r16, kg));
         float pr[4];
         float tmax = -1.0e30f;
         bool valid[4];
@@ -449,23 +488,10 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
 #pragma unroll
             for (int j = 0; j < 4; ++j) mgacc[j] = fmaf(mgacc[j], al[j], mg[j]);
         }
-        // ---- ACC += P . x: all transposed fragment reads of the slice in flight, then the MFMAs ------------
+        // ---- ACC += P . x: the transposed fragment reads in groups of PG blocks in flight, then their MFMAs --------
         {
             const unsigned img_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(ffimg);
-            bf16x4 bv[KS];
-#pragma unroll
-            for (int u = 0; u < KS; ++u) {
-                const int ch0 = ch_base + 16 * u;
-                const unsigned addr = img_lds + (ch0 >> 7) * 4096 + tr_row_off + 16 * ((((ch0 & 127) >> 3) + (pp >> 1)) ^ tr_swz);
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(bv[u]) : "v"(addr));
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < KS; ++u) {
-                const bf16x8 b2 = bf16x8{bv[u][0], bv[u][1], bv[u][2], bv[u][3], bv[u][0], bv[u][1], bv[u][2], bv[u][3]};
-                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pw, b2, acc[u], 0, 0, 0);
-            }
+            px_step(img_lds, pw, acc);
         }
 
         HICOM_TR(0); HICOM_TR(1);   // tile: P.x issued
@@ -546,20 +572,7 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
                 if (plane == 1) lds_barrier();                         // [B] hi-plane slot released
                 const char* img = (plane == 0 ? febuf : ffbuf) + (t & 1) * TILE_BYTES;
                 const unsigned img_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(img);
-                bf16x4 bv[KS];
-#pragma unroll
-                for (int u = 0; u < KS; ++u) {
-                    const int ch0 = ch_base + 16 * u;
-                    const unsigned addr = img_lds + (ch0 >> 7) * 4096 + tr_row_off + 16 * ((((ch0 & 127) >> 3) + (pp >> 1)) ^ tr_swz);
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(bv[u]) : "v"(addr));
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < KS; ++u) {
-                    const bf16x8 b2 = bf16x8{bv[u][0], bv[u][1], bv[u][2], bv[u][3], bv[u][0], bv[u][1], bv[u][2], bv[u][3]};
-                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pwp, b2, acc[u], 0, 0, 0);
-                }
+                px_step(img_lds, pwp, acc);
             }
         }
     }
