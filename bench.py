@@ -136,7 +136,9 @@ def main():
 
     def step():
         if distributed:
-            return sharded_forward(module, ff, fe, guide, total_frames)
+            # deferred: the token all-gather of step i (comm stream, second buffer set) overlaps the streaming of
+            # step i+1; fence() below waits for every stream before the clock stops
+            return sharded_forward(module, ff, fe, guide, total_frames, deferred=True)[0]
         return module(ff, fe, guide, "video", None)
 
     def fence():

@@ -251,6 +251,19 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const void* src, int 
     }
 }
 
+// Rows of `nblocks` equal blocks that sit `block_stride` bytes apart (the per-rank segments of an all-gathered
+// buffer) -> consecutive packed rows of the output (newline rows skipped every nl_group rows).  Same dtype on
+// both sides: 16-byte copies, four rows per workgroup.
+__global__ __launch_bounds__(256) void place_blocks_kernel(const char* src, int block_rows, long block_stride, int row_bytes,
+                                                           char* dst, long ldd_bytes, long row0, int nl_group, int count) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= count) return;
+    const int b = i / block_rows, r = i - b * block_rows;
+    const char* s = src + (long)b * block_stride + (long)r * row_bytes;
+    char* d = dst + (row0 + i + (nl_group > 0 ? i / nl_group : 0)) * ldd_bytes;
+    for (int c = lane * 16; c < row_bytes; c += 64 * 16) *reinterpret_cast<u32x4*>(d + c) = *reinterpret_cast<const u32x4*>(s + c);
+}
+
 }  // namespace hicom
 
 using namespace hicom;
@@ -349,4 +362,17 @@ extern "C" int hicom_scatter_rows_fwd(const void* src, int32_t src_dt, int32_t s
                        src_dt == HICOM_DT_F32, src_rows, ncols, dst, dst_dt == HICOM_DT_F32, (long)ldd, (long)row0,
                        (long)row_step, nl_group, count);
     return hicom_host::check_launch("scatter_rows");
+}
+
+extern "C" int hicom_place_blocks_fwd(const void* src, int32_t block_rows, int32_t nblocks, int64_t block_stride_bytes,
+                                      int32_t row_bytes, void* dst, int64_t ldd_bytes, int64_t row0, int32_t nl_group,
+                                      void* stream) {
+    HICOM_REQUIRE(src && dst, HICOM_EINVAL, "place_blocks: NULL pointer");
+    HICOM_REQUIRE(block_rows > 0 && nblocks > 0 && row_bytes > 0 && row_bytes % 16 == 0 && ldd_bytes >= row_bytes && ldd_bytes % 16 == 0 &&
+                      block_stride_bytes % 16 == 0 && nl_group >= 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0),
+                  HICOM_EINVAL, "place_blocks: bad shape / alignment");
+    const int count = block_rows * nblocks;
+    hipLaunchKernelGGL(place_blocks_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const char*)src,
+                       block_rows, (long)block_stride_bytes, row_bytes, (char*)dst, (long)ldd_bytes, (long)row0, nl_group, count);
+    return hicom_host::check_launch("place_blocks");
 }

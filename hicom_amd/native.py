@@ -27,7 +27,7 @@ EXPORTS = (
     "hicom_readout_gemm_fwd", "hicom_scatter_rows_fwd", "hicom_fold_query_split_fwd",
     "hicom_global_combine_strided_fwd", "hicom_compressor_workspace_bytes", "hicom_compressor_zero_prefix_bytes",
     "hicom_compressor_fwd", "hicom_linear_to_rows_fwd", "hicom_fused_stream_fwd", "hicom_fused_stream_nparts",
-    "hicom_planes_gemm_fwd", "hicom_row_ln_fwd", "hicom_small_mha_fwd",
+    "hicom_planes_gemm_fwd", "hicom_row_ln_fwd", "hicom_small_mha_fwd", "hicom_place_blocks_fwd",
 )
 
 PHASE_STREAM, PHASE_FINISH = 1, 2
@@ -116,6 +116,7 @@ def lib() -> C.CDLL:
     L.hicom_global_combine_fwd.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     L.hicom_readout_gemm_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i64, i64, i32, vp]
     L.hicom_scatter_rows_fwd.argtypes = [vp, i32, i32, i32, vp, i32, i64, i64, i64, i32, i32, vp]
+    L.hicom_place_blocks_fwd.argtypes = [vp, i32, i32, i64, i32, vp, i64, i64, i32, vp]
     for name in EXPORTS[2:]:
         getattr(L, name).restype = C.c_int
     L.hicom_compressor_workspace_bytes.restype = C.c_int64
@@ -232,6 +233,12 @@ def scatter_rows(src, dst, row0, count, row_step=1, nl_group=0):
     src2 = src.reshape(-1, src.shape[-1])
     _check(lib().hicom_scatter_rows_fwd(_ptr(src2), _dt(src2), src2.shape[0], src2.shape[1], _ptr(dst), _dt(dst),
                                         dst.shape[-1], row0, row_step, nl_group, count, _stream()), "hicom_scatter_rows_fwd")
+
+
+def place_blocks(src_ptr: int, block_rows, nblocks, block_stride_bytes, row_bytes, dst, row0, nl_group=0, stream=None):
+    _check(lib().hicom_place_blocks_fwd(src_ptr, block_rows, nblocks, block_stride_bytes, row_bytes, _ptr(dst),
+                                        dst.shape[-1] * dst.element_size(), row0, nl_group, _stream() if stream is None else stream),
+           "hicom_place_blocks_fwd")
 
 
 def fold_query_split(qp, w_k, kpe, nh, scale, qhi, qlo, pos_a, fill_row=None, fill_row0=0, fill_rows=0):

@@ -223,6 +223,14 @@ int hicom_scatter_rows_fwd(const void* src, int32_t src_dt, int32_t src_rows, in
                            void* dst, int32_t dst_dt, int64_t ldd, int64_t row0, int64_t row_step,
                            int32_t nl_group, int32_t count, void* stream);
 
+/* Rows of `nblocks` equal blocks lying `block_stride_bytes` apart (the per-rank segments of an all-gathered
+ * buffer) -> consecutive packed rows of dst starting at row0, skipping one row after every nl_group rows (the
+ * newline slots of mm_utils.py:100-135); same dtype on both sides, rows and strides multiples of 16 bytes.
+ * Used by the frame-sharded path to place every rank's local tokens with one launch. */
+int hicom_place_blocks_fwd(const void* src, int32_t block_rows, int32_t nblocks, int64_t block_stride_bytes,
+                           int32_t row_bytes, void* dst, int64_t ldd_bytes, int64_t row0, int32_t nl_group,
+                           void* stream);
+
 /* Same, with the per-set (M,L) pairs and ACC blocks `set_stride` floats apart (the layout of the
  * all-gathered per-rank buffers): ml_k = ml + k*set_stride, acc_k = acc + k*set_stride. */
 int hicom_global_combine_strided_fwd(const float* ml, const float* acc, int64_t set_stride, int32_t nsets,
