@@ -112,7 +112,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # HICOM_BENCH_FORCE_DIST=1: take the frame-sharded code path at world size 1 (one-GPU check of the N > 1 branch)
+    distributed = world > 1 or os.environ.get("HICOM_BENCH_FORCE_DIST") == "1"
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
@@ -121,6 +122,9 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)      # "nccl" is RCCL on ROCm
 
     fpg = args.frames_per_gpu
