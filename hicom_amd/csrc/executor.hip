@@ -187,6 +187,10 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         // main: q_proj, fold (+ guide -> local rows of the A operand), fused stream      | fork |
         // main: readout GEMMs            side: merge -> (finish)                 | join |
         CHK(query_prep(sm, true));
+        // the stream kernel overwrites the partial states: the previous call's merge (side stream, possibly still
+        // running when that call deferred its join) has to be done with them
+        if (a.ev_merge)
+            HICOM_REQUIRE(hipStreamWaitEvent(sm, (hipEvent_t)a.ev_merge, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
         CHK(hicom_fused_stream_fwd(a.ff, a.fe ? a.fe : a.ff, a.T, a.H, a.W, a.E, a.at.k, a.ay.k, ws + w.qhi, ws + w.qlo,
                                    w.R, a.l_scale, a.l_bias, a.pe ? F(w.pos_a) : nullptr, a.P, a.pe ? a.pe_hi : nullptr, a.pe ? a.pe_lo : nullptr, a.t_index0, a.y_index0,
                                    a.x_index0, F(w.part_m), F(w.part_l), F(w.part_acc),
@@ -195,6 +199,8 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         // the value-side pos-emb is already inside the partial contexts: a plain merge, one launch
         CHK(hicom_global_merge_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E, nullptr, 0, w.N,
                                    a.H, a.W, nullptr, 0, 0, 0, nullptr, ml_out, acc_out, solo ? 1 : 0, ss));
+        if (a.ev_merge)
+            HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_merge, ss) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
         // readout MLP on bf16 planes: contexts (hi/lo) -> hidden (hi/lo) -> packed output rows
         CHK(hicom_planes_gemm_fwd(ws + w.ctx_hi, ws + w.ctx_lo, a.lw0, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E,
                                   HICOM_ACT_GELU, ws + w.hid_hi, ws + w.hid_lo, nullptr, 0, 0, 0, 0, sm));
@@ -254,7 +260,9 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
 
     if (both && do_stream) {
         HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_join, ss) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
-        HICOM_REQUIRE(hipStreamWaitEvent(sm, (hipEvent_t)a.ev_join, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
+        const bool defer = fused && a.defer_join && a.ev_merge;      // the caller joins on ev_join itself
+        if (!defer)
+            HICOM_REQUIRE(hipStreamWaitEvent(sm, (hipEvent_t)a.ev_join, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
     }
     return HICOM_OK;
 }

@@ -21,10 +21,14 @@ class _DeviceResources:
         self.side = torch.cuda.Stream(device=device, priority=-1)
         self.ev_fork = torch.cuda.Event()
         self.ev_join = torch.cuda.Event()
+        self.ev_merge = torch.cuda.Event()
         # hipEventRecord needs created events: torch creates them lazily on first record
         cur = torch.cuda.current_stream(device)
         self.ev_fork.record(cur)
         self.ev_join.record(cur)
+        self.ev_merge.record(cur)
+        self.done = [torch.cuda.Event() for _ in range(16)]     # per-call completion events of deferred forwards
+        self.n_done = 0
 
 
 _RES: Dict[Tuple[int, int], _DeviceResources] = {}
@@ -157,6 +161,7 @@ def attach_execution(a: nv.CompressorArgs, device, key_extra=(), main_stream=Non
     a.stream_main = main_stream.cuda_stream
     a.stream_side = res.side.cuda_stream
     a.ev_fork, a.ev_join = res.ev_fork.cuda_event, res.ev_join.cuda_event
+    a.ev_merge, a.defer_join = res.ev_merge.cuda_event, 0
     return a
 
 
@@ -196,14 +201,18 @@ def _plan_key(proj, ff, fe, guide_embed, modal, image_newline, out_dtype):
             0 if proj.global_compressor is None else proj.global_compressor._cache_gen, _param_stamp(proj))
 
 
-def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype) -> torch.Tensor:
+def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferred: bool = False):
     """HIComProjector.forward for a dense [T,H,W,E] input through hicom_compressor_fwd.
 
     Plans (argument blocks) are cached per input-buffer identity, so a repeated call costs one
     ctypes call.  With `proj.graph_replay = True` the launch sequence of a plan is captured into a
     hipGraph on its second use and replayed afterwards (one graph launch + one device copy of the
     result), which removes the per-kernel host launch cost from steady-state serving loops that
-    reuse their feature buffers."""
+    reuse their feature buffers.
+
+    deferred=True returns (out, event): the main stream does not wait for the side stream's global chain (merge +
+    the four small linears that produce the 32 global rows); `event` fires when they are written.  Back-to-back
+    forwards of independent videos then overlap that latency-bound chain with the next video's streaming."""
     from .projector import _require_bf16_cuda
     _require_bf16_cuda("frames_feature", ff)          # fail loudly on CPU tensors before touching any stream
     lc, gc = proj.local_compressor, proj.global_compressor
@@ -227,13 +236,15 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype) -> tor
         out = torch.empty((n_local + n_global, hidden), dtype=out_dtype, device=ff.device)
         a = build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, global_row0=n_local)
         attach_execution(a, ff.device)
+        a.defer_join = int(bool(deferred))
         nv.compressor_fwd(a)
+        done = _record_done(ff.device) if deferred else None
         if cacheable:
             a._keep = None             # do not pin the caller's feature tensors
             if len(plans) >= _MAX_PLANS:
                 plans.pop(next(iter(plans)))
             plans[key] = _Plan(a, n_local + n_global, hidden)
-        return out
+        return (out, done) if deferred else out
     plan.hits += 1
     a = plan.args
     if getattr(proj, "graph_replay", False):
@@ -252,8 +263,20 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype) -> tor
         return plan.static_out.clone()                 # callers own their result (no aliasing across calls)
     out = torch.empty((plan.rows, plan.hidden), dtype=out_dtype, device=ff.device)
     a.out = out.data_ptr()
+    a.defer_join = int(bool(deferred))
     nv.compressor_fwd(a)
+    if deferred:
+        return out, _record_done(ff.device)
     return out
+
+
+def _record_done(device):
+    """Completion event of the side stream's chain of the call just enqueued (a small ring of reusable events)."""
+    res = _resources(device)
+    ev = res.done[res.n_done % len(res.done)]
+    res.n_done += 1
+    ev.record(res.side)
+    return ev
 
 
 # ---------------------------------------------------------------------------------------------

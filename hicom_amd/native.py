@@ -66,6 +66,7 @@ class CompressorArgs(C.Structure):
         ("state_set_stride", C.c_int64),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("stream_main", C.c_void_p), ("stream_side", C.c_void_p), ("ev_fork", C.c_void_p), ("ev_join", C.c_void_p),
+        ("ev_merge", C.c_void_p), ("defer_join", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 

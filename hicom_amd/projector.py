@@ -479,6 +479,18 @@ class HIComProjector(nn.Module):
                                     _out_dtype(self))
         return self.forward_stepwise(frames_feature, frames_embed, guide_embed, modal, image_newline)
 
+    def forward_deferred(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None):
+        """forward() without the final join of the side stream: returns (out, event).  The local rows of `out`
+        are ordered on the caller's stream as usual; its 32 global rows are complete once `event` has fired
+        (`torch.cuda.current_stream().wait_event(event)` before consuming them).  A serving loop that issues
+        independent videos back to back hides the latency-bound global chain behind the next video's streaming."""
+        plain = all(c is None or c.is_plain for c in (self.local_compressor, self.global_compressor))
+        if not plain or isinstance(frames_feature, dict) or getattr(self, "graph_replay", False):
+            raise NotImplementedError("forward_deferred: dense inputs of the plain recipes, eager launches")
+        from . import engine
+        return engine.run_dense(self, frames_feature, frames_embed, guide_embed, modal, image_newline, _out_dtype(self),
+                                deferred=True)
+
     def forward_async(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None, lanes: int = 2):
         """forward() for serving loops: the call is enqueued on one of `lanes` internal stream sets and a
         handle is returned at once; handle.wait() yields the tensor (ordered on the caller's stream).

@@ -311,6 +311,13 @@ typedef struct hicom_compressor_args {
     void* ws;
     int64_t ws_bytes;
     void *stream_main, *stream_side, *ev_fork, *ev_join;
+    /* Deferred join (release recipe only): with defer_join != 0 the main stream does NOT wait for the side stream's
+     * global chain at the end of the call -- the 32 global rows of `out` are complete when ev_join (recorded on the
+     * side stream) has fired, so the chain of one video overlaps the streaming of the next.  ev_merge (may be NULL
+     * when defer_join == 0) is recorded after the merge kernel and waited on before the next stream kernel, which
+     * overwrites the partial states the merge reads. */
+    void* ev_merge;
+    int32_t defer_join, reserved_;
 } hicom_compressor_args;
 
 int64_t hicom_compressor_workspace_bytes(const hicom_compressor_args* args);

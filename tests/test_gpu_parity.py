@@ -180,6 +180,25 @@ def test_executor_equals_stepwise(name):
     assert torch.equal(a, a2)
 
 
+def test_forward_deferred_equals_forward(c2):
+    """forward_deferred (no join of the side stream at the end of a call) gives, for DIFFERENT videos issued back
+    to back, exactly the bits of the joined forward of each -- also when interleaved with joined calls."""
+    m, ff, fe, g, _ = c2
+    vids = [(ff, fe), (fe, ff), (ff.flip(0).contiguous(), fe), (ff, fe)]
+    with torch.no_grad():
+        want = [m(a, b, g, "video", None).clone() for a, b in vids]
+        for rep in range(3):
+            got = [m.forward_deferred(a, b, g, "video", None) for a, b in vids for _ in range(2)]
+            mid = m(fe, ff, g, "video", None)                       # a joined call right behind deferred ones
+            more = [m.forward_deferred(a, b, g, "video", None) for a, b in vids]
+            torch.cuda.synchronize()
+            assert torch.equal(mid, want[1])
+            for k, (o, ev) in enumerate(got):
+                assert ev.query() and torch.equal(o, want[k // 2]), (rep, k)
+            for k, (o, ev) in enumerate(more):
+                assert torch.equal(o, want[k]), (rep, "more", k)
+
+
 def test_forward_async_lanes_equal_forward(c2):
     """forward_async (alternating stream lanes) returns, for a stream of DIFFERENT videos submitted back to
     back, exactly the bits of the synchronous forward of each."""
