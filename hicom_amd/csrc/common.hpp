@@ -82,7 +82,20 @@ __device__ __forceinline__ float wave_max(float v) {
 // orders below the 1e-3 parity budget.  x = -1e30 (masked / first tile) gives exactly 0.
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-GELU (nn.GELU() default, reference projector.py:309).  erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, one
+// exp2 + one rcp): libm's erff is ~60 VALU instructions, which in a GEMM epilogue with one wave per SIMD was a
+// quarter of the kernel.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float tail = poly * t * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);   // 1 - erf(z), z >= 0
+    // 1 + erf(x/sqrt2) = 2 - tail (x >= 0) or tail (x < 0)
+    return 0.5f * x * (x >= 0.f ? 2.0f - tail : tail);
+}
 
 // start of window i along an axis (projector.py:501-522 restated in closed form)
 __device__ __host__ __forceinline__ int axis_start(const hicom_axis& a, int i) {

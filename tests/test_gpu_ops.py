@@ -359,7 +359,9 @@ def test_fused_stream_matches_separate_kernels(T, H, W, kt, ks):
     assert ran
 
 
-@pytest.mark.parametrize("M,N,K,act", [(8, 64, 1152, 1), (81, 896, 1152, 1), (130, 64, 64, 0), (1296, 896, 896, 0), (1296, 896, 1152, 1)])
+@pytest.mark.parametrize("M,N,K,act", [(8, 64, 1152, 1), (81, 896, 1152, 1), (130, 64, 64, 0), (1296, 896, 896, 0), (1296, 896, 1152, 1),
+                                       (50, 200, 128, 1), (97, 66, 192, 0), (49, 130, 256, 1), (300, 257, 320, 0), (48, 128, 384, 1),
+                                       (1, 4, 448, 0)])
 def test_planes_gemm_matches_torch(M, N, K, act):
     x = synth.normal_like((M, K), 91)
     x = (x + synth.normal_like((M, K), 95) * 2.0 ** -10).astype(np.float32)   # NOT bf16-representable
@@ -381,6 +383,15 @@ def test_planes_gemm_matches_torch(M, N, K, act):
     rows = torch.tensor([2 + m + m // 9 for m in range(M)])
     assert maxabs(y.cpu()[rows], want) <= tol
     assert float(y[:2].abs().max()) == 0.0
+    # bf16 output rows, and the hi-plane-only form (exactly-bf16 activations)
+    yb = torch.zeros((M + M // 9 + 4, N), dtype=torch.bfloat16, device="cuda")
+    nv.planes_gemm(a_hi, a_lo, bf(w), bf(b), act=act, y=yb, row0=2, nl_group=9)
+    assert torch.equal(yb[rows.cuda()], y[rows.cuda()].bfloat16())
+    want_hi = a_hi.double().cpu() @ torch.from_numpy(w).double().t() + torch.from_numpy(b).double()
+    if act:
+        want_hi = 0.5 * want_hi * (1 + torch.erf(want_hi / math.sqrt(2)))
+    nv.planes_gemm(a_hi, None, bf(w), bf(b), act=act, out_hi=o_hi, out_lo=o_lo)
+    assert maxabs(o_hi.float() + o_lo.float(), want_hi) <= tol
 
 
 def test_row_ln_variants_match_torch():
