@@ -194,7 +194,7 @@ def _param_stamp(proj):
 
 def _plan_key(proj, ff, fe, guide_embed, modal, image_newline, out_dtype):
     return (ff.data_ptr(), tuple(ff.shape), None if fe is None else fe.data_ptr(),
-            None if guide_embed is None else guide_embed.data_ptr(), modal,
+            None if guide_embed is None else (guide_embed.data_ptr(), guide_embed._version), modal,
             None if image_newline is None else image_newline.data_ptr(), out_dtype,
             torch.cuda.current_stream(ff.device).cuda_stream,
             None if proj.local_logit_scale is None else float(proj.local_logit_scale),
@@ -238,6 +238,8 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
         attach_execution(a, ff.device)
         a.defer_join = int(bool(deferred))
         nv.compressor_fwd(a)
+        if deferred:
+            out.record_stream(_resources(ff.device).side)        # the side stream is still writing the global rows
         done = _record_done(ff.device) if deferred else None
         if cacheable:
             a._keep = None             # do not pin the caller's feature tensors
@@ -266,6 +268,7 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
     a.defer_join = int(bool(deferred))
     nv.compressor_fwd(a)
     if deferred:
+        out.record_stream(_resources(ff.device).side)
         return out, _record_done(ff.device)
     return out
 

@@ -199,6 +199,26 @@ def test_forward_deferred_equals_forward(c2):
                 assert torch.equal(o, want[k]), (rep, "more", k)
 
 
+def test_alternating_guides_share_one_workspace(c2):
+    """Cached plans of two guides alternate on one workspace (different folded queries, deferred and joined calls
+    back to back): every result equals the isolated forward of its guide."""
+    m, ff, fe, g, _ = c2
+    g2 = (g.float() * -0.7 + 0.05).to(g.dtype)
+    with torch.no_grad():
+        want = {}
+        for name, guide in (("g", g), ("g2", g2)):
+            torch.cuda.synchronize()
+            want[name] = m(ff, fe, guide, "video", None).clone()
+            torch.cuda.synchronize()
+        assert not torch.equal(want["g"], want["g2"])
+        seq = ["g", "g2", "g2", "g", "g2", "g", "g", "g2"] * 3
+        outs = [m(ff, fe, g if k == "g" else g2, "video", None) for k in seq]
+        outs_d = [m.forward_deferred(ff, fe, g if k == "g" else g2, "video", None)[0] for k in seq]
+        torch.cuda.synchronize()
+        for k, o, od in zip(seq, outs, outs_d):
+            assert torch.equal(o, want[k]) and torch.equal(od, want[k]), k
+
+
 def test_forward_async_lanes_equal_forward(c2):
     """forward_async (alternating stream lanes) returns, for a stream of DIFFERENT videos submitted back to
     back, exactly the bits of the synchronous forward of each."""
