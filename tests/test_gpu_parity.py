@@ -131,6 +131,44 @@ def test_c2_shape_and_first_group_matches_oracle(c2):
     assert torch.equal(out[-32:], out[-32:-31].expand(32, -1))
 
 
+@pytest.mark.parametrize("T,hidden,with_global_oracle", [(32, 3584, True), (128, 896, False)])
+def test_other_baseline_configs_against_oracle(T, hidden, with_global_oracle):
+    """BASELINE.json's other single-GPU shapes: C4 (32 frames, the 7B LLM's hidden size 3584) and one GPU's share of
+    C5 (128 frames): first and last 4-frame group against the oracle on those frames, the global rows against the
+    oracle on the whole clip (C4: 23k keys, seconds on the host) or against the frame-sharded composition (C5)."""
+    from types import SimpleNamespace
+    from hicom_amd import synth
+    from oracle import hicom_oracle as orc
+    cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "hidden_size": hidden, "max_num_frames": max(64, T)})
+    sd = synth.synth_state_dict(orc.param_shapes(cfg), tag="c%d" % T)
+    x = synth.synth_inputs(T, 27, 27, 1152, tag="c%d" % T)
+    m = build_module(SimpleNamespace(cfg=cfg, sd=sd))
+    ff, fe, g = dev_bf16(x["ff"]), dev_bf16(x["fe"]), dev_bf16(x["g"])
+    nw = T // 4 * 81
+    with torch.no_grad():
+        out = m(ff, fe, g, "video", None)
+        again = m(ff, fe, g, "video", None)
+    assert out.shape == (nw + 32, hidden) and bool(torch.isfinite(out).all()) and torch.equal(out, again)
+    assert torch.equal(out[-32:], out[-32:-31].expand(32, -1))
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    spec = orc.parse_projector_type(cfg.mm_projector_type)
+    for lo in (0, T - 4):
+        want = orc.local_forward(spec["local"], "direct", sdt, "local_compressor", ff[lo:lo + 4].float().cpu(),
+                                 fe[lo:lo + 4].float().cpu(), g.float().cpu(), "video").reshape(81, hidden)
+        assert float((out[lo // 4 * 81:lo // 4 * 81 + 81].cpu() - want).abs().max()) <= TOL, lo
+    if with_global_oracle:
+        want = orc.global_forward(spec["global"], "direct", sdt, "global_compressor", ff.float().cpu(), g.float().cpu())
+        assert float((out[-32:].cpu() - want.reshape(32, hidden)).abs().max()) <= TOL
+    else:
+        gc = m.global_compressor
+        with torch.no_grad():
+            q_in, n_rows = gc.injected_queries(g)
+            parts = [gc.partial_context(ff[lo:lo + T // 4], q_in, t_offset=lo) for lo in range(0, T, T // 4)]
+            glob = torch.empty((32, hidden), dtype=torch.float32, device="cuda")
+            gc.finish(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), q_in, glob, 0, n_rows)
+        assert float((glob - out[-32:]).abs().max()) <= 2e-5
+
+
 def test_c2_frame_shards_compose(c2):
     """Sharding the 64 frames 4-ways (absolute frame offsets) and combining the partial softmax
     states reproduces the unsharded result; local tokens of a shard equal the matching slice."""
