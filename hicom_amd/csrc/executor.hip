@@ -264,5 +264,16 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         if (!defer)
             HICOM_REQUIRE(hipStreamWaitEvent(sm, (hipEvent_t)a.ev_join, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
     }
+    if (a.place_src && do_finish) {
+        const int esz = a.out_dt == HICOM_DT_F32 ? 4 : 2;
+        CHK(hicom_place_blocks_fwd(a.place_src, a.place_block_rows, a.place_nblocks, a.place_block_stride, a.hidden * esz, a.out,
+                                   a.ldo * esz, 0, a.nl_group, sm));
+    }
+    if (a.ev_done) {
+        HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_done, sm) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
+        if (a.stream_next)
+            HICOM_REQUIRE(hipStreamWaitEvent((hipStream_t)a.stream_next, (hipEvent_t)a.ev_done, 0) == hipSuccess, HICOM_ELAUNCH,
+                          "compressor: stream wait");
+    }
     return HICOM_OK;
 }

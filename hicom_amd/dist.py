@@ -84,11 +84,29 @@ def gather_buffers(mine: torch.Tensor, group=None) -> torch.Tensor:
 class _ShardSet:
     """One set of exchange buffers + argument blocks (two sets alternate so that the all-gather of step i can
     still be reading its send buffer while step i+1 streams into the other one)."""
-    __slots__ = ("mine", "everyone", "tok_off", "a_stream", "a_finish", "ev_stream", "ev_tok")
+    __slots__ = ("mine", "everyone", "tok_off", "a_stream", "a_finish", "ev_stream", "ev_tok", "out")
 
 
 class _ShardPlan:
     __slots__ = ("sets", "n", "comm", "res", "lay", "nw", "hidden", "odt", "n_rows_total", "world")
+
+
+def _fast_key(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group, cur):
+    """Cheap identity of a repeated call (the full key walks every parameter's pointer; here: the parameter-list
+    generation, the sum of the parameters' in-place version counters and the input buffers)."""
+    from . import engine
+    d = projector.__dict__
+    cached = d.get("_engine_params")
+    if cached is None or cached[0] != d.get("_engine_params_gen", 0):
+        engine._param_stamp(projector)
+        cached = d["_engine_params"]
+    ver = 0
+    for p in cached[1]:
+        ver += p._version
+    return (ff_shard.data_ptr(), ff_shard.shape[0], None if fe_shard is None else fe_shard.data_ptr(),
+            None if guide_embed is None else (guide_embed.data_ptr(), guide_embed._version),
+            None if image_newline is None else image_newline.data_ptr(), total_frames, group, cur.cuda_stream, cached[0], ver,
+            projector.global_compressor._cache_gen)
 
 
 def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group):
@@ -96,15 +114,21 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
     from . import native as nv
     from .projector import _out_dtype
     lc, gc = projector.local_compressor, projector.global_compressor
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
     dev = ff_shard.device
     cur = torch.cuda.current_stream(dev)
+    last = projector.__dict__.get("_shard_last")
+    if last is not None and last[0] == _fast_key(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group, cur):
+        return last[1]
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
     key = ("shard", ff_shard.data_ptr(), tuple(ff_shard.shape), None if fe_shard is None else fe_shard.data_ptr(),
-           None if guide_embed is None else guide_embed.data_ptr(), None if image_newline is None else image_newline.data_ptr(),
+           None if guide_embed is None else (guide_embed.data_ptr(), guide_embed._version),
+           None if image_newline is None else image_newline.data_ptr(),
            _out_dtype(projector), world, rank, total_frames, cur.cuda_stream, gc._cache_gen, engine._param_stamp(projector))
     plans = projector.__dict__.setdefault("_engine_plans", {})
     plan = plans.get(key)
     if plan is not None:
+        projector.__dict__["_shard_last"] = (_fast_key(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline,
+                                                       group, cur), plan)
         return plan
     shard = FrameShardPlan(total_frames, world, lc.temporal_kernel_size)
     t0, t1 = shard.frame_range(rank)
@@ -149,13 +173,29 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
         # the FINISH phase runs on the comm stream (own workspace: it reads only the gathered states)
         engine.attach_execution(st.a_finish, dev, key_extra=("shard-finish",), main_stream=plan.comm, res=plan.res)
         st.a_stream._keep = st.a_finish._keep = None
+        st.out = torch.empty((plan.n_rows_total, hidden), dtype=odt, device=dev)
         st.ev_stream, st.ev_tok = torch.cuda.Event(), torch.cuda.Event()
+        st.ev_stream.record(cur)                   # (hipEventRecord from C needs created events)
         st.ev_tok.record(cur)
+        # what follows each phase on its stream rides in the same C call (every separate host call is 3-6 us and the
+        # sharded step is host-bound): STREAM -> record ev_stream, comm waits for it; FINISH -> place every rank's
+        # token block into the packed output, record ev_tok
+        st.a_stream.ev_done, st.a_stream.stream_next = st.ev_stream.cuda_event, plan.comm.cuda_stream
+        st.a_finish.place_src = st.everyone.data_ptr() + st.tok_off
+        st.a_finish.place_block_rows, st.a_finish.place_nblocks = nw, world
+        st.a_finish.place_block_stride = st.mine.numel()
+        st.a_finish.nl_group = lay.nl_group
+        st.a_finish.ev_done = st.ev_tok.cuda_event
         plan.sets.append(st)
     if len(plans) >= engine._MAX_PLANS:
         plans.pop(next(iter(plans)))
     plans[key] = plan
     return plan
+
+
+def _set_stream(stream):
+    """torch.cuda.set_stream without the context manager's device / current-stream lookups (a few us each)."""
+    torch._C._cuda_setStream(stream_id=stream.stream_id, device_index=stream.device_index, device_type=stream.device_type)
 
 
 def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: int,
@@ -170,7 +210,8 @@ def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: in
                   global rows) and ONE launch that places every rank's token block in the packed output.
     deferred=False: the caller's stream waits for the comm stream before returning (plain tensor semantics).
     deferred=True : returns (out, event); the token rows are complete once `event` has fired.  Back-to-back steps
-                  then overlap the token exchange of step i with the streaming of step i+1 (two buffer sets)."""
+                  then overlap the token exchange of step i with the streaming of step i+1 (two buffer sets); `out`
+                  belongs to the buffer set and is overwritten by the second-next deferred call."""
     from . import native as nv
     lc, gc = projector.local_compressor, projector.global_compressor
     if lc is None or gc is None:
@@ -182,25 +223,39 @@ def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: in
     st = plan.sets[plan.n & 1]
     plan.n += 1
     main, comm = torch.cuda.current_stream(dev), plan.comm
-    out = torch.empty((plan.n_rows_total, plan.hidden), dtype=plan.odt, device=dev)
-    out.record_stream(comm)
+    if deferred:
+        # pipelined serving: the result lives in this buffer set (no allocator traffic, no record_stream bookkeeping
+        # on the host-bound path) and is overwritten by the comm stream two steps later, i.e. after everything the
+        # caller has queued on ITS stream before that step
+        out = st.out
+    else:
+        out = torch.empty((plan.n_rows_total, plan.hidden), dtype=plan.odt, device=dev)
+        out.record_stream(comm)
     main.wait_event(st.ev_tok)                     # this buffer set's previous exchange (two steps ago) has drained
     st.a_stream.out = st.a_finish.out = out.data_ptr()
-    nv.compressor_fwd(st.a_stream)                 # main: prep, stream kernel, readout GEMMs   side: merge -> state
-    st.ev_stream.record(main)
-    esz = out.element_size()
-    with torch.cuda.stream(comm):                  # c10d orders a collective after the CURRENT stream
-        comm.wait_event(st.ev_stream)              # this rank's state and local tokens are complete
-        dist.all_gather_into_tensor(st.everyone.view(-1), st.mine, group=group)
-        nv.compressor_fwd(st.a_finish)             # combine + the global chain -> the 32 global rows (stream baked in: comm)
-        nv.place_blocks(st.everyone.data_ptr() + st.tok_off, plan.nw, plan.world, st.mine.numel(), plan.hidden * esz, out, 0,
-                        nl_group=plan.lay.nl_group, stream=comm.cuda_stream)
-        if plan.lay.newline_rows:
-            first = plan.lay.newline_rows[0]
-            step = plan.lay.newline_rows[1] - first if len(plan.lay.newline_rows) > 1 else 1
-            nv.scatter_rows(image_newline.view(1, -1), out, first, len(plan.lay.newline_rows), row_step=step)
-        st.ev_tok.record(comm)
+    # main: prep, stream kernel, readout GEMMs   side: merge -> state; then ev_stream, which the comm stream waits for
+    nv.compressor_fwd(st.a_stream)
+    _comm_step(plan, st, out, image_newline, group, main)
     if deferred:
         return out, st.ev_tok
     main.wait_event(st.ev_tok)
     return out
+
+
+def _comm_step(plan, st, out, image_newline, group, restore=None):
+    """Comm-stream half of a step: ONE all-gather, then (one C call) combine + the global chain -> the 32 global
+    rows, every rank's token block into the packed output, ev_tok."""
+    from . import native as nv
+    comm = plan.comm
+    _set_stream(comm)                              # c10d orders a collective after the CURRENT (thread-local) stream
+    try:
+        dist.all_gather_into_tensor(st.everyone.view(-1), st.mine, group=group)
+    finally:
+        if restore is not None:
+            _set_stream(restore)
+    nv.compressor_fwd(st.a_finish)
+    if plan.lay.newline_rows:
+        first = plan.lay.newline_rows[0]
+        step = plan.lay.newline_rows[1] - first if len(plan.lay.newline_rows) > 1 else 1
+        nv.scatter_rows(image_newline.view(1, -1), out, first, len(plan.lay.newline_rows), row_step=step, stream=comm.cuda_stream)
+        st.ev_tok.record(comm)

@@ -67,6 +67,8 @@ class CompressorArgs(C.Structure):
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("stream_main", C.c_void_p), ("stream_side", C.c_void_p), ("ev_fork", C.c_void_p), ("ev_join", C.c_void_p),
         ("ev_merge", C.c_void_p), ("defer_join", C.c_int32), ("reserved_", C.c_int32),
+        ("place_src", C.c_void_p), ("place_block_stride", C.c_int64), ("place_block_rows", C.c_int32), ("place_nblocks", C.c_int32),
+        ("ev_done", C.c_void_p), ("stream_next", C.c_void_p),
     ]
 
 
@@ -230,10 +232,11 @@ def readout_gemm(x, w, b, y, act=ACT_NONE, row0=0, nl_group=0, M=None):
                                         _ptr(y), _dt(y), y.shape[-1], row0, nl_group, _stream()), "hicom_readout_gemm_fwd")
 
 
-def scatter_rows(src, dst, row0, count, row_step=1, nl_group=0):
+def scatter_rows(src, dst, row0, count, row_step=1, nl_group=0, stream=None):
     src2 = src.reshape(-1, src.shape[-1])
     _check(lib().hicom_scatter_rows_fwd(_ptr(src2), _dt(src2), src2.shape[0], src2.shape[1], _ptr(dst), _dt(dst),
-                                        dst.shape[-1], row0, row_step, nl_group, count, _stream()), "hicom_scatter_rows_fwd")
+                                        dst.shape[-1], row0, row_step, nl_group, count, _stream() if stream is None else stream),
+           "hicom_scatter_rows_fwd")
 
 
 def place_blocks(src_ptr: int, block_rows, nblocks, block_stride_bytes, row_bytes, dst, row0, nl_group=0, stream=None):

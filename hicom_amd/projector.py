@@ -451,6 +451,7 @@ class HIComProjector(nn.Module):
         self.__dict__["_engine_params_gen"] = self.__dict__.get("_engine_params_gen", 0) + 1
         self.__dict__.pop("_engine_plans", None)
         self.__dict__.pop("_engine_lanes", None)
+        self.__dict__.pop("_shard_last", None)
 
     def _apply(self, fn, *args, **kwargs):           # .to() / .cuda() / .bfloat16() ...
         self._invalidate_plans()

@@ -318,6 +318,17 @@ typedef struct hicom_compressor_args {
      * overwrites the partial states the merge reads. */
     void* ev_merge;
     int32_t defer_join, reserved_;
+    /* Frame-sharded serving (hicom_amd/dist.py): what follows a phase on its own stream, so that one C call enqueues
+     * it all (each separate host call costs 3-6 us, and the sharded step is host-bound).
+     *   place_src != NULL (FINISH phase): the gathered per-rank token blocks -- place_nblocks blocks of
+     *     place_block_rows rows of `hidden` elements, place_block_stride bytes apart -- are placed into the packed
+     *     rows of `out` from row 0 (newline gaps as in nl_group), as hicom_place_blocks_fwd does;
+     *   ev_done != NULL: recorded at the end of the call on the stream the phase ran on (after the join);
+     *   stream_next != NULL (needs ev_done): that stream is made to wait for ev_done. */
+    const void* place_src;
+    int64_t place_block_stride;
+    int32_t place_block_rows, place_nblocks;
+    void *ev_done, *stream_next;
 } hicom_compressor_args;
 
 int64_t hicom_compressor_workspace_bytes(const hicom_compressor_args* args);

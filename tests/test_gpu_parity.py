@@ -288,8 +288,20 @@ def test_sharded_forward_world1_equals_forward(c2):
     try:
         with torch.no_grad():
             want = m(ff, fe, g, "video", None)
+            want2 = m(fe, ff, g, "video", None)
+            junk = torch.full_like(want, float("nan"))      # the block the allocator hands out next is poisoned
+            torch.cuda.synchronize()
+            del junk
             got = sharded_forward(m, ff, fe, g, 64)
-        torch.cuda.synchronize()
-        assert got.shape == want.shape and float((got - want).abs().max()) <= 2e-5
+            torch.cuda.synchronize()
+            assert got.shape == want.shape and float((got - want).abs().max()) <= 2e-5
+            # pipelined form: two buffer sets alternate, results live in the set; every row is rewritten each step
+            for k in range(6):
+                a, b, w = (ff, fe, want) if k % 3 else (fe, ff, want2)
+                o, ev = sharded_forward(m, a, b, g, 64, deferred=True)
+                ev.synchronize()
+                assert float((o - w).abs().max()) <= 2e-5, k
+                o.fill_(float("nan"))
+            torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
