@@ -145,7 +145,9 @@ def main():
             return sharded_forward(module, ff, fe, guide, total_frames, deferred=True)[0]
         # deferred join: the side stream's global chain (merge + 4 small linears -> 32 global rows) of step i overlaps
         # the streaming of step i+1; every step still does all of its work, fence() waits for every stream
-        return module.forward_deferred(ff, fe, guide, "video", None)[0]
+        # next_guide: the loop knows the next request's instruction embedding (here the same synthetic one), so this
+        # step's side stream also runs the NEXT step's two guide-only prep kernels; same kernels per step
+        return module.forward_deferred(ff, fe, guide, "video", None, next_guide=guide)[0]
 
     def fence():
         torch.cuda.synchronize()
@@ -192,7 +194,7 @@ def main():
                                f"use_guide=direct, hidden {args.hidden} -> {n_out} compressed tokens",
                    "frames": total_frames, "frames_per_gpu": fpg, "hidden": args.hidden,
                    "parallelism": f"frame-shard x{world}" + (" + RCCL all-gather" if distributed else ""),
-                   "launch": "hipGraph replay" if module.graph_replay else "eager (one C call per step), side-stream join deferred to the fence"},
+                   "launch": "hipGraph replay" if module.graph_replay else "eager (one C call per step), side-stream join deferred to the fence, next guide prefetched"},
         "ms_per_step_joined": joined_ms,
         "input_visual_tokens_per_sec": total_frames * GRID * GRID / (ms_per_step * 1e-3),
         "roofline": roofline,

@@ -134,6 +134,11 @@ extern "C" int64_t hicom_compressor_zero_prefix_bytes(const hicom_compressor_arg
     return (int64_t)(a->has_local ? w.ctx_local : w.qp);
 }
 
+extern "C" int hicom_compressor_is_fused(const hicom_compressor_args* a) {
+    if (!a) return 0;
+    return ((a->phases & HICOM_PHASE_STREAM) && can_fuse(*a)) ? 1 : 0;
+}
+
 extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
     HICOM_REQUIRE(ap, HICOM_EINVAL, "compressor: NULL args");
     const hicom_compressor_args& a = *ap;
@@ -159,12 +164,13 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         HICOM_REQUIRE(hipStreamWaitEvent(ss, (hipEvent_t)a.ev_fork, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
         return HICOM_OK;
     };
-    auto query_prep = [&](hipStream_t st, bool with_local_rows) -> int {
-        CHK(hicom_linear_fwd(a.gq, HICOM_DT_BF16, a.wq, HICOM_DT_BF16, a.bq, HICOM_DT_BF16, nullptr, 0, a.nq, a.E, a.E,
+    auto query_prep_of = [&](const void* gq, const void* lq, hipStream_t st, bool with_local_rows) -> int {
+        CHK(hicom_linear_fwd(gq, HICOM_DT_BF16, a.wq, HICOM_DT_BF16, a.bq, HICOM_DT_BF16, nullptr, 0, a.nq, a.E, a.E,
                              0, 0, HICOM_ACT_NONE, F(w.qp), st));
         return hicom_fold_query_split_fwd(F(w.qp), a.wk, a.kpe, a.nq, a.nh, a.E, a.P, qscale, ws + w.qhi, ws + w.qlo,
-                                          F(w.pos_a), a.P, with_local_rows ? a.lq : nullptr, w.R, 16 - w.R, st);
+                                          F(w.pos_a), a.P, with_local_rows ? lq : nullptr, w.R, 16 - w.R, st);
     };
+    auto query_prep = [&](hipStream_t st, bool with_local_rows) -> int { return query_prep_of(a.gq, a.lq, st, with_local_rows); };
     auto merge = [&](hipStream_t st) -> int {
         return hicom_global_merge_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E,
                                       F(w.scores), w.score_stride, w.N, a.H, a.W, a.pe, a.t_index0, a.y_index0,
@@ -186,16 +192,19 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         // ---- release recipe: ONE streaming kernel reads frames_embed and frames_feature once ------
         // main: q_proj, fold (+ guide -> local rows of the A operand), fused stream      | fork |
         // main: readout GEMMs            side: merge -> (finish)                 | join |
-        CHK(query_prep(sm, true));
         // the stream kernel overwrites the partial states: the previous call's merge (side stream, possibly still
-        // running when that call deferred its join) has to be done with them
+        // running when that call deferred its join) has to be done with them; the same event also orders this call
+        // behind a guide prefetch the previous call may have run on the side stream (query buffers)
         if (a.ev_merge)
             HICOM_REQUIRE(hipStreamWaitEvent(sm, (hipEvent_t)a.ev_merge, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
+        if (!a.skip_prep) CHK(query_prep(sm, true));
         CHK(hicom_fused_stream_fwd(a.ff, a.fe ? a.fe : a.ff, a.T, a.H, a.W, a.E, a.at.k, a.ay.k, ws + w.qhi, ws + w.qlo,
                                    w.R, a.l_scale, a.l_bias, a.pe ? F(w.pos_a) : nullptr, a.P, a.pe ? a.pe_hi : nullptr, a.pe ? a.pe_lo : nullptr, a.t_index0, a.y_index0,
                                    a.x_index0, F(w.part_m), F(w.part_l), F(w.part_acc),
                                    w.nparts, nullptr, ws + w.ctx_hi, ws + w.ctx_lo, sm));
         CHK(fork());
+        // guide prefetch: the stream kernel is done with the query buffers -> the NEXT call's prep, ahead of the merge
+        if (a.next_gq && a.next_lq && a.ev_merge) CHK(query_prep_of(a.next_gq, a.next_lq, ss, true));
         // the value-side pos-emb is already inside the partial contexts: a plain merge, one launch
         CHK(hicom_global_merge_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E, nullptr, 0, w.N,
                                    a.H, a.W, nullptr, 0, 0, 0, nullptr, ml_out, acc_out, solo ? 1 : 0, ss));

@@ -28,6 +28,7 @@ class _DeviceResources:
         self.ev_join.record(cur)
         self.ev_merge.record(cur)
         self.done = [torch.cuda.Event() for _ in range(16)]     # per-call completion events of deferred forwards
+        self.q_ready = None      # signature of the (workspace, guide) whose folded queries a prefetch left in the buffers
         self.n_done = 0
 
 
@@ -168,10 +169,11 @@ def attach_execution(a: nv.CompressorArgs, device, key_extra=(), main_stream=Non
 class _Plan:
     """A filled argument block for one (projector state, input buffers) combination, plus -- in graph
     mode -- the captured hipGraph of its launch sequence and the static buffer it writes."""
-    __slots__ = ("args", "rows", "hidden", "graph", "static_out", "hits")
+    __slots__ = ("args", "rows", "hidden", "graph", "static_out", "hits", "fused")
 
     def __init__(self, args, rows, hidden):
         self.args, self.rows, self.hidden = args, rows, hidden
+        self.fused = nv.compressor_is_fused(args)
         self.graph = None
         self.static_out = None
         self.hits = 0
@@ -201,7 +203,38 @@ def _plan_key(proj, ff, fe, guide_embed, modal, image_newline, out_dtype):
             0 if proj.global_compressor is None else proj.global_compressor._cache_gen, _param_stamp(proj))
 
 
-def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferred: bool = False):
+def _weights_sig(proj):
+    d = proj.__dict__
+    cached = d.get("_engine_params")
+    if cached is None or cached[0] != d.get("_engine_params_gen", 0):
+        _param_stamp(proj)
+        cached = d["_engine_params"]
+    ver = 0
+    for p in cached[1]:
+        ver += p._version
+    return (cached[0], ver, 0 if proj.global_compressor is None else proj.global_compressor._cache_gen)
+
+
+def prefetch_begin(a, res, proj, guide_embed, next_guide, fused: bool):
+    """Guide prefetch bookkeeping around one hicom_compressor_fwd (include/hicom_hip.h next_gq):
+    skip this call's prep iff the previous call on this workspace prefetched exactly this guide under these weights,
+    and ask this call to prefetch `next_guide`.  Returns the signature to store after the call (or None)."""
+    sig_w = _weights_sig(proj) if (res.q_ready is not None or next_guide is not None) else None
+    a.skip_prep = int(fused and guide_embed is not None and res.q_ready is not None and
+                      res.q_ready == (a.ws, a.gq, a.lq, guide_embed._version, sig_w))
+    res.q_ready = None
+    a.next_gq = a.next_lq = None
+    if next_guide is None or not fused or a.gq != a.lq:      # (the injected query must BE the guide: plain direct recipe)
+        return None
+    from .projector import _require_bf16_cuda
+    _require_bf16_cuda("next_guide", next_guide)
+    if next_guide.ndim != 1 or next_guide.shape[0] != a.E or not next_guide.is_contiguous():
+        raise ValueError("next_guide: a contiguous [D] guide embedding")
+    a.next_gq = a.next_lq = next_guide.data_ptr()
+    return (a.ws, a.next_gq, a.next_lq, next_guide._version, sig_w)
+
+
+def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferred: bool = False, next_guide=None):
     """HIComProjector.forward for a dense [T,H,W,E] input through hicom_compressor_fwd.
 
     Plans (argument blocks) are cached per input-buffer identity, so a repeated call costs one
@@ -237,9 +270,12 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
         a = build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, global_row0=n_local)
         attach_execution(a, ff.device)
         a.defer_join = int(bool(deferred))
+        res = _resources(ff.device)
+        pending = prefetch_begin(a, res, proj, guide_embed, next_guide, nv.compressor_is_fused(a))
         nv.compressor_fwd(a)
+        res.q_ready = pending
         if deferred:
-            out.record_stream(_resources(ff.device).side)        # the side stream is still writing the global rows
+            out.record_stream(res.side)        # the side stream is still writing the global rows
         done = _record_done(ff.device) if deferred else None
         if cacheable:
             a._keep = None             # do not pin the caller's feature tensors
@@ -250,6 +286,8 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
     plan.hits += 1
     a = plan.args
     if getattr(proj, "graph_replay", False):
+        a.skip_prep, a.next_gq, a.next_lq = 0, None, None
+        _resources(ff.device).q_ready = None
         if plan.graph is None:
             plan.static_out = torch.empty((plan.rows, plan.hidden), dtype=out_dtype, device=ff.device)
             a.out = plan.static_out.data_ptr()
@@ -266,9 +304,12 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
     out = torch.empty((plan.rows, plan.hidden), dtype=out_dtype, device=ff.device)
     a.out = out.data_ptr()
     a.defer_join = int(bool(deferred))
+    res = _resources(ff.device)
+    pending = prefetch_begin(a, res, proj, guide_embed, next_guide, plan.fused)
     nv.compressor_fwd(a)
+    res.q_ready = pending
     if deferred:
-        out.record_stream(_resources(ff.device).side)
+        out.record_stream(res.side)
         return out, _record_done(ff.device)
     return out
 

@@ -25,7 +25,7 @@ EXPORTS = (
     "hicom_linear_fwd", "hicom_fold_query_fwd", "hicom_split_bf16_fwd", "hicom_global_stream_fwd",
     "hicom_global_stream_nparts", "hicom_global_merge_fwd", "hicom_global_combine_fwd",
     "hicom_readout_gemm_fwd", "hicom_scatter_rows_fwd", "hicom_fold_query_split_fwd",
-    "hicom_global_combine_strided_fwd", "hicom_compressor_workspace_bytes", "hicom_compressor_zero_prefix_bytes",
+    "hicom_global_combine_strided_fwd", "hicom_compressor_workspace_bytes", "hicom_compressor_zero_prefix_bytes", "hicom_compressor_is_fused",
     "hicom_compressor_fwd", "hicom_linear_to_rows_fwd", "hicom_fused_stream_fwd", "hicom_fused_stream_nparts",
     "hicom_planes_gemm_fwd", "hicom_row_ln_fwd", "hicom_small_mha_fwd", "hicom_place_blocks_fwd",
 )
@@ -69,6 +69,7 @@ class CompressorArgs(C.Structure):
         ("ev_merge", C.c_void_p), ("defer_join", C.c_int32), ("reserved_", C.c_int32),
         ("place_src", C.c_void_p), ("place_block_stride", C.c_int64), ("place_block_rows", C.c_int32), ("place_nblocks", C.c_int32),
         ("ev_done", C.c_void_p), ("stream_next", C.c_void_p),
+        ("next_gq", C.c_void_p), ("next_lq", C.c_void_p), ("skip_prep", C.c_int32), ("reserved2_", C.c_int32),
     ]
 
 
@@ -115,6 +116,7 @@ def lib() -> C.CDLL:
     ap = C.POINTER(CompressorArgs)
     L.hicom_compressor_workspace_bytes.argtypes = [ap]
     L.hicom_compressor_zero_prefix_bytes.argtypes = [ap]
+    L.hicom_compressor_is_fused.argtypes = [ap]
     L.hicom_compressor_fwd.argtypes = [ap]
     L.hicom_global_combine_fwd.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     L.hicom_readout_gemm_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i64, i64, i32, vp]
@@ -268,6 +270,11 @@ def compressor_workspace(args: CompressorArgs):
 
 def compressor_fwd(args: CompressorArgs):
     _check(lib().hicom_compressor_fwd(C.byref(args)), "hicom_compressor_fwd")
+
+
+def compressor_is_fused(args: CompressorArgs) -> bool:
+    """True when these arguments take the release-recipe path: one streaming kernel for both levels."""
+    return bool(lib().hicom_compressor_is_fused(C.byref(args)))
 
 
 def linear_to_rows(x, w, b, dst, row0, n_rows, act=ACT_NONE):

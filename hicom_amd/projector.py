@@ -480,17 +480,23 @@ class HIComProjector(nn.Module):
                                     _out_dtype(self))
         return self.forward_stepwise(frames_feature, frames_embed, guide_embed, modal, image_newline)
 
-    def forward_deferred(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None):
+    def forward_deferred(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None, next_guide=None):
         """forward() without the final join of the side stream: returns (out, event).  The local rows of `out`
         are ordered on the caller's stream as usual; its 32 global rows are complete once `event` has fired
         (`torch.cuda.current_stream().wait_event(event)` before consuming them).  A serving loop that issues
-        independent videos back to back hides the latency-bound global chain behind the next video's streaming."""
+        independent videos back to back hides the latency-bound global chain behind the next video's streaming.
+
+        next_guide (optional, plain direct recipe): the guide embedding of the NEXT call, if the loop already has
+        it (the text of a request is known long before its frames are encoded).  This call then also runs that
+        call's two guide-only prep kernels (q_proj, fold) on its side stream, and the next call -- if it does come
+        with that guide (same tensor, unmodified) on this shape -- starts directly with its streaming kernel.
+        Every call still runs the same kernels; a wrong or missing prediction only costs the overlap."""
         plain = all(c is None or c.is_plain for c in (self.local_compressor, self.global_compressor))
         if not plain or isinstance(frames_feature, dict) or getattr(self, "graph_replay", False):
             raise NotImplementedError("forward_deferred: dense inputs of the plain recipes, eager launches")
         from . import engine
         return engine.run_dense(self, frames_feature, frames_embed, guide_embed, modal, image_newline, _out_dtype(self),
-                                deferred=True)
+                                deferred=True, next_guide=next_guide)
 
     def forward_async(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None, lanes: int = 2):
         """forward() for serving loops: the call is enqueued on one of `lanes` internal stream sets and a

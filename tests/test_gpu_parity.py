@@ -257,6 +257,38 @@ def test_alternating_guides_share_one_workspace(c2):
             assert torch.equal(o, want[k]) and torch.equal(od, want[k]), k
 
 
+def test_guide_prefetch_right_wrong_and_modified(c2):
+    """forward_deferred(next_guide=...) runs the next call's prep kernels on this call's side stream; the next call
+    skips its own only if it really comes with that guide, unmodified, on the same workspace.  Right and wrong
+    predictions, a guide overwritten in place after it was prefetched, and plain forwards in between all give
+    the bits of isolated forwards."""
+    m, ff, fe, g, _ = c2
+    g2 = (g.float() * -0.7 + 0.05).to(g.dtype)
+    g3 = g.clone()
+    with torch.no_grad():
+        want = {}
+        for name, guide in (("g", g), ("g2", g2)):
+            want[name] = m(ff, fe, guide, "video", None).clone()
+        torch.cuda.synchronize()
+        guides = {"g": g, "g2": g2}
+        #        this call, predicted next
+        seq = [("g", "g"), ("g", "g2"), ("g2", "g2"), ("g2", "g"), ("g2", "g2"), ("g2", None), ("g", "g"), ("g", "g")] * 2
+        outs = []
+        for cur, nxt in seq:
+            outs.append((cur, m.forward_deferred(ff, fe, guides[cur], "video", None,
+                                                 next_guide=None if nxt is None else guides[nxt])[0]))
+        outs.append(("g", m(ff, fe, g, "video", None)))                 # joined call consuming the last prefetch
+        torch.cuda.synchronize()
+        for k, (cur, o) in enumerate(outs):
+            assert torch.equal(o, want[cur]), (k, cur)
+        # prefetched, then overwritten in place before use: the version counter voids the prefetch
+        o1 = m.forward_deferred(ff, fe, g2, "video", None, next_guide=g3)[0]
+        g3.copy_(g2)
+        o2 = m.forward_deferred(ff, fe, g3, "video", None)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(o1, want["g2"]) and torch.equal(o2, want["g2"])
+
+
 def test_forward_async_lanes_equal_forward(c2):
     """forward_async (alternating stream lanes) returns, for a stream of DIFFERENT videos submitted back to
     back, exactly the bits of the synchronous forward of each."""
