@@ -14,6 +14,8 @@
 // frame-sharded multi-GPU path can place its RCCL all-gather between them.
 #include <string.h>
 
+#include <utility>
+
 #include "common.hpp"
 
 using namespace hicom;
@@ -25,6 +27,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct WsLayout {
     size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, qp, qhi, qlo, pos_a, scores, part_m, part_l, part_acc, scratch, ml, acc,
         ctx_g, o, qres, pre, hid_g, tok, total;
+    size_t qp_n, qhi_n, qlo_n, pos_a_n;     // the OTHER query-buffer set (args.q_set selects; a guide prefetch writes this one)
     int nw, R, rows_pad, nparts, P;
     long N, score_stride;
 };
@@ -69,6 +72,9 @@ WsLayout make_layout(const hicom_compressor_args& a) {
     w.qhi = take((size_t)w.rows_pad * a.E * 2);
     w.qlo = take((size_t)w.rows_pad * a.E * 2);
     w.pos_a = take((size_t)w.rows_pad * (a.P > 0 ? a.P : 1) * 4);
+    w.qhi_n = take((size_t)w.rows_pad * a.E * 2);
+    w.qlo_n = take((size_t)w.rows_pad * a.E * 2);
+    w.pos_a_n = take((size_t)w.rows_pad * (a.P > 0 ? a.P : 1) * 4);
     if (a.has_local) {
         w.ctx_local = take((size_t)w.nw * a.E * 4);          // fp32 form (two-kernel path) ...
         w.hid_local = take((size_t)w.nw * a.hidden * 4);
@@ -80,6 +86,7 @@ WsLayout make_layout(const hicom_compressor_args& a) {
     }
     if (a.has_global) {
         w.qp = take((size_t)a.nq * a.E * 4);
+        w.qp_n = take((size_t)a.nq * a.E * 4);
         w.scores = take((size_t)w.rows_pad * w.score_stride * 4);
         w.part_m = take((size_t)w.nparts * w.rows_pad * 4);
         w.part_l = take((size_t)w.nparts * w.rows_pad * 4);
@@ -95,6 +102,12 @@ WsLayout make_layout(const hicom_compressor_args& a) {
         w.tok = take((size_t)a.nq * a.hidden * 4);
     }
     w.total = off;
+    if (a.q_set) {
+        std::swap(w.qhi, w.qhi_n);
+        std::swap(w.qlo, w.qlo_n);
+        std::swap(w.pos_a, w.pos_a_n);
+        std::swap(w.qp, w.qp_n);
+    }
     return w;
 }
 
@@ -131,7 +144,7 @@ extern "C" int64_t hicom_compressor_workspace_bytes(const hicom_compressor_args*
 extern "C" int64_t hicom_compressor_zero_prefix_bytes(const hicom_compressor_args* a) {
     if (!a) return HICOM_EINVAL;
     const WsLayout w = make_layout(*a);
-    return (int64_t)(a->has_local ? w.ctx_local : w.qp);
+    return (int64_t)(a->has_local ? w.ctx_local : (w.qp < w.qp_n ? w.qp : w.qp_n));
 }
 
 extern "C" int hicom_compressor_is_fused(const hicom_compressor_args* a) {
@@ -164,13 +177,15 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         HICOM_REQUIRE(hipStreamWaitEvent(ss, (hipEvent_t)a.ev_fork, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
         return HICOM_OK;
     };
-    auto query_prep_of = [&](const void* gq, const void* lq, hipStream_t st, bool with_local_rows) -> int {
+    auto query_prep_of = [&](const void* gq, const void* lq, hipStream_t st, bool with_local_rows, bool other_set) -> int {
+        const size_t qp = other_set ? w.qp_n : w.qp, qhi = other_set ? w.qhi_n : w.qhi, qlo = other_set ? w.qlo_n : w.qlo,
+                     pos_a = other_set ? w.pos_a_n : w.pos_a;
         CHK(hicom_linear_fwd(gq, HICOM_DT_BF16, a.wq, HICOM_DT_BF16, a.bq, HICOM_DT_BF16, nullptr, 0, a.nq, a.E, a.E,
-                             0, 0, HICOM_ACT_NONE, F(w.qp), st));
-        return hicom_fold_query_split_fwd(F(w.qp), a.wk, a.kpe, a.nq, a.nh, a.E, a.P, qscale, ws + w.qhi, ws + w.qlo,
-                                          F(w.pos_a), a.P, with_local_rows ? lq : nullptr, w.R, 16 - w.R, st);
+                             0, 0, HICOM_ACT_NONE, F(qp), st));
+        return hicom_fold_query_split_fwd(F(qp), a.wk, a.kpe, a.nq, a.nh, a.E, a.P, qscale, ws + qhi, ws + qlo,
+                                          F(pos_a), a.P, with_local_rows ? lq : nullptr, w.R, 16 - w.R, st);
     };
-    auto query_prep = [&](hipStream_t st, bool with_local_rows) -> int { return query_prep_of(a.gq, a.lq, st, with_local_rows); };
+    auto query_prep = [&](hipStream_t st, bool with_local_rows) -> int { return query_prep_of(a.gq, a.lq, st, with_local_rows, false); };
     auto merge = [&](hipStream_t st) -> int {
         return hicom_global_merge_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E,
                                       F(w.scores), w.score_stride, w.N, a.H, a.W, a.pe, a.t_index0, a.y_index0,
@@ -192,9 +207,13 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         // ---- release recipe: ONE streaming kernel reads frames_embed and frames_feature once ------
         // main: q_proj, fold (+ guide -> local rows of the A operand), fused stream      | fork |
         // main: readout GEMMs            side: merge -> (finish)                 | join |
+        // guide prefetch: the NEXT call's prep goes into the other query-buffer set, at the head of this call's side
+        // stream work -- it runs under this call's stream kernel (that set's last reader, an earlier stream kernel,
+        // finished before the side-stream work that precedes this in stream order was released)
+        if (a.next_gq && a.next_lq && a.ev_merge && both) CHK(query_prep_of(a.next_gq, a.next_lq, ss, true, true));
         // the stream kernel overwrites the partial states: the previous call's merge (side stream, possibly still
         // running when that call deferred its join) has to be done with them; the same event also orders this call
-        // behind a guide prefetch the previous call may have run on the side stream (query buffers)
+        // behind the guide prefetch the previous call ran on the side stream
         if (a.ev_merge)
             HICOM_REQUIRE(hipStreamWaitEvent(sm, (hipEvent_t)a.ev_merge, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
         if (!a.skip_prep) CHK(query_prep(sm, true));
@@ -203,8 +222,6 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                                    a.x_index0, F(w.part_m), F(w.part_l), F(w.part_acc),
                                    w.nparts, nullptr, ws + w.ctx_hi, ws + w.ctx_lo, sm));
         CHK(fork());
-        // guide prefetch: the stream kernel is done with the query buffers -> the NEXT call's prep, ahead of the merge
-        if (a.next_gq && a.next_lq && a.ev_merge) CHK(query_prep_of(a.next_gq, a.next_lq, ss, true));
         // the value-side pos-emb is already inside the partial contexts: a plain merge, one launch
         CHK(hicom_global_merge_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E, nullptr, 0, w.N,
                                    a.H, a.W, nullptr, 0, 0, 0, nullptr, ml_out, acc_out, solo ? 1 : 0, ss));

@@ -28,7 +28,8 @@ class _DeviceResources:
         self.ev_join.record(cur)
         self.ev_merge.record(cur)
         self.done = [torch.cuda.Event() for _ in range(16)]     # per-call completion events of deferred forwards
-        self.q_ready = None      # signature of the (workspace, guide) whose folded queries a prefetch left in the buffers
+        self.q_ready = None      # signature of the (workspace, set, guide) a prefetch has prepared
+        self.q_last = {}         # workspace -> the query-buffer set its last call read
         self.n_done = 0
 
 
@@ -220,8 +221,13 @@ def prefetch_begin(a, res, proj, guide_embed, next_guide, fused: bool):
     skip this call's prep iff the previous call on this workspace prefetched exactly this guide under these weights,
     and ask this call to prefetch `next_guide`.  Returns the signature to store after the call (or None)."""
     sig_w = _weights_sig(proj) if (res.q_ready is not None or next_guide is not None) else None
-    a.skip_prep = int(fused and guide_embed is not None and res.q_ready is not None and
-                      res.q_ready == (a.ws, a.gq, a.lq, guide_embed._version, sig_w))
+    last = res.q_last.get(a.ws, 0)
+    hit = (fused and guide_embed is not None and res.q_ready is not None and
+           res.q_ready == (a.ws, 1 - last, a.gq, a.lq, guide_embed._version, sig_w))
+    # a hit reads the set the prefetch wrote; otherwise this call preps (main stream) into the set the last call on
+    # this workspace read -- never into the one a pending prefetch may still be writing
+    a.skip_prep, a.q_set = int(hit), (1 - last if hit else last)
+    res.q_last[a.ws] = a.q_set
     res.q_ready = None
     a.next_gq = a.next_lq = None
     if next_guide is None or not fused or a.gq != a.lq:      # (the injected query must BE the guide: plain direct recipe)
@@ -231,7 +237,7 @@ def prefetch_begin(a, res, proj, guide_embed, next_guide, fused: bool):
     if next_guide.ndim != 1 or next_guide.shape[0] != a.E or not next_guide.is_contiguous():
         raise ValueError("next_guide: a contiguous [D] guide embedding")
     a.next_gq = a.next_lq = next_guide.data_ptr()
-    return (a.ws, a.next_gq, a.next_lq, next_guide._version, sig_w)
+    return (a.ws, 1 - a.q_set, a.next_gq, a.next_lq, next_guide._version, sig_w)
 
 
 def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferred: bool = False, next_guide=None):
@@ -288,6 +294,7 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
     if getattr(proj, "graph_replay", False):
         a.skip_prep, a.next_gq, a.next_lq = 0, None, None
         _resources(ff.device).q_ready = None
+        a.q_set = _resources(ff.device).q_last.get(a.ws, 0)
         if plan.graph is None:
             plan.static_out = torch.empty((plan.rows, plan.hidden), dtype=out_dtype, device=ff.device)
             a.out = plan.static_out.data_ptr()

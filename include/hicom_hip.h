@@ -330,13 +330,15 @@ typedef struct hicom_compressor_args {
     int32_t place_block_rows, place_nblocks;
     void *ev_done, *stream_next;
     /* Guide prefetch (release recipe only): a serving loop knows the text of its next request long before that
-     * request's frames exist.  next_gq / next_lq (the NEXT call's injected query and local query, as gq / lq) make
-     * this call run the next call's two guide-only prep kernels on the side stream, right after the stream kernel
-     * has released the query buffers and ahead of the merge; the next call then passes skip_prep = 1 and starts with
-     * its stream kernel (ordered by ev_merge).  Same kernels per call, ~10 us less on the main stream.  The caller
-     * (hicom_amd/engine.py) tracks which (workspace, guide) the buffers hold and never skips without a prefetch. */
+     * request's frames exist.  The workspace holds TWO sets of query buffers (folded queries hi/lo, score-side pos
+     * table); q_set (0/1) is the set this call reads.  next_gq / next_lq (the NEXT call's injected query and local
+     * query, as gq / lq) make this call run the next call's two guide-only prep kernels into the OTHER set, at the
+     * head of its side-stream work, i.e. under its own stream kernel; the next call then passes that set and
+     * skip_prep = 1 and starts directly with its stream kernel (ordered by ev_merge).  Same kernels per call, ~10 us
+     * less on the main stream.  The caller (hicom_amd/engine.py) tracks which (workspace, set, guide) is ready and
+     * never skips without a prefetch. */
     const void *next_gq, *next_lq;
-    int32_t skip_prep, reserved2_;
+    int32_t skip_prep, q_set;
 } hicom_compressor_args;
 
 /* 1 when hicom_compressor_fwd takes the release-recipe (single streaming kernel) path for these arguments. */
