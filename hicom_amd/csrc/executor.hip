@@ -111,11 +111,41 @@ WsLayout make_layout(const hicom_compressor_args& a) {
     return w;
 }
 
+#ifdef HICOM_HOSTTIME   // dev-only: host microseconds per call site of the executor (tools/hosttime.py builds this variant)
+#include <stdio.h>
+#include <time.h>
+static double g_ht[512], g_hgap[512];
+static long g_hn[512];
+static double g_hlast;
+static inline double ht_now() {
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e6 + t.tv_nsec * 1e-3;
+}
+struct HtDump {
+    ~HtDump() {
+        for (int i = 0; i < 512; ++i)
+            if (g_hn[i]) fprintf(stderr, "[hosttime] executor.hip:%3d n=%6ld call %.2f us, since previous site %.2f us\n", i, g_hn[i], g_ht[i] / g_hn[i], g_hgap[i] / g_hn[i]);
+    }
+} g_htdump;
+#define CHK(call)                                             \
+    do {                                                      \
+        const double t0_ = ht_now();                          \
+        int rc_ = (call);                                     \
+        const double t1_ = ht_now();                          \
+        g_ht[__LINE__ % 512] += t1_ - t0_;                    \
+        g_hgap[__LINE__ % 512] += t0_ - g_hlast;              \
+        g_hn[__LINE__ % 512]++;                               \
+        g_hlast = t1_;                                        \
+        if (rc_ != HICOM_OK) return rc_;                      \
+    } while (0)
+#else
 #define CHK(call)                  \
     do {                           \
         int rc_ = (call);          \
         if (rc_ != HICOM_OK) return rc_; \
     } while (0)
+#endif
 
 int check_args(const hicom_compressor_args& a) {
     HICOM_REQUIRE(a.has_local || a.has_global, HICOM_EINVAL, "compressor: nothing to do");
@@ -155,6 +185,9 @@ extern "C" int hicom_compressor_is_fused(const hicom_compressor_args* a) {
 extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
     HICOM_REQUIRE(ap, HICOM_EINVAL, "compressor: NULL args");
     const hicom_compressor_args& a = *ap;
+#ifdef HICOM_HOSTTIME
+    g_hlast = ht_now();
+#endif
     CHK(check_args(a));
     const WsLayout w = make_layout(a);
     HICOM_REQUIRE(a.ws_bytes >= (int64_t)w.total, HICOM_EINVAL, "compressor: workspace too small (%lld < %zu)",
@@ -165,6 +198,9 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
     const bool both = a.has_local && a.has_global;
     const bool do_stream = a.phases & HICOM_PHASE_STREAM, do_finish = a.phases & HICOM_PHASE_FINISH;
     const bool fused = do_stream && can_fuse(a);
+    const bool merge_on_next = fused && (a.phases & HICOM_PHASE_MERGE_ON_NEXT);
+    if (a.phases & HICOM_PHASE_MERGE_ON_NEXT)
+        HICOM_REQUIRE(fused && a.ev_done && a.stream_next, HICOM_EINVAL, "compressor: MERGE_ON_NEXT needs the release recipe, ev_done and stream_next");
     // the global chain runs on the side stream only when there is local work to overlap it with
     hipStream_t sg = (both && do_stream) ? ss : sm;
     const float qscale = a.has_global ? 1.0f / sqrtf((float)(a.E / a.nh)) : 0.f;
@@ -210,23 +246,25 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         // guide prefetch: the NEXT call's prep goes into the other query-buffer set, at the head of this call's side
         // stream work -- it runs under this call's stream kernel (that set's last reader, an earlier stream kernel,
         // finished before the side-stream work that precedes this in stream order was released)
-        if (a.next_gq && a.next_lq && a.ev_merge && both) CHK(query_prep_of(a.next_gq, a.next_lq, ss, true, true));
+        if (a.next_gq && a.next_lq && a.ev_merge && both && !merge_on_next) CHK(query_prep_of(a.next_gq, a.next_lq, ss, true, true));
         // the stream kernel overwrites the partial states: the previous call's merge (side stream, possibly still
         // running when that call deferred its join) has to be done with them; the same event also orders this call
         // behind the guide prefetch the previous call ran on the side stream
-        if (a.ev_merge)
+        if (a.ev_merge && !merge_on_next)
             HICOM_REQUIRE(hipStreamWaitEvent(sm, (hipEvent_t)a.ev_merge, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
         if (!a.skip_prep) CHK(query_prep(sm, true));
         CHK(hicom_fused_stream_fwd(a.ff, a.fe ? a.fe : a.ff, a.T, a.H, a.W, a.E, a.at.k, a.ay.k, ws + w.qhi, ws + w.qlo,
                                    w.R, a.l_scale, a.l_bias, a.pe ? F(w.pos_a) : nullptr, a.P, a.pe ? a.pe_hi : nullptr, a.pe ? a.pe_lo : nullptr, a.t_index0, a.y_index0,
                                    a.x_index0, F(w.part_m), F(w.part_l), F(w.part_acc),
                                    w.nparts, nullptr, ws + w.ctx_hi, ws + w.ctx_lo, sm));
-        CHK(fork());
-        // the value-side pos-emb is already inside the partial contexts: a plain merge, one launch
-        CHK(hicom_global_merge_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E, nullptr, 0, w.N,
-                                   a.H, a.W, nullptr, 0, 0, 0, nullptr, ml_out, acc_out, solo ? 1 : 0, ss));
-        if (a.ev_merge)
-            HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_merge, ss) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
+        if (!merge_on_next) {
+            CHK(fork());
+            // the value-side pos-emb is already inside the partial contexts: a plain merge, one launch
+            CHK(hicom_global_merge_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E, nullptr, 0, w.N,
+                                       a.H, a.W, nullptr, 0, 0, 0, nullptr, ml_out, acc_out, solo ? 1 : 0, ss));
+            if (a.ev_merge)
+                HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_merge, ss) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
+        }
         // readout MLP on bf16 planes: contexts (hi/lo) -> hidden (hi/lo) -> packed output rows
         CHK(hicom_planes_gemm_fwd(ws + w.ctx_hi, ws + w.ctx_lo, a.lw0, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E,
                                   HICOM_ACT_GELU, ws + w.hid_hi, ws + w.hid_lo, nullptr, 0, 0, 0, 0, sm));
@@ -284,7 +322,7 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                                      a.hidden, HICOM_ACT_NONE, a.out, a.out_dt, a.ldo, a.global_row0, a.n_global_rows, sg));
     }
 
-    if (both && do_stream) {
+    if (both && do_stream && !merge_on_next) {
         HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_join, ss) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
         const bool defer = fused && a.defer_join && a.ev_merge;      // the caller joins on ev_join itself
         if (!defer)
@@ -301,5 +339,8 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
             HICOM_REQUIRE(hipStreamWaitEvent((hipStream_t)a.stream_next, (hipEvent_t)a.ev_done, 0) == hipSuccess, HICOM_ELAUNCH,
                           "compressor: stream wait");
     }
+    if (merge_on_next)
+        CHK(hicom_global_merge_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E, nullptr, 0, w.N,
+                                   a.H, a.W, nullptr, 0, 0, 0, nullptr, ml_out, acc_out, solo ? 1 : 0, (hipStream_t)a.stream_next));
     return HICOM_OK;
 }

@@ -152,7 +152,7 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
     plan.n = 0
     plan.sets = []
     probe = torch.empty((plan.n_rows_total, hidden), dtype=odt, device=dev)      # any valid `out` for the argument blocks
-    for _ in range(2):
+    for set_idx in range(2):
         st = _ShardSet()
         # ONE exchange buffer per rank: [state f32 | pad to 16 B | local tokens] -> one collective per step (the host
         # cost of a torch.distributed call, not the wire, is what a second collective would add)
@@ -165,7 +165,9 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
         st.a_stream = engine.build_args(projector, ff_shard, fe_shard, guide_embed, "video", None, probe, None, t_offset=t0,
                                         phases=nv.PHASE_STREAM, local_out=tok_mine, state_out=state_mine,
                                         global_row0=lay.n_rows)
-        engine.attach_execution(st.a_stream, dev, key_extra=("shard",))
+        # one workspace per buffer set: with MERGE_ON_NEXT the comm stream merges this set's partial states while the
+        # main stream already runs the next step (on the other set)
+        engine.attach_execution(st.a_stream, dev, key_extra=("shard", set_idx))
         st.a_finish = engine.build_args(projector, ff_shard, fe_shard, guide_embed, "video", None, probe, None, t_offset=t0,
                                         phases=nv.PHASE_FINISH, local_out=tok_mine, state_out=state_mine,
                                         state_sets=st.everyone, state_set_stride=st.mine.numel() // 4, nsets=world,
@@ -181,6 +183,10 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
         # sharded step is host-bound): STREAM -> record ev_stream, comm waits for it; FINISH -> place every rank's
         # token block into the packed output, record ev_tok
         st.a_stream.ev_done, st.a_stream.stream_next = st.ev_stream.cuda_event, plan.comm.cuda_stream
+        if nv.compressor_is_fused(st.a_stream):
+            # release recipe: no side stream -- the merge of the partials runs on the comm stream, in front of the
+            # all-gather (the fork / join / ev_merge event traffic was ~17 us of host time on a host-bound step)
+            st.a_stream.phases = nv.PHASE_STREAM | nv.PHASE_MERGE_ON_NEXT
         st.a_finish.place_src = st.everyone.data_ptr() + st.tok_off
         st.a_finish.place_block_rows, st.a_finish.place_nblocks = nw, world
         st.a_finish.place_block_stride = st.mine.numel()
@@ -233,7 +239,7 @@ def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: in
         out.record_stream(comm)
     main.wait_event(st.ev_tok)                     # this buffer set's previous exchange (two steps ago) has drained
     st.a_stream.out = st.a_finish.out = out.data_ptr()
-    # main: prep, stream kernel, readout GEMMs   side: merge -> state; then ev_stream, which the comm stream waits for
+    # main: prep, stream kernel, readout GEMMs, ev_stream; the comm stream waits for it and merges the partials -> state
     nv.compressor_fwd(st.a_stream)
     _comm_step(plan, st, out, image_newline, group, main)
     if deferred:

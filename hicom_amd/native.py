@@ -30,7 +30,7 @@ EXPORTS = (
     "hicom_planes_gemm_fwd", "hicom_row_ln_fwd", "hicom_small_mha_fwd", "hicom_place_blocks_fwd",
 )
 
-PHASE_STREAM, PHASE_FINISH = 1, 2
+PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
 
 
 class HicomNativeError(RuntimeError):

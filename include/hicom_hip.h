@@ -271,6 +271,12 @@ int hicom_small_mha_fwd(const float* q, const float* k, const float* v, int32_t 
  *         concurrently running forwards. */
 #define HICOM_PHASE_STREAM 1
 #define HICOM_PHASE_FINISH 2
+/* With HICOM_PHASE_STREAM on the release recipe, for the frame-sharded step: no side stream at all -- the merge of the
+ * partial states runs on stream_next after it has been made to wait for ev_done (both required), i.e. on the comm
+ * stream right in front of the all-gather.  Saves the fork / join / ev_merge event traffic (~17 us of host time per
+ * step); the caller gives every buffer set its own workspace, since the merge then reads the partials while the
+ * main stream may already run the next step. */
+#define HICOM_PHASE_MERGE_ON_NEXT 4
 
 typedef struct hicom_compressor_args {
     /* inputs: frames_feature (values; keys/values of the global stage), frames_embed (local keys, may be NULL) */
