@@ -28,6 +28,8 @@ class _DeviceResources:
         self.ev_join.record(cur)
         self.ev_merge.record(cur)
         self.done = [torch.cuda.Event() for _ in range(16)]     # per-call completion events of deferred forwards
+        for ev in self.done:
+            ev.record(cur)                                      # (created: the executor records them from C)
         self.q_ready = None      # signature of the (workspace, set, guide) a prefetch has prepared
         self.q_last = {}         # workspace -> the query-buffer set its last call read
         self.n_done = 0
@@ -259,9 +261,24 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
     cacheable = all(t is None or t.is_contiguous() for t in (ff, fe, guide_embed, image_newline))
     ff = ff.contiguous()
     fe = fe.contiguous() if fe is not None else None
-    key = _plan_key(proj, ff, fe, guide_embed, modal, image_newline, out_dtype) if cacheable else None
     plans = proj.__dict__.setdefault("_engine_plans", {})
-    plan = plans.get(key) if cacheable else None
+    plan = key = None
+    if cacheable:
+        # repeated call: a cheap identity (buffers, parameter-list generation + sum of the parameters' in-place
+        # version counters) before the full key, which walks every parameter's pointer
+        fast = (ff.data_ptr(), ff.shape[0], None if fe is None else fe.data_ptr(),
+                None if guide_embed is None else (guide_embed.data_ptr(), guide_embed._version), modal,
+                None if image_newline is None else image_newline.data_ptr(), out_dtype,
+                torch.cuda.current_stream(ff.device).cuda_stream,
+                None if proj.local_logit_scale is None else float(proj.local_logit_scale), _weights_sig(proj))
+        last = proj.__dict__.get("_dense_last")
+        if last is not None and last[0] == fast and plans.get(last[1]) is last[2]:
+            plan = last[2]
+        else:
+            key = _plan_key(proj, ff, fe, guide_embed, modal, image_newline, out_dtype)
+            plan = plans.get(key)
+            if plan is not None:
+                proj.__dict__["_dense_last"] = (fast, key, plan)
     if plan is None:
         T, H, W, _ = ff.shape
         layout = None
@@ -278,21 +295,24 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
         a.defer_join = int(bool(deferred))
         res = _resources(ff.device)
         pending = prefetch_begin(a, res, proj, guide_embed, next_guide, nv.compressor_is_fused(a))
+        done = _next_done(a, res) if deferred else None
         nv.compressor_fwd(a)
         res.q_ready = pending
         if deferred:
             out.record_stream(res.side)        # the side stream is still writing the global rows
-        done = _record_done(ff.device) if deferred else None
         if cacheable:
             a._keep = None             # do not pin the caller's feature tensors
             if len(plans) >= _MAX_PLANS:
                 plans.pop(next(iter(plans)))
+            if key is None:
+                key = _plan_key(proj, ff, fe, guide_embed, modal, image_newline, out_dtype)
             plans[key] = _Plan(a, n_local + n_global, hidden)
         return (out, done) if deferred else out
     plan.hits += 1
     a = plan.args
     if getattr(proj, "graph_replay", False):
         a.skip_prep, a.next_gq, a.next_lq = 0, None, None
+        a.ev_join, a.defer_join = _resources(ff.device).ev_join.cuda_event, 0
         _resources(ff.device).q_ready = None
         a.q_set = _resources(ff.device).q_last.get(a.ws, 0)
         if plan.graph is None:
@@ -313,20 +333,24 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
     a.defer_join = int(bool(deferred))
     res = _resources(ff.device)
     pending = prefetch_begin(a, res, proj, guide_embed, next_guide, plan.fused)
+    if deferred:
+        done = _next_done(a, res)
+    else:
+        a.ev_join = res.ev_join.cuda_event
     nv.compressor_fwd(a)
     res.q_ready = pending
     if deferred:
         out.record_stream(res.side)
-        return out, _record_done(ff.device)
+        return out, done
     return out
 
 
-def _record_done(device):
-    """Completion event of the side stream's chain of the call just enqueued (a small ring of reusable events)."""
-    res = _resources(device)
+def _next_done(a, res):
+    """Completion event of the side stream's chain of a deferred call: one of a small ring of reusable events, handed
+    to the executor as its join event (recorded on the side stream at the end of the call; no second record)."""
     ev = res.done[res.n_done % len(res.done)]
     res.n_done += 1
-    ev.record(res.side)
+    a.ev_join = ev.cuda_event
     return ev
 
 

@@ -452,6 +452,7 @@ class HIComProjector(nn.Module):
         self.__dict__.pop("_engine_plans", None)
         self.__dict__.pop("_engine_lanes", None)
         self.__dict__.pop("_shard_last", None)
+        self.__dict__.pop("_dense_last", None)
 
     def _apply(self, fn, *args, **kwargs):           # .to() / .cuda() / .bfloat16() ...
         self._invalidate_plans()
