@@ -91,7 +91,7 @@ class _ShardPlan:
     __slots__ = ("sets", "n", "comm", "res", "lay", "nw", "hidden", "odt", "n_rows_total", "world")
 
 
-def _fast_key(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group, cur):
+def _fast_key(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group, cur, rank=None, world=None):
     """Cheap identity of a repeated call (the full key walks every parameter's pointer; here: the parameter-list
     generation, the sum of the parameters' in-place version counters and the input buffers)."""
     from . import engine
@@ -105,11 +105,13 @@ def _fast_key(projector, ff_shard, fe_shard, guide_embed, total_frames, image_ne
         ver += p._version
     return (ff_shard.data_ptr(), ff_shard.shape[0], None if fe_shard is None else fe_shard.data_ptr(),
             None if guide_embed is None else (guide_embed.data_ptr(), guide_embed._version),
-            None if image_newline is None else image_newline.data_ptr(), total_frames, group, cur.cuda_stream, cached[0], ver,
-            projector.global_compressor._cache_gen)
+            None if image_newline is None else image_newline.data_ptr(), total_frames, group, rank, world, cur.cuda_stream,
+            cached[0], ver, projector.global_compressor._cache_gen)
 
 
-def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group):
+def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group, rank=None, world=None):
+    """Cached per-(inputs, rank, world) plan: two buffer sets with their argument blocks.  `rank` / `world` default to
+    the process group's; the single-GPU test of the N > 1 device path passes them explicitly (no collective)."""
     from . import engine
     from . import native as nv
     from .projector import _out_dtype
@@ -117,9 +119,12 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
     dev = ff_shard.device
     cur = torch.cuda.current_stream(dev)
     last = projector.__dict__.get("_shard_last")
-    if last is not None and last[0] == _fast_key(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group, cur):
+    if last is not None and last[0] == _fast_key(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group, cur,
+                                                 rank, world):
         return last[1]
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    fk_rank, fk_world = rank, world
+    if rank is None or world is None:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
     key = ("shard", ff_shard.data_ptr(), tuple(ff_shard.shape), None if fe_shard is None else fe_shard.data_ptr(),
            None if guide_embed is None else (guide_embed.data_ptr(), guide_embed._version),
            None if image_newline is None else image_newline.data_ptr(),
@@ -128,7 +133,7 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
     plan = plans.get(key)
     if plan is not None:
         projector.__dict__["_shard_last"] = (_fast_key(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline,
-                                                       group, cur), plan)
+                                                       group, cur, fk_rank, fk_world), plan)
         return plan
     shard = FrameShardPlan(total_frames, world, lc.temporal_kernel_size)
     t0, t1 = shard.frame_range(rank)

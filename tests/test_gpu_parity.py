@@ -304,6 +304,41 @@ def test_forward_async_lanes_equal_forward(c2):
                 assert torch.equal(o, want[k // 2]), (lanes, k)
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_device_path_emulated_on_one_gpu(c2, world):
+    """The N > 1 device path without a collective: every "rank" runs ITS shard's STREAM phase (absolute frame
+    offsets, state + local tokens into its send buffer, merge on the comm stream), the all-gather is emulated by
+    copying the send buffers into rank 0's receive buffer, and rank 0's FINISH phase (combine of `world` states, the
+    global chain, placement of `world` token blocks) must reproduce the dense forward of all frames."""
+    from hicom_amd import dist as hd, native as nv
+    m, ff, fe, g, _ = c2
+    T = ff.shape[0]
+    per = T // world
+    with torch.no_grad():
+        want = m(ff, fe, g, "video", None)
+        sends, plans = [], []
+        for r in range(world):
+            a, b = ff[r * per:(r + 1) * per].contiguous(), fe[r * per:(r + 1) * per].contiguous()
+            plan = hd._shard_plan(m, a, b, g, T, None, None, rank=r, world=world)
+            st = plan.sets[0]
+            st.a_stream.out = st.a_finish.out = st.out.data_ptr()
+            nv.compressor_fwd(st.a_stream)
+            torch.cuda.synchronize()
+            sends.append(st.mine.clone())
+            plans.append((plan, a, b))                       # keep the shard tensors alive: the plans hold raw pointers
+        plan, st = plans[0][0], plans[0][0].sets[0]
+        for r in range(world):
+            st.everyone[r].copy_(sends[r])
+        st.out.fill_(float("nan"))
+        torch.cuda.synchronize()
+        nv.compressor_fwd(st.a_finish)
+        torch.cuda.synchronize()
+        assert st.out.shape == want.shape
+        # (not bit-equal: a shard's workgroups hold fewer windows each, so windows meet the 16-token tiles at other
+        # offsets and their sums associate differently)
+        assert float((st.out - want).abs().max()) <= 2e-5
+
+
 def test_sharded_forward_world1_equals_forward(c2):
     """sharded_forward with a 1-rank RCCL group (STREAM phase -> all-gather -> FINISH phase) reproduces
     the single-call forward at the full C2 size."""
