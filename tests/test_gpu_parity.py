@@ -339,6 +339,45 @@ def test_multi_rank_device_path_emulated_on_one_gpu(c2, world):
         assert float((st.out - want).abs().max()) <= 2e-5
 
 
+def test_c3_eight_rank_emulation():
+    """BASELINE configs[2] (512 frames over 8 GPUs, 64 per GPU) on one GPU: the eight ranks' STREAM phases one after
+    the other, the all-gather replaced by copies, rank 5's FINISH phase -- against the dense forward of all 512
+    frames (which itself takes the multi-round form of the stream kernel: 10368 windows)."""
+    from types import SimpleNamespace
+    from hicom_amd import dist as hd, native as nv, synth
+    from oracle import hicom_oracle as orc
+    world, per = 8, 64
+    T = world * per
+    cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "hidden_size": 896, "max_num_frames": T})
+    sd = synth.synth_state_dict(orc.param_shapes(cfg), tag="c3")
+    m = build_module(SimpleNamespace(cfg=cfg, sd=sd))
+    gen = torch.Generator(device="cuda").manual_seed(31)
+    ff = torch.randn(T, 27, 27, 1152, device="cuda", generator=gen).bfloat16()
+    fe = torch.randn(T, 27, 27, 1152, device="cuda", generator=gen).bfloat16()
+    g = torch.randn(1152, device="cuda", generator=gen).bfloat16()
+    with torch.no_grad():
+        want = m(ff, fe, g, "video", None)
+        assert want.shape == (T // 4 * 81 + 32, 896) and bool(torch.isfinite(want).all())
+        sends, keep = [], []
+        for r in range(world):
+            a, b = ff[r * per:(r + 1) * per], fe[r * per:(r + 1) * per]          # dense slices along dim 0
+            plan = hd._shard_plan(m, a, b, g, T, None, None, rank=r, world=world)
+            st = plan.sets[0]
+            st.a_stream.out = st.a_finish.out = st.out.data_ptr()
+            nv.compressor_fwd(st.a_stream)
+            torch.cuda.synchronize()
+            sends.append(st.mine.clone())
+            keep.append(plan)
+        st = keep[5].sets[0]
+        for r in range(world):
+            st.everyone[r].copy_(sends[r])
+        st.out.fill_(float("nan"))
+        torch.cuda.synchronize()
+        nv.compressor_fwd(st.a_finish)
+        torch.cuda.synchronize()
+        assert st.out.shape == want.shape and float((st.out - want).abs().max()) <= 2e-5
+
+
 def test_sharded_forward_world1_equals_forward(c2):
     """sharded_forward with a 1-rank RCCL group (STREAM phase -> all-gather -> FINISH phase) reproduces
     the single-call forward at the full C2 size."""
