@@ -21,6 +21,8 @@
 //   * softmax fused at wavefront level: lane (row, token-quad) owns 4 logits, row max / row sum
 //     are two cross-lane shuffles; P is split hi/lo and is already in A-fragment order.
 //   * P.x: v_mfma_f32_16x16x16_bf16, each wave owns E/4 output channels (72 accumulator VGPRs).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace hicom {
@@ -244,6 +246,231 @@ __global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide form for many query rows (guide off: 32 queries x 9 heads = 288 folded rows).  The kernel above gives
+// every 16-row group its own pass over the token stream (18 passes = 1.9 GB through the memory system), has one
+// tile of prefetch and does the positional lookups by division and global loads in the compute path: ~6 us per
+// 16-token tile.  Here a 512-thread workgroup (one per CU) owns RG = 2 row groups: waves 0-3 and waves 4-7 are two
+// copies of the 4-wave machine above working on the SAME LDS tile, so the stream is read half as often; the ring is
+// three tiles deep with counted vmcnt (waves 0-3 issue the DMA), the positional tables of the 32 rows sit in LDS
+// (frames this workgroup's tokens can touch | rows | columns) with the tile's token coordinates tabled once per
+// tile by an otherwise idle lane group, and P.x uses one K = 32 MFMA per 16-channel block (P hi | lo against the
+// fragment twice).
+// ---------------------------------------------------------------------------------------------
+constexpr int kWideRG = 2;
+constexpr int kWideBuf = 3;
+constexpr int kWideFrames = 8;      // frames a workgroup's token range may touch
+
+template <int NB>
+__global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams p) {
+    constexpr int E = NB * 128;
+    constexpr int SLICE = E / 4;
+    constexpr int KSTEPS = SLICE / 32;
+    constexpr int CBLK = SLICE / 16;
+    constexpr int TILE_BYTES = NB * 4096;
+    constexpr int PIECES = NB * 4;
+    constexpr int PPW = PIECES / 4;       // DMA pieces per (loading) wave and tile
+    constexpr int RG = kWideRG;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* tilebuf = smem;                                                    // [kWideBuf][TILE_BYTES]
+    float* red = reinterpret_cast<float*>(smem + kWideBuf * TILE_BYTES);    // [RG][4 waves][16 rows][16 tokens]
+    int* tokpos = reinterpret_cast<int*>(red + RG * 4 * 256);               // [16] packed (frame - f_first) << 16 | y << 8 | x of this tile's tokens
+    float* postab = reinterpret_cast<float*>(tokpos + 16);                   // [RG * 16][kWideFrames + H + W]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave8 >> 2, wave = wave8 & 3;       // row group of this wave, channel slice of this wave
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int part = blockIdx.x, rg = blockIdx.y * RG + grp, nparts = gridDim.x;
+    const int tb = (int)(((long)p.ntiles * part) / nparts);
+    const int te = (int)(((long)p.ntiles * (part + 1)) / nparts);
+    const int S = kWideFrames + p.H + p.W;
+    const unsigned f_first = (unsigned)(tb * 16) / (unsigned)p.HW;
+    const long row_glob = (long)rg * 16 + r16;
+    const unsigned tokpos_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const int*)(tokpos);
+    const unsigned tile_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(tilebuf));
+
+    bf16x8 ahi[KSTEPS], alo[KSTEPS];
+    {
+        const long off = row_glob * E + SLICE * wave + 8 * kg;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            ahi[s] = *reinterpret_cast<const bf16x8*>(p.qhi + off + 32 * s);
+            alo[s] = *reinterpret_cast<const bf16x8*>(p.qlo + off + 32 * s);
+        }
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(ahi[s]), "+v"(alo[s]));   // landed before any DMA is issued
+    }
+    if (p.pos_a) {
+        for (int e = tid; e < RG * 16 * S; e += 512) {
+            const int r = e / S, c = e - r * S;
+            const long row = (long)(blockIdx.y * RG) * 16 + r;
+            int col;
+            if (c < kWideFrames) col = p.t0i + (int)f_first + c;
+            else if (c < kWideFrames + p.H) col = p.y0i + (c - kWideFrames);
+            else col = p.x0i + (c - kWideFrames - p.H);
+            postab[e] = col < p.pos_stride ? p.pos_a[row * p.pos_stride + col] : 0.f;
+        }
+    }
+
+    f32x4 acc[CBLK];
+#pragma unroll
+    for (int cb = 0; cb < CBLK; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -1.0e30f, l_run = 0.f;
+
+    auto stage = [&](int tile, int buf) {
+        if (grp != 0) return;                            // waves 0-3 own the vector-memory requests
+        const int r = lane >> 4, cpos = lane & 15;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int pi = wave + 4 * i;
+            const int blk = pi >> 2, row = 4 * (pi & 3) + r;
+            long tok = (long)tile * 16 + row;
+            tok = tok < p.N ? tok : p.N - 1;
+            const char* src = reinterpret_cast<const char*>(p.x) + tok * (long)(E * 2) + blk * 256 + 16 * (cpos ^ swz(row));
+            // Issued as inline asm: the compiler then does not know about the outstanding LDS writes and does not put
+            // "s_waitcnt vmcnt(0)" in front of the next LDS read it cannot tell apart from them (which drained the
+            // whole prefetch once per tile).  Ordering is this kernel's own: counted vmcnt + barrier [A].
+            const unsigned dst = tile_lds + buf * TILE_BYTES + pi * 1024;          // wave-uniform LDS base of the piece
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory", "m0");
+        }
+    };
+
+    const int q4 = (lane >> 2) & 3, pp = lane & 3;
+    const int trow = 4 * sig(kg) + q4;
+    const int rd_row_off = r16 * 256, rd_swz = swz(r16);
+    const int tr_row_off = trow * 256 + 8 * (pp & 1), tr_swz = swz(trow);
+
+    if (tb < te) stage(tb, 0);
+    if (tb + 1 < te) stage(tb + 1, 1);
+    __syncthreads();                                   // positional tables (the DMA is not waited for here: vmcnt below)
+
+    for (int tile = tb; tile < te; ++tile) {
+        const int cur = (tile - tb) % kWideBuf;
+        // tile `tile` has landed (the younger tile may stay in flight; the score stores of the previous tile are
+        // younger than its pieces as well), every wave is done with the buffer two tiles back and with `red`
+        if (tile + 1 < te) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (tile + 2 < te) stage(tile + 2, (tile + 2 - tb) % kWideBuf);
+        const char* img = tilebuf + cur * TILE_BYTES;
+
+        // ---- partial scores of this wave's row group over its channel slice ----
+        f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const int ch0 = SLICE * wave + 32 * s;
+            const int blk = ch0 >> 7, cbase = (ch0 & 127) >> 3;
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(img + blk * 4096 + rd_row_off + 16 * ((cbase + kg) ^ rd_swz));
+            s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[s], b, s4, 0, 0, 0);
+            s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[s], b, s4, 0, 0, 0);
+        }
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // MFMA -> VALU read (see fused_ring.hip)
+        {
+            float* rw = red + (grp * 4 + wave) * 256;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rw[(4 * kg + j) * 16 + r16] = s4[j];
+        }
+        if (p.pos_a && wave8 == 7 && lane < 16) {
+            long nn = (long)tile * 16 + lane;
+            nn = nn < p.N ? nn : p.N - 1;
+            const unsigned un = (unsigned)nn;
+            const unsigned t = un / (unsigned)p.HW, rem = un - t * (unsigned)p.HW;
+            const unsigned y = rem / (unsigned)p.W, xx = rem - y * (unsigned)p.W;
+            unsigned tf = t - f_first;
+            tf = tf < (unsigned)kWideFrames ? tf : kWideFrames - 1;             // (only masked tail tokens clamp)
+            tokpos[lane] = (int)((tf << 16) | (y << 8) | xx);
+        }
+        lds_barrier();   // [B]
+
+        const long n0 = (long)tile * 16 + 4 * sig(kg);
+        const float* rb = red + grp * 4 * 256 + r16 * 16 + 4 * sig(kg);
+        f32x4 lg = *reinterpret_cast<const f32x4*>(rb);
+        lg += *reinterpret_cast<const f32x4*>(rb + 256);
+        lg += *reinterpret_cast<const f32x4*>(rb + 512);
+        lg += *reinterpret_cast<const f32x4*>(rb + 768);
+        if (p.pos_a) {
+            // (inline asm: hipcc drains vmcnt -- i.e. the tile prefetch -- in front of an LDS read it cannot tell apart
+            // from the LDS-DMA destinations)
+            int4 v;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(tokpos_lds + 16 * sig(kg)) : "memory");
+            const int tp[4] = {v.x, v.y, v.z, v.w};
+            const float* pr_ = postab + (grp * 16 + r16) * S;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                lg[j] += pr_[tp[j] >> 16] + pr_[kWideFrames + ((tp[j] >> 8) & 255)] + pr_[kWideFrames + p.H + (tp[j] & 255)];
+        }
+        if (wave == 0) *reinterpret_cast<f32x4*>(p.scores + row_glob * p.score_stride + n0) = lg;
+
+        float tmax = -1.0e30f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tmax = (n0 + j < p.N) ? fmaxf(tmax, lg[j]) : tmax;
+        tmax = xrow4_max(tmax);
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = fast_exp(m_run - m_new);
+        float pr[4], lsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pr[j] = (n0 + j < p.N) ? fast_exp(lg[j] - m_new) : 0.f;
+            lsum += pr[j];
+        }
+        l_run = l_run * alpha + xrow4_sum(lsum);
+        m_run = m_new;
+        bf16x8 pw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint16_t h, l;
+            split_bf16(pr[j], h, l);
+            pw[j] = (short)h;
+            pw[4 + j] = (short)l;
+        }
+        if (__any(alpha != 1.0f)) {
+            const float a0 = __shfl(alpha, 4 * kg + 0, 64), a1 = __shfl(alpha, 4 * kg + 1, 64);
+            const float a2 = __shfl(alpha, 4 * kg + 2, 64), a3 = __shfl(alpha, 4 * kg + 3, 64);
+#pragma unroll
+            for (int cb = 0; cb < CBLK; ++cb) {
+                acc[cb][0] *= a0; acc[cb][1] *= a1; acc[cb][2] *= a2; acc[cb][3] *= a3;
+            }
+        }
+        const unsigned img_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(img);
+        constexpr int PGW = (CBLK % 6 == 0) ? 6 : CBLK;      // transposed fragments in flight together
+#pragma unroll
+        for (int c0 = 0; c0 < CBLK; c0 += PGW) {
+            bf16x4 bvs[PGW];
+#pragma unroll
+            for (int u = 0; u < PGW; ++u) {
+                const int ch0 = SLICE * wave + 16 * (c0 + u);
+                const int blk = ch0 >> 7, c2 = (ch0 & 127) >> 3;
+                const unsigned a = img_lds + blk * 4096 + tr_row_off + 16 * ((c2 + (pp >> 1)) ^ tr_swz);
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(bvs[u]) : "v"(a));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < PGW; ++u) {
+                const bf16x8 b2 = bf16x8{bvs[u][0], bvs[u][1], bvs[u][2], bvs[u][3], bvs[u][0], bvs[u][1], bvs[u][2], bvs[u][3]};
+                acc[c0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pw, b2, acc[c0 + u], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    const long prow = (long)part * p.rows_pad + rg * 16;
+    if (wave == 0 && kg == 0 && rg * 16 + r16 < p.rows) {
+        p.part_m[prow + r16] = m_run;
+        p.part_l[prow + r16] = l_run;
+    }
+#pragma unroll
+    for (int cb = 0; cb < CBLK; ++cb) {
+        float* o = p.part_acc + (prow + 4 * kg) * E + SLICE * wave + 16 * cb + r16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (rg * 16 + 4 * kg + j < p.rows) o[(long)j * E] = acc[cb][j];
+    }
+}
+
 static int g_num_cus = 0;
 static int num_cus() {
     if (g_num_cus == 0) {
@@ -265,6 +492,7 @@ extern "C" int hicom_global_stream_nparts(int64_t N, int32_t rows_pad) {
     const long ntiles = (N + 15) / 16;
     const int groups = rows_pad / 16;
     long want = 2L * num_cus() / (groups > 0 ? groups : 1);   // 2 resident workgroups per CU
+    if (rows_pad % (16 * kWideRG) == 0 && rows_pad > 16) want = (long)num_cus() / (groups / kWideRG);   // wide form: one per CU
     if (want < 1) want = 1;
     // keep >= 4 tiles per chunk so the per-chunk partial write stays a small fraction of the stream
     long cap = ntiles / 4;
@@ -300,6 +528,22 @@ extern "C" int hicom_global_stream_fwd(const void* x, int64_t N, int32_t E,
     p.ntiles = (int)((N + 15) / 16);
     dim3 grid((unsigned)nparts, (unsigned)(rows_pad / 16));
     hipStream_t s = (hipStream_t)stream;
+    // many rows: the wide form (two row groups per workgroup, three-deep ring) when its limits hold
+    const long tiles_per_part = (p.ntiles + nparts - 1) / nparts + 1;
+    const bool span_ok = !pos_a || (tiles_per_part * 16 + p.HW - 1) / p.HW + 1 <= kWideFrames;
+    const char* force_narrow = getenv("HICOM_GLOBAL_NARROW");      // dev / test switch: always take the one-row-group kernel
+    if (!(force_narrow && force_narrow[0] == '1') && E == 1152 && rows_pad > 16 && rows_pad % (16 * kWideRG) == 0 && (!pos_a || (H <= 64 && W <= 64)) && span_ok) {
+        const int S = kWideFrames + (pos_a ? H + W : 0);
+        const size_t smem = (size_t)kWideBuf * 9 * 4096 + (size_t)kWideRG * 4 * 1024 + 64 + (size_t)kWideRG * 16 * S * 4;
+        static bool wide_attr = false;
+        if (!wide_attr) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(global_stream_wide_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+            wide_attr = true;
+        }
+        if (!pos_a) { p.H = 1; p.W = 1; p.HW = 1; }
+        hipLaunchKernelGGL(global_stream_wide_kernel<9>, dim3((unsigned)nparts, (unsigned)(rows_pad / (16 * kWideRG))), dim3(512), smem, s, p);
+        return hicom_host::check_launch("global_stream");
+    }
     if (E == 1152) {
         constexpr int smem = 2 * 9 * 4096 + 4096;
         static bool attr_set = false;

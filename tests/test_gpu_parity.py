@@ -339,6 +339,37 @@ def test_multi_rank_device_path_emulated_on_one_gpu(c2, world):
         assert float((st.out - want).abs().max()) <= 2e-5
 
 
+def test_guide_off_wide_global_kernel_matches_narrow():
+    """Guide off at 16 frames of the full grid (288 folded query rows): the wide global stream kernel (two row groups
+    per workgroup, three-deep ring) against the one-row-group kernel it replaces, and the 81 x 4 local tokens of the
+    first groups + the 32 distinct global rows against the oracle."""
+    import os
+    from types import SimpleNamespace
+    from hicom_amd import synth
+    from oracle import hicom_oracle as orc
+    cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "mm_projector_type": "local43_global32", "use_guide": None,
+                             "hidden_size": 896, "max_num_frames": 64})
+    sd = synth.synth_state_dict(orc.param_shapes(cfg), tag="off16")
+    x = synth.synth_inputs(16, 27, 27, 1152, tag="off16")
+    m = build_module(SimpleNamespace(cfg=cfg, sd=sd))
+    ff, fe, g = dev_bf16(x["ff"]), dev_bf16(x["fe"]), dev_bf16(x["g"])
+    with torch.no_grad():
+        wide = m(ff, fe, g, "video", None).clone()
+        os.environ["HICOM_GLOBAL_NARROW"] = "1"
+        try:
+            narrow = m(ff, fe, g, "video", None).clone()
+        finally:
+            del os.environ["HICOM_GLOBAL_NARROW"]
+        torch.cuda.synchronize()
+    assert wide.shape == (4 * 81 + 32, 896)
+    assert float((wide - narrow).abs().max()) <= 2e-5
+    assert not torch.equal(wide[-32:-31], wide[-31:-30])                 # 32 DISTINCT global rows in this mode
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    spec = orc.parse_projector_type(cfg.mm_projector_type)
+    want = orc.global_forward(spec["global"], None, sdt, "global_compressor", ff.float().cpu(), None)
+    assert float((wide[-32:].cpu() - want.reshape(32, 896)).abs().max()) <= TOL
+
+
 def test_c3_eight_rank_emulation():
     """BASELINE configs[2] (512 frames over 8 GPUs, 64 per GPU) on one GPU: the eight ranks' STREAM phases one after
     the other, the all-gather replaced by copies, rank 5's FINISH phase -- against the dense forward of all 512
