@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=64)
     ap.add_argument("--hidden", type=int, default=896)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the use_guide=None sweep")
     ap.add_argument("--graph", action="store_true", help="hipGraph replay of the cached plan (measured slower than the C launch loop on ROCm 7.2)")
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches: one C call per step")
     args = ap.parse_args()
@@ -207,12 +208,34 @@ def main():
     if rank == 0:
         if world == 1:
             result["parity"] = parity_probe(device)
+            if not distributed and not args.no_secondary:
+                result["secondary"] = secondary_sweep(args, device, ff, fe, guide)
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(cfg, module, fpg)
                 result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result))
     if distributed:
         dist.destroy_process_group()
+
+
+def secondary_sweep(args, device, ff, fe, guide):
+    """SURVEY.md §8(d) secondary sweep: the generic mode (use_guide=None: 32 distinct learnable queries x 9 heads =
+    288 folded rows, where the global QK^T / PV contraction is dense MFMA work), same shapes, plain joined forwards."""
+    cfg = release_config(args.hidden, args.frames_per_gpu)
+    cfg.mm_projector_type, cfg.use_guide = "local43_global32", None
+    m = make_projector(cfg, device)
+    with torch.no_grad():
+        for _ in range(5):
+            out = m(ff, fe, guide, "video", None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 30
+        for _ in range(n):
+            out = m(ff, fe, guide, "video", None)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+    return {"use_guide=None (32 distinct queries)": {"ms_per_forward": dt * 1e3, "tokens_per_sec": out.shape[0] / dt,
+                                                     "note": "joined forwards; two-kernel path (local windows || wide global stream kernel)"}}
 
 
 def dominant_kernel_roofline(module, ff, fe, guide, iters):
