@@ -143,7 +143,7 @@ def main():
         if distributed:
             # deferred: the token all-gather of step i (comm stream, second buffer set) overlaps the streaming of
             # step i+1; fence() below waits for every stream before the clock stops
-            return sharded_forward(module, ff, fe, guide, total_frames, deferred=True)[0]
+            return sharded_forward(module, ff, fe, guide, total_frames, deferred=True, guide_after_next=guide)[0]
         # deferred join: the side stream's global chain (merge + 4 small linears -> 32 global rows) of step i overlaps
         # the streaming of step i+1; every step still does all of its work, fence() waits for every stream
         # next_guide: the loop knows the next request's instruction embedding (here the same synthetic one), so this

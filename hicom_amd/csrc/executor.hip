@@ -213,13 +213,15 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         HICOM_REQUIRE(hipStreamWaitEvent(ss, (hipEvent_t)a.ev_fork, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
         return HICOM_OK;
     };
-    auto query_prep_of = [&](const void* gq, const void* lq, hipStream_t st, bool with_local_rows, bool other_set) -> int {
+    auto query_prep_of = [&](const void* gq, const void* lq, hipStream_t st, bool with_local_rows, bool other_set,
+                             char* base = nullptr) -> int {
         const size_t qp = other_set ? w.qp_n : w.qp, qhi = other_set ? w.qhi_n : w.qhi, qlo = other_set ? w.qlo_n : w.qlo,
                      pos_a = other_set ? w.pos_a_n : w.pos_a;
+        char* b = base ? base : ws;
         CHK(hicom_linear_fwd(gq, HICOM_DT_BF16, a.wq, HICOM_DT_BF16, a.bq, HICOM_DT_BF16, nullptr, 0, a.nq, a.E, a.E,
-                             0, 0, HICOM_ACT_NONE, F(qp), st));
-        return hicom_fold_query_split_fwd(F(qp), a.wk, a.kpe, a.nq, a.nh, a.E, a.P, qscale, ws + qhi, ws + qlo,
-                                          F(pos_a), a.P, with_local_rows ? lq : nullptr, w.R, 16 - w.R, st);
+                             0, 0, HICOM_ACT_NONE, (float*)(b + qp), st));
+        return hicom_fold_query_split_fwd((float*)(b + qp), a.wk, a.kpe, a.nq, a.nh, a.E, a.P, qscale, b + qhi, b + qlo,
+                                          (float*)(b + pos_a), a.P, with_local_rows ? lq : nullptr, w.R, 16 - w.R, st);
     };
     auto query_prep = [&](hipStream_t st, bool with_local_rows) -> int { return query_prep_of(a.gq, a.lq, st, with_local_rows, false); };
     auto merge = [&](hipStream_t st) -> int {
@@ -333,6 +335,8 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         CHK(hicom_place_blocks_fwd(a.place_src, a.place_block_rows, a.place_nblocks, a.place_block_stride, a.hidden * esz, a.out,
                                    a.ldo * esz, 0, a.nl_group, sm));
     }
+    if (a.prep_ws && a.next_gq && a.next_lq && do_finish && !do_stream && a.has_local && a.has_global)
+        CHK(query_prep_of(a.next_gq, a.next_lq, sm, true, false, (char*)a.prep_ws));     // guide prefetch for this set's next use
     if (a.ev_done) {
         HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_done, sm) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
         if (a.stream_next)

@@ -84,7 +84,7 @@ def gather_buffers(mine: torch.Tensor, group=None) -> torch.Tensor:
 class _ShardSet:
     """One set of exchange buffers + argument blocks (two sets alternate so that the all-gather of step i can
     still be reading its send buffer while step i+1 streams into the other one)."""
-    __slots__ = ("mine", "everyone", "tok_off", "a_stream", "a_finish", "ev_stream", "ev_tok", "out")
+    __slots__ = ("mine", "everyone", "tok_off", "a_stream", "a_finish", "ev_stream", "ev_tok", "out", "fused", "q_ready")
 
 
 class _ShardPlan:
@@ -188,7 +188,8 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
         # sharded step is host-bound): STREAM -> record ev_stream, comm waits for it; FINISH -> place every rank's
         # token block into the packed output, record ev_tok
         st.a_stream.ev_done, st.a_stream.stream_next = st.ev_stream.cuda_event, plan.comm.cuda_stream
-        if nv.compressor_is_fused(st.a_stream):
+        st.fused, st.q_ready = nv.compressor_is_fused(st.a_stream), None
+        if st.fused:
             # release recipe: no side stream -- the merge of the partials runs on the comm stream, in front of the
             # all-gather (the fork / join / ev_merge event traffic was ~17 us of host time on a host-bound step)
             st.a_stream.phases = nv.PHASE_STREAM | nv.PHASE_MERGE_ON_NEXT
@@ -210,7 +211,8 @@ def _set_stream(stream):
 
 
 def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: int,
-                    image_newline: Optional[torch.Tensor] = None, group=None, deferred: bool = False):
+                    image_newline: Optional[torch.Tensor] = None, group=None, deferred: bool = False,
+                    guide_after_next: Optional[torch.Tensor] = None):
     """HIComProjector.forward for modal='video' with the frames split evenly over the ranks of
     `group`; every rank passes ITS frames and receives the full [n_tok, hidden] result.
 
@@ -222,7 +224,11 @@ def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: in
     deferred=False: the caller's stream waits for the comm stream before returning (plain tensor semantics).
     deferred=True : returns (out, event); the token rows are complete once `event` has fired.  Back-to-back steps
                   then overlap the token exchange of step i with the streaming of step i+1 (two buffer sets); `out`
-                  belongs to the buffer set and is overwritten by the second-next deferred call."""
+                  belongs to the buffer set and is overwritten by the second-next deferred call.
+    guide_after_next: guide prefetch (release recipe): the guide embedding of the call AFTER the next one, i.e. of this
+                  buffer set's next use, if the serving loop already has it -- its two guide-only prep kernels then
+                  run at the end of this call's comm-stream work and that call starts with its streaming kernel
+                  (if it does come with that guide, unmodified).  Same kernels per call either way."""
     from . import native as nv
     lc, gc = projector.local_compressor, projector.global_compressor
     if lc is None or gc is None:
@@ -244,9 +250,27 @@ def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: in
         out.record_stream(comm)
     main.wait_event(st.ev_tok)                     # this buffer set's previous exchange (two steps ago) has drained
     st.a_stream.out = st.a_finish.out = out.data_ptr()
+    # guide prefetch bookkeeping (engine.prefetch_begin has the dense counterpart)
+    from . import engine
+    a_s, a_f = st.a_stream, st.a_finish
+    sig_w = engine._weights_sig(projector) if (st.q_ready is not None or guide_after_next is not None) else None
+    a_s.skip_prep = int(st.fused and st.q_ready is not None and
+                        st.q_ready == (a_s.gq, a_s.lq, guide_embed._version, sig_w))
+    st.q_ready = None
+    pending = None
+    a_f.next_gq = a_f.next_lq = a_f.prep_ws = None
+    if guide_after_next is not None and st.fused and a_s.gq == a_s.lq:
+        from .projector import _require_bf16_cuda
+        _require_bf16_cuda("guide_after_next", guide_after_next)
+        if guide_after_next.ndim != 1 or guide_after_next.shape[0] != a_s.E or not guide_after_next.is_contiguous():
+            raise ValueError("guide_after_next: a contiguous [D] guide embedding")
+        a_f.next_gq = a_f.next_lq = guide_after_next.data_ptr()
+        a_f.prep_ws = a_s.ws
+        pending = (a_f.next_gq, a_f.next_lq, guide_after_next._version, sig_w)
     # main: prep, stream kernel, readout GEMMs, ev_stream; the comm stream waits for it and merges the partials -> state
     nv.compressor_fwd(st.a_stream)
     _comm_step(plan, st, out, image_newline, group, main)
+    st.q_ready = pending
     if deferred:
         return out, st.ev_tok
     main.wait_event(st.ev_tok)

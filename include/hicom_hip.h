@@ -345,6 +345,11 @@ typedef struct hicom_compressor_args {
      * never skips without a prefetch. */
     const void *next_gq, *next_lq;
     int32_t skip_prep, q_set;
+    /* FINISH-only calls of the frame-sharded step: prep_ws != NULL (with next_gq / next_lq) runs the prep kernels at the
+     * end of the phase, before ev_done, into query-buffer set q_set of THAT workspace -- the STREAM workspace of the
+     * same buffer set (same shapes, hence the same layout), whose next use is two steps later; ev_done, which the
+     * main stream waits for before it touches the set again, then also covers the prefetch: no extra event. */
+    void* prep_ws;
 } hicom_compressor_args;
 
 /* 1 when hicom_compressor_fwd takes the release-recipe (single streaming kernel) path for these arguments. */

@@ -440,5 +440,14 @@ def test_sharded_forward_world1_equals_forward(c2):
                 assert float((o - w).abs().max()) <= 2e-5, k
                 o.fill_(float("nan"))
             torch.cuda.synchronize()
+            # guide prefetch two calls ahead (this buffer set's next use): right and wrong predictions
+            g2 = (g.float() * -0.7 + 0.05).to(g.dtype)
+            want_g2 = m(ff, fe, g2, "video", None)
+            seq = [(g, g), (g, g2), (g, g), (g2, g), (g, None), (g, g2), (g2, g2), (g2, g)]
+            for k, (cur, nxt2) in enumerate(seq):
+                o, ev = sharded_forward(m, ff, fe, cur, 64, deferred=True, guide_after_next=nxt2)
+                ev.synchronize()
+                assert float((o - (want if cur is g else want_g2)).abs().max()) <= 2e-5, ("prefetch", k)
+            torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
