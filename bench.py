@@ -287,7 +287,7 @@ def dominant_kernel_roofline(module, ff, fe, guide, iters):
     achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
     traffic = None
     try:   # HBM bytes per launch from the committed PMC pass of this same workload (profiles/)
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_g_pmc_hbm_traffic.json")))
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_hbm_traffic.json")))
         if prof.get("frames") == T:
             traffic = prof["kernels"]["fused_ring_kernel"]["hbm_bytes_per_launch_corrected"]
     except Exception:
