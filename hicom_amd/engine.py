@@ -215,7 +215,8 @@ def _weights_sig(proj):
     ver = 0
     for p in cached[1]:
         ver += p._version
-    return (cached[0], ver, 0 if proj.global_compressor is None else proj.global_compressor._cache_gen)
+    # (the module's identity is part of it: two projectors of one shape share workspaces and resource sets)
+    return (id(proj), cached[0], ver, 0 if proj.global_compressor is None else proj.global_compressor._cache_gen)
 
 
 def prefetch_begin(a, res, proj, guide_embed, next_guide, fused: bool):

@@ -262,6 +262,7 @@ def test_guide_prefetch_right_wrong_and_modified(c2):
     skips its own only if it really comes with that guide, unmodified, on the same workspace.  Right and wrong
     predictions, a guide overwritten in place after it was prefetched, and plain forwards in between all give
     the bits of isolated forwards."""
+    from types import SimpleNamespace
     m, ff, fe, g, _ = c2
     g2 = (g.float() * -0.7 + 0.05).to(g.dtype)
     g3 = g.clone()
@@ -281,6 +282,15 @@ def test_guide_prefetch_right_wrong_and_modified(c2):
         torch.cuda.synchronize()
         for k, (cur, o) in enumerate(outs):
             assert torch.equal(o, want[cur]), (k, cur)
+        # a second projector of the same shape (same workspace, same guide tensor) must not inherit the prefetch
+        case2 = SimpleNamespace(cfg=c2[4].cfg, sd={k: (v * 0.5 if k.endswith("q_proj.weight") else v) for k, v in c2[4].sd.items()})
+        m2 = build_module(case2)
+        want2 = m2(ff, fe, g, "video", None).clone()
+        assert not torch.equal(want2, want["g"])
+        m.forward_deferred(ff, fe, g, "video", None, next_guide=g)
+        o_other = m2.forward_deferred(ff, fe, g, "video", None)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(o_other, want2)
         # prefetched, then overwritten in place before use: the version counter voids the prefetch
         o1 = m.forward_deferred(ff, fe, g2, "video", None, next_guide=g3)[0]
         g3.copy_(g2)
