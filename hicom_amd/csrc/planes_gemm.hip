@@ -45,6 +45,7 @@ struct PlanesGemmParams {
     long ldy, row0;
     int nl_group;
     int vec;          // 4-column groups may be stored as one vector (alignment checked on the host)
+    int bvec;         // ... and the bias may be loaded as one vector per 4 columns
 };
 
 constexpr int kPTM = 48, kPTN = 128;
@@ -173,6 +174,20 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(PlanesGemmParams p)
     // prologue: stages 0 .. kPRing-2 in flight, stage 0 landed, its fragments on the way
     const int npro = ns < kPRing - 1 ? ns : kPRing - 1;
     for (int s = 0; s < npro; ++s) issue(s, s);
+    // the bias of this wave's epilogue columns, fetched now (raw, one vector load per column block): a dependent load
+    // in the epilogue is ~1 us of a 13-us kernel
+    uint2 braw[2] = {make_uint2(0, 0), make_uint2(0, 0)};
+    float4 brawf[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    bool bpre[2];
+#pragma unroll
+    for (int jl = 0; jl < 2; ++jl) {
+        const int nb = n0 + 64 * ch + 16 * (2 * kh + jl) + 4 * kg;
+        bpre[jl] = p.b && p.bvec && nb + 3 < p.N;
+        if (bpre[jl]) {
+            if (p.b_f32) brawf[jl] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.b) + nb);
+            else braw[jl] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.b) + nb);
+        }
+    }
     if (npro == kPRing - 1) wait_vm<(kPRing - 2) * PW>();
     else wait_stages(npro - 1);
     __builtin_amdgcn_s_barrier();
@@ -252,7 +267,14 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(PlanesGemmParams p)
         const int n = n0 + 64 * ch + 16 * (2 * kh + jl) + 4 * kg;
         if (n >= p.N) continue;
         float bias[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.b) {
+        if (bpre[jl]) {
+            if (p.b_f32) {
+                bias[0] = brawf[jl].x; bias[1] = brawf[jl].y; bias[2] = brawf[jl].z; bias[3] = brawf[jl].w;
+            } else {
+                bias[0] = bf16lo_to_f32(braw[jl].x); bias[1] = bf16hi_to_f32(braw[jl].x);
+                bias[2] = bf16lo_to_f32(braw[jl].y); bias[3] = bf16hi_to_f32(braw[jl].y);
+            }
+        } else if (p.b) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int nn = n + q < p.N ? n + q : p.N - 1;
@@ -326,7 +348,7 @@ extern "C" int hicom_planes_gemm_fwd(const void* a_hi, const void* a_lo, const v
                      (!y || (ldy % 4 == 0 && (uintptr_t)y % 16 == 0));
     PlanesGemmParams p{(const uint16_t*)a_hi, (const uint16_t*)a_lo, (const uint16_t*)w, b, b_dt == HICOM_DT_F32,
                        M, N, K, act, (uint16_t*)out_hi, (uint16_t*)out_lo, y, y_dt == HICOM_DT_F32, (long)ldy, (long)row0,
-                       nl_group, vec ? 1 : 0};
+                       nl_group, vec ? 1 : 0, (b && (uintptr_t)b % 16 == 0) ? 1 : 0};
     const int nbx = (N + kPTN - 1) / kPTN, nby = (M + kPTM - 1) / kPTM;
     static bool attr_set = false;
     if (!attr_set) {
