@@ -120,8 +120,14 @@ def main():
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    real_stdout = None
     if distributed:
         import torch.distributed as dist
+        # RCCL prints a version banner to the C-level stdout (flushed at exit, i.e. AFTER the JSON line): keep fd 1
+        # for the one JSON line and send everything else to stderr
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
@@ -213,7 +219,11 @@ def main():
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(cfg, module, fpg)
                 result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
-        print(json.dumps(result))
+        line = json.dumps(result)
+        if real_stdout is None:
+            print(line)
+        else:
+            os.write(real_stdout, (line + "\n").encode())
     if distributed:
         dist.destroy_process_group()
 
