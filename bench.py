@@ -237,15 +237,18 @@ def secondary_sweep(args, device, ff, fe, guide):
     with torch.no_grad():
         for _ in range(5):
             out = m(ff, fe, guide, "video", None)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 30
-        for _ in range(n):
-            out = m(ff, fe, guide, "video", None)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
+        dts = []
+        for _ in range(3):                      # best of three batches: a shared box throws the odd 20-ms stall
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 10
+            for _ in range(n):
+                out = m(ff, fe, guide, "video", None)
+            torch.cuda.synchronize()
+            dts.append((time.perf_counter() - t0) / n)
+        dt = min(dts)
     return {"use_guide=None (32 distinct queries)": {"ms_per_forward": dt * 1e3, "tokens_per_sec": out.shape[0] / dt,
-                                                     "note": "joined forwards; two-kernel path (local windows || wide global stream kernel)"}}
+                                                     "note": "joined forwards, best of 3 batches of 10; two-kernel path (local windows || wide global stream kernel)"}}
 
 
 def dominant_kernel_roofline(module, ff, fe, guide, iters):
