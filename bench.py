@@ -100,7 +100,7 @@ def parity_probe(device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--frames-per-gpu", type=int, default=64)
     ap.add_argument("--hidden", type=int, default=896)
@@ -172,11 +172,15 @@ def main():
             out = step()
         assert out.shape == (n_out, args.hidden)
         fence()
+        import gc
+        gc.collect()
+        gc.disable()                       # no collector pause inside the timed region (a step is ~80 us)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = step()
         fence()
         elapsed = time.perf_counter() - t0
+        gc.enable()
     if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
