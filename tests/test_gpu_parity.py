@@ -299,6 +299,37 @@ def test_guide_prefetch_right_wrong_and_modified(c2):
         assert torch.equal(o1, want["g2"]) and torch.equal(o2, want["g2"])
 
 
+def test_random_mix_of_shapes_guides_prefetches_and_joins(c2):
+    """150 back-to-back calls drawn at random from {three videos of two shapes} x {two guides} x {prefetch the right /
+    a wrong / no next guide} x {deferred, joined}: every result equals, bit for bit, the isolated forward of its
+    (video, guide) -- the workspaces, query-buffer sets and events are shared across all of them."""
+    import random
+    m, ff, fe, g, _ = c2
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    small = (torch.randn(16, 27, 27, 1152, device="cuda", generator=gen).bfloat16(),
+             torch.randn(16, 27, 27, 1152, device="cuda", generator=gen).bfloat16())
+    vids = {"a": (ff, fe), "b": small, "c": (fe, ff)}
+    gs = {"g1": g, "g2": (g.float() * -0.7 + 0.05).to(g.dtype)}
+    with torch.no_grad():
+        want = {}
+        for v, (x, y) in vids.items():
+            for k, gg in gs.items():
+                want[v, k] = m(x, y, gg, "video", None).clone()
+                torch.cuda.synchronize()
+        rnd = random.Random(11)
+        seq = [(rnd.choice("abc"), rnd.choice(["g1", "g2"]), rnd.choice(["g1", "g2", None]), rnd.random() < 0.7) for _ in range(150)]
+        outs = []
+        for v, k, nxt, deferred in seq:
+            x, y = vids[v]
+            if deferred:
+                outs.append(m.forward_deferred(x, y, gs[k], "video", None, next_guide=None if nxt is None else gs[nxt])[0])
+            else:
+                outs.append(m(x, y, gs[k], "video", None))
+        torch.cuda.synchronize()
+        bad = [i for i, ((v, k, _, _), o) in enumerate(zip(seq, outs)) if not torch.equal(o, want[v, k])]
+    assert not bad, bad[:10]
+
+
 def test_forward_async_lanes_equal_forward(c2):
     """forward_async (alternating stream lanes) returns, for a stream of DIFFERENT videos submitted back to
     back, exactly the bits of the synchronous forward of each."""
