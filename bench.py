@@ -186,7 +186,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    joined_ms = None
+    joined_ms = deferred_ms = None
     if not distributed:
         # for reference: the same loop with every step joined before the next one starts (plain forward())
         with torch.no_grad():
@@ -198,6 +198,15 @@ def main():
                 module(ff, fe, guide, "video", None)
             torch.cuda.synchronize()
             joined_ms = (time.perf_counter() - t0) / max(20, args.steps // 2) * 1e3
+            # ... and the pipelined loop WITHOUT the guide prefetch (forward_deferred alone)
+            for _ in range(20):
+                module.forward_deferred(ff, fe, guide, "video", None)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(max(20, args.steps // 2)):
+                module.forward_deferred(ff, fe, guide, "video", None)
+            torch.cuda.synchronize()
+            deferred_ms = (time.perf_counter() - t0) / max(20, args.steps // 2) * 1e3
 
     # ---- roofline of the dominant kernel (HIP events on the stream it is launched on) ----------
     roofline = dominant_kernel_roofline(module, ff, fe, guide, args.steps)
@@ -211,7 +220,7 @@ def main():
                    "frames": total_frames, "frames_per_gpu": fpg, "hidden": args.hidden,
                    "parallelism": f"frame-shard x{world}" + (" + RCCL all-gather" if distributed else ""),
                    "launch": "hipGraph replay" if module.graph_replay else "eager (one C call per step), side-stream join deferred to the fence, next guide prefetched"},
-        "ms_per_step_joined": joined_ms,
+        "ms_per_step_joined": joined_ms, "ms_per_step_deferred_no_prefetch": deferred_ms,
         "input_visual_tokens_per_sec": total_frames * GRID * GRID / (ms_per_step * 1e-3),
         "roofline": roofline,
     }
