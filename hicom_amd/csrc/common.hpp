@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 (CDNA4, wave64) HICom kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/hicom_hip.h"
@@ -123,7 +124,19 @@ __device__ __forceinline__ void lds_barrier() {
 namespace hicom_host {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// An event to be recorded right behind the NEXT kernel launch of this thread, folded into that launch
+// (hipExtLaunchKernelGGL's stop event) instead of a separate hipEventRecord: every host call costs 2-4 us and the
+// executor's call sequence is what bounds the step on slow hosts.  Consumed by HICOM_LAUNCH.
+void set_stop_event(void* ev);
+void* take_stop_event();
 }  // namespace hicom_host
+
+#define HICOM_LAUNCH(kernel, grid, block, smem, stream, ...)                                                      \
+    do {                                                                                                         \
+        void* stop_ev_ = hicom_host::take_stop_event();                                                          \
+        if (stop_ev_) hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, nullptr, (hipEvent_t)stop_ev_, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                                 \
+    } while (0)
 
 #define HICOM_REQUIRE(cond, code, ...)            \
     do {                                          \

@@ -14,6 +14,7 @@
 // frame-sharded multi-GPU path can place its RCCL all-gather between them.
 #include <string.h>
 
+#include <stdlib.h>
 #include <utility>
 
 #include "common.hpp"
@@ -185,6 +186,7 @@ extern "C" int hicom_compressor_is_fused(const hicom_compressor_args* a) {
 extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
     HICOM_REQUIRE(ap, HICOM_EINVAL, "compressor: NULL args");
     const hicom_compressor_args& a = *ap;
+    (void)hicom_host::take_stop_event();      // (nothing pending from a call that failed half-way)
 #ifdef HICOM_HOSTTIME
     g_hlast = ht_now();
 #endif
@@ -199,6 +201,10 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
     const bool do_stream = a.phases & HICOM_PHASE_STREAM, do_finish = a.phases & HICOM_PHASE_FINISH;
     const bool fused = do_stream && can_fuse(a);
     const bool merge_on_next = fused && (a.phases & HICOM_PHASE_MERGE_ON_NEXT);
+    // event records folded into the launches they follow (release recipe); HICOM_FOLD_EVENTS=0 keeps separate records
+    static const bool fold_env = !(getenv("HICOM_FOLD_EVENTS") && getenv("HICOM_FOLD_EVENTS")[0] == '0');
+    const bool fold_ev = fused && fold_env;
+    bool join_folded = false, done_folded = false;
     if (a.phases & HICOM_PHASE_MERGE_ON_NEXT)
         HICOM_REQUIRE(fused && a.ev_done && a.stream_next, HICOM_EINVAL, "compressor: MERGE_ON_NEXT needs the release recipe, ev_done and stream_next");
     // the global chain runs on the side stream only when there is local work to overlap it with
@@ -214,12 +220,13 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         return HICOM_OK;
     };
     auto query_prep_of = [&](const void* gq, const void* lq, hipStream_t st, bool with_local_rows, bool other_set,
-                             char* base = nullptr) -> int {
+                             char* base = nullptr, void* stop_ev = nullptr) -> int {
         const size_t qp = other_set ? w.qp_n : w.qp, qhi = other_set ? w.qhi_n : w.qhi, qlo = other_set ? w.qlo_n : w.qlo,
                      pos_a = other_set ? w.pos_a_n : w.pos_a;
         char* b = base ? base : ws;
         CHK(hicom_linear_fwd(gq, HICOM_DT_BF16, a.wq, HICOM_DT_BF16, a.bq, HICOM_DT_BF16, nullptr, 0, a.nq, a.E, a.E,
                              0, 0, HICOM_ACT_NONE, (float*)(b + qp), st));
+        if (stop_ev) hicom_host::set_stop_event(stop_ev);
         return hicom_fold_query_split_fwd((float*)(b + qp), a.wk, a.kpe, a.nq, a.nh, a.E, a.P, qscale, b + qhi, b + qlo,
                                           (float*)(b + pos_a), a.P, with_local_rows ? lq : nullptr, w.R, 16 - w.R, st);
     };
@@ -255,21 +262,28 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         if (a.ev_merge && !merge_on_next)
             HICOM_REQUIRE(hipStreamWaitEvent(sm, (hipEvent_t)a.ev_merge, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
         if (!a.skip_prep) CHK(query_prep(sm, true));
+        if (fold_ev && !merge_on_next) hicom_host::set_stop_event(a.ev_fork);      // "record ev_fork" rides on the launch
         CHK(hicom_fused_stream_fwd(a.ff, a.fe ? a.fe : a.ff, a.T, a.H, a.W, a.E, a.at.k, a.ay.k, ws + w.qhi, ws + w.qlo,
                                    w.R, a.l_scale, a.l_bias, a.pe ? F(w.pos_a) : nullptr, a.P, a.pe ? a.pe_hi : nullptr, a.pe ? a.pe_lo : nullptr, a.t_index0, a.y_index0,
                                    a.x_index0, F(w.part_m), F(w.part_l), F(w.part_acc),
                                    w.nparts, nullptr, ws + w.ctx_hi, ws + w.ctx_lo, sm));
         if (!merge_on_next) {
-            CHK(fork());
+            if (fold_ev) HICOM_REQUIRE(hipStreamWaitEvent(ss, (hipEvent_t)a.ev_fork, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
+            else CHK(fork());
             // the value-side pos-emb is already inside the partial contexts: a plain merge, one launch
+            if (fold_ev && a.ev_merge) hicom_host::set_stop_event(a.ev_merge);
             CHK(hicom_global_merge_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E, nullptr, 0, w.N,
                                        a.H, a.W, nullptr, 0, 0, 0, nullptr, ml_out, acc_out, solo ? 1 : 0, ss));
-            if (a.ev_merge)
+            if (a.ev_merge && !fold_ev)
                 HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_merge, ss) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
         }
         // readout MLP on bf16 planes: contexts (hi/lo) -> hidden (hi/lo) -> packed output rows
         CHK(hicom_planes_gemm_fwd(ws + w.ctx_hi, ws + w.ctx_lo, a.lw0, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E,
                                   HICOM_ACT_GELU, ws + w.hid_hi, ws + w.hid_lo, nullptr, 0, 0, 0, 0, sm));
+        if (fold_ev && a.ev_done && merge_on_next && !do_finish && !(a.nl_count > 0 && !a.local_out)) {
+            hicom_host::set_stop_event(a.ev_done);        // last main-stream launch of a STREAM-only call
+            done_folded = true;
+        }
         CHK(hicom_planes_gemm_fwd(ws + w.hid_hi, ws + w.hid_lo, a.lw2, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden,
                                   HICOM_ACT_NONE, nullptr, nullptr, a.local_out ? a.local_out : a.out, a.out_dt,
                                   a.local_out ? a.hidden : a.ldo, a.local_out ? 0 : a.local_row0,
@@ -320,24 +334,39 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                              0, 0, HICOM_ACT_NONE, F(w.pre), sg));
         CHK(hicom_linear_fwd(F(w.pre), HICOM_DT_F32, a.gw0, HICOM_DT_BF16, a.gb0, HICOM_DT_BF16, nullptr, 0, a.nq, a.hidden,
                              a.E, 0, 0, HICOM_ACT_GELU, F(w.hid_g), sg));
+        join_folded = fold_ev && both && do_stream && !merge_on_next && sg == ss;
+        if (join_folded) hicom_host::set_stop_event(a.ev_join);                    // "record ev_join" rides on the last launch
         CHK(hicom_linear_to_rows_fwd(F(w.hid_g), HICOM_DT_F32, a.gw2, HICOM_DT_BF16, a.gb2, HICOM_DT_BF16, a.nq, a.hidden,
                                      a.hidden, HICOM_ACT_NONE, a.out, a.out_dt, a.ldo, a.global_row0, a.n_global_rows, sg));
     }
 
     if (both && do_stream && !merge_on_next) {
-        HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_join, ss) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
+        if (!join_folded)
+            HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_join, ss) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
         const bool defer = fused && a.defer_join && a.ev_merge;      // the caller joins on ev_join itself
         if (!defer)
             HICOM_REQUIRE(hipStreamWaitEvent(sm, (hipEvent_t)a.ev_join, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
     }
+    const bool tail_prefetch = a.prep_ws && a.next_gq && a.next_lq && do_finish && !do_stream && a.has_local && a.has_global;
+    static const bool fold_env2 = !(getenv("HICOM_FOLD_EVENTS") && getenv("HICOM_FOLD_EVENTS")[0] == '0');
     if (a.place_src && do_finish) {
         const int esz = a.out_dt == HICOM_DT_F32 ? 4 : 2;
+        if (fold_env2 && a.ev_done && !do_stream && !tail_prefetch) {
+            hicom_host::set_stop_event(a.ev_done);
+            done_folded = true;
+        }
         CHK(hicom_place_blocks_fwd(a.place_src, a.place_block_rows, a.place_nblocks, a.place_block_stride, a.hidden * esz, a.out,
                                    a.ldo * esz, 0, a.nl_group, sm));
     }
-    if (a.prep_ws && a.next_gq && a.next_lq && do_finish && !do_stream && a.has_local && a.has_global)
-        CHK(query_prep_of(a.next_gq, a.next_lq, sm, true, false, (char*)a.prep_ws));     // guide prefetch for this set's next use
-    if (a.ev_done) {
+    if (tail_prefetch) {
+        if (fold_env2 && a.ev_done) done_folded = true;            // rides on the fold kernel, the last launch of the prep
+        CHK(query_prep_of(a.next_gq, a.next_lq, sm, true, false, (char*)a.prep_ws, done_folded ? a.ev_done : nullptr));
+    }
+    if (a.ev_done && done_folded) {
+        if (a.stream_next)
+            HICOM_REQUIRE(hipStreamWaitEvent((hipStream_t)a.stream_next, (hipEvent_t)a.ev_done, 0) == hipSuccess, HICOM_ELAUNCH,
+                          "compressor: stream wait");
+    } else if (a.ev_done) {
         HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_done, sm) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
         if (a.stream_next)
             HICOM_REQUIRE(hipStreamWaitEvent((hipStream_t)a.stream_next, (hipEvent_t)a.ev_done, 0) == hipSuccess, HICOM_ELAUNCH,

@@ -685,6 +685,6 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T,
                       HICOM_ELAUNCH, "fused_stream: 160 KiB of LDS per workgroup not available");
         attr_set = true;
     }
-    hipLaunchKernelGGL(fused_ring_kernel<9>, dim3((unsigned)nparts), dim3(kRingThreads), smem, (hipStream_t)stream, p);
+    HICOM_LAUNCH(fused_ring_kernel<9>, dim3((unsigned)nparts), dim3(kRingThreads), smem, (hipStream_t)stream, p);
     return hicom_host::check_launch("fused_stream");
 }

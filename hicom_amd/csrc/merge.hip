@@ -256,7 +256,7 @@ extern "C" int hicom_global_merge_fwd(const float* part_m, const float* part_l, 
     HICOM_REQUIRE(E % 4 == 0 && (!pe || H + W <= 1024), HICOM_EUNSUP, "global_merge: E %% 4 and H + W <= 1024");
     const size_t smem2 = ((size_t)nparts + (pe ? (size_t)2 * T + H + W + (size_t)kTC * (H + W + 2) : 0) + 16 * 64 + 4) * 4;
     HICOM_REQUIRE(smem2 <= 60000, HICOM_EUNSUP, "global_merge: too many partials/frames for one pass");
-    hipLaunchKernelGGL(merge_ctx_kernel, dim3((unsigned)rows, (unsigned)((E + 31) / 32)), dim3(256), smem2, s, p);
+    HICOM_LAUNCH(merge_ctx_kernel, dim3((unsigned)rows, (unsigned)((E + 31) / 32)), dim3(256), smem2, s, p);
     return hicom_host::check_launch("global_merge");
 }
 

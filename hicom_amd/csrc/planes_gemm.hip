@@ -359,7 +359,7 @@ extern "C" int hicom_planes_gemm_fwd(const void* a_hi, const void* a_lo, const v
         attr_set = true;
     }
     const dim3 grid((unsigned)(8 * nbx * ((nby + 7) / 8)));
-    if (a_lo) hipLaunchKernelGGL(planes_gemm_kernel<true>, grid, dim3(256), kPRing * kPStage, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(planes_gemm_kernel<false>, grid, dim3(256), kPRing * kPStage, (hipStream_t)stream, p);
+    if (a_lo) HICOM_LAUNCH(planes_gemm_kernel<true>, grid, dim3(256), kPRing * kPStage, (hipStream_t)stream, p);
+    else HICOM_LAUNCH(planes_gemm_kernel<false>, grid, dim3(256), kPRing * kPStage, (hipStream_t)stream, p);
     return hicom_host::check_launch("planes_gemm");
 }

@@ -14,6 +14,13 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+static thread_local void* g_stop_event = nullptr;
+void set_stop_event(void* ev) { g_stop_event = ev; }
+void* take_stop_event() {
+    void* ev = g_stop_event;
+    g_stop_event = nullptr;
+    return ev;
+}
 int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -274,10 +281,10 @@ static int launch_linear(const LinearParams& p, void* stream) {
 #define HICOM_LAUNCH_LINEAR(MR)                                                                                        \
     do {                                                                                                               \
         dim3 grid((unsigned)((N + 3) / 4), (unsigned)((M + (MR)-1) / (MR)));                                            \
-        if (p.x_f32 && p.w_f32) hipLaunchKernelGGL((linear_rows_kernel<true, true, MR>), grid, dim3(256), 0, s, p);     \
-        else if (p.x_f32) hipLaunchKernelGGL((linear_rows_kernel<true, false, MR>), grid, dim3(256), 0, s, p);          \
-        else if (p.w_f32) hipLaunchKernelGGL((linear_rows_kernel<false, true, MR>), grid, dim3(256), 0, s, p);          \
-        else hipLaunchKernelGGL((linear_rows_kernel<false, false, MR>), grid, dim3(256), 0, s, p);                      \
+        if (p.x_f32 && p.w_f32) HICOM_LAUNCH((linear_rows_kernel<true, true, MR>), grid, dim3(256), 0, s, p);           \
+        else if (p.x_f32) HICOM_LAUNCH((linear_rows_kernel<true, false, MR>), grid, dim3(256), 0, s, p);                \
+        else if (p.w_f32) HICOM_LAUNCH((linear_rows_kernel<false, true, MR>), grid, dim3(256), 0, s, p);                \
+        else HICOM_LAUNCH((linear_rows_kernel<false, false, MR>), grid, dim3(256), 0, s, p);                            \
     } while (0)
     if (M == 1) HICOM_LAUNCH_LINEAR(1);     // GEMV: one shuffle reduction per column instead of eight
     else HICOM_LAUNCH_LINEAR(8);
@@ -318,8 +325,8 @@ static int launch_fold(const float* qp, const void* w_k, const float* kpe, int n
     FoldParams p{qp, (const uint16_t*)w_k, kpe, nq, nh, E, kpe ? P : 0, scale, qt, (uint16_t*)hi, (uint16_t*)lo,
                  pos_a, pos_stride, (E + 31) / 32, (const uint16_t*)fill, fill_row0, fill ? fill_rows : 0};
     const unsigned gx = (unsigned)(p.nbE + (p.P + 15) / 16), gy = (unsigned)(nh + (p.fill_rows > 0 ? 1 : 0));
-    if (nq == 1) hipLaunchKernelGGL(fold_query_kernel<1>, dim3(gx, gy, 1), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(fold_query_kernel<8>, dim3(gx, gy, (unsigned)((nq + 7) / 8)), dim3(256), 0, (hipStream_t)stream, p);
+    if (nq == 1) HICOM_LAUNCH(fold_query_kernel<1>, dim3(gx, gy, 1), dim3(256), 0, (hipStream_t)stream, p);
+    else HICOM_LAUNCH(fold_query_kernel<8>, dim3(gx, gy, (unsigned)((nq + 7) / 8)), dim3(256), 0, (hipStream_t)stream, p);
     return hicom_host::check_launch("fold_query");
 }
 
@@ -372,7 +379,7 @@ extern "C" int hicom_place_blocks_fwd(const void* src, int32_t block_rows, int32
                       block_stride_bytes % 16 == 0 && nl_group >= 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0),
                   HICOM_EINVAL, "place_blocks: bad shape / alignment");
     const int count = block_rows * nblocks;
-    hipLaunchKernelGGL(place_blocks_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const char*)src,
+    HICOM_LAUNCH(place_blocks_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const char*)src,
                        block_rows, (long)block_stride_bytes, row_bytes, (char*)dst, (long)ldd_bytes, (long)row0, nl_group, count);
     return hicom_host::check_launch("place_blocks");
 }
