@@ -32,6 +32,8 @@ def is_stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
+    # HICOM_FORCE_BUILD=1: compile even when an up-to-date library is present (the driver's "does it build" check)
+    force = force or os.environ.get("HICOM_FORCE_BUILD") == "1"
     if not force and not is_stale():
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

@@ -28,7 +28,6 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct WsLayout {
     size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, qp, qhi, qlo, pos_a, scores, part_m, part_l, part_acc, scratch, ml, acc,
         ctx_g, o, qres, pre, hid_g, tok, total;
-    size_t qp_n, qhi_n, qlo_n, pos_a_n;     // the OTHER query-buffer set (args.q_set selects; a guide prefetch writes this one)
     int nw, R, rows_pad, nparts, P;
     long N, score_stride;
 };
@@ -73,9 +72,6 @@ WsLayout make_layout(const hicom_compressor_args& a) {
     w.qhi = take((size_t)w.rows_pad * a.E * 2);
     w.qlo = take((size_t)w.rows_pad * a.E * 2);
     w.pos_a = take((size_t)w.rows_pad * (a.P > 0 ? a.P : 1) * 4);
-    w.qhi_n = take((size_t)w.rows_pad * a.E * 2);
-    w.qlo_n = take((size_t)w.rows_pad * a.E * 2);
-    w.pos_a_n = take((size_t)w.rows_pad * (a.P > 0 ? a.P : 1) * 4);
     if (a.has_local) {
         w.ctx_local = take((size_t)w.nw * a.E * 4);          // fp32 form (two-kernel path) ...
         w.hid_local = take((size_t)w.nw * a.hidden * 4);
@@ -87,7 +83,6 @@ WsLayout make_layout(const hicom_compressor_args& a) {
     }
     if (a.has_global) {
         w.qp = take((size_t)a.nq * a.E * 4);
-        w.qp_n = take((size_t)a.nq * a.E * 4);
         w.scores = take((size_t)w.rows_pad * w.score_stride * 4);
         w.part_m = take((size_t)w.nparts * w.rows_pad * 4);
         w.part_l = take((size_t)w.nparts * w.rows_pad * 4);
@@ -103,12 +98,6 @@ WsLayout make_layout(const hicom_compressor_args& a) {
         w.tok = take((size_t)a.nq * a.hidden * 4);
     }
     w.total = off;
-    if (a.q_set) {
-        std::swap(w.qhi, w.qhi_n);
-        std::swap(w.qlo, w.qlo_n);
-        std::swap(w.pos_a, w.pos_a_n);
-        std::swap(w.qp, w.qp_n);
-    }
     return w;
 }
 
@@ -175,7 +164,7 @@ extern "C" int64_t hicom_compressor_workspace_bytes(const hicom_compressor_args*
 extern "C" int64_t hicom_compressor_zero_prefix_bytes(const hicom_compressor_args* a) {
     if (!a) return HICOM_EINVAL;
     const WsLayout w = make_layout(*a);
-    return (int64_t)(a->has_local ? w.ctx_local : (w.qp < w.qp_n ? w.qp : w.qp_n));
+    return (int64_t)(a->has_local ? w.ctx_local : w.qp);
 }
 
 extern "C" int hicom_compressor_is_fused(const hicom_compressor_args* a) {
@@ -203,7 +192,11 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
     const bool merge_on_next = fused && (a.phases & HICOM_PHASE_MERGE_ON_NEXT);
     // event records folded into the launches they follow (release recipe); HICOM_FOLD_EVENTS=0 keeps separate records
     static const bool fold_env = !(getenv("HICOM_FOLD_EVENTS") && getenv("HICOM_FOLD_EVENTS")[0] == '0');
-    const bool fold_ev = fused && fold_env;
+    // ... but never while the main stream is being captured into a hipGraph: the stop event of hipExtLaunchKernelGGL is
+    // not a captured event-record node, so the fork / join edges of the side stream would be missing from the graph
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(sm, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    const bool fold_ev = fused && fold_env && !capturing;
     bool join_folded = false, done_folded = false;
     if (a.phases & HICOM_PHASE_MERGE_ON_NEXT)
         HICOM_REQUIRE(fused && a.ev_done && a.stream_next, HICOM_EINVAL, "compressor: MERGE_ON_NEXT needs the release recipe, ev_done and stream_next");
@@ -219,18 +212,12 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         HICOM_REQUIRE(hipStreamWaitEvent(ss, (hipEvent_t)a.ev_fork, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
         return HICOM_OK;
     };
-    auto query_prep_of = [&](const void* gq, const void* lq, hipStream_t st, bool with_local_rows, bool other_set,
-                             char* base = nullptr, void* stop_ev = nullptr) -> int {
-        const size_t qp = other_set ? w.qp_n : w.qp, qhi = other_set ? w.qhi_n : w.qhi, qlo = other_set ? w.qlo_n : w.qlo,
-                     pos_a = other_set ? w.pos_a_n : w.pos_a;
-        char* b = base ? base : ws;
-        CHK(hicom_linear_fwd(gq, HICOM_DT_BF16, a.wq, HICOM_DT_BF16, a.bq, HICOM_DT_BF16, nullptr, 0, a.nq, a.E, a.E,
-                             0, 0, HICOM_ACT_NONE, (float*)(b + qp), st));
-        if (stop_ev) hicom_host::set_stop_event(stop_ev);
-        return hicom_fold_query_split_fwd((float*)(b + qp), a.wk, a.kpe, a.nq, a.nh, a.E, a.P, qscale, b + qhi, b + qlo,
-                                          (float*)(b + pos_a), a.P, with_local_rows ? lq : nullptr, w.R, 16 - w.R, st);
+    auto query_prep = [&](hipStream_t st, bool with_local_rows) -> int {
+        CHK(hicom_linear_fwd(a.gq, HICOM_DT_BF16, a.wq, HICOM_DT_BF16, a.bq, HICOM_DT_BF16, nullptr, 0, a.nq, a.E, a.E,
+                             0, 0, HICOM_ACT_NONE, F(w.qp), st));
+        return hicom_fold_query_split_fwd(F(w.qp), a.wk, a.kpe, a.nq, a.nh, a.E, a.P, qscale, ws + w.qhi, ws + w.qlo,
+                                          F(w.pos_a), a.P, with_local_rows ? a.lq : nullptr, w.R, 16 - w.R, st);
     };
-    auto query_prep = [&](hipStream_t st, bool with_local_rows) -> int { return query_prep_of(a.gq, a.lq, st, with_local_rows, false); };
     auto merge = [&](hipStream_t st) -> int {
         return hicom_global_merge_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E,
                                       F(w.scores), w.score_stride, w.N, a.H, a.W, a.pe, a.t_index0, a.y_index0,
@@ -252,16 +239,11 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         // ---- release recipe: ONE streaming kernel reads frames_embed and frames_feature once ------
         // main: q_proj, fold (+ guide -> local rows of the A operand), fused stream      | fork |
         // main: readout GEMMs            side: merge -> (finish)                 | join |
-        // guide prefetch: the NEXT call's prep goes into the other query-buffer set, at the head of this call's side
-        // stream work -- it runs under this call's stream kernel (that set's last reader, an earlier stream kernel,
-        // finished before the side-stream work that precedes this in stream order was released)
-        if (a.next_gq && a.next_lq && a.ev_merge && both && !merge_on_next) CHK(query_prep_of(a.next_gq, a.next_lq, ss, true, true));
         // the stream kernel overwrites the partial states: the previous call's merge (side stream, possibly still
-        // running when that call deferred its join) has to be done with them; the same event also orders this call
-        // behind the guide prefetch the previous call ran on the side stream
+        // running when that call deferred its join) has to be done with them
         if (a.ev_merge && !merge_on_next)
             HICOM_REQUIRE(hipStreamWaitEvent(sm, (hipEvent_t)a.ev_merge, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
-        if (!a.skip_prep) CHK(query_prep(sm, true));
+        CHK(query_prep(sm, true));
         if (fold_ev && !merge_on_next) hicom_host::set_stop_event(a.ev_fork);      // "record ev_fork" rides on the launch
         CHK(hicom_fused_stream_fwd(a.ff, a.fe ? a.fe : a.ff, a.T, a.H, a.W, a.E, a.at.k, a.ay.k, ws + w.qhi, ws + w.qlo,
                                    w.R, a.l_scale, a.l_bias, a.pe ? F(w.pos_a) : nullptr, a.P, a.pe ? a.pe_hi : nullptr, a.pe ? a.pe_lo : nullptr, a.t_index0, a.y_index0,
@@ -347,20 +329,15 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         if (!defer)
             HICOM_REQUIRE(hipStreamWaitEvent(sm, (hipEvent_t)a.ev_join, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
     }
-    const bool tail_prefetch = a.prep_ws && a.next_gq && a.next_lq && do_finish && !do_stream && a.has_local && a.has_global;
-    static const bool fold_env2 = !(getenv("HICOM_FOLD_EVENTS") && getenv("HICOM_FOLD_EVENTS")[0] == '0');
+    const bool fold_ev2 = fold_env && !capturing;
     if (a.place_src && do_finish) {
         const int esz = a.out_dt == HICOM_DT_F32 ? 4 : 2;
-        if (fold_env2 && a.ev_done && !do_stream && !tail_prefetch) {
+        if (fold_ev2 && a.ev_done && !do_stream) {
             hicom_host::set_stop_event(a.ev_done);
             done_folded = true;
         }
         CHK(hicom_place_blocks_fwd(a.place_src, a.place_block_rows, a.place_nblocks, a.place_block_stride, a.hidden * esz, a.out,
                                    a.ldo * esz, 0, a.nl_group, sm));
-    }
-    if (tail_prefetch) {
-        if (fold_env2 && a.ev_done) done_folded = true;            // rides on the fold kernel, the last launch of the prep
-        CHK(query_prep_of(a.next_gq, a.next_lq, sm, true, false, (char*)a.prep_ws, done_folded ? a.ev_done : nullptr));
     }
     if (a.ev_done && done_folded) {
         if (a.stream_next)

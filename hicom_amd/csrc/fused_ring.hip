@@ -401,10 +401,13 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
             f0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bff_t, ahi_t, f0, 0, 0, 0);
             f1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bff_t, alo_t, f1, 0, 0, 0);
         }
-        // The accumulators are read by VALU right away.  hipcc pads an MFMA -> VALU read with the wait states of
-        // its own latency table, and for the K = 16 tail (v_mfma_f32_16x16x16_bf16 on gfx950) that padding proved
-        // too short under load: logits of a tile came out stale whenever a co-resident wave delayed the matrix
-        // pipe (timing-dependent corruption of single tiles).  Sixteen explicit wait states close the hazard.
+        // The accumulators are read by VALU right away.  Required software wait states, CDNA4 ISA §4.1 (data-hazard table,
+        // "XDL write VGPR -> VALU read / write of that VGPR"; summarised in cdna_hip_programming.md §5.7 item 2): an 8-pass
+        // XDL op (32x32x16) needs 12, the 4-pass 16x16x32 / 16x16x16 forms used here fewer.  hipcc inserts them from its
+        // own table, but for the K = 16 tail (v_mfma_f32_16x16x16_bf16) its padding proved too short under load on
+        // gfx950 / ROCm 7.2 (logits of single tiles read stale whenever a co-resident wave delayed the matrix pipe;
+        // tools/dbg_async.py reproduces it on the unpadded build).  16 explicit states = the table's largest entry
+        // for any shape in this file, independent of the compiler's model.
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
         {
             const f32x4 part_logit = (r16 < R) ? (f0 + f1) : e0;

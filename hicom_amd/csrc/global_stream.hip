@@ -333,7 +333,11 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
             // "s_waitcnt vmcnt(0)" in front of the next LDS read it cannot tell apart from them (which drained the
             // whole prefetch once per tile).  Ordering is this kernel's own: counted vmcnt + barrier [A].
             const unsigned dst = tile_lds + buf * TILE_BYTES + pi * 1024;          // wave-uniform LDS base of the piece
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory", "m0");
+            // M0 (the DMA's LDS base) is compiler-reserved and not preserved around an asm statement: save it, write it
+            // and restore it inside ONE statement (cdna_hip_programming.md §5.7, "Operands and clobbers")
+            unsigned keep_m0;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep_m0) : "v"(src), "s"(dst) : "memory");
         }
     };
 

@@ -12,8 +12,10 @@ north star asks for.  What makes it exact:
 Exchange = ONE all-gather of a flat per-rank buffer [state | local tokens] (a few MB): on a
 fully-connected xGMI node that is 7 concurrent peer writes, not a ring.
 
-`FrameShardPlan` and `exchange()` are device-agnostic (exercised with gloo on CPU in
-tests/test_dist_cpu.py); `sharded_forward()` is the HIP path.
+`FrameShardPlan`, `PackLayout` and `gather_packed()` are device-agnostic and are THE pack / all-gather / unpack
+code of both paths: the HIP path (`sharded_forward`) has its kernels write straight into a `PackLayout` send
+buffer and read the gathered buffer at the layout's offsets; the CPU/gloo test (tests/test_dist_cpu.py) fills and
+reads the same layout with copies (`exchange`).
 """
 from __future__ import annotations
 
@@ -22,8 +24,6 @@ from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
-
-from . import geometry as geo
 
 
 @dataclass(frozen=True)
@@ -49,92 +49,124 @@ class FrameShardPlan:
         return self.frames_per_rank // self.kt * wh * ww
 
 
+@dataclass(frozen=True)
+class PackLayout:
+    """Per-rank exchange buffer: [state f32 x state_floats | pad to 16 B | local tokens rows x cols | pad to 16 B]."""
+    state_floats: int
+    token_rows: int
+    token_cols: int
+    token_itemsize: int
+
+    @property
+    def state_bytes(self) -> int:
+        return self.state_floats * 4
+
+    @property
+    def tok_off(self) -> int:
+        return self.state_bytes + (-self.state_bytes) % 16
+
+    @property
+    def tok_bytes(self) -> int:
+        return self.token_rows * self.token_cols * self.token_itemsize
+
+    @property
+    def total(self) -> int:
+        n = self.tok_off + self.tok_bytes
+        return n + (-n) % 16
+
+    @property
+    def set_stride_floats(self) -> int:
+        """Distance, in floats, between two ranks' states inside the gathered buffer."""
+        return self.total // 4
+
+    def new_buffer(self, device, world: int = 0) -> torch.Tensor:
+        shape = (self.total,) if world == 0 else (world, self.total)
+        return torch.zeros(shape, dtype=torch.uint8, device=device)
+
+    def state_view(self, buf: torch.Tensor) -> torch.Tensor:
+        """f32 view of the state part: [state_floats] of a send buffer, [world, state_floats] of a gathered one."""
+        return buf[..., :self.state_bytes].view(torch.float32) if buf.ndim == 1 else \
+            buf[:, :self.state_bytes].contiguous().view(torch.float32)
+
+    def tokens_view(self, buf: torch.Tensor, dtype) -> torch.Tensor:
+        """Token rows: [rows, cols] of a send buffer (a view), [world * rows, cols] of a gathered one (rank order =
+        frame order)."""
+        a, b = self.tok_off, self.tok_off + self.tok_bytes
+        if buf.ndim == 1:
+            return buf[a:b].view(dtype).view(self.token_rows, self.token_cols)
+        return buf[:, a:b].contiguous().view(dtype).view(buf.shape[0] * self.token_rows, self.token_cols)
+
+
+def gather_packed(mine: torch.Tensor, everyone: torch.Tensor, group=None) -> torch.Tensor:
+    """THE collective of the path: all-gathers every rank's packed buffer into `everyone` [world, total] (rank-major),
+    ordered on the current stream of `mine`'s device."""
+    dist.all_gather_into_tensor(everyone.view(-1), mine, group=group)
+    return everyone
+
+
 def exchange(state: torch.Tensor, local_tokens: torch.Tensor, group=None):
     """All-gathers (state f32 [S], local tokens [Nw_rank, H]) of every rank with ONE collective.
-
-    Returns (states [world, S] f32, tokens [world * Nw_rank, H]) in rank order = frame order.
-    (Copying reference form used by the CPU/gloo test; the HIP path below gathers a pre-packed
-    send buffer that the kernels wrote in place.)"""
+    Returns (states [world, S] f32, tokens [world * Nw_rank, H]) in rank order = frame order."""
     world = dist.get_world_size(group)
-    mine, s_bytes, pad = pack_buffer(state.numel(), local_tokens.shape, local_tokens.dtype, state.device)
-    mine[:s_bytes].view(torch.float32).copy_(state.reshape(-1))
-    mine[s_bytes + pad:].view(local_tokens.dtype).copy_(local_tokens.reshape(-1))
-    everyone = gather_buffers(mine, group)
-    states = everyone[:, :s_bytes].contiguous().view(torch.float32).view(world, -1)
-    tokens = everyone[:, s_bytes + pad:].contiguous().view(local_tokens.dtype).view(world * local_tokens.shape[0], -1)
-    return states, tokens
-
-
-def pack_buffer(state_floats: int, token_shape, token_dtype, device):
-    """Per-rank send buffer [state f32 | pad to 16 B | local tokens]; returns (buffer, state bytes, pad)."""
-    s_bytes = state_floats * 4
-    pad = (-s_bytes) % 16
-    t_bytes = token_shape[0] * token_shape[1] * torch.empty((), dtype=token_dtype).element_size()
-    tail = (-(s_bytes + pad + t_bytes)) % 16
-    return torch.empty(s_bytes + pad + t_bytes + tail, dtype=torch.uint8, device=device), s_bytes, pad
-
-
-def gather_buffers(mine: torch.Tensor, group=None) -> torch.Tensor:
-    world = dist.get_world_size(group)
-    flat = torch.empty(world * mine.numel(), dtype=torch.uint8, device=mine.device)
-    dist.all_gather_into_tensor(flat, mine, group=group)      # rank-major concatenation
-    return flat.view(world, mine.numel())
+    lay = PackLayout(state.numel(), local_tokens.shape[0], local_tokens.shape[1], local_tokens.element_size())
+    mine = lay.new_buffer(state.device)
+    lay.state_view(mine).copy_(state.reshape(-1))
+    lay.tokens_view(mine, local_tokens.dtype).copy_(local_tokens)
+    everyone = gather_packed(mine, lay.new_buffer(state.device, world), group)
+    return lay.state_view(everyone), lay.tokens_view(everyone, local_tokens.dtype)
 
 
 class _ShardSet:
-    """One set of exchange buffers + argument blocks (two sets alternate so that the all-gather of step i can
-    still be reading its send buffer while step i+1 streams into the other one)."""
-    __slots__ = ("mine", "everyone", "tok_off", "a_stream", "a_finish", "ev_stream", "ev_tok", "out", "fused", "q_ready")
+    """One set of exchange buffers + argument blocks + workspaces (two sets alternate so that the all-gather of step i
+    can still be reading its send buffer while step i+1 streams into the other one)."""
+    __slots__ = ("mine", "everyone", "a_stream", "a_finish", "ws_stream", "ws_finish", "ev_stream", "ev_tok", "out", "fused")
 
 
 class _ShardPlan:
-    __slots__ = ("sets", "n", "comm", "res", "lay", "nw", "hidden", "odt", "n_rows_total", "world")
+    __slots__ = ("sets", "n", "comm", "res", "lay", "pack", "nw", "hidden", "odt", "n_rows_total", "world", "rank", "sig",
+                 "guide_fields")
+
+    def set_inputs(self, st: _ShardSet, ff, fe, guide, out):
+        """Patches this call's tensors into both argument blocks of a buffer set."""
+        for a in (st.a_stream, st.a_finish):
+            a.ff = ff.data_ptr()
+            if fe is not None:
+                a.fe = fe.data_ptr()
+            if guide is not None:
+                for f in self.guide_fields:
+                    setattr(a, f, guide.data_ptr())
+            a.out = out.data_ptr()
+
+    def release(self):
+        """Before the plan's buffers go back to the allocator: everything its comm stream still does with them."""
+        self.comm.synchronize()
 
 
-def _fast_key(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group, cur, rank=None, world=None):
-    """Cheap identity of a repeated call (the full key walks every parameter's pointer; here: the parameter-list
-    generation, the sum of the parameters' in-place version counters and the input buffers)."""
-    from . import engine
-    d = projector.__dict__
-    cached = d.get("_engine_params")
-    if cached is None or cached[0] != d.get("_engine_params_gen", 0):
-        engine._param_stamp(projector)
-        cached = d["_engine_params"]
-    ver = 0
-    for p in cached[1]:
-        ver += p._version
-    return (ff_shard.data_ptr(), ff_shard.shape[0], None if fe_shard is None else fe_shard.data_ptr(),
-            None if guide_embed is None else (guide_embed.data_ptr(), guide_embed._version),
-            None if image_newline is None else image_newline.data_ptr(), total_frames, group, rank, world, cur.cuda_stream,
-            cached[0], ver, projector.global_compressor._cache_gen)
+_MAX_SHARD_PLANS = 8
 
 
-def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group, rank=None, world=None):
-    """Cached per-(inputs, rank, world) plan: two buffer sets with their argument blocks.  `rank` / `world` default to
-    the process group's; the single-GPU test of the N > 1 device path passes them explicitly (no collective)."""
+def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group, rank=None, world=None) -> _ShardPlan:
+    """Plan of one (problem shape, rank, world, caller stream, weight state): two buffer sets, each with its own argument
+    blocks, exchange buffers and workspaces, and the plan's comm stream.  The input pointers are patched per call
+    (`set_inputs`).  `rank` / `world` default to the process group's; the single-GPU tests of the N > 1 device path pass
+    them explicitly (no collective)."""
     from . import engine
     from . import native as nv
     from .projector import _out_dtype
     lc, gc = projector.local_compressor, projector.global_compressor
     dev = ff_shard.device
     cur = torch.cuda.current_stream(dev)
-    last = projector.__dict__.get("_shard_last")
-    if last is not None and last[0] == _fast_key(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group, cur,
-                                                 rank, world):
-        return last[1]
-    fk_rank, fk_world = rank, world
     if rank is None or world is None:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-    key = ("shard", ff_shard.data_ptr(), tuple(ff_shard.shape), None if fe_shard is None else fe_shard.data_ptr(),
-           None if guide_embed is None else (guide_embed.data_ptr(), guide_embed._version),
-           None if image_newline is None else image_newline.data_ptr(),
-           _out_dtype(projector), world, rank, total_frames, cur.cuda_stream, gc._cache_gen, engine._param_stamp(projector))
-    plans = projector.__dict__.setdefault("_engine_plans", {})
+    key = (tuple(ff_shard.shape), fe_shard is not None, None if guide_embed is None else tuple(guide_embed.shape),
+           image_newline is not None, _out_dtype(projector), world, rank, total_frames, cur.cuda_stream, id(group))
+    plans = projector.__dict__.setdefault("_shard_plans", {})
     plan = plans.get(key)
-    if plan is not None:
-        projector.__dict__["_shard_last"] = (_fast_key(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline,
-                                                       group, cur, fk_rank, fk_world), plan)
+    sig = engine.weights_sig(projector)
+    if plan is not None and plan.sig == sig:
         return plan
+    if plan is not None:
+        plans.pop(key).release()
     shard = FrameShardPlan(total_frames, world, lc.temporal_kernel_size)
     t0, t1 = shard.frame_range(rank)
     if ff_shard.shape[0] != t1 - t0:
@@ -146,39 +178,36 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
     nw = at.nwin * ay.nwin * ax.nwin
     q_in, n_rows = gc.injected_queries(guide_embed)
     R = q_in.shape[0] * gc.attn_layer.num_heads
-    S = 2 * R + R * E                                   # (M, L) pairs, then ACC, of one shard
-    S_pad = (S + 3) // 4 * 4
     lay = projector._layout((at.nwin * world, ay.nwin, ax.nwin), "video", image_newline is not None, False)
     plan = _ShardPlan()
     plan.comm = torch.cuda.Stream(device=dev, priority=-1)
     plan.res = engine._resources(dev)                  # side stream + fork/join events of the caller's stream
-    plan.lay, plan.nw, plan.hidden, plan.odt, plan.world = lay, nw, hidden, odt, world
+    plan.lay, plan.nw, plan.hidden, plan.odt, plan.world, plan.rank = lay, nw, hidden, odt, world, rank
     plan.n_rows_total = lay.n_rows + n_rows
     plan.n = 0
     plan.sets = []
+    # ONE exchange buffer per rank: [state (M, L) pairs + ACC | local tokens] -> one collective per step (the host cost
+    # of a torch.distributed call, not the wire, is what a second collective would add)
+    plan.pack = pack = PackLayout(2 * R + R * E, nw, hidden, torch.empty((), dtype=odt).element_size())
     probe = torch.empty((plan.n_rows_total, hidden), dtype=odt, device=dev)      # any valid `out` for the argument blocks
-    for set_idx in range(2):
+    for _ in range(2):
         st = _ShardSet()
-        # ONE exchange buffer per rank: [state f32 | pad to 16 B | local tokens] -> one collective per step (the host
-        # cost of a torch.distributed call, not the wire, is what a second collective would add)
-        st.mine, s_bytes, pad = pack_buffer(S, (nw, hidden), odt, dev)
-        st.mine.zero_()
-        st.tok_off = s_bytes + pad
-        st.everyone = torch.empty((world, st.mine.numel()), dtype=torch.uint8, device=dev)
-        state_mine = st.mine[:s_bytes].view(torch.float32)
-        tok_mine = st.mine[st.tok_off:st.tok_off + nw * hidden * probe.element_size()].view(odt).view(nw, hidden)
+        st.mine = pack.new_buffer(dev)
+        st.everyone = pack.new_buffer(dev, world)
+        state_mine, tok_mine = pack.state_view(st.mine), pack.tokens_view(st.mine, odt)
         st.a_stream = engine.build_args(projector, ff_shard, fe_shard, guide_embed, "video", None, probe, None, t_offset=t0,
                                         phases=nv.PHASE_STREAM, local_out=tok_mine, state_out=state_mine,
                                         global_row0=lay.n_rows)
-        # one workspace per buffer set: with MERGE_ON_NEXT the comm stream merges this set's partial states while the
-        # main stream already runs the next step (on the other set)
-        engine.attach_execution(st.a_stream, dev, key_extra=("shard", set_idx))
+        # one workspace per buffer set AND plan: with MERGE_ON_NEXT the comm stream merges this set's partial states
+        # while the main stream already runs the next step (on the other set, or of another plan)
+        st.ws_stream = engine.attach_execution(st.a_stream, dev)
         st.a_finish = engine.build_args(projector, ff_shard, fe_shard, guide_embed, "video", None, probe, None, t_offset=t0,
                                         phases=nv.PHASE_FINISH, local_out=tok_mine, state_out=state_mine,
-                                        state_sets=st.everyone, state_set_stride=st.mine.numel() // 4, nsets=world,
+                                        state_sets=st.everyone, state_set_stride=pack.set_stride_floats, nsets=world,
                                         global_row0=lay.n_rows)
-        # the FINISH phase runs on the comm stream (own workspace: it reads only the gathered states)
-        engine.attach_execution(st.a_finish, dev, key_extra=("shard-finish",), main_stream=plan.comm, res=plan.res)
+        # the FINISH phase runs on the comm stream (it reads only the gathered states)
+        st.ws_finish = engine.attach_execution(st.a_finish, dev, main_stream=plan.comm, res=plan.res)
+        plan.guide_fields = st.a_stream._guide_ptr_fields
         st.a_stream._keep = st.a_finish._keep = None
         st.out = torch.empty((plan.n_rows_total, hidden), dtype=odt, device=dev)
         st.ev_stream, st.ev_tok = torch.cuda.Event(), torch.cuda.Event()
@@ -188,19 +217,20 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
         # sharded step is host-bound): STREAM -> record ev_stream, comm waits for it; FINISH -> place every rank's
         # token block into the packed output, record ev_tok
         st.a_stream.ev_done, st.a_stream.stream_next = st.ev_stream.cuda_event, plan.comm.cuda_stream
-        st.fused, st.q_ready = nv.compressor_is_fused(st.a_stream), None
+        st.fused = nv.compressor_is_fused(st.a_stream)
         if st.fused:
             # release recipe: no side stream -- the merge of the partials runs on the comm stream, in front of the
             # all-gather (the fork / join / ev_merge event traffic was ~17 us of host time on a host-bound step)
             st.a_stream.phases = nv.PHASE_STREAM | nv.PHASE_MERGE_ON_NEXT
-        st.a_finish.place_src = st.everyone.data_ptr() + st.tok_off
+        st.a_finish.place_src = st.everyone.data_ptr() + pack.tok_off
         st.a_finish.place_block_rows, st.a_finish.place_nblocks = nw, world
-        st.a_finish.place_block_stride = st.mine.numel()
+        st.a_finish.place_block_stride = pack.total
         st.a_finish.nl_group = lay.nl_group
         st.a_finish.ev_done = st.ev_tok.cuda_event
         plan.sets.append(st)
-    if len(plans) >= engine._MAX_PLANS:
-        plans.pop(next(iter(plans)))
+    plan.sig = engine.weights_sig(projector)
+    if len(plans) >= _MAX_SHARD_PLANS:
+        plans.pop(next(iter(plans))).release()
     plans[key] = plan
     return plan
 
@@ -211,28 +241,25 @@ def _set_stream(stream):
 
 
 def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: int,
-                    image_newline: Optional[torch.Tensor] = None, group=None, deferred: bool = False,
-                    guide_after_next: Optional[torch.Tensor] = None):
+                    image_newline: Optional[torch.Tensor] = None, group=None, deferred: bool = False):
     """HIComProjector.forward for modal='video' with the frames split evenly over the ranks of
     `group`; every rank passes ITS frames and receives the full [n_tok, hidden] result.
 
-    main stream : STREAM phase of the native executor only (query prep, stream kernel, readout GEMMs; its side
-                  stream merges the partials into this rank's softmax state) -- local tokens and state go
-                  straight into ONE send buffer [state | tokens]
-    comm stream : ONE all-gather (RCCL), the FINISH phase (combine the states, the small global chain -> 32
-                  global rows) and ONE launch that places every rank's token block in the packed output.
+    main stream : STREAM phase of the native executor only (query prep, stream kernel, readout GEMMs) -- local tokens
+                  and the shard's softmax state go straight into ONE send buffer [state | tokens]
+    comm stream : merge of the partial states, ONE all-gather (RCCL), the FINISH phase (combine the states, the small
+                  global chain -> 32 global rows) and ONE launch that places every rank's token block in the packed
+                  output.
     deferred=False: the caller's stream waits for the comm stream before returning (plain tensor semantics).
     deferred=True : returns (out, event); the token rows are complete once `event` has fired.  Back-to-back steps
                   then overlap the token exchange of step i with the streaming of step i+1 (two buffer sets); `out`
-                  belongs to the buffer set and is overwritten by the second-next deferred call.
-    guide_after_next: guide prefetch (release recipe): the guide embedding of the call AFTER the next one, i.e. of this
-                  buffer set's next use, if the serving loop already has it -- its two guide-only prep kernels then
-                  run at the end of this call's comm-stream work and that call starts with its streaming kernel
-                  (if it does come with that guide, unmodified).  Same kernels per call either way."""
+                  belongs to the buffer set and is overwritten by the second-next deferred call on this shape."""
     from . import native as nv
     lc, gc = projector.local_compressor, projector.global_compressor
     if lc is None or gc is None:
         raise NotImplementedError("sharded_forward expects both compressors")
+    if torch.is_grad_enabled() and projector._needs_grad(ff_shard, fe_shard, guide_embed, image_newline):
+        raise RuntimeError("sharded_forward is an inference path: call it under torch.no_grad() / inference_mode()")
     if not all(t is None or t.is_contiguous() for t in (ff_shard, fe_shard, guide_embed, image_newline)):
         raise ValueError("sharded_forward: contiguous inputs only")
     dev = ff_shard.device
@@ -241,37 +268,23 @@ def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: in
     plan.n += 1
     main, comm = torch.cuda.current_stream(dev), plan.comm
     if deferred:
-        # pipelined serving: the result lives in this buffer set (no allocator traffic, no record_stream bookkeeping
-        # on the host-bound path) and is overwritten by the comm stream two steps later, i.e. after everything the
-        # caller has queued on ITS stream before that step
+        # pipelined serving: the result lives in this buffer set (no allocator traffic on the host-bound path) and is
+        # overwritten by the comm stream two steps later, i.e. after everything the caller has queued on ITS stream
+        # before that step
         out = st.out
     else:
         out = torch.empty((plan.n_rows_total, plan.hidden), dtype=plan.odt, device=dev)
         out.record_stream(comm)
     main.wait_event(st.ev_tok)                     # this buffer set's previous exchange (two steps ago) has drained
-    st.a_stream.out = st.a_finish.out = out.data_ptr()
-    # guide prefetch bookkeeping (engine.prefetch_begin has the dense counterpart)
-    from . import engine
-    a_s, a_f = st.a_stream, st.a_finish
-    sig_w = engine._weights_sig(projector) if (st.q_ready is not None or guide_after_next is not None) else None
-    a_s.skip_prep = int(st.fused and st.q_ready is not None and
-                        st.q_ready == (a_s.gq, a_s.lq, guide_embed._version, sig_w))
-    st.q_ready = None
-    pending = None
-    a_f.next_gq = a_f.next_lq = a_f.prep_ws = None
-    if guide_after_next is not None and st.fused and a_s.gq == a_s.lq:
-        from .projector import _require_bf16_cuda
-        _require_bf16_cuda("guide_after_next", guide_after_next)
-        if guide_after_next.ndim != 1 or guide_after_next.shape[0] != a_s.E or not guide_after_next.is_contiguous():
-            raise ValueError("guide_after_next: a contiguous [D] guide embedding")
-        a_f.next_gq = a_f.next_lq = guide_after_next.data_ptr()
-        a_f.prep_ws = a_s.ws
-        pending = (a_f.next_gq, a_f.next_lq, guide_after_next._version, sig_w)
+    plan.set_inputs(st, ff_shard, fe_shard, guide_embed, out)
     # main: prep, stream kernel, readout GEMMs, ev_stream; the comm stream waits for it and merges the partials -> state
     nv.compressor_fwd(st.a_stream)
     _comm_step(plan, st, out, image_newline, group, main)
-    st.q_ready = pending
     if deferred:
+        # the comm stream reads the guide (residual of out_proj) and the newline token after this call has returned
+        for t in (guide_embed, image_newline):
+            if t is not None:
+                t.record_stream(comm)
         return out, st.ev_tok
     main.wait_event(st.ev_tok)
     return out
@@ -284,7 +297,7 @@ def _comm_step(plan, st, out, image_newline, group, restore=None):
     comm = plan.comm
     _set_stream(comm)                              # c10d orders a collective after the CURRENT (thread-local) stream
     try:
-        dist.all_gather_into_tensor(st.everyone.view(-1), st.mine, group=group)
+        gather_packed(st.mine, st.everyone, group)
     finally:
         if restore is not None:
             _set_stream(restore)

@@ -1,7 +1,12 @@
 """Host side of the native executor (hicom_compressor_fwd): fills `hicom_compressor_args` from a
-HIComProjector and its inputs, and owns the per-shape workspace, the side stream and the two
-fork/join events.  All compute happens in libhicom_hip.so; torch is used for device memory,
-streams and events only.
+HIComProjector and its inputs, and owns the workspaces, the side stream and the fork/join events.
+All compute happens in libhicom_hip.so; torch is used for device memory, streams and events only.
+
+Plans (filled argument blocks + their workspace) are keyed by what determines the launch sequence --
+shapes, recipe, dtype, caller stream, the state of the weights -- and NOT by the identity of the input
+buffers: the pointers of frames_feature / frames_embed / guide / newline / out are patched into the cached
+block on every call.  A serving loop that hands over a fresh `split` view per video (reference
+hicom_arch.py:162-164) therefore pays one ctypes call per forward, not a plan build.
 """
 from __future__ import annotations
 
@@ -30,13 +35,10 @@ class _DeviceResources:
         self.done = [torch.cuda.Event() for _ in range(16)]     # per-call completion events of deferred forwards
         for ev in self.done:
             ev.record(cur)                                      # (created: the executor records them from C)
-        self.q_ready = None      # signature of the (workspace, set, guide) a prefetch has prepared
-        self.q_last = {}         # workspace -> the query-buffer set its last call read
         self.n_done = 0
 
 
 _RES: Dict[Tuple[int, int], _DeviceResources] = {}
-_WS: Dict[Tuple, torch.Tensor] = {}
 
 
 def _resources(device) -> _DeviceResources:
@@ -75,6 +77,8 @@ def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, 
     a.has_local, a.has_global = int(lc is not None), int(gc is not None)
     a.hidden = (lc or gc).readout[2].out_features
     keep = [ff]
+    a._guide_ptr_fields = ()            # argument fields that alias the caller's guide tensor (patched per call)
+    gptr = None if guide_embed is None else guide_embed.data_ptr()
     if lc is not None:
         lc._check_native()
         if fe is not None:
@@ -85,31 +89,34 @@ def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, 
             keep.append(fe)
         at, ay, ax = lc.tilings(T, H, W, modal)
         a.at, a.ay, a.ax = (nv.Axis(t.n, t.k, t.nwin, t.nfull) for t in (at, ay, ax))
-        ls, lb = proj.local_logit_scale, proj.local_logit_bias
+        ls = proj.local_logit
         a.l2norm = 0
         if ls is not None:                                            # ref :527-529, :549
-            a.l_scale, a.l_bias = float(torch.exp(ls.float())), float(lb)
+            a.l_scale, a.l_bias = math.exp(ls[0]), ls[1]
             if fe is not None:
                 a.l2norm = 1 | (2 if lc.use_guide == "direct" else 0)
         else:
             a.l_scale, a.l_bias = 1.0 / math.sqrt(lc.qk_dim), 0.0      # ref :551
         if lc.use_guide == "direct":
-            g = guide_embed.contiguous()
+            g = guide_embed
             _require_bf16_cuda("guide_embed", g)
             if g.ndim != 1 or g.shape[0] != E:
                 raise ValueError("direct guide injection takes a [D] guide embedding")
             a.lq, a.lq_dt, a.lq_stride = g.data_ptr(), nv.DT_BF16, 0
+            a._guide_ptr_fields += ("lq",)
             keep.append(g)
         else:
             a.lq = None                                               # pooled per-window query, made natively
         a.lw0, a.lb0 = _w(lc.readout[0])
         a.lw2, a.lb2 = _w(lc.readout[2])
     if gc is not None:
-        gc._check_native(proj.global_logit_scale)
+        gc._check_native(proj.global_logit)
         q_in, n_rows = gc.injected_queries(guide_embed)
         keep.append(q_in)
         att = gc.attn_layer
         a.gq, a.nq, a.nh, a.n_global_rows = q_in.data_ptr(), q_in.shape[0], att.num_heads, n_rows
+        if gptr is not None and q_in.data_ptr() == gptr:
+            a._guide_ptr_fields += ("gq",)
         a.wq, a.bq = _w(att.q_proj)
         a.wk, _ = _w(att.k_proj)
         a.wv, a.bv = _w(att.v_proj)
@@ -132,7 +139,7 @@ def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, 
     a.global_row0 = global_row0 if global_row0 is not None else (layout.n_rows if layout is not None else 0)
     a.nl_count = 0
     if layout is not None and layout.newline_rows:
-        nl = image_newline.contiguous()
+        nl = image_newline
         keep.append(nl)
         a.newline, a.newline_dt = nl.data_ptr(), nv._dt(nl)
         a.nl_first = layout.newline_rows[0]
@@ -144,39 +151,35 @@ def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, 
     return a
 
 
-def attach_execution(a: nv.CompressorArgs, device, key_extra=(), main_stream=None, res=None):
-    """Workspace (zero-prefixed once, cached per problem shape) + streams/events.  `main_stream` / `res`
-    default to torch's current stream and its resource set; the pipelined lanes pass their own."""
+def attach_execution(a: nv.CompressorArgs, device, main_stream=None, res=None) -> torch.Tensor:
+    """Gives the argument block its OWN workspace (zero-prefixed once; the caller keeps the returned tensor alive with
+    the plan) + streams/events.  Two plans never share a workspace: a deferred call's side / comm stream may still
+    read its partial states while the next call -- possibly of another plan -- already streams."""
     if main_stream is None:
         main_stream = torch.cuda.current_stream(device)
     if res is None:
         res = _resources(device)
     total, prefix = nv.compressor_workspace(a)
-    # one workspace per problem shape AND main stream (two streams may run the same shape concurrently)
-    key = (device.index, main_stream.cuda_stream, a.T, a.H, a.W, a.E, a.hidden, a.nq, a.P,
-           a.has_local, a.has_global, a.at.nwin, a.ay.nwin, a.ax.nwin, bool(a.lq), *key_extra)
-    ws = _WS.get(key)
-    if ws is None or ws.numel() < total:
-        with torch.cuda.stream(main_stream):
-            ws = torch.empty(total, dtype=torch.uint8, device=device)
-            ws[:prefix].zero_()
-        _WS[key] = ws
+    with torch.cuda.stream(main_stream):
+        ws = torch.empty(total, dtype=torch.uint8, device=device)
+        ws[:prefix].zero_()
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     a.stream_main = main_stream.cuda_stream
     a.stream_side = res.side.cuda_stream
     a.ev_fork, a.ev_join = res.ev_fork.cuda_event, res.ev_join.cuda_event
     a.ev_merge, a.defer_join = res.ev_merge.cuda_event, 0
-    return a
+    return ws
 
 
 class _Plan:
-    """A filled argument block for one (projector state, input buffers) combination, plus -- in graph
-    mode -- the captured hipGraph of its launch sequence and the static buffer it writes."""
-    __slots__ = ("args", "rows", "hidden", "graph", "static_out", "hits", "fused")
+    """A filled argument block for one (projector state, problem shape) combination and the workspace it owns, plus --
+    in graph mode -- the captured hipGraph of its launch sequence and the static buffer it writes."""
+    __slots__ = ("args", "ws", "rows", "hidden", "graph", "static_out", "hits", "fused", "sig", "guide_fields", "res")
 
-    def __init__(self, args, rows, hidden):
-        self.args, self.rows, self.hidden = args, rows, hidden
+    def __init__(self, args, ws, rows, hidden, sig, res):
+        self.args, self.ws, self.rows, self.hidden, self.sig, self.res = args, ws, rows, hidden, sig, res
         self.fused = nv.compressor_is_fused(args)
+        self.guide_fields = args._guide_ptr_fields
         self.graph = None
         self.static_out = None
         self.hits = 0
@@ -185,72 +188,47 @@ class _Plan:
 _MAX_PLANS = 16      # per projector; plans live ON the module (they point into its cached device tables)
 
 
-def _param_stamp(proj):
-    """(pointer, version) of every parameter.  The parameter LIST is cached on the module (walking
-    nn.Module.parameters() costs tens of microseconds) and refreshed whenever the module is moved /
-    cast (_apply) or reloaded (load_state_dict); in-place updates bump `_version`."""
-    gen = proj.__dict__.get("_engine_params_gen", 0)
-    cached = proj.__dict__.get("_engine_params")
+def _param_list(proj):
+    """The parameter LIST is cached on the module (walking nn.Module.parameters() costs tens of microseconds) and
+    refreshed whenever the module is moved / cast (_apply) or reloaded (load_state_dict)."""
+    d = proj.__dict__
+    gen = d.get("_engine_params_gen", 0)
+    cached = d.get("_engine_params")
     if cached is None or cached[0] != gen:
         cached = (gen, [p for p in proj.parameters()])
-        proj.__dict__["_engine_params"] = cached
-    return tuple([(p.data_ptr(), p._version) for p in cached[1]])
+        d["_engine_params"] = cached
+    return cached
 
 
-def _plan_key(proj, ff, fe, guide_embed, modal, image_newline, out_dtype):
-    return (ff.data_ptr(), tuple(ff.shape), None if fe is None else fe.data_ptr(),
-            None if guide_embed is None else (guide_embed.data_ptr(), guide_embed._version), modal,
-            None if image_newline is None else image_newline.data_ptr(), out_dtype,
-            torch.cuda.current_stream(ff.device).cuda_stream,
-            None if proj.local_logit_scale is None else float(proj.local_logit_scale),
-            0 if proj.global_compressor is None else proj.global_compressor._cache_gen, _param_stamp(proj))
+def weights_sig(proj):
+    """State of everything a plan has baked in besides the per-call pointers: identity of the module, generation of its
+    parameter list, every parameter's storage pointer (`p.data = ...` swaps it without touching the version counter) and
+    in-place version counter, the generation of the cached device tables, the clip-scale logits."""
+    gen, params = _param_list(proj)
+    acc = 0
+    for p in params:
+        acc += p.data_ptr() + p._version * 1000003
+    gc = proj.global_compressor
+    return (id(proj), gen, acc, 0 if gc is None else gc._cache_gen, proj.local_logit, proj.global_logit)
 
 
-def _weights_sig(proj):
-    d = proj.__dict__
-    cached = d.get("_engine_params")
-    if cached is None or cached[0] != d.get("_engine_params_gen", 0):
-        _param_stamp(proj)
-        cached = d["_engine_params"]
-    ver = 0
-    for p in cached[1]:
-        ver += p._version
-    # (the module's identity is part of it: two projectors of one shape share workspaces and resource sets)
-    return (id(proj), cached[0], ver, 0 if proj.global_compressor is None else proj.global_compressor._cache_gen)
+def _evict_one(plans: dict):
+    """Drops the oldest plan.  Its workspace may still be read by a deferred call's side stream: the caching allocator
+    must not hand the block to another stream before that work has drained."""
+    k = next(iter(plans))
+    old = plans.pop(k)
+    res = getattr(old, "res", None)
+    ws = getattr(old, "ws", None)
+    if res is not None and ws is not None:
+        ws.record_stream(res.side)
 
 
-def prefetch_begin(a, res, proj, guide_embed, next_guide, fused: bool):
-    """Guide prefetch bookkeeping around one hicom_compressor_fwd (include/hicom_hip.h next_gq):
-    skip this call's prep iff the previous call on this workspace prefetched exactly this guide under these weights,
-    and ask this call to prefetch `next_guide`.  Returns the signature to store after the call (or None)."""
-    sig_w = _weights_sig(proj) if (res.q_ready is not None or next_guide is not None) else None
-    last = res.q_last.get(a.ws, 0)
-    hit = (fused and guide_embed is not None and res.q_ready is not None and
-           res.q_ready == (a.ws, 1 - last, a.gq, a.lq, guide_embed._version, sig_w))
-    # a hit reads the set the prefetch wrote; otherwise this call preps (main stream) into the set the last call on
-    # this workspace read -- never into the one a pending prefetch may still be writing
-    a.skip_prep, a.q_set = int(hit), (1 - last if hit else last)
-    res.q_last[a.ws] = a.q_set
-    res.q_ready = None
-    a.next_gq = a.next_lq = None
-    if next_guide is None or not fused or a.gq != a.lq:      # (the injected query must BE the guide: plain direct recipe)
-        return None
-    from .projector import _require_bf16_cuda
-    _require_bf16_cuda("next_guide", next_guide)
-    if next_guide.ndim != 1 or next_guide.shape[0] != a.E or not next_guide.is_contiguous():
-        raise ValueError("next_guide: a contiguous [D] guide embedding")
-    a.next_gq = a.next_lq = next_guide.data_ptr()
-    return (a.ws, 1 - a.q_set, a.next_gq, a.next_lq, next_guide._version, sig_w)
-
-
-def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferred: bool = False, next_guide=None):
+def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferred: bool = False):
     """HIComProjector.forward for a dense [T,H,W,E] input through hicom_compressor_fwd.
 
-    Plans (argument blocks) are cached per input-buffer identity, so a repeated call costs one
-    ctypes call.  With `proj.graph_replay = True` the launch sequence of a plan is captured into a
-    hipGraph on its second use and replayed afterwards (one graph launch + one device copy of the
-    result), which removes the per-kernel host launch cost from steady-state serving loops that
-    reuse their feature buffers.
+    With `proj.graph_replay = True` the launch sequence of a plan is captured into a hipGraph on its second use and
+    replayed afterwards (one graph launch + one device copy of the result); graph plans are additionally keyed by the
+    input buffers, whose pointers the captured nodes hold.
 
     deferred=True returns (out, event): the main stream does not wait for the side stream's global chain (merge +
     the four small linears that produce the 32 global rows); `event` fires when they are written.  Back-to-back
@@ -258,180 +236,82 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
     from .projector import _require_bf16_cuda
     _require_bf16_cuda("frames_feature", ff)          # fail loudly on CPU tensors before touching any stream
     lc, gc = proj.local_compressor, proj.global_compressor
-    # plans hold raw device pointers: only dense (already contiguous) caller buffers may be cached
-    cacheable = all(t is None or t.is_contiguous() for t in (ff, fe, guide_embed, image_newline))
+    dev = ff.device
     ff = ff.contiguous()
     fe = fe.contiguous() if fe is not None else None
+    guide = guide_embed.contiguous() if guide_embed is not None else None
+    nl = image_newline.contiguous() if image_newline is not None else None
+    graph = bool(getattr(proj, "graph_replay", False)) and not deferred
+    res = _resources(dev)
+    key = (tuple(ff.shape), fe is not None, None if guide is None else tuple(guide.shape), modal, nl is not None, out_dtype,
+           torch.cuda.current_stream(dev).cuda_stream,
+           (ff.data_ptr(), _p(fe), _p(guide), _p(nl)) if graph else None)
     plans = proj.__dict__.setdefault("_engine_plans", {})
-    plan = key = None
-    if cacheable:
-        # repeated call: a cheap identity (buffers, parameter-list generation + sum of the parameters' in-place
-        # version counters) before the full key, which walks every parameter's pointer
-        fast = (ff.data_ptr(), ff.shape[0], None if fe is None else fe.data_ptr(),
-                None if guide_embed is None else (guide_embed.data_ptr(), guide_embed._version), modal,
-                None if image_newline is None else image_newline.data_ptr(), out_dtype,
-                torch.cuda.current_stream(ff.device).cuda_stream,
-                None if proj.local_logit_scale is None else float(proj.local_logit_scale), _weights_sig(proj))
-        last = proj.__dict__.get("_dense_last")
-        if last is not None and last[0] == fast and plans.get(last[1]) is last[2]:
-            plan = last[2]
-        else:
-            key = _plan_key(proj, ff, fe, guide_embed, modal, image_newline, out_dtype)
-            plan = plans.get(key)
-            if plan is not None:
-                proj.__dict__["_dense_last"] = (fast, key, plan)
+    plan = plans.get(key)
+    sig = weights_sig(proj)
+    if plan is not None and plan.sig != sig:
+        plans.pop(key)
+        plan = None
     if plan is None:
         T, H, W, _ = ff.shape
         layout = None
         n_local = 0
         if lc is not None:
             at, ay, ax = lc.tilings(T, H, W, modal)
-            layout = proj._layout((at.nwin, ay.nwin, ax.nwin), modal, image_newline is not None, False)
+            layout = proj._layout((at.nwin, ay.nwin, ax.nwin), modal, nl is not None, False)
             n_local = layout.n_rows
         n_global = gc.num_queries if gc is not None else 0
         hidden = (lc or gc).readout[2].out_features
-        out = torch.empty((n_local + n_global, hidden), dtype=out_dtype, device=ff.device)
-        a = build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, global_row0=n_local)
-        attach_execution(a, ff.device)
-        a.defer_join = int(bool(deferred))
-        res = _resources(ff.device)
-        pending = prefetch_begin(a, res, proj, guide_embed, next_guide, nv.compressor_is_fused(a))
-        done = _next_done(a, res) if deferred else None
-        nv.compressor_fwd(a)
-        res.q_ready = pending
-        if deferred:
-            out.record_stream(res.side)        # the side stream is still writing the global rows
-        if cacheable:
-            a._keep = None             # do not pin the caller's feature tensors
-            if len(plans) >= _MAX_PLANS:
-                plans.pop(next(iter(plans)))
-            if key is None:
-                key = _plan_key(proj, ff, fe, guide_embed, modal, image_newline, out_dtype)
-            plans[key] = _Plan(a, n_local + n_global, hidden)
-        return (out, done) if deferred else out
+        probe = torch.empty((n_local + n_global, hidden), dtype=out_dtype, device=dev)
+        a = build_args(proj, ff, fe, guide, modal, nl, probe, layout, global_row0=n_local)
+        ws = attach_execution(a, dev, res=res)
+        a._keep = None                 # the plan does not pin the caller's tensors: their pointers are patched per call
+        sig = weights_sig(proj)        # (build_args may have (re)built the cached positional tables)
+        if len(plans) >= _MAX_PLANS:
+            _evict_one(plans)
+        plan = plans[key] = _Plan(a, ws, n_local + n_global, hidden, sig, res)
     plan.hits += 1
     a = plan.args
-    if getattr(proj, "graph_replay", False):
-        a.skip_prep, a.next_gq, a.next_lq = 0, None, None
-        a.ev_join, a.defer_join = _resources(ff.device).ev_join.cuda_event, 0
-        _resources(ff.device).q_ready = None
-        a.q_set = _resources(ff.device).q_last.get(a.ws, 0)
+    # per-call pointers
+    a.ff = ff.data_ptr()
+    if fe is not None:
+        a.fe = fe.data_ptr()
+    if guide is not None:
+        gp = guide.data_ptr()
+        for f in plan.guide_fields:
+            setattr(a, f, gp)
+    if nl is not None and a.nl_count > 0:
+        a.newline = nl.data_ptr()
+    if graph:
+        a.ev_join, a.defer_join = res.ev_join.cuda_event, 0
         if plan.graph is None:
-            plan.static_out = torch.empty((plan.rows, plan.hidden), dtype=out_dtype, device=ff.device)
+            plan.static_out = torch.empty((plan.rows, plan.hidden), dtype=out_dtype, device=dev)
             a.out = plan.static_out.data_ptr()
             nv.compressor_fwd(a)                       # warm (lazy module loads must not happen in capture)
-            torch.cuda.current_stream(ff.device).synchronize()
+            torch.cuda.current_stream(dev).synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=torch.cuda.Stream(device=ff.device)):
+            with torch.cuda.graph(g, stream=torch.cuda.Stream(device=dev)):
                 # inside capture torch's current stream is the capture stream: re-point the plan at it
-                a.stream_main = torch.cuda.current_stream(ff.device).cuda_stream
+                a.stream_main = torch.cuda.current_stream(dev).cuda_stream
                 nv.compressor_fwd(a)
             plan.graph = g
         plan.graph.replay()
         return plan.static_out.clone()                 # callers own their result (no aliasing across calls)
-    out = torch.empty((plan.rows, plan.hidden), dtype=out_dtype, device=ff.device)
+    out = torch.empty((plan.rows, plan.hidden), dtype=out_dtype, device=dev)
     a.out = out.data_ptr()
     a.defer_join = int(bool(deferred))
-    res = _resources(ff.device)
-    pending = prefetch_begin(a, res, proj, guide_embed, next_guide, plan.fused)
     if deferred:
-        done = _next_done(a, res)
+        ev = res.done[res.n_done % len(res.done)]      # one of a small ring of reusable events, recorded from C at
+        res.n_done += 1                                # the end of the side stream's chain (no second record)
+        a.ev_join = ev.cuda_event
     else:
         a.ev_join = res.ev_join.cuda_event
     nv.compressor_fwd(a)
-    res.q_ready = pending
     if deferred:
+        # the side stream is still busy with the 32 global rows: it writes `out` and reads the guide (the residual of
+        # out_proj) after this call has returned
         out.record_stream(res.side)
-        return out, done
+        if guide is not None:
+            guide.record_stream(res.side)
+        return out, ev
     return out
-
-
-def _next_done(a, res):
-    """Completion event of the side stream's chain of a deferred call: one of a small ring of reusable events, handed
-    to the executor as its join event (recorded on the side stream at the end of the call; no second record)."""
-    ev = res.done[res.n_done % len(res.done)]
-    res.n_done += 1
-    a.ev_join = ev.cuda_event
-    return ev
-
-
-# ---------------------------------------------------------------------------------------------
-# Pipelined submission: consecutive, independent forwards on alternating "lanes" (a lane = its own
-# main stream, side stream, events, workspace and plans).  The latency-bound tail of one video (readout
-# GEMMs, merge, the small global chain) then overlaps the query prep and the HBM-bound stream kernel
-# of the next one.  The host path is kept as short as the synchronous one: no stream context switch,
-# the lane's stream handles are baked into its cached argument blocks.
-class _Lane:
-    def __init__(self, device):
-        self.stream = torch.cuda.Stream(device=device)
-        self.ev_in = torch.cuda.Event()
-        cur = torch.cuda.current_stream(device)
-        with torch.cuda.stream(self.stream):
-            self.res = _DeviceResources(device)      # side stream + fork/join events of this lane
-        self.ev_in.record(cur)
-        self.done = [torch.cuda.Event() for _ in range(8)]
-        self.n = 0
-        self.plans = {}
-
-
-class Pending:
-    """Result handle of forward_async.  wait() orders the caller's current stream after the lane's
-    work and returns the tensor; the inputs are kept alive until then."""
-    __slots__ = ("_out", "_done", "_inputs")
-
-    def __init__(self, out, done, inputs):
-        self._out, self._done, self._inputs = out, done, inputs
-
-    def wait(self) -> torch.Tensor:
-        cur = torch.cuda.current_stream(self._out.device)
-        cur.wait_event(self._done)
-        self._inputs = None
-        return self._out
-
-
-def submit(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, n_lanes: int = 2) -> Pending:
-    from .projector import _require_bf16_cuda
-    _require_bf16_cuda("frames_feature", ff)
-    dev = ff.device
-    if not all(t is None or t.is_contiguous() for t in (ff, fe, guide_embed, image_newline)):
-        raise ValueError("forward_async: contiguous inputs only")
-    state = proj.__dict__.setdefault("_engine_lanes", {})
-    key = (dev.index, n_lanes)
-    if key not in state:
-        state[key] = [[_Lane(dev) for _ in range(n_lanes)], 0]
-    lanes, rr = state[key]
-    lane = lanes[rr % n_lanes]
-    state[key][1] = rr + 1
-    cur = torch.cuda.current_stream(dev)
-    lane.ev_in.record(cur)                     # inputs are ready where the caller stands now
-    lane.stream.wait_event(lane.ev_in)
-    lc, gc = proj.local_compressor, proj.global_compressor
-    pkey = _plan_key(proj, ff, fe, guide_embed, modal, image_newline, out_dtype)
-    plan = lane.plans.get(pkey)
-    if plan is None:
-        T, H, W, _ = ff.shape
-        layout, n_local = None, 0
-        if lc is not None:
-            at, ay, ax = lc.tilings(T, H, W, modal)
-            layout = proj._layout((at.nwin, ay.nwin, ax.nwin), modal, image_newline is not None, False)
-            n_local = layout.n_rows
-        n_global = gc.num_queries if gc is not None else 0
-        hidden = (lc or gc).readout[2].out_features
-        out = torch.empty((n_local + n_global, hidden), dtype=out_dtype, device=dev)
-        with torch.cuda.stream(lane.stream):   # one-time table builds (pos planes, kpe, ...) go to the lane
-            a = build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, global_row0=n_local)
-        attach_execution(a, dev, main_stream=lane.stream, res=lane.res)
-        a._keep = None
-        if len(lane.plans) >= _MAX_PLANS:
-            lane.plans.pop(next(iter(lane.plans)))
-        plan = lane.plans[pkey] = _Plan(a, n_local + n_global, hidden)
-    else:
-        out = torch.empty((plan.rows, plan.hidden), dtype=out_dtype, device=dev)
-    a = plan.args
-    a.out = out.data_ptr()
-    out.record_stream(lane.stream)             # allocated on the caller's stream, written on the lane's
-    nv.compressor_fwd(a)
-    done = lane.done[lane.n % len(lane.done)]
-    lane.n += 1
-    done.record(lane.stream)
-    return Pending(out, done, (ff, fe, guide_embed, image_newline))

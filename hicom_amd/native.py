@@ -15,7 +15,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 # HICOM_NATIVE_LIB: dev override (instrumented builds from tools/); the product loads the in-tree library
 LIB_PATH = os.environ.get("HICOM_NATIVE_LIB") or os.path.join(HERE, "libhicom_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 DT_BF16, DT_F32 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
@@ -69,7 +69,6 @@ class CompressorArgs(C.Structure):
         ("ev_merge", C.c_void_p), ("defer_join", C.c_int32), ("reserved_", C.c_int32),
         ("place_src", C.c_void_p), ("place_block_stride", C.c_int64), ("place_block_rows", C.c_int32), ("place_nblocks", C.c_int32),
         ("ev_done", C.c_void_p), ("stream_next", C.c_void_p),
-        ("next_gq", C.c_void_p), ("next_lq", C.c_void_p), ("skip_prep", C.c_int32), ("q_set", C.c_int32), ("prep_ws", C.c_void_p),
     ]
 
 

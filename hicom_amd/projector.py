@@ -76,6 +76,45 @@ class MultiheadAttention(nn.Module):
         self.out_proj = nn.Linear(embed_dim, embed_dim)
         self.apply(_init_like_reference)
 
+    def forward(self, query, key, value, attention_mask=None, logit_scale=None, logit_bias=None):
+        """Reference signature (ref :166-228): [B, q, E] x [B, kv, E] -> ([B, q, E], None).  The attention weights the
+        reference returns second are never formed here (every caller drops them, ref :391, :645).
+          kv <= 64 keys (the text tokens of "fine" injection): projected states + hicom_small_mha_fwd;
+          otherwise key and value must be the same bf16 tensor: k_proj / v_proj are folded around the raw tokens and
+          the tokens are streamed once (hicom_global_stream_fwd), as in GlobalCompressor."""
+        from . import injector as inj
+        if query.ndim != 3 or key.ndim != 3 or value.ndim != 3:
+            raise ValueError("MultiheadAttention: inputs are Batch x Time x Channel")
+        if attention_mask is not None:
+            raise NotImplementedError("MultiheadAttention: attention_mask has no HIP path (never passed by the reference)")
+        B, q_len, _ = query.shape
+        kv_len = key.shape[1]
+        outs = []
+        for b in range(B):
+            q2, k2, v2 = query[b].contiguous(), key[b].contiguous(), value[b].contiguous()
+            if kv_len <= 64:
+                if logit_scale is not None:
+                    raise NotImplementedError("MultiheadAttention: clip-scale on the small-key path")
+                qp, kp, vp = inj.linear_rows(q2, self.q_proj), inj.linear_rows(k2, self.k_proj), inj.linear_rows(v2, self.v_proj)
+                ao = _f32((q_len, self.embed_dim), q2.device)
+                nv.small_mha(qp, kp, vp, self.num_heads, ao)
+                outs.append(inj.linear_rows(ao, self.out_proj))
+                continue
+            if key[b].data_ptr() != value[b].data_ptr() or key.shape != value.shape:
+                raise NotImplementedError("MultiheadAttention: long key streams take key is value (k_proj / v_proj folded)")
+            if logit_scale is not None:
+                raise NotImplementedError("MultiheadAttention: clip-scale normalises the PROJECTED keys (ref :184-186); "
+                                          "no HIP path yet")
+            ml, acc = _stream_attention(self, k2, q2, None, 0, 0, 0, 0, 0)
+            ctx = _f32(acc.shape, acc.device)
+            nv.global_combine(ml.unsqueeze(0), acc.unsqueeze(0), ctx)
+            wv, bv = _linear_params(self.v_proj)
+            o = _f32((q_len, self.embed_dim), q2.device)
+            nv.linear(ctx, wv, bv, o, head_rows=self.num_heads, head_dim=self.head_dim)
+            outs.append(inj.linear_rows(o, self.out_proj))
+        out = torch.stack(outs, 0)
+        return (out if getattr(self, "return_fp32", False) else out.to(query.dtype)), None
+
 
 class GuideInjector(nn.Module):
     """Parameters of the instruction injector (ref :315-342).  'direct' has none."""
@@ -100,6 +139,18 @@ class GuideInjector(nn.Module):
         elif use_guide != "direct":
             raise NotImplementedError(f"use_guide={use_guide!r}")
 
+    def forward(self, visual_embed, guide_embed):
+        """Reference signature (ref :344-397): visual_embed [t,h,w,d] or [n,d] -> injected queries of that shape
+        (fp32: they feed the score kernels).  "direct" returns the (adapted) guide broadcast to the visual shape as a
+        stride-0 view -- the reference materialises the repeat (:356, :360)."""
+        from . import injector as inj
+        if visual_embed.ndim not in (2, 4):
+            raise ValueError("Invalid input shape for guide embedding.")
+        shape = visual_embed.shape
+        vis = visual_embed.reshape(-1, shape[-1])
+        q, shared = inj.inject(self, self.use_guide, vis, guide_embed.contiguous())
+        return q.reshape(1, -1).expand(vis.shape[0], -1).reshape(shape) if shared else q.reshape(shape)
+
 
 def _f32(shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
@@ -121,6 +172,43 @@ def _require_bf16_cuda(name: str, t: torch.Tensor):
 def _linear_params(lin: nn.Linear):
     _require_bf16_cuda("weight", lin.weight)
     return lin.weight.detach(), (lin.bias.detach() if lin.bias is not None else None)
+
+
+def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i):
+    """Streams the tokens x2 [N, E] (bf16) once against the folded queries of q_in [nq, E]: returns the un-normalised
+    online-softmax state (ml [R,2], acc [R,E]), R = nq * heads (ref :180-215 restated)."""
+    E, nh = att.embed_dim, att.num_heads
+    _require_bf16_cuda("key / value tokens", x2)
+    N, dev = x2.shape[0], x2.device
+    nq = q_in.shape[0]
+    R = nq * nh
+    rows_pad = (R + 15) // 16 * 16
+    wq, bq = _linear_params(att.q_proj)
+    wk, _ = _linear_params(att.k_proj)      # b_k only shifts every logit of a row: softmax cancels it
+    qp = _f32((nq, E), dev)
+    nv.linear(q_in, wq, bq, qp)
+    qt = _f32((R, E), dev)
+    nv.fold_query(qp, wk, nh, att.scale, qt)
+    qhi = torch.empty((rows_pad, E), dtype=torch.bfloat16, device=dev)
+    qlo = torch.empty_like(qhi)
+    nv.split_bf16(qt, rows_pad, qhi, qlo)
+    pos_a = None
+    if pe is not None:
+        pos_a = torch.zeros((rows_pad, pe.shape[0]), dtype=torch.float32, device=dev)
+        nv.linear(qt, pe, None, pos_a, M=R)                     # a[r, p] = qt[r] . PE[p]
+    else:
+        H, W = 1, N                                             # any factorisation of N: no positional terms
+    nparts = nv.global_stream_nparts(N, rows_pad)
+    stride = (N + 15) // 16 * 16
+    scores = _f32((rows_pad, stride), dev)
+    part_m, part_l = _f32((nparts, rows_pad), dev), _f32((nparts, rows_pad), dev)
+    part_acc = _f32((nparts, rows_pad, E), dev)
+    nv.global_stream(x2, N, qhi, qlo, pos_a, H, W, t0i, y0i, x0i, scores, part_m, part_l, part_acc, rows=R)
+    ml, acc = _f32((R, 2), dev), _f32((R, E), dev)
+    T = N // (H * W)
+    scratch = _f32((R * T * (H + W + 2),), dev) if pe is not None else None
+    nv.global_merge(part_m, part_l, part_acc, R, scores, N, H, W, pe, t0i, y0i, x0i, scratch, ml, acc)
+    return ml, acc
 
 
 class LocalCompressor(nn.Module):
@@ -200,7 +288,7 @@ class LocalCompressor(nn.Module):
         nw = grid[0] * grid[1] * grid[2]
         l2norm = 0
         if logit_scale is not None:                                   # ref :527-529, :549
-            scale, bias = float(torch.exp(logit_scale.float())), float(logit_bias)
+            scale, bias = math.exp(float(logit_scale)), float(logit_bias)
             if frames_embed is not None:
                 if self.adapt_k or self.use_guide not in (None, "off", "direct"):
                     raise NotImplementedError("LocalCompressor: clip-scale together with adapt_k / coarse / fine "
@@ -238,10 +326,19 @@ class LocalCompressor(nn.Module):
         nv.readout_gemm(hid, w2, b2, out, row0=row0, nl_group=nl_group)
 
     def forward(self, frames_feature, frames_embed, guide_embed, modal, logit_scale=None, logit_bias=None):
+        _refuse_grad(self)
         ctx, grid = self.window_context(frames_feature, frames_embed, guide_embed, modal, logit_scale, logit_bias)
         out = torch.empty((ctx.shape[0], self.readout[2].out_features), dtype=_out_dtype(self), device=ctx.device)
         self.readout_into(ctx, out, 0, 0)
         return out.view(*grid, -1)
+
+
+def _refuse_grad(module: nn.Module):
+    """The stage modules have no autograd graph of their own (HIComProjector.forward has: hicom_amd/autograd.py).
+    Returning a detached tensor to a training loop would silently freeze the projector, so refuse instead."""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise RuntimeError(f"{type(module).__name__}.forward builds no autograd graph: call it under torch.no_grad(), or "
+                           "go through HIComProjector.forward, which does")
 
 
 def _out_dtype(module: nn.Module) -> torch.dtype:
@@ -348,42 +445,16 @@ class GlobalCompressor(nn.Module):
     def partial_context(self, frames_feature, q_in, t_offset: int = 0):
         """Streams this call's frames once: returns (ml [R,2], acc [R,E]) un-normalised online-softmax
         state for R = nq_eff * num_heads folded query rows (ref :180-215 restated)."""
-        att = self.attn_layer
-        E, nh = self.embed_dim, att.num_heads
         ff = frames_feature.contiguous()
         _require_bf16_cuda("frames_feature", ff)
-        T, H, W, _ = ff.shape
-        N = T * H * W
-        dev = ff.device
-        nq = q_in.shape[0]
-        R = nq * nh
-        rows_pad = (R + 15) // 16 * 16
-        wq, bq = _linear_params(att.q_proj)
-        wk, _ = _linear_params(att.k_proj)      # b_k only shifts every logit of a row: softmax cancels it
-        qp = _f32((nq, E), dev)
-        nv.linear(q_in, wq, bq, qp)
-        qt = _f32((R, E), dev)
-        nv.fold_query(qp, wk, nh, att.scale, qt)
-        qhi = torch.empty((rows_pad, E), dtype=torch.bfloat16, device=dev)
-        qlo = torch.empty_like(qhi)
-        nv.split_bf16(qt, rows_pad, qhi, qlo)
-        pos_a = pe = None
+        T, H, W, E = ff.shape
+        pe = None
         t0i = y0i = x0i = 0
         if self.use_pos_emb:
-            pe, cap = self.pos_tables(t_offset + T, H, W, dev)
+            pe, cap = self.pos_tables(t_offset + T, H, W, ff.device)
             t0i, y0i, x0i = t_offset, cap, cap + H
-            pos_a = torch.zeros((rows_pad, pe.shape[0]), dtype=torch.float32, device=dev)
-            nv.linear(qt, pe, None, pos_a, M=R)                     # a[r, p] = qt[r] . PE[p]
-        nparts = nv.global_stream_nparts(N, rows_pad)
-        stride = (N + 15) // 16 * 16
-        scores = _f32((rows_pad, stride), dev)
-        part_m, part_l = _f32((nparts, rows_pad), dev), _f32((nparts, rows_pad), dev)
-        part_acc = _f32((nparts, rows_pad, E), dev)
-        nv.global_stream(ff, N, qhi, qlo, pos_a, H, W, t0i, y0i, x0i, scores, part_m, part_l, part_acc, rows=R)
-        ml, acc = _f32((R, 2), dev), _f32((R, E), dev)
-        scratch = _f32((R * T * (H + W + 2),), dev) if pe is not None else None
-        nv.global_merge(part_m, part_l, part_acc, R, scores, N, H, W, pe, t0i, y0i, x0i, scratch, ml, acc)
-        return ml, acc, scores
+        ml, acc = _stream_attention(self.attn_layer, ff.view(T * H * W, E), q_in, pe, H, W, t0i, y0i, x0i)
+        return ml, acc, None
 
     def finish(self, ml_sets, acc_sets, q_in, out, row0: int, n_rows: int):
         """Combine shard states, apply v_proj per head, out_proj + residual, readout, and write
@@ -411,16 +482,17 @@ class GlobalCompressor(nn.Module):
         nv.linear(hid, w2, b2, tok)
         nv.scatter_rows(tok, out, row0, n_rows)
 
-    def forward_into(self, frames_feature, guide_embed, logit_scale, out, row0: int):
+    def forward_into(self, frames_feature, guide_embed, logit_scale, out, row0: int, logit_bias=None):
         self._check_native(logit_scale)
         q_in, n_rows = self.injected_queries(guide_embed)
         ml, acc, _ = self.partial_context(frames_feature, q_in)
         self.finish(ml.unsqueeze(0), acc.unsqueeze(0), q_in, out, row0, n_rows)
 
     def forward(self, frames_feature, frames_embed, guide_embed, modal, logit_scale=None, logit_bias=None):
+        _refuse_grad(self)
         out = torch.empty((self.num_queries, self.readout[2].out_features), dtype=_out_dtype(self),
                           device=frames_feature.device)
-        self.forward_into(frames_feature, guide_embed, logit_scale, out, 0)
+        self.forward_into(frames_feature, guide_embed, logit_scale, out, 0, logit_bias)
         return out
 
 
@@ -430,15 +502,15 @@ class HIComProjector(nn.Module):
     def __init__(self, config, local_compressor=None, global_compressor=None):
         super().__init__()
         self.config = config
-        use_clip_scale = getattr(config, "use_clip_scale", "").split(",")
+        use_clip_scale = (getattr(config, "use_clip_scale", "") or "").split(",")
         self.local_use_clip_scale = "local" in use_clip_scale
         self.global_use_clip_scale = "global" in use_clip_scale
+        # The reference copies SigLIP's logit_scale / logit_bias out of the hub checkpoint at construction
+        # (ref :660-670); this build has no hub access and takes them from set_clip_logits() -- a projector configured
+        # with use_clip_scale constructs fine and refuses to run until they have been set.
         self.local_logit_scale = self.local_logit_bias = None
         self.global_logit_scale = self.global_logit_bias = None
-        if self.local_use_clip_scale or self.global_use_clip_scale:
-            # the reference copies SigLIP's logit_scale / logit_bias out of the checkpoint here
-            # (ref :660-670); this build takes them from set_clip_logits() instead of the hub.
-            raise NotImplementedError("use_clip_scale: call set_clip_logits() on a projector built without it")
+        self.local_logit = self.global_logit = None          # (log scale, bias) as Python floats: what the plans bake in
         self.local_compressor = local_compressor
         self.global_compressor = global_compressor
         assert local_compressor is not None or global_compressor is not None, \
@@ -450,9 +522,7 @@ class HIComProjector(nn.Module):
     def _invalidate_plans(self):
         self.__dict__["_engine_params_gen"] = self.__dict__.get("_engine_params_gen", 0) + 1
         self.__dict__.pop("_engine_plans", None)
-        self.__dict__.pop("_engine_lanes", None)
-        self.__dict__.pop("_shard_last", None)
-        self.__dict__.pop("_dense_last", None)
+        self.__dict__.pop("_shard_plans", None)
 
     def _apply(self, fn, *args, **kwargs):           # .to() / .cuda() / .bfloat16() ...
         self._invalidate_plans()
@@ -463,17 +533,46 @@ class HIComProjector(nn.Module):
         return super().load_state_dict(*args, **kwargs)
 
     def set_clip_logits(self, local=None, glob=None):
+        """(logit_scale, logit_bias) of the SigLIP checkpoint for the stages named in config.use_clip_scale
+        (ref :660-670 reads them from AutoModel.from_pretrained).  Tensors or numbers; read once."""
         if local is not None:
             self.local_logit_scale, self.local_logit_bias = local
+            self.local_logit = (float(local[0]), float(local[1]))
         if glob is not None:
             self.global_logit_scale, self.global_logit_bias = glob
+            self.global_logit = (float(glob[0]), float(glob[1]))
+        self._invalidate_plans()
+
+    def _check_clip_logits(self):
+        if (self.local_use_clip_scale and self.local_logit is None) or (self.global_use_clip_scale and self.global_logit is None):
+            raise RuntimeError("config.use_clip_scale names a stage whose SigLIP logit_scale / logit_bias have not been "
+                               "given: call set_clip_logits(local=(scale, bias), glob=(scale, bias)) first")
 
     def _layout(self, grid, modal, has_newline, is_anyres):
         return geo.pack_layout(getattr(self.config, "mm_patch_merge_type", "flat"),
                                getattr(self.config, "mm_newline_position", "one_token"),
                                modal, grid[0], grid[1], grid[2], has_newline, is_anyres)
 
+    def _needs_grad(self, *tensors) -> bool:
+        """True when autograd would expect a graph from this call (training stages 1-2 keep the projector trainable,
+        ref train.py:704-712).  Inference runs under torch.inference_mode() / no_grad (ref __init__.py:107): one
+        flag test."""
+        if not torch.is_grad_enabled():
+            return False
+        from . import engine
+        if any(p.requires_grad for p in engine._param_list(self)[1]):
+            return True
+        for t in tensors:
+            for u in (t.values() if isinstance(t, dict) else (t,)):
+                if isinstance(u, torch.Tensor) and u.requires_grad:
+                    return True
+        return False
+
     def forward(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None):
+        self._check_clip_logits()
+        if self._needs_grad(frames_feature, frames_embed, guide_embed, image_newline):
+            from . import autograd
+            return autograd.forward_with_grad(self, frames_feature, frames_embed, guide_embed, modal, image_newline)
         plain = all(c is None or c.is_plain for c in (self.local_compressor, self.global_compressor))
         if self.use_executor and plain and not isinstance(frames_feature, dict):
             from . import engine
@@ -481,33 +580,22 @@ class HIComProjector(nn.Module):
                                     _out_dtype(self))
         return self.forward_stepwise(frames_feature, frames_embed, guide_embed, modal, image_newline)
 
-    def forward_deferred(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None, next_guide=None):
+    def forward_deferred(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None):
         """forward() without the final join of the side stream: returns (out, event).  The local rows of `out`
         are ordered on the caller's stream as usual; its 32 global rows are complete once `event` has fired
         (`torch.cuda.current_stream().wait_event(event)` before consuming them).  A serving loop that issues
         independent videos back to back hides the latency-bound global chain behind the next video's streaming.
-
-        next_guide (optional, plain direct recipe): the guide embedding of the NEXT call, if the loop already has
-        it (the text of a request is known long before its frames are encoded).  This call then also runs that
-        call's two guide-only prep kernels (q_proj, fold) on its side stream, and the next call -- if it does come
-        with that guide (same tensor, unmodified) on this shape -- starts directly with its streaming kernel.
-        Every call still runs the same kernels; a wrong or missing prediction only costs the overlap."""
-        plain = all(c is None or c.is_plain for c in (self.local_compressor, self.global_compressor))
-        if not plain or isinstance(frames_feature, dict) or getattr(self, "graph_replay", False):
-            raise NotImplementedError("forward_deferred: dense inputs of the plain recipes, eager launches")
-        from . import engine
-        return engine.run_dense(self, frames_feature, frames_embed, guide_embed, modal, image_newline, _out_dtype(self),
-                                deferred=True, next_guide=next_guide)
-
-    def forward_async(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None, lanes: int = 2):
-        """forward() for serving loops: the call is enqueued on one of `lanes` internal stream sets and a
-        handle is returned at once; handle.wait() yields the tensor (ordered on the caller's stream).
-        Independent videos submitted back to back overlap on the GPU.  Dense plain inputs only."""
+        Inference only (no autograd graph)."""
+        self._check_clip_logits()
+        if self._needs_grad(frames_feature, frames_embed, guide_embed, image_newline):
+            raise RuntimeError("forward_deferred is an inference API: call it under torch.no_grad() / inference_mode(), "
+                               "or use forward() for training")
         plain = all(c is None or c.is_plain for c in (self.local_compressor, self.global_compressor))
         if not plain or isinstance(frames_feature, dict):
-            raise NotImplementedError("forward_async: dense inputs of the plain recipes only (use forward())")
+            raise NotImplementedError("forward_deferred: dense inputs of the plain recipes")
         from . import engine
-        return engine.submit(self, frames_feature, frames_embed, guide_embed, modal, image_newline, _out_dtype(self), lanes)
+        return engine.run_dense(self, frames_feature, frames_embed, guide_embed, modal, image_newline, _out_dtype(self),
+                                deferred=True)
 
     def forward_stepwise(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None):
         """Same result, one C-ABI call per operator (anyres dict inputs; also the cross-check of the
@@ -546,7 +634,7 @@ class HIComProjector(nn.Module):
             row += lay.n_rows
         if gc is not None:
             gff = frames_feature["patch"].unsqueeze(0) if isinstance(frames_feature, dict) else frames_feature
-            gc.forward_into(gff, guide_embed, self.global_logit_scale, out, row)
+            gc.forward_into(gff, guide_embed, self.global_logit_scale, out, row, self.global_logit_bias)
         return out
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HICOM_ABI_VERSION 1
+#define HICOM_ABI_VERSION 2
 
 #define HICOM_OK         0
 #define HICOM_EINVAL    -1   /* bad argument (shape, alignment, NULL)        */
@@ -335,21 +335,6 @@ typedef struct hicom_compressor_args {
     int64_t place_block_stride;
     int32_t place_block_rows, place_nblocks;
     void *ev_done, *stream_next;
-    /* Guide prefetch (release recipe only): a serving loop knows the text of its next request long before that
-     * request's frames exist.  The workspace holds TWO sets of query buffers (folded queries hi/lo, score-side pos
-     * table); q_set (0/1) is the set this call reads.  next_gq / next_lq (the NEXT call's injected query and local
-     * query, as gq / lq) make this call run the next call's two guide-only prep kernels into the OTHER set, at the
-     * head of its side-stream work, i.e. under its own stream kernel; the next call then passes that set and
-     * skip_prep = 1 and starts directly with its stream kernel (ordered by ev_merge).  Same kernels per call, ~10 us
-     * less on the main stream.  The caller (hicom_amd/engine.py) tracks which (workspace, set, guide) is ready and
-     * never skips without a prefetch. */
-    const void *next_gq, *next_lq;
-    int32_t skip_prep, q_set;
-    /* FINISH-only calls of the frame-sharded step: prep_ws != NULL (with next_gq / next_lq) runs the prep kernels at the
-     * end of the phase, before ev_done, into query-buffer set q_set of THAT workspace -- the STREAM workspace of the
-     * same buffer set (same shapes, hence the same layout), whose next use is two steps later; ev_done, which the
-     * main stream waits for before it touches the set again, then also covers the prefetch: no extra event. */
-    void* prep_ws;
 } hicom_compressor_args;
 
 /* 1 when hicom_compressor_fwd takes the release-recipe (single streaming kernel) path for these arguments. */

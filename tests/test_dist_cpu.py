@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import cases
-from hicom_amd.dist import FrameShardPlan, exchange
+from hicom_amd.dist import FrameShardPlan, PackLayout, exchange, gather_packed
 from oracle import hicom_oracle as orc
 
 
@@ -60,6 +60,19 @@ def _worker(rank, world, port, tmp):
         states, tokens = exchange(state, loc)
         assert states.shape == (world, state.numel()) and tokens.shape == (world * loc.shape[0], loc.shape[1])
         assert torch.equal(states[rank], state) and torch.equal(tokens[rank * loc.shape[0]:(rank + 1) * loc.shape[0]], loc)
+        # the same layout object drives the HIP path: its kernels write the send buffer in place and read the gathered one
+        # at these offsets (state_set_stride / place_src / place_block_stride in hicom_amd/dist.py)
+        lay = PackLayout(state.numel(), loc.shape[0], loc.shape[1], 2)
+        assert lay.tok_off % 16 == 0 and lay.total % 16 == 0 and lay.set_stride_floats * 4 == lay.total
+        mine = lay.new_buffer("cpu")
+        lay.state_view(mine).copy_(state)
+        lay.tokens_view(mine, torch.bfloat16).copy_(loc.bfloat16())
+        everyone = gather_packed(mine, lay.new_buffer("cpu", world))
+        flat = everyone.view(-1)
+        for r in range(world):             # what hicom_global_combine_strided_fwd / hicom_place_blocks_fwd address
+            st_r = flat[r * lay.total: r * lay.total + lay.state_bytes].view(torch.float32)
+            tk_r = flat[r * lay.total + lay.tok_off: r * lay.total + lay.tok_off + lay.tok_bytes].view(torch.bfloat16)
+            assert torch.equal(st_r, states[r]) and torch.equal(tk_r.view(loc.shape), tokens[r * loc.shape[0]:(r + 1) * loc.shape[0]].bfloat16())
         # combine exactly as hicom_global_combine_fwd does
         R, E = ACC.shape
         ml = states[:, :2 * R].reshape(world, R, 2).double()

@@ -257,52 +257,10 @@ def test_alternating_guides_share_one_workspace(c2):
             assert torch.equal(o, want[k]) and torch.equal(od, want[k]), k
 
 
-def test_guide_prefetch_right_wrong_and_modified(c2):
-    """forward_deferred(next_guide=...) runs the next call's prep kernels on this call's side stream; the next call
-    skips its own only if it really comes with that guide, unmodified, on the same workspace.  Right and wrong
-    predictions, a guide overwritten in place after it was prefetched, and plain forwards in between all give
-    the bits of isolated forwards."""
-    from types import SimpleNamespace
-    m, ff, fe, g, _ = c2
-    g2 = (g.float() * -0.7 + 0.05).to(g.dtype)
-    g3 = g.clone()
-    with torch.no_grad():
-        want = {}
-        for name, guide in (("g", g), ("g2", g2)):
-            want[name] = m(ff, fe, guide, "video", None).clone()
-        torch.cuda.synchronize()
-        guides = {"g": g, "g2": g2}
-        #        this call, predicted next
-        seq = [("g", "g"), ("g", "g2"), ("g2", "g2"), ("g2", "g"), ("g2", "g2"), ("g2", None), ("g", "g"), ("g", "g")] * 2
-        outs = []
-        for cur, nxt in seq:
-            outs.append((cur, m.forward_deferred(ff, fe, guides[cur], "video", None,
-                                                 next_guide=None if nxt is None else guides[nxt])[0]))
-        outs.append(("g", m(ff, fe, g, "video", None)))                 # joined call consuming the last prefetch
-        torch.cuda.synchronize()
-        for k, (cur, o) in enumerate(outs):
-            assert torch.equal(o, want[cur]), (k, cur)
-        # a second projector of the same shape (same workspace, same guide tensor) must not inherit the prefetch
-        case2 = SimpleNamespace(cfg=c2[4].cfg, sd={k: (v * 0.5 if k.endswith("q_proj.weight") else v) for k, v in c2[4].sd.items()})
-        m2 = build_module(case2)
-        want2 = m2(ff, fe, g, "video", None).clone()
-        assert not torch.equal(want2, want["g"])
-        m.forward_deferred(ff, fe, g, "video", None, next_guide=g)
-        o_other = m2.forward_deferred(ff, fe, g, "video", None)[0]
-        torch.cuda.synchronize()
-        assert torch.equal(o_other, want2)
-        # prefetched, then overwritten in place before use: the version counter voids the prefetch
-        o1 = m.forward_deferred(ff, fe, g2, "video", None, next_guide=g3)[0]
-        g3.copy_(g2)
-        o2 = m.forward_deferred(ff, fe, g3, "video", None)[0]
-        torch.cuda.synchronize()
-        assert torch.equal(o1, want["g2"]) and torch.equal(o2, want["g2"])
-
-
-def test_random_mix_of_shapes_guides_prefetches_and_joins(c2):
-    """150 back-to-back calls drawn at random from {three videos of two shapes} x {two guides} x {prefetch the right /
-    a wrong / no next guide} x {deferred, joined}: every result equals, bit for bit, the isolated forward of its
-    (video, guide) -- the workspaces, query-buffer sets and events are shared across all of them."""
+def test_random_mix_of_shapes_guides_and_joins(c2):
+    """150 back-to-back calls drawn at random from {three videos of two shapes} x {two guides} x {deferred, joined},
+    every call with FRESH input tensors (clones: new pointers, as a serving loop hands over): every result equals, bit
+    for bit, the isolated forward of its (video, guide) -- plans, workspaces and events are shared across all of them."""
     import random
     m, ff, fe, g, _ = c2
     gen = torch.Generator(device="cuda").manual_seed(5)
@@ -316,68 +274,128 @@ def test_random_mix_of_shapes_guides_prefetches_and_joins(c2):
             for k, gg in gs.items():
                 want[v, k] = m(x, y, gg, "video", None).clone()
                 torch.cuda.synchronize()
+        n_plans = len(m.__dict__["_engine_plans"])
         rnd = random.Random(11)
-        seq = [(rnd.choice("abc"), rnd.choice(["g1", "g2"]), rnd.choice(["g1", "g2", None]), rnd.random() < 0.7) for _ in range(150)]
+        seq = [(rnd.choice("abc"), rnd.choice(["g1", "g2"]), rnd.random() < 0.7, rnd.random() < 0.5) for _ in range(150)]
         outs = []
-        for v, k, nxt, deferred in seq:
+        for v, k, deferred, fresh in seq:
             x, y = vids[v]
+            gg = gs[k]
+            if fresh and v == "b":
+                x, y, gg = x.clone(), y.clone(), gg.clone()          # new buffers: same plan, patched pointers
+            elif fresh:
+                gg = gg.clone()
             if deferred:
-                outs.append(m.forward_deferred(x, y, gs[k], "video", None, next_guide=None if nxt is None else gs[nxt])[0])
+                outs.append(m.forward_deferred(x, y, gg, "video", None)[0])
             else:
-                outs.append(m(x, y, gs[k], "video", None))
+                outs.append(m(x, y, gg, "video", None))
+            del x, y, gg
         torch.cuda.synchronize()
         bad = [i for i, ((v, k, _, _), o) in enumerate(zip(seq, outs)) if not torch.equal(o, want[v, k])]
+        assert len(m.__dict__["_engine_plans"]) == n_plans           # no plan was rebuilt for a new buffer
     assert not bad, bad[:10]
 
 
-def test_forward_async_lanes_equal_forward(c2):
-    """forward_async (alternating stream lanes) returns, for a stream of DIFFERENT videos submitted back to
-    back, exactly the bits of the synchronous forward of each."""
+def test_weight_update_invalidates_plan(c2):
+    """In-place updates and `.data` swaps of a parameter are seen by the next call (plans bake weight pointers)."""
     m, ff, fe, g, _ = c2
-    vids = [(ff, fe), (fe, ff), (ff.flip(0).contiguous(), fe), (ff, fe)]
     with torch.no_grad():
-        want = [m(a, b, g, "video", None).clone() for a, b in vids]
-        for lanes in (2, 3, 2, 3, 2):                    # repeated: overlapping lanes perturb every kernel's timing
-            handles = [m.forward_async(a, b, g, "video", None, lanes=lanes) for a, b in vids for _ in range(2)]
-            got = [h.wait() for h in handles]
+        base = m(ff[:8], fe[:8], g, "video", None).clone()
+        w = m.local_compressor.readout[2].bias
+        w.add_(1.0)
+        moved = m(ff[:8], fe[:8], g, "video", None).clone()
+        w.sub_(1.0)
+        assert float((moved[:-32] - base[:-32] - 1.0).abs().max()) < 2e-2
+        old = w.data
+        w.data = (old.float() + 2.0).to(old.dtype)                   # pointer swap, version counter untouched
+        swapped = m(ff[:8], fe[:8], g, "video", None).clone()
+        w.data = old
+        assert float((swapped[:-32] - base[:-32] - 2.0).abs().max()) < 2e-2
+        assert torch.equal(m(ff[:8], fe[:8], g, "video", None), base)
+
+
+def test_graph_replay_equals_eager(c2):
+    """hipGraph capture / replay of a plan (two streams, fork / join as captured event nodes) reproduces eager bits."""
+    m, ff, fe, g, _ = c2
+    with torch.no_grad():
+        want = m(ff[:16], fe[:16], g, "video", None).clone()
+        m.graph_replay = True
+        try:
+            outs = [m(ff[:16], fe[:16], g, "video", None) for _ in range(4)]
             torch.cuda.synchronize()
-            for k, o in enumerate(got):
-                assert torch.equal(o, want[k // 2]), (lanes, k)
+        finally:
+            m.graph_replay = False
+            m._invalidate_plans()
+        for o in outs:
+            assert torch.equal(o, want)
+
+
+def test_grad_mode_builds_a_graph_or_refuses(c2):
+    """With autograd on and trainable parameters, forward() must never hand back a silently detached tensor."""
+    m, ff, fe, g, _ = c2
+    out = m(ff[:4], fe[:4], g, "video", None)                        # grad mode on, parameters require grad
+    assert out.requires_grad and out.grad_fn is not None
+    with pytest.raises(RuntimeError):
+        m.local_compressor(ff[:4], fe[:4], g, "video")
+    with pytest.raises(RuntimeError):
+        m.forward_deferred(ff[:4], fe[:4], g, "video", None)
+    with torch.no_grad():
+        assert not m(ff[:4], fe[:4], g, "video", None).requires_grad
+
+
+def test_c2_full_output_matches_oracle(c2):
+    """ALL 1328 x 896 outputs of the benchmark configuration against the fp32 oracle of the whole 64-frame clip
+    (reference projector.py:676-708; ~1 s of host time): every window of every workgroup of the ring kernel, the
+    global rows, the packing."""
+    m, ff, fe, g, case = c2
+    from oracle import hicom_oracle as orc
+    with torch.no_grad():
+        out = m(ff, fe, g, "video", None)
+        sd = {k: torch.from_numpy(v) for k, v in case.sd.items()}
+        want = orc.projector_forward(case.cfg, sd, ff.float().cpu(), fe.float().cpu(), g.float().cpu(), "video", None)
+    assert out.shape == want.shape == (1328, 896)
+    err = (out.cpu() - want).abs()
+    assert float(err.max()) <= TOL, (float(err.max()), int(err.argmax()) // 896)
+
+
+def _emulate_ranks(m, ff, fe, g, world, finish_rank):
+    """The N > 1 device path without a collective: every "rank" runs ITS shard's STREAM phase (absolute frame offsets,
+    state + local tokens into its send buffer, merge on the comm stream); the all-gather is emulated by copying the
+    send buffers into `finish_rank`'s receive buffer; that rank's FINISH phase produces the full output."""
+    from hicom_amd import dist as hd, native as nv
+    T = ff.shape[0]
+    per = T // world
+    sends, keep = [], []
+    for r in range(world):
+        a, b = ff[r * per:(r + 1) * per], fe[r * per:(r + 1) * per]              # dense slices along dim 0
+        plan = hd._shard_plan(m, a, b, g, T, None, None, rank=r, world=world)
+        st = plan.sets[0]
+        plan.set_inputs(st, a, b, g, st.out)
+        nv.compressor_fwd(st.a_stream)
+        torch.cuda.synchronize()
+        sends.append(st.mine.clone())
+        keep.append(plan)
+    plan = keep[finish_rank]
+    st = plan.sets[0]
+    for r in range(world):
+        st.everyone[r].copy_(sends[r])
+    st.out.fill_(float("nan"))
+    torch.cuda.synchronize()
+    nv.compressor_fwd(st.a_finish)
+    torch.cuda.synchronize()
+    return st.out.clone()
 
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_multi_rank_device_path_emulated_on_one_gpu(c2, world):
-    """The N > 1 device path without a collective: every "rank" runs ITS shard's STREAM phase (absolute frame
-    offsets, state + local tokens into its send buffer, merge on the comm stream), the all-gather is emulated by
-    copying the send buffers into rank 0's receive buffer, and rank 0's FINISH phase (combine of `world` states, the
-    global chain, placement of `world` token blocks) must reproduce the dense forward of all frames."""
-    from hicom_amd import dist as hd, native as nv
+    """2- and 4-rank worlds on one GPU (see _emulate_ranks) against the dense forward of all frames."""
     m, ff, fe, g, _ = c2
-    T = ff.shape[0]
-    per = T // world
     with torch.no_grad():
         want = m(ff, fe, g, "video", None)
-        sends, plans = [], []
-        for r in range(world):
-            a, b = ff[r * per:(r + 1) * per].contiguous(), fe[r * per:(r + 1) * per].contiguous()
-            plan = hd._shard_plan(m, a, b, g, T, None, None, rank=r, world=world)
-            st = plan.sets[0]
-            st.a_stream.out = st.a_finish.out = st.out.data_ptr()
-            nv.compressor_fwd(st.a_stream)
-            torch.cuda.synchronize()
-            sends.append(st.mine.clone())
-            plans.append((plan, a, b))                       # keep the shard tensors alive: the plans hold raw pointers
-        plan, st = plans[0][0], plans[0][0].sets[0]
-        for r in range(world):
-            st.everyone[r].copy_(sends[r])
-        st.out.fill_(float("nan"))
-        torch.cuda.synchronize()
-        nv.compressor_fwd(st.a_finish)
-        torch.cuda.synchronize()
-        assert st.out.shape == want.shape
-        # (not bit-equal: a shard's workgroups hold fewer windows each, so windows meet the 16-token tiles at other
-        # offsets and their sums associate differently)
-        assert float((st.out - want).abs().max()) <= 2e-5
+        got = _emulate_ranks(m, ff, fe, g, world, 0)
+    # (not bit-equal: a shard's workgroups hold fewer windows each, so windows meet the 16-token tiles at other
+    # offsets and their sums associate differently)
+    assert got.shape == want.shape and float((got - want).abs().max()) <= 2e-5
 
 
 def test_guide_off_wide_global_kernel_matches_narrow():
@@ -411,14 +429,17 @@ def test_guide_off_wide_global_kernel_matches_narrow():
     assert float((wide[-32:].cpu() - want.reshape(32, 896)).abs().max()) <= TOL
 
 
-def test_c3_eight_rank_emulation():
-    """BASELINE configs[2] (512 frames over 8 GPUs, 64 per GPU) on one GPU: the eight ranks' STREAM phases one after
-    the other, the all-gather replaced by copies, rank 5's FINISH phase -- against the dense forward of all 512
-    frames (which itself takes the multi-round form of the stream kernel: 10368 windows)."""
+@pytest.mark.parametrize("per,finish_rank", [(64, 5), (128, 6)])
+def test_c3_c5_eight_rank_emulation(per, finish_rank):
+    """BASELINE configs[2] (512 frames over 8 GPUs, 64 per GPU) and configs[4] (1024 frames, 128 per GPU) on one GPU:
+    the eight ranks' STREAM phases one after the other (frame offsets up to 896), the all-gather replaced by copies,
+    one rank's FINISH phase -- against the dense forward of all frames (which takes the multi-round form of the stream
+    kernel), and the first / a middle / the last 4-frame group plus the global rows of a 32-frame sub-clip composition
+    against the oracle."""
     from types import SimpleNamespace
-    from hicom_amd import dist as hd, native as nv, synth
+    from hicom_amd import synth
     from oracle import hicom_oracle as orc
-    world, per = 8, 64
+    world = 8
     T = world * per
     cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "hidden_size": 896, "max_num_frames": T})
     sd = synth.synth_state_dict(orc.param_shapes(cfg), tag="c3")
@@ -430,24 +451,20 @@ def test_c3_eight_rank_emulation():
     with torch.no_grad():
         want = m(ff, fe, g, "video", None)
         assert want.shape == (T // 4 * 81 + 32, 896) and bool(torch.isfinite(want).all())
-        sends, keep = [], []
-        for r in range(world):
-            a, b = ff[r * per:(r + 1) * per], fe[r * per:(r + 1) * per]          # dense slices along dim 0
-            plan = hd._shard_plan(m, a, b, g, T, None, None, rank=r, world=world)
-            st = plan.sets[0]
-            st.a_stream.out = st.a_finish.out = st.out.data_ptr()
-            nv.compressor_fwd(st.a_stream)
-            torch.cuda.synchronize()
-            sends.append(st.mine.clone())
-            keep.append(plan)
-        st = keep[5].sets[0]
-        for r in range(world):
-            st.everyone[r].copy_(sends[r])
-        st.out.fill_(float("nan"))
-        torch.cuda.synchronize()
-        nv.compressor_fwd(st.a_finish)
-        torch.cuda.synchronize()
-        assert st.out.shape == want.shape and float((st.out - want).abs().max()) <= 2e-5
+        got = _emulate_ranks(m, ff, fe, g, world, finish_rank)
+    assert got.shape == want.shape and float((got - want).abs().max()) <= 2e-5
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    spec = orc.parse_projector_type(cfg.mm_projector_type)
+    for lo in (0, (world - 3) * per + 8, T - 4):                 # last two sit in shards with frame offset >= 5/8 T
+        ref = orc.local_forward(spec["local"], "direct", sdt, "local_compressor", ff[lo:lo + 4].float().cpu(),
+                                fe[lo:lo + 4].float().cpu(), g.float().cpu(), "video").reshape(81, 896)
+        assert float((got[lo // 4 * 81:lo // 4 * 81 + 81].cpu() - ref).abs().max()) <= TOL, lo
+    # global rows: equal to the dense forward's (above); at 512 frames also the oracle on ALL 373k keys (fp32 CPU: a few
+    # seconds and ~9 GB of host memory -- the 746k-key clip is left to the composition)
+    import psutil
+    if per == 64 and psutil.virtual_memory().available > 32 * 2 ** 30:
+        ref = orc.global_forward(spec["global"], "direct", sdt, "global_compressor", ff.float().cpu(), g.float().cpu())
+        assert float((got[-32:].cpu() - ref.reshape(32, 896)).abs().max()) <= TOL
 
 
 def test_sharded_forward_world1_equals_forward(c2):
@@ -481,14 +498,27 @@ def test_sharded_forward_world1_equals_forward(c2):
                 assert float((o - w).abs().max()) <= 2e-5, k
                 o.fill_(float("nan"))
             torch.cuda.synchronize()
-            # guide prefetch two calls ahead (this buffer set's next use): right and wrong predictions
+            # alternating input buffers AND guides, deferred, NO host sync between the calls: every plan
+            # owns its workspaces, so a call never streams into partial states a comm stream is still merging
             g2 = (g.float() * -0.7 + 0.05).to(g.dtype)
             want_g2 = m(ff, fe, g2, "video", None)
-            seq = [(g, g), (g, g2), (g, g), (g2, g), (g, None), (g, g2), (g2, g2), (g2, g)]
-            for k, (cur, nxt2) in enumerate(seq):
-                o, ev = sharded_forward(m, ff, fe, cur, 64, deferred=True, guide_after_next=nxt2)
-                ev.synchronize()
-                assert float((o - (want if cur is g else want_g2)).abs().max()) <= 2e-5, ("prefetch", k)
+            want2_g2 = m(fe, ff, g2, "video", None)
+            half_a, half_b = ff[:32].contiguous(), fe[:32].contiguous()
+            want_half = m(half_a, half_b, g, "video", None)
+            outs = []
+            for k in range(24):
+                a, b = (ff, fe) if k % 2 == 0 else (fe, ff)
+                gg = g if (k // 2) % 2 == 0 else g2
+                if k % 6 == 5:
+                    o, ev = sharded_forward(m, half_a, half_b, g, 32, deferred=True)     # another plan (shape) in between
+                    outs.append((o.clone(), want_half))
+                    continue
+                o, ev = sharded_forward(m, a.clone(), b.clone(), gg.clone(), 64, deferred=True)   # fresh buffers every call
+                w = {(0, 0): want, (1, 0): want2, (0, 1): want_g2, (1, 1): want2_g2}[k % 2, (k // 2) % 2]
+                torch.cuda.current_stream().wait_event(ev)
+                outs.append((o.clone(), w))
             torch.cuda.synchronize()
+            for k, (o, w) in enumerate(outs):
+                assert float((o - w).abs().max()) <= 2e-5, ("alternating", k)
     finally:
         dist.destroy_process_group()
