@@ -1,16 +1,187 @@
 """Training path of the drop-in projector: autograd through hicom_compressor_fwd.
 
 The projector is the trainable module of the reference's stages 1-2 (scripts/qwen2.5_7B/release/
-directg_local43_global32.sh:54,113; hicom/train.py:704-712), called under autograd + gradient checkpointing.
+directg_local43_global32.sh:54,113; hicom/train.py:704-712), called under autograd + gradient checkpointing
+(:78).  `forward_with_grad` returns exactly what the inference path returns (same kernels, same bits) wrapped
+in a `torch.autograd.Function`; the backward is recompute-based (nothing but the inputs is kept alive, which is what
+gradient checkpointing wants):
+
+  streaming part (HIP)   window contexts recomputed by hicom_local_attn_fwd; the global logits / softmax state by
+                         hicom_global_stream_fwd + merge; the attention backward over all T*729 tokens by
+                         hicom_global_stream_bwd (one more pass over frames_feature: dS and sum dS . x)
+  dense weight gradients plain library GEMMs / outer products through torch (rocBLAS) in fp32 on the small
+                         [Nw, 1152] / [9, 1152] tensors -- dW = dY^T X is not a kernel worth hand-writing
+
+Scope: the release recipe (`use_guide="direct"`, no adaptors, no clip-scale), dense video / image inputs, gradients of
+every projector parameter and of `image_newline`.  Gradients w.r.t. the visual features and the guide embedding
+(stage 3 of the release script, where the SigLIP head and the guide encoder train too) are not built: asking for
+them raises instead of returning None silently.  Other recipes raise NotImplementedError.
 """
 from __future__ import annotations
 
+import math
+
 import torch
+
+from . import native as nv
+
+
+LAST_FP32_GRADS = None      # test hook: the fp32 gradients of the last backward (before the cast to the parameter dtype)
+
+
+def _gelu_grad(x):
+    return 0.5 * (1.0 + torch.erf(x * 0.7071067811865476)) + x * torch.exp(-0.5 * x * x) * 0.3989422804014327
+
+
+def _supported(proj) -> bool:
+    lc, gc = proj.local_compressor, proj.global_compressor
+    for c in (lc, gc):
+        if c is not None and not (c.is_plain and c.use_guide == "direct"):
+            return False
+    return proj.local_logit is None and proj.global_logit is None
+
+
+class _CompressorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, proj, ff, fe, guide, modal, nl, names, *params):
+        from . import engine
+        from .projector import _out_dtype
+        with torch.no_grad():
+            out = engine.run_dense(proj, ff, fe, guide, modal, nl, _out_dtype(proj))
+        ctx.proj, ctx.modal, ctx.names = proj, modal, names
+        ctx.save_for_backward(ff, fe, guide, nl)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ff, fe, guide, nl = ctx.saved_tensors
+        need = ctx.needs_input_grad            # (proj, ff, fe, guide, modal, nl, names, *params)
+        if need[1] or need[2] or need[3]:
+            raise NotImplementedError("hicom_amd backward: gradients w.r.t. frames_feature / frames_embed / guide_embed are "
+                                      "not built (projector-only training, reference stages 1-2); detach them")
+        with torch.no_grad():
+            grads, d_nl = compressor_backward(ctx.proj, ff, fe, guide, ctx.modal, nl, dout)
+        global LAST_FP32_GRADS
+        LAST_FP32_GRADS = grads
+        plist = dict(ctx.proj.named_parameters())
+        out = []
+        for k, name in enumerate(ctx.names):
+            g = grads.get(name) if need[7 + k] else None
+            out.append(None if g is None else g.to(plist[name].dtype).reshape(plist[name].shape))
+        return (None, None, None, None, None, (d_nl.to(nl.dtype) if (nl is not None and need[5] and d_nl is not None) else None),
+                None, *out)
+
+
+def compressor_backward(proj, ff, fe, guide, modal, nl, dout):
+    """fp32 gradients {parameter name: tensor} of sum(out * dout) and d image_newline, for the direct recipe.
+    Restates autograd through reference projector.py:524-559 (local), :634-646 + :166-228 (global) and
+    mm_utils.py:92-140 (packing)."""
+    lc, gc = proj.local_compressor, proj.global_compressor
+    dev = ff.device
+    dout = dout.float()
+    T, H, W, E = ff.shape
+    grads = {}
+    d_nl = None
+    n_local = 0
+    if lc is not None:
+        at, ay, ax = lc.tilings(T, H, W, modal)
+        grid = (at.nwin, ay.nwin, ax.nwin)
+        lay = proj._layout(grid, modal, nl is not None, False)
+        nw = grid[0] * grid[1] * grid[2]
+        n_local = lay.n_rows
+        idx = torch.arange(nw, device=dev)
+        rows = idx + (idx // lay.nl_group if lay.nl_group else 0)          # packing row map of the readout store
+        dY = dout[rows]
+        if lay.newline_rows:
+            d_nl = dout[torch.tensor(lay.newline_rows, device=dev)].sum(0)
+        ctx_l, _ = lc.window_context(ff, fe, guide, modal, None, None)     # HIP: [Nw, E] fp32 window contexts
+        W0, b0 = lc.readout[0].weight.float(), lc.readout[0].bias.float()
+        W2 = lc.readout[2].weight.float()
+        pre = torch.addmm(b0, ctx_l, W0.t())
+        h = torch.nn.functional.gelu(pre)
+        grads["local_compressor.readout.2.weight"] = dY.t() @ h
+        grads["local_compressor.readout.2.bias"] = dY.sum(0)
+        dpre = (dY @ W2) * _gelu_grad(pre)
+        grads["local_compressor.readout.0.weight"] = dpre.t() @ ctx_l
+        grads["local_compressor.readout.0.bias"] = dpre.sum(0)
+    if gc is not None:
+        att = gc.attn_layer
+        nh, hd = att.num_heads, att.head_dim
+        q_in, n_rows = gc.injected_queries(guide)                          # direct: the guide itself, one row
+        ml, acc, scores = gc.partial_context(ff, q_in)                     # HIP: forward logits + softmax state
+        R = ml.shape[0]
+        ctxg = acc / ml[:, 1:2]                                            # per-head contexts [9, E]
+        g32 = q_in.float().reshape(-1)
+        Wq, bq = att.q_proj.weight.float(), att.q_proj.bias.float()
+        Wk = att.k_proj.weight.float()
+        Wv, bv = att.v_proj.weight.float(), att.v_proj.bias.float()
+        Wo, bo = att.out_proj.weight.float(), att.out_proj.bias.float()
+        G0, gb0 = gc.readout[0].weight.float(), gc.readout[0].bias.float()
+        G2 = gc.readout[2].weight.float()
+        o = torch.einsum("hje,he->hj", Wv.view(nh, hd, E), ctxg).reshape(E) + bv          # ref :182,:215 after folding
+        pre = Wo @ o + bo + g32                                            # out_proj + residual with the injected query (:646)
+        a1 = G0 @ pre + gb0
+        hid = torch.nn.functional.gelu(a1)
+        dtok = dout[n_local:n_local + n_rows].sum(0)                       # the 32 global rows are copies of one row
+        P = "global_compressor."
+        grads[P + "readout.2.weight"] = torch.outer(dtok, hid)
+        grads[P + "readout.2.bias"] = dtok
+        da1 = (G2.t() @ dtok) * _gelu_grad(a1)
+        grads[P + "readout.0.weight"] = torch.outer(da1, pre)
+        grads[P + "readout.0.bias"] = da1
+        dpre = G0.t() @ da1
+        grads[P + "attn_layer.out_proj.weight"] = torch.outer(dpre, o)
+        grads[P + "attn_layer.out_proj.bias"] = dpre
+        do = Wo.t() @ dpre
+        grads[P + "attn_layer.v_proj.bias"] = do
+        grads[P + "attn_layer.v_proj.weight"] = (do.view(nh, hd, 1) * ctxg.view(nh, 1, E)).reshape(E, E)
+        dctx = torch.einsum("hje,hj->he", Wv.view(nh, hd, E), do.view(nh, hd)).contiguous()   # [9, E]
+        delta = (dctx * ctxg).sum(1).contiguous()
+        # ---- attention backward over the token stream (HIP) ------------------------------------------------
+        rows_pad = (R + 15) // 16 * 16
+        dhi = torch.empty((rows_pad, E), dtype=torch.bfloat16, device=dev)
+        dlo = torch.empty_like(dhi)
+        nv.split_bf16(dctx, rows_pad, dhi, dlo)
+        N = T * H * W
+        pe = None
+        t0i = y0i = x0i = 0
+        pos_b = None
+        if gc.use_pos_emb:
+            pe, cap = gc.pos_tables(T, H, W, dev)
+            t0i, y0i, x0i = 0, cap, cap + H
+            pos_b = torch.zeros((rows_pad, pe.shape[0]), dtype=torch.float32, device=dev)
+            nv.linear(dctx, pe, None, pos_b, M=R)
+        ds = torch.empty_like(scores)
+        nparts = nv.global_stream_nparts(N, rows_pad)
+        part = torch.empty((nparts, rows_pad, E), dtype=torch.float32, device=dev)
+        nv.global_stream_bwd(ff.view(N, E), N, dhi, dlo, pos_b, H if pe is not None else 1, W if pe is not None else N,
+                             t0i, y0i, x0i, scores, ml, delta, ds, part, R)
+        dqt = part.sum(0)[:R]                                              # sum_n dS[r, n] x_n
+        if pe is not None:
+            dS = ds[:R, :N].view(R, T, H, W)
+            dqt = dqt + dS.sum((2, 3)) @ pe[t0i:t0i + T] + dS.sum((1, 3)) @ pe[y0i:y0i + H] + dS.sum((1, 2)) @ pe[x0i:x0i + W]
+        # ---- through the fold: qt_h = scale W_k,h^T (W_q g + b_q)_h  (ref :180-181,:193-197) -----------------
+        scale = att.scale
+        qp = Wq @ g32 + bq
+        grads[P + "attn_layer.k_proj.weight"] = scale * (qp.view(nh, hd, 1) * dqt.view(nh, 1, E)).reshape(E, E)
+        grads[P + "attn_layer.k_proj.bias"] = torch.zeros(E, device=dev)   # a per-row logit shift: softmax cancels it exactly
+        dqp = scale * torch.einsum("hje,he->hj", Wk.view(nh, hd, E), dqt).reshape(E)
+        grads[P + "attn_layer.q_proj.weight"] = torch.outer(dqp, g32)
+        grads[P + "attn_layer.q_proj.bias"] = dqp
+        # global_compressor.query does not enter the direct recipe (ref :352-368: only its shape is used): no gradient
+    return grads, d_nl
 
 
 def forward_with_grad(proj, frames_feature, frames_embed, guide_embed, modal, image_newline):
     from .projector import _require_bf16_cuda
     some = frames_feature["patch"] if isinstance(frames_feature, dict) else frames_feature
     _require_bf16_cuda("frames_feature", some)
-    raise NotImplementedError("hicom_amd: no backward for this recipe yet -- run inference under torch.no_grad() / "
-                              "torch.inference_mode(); forward() never returns a silently detached tensor")
+    if isinstance(frames_feature, dict) or not _supported(proj):
+        raise NotImplementedError("hicom_amd: the backward pass covers the release recipe (use_guide='direct', no adaptors, no "
+                                  "clip-scale, dense inputs); run other recipes under torch.no_grad() / inference_mode() -- "
+                                  "forward() never returns a silently detached tensor")
+    names, params = zip(*[(n, p) for n, p in proj.named_parameters()])
+    ff = frames_feature.contiguous()
+    fe = frames_embed.contiguous() if frames_embed is not None else None
+    return _CompressorFn.apply(proj, ff, fe, guide_embed.contiguous(), modal,
+                               image_newline.contiguous() if image_newline is not None else None, names, *params)

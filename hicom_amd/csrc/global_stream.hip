@@ -44,6 +44,10 @@ struct StreamParams {
     int rows_pad;
     int rows;      // rows < rows_pad that carry real queries; padded rows are never stored
     int ntiles;
+    // backward mode (global_stream_kernel<NB, true>): softmax state and scores of the forward pass
+    const float* s_in;     // [rows_pad][score_stride] raw logits S written by the forward pass
+    const float* ml;       // [rows][2] (M, L) of the forward softmax
+    const float* delta;    // [rows] dctx_r . ctx_r
 };
 
 // bit rotation of the row index used as the 16-byte-chunk swizzle (bijective on 0..15)
@@ -52,7 +56,14 @@ __device__ __forceinline__ int swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 
 // 4-row blocks a 32-lane half reads with ds_read_b64_tr_b16 sit 8 rows apart (conflict-free)
 __device__ __forceinline__ int sig(int g) { return ((g & 1) << 1) | (g >> 1); }
 
-template <int NB>
+// BWD = false: forward (above).  BWD = true: attention backward over the same stream (reference autograd through
+// projector.py:197-215): the "queries" are the upstream gradients dctx_r of the per-head contexts, so the MFMA score
+// tile is dP[r, n] = dctx_r . (x_n + pos_n); with the forward's logits S and softmax state (M, L) the lane forms
+//     dS[r, n] = exp(S[r, n] - M_r) / L_r * (dP[r, n] - delta_r),      delta_r = dctx_r . ctx_r
+// writes it to `scores` (the positional marginals are taken from it afterwards) and accumulates
+//     ACC[r, :] += dS[r, n] x[n, :]        ( = the x part of d q~_r )
+// through the same hi/lo P.x MFMAs.  No running max: the state is known.
+template <int NB, bool BWD = false>
 __global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
     constexpr int E = NB * 128;
     constexpr int SLICE = E / 4;          // channels owned by one wave
@@ -134,8 +145,24 @@ __global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
         }
     };
 
+    // backward: the forward's logits of (row r16, tokens 4*sig(kg)..+3), fetched one tile ahead like the positional terms
+    f32x4 s_next = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bw_m = 0.f, bw_linv = 0.f, bw_delta = 0.f;
+    auto fetch_s = [&](int tile) {
+        if constexpr (BWD)
+            s_next = *reinterpret_cast<const f32x4*>(p.s_in + row_glob * p.score_stride + (long)tile * 16 + 4 * sig(kg));
+    };
+    if constexpr (BWD) {
+        if (row_glob < p.rows) {
+            bw_m = p.ml[2 * row_glob];
+            bw_linv = 1.0f / p.ml[2 * row_glob + 1];
+            bw_delta = p.delta[row_glob];
+        }
+    }
+
     if (tb < te) {
         fetch_pos(tb);
+        fetch_s(tb);
         stage(tb, 0);
     }
 
@@ -149,8 +176,10 @@ __global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
         float padd[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) padd[j] = pt[j] + py[j] + px[j];
+        const f32x4 s_cur = s_next;
         if (tile + 1 < te) {
             fetch_pos(tile + 1);
+            fetch_s(tile + 1);
             stage(tile + 1, cur ^ 1);
         }
         const char* img = tilebuf + cur * TILE_BYTES;
@@ -181,6 +210,14 @@ __global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
         const long n0 = (long)tile * 16 + 4 * sig(kg);
 #pragma unroll
         for (int j = 0; j < 4; ++j) lg[j] += padd[j];
+        float pr[4];
+        if constexpr (BWD) {
+            // dS = softmax weight x (dP - delta); padded rows (state 0, 0, 0) and tail tokens contribute nothing
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                pr[j] = (n0 + j < p.N && row_glob < p.rows) ? expf(s_cur[j] - bw_m) * bw_linv * (lg[j] - bw_delta) : 0.f;
+            if (wave == 0) *reinterpret_cast<f32x4*>(p.scores + row_glob * p.score_stride + n0) = f32x4{pr[0], pr[1], pr[2], pr[3]};
+        } else {
         if (wave == 0) *reinterpret_cast<f32x4*>(p.scores + row_glob * p.score_stride + n0) = lg;
 
         // ---- online softmax for row r16 (lanes r16, r16+16, r16+32, r16+48 share the row) -------
@@ -191,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
         const float alpha = expf(m_run - m_new);
-        float pr[4], lsum = 0.f;
+        float lsum = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             pr[j] = (n0 + j < p.N) ? expf(lg[j] - m_new) : 0.f;
@@ -201,14 +238,6 @@ __global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
         lsum += __shfl_xor(lsum, 32, 64);
         l_run = l_run * alpha + lsum;
         m_run = m_new;
-        bf16x4 phi, plo;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint16_t h, l;
-            split_bf16(pr[j], h, l);
-            phi[j] = (short)h;
-            plo[j] = (short)l;
-        }
         // rescale the running context when any row's max moved (wave-uniform branch)
         if (__any(alpha != 1.0f)) {
             const float a0 = __shfl(alpha, 4 * kg + 0, 64), a1 = __shfl(alpha, 4 * kg + 1, 64);
@@ -217,6 +246,15 @@ __global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
             for (int cb = 0; cb < CBLK; ++cb) {
                 acc[cb][0] *= a0; acc[cb][1] *= a1; acc[cb][2] *= a2; acc[cb][3] *= a3;
             }
+        }
+        }
+        bf16x4 phi, plo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint16_t h, l;
+            split_bf16(pr[j], h, l);
+            phi[j] = (short)h;
+            plo[j] = (short)l;
         }
 
         // ---- ACC += P . x over this wave's output channels ----------------------------------------
@@ -233,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
 
     // ---- partial results of this token chunk ----------------------------------------------------
     const long prow = (long)part * p.rows_pad + rg * 16;
-    if (wave == 0 && kg == 0 && rg * 16 + r16 < p.rows) {
+    if (!BWD && wave == 0 && kg == 0 && rg * 16 + r16 < p.rows) {
         p.part_m[prow + r16] = m_run;
         p.part_l[prow + r16] = l_run;
     }
@@ -530,6 +568,7 @@ extern "C" int hicom_global_stream_fwd(const void* x, int64_t N, int32_t E,
     p.scores = scores; p.score_stride = score_stride;
     p.part_m = part_m; p.part_l = part_l; p.part_acc = part_acc; p.rows_pad = rows_pad; p.rows = rows;
     p.ntiles = (int)((N + 15) / 16);
+    p.s_in = nullptr; p.ml = nullptr; p.delta = nullptr;
     dim3 grid((unsigned)nparts, (unsigned)(rows_pad / 16));
     hipStream_t s = (hipStream_t)stream;
     // many rows: the wide form (two row groups per workgroup, three-deep ring) when its limits hold
@@ -562,4 +601,47 @@ extern "C" int hicom_global_stream_fwd(const void* x, int64_t N, int32_t E,
         hipLaunchKernelGGL(global_stream_kernel<6>, grid, dim3(256), smem, s, p);
     }
     return hicom_host::check_launch("global_stream");
+}
+
+// ---- attention backward over the stream (training path) --------------------------------------------
+// dctx_hi / dctx_lo : bf16 [rows_pad, E] hi / lo planes of the upstream gradients of the per-head contexts (rows >= rows zero)
+// pos_b             : f32 [rows_pad, pos_stride] = dctx . PE^T (score-side table of dP), or NULL
+// s_in              : the logits the forward pass (hicom_global_stream_fwd) wrote; ml [rows][2]; delta [rows]
+// ds_out            : f32 [rows_pad, score_stride] dS; part_acc : f32 [nparts, rows_pad, E] partial sums of dS . x
+extern "C" int hicom_global_stream_bwd(const void* x, int64_t N, int32_t E, const void* dctx_hi, const void* dctx_lo,
+                                       int32_t rows, int32_t rows_pad, const float* pos_b, int32_t pos_stride,
+                                       int32_t H, int32_t W, int32_t t_index0, int32_t y_index0, int32_t x_index0,
+                                       const float* s_in, int64_t score_stride, const float* ml, const float* delta,
+                                       float* ds_out, float* part_acc, int32_t nparts, void* stream) {
+    HICOM_REQUIRE(x && dctx_hi && dctx_lo && s_in && ml && delta && ds_out && part_acc, HICOM_EINVAL, "global_stream_bwd: NULL pointer");
+    HICOM_REQUIRE(E == 1152 || E == 768, HICOM_EUNSUP, "global_stream_bwd: E=%d (only 1152 / 768)", E);
+    HICOM_REQUIRE(N > 0 && N < (1L << 31) && rows_pad > 0 && rows_pad % 16 == 0 && rows > 0 && rows <= rows_pad && nparts > 0,
+                  HICOM_EINVAL, "global_stream_bwd: bad shape");
+    HICOM_REQUIRE(score_stride >= ((N + 15) / 16) * 16 && score_stride % 4 == 0, HICOM_EINVAL, "global_stream_bwd: score_stride");
+    HICOM_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)dctx_hi % 16 == 0) && ((uintptr_t)dctx_lo % 16 == 0) &&
+                      ((uintptr_t)s_in % 16 == 0) && ((uintptr_t)ds_out % 16 == 0), HICOM_EINVAL, "global_stream_bwd: alignment");
+    if (pos_b) HICOM_REQUIRE(H > 0 && W > 0 && pos_stride > 0, HICOM_EINVAL, "global_stream_bwd: pos geometry");
+    StreamParams p;
+    p.x = (const uint16_t*)x; p.N = N; p.qhi = (const uint16_t*)dctx_hi; p.qlo = (const uint16_t*)dctx_lo;
+    p.pos_a = pos_b; p.pos_stride = pos_stride; p.H = H; p.W = W; p.HW = H * W;
+    p.t0i = t_index0; p.y0i = y_index0; p.x0i = x_index0;
+    p.scores = ds_out; p.score_stride = score_stride;
+    p.part_m = nullptr; p.part_l = nullptr; p.part_acc = part_acc; p.rows_pad = rows_pad; p.rows = rows;
+    p.ntiles = (int)((N + 15) / 16);
+    p.s_in = s_in; p.ml = ml; p.delta = delta;
+    dim3 grid((unsigned)nparts, (unsigned)(rows_pad / 16));
+    hipStream_t s = (hipStream_t)stream;
+    if (E == 1152) {
+        constexpr int smem = 2 * 9 * 4096 + 4096;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(global_stream_kernel<9, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((global_stream_kernel<9, true>), grid, dim3(256), smem, s, p);
+    } else {
+        constexpr int smem = 2 * 6 * 4096 + 4096;
+        hipLaunchKernelGGL((global_stream_kernel<6, true>), grid, dim3(256), smem, s, p);
+    }
+    return hicom_host::check_launch("global_stream_bwd");
 }

@@ -28,6 +28,7 @@ EXPORTS = (
     "hicom_global_combine_strided_fwd", "hicom_compressor_workspace_bytes", "hicom_compressor_zero_prefix_bytes", "hicom_compressor_is_fused",
     "hicom_compressor_fwd", "hicom_linear_to_rows_fwd", "hicom_fused_stream_fwd", "hicom_fused_stream_nparts",
     "hicom_planes_gemm_fwd", "hicom_row_ln_fwd", "hicom_small_mha_fwd", "hicom_place_blocks_fwd",
+    "hicom_global_stream_bwd",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -100,6 +101,8 @@ def lib() -> C.CDLL:
     L.hicom_global_stream_fwd.argtypes = [vp, i64, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i64,
                                           vp, vp, vp, i32, vp]
     L.hicom_global_stream_nparts.argtypes = [i64, i32]
+    L.hicom_global_stream_bwd.argtypes = [vp, i64, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp, vp,
+                                          vp, vp, i32, vp]
     L.hicom_global_merge_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, i64, i64, i32, i32, vp, i32, i32, i32,
                                          vp, vp, vp, i32, vp]
     L.hicom_linear_to_rows_fwd.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i64, i64, i32, vp]
@@ -208,6 +211,14 @@ def global_stream(x, N, qhi, qlo, pos_a, H, W, t0i, y0i, x0i, scores, part_m, pa
                                          pos_a.shape[1] if pos_a is not None else 0, H, W, t0i, y0i, x0i,
                                          _ptr(scores), scores.shape[1], _ptr(part_m), _ptr(part_l), _ptr(part_acc),
                                          nparts, _stream()), "hicom_global_stream_fwd")
+
+
+def global_stream_bwd(x, N, dhi, dlo, pos_b, H, W, t0i, y0i, x0i, s_in, ml, delta, ds_out, part_acc, rows):
+    E = x.shape[-1]
+    _check(lib().hicom_global_stream_bwd(_ptr(x), N, E, _ptr(dhi), _ptr(dlo), rows, dhi.shape[0], _ptr(pos_b),
+                                         pos_b.shape[1] if pos_b is not None else 0, H, W, t0i, y0i, x0i, _ptr(s_in),
+                                         s_in.shape[1], _ptr(ml), _ptr(delta), _ptr(ds_out), _ptr(part_acc),
+                                         part_acc.shape[0], _stream()), "hicom_global_stream_bwd")
 
 
 def global_merge(part_m, part_l, part_acc, rows, scores, N, H, W, pe, t0i, y0i, x0i, scratch, out_ml, out_acc,

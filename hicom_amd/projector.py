@@ -105,7 +105,7 @@ class MultiheadAttention(nn.Module):
             if logit_scale is not None:
                 raise NotImplementedError("MultiheadAttention: clip-scale normalises the PROJECTED keys (ref :184-186); "
                                           "no HIP path yet")
-            ml, acc = _stream_attention(self, k2, q2, None, 0, 0, 0, 0, 0)
+            ml, acc, _ = _stream_attention(self, k2, q2, None, 0, 0, 0, 0, 0)
             ctx = _f32(acc.shape, acc.device)
             nv.global_combine(ml.unsqueeze(0), acc.unsqueeze(0), ctx)
             wv, bv = _linear_params(self.v_proj)
@@ -208,7 +208,7 @@ def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i):
     T = N // (H * W)
     scratch = _f32((R * T * (H + W + 2),), dev) if pe is not None else None
     nv.global_merge(part_m, part_l, part_acc, R, scores, N, H, W, pe, t0i, y0i, x0i, scratch, ml, acc)
-    return ml, acc
+    return ml, acc, scores
 
 
 class LocalCompressor(nn.Module):
@@ -443,8 +443,8 @@ class GlobalCompressor(nn.Module):
         return q.reshape(-1, self.embed_dim).contiguous(), self.num_queries
 
     def partial_context(self, frames_feature, q_in, t_offset: int = 0):
-        """Streams this call's frames once: returns (ml [R,2], acc [R,E]) un-normalised online-softmax
-        state for R = nq_eff * num_heads folded query rows (ref :180-215 restated)."""
+        """Streams this call's frames once: returns (ml [R,2], acc [R,E], raw logits [rows_pad, N']) -- the un-normalised
+        online-softmax state for R = nq_eff * num_heads folded query rows (ref :180-215 restated)."""
         ff = frames_feature.contiguous()
         _require_bf16_cuda("frames_feature", ff)
         T, H, W, E = ff.shape
@@ -453,8 +453,7 @@ class GlobalCompressor(nn.Module):
         if self.use_pos_emb:
             pe, cap = self.pos_tables(t_offset + T, H, W, ff.device)
             t0i, y0i, x0i = t_offset, cap, cap + H
-        ml, acc = _stream_attention(self.attn_layer, ff.view(T * H * W, E), q_in, pe, H, W, t0i, y0i, x0i)
-        return ml, acc, None
+        return _stream_attention(self.attn_layer, ff.view(T * H * W, E), q_in, pe, H, W, t0i, y0i, x0i)
 
     def finish(self, ml_sets, acc_sets, q_in, out, row0: int, n_rows: int):
         """Combine shard states, apply v_proj per head, out_proj + residual, readout, and write

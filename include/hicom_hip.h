@@ -145,6 +145,20 @@ int hicom_global_stream_fwd(const void* x, int64_t N, int32_t E,
                             float* part_m, float* part_l, float* part_acc, int32_t nparts,
                             void* stream);
 
+/* ---- backward of the global attention over the token stream (training) ------
+ * Autograd through projector.py:197-215 in the folded form: with the forward's logits S (the `scores`
+ * hicom_global_stream_fwd wrote), its softmax state ml [rows][2] = (M, L) and delta_r = dctx_r . ctx_r,
+ *   dP[r,n] = dctx_r . (x_n + pos_n),   dS[r,n] = exp(S[r,n] - M_r) / L_r * (dP[r,n] - delta_r)
+ *   part_acc[p, r, :] = sum over chunk p of dS[r,n] x_n          (sum over p = the x part of d qt_r)
+ * dctx_hi / dctx_lo: bf16 [rows_pad, E] planes of the upstream context gradients (padding rows zero);
+ * pos_b: f32 [rows_pad, pos_stride] = dctx . PE^T (or NULL); ds_out: f32 [rows_pad, score_stride] (its t / y / x
+ * marginals times PE give the positional part of d qt).  One pass over x, same tiling as the forward. */
+int hicom_global_stream_bwd(const void* x, int64_t N, int32_t E, const void* dctx_hi, const void* dctx_lo,
+                            int32_t rows, int32_t rows_pad, const float* pos_b, int32_t pos_stride,
+                            int32_t H, int32_t W, int32_t t_index0, int32_t y_index0, int32_t x_index0,
+                            const float* s_in, int64_t score_stride, const float* ml, const float* delta,
+                            float* ds_out, float* part_acc, int32_t nparts, void* stream);
+
 /* Suggested nparts for N tokens (fills the chip: 2 workgroups per CU). */
 int hicom_global_stream_nparts(int64_t N, int32_t rows_pad);
 

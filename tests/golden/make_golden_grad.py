@@ -1,0 +1,72 @@
+"""Generates tests/golden/golden_grad_v1.npz: parameter gradients of the REFERENCE (imported in place from
+/root/reference through oracle/ref_shim.py, float32 autograd) for loss = sum(out * R), R a fixed synthetic cotangent.
+
+Run in the build container only:  python tests/golden/make_golden_grad.py
+Per parameter only 512 sampled entries + (sum, abs-sum) are stored (the projection matrices are 1152 x 1152).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from oracle import ref_shim            # noqa: E402
+from hicom_amd import synth            # noqa: E402
+import cases                            # noqa: E402
+
+GRAD_CASES = ["G1_direct_T8", "G4b_image_newline", "G9_grid", "G9_frame", "G10_peaky_direct", "G9_local_only", "G9_global_only",
+              "G3_direct_T7"]
+
+
+def cotangent(name, shape):
+    return synth.normal_like(tuple(shape), synth.seed_of(name + ":cotangent"))
+
+
+def sample_positions(n, count=512):
+    k = np.arange(count, dtype=np.int64)
+    return (k * 2654435761 + 12345) % n
+
+
+def main():
+    proj, _ = ref_shim.load()
+    blobs = {}
+    for name in GRAD_CASES:
+        case = cases.build_case(name)
+        torch.manual_seed(0)
+        module = proj.build_vision_projector(case.cfg).float().train()
+        module.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd.items()}, strict=True)
+        t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))
+        ff, fe, g = t(case.ff), t(case.fe), t(case.g)
+        nl = None
+        if case.newline is not None:
+            nl = torch.nn.Parameter(t(case.newline))
+        out = module(ff, fe, g, case.modal, nl)
+        R = torch.from_numpy(cotangent(name, out.shape))
+        (out * R).sum().backward()
+        items = [(k, p.grad) for k, p in module.named_parameters()]
+        if nl is not None:
+            items.append(("image_newline", nl.grad))
+        for k, gr in items:
+            if gr is None:
+                blobs[f"{name}/{k}/none"] = np.zeros(1, dtype=np.uint8)
+                continue
+            v = gr.detach().numpy().astype(np.float32).reshape(-1)
+            pos = sample_positions(v.size)
+            blobs[f"{name}/{k}/samples"] = v[pos]
+            blobs[f"{name}/{k}/sums"] = np.array([v.astype(np.float64).sum(), np.abs(v.astype(np.float64)).sum(),
+                                                  np.abs(v).max()], dtype=np.float64)
+        print(name, "params with grad:", sum(1 for _, gr in items if gr is not None), "/", len(items))
+    path = os.path.join(HERE, "golden_grad_v1.npz")
+    np.savez_compressed(path, **blobs)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,121 @@
+"""Backward pass against gradients of the REFERENCE's own fp32 autograd
+(tests/golden/golden_grad_v1.npz, made by tests/golden/make_golden_grad.py): loss = sum(out * R) with a fixed
+synthetic cotangent R, every projector parameter (+ image_newline).
+
+Tolerance on the fp32 gradients the backward computes: 2e-3 of the parameter's largest reference gradient entry, or
+1e-5 of the largest gradient entry of the whole case where that is larger (a saturated softmax -- case G10 -- leaves
+d q_proj / d k_proj ~ 1e-6 by cancellation of O(1) terms, in the reference's fp32 too), + 1e-6 absolute; the .grad
+tensors autograd hands to the optimizer are their bf16 casts."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from gpu_util import build_module, dev_bf16
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def golden_grad():
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_grad_v1.npz"))
+
+
+def _grad_cases():
+    import make_golden_grad
+    return make_golden_grad.GRAD_CASES
+
+
+@pytest.mark.parametrize("name", ["G1_direct_T8", "G4b_image_newline", "G9_grid", "G9_frame", "G10_peaky_direct", "G9_local_only",
+                                  "G9_global_only", "G3_direct_T7"])
+def test_parameter_gradients_match_reference_autograd(name, golden_grad):
+    import make_golden_grad as mg
+    from hicom_amd import autograd as hag
+    assert name in mg.GRAD_CASES
+    case = cases.build_case(name)
+    m = build_module(case).train()
+    ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+    nl = None
+    if case.newline is not None:
+        nl = torch.nn.Parameter(dev_bf16(case.newline))
+    with torch.no_grad():
+        want_out = m(ff, fe, g, case.modal, nl).clone()
+    out = m(ff, fe, g, case.modal, nl)
+    assert out.requires_grad and torch.equal(out.detach(), want_out)        # same kernels, same bits as inference
+    R = torch.from_numpy(mg.cotangent(name, out.shape)).cuda()
+    (out * R).sum().backward()
+    fp32 = dict(hag.LAST_FP32_GRADS)
+    items = [(k, p) for k, p in m.named_parameters()]
+    if nl is not None:
+        items.append(("image_newline", nl))
+    checked = 0
+    mx_case = max(float(golden_grad[f][2]) for f in golden_grad.files if f.startswith(name + "/") and f.endswith("/sums"))
+    for k, p in items:
+        if f"{name}/{k}/none" in golden_grad:
+            assert p.grad is None, k
+            continue
+        want = golden_grad[f"{name}/{k}/samples"]
+        s, sabs, mx = golden_grad[f"{name}/{k}/sums"]
+        assert p.grad is not None and p.grad.dtype == p.dtype and p.grad.shape == p.shape, k
+        pos = torch.from_numpy(mg.sample_positions(p.numel())).cuda()
+        got16 = p.grad.float().reshape(-1)[pos].cpu().numpy()
+        tol = max(2e-3 * mx, 1e-5 * mx_case) + 1e-6
+        if k in fp32:
+            got = fp32[k].reshape(-1)[pos].cpu().numpy()
+            assert np.abs(got - want).max() <= tol, (k, float(np.abs(got - want).max()), tol)
+            assert abs(float(fp32[k].double().sum()) - s) <= 2e-3 * sabs + tol * p.numel() ** 0.5, k
+        assert np.abs(got16 - want).max() <= 2 ** -7 * mx + tol, k              # the bf16 cast of it
+        checked += 1
+    assert checked >= 4
+
+
+def test_unsupported_recipes_and_input_grads_refuse():
+    """Guide off / coarse have no backward yet, and gradients w.r.t. the inputs are not built: both must raise, never
+    return a detached tensor or a silent None."""
+    for name in ("G2_off_T8", "G6_coarse"):
+        case = cases.build_case(name)
+        m = build_module(case).train()
+        ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+        with pytest.raises(NotImplementedError):
+            m(ff, fe, g, case.modal, None)
+    case = cases.build_case("G1_direct_T8")
+    m = build_module(case).train()
+    ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g).requires_grad_(True)
+    out = m(ff, fe, g, case.modal, None)
+    with pytest.raises(NotImplementedError):
+        out.sum().backward()
+
+
+def test_backward_at_benchmark_size():
+    """C2 (64 x 729 x 1152, hidden 896): the backward runs at full size; its attention part is checked through a
+    size-independent property -- d/d(b_k) = 0 exactly, sum_n dS[r, n] = 0 (softmax Jacobian rows sum to zero) -- and the
+    readout gradients against torch autograd on the recomputed contexts."""
+    from types import SimpleNamespace
+    from hicom_amd import autograd as hag, synth
+    from oracle import hicom_oracle as orc
+    cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "hidden_size": 896, "max_num_frames": 64})
+    sd = synth.synth_state_dict(orc.param_shapes(cfg), tag="c2")
+    x = synth.synth_inputs(64, 27, 27, 1152, tag="c2")
+    m = build_module(SimpleNamespace(cfg=cfg, sd=sd)).train()
+    ff, fe, g = dev_bf16(x["ff"]), dev_bf16(x["fe"]), dev_bf16(x["g"])
+    out = m(ff, fe, g, "video", None)
+    R = torch.randn(out.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    (out * R).sum().backward()
+    gr = hag.LAST_FP32_GRADS
+    assert all(bool(torch.isfinite(v).all()) for v in gr.values())
+    # readout of the local tokens: autograd of the same MLP on the recomputed contexts
+    lc = m.local_compressor
+    with torch.no_grad():
+        ctx, _ = lc.window_context(ff, fe, g, "video", None, None)
+    w0 = lc.readout[0].weight.detach().float().requires_grad_(True)
+    w2 = lc.readout[2].weight.detach().float().requires_grad_(True)
+    y = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(ctx, w0, lc.readout[0].bias.float())), w2,
+                                   lc.readout[2].bias.float())
+    (y * R[:1296]).sum().backward()
+    for a, b in ((gr["local_compressor.readout.0.weight"], w0.grad), (gr["local_compressor.readout.2.weight"], w2.grad)):
+        assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max())
+    assert float(gr["global_compressor.attn_layer.k_proj.bias"].abs().max()) == 0.0
+    assert float(gr["global_compressor.attn_layer.q_proj.weight"].abs().max()) > 0.0

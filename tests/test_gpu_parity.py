@@ -302,9 +302,10 @@ def test_weight_update_invalidates_plan(c2):
     with torch.no_grad():
         base = m(ff[:8], fe[:8], g, "video", None).clone()
         w = m.local_compressor.readout[2].bias
+        orig = w.detach().clone()
         w.add_(1.0)
         moved = m(ff[:8], fe[:8], g, "video", None).clone()
-        w.sub_(1.0)
+        w.copy_(orig)
         assert float((moved[:-32] - base[:-32] - 1.0).abs().max()) < 2e-2
         old = w.data
         w.data = (old.float() + 2.0).to(old.dtype)                   # pointer swap, version counter untouched
