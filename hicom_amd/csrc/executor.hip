@@ -27,7 +27,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct WsLayout {
     size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, qp, qhi, qlo, pos_a, scores, part_m, part_l, part_acc, scratch, ml, acc,
-        ctx_g, o, qres, pre, hid_g, tok, total;
+        ctx_g, o, qres, pre, hid_g, tok, po, total;
     int nw, R, rows_pad, nparts, P;
     long N, score_stride;
 };
@@ -96,6 +96,7 @@ WsLayout make_layout(const hicom_compressor_args& a) {
         w.pre = take((size_t)a.nq * a.E * 4);
         w.hid_g = take((size_t)a.nq * a.hidden * 4);
         w.tok = take((size_t)a.nq * a.hidden * 4);
+        w.po = take((size_t)(a.E / 64) * a.E * 4);
     }
     w.total = off;
     return w;
@@ -239,16 +240,49 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         // ---- release recipe: ONE streaming kernel reads frames_embed and frames_feature once ------
         // main: q_proj, fold (+ guide -> local rows of the A operand), fused stream      | fork |
         // main: readout GEMMs            side: merge -> (finish)                 | join |
-        // the stream kernel overwrites the partial states: the previous call's merge (side stream, possibly still
-        // running when that call deferred its join) has to be done with them
-        if (a.ev_merge && !merge_on_next)
+        // fp16 readout (lw0_f16 / lw2_f16 given): contexts / hidden travel as ONE fp16 plane (in the bytes of the hi plane)
+        const bool f16 = a.lw0_f16 && a.lw2_f16;
+        // single-stream tail (solo call, one query row per head): no side stream, no events.  Cross-stream event hops cost
+        // 12-16 us each on this platform (fork after the ring kernel, join at the end: profiles/r02_a timeline), more than the
+        // overlap they bought; instead the global chain's small GEMVs ride INSIDE the two readout GEMM launches:
+        //   merge+v_proj | GEMM 1 (+ out_proj GEMV) | GEMM 2 (+ global readout 0 GEMV) | global readout 2 -> 32 rows
+        const bool single = f16 && !merge_on_next && do_finish && solo && a.nq == 1 && !a.state_sets && w.nparts <= 256 &&
+                            a.E / a.nh <= 128 && a.E <= 1536;
+        // two-stream form: the stream kernel overwrites the partial states: the previous call's merge (side stream, possibly
+        // still running when that call deferred its join) has to be done with them
+        if (a.ev_merge && !merge_on_next && !single)
             HICOM_REQUIRE(hipStreamWaitEvent(sm, (hipEvent_t)a.ev_merge, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
         CHK(query_prep(sm, true));
-        if (fold_ev && !merge_on_next) hicom_host::set_stop_event(a.ev_fork);      // "record ev_fork" rides on the launch
+        if (fold_ev && !merge_on_next && !single) hicom_host::set_stop_event(a.ev_fork);      // "record ev_fork" rides on the launch
         CHK(hicom_fused_stream_fwd(a.ff, a.fe ? a.fe : a.ff, a.T, a.H, a.W, a.E, a.at.k, a.ay.k, ws + w.qhi, ws + w.qlo,
                                    w.R, a.l_scale, a.l_bias, a.pe ? F(w.pos_a) : nullptr, a.P, a.pe ? a.pe_hi : nullptr, a.pe ? a.pe_lo : nullptr, a.t_index0, a.y_index0,
                                    a.x_index0, F(w.part_m), F(w.part_l), F(w.part_acc),
-                                   w.nparts, nullptr, ws + w.ctx_hi, ws + w.ctx_lo, sm));
+                                   w.nparts, nullptr, f16 ? nullptr : ws + w.ctx_hi, f16 ? nullptr : ws + w.ctx_lo, f16 ? ws + w.ctx_hi : nullptr, sm));
+        if (single) {
+            CHK(hicom_merge_vproj_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E, a.wv, F(w.po),
+                                      F(w.ml), F(w.ctx_g), sm));
+            hicom_aux_gemv ax1{F(w.po), a.E / 64, a.E, a.bv, a.wo, a.bo, a.gq, a.E, a.E, HICOM_ACT_NONE, F(w.pre)};
+            CHK(hicom_readout16_gemm_fwd(ws + w.ctx_hi, a.lw0_f16, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E, HICOM_ACT_GELU,
+                                         ws + w.hid_hi, nullptr, 0, 0, 0, 0, &ax1, sm));
+            hicom_aux_gemv ax2{F(w.pre), 1, a.E, nullptr, a.gw0, a.gb0, nullptr, a.hidden, a.E, HICOM_ACT_GELU, F(w.hid_g)};
+            CHK(hicom_readout16_gemm_fwd(ws + w.hid_hi, a.lw2_f16, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden, HICOM_ACT_NONE,
+                                         nullptr, a.local_out ? a.local_out : a.out, a.out_dt, a.local_out ? a.hidden : a.ldo,
+                                         a.local_out ? 0 : a.local_row0, a.local_out ? 0 : a.nl_group, &ax2, sm));
+            if (a.nl_count > 0 && !a.local_out)
+                CHK(hicom_scatter_rows_fwd(a.newline, a.newline_dt, 1, a.hidden, a.out, a.out_dt, a.ldo, a.nl_first, a.nl_step,
+                                           0, a.nl_count, sm));
+            CHK(hicom_linear_to_rows_fwd(F(w.hid_g), HICOM_DT_F32, a.gw2, HICOM_DT_BF16, a.gb2, HICOM_DT_BF16, a.nq, a.hidden,
+                                         a.hidden, HICOM_ACT_NONE, a.out, a.out_dt, a.ldo, a.global_row0, a.n_global_rows, sm));
+            if (a.defer_join && a.ev_join)      // (a deferred call's completion event: everything is on the main stream here)
+                HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_join, sm) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
+            if (a.ev_done) {
+                HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_done, sm) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
+                if (a.stream_next)
+                    HICOM_REQUIRE(hipStreamWaitEvent((hipStream_t)a.stream_next, (hipEvent_t)a.ev_done, 0) == hipSuccess, HICOM_ELAUNCH,
+                                  "compressor: stream wait");
+            }
+            return HICOM_OK;
+        }
         if (!merge_on_next) {
             if (fold_ev) HICOM_REQUIRE(hipStreamWaitEvent(ss, (hipEvent_t)a.ev_fork, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
             else CHK(fork());
@@ -260,16 +294,21 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                 HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_merge, ss) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
         }
         // readout MLP on bf16 planes: contexts (hi/lo) -> hidden (hi/lo) -> packed output rows
-        CHK(hicom_planes_gemm_fwd(ws + w.ctx_hi, ws + w.ctx_lo, a.lw0, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E,
-                                  HICOM_ACT_GELU, ws + w.hid_hi, ws + w.hid_lo, nullptr, 0, 0, 0, 0, sm));
+        if (f16) CHK(hicom_readout16_gemm_fwd(ws + w.ctx_hi, a.lw0_f16, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E, HICOM_ACT_GELU,
+                                              ws + w.hid_hi, nullptr, 0, 0, 0, 0, nullptr, sm));
+        else CHK(hicom_planes_gemm_fwd(ws + w.ctx_hi, ws + w.ctx_lo, a.lw0, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E,
+                                       HICOM_ACT_GELU, ws + w.hid_hi, ws + w.hid_lo, nullptr, 0, 0, 0, 0, sm));
         if (fold_ev && a.ev_done && merge_on_next && !do_finish && !(a.nl_count > 0 && !a.local_out)) {
             hicom_host::set_stop_event(a.ev_done);        // last main-stream launch of a STREAM-only call
             done_folded = true;
         }
-        CHK(hicom_planes_gemm_fwd(ws + w.hid_hi, ws + w.hid_lo, a.lw2, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden,
-                                  HICOM_ACT_NONE, nullptr, nullptr, a.local_out ? a.local_out : a.out, a.out_dt,
-                                  a.local_out ? a.hidden : a.ldo, a.local_out ? 0 : a.local_row0,
-                                  a.local_out ? 0 : a.nl_group, sm));
+        if (f16) CHK(hicom_readout16_gemm_fwd(ws + w.hid_hi, a.lw2_f16, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden, HICOM_ACT_NONE,
+                                              nullptr, a.local_out ? a.local_out : a.out, a.out_dt, a.local_out ? a.hidden : a.ldo,
+                                              a.local_out ? 0 : a.local_row0, a.local_out ? 0 : a.nl_group, nullptr, sm));
+        else CHK(hicom_planes_gemm_fwd(ws + w.hid_hi, ws + w.hid_lo, a.lw2, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden,
+                                       HICOM_ACT_NONE, nullptr, nullptr, a.local_out ? a.local_out : a.out, a.out_dt,
+                                       a.local_out ? a.hidden : a.ldo, a.local_out ? 0 : a.local_row0,
+                                       a.local_out ? 0 : a.nl_group, sm));
         if (a.nl_count > 0 && !a.local_out)
             CHK(hicom_scatter_rows_fwd(a.newline, a.newline_dt, 1, a.hidden, a.out, a.out_dt, a.ldo, a.nl_first, a.nl_step,
                                        0, a.nl_count, sm));

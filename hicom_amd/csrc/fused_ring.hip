@@ -76,6 +76,7 @@ struct RingParams {
     float* ctx_local;      // [NW][E] fp32 window contexts (may be NULL)
     uint16_t* ctx_hi;      // [NW][E] the same as bf16 hi / lo planes for hicom_planes_gemm_fwd (may be NULL)
     uint16_t* ctx_lo;
+    _Float16* ctx_f16;     // [NW][E] the same as ONE fp16 plane (saturating) for hicom_readout16_gemm_fwd (may be NULL)
     int wpw;               // windows per workgroup
 };
 
@@ -540,6 +541,13 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
                         *reinterpret_cast<uint2*>(p.ctx_hi + o) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
                         *reinterpret_cast<uint2*>(p.ctx_lo + o) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
                     }
+                    if (p.ctx_f16) {
+                        typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+                        half4_t hv;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) hv[u] = (_Float16)fminf(fmaxf(v[u], -65504.f), 65504.f);
+                        *reinterpret_cast<half4_t*>(p.ctx_f16 + o) = hv;
+                    }
                 }
             }
             if (r16 == row) { m_run = -1.0e30f; l_run = 0.f; }   // every copy of the row's state is recycled
@@ -644,10 +652,11 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T,
                                       int32_t t_index0, int32_t y_index0, int32_t x_index0,
                                       float* part_m, float* part_l,
                                       float* part_acc, int32_t nparts, float* ctx_local, void* ctx_hi,
-                                      void* ctx_lo, void* stream) {
+                                      void* ctx_lo, void* ctx_f16, void* stream) {
     HICOM_REQUIRE(ff && fe && q_hi && q_lo && part_m && part_l && part_acc && ((pe_hi && pe_lo) || !pos_a) && (pos_a || !pe_hi), HICOM_EINVAL,
                   "fused_stream: NULL pointer");
-    HICOM_REQUIRE(ctx_local || (ctx_hi && ctx_lo), HICOM_EINVAL, "fused_stream: no local output");
+    HICOM_REQUIRE(ctx_local || (ctx_hi && ctx_lo) || ctx_f16, HICOM_EINVAL, "fused_stream: no local output");
+    HICOM_REQUIRE(!ctx_hi == !ctx_lo, HICOM_EINVAL, "fused_stream: ctx_hi and ctx_lo go together");
     HICOM_REQUIRE(E == 1152, HICOM_EUNSUP, "fused_stream: E=%d (only 1152)", E);
     HICOM_REQUIRE(T > 0 && H > 0 && W > 0 && kt > 0 && ks > 0 && T % kt == 0 && H % ks == 0 && W % ks == 0, HICOM_EUNSUP,
                   "fused_stream: windows must partition the [%d,%d,%d] grid exactly", T, H, W);
@@ -680,7 +689,7 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T,
     p.l_scale = l_scale; p.l_bias = l_bias;
     p.pos_a = pos_a; p.pos_stride = pos_stride; p.t0i = t_index0; p.y0i = y_index0; p.x0i = x_index0;
     p.part_m = part_m; p.part_l = part_l; p.part_acc = part_acc; p.pe_hi = (const uint16_t*)pe_hi; p.pe_lo = (const uint16_t*)pe_lo;
-    p.ctx_local = ctx_local; p.ctx_hi = (uint16_t*)ctx_hi; p.ctx_lo = (uint16_t*)ctx_lo; p.wpw = wpw;
+    p.ctx_local = ctx_local; p.ctx_hi = (uint16_t*)ctx_hi; p.ctx_lo = (uint16_t*)ctx_lo; p.ctx_f16 = (_Float16*)ctx_f16; p.wpw = wpw;
     static bool attr_set = false;
     if (!attr_set) {
         HICOM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_ring_kernel<9>),

@@ -227,6 +227,92 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* ml, const flo
     ctx[(long)r * E + c] = a / L;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Release recipe, single query (direct mode): merge of the ring kernel's partial states FUSED with v_proj
+// (reference projector.py:182,215 after folding: o_h = W_v,h ctx_h).  One workgroup per (head h, 64-channel slab):
+//   M, L of the row; ctx_h[slab] = sum_p e^(m_p - M) acc_p[h, slab] / L        (the plain merge; pos-emb already inside acc)
+//   po[slab, h*hd + j] = sum_{c in slab} W_v[h*hd + j, c] ctx_h[c]               (partial v_proj over the slab)
+// The E/64 partial vectors po[slab, :] are summed (in slab order: deterministic, no atomics) by the consumer, the
+// out_proj GEMV that rides in the first readout GEMM's launch.  Also emits the merged state (ml, ctx) for callers
+// that want it (may be NULL).
+struct MergeVprojParams {
+    const float* part_m;
+    const float* part_l;
+    const float* part_acc;
+    int nparts, rows_pad, E, hd;
+    const uint16_t* wv;     // bf16 [E, E]
+    float* po;              // [E / 64][E]
+    float* out_ml;          // [R][2] or NULL
+    float* out_ctx;         // [R][E] normalised, or NULL
+};
+
+__global__ __launch_bounds__(256) void merge_vproj_kernel(MergeVprojParams p) {
+    __shared__ float wp[256];
+    __shared__ float red[4];
+    __shared__ __attribute__((aligned(16))) float cpart[16][64];
+    __shared__ __attribute__((aligned(16))) float cx[64];
+    const int slab = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    // raw partial rows first (independent of M): thread = (float4 column c4 of the slab, partial group pg of 16);
+    // all of a thread's <= 16 loads are in flight together
+    const int c4 = tid & 15, pg = tid >> 4;
+    const float* base = p.part_acc + (long)h * p.E + slab * 64 + 4 * c4;
+    const long pstride = (long)p.rows_pad * p.E;
+    float4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int i = pg + 16 * u;
+        v[u] = (i < p.nparts) ? *reinterpret_cast<const float4*>(base + (long)i * pstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float mx = -1.0e30f;
+    for (int i = tid; i < p.nparts; i += 256) mx = fmaxf(mx, p.part_m[(long)i * p.rows_pad + h]);
+    const float M = block_reduce_max(mx, red);
+    float ls = 0.f;
+    for (int i = tid; i < 256; i += 256) {
+        const float w = i < p.nparts ? expf(p.part_m[(long)i * p.rows_pad + h] - M) : 0.f;
+        wp[i] = w;
+        ls += i < p.nparts ? w * p.part_l[(long)i * p.rows_pad + h] : 0.f;
+    }
+    const float L = block_reduce_sum(ls, red);       // (barriers inside: wp[] is visible afterwards)
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const float w = wp[pg + 16 * u];
+        a.x = fmaf(w, v[u].x, a.x); a.y = fmaf(w, v[u].y, a.y); a.z = fmaf(w, v[u].z, a.z); a.w = fmaf(w, v[u].w, a.w);
+    }
+    *reinterpret_cast<float4*>(&cpart[pg][4 * c4]) = a;
+    __syncthreads();
+    if (tid < 64) {
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) sum += cpart[g][tid];
+        const float val = sum / L;
+        cx[tid] = val;
+        if (p.out_ctx) p.out_ctx[(long)h * p.E + slab * 64 + tid] = val;
+    }
+    if (tid == 0 && slab == 0 && p.out_ml) {
+        p.out_ml[2 * h] = M;
+        p.out_ml[2 * h + 1] = L;
+    }
+    __syncthreads();
+    // partial v_proj: thread (j = tid >> 1, half = tid & 1) dots 32 channels of weight row h*hd + j
+    const int j = tid >> 1, half = tid & 1;
+    float dot = 0.f;
+    if (j < p.hd) {
+        const uint16_t* wr = p.wv + (long)(h * p.hd + j) * p.E + slab * 64 + 32 * half;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32x4 g = *reinterpret_cast<const u32x4*>(wr + 8 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dot = fmaf(bf16lo_to_f32(g[i]), cx[32 * half + 8 * q + 2 * i], dot);
+                dot = fmaf(bf16hi_to_f32(g[i]), cx[32 * half + 8 * q + 2 * i + 1], dot);
+            }
+        }
+    }
+    dot += __shfl_xor(dot, 1, 64);
+    if (half == 0 && j < p.hd) p.po[(long)slab * p.E + h * p.hd + j] = dot;
+}
+
 }  // namespace hicom
 
 using namespace hicom;
@@ -276,4 +362,15 @@ extern "C" int hicom_global_combine_strided_fwd(const float* ml, const float* ac
     hipLaunchKernelGGL(combine_kernel, dim3((unsigned)rows, (unsigned)((E + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, ml, acc, (long)set_stride, (long)set_stride, nsets, rows, E, ctx);
     return hicom_host::check_launch("global_combine_strided");
+}
+
+extern "C" int hicom_merge_vproj_fwd(const float* part_m, const float* part_l, const float* part_acc, int32_t nparts,
+                                     int32_t rows, int32_t rows_pad, int32_t E, const void* w_v, float* po,
+                                     float* out_ml, float* out_ctx, void* stream) {
+    HICOM_REQUIRE(part_m && part_l && part_acc && w_v && po, HICOM_EINVAL, "merge_vproj: NULL pointer");
+    HICOM_REQUIRE(nparts > 0 && nparts <= 256 && rows > 0 && rows <= rows_pad && E > 0 && E % 64 == 0 && E % rows == 0 &&
+                      E / rows <= 128 && (E / rows) % 1 == 0, HICOM_EINVAL, "merge_vproj: bad shape (nparts <= 256, head dim <= 128)");
+    MergeVprojParams p{part_m, part_l, part_acc, nparts, rows_pad, E, E / rows, (const uint16_t*)w_v, po, out_ml, out_ctx};
+    HICOM_LAUNCH(merge_vproj_kernel, dim3((unsigned)(E / 64), (unsigned)rows), dim3(256), 0, (hipStream_t)stream, p);
+    return hicom_host::check_launch("merge_vproj");
 }

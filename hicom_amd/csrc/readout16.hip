@@ -1,0 +1,442 @@
+// Readout MLP GEMM on ONE fp16 plane, with a co-scheduled GEMV role:  y = act(a . w^T + b).
+//
+// Replaces nn.Linear / nn.GELU / nn.Linear of build_mlp on the window tokens (reference projector.py:307-312, :559)
+// on the hot path.  Round 1 carried the fp32 window contexts / hidden activations between kernels as TWO bf16 planes
+// (hi + lo) and issued every MFMA twice.  An fp16 plane keeps 11 significand bits -- the rounding of an activation
+// costs <= 2^-12 relative, ~5e-5 absolute on these outputs, inside the 1e-3 parity budget -- at HALF the operand
+// bytes and HALF the MFMAs; bf16 weights convert to fp16 exactly (8 significand bits; |w| < 6.1e-5 becomes an fp16
+// subnormal with <= 3e-8 absolute error), once per weight version (the caller caches the fp16 copies, the way the
+// reference caches its pos_embed buffer).  Activations are clamped to the fp16 range when they are written.
+//
+// The problem is small (1296 x 896 outputs) and is bound by what ONE CU pulls through its vector-memory path
+// (~70 GB/s from L2 by LDS-DMA, MI355X_MICROARCH.md "Indexed rows"), so the tile is chosen to minimise the bytes a CU
+// stages: 96 x 64 outputs per 256-thread workgroup = (96 + 64) x 128 B = 20 KB per BK = 64 stage (the 48 x 128 hi/lo
+// tile of round 1: 28 KB), 14 x 14 = 196 workgroups, one per CU.  Six-stage LDS-DMA ring (global_load_lds_dwordx4,
+// counted vmcnt, raw s_barrier), XOR-swizzled [rows][128 B] images, fragment reads of stage s+1 under the MFMAs of
+// stage s, product computed transposed (W fragment as the A operand) so that a lane stores 4 consecutive columns.
+//
+// Horizontal fusion: the launch may carry `n_aux` extra workgroups that run a single-row linear layer (GEMV) of the
+// global compressor's tail (out_proj / readout of the 32 global rows, projector.py:226,646) on the CUs the tiles
+// leave idle: two dependent small launches of the step disappear under the two GEMMs.
+#include <stdlib.h>
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace hicom {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+struct AuxGemv {
+    // y[n] = act(sum_k w[n,k] x[k] + b[n]) + res[n],   x[k] = sum_{s < x_parts} xs[s * x_stride + k] + xb[k]
+    const float* xs;
+    int x_parts;
+    long x_stride;
+    const uint16_t* xb;     // bf16 [K] added to x (the bias of the producing layer), or NULL
+    const uint16_t* w;      // bf16 [N, K]
+    const uint16_t* b;      // bf16 [N] or NULL
+    const uint16_t* res;    // bf16 [N] or NULL
+    int N, K, act;
+    float* y;
+};
+
+struct R16Params {
+    const _Float16* a;
+    const _Float16* w;
+    const void* b;
+    int b_f32;
+    int M, N, K, act;
+    _Float16* o16;          // fp16 plane [M][N] (hidden activations for the next GEMM), or NULL
+    void* y;                // packed rows of the final tensor (dtype y_f32 ? f32 : bf16), or NULL
+    int y_f32;
+    long ldy, row0;
+    int nl_group;
+    int vec, bvec;
+    int n_gemm;             // workgroups of the tile grid; blocks >= n_gemm run the aux role
+    AuxGemv aux;
+};
+
+constexpr int kRM = 96, kRN = 64;
+constexpr int kRImgA = kRM * 128;                   // 12 KB: 96 rows x 64 fp16
+constexpr int kRStage = kRImgA + kRN * 128;         // 20 KB
+constexpr int kRRingMax = 8;                        // ring depth is a template parameter (6 or 8 stages: 120 / 160 KB of LDS)
+constexpr int kRPW = 5;                             // DMA pieces (1 KiB = 8 rows x 128 B) per wave and stage: 12 A + 8 W
+
+__device__ __forceinline__ _Float16 to_f16_sat(float v) {
+    v = fminf(fmaxf(v, -65504.f), 65504.f);
+    return (_Float16)v;
+}
+
+// ---- aux role: one GEMV over `n_aux` workgroups; a wave handles batches of 4 columns with all loads in flight ----
+__device__ __forceinline__ void aux_gemv_role(const AuxGemv& g, int aux_idx, int n_aux, char* lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* xl = reinterpret_cast<float*>(lds);       // [K]   x
+    float* xp = xl + 1536;                            // [x_parts][K] staged partial vectors
+    // x = sum of the partial vectors (+ bias).  Phase 1: every float4 of every part is requested at once (a serial
+    // loop over the parts is x_parts dependent L2 round trips: 20 us for 18 parts) and parked in LDS; phase 2 sums
+    // each column over the parts in part order -- deterministic, no atomics.
+    const int k4n = g.K >> 2, items = g.x_parts * k4n;
+    constexpr int XR = 28;                            // x_parts * K / 4 <= 28 * 256 (host-checked)
+    float4 t[XR];
+#pragma unroll
+    for (int u = 0; u < XR; ++u) {
+        const int it = tid + 256 * u < items ? tid + 256 * u : 0;       // (clamped: the loads are unconditional)
+        const int sidx = it / k4n, k4 = it - sidx * k4n;
+        t[u] = *reinterpret_cast<const float4*>(g.xs + (long)sidx * g.x_stride + 4 * k4);
+    }
+#pragma unroll
+    for (int u = 0; u < XR; ++u) {
+        const int it = tid + 256 * u;
+        if (it < items) *reinterpret_cast<float4*>(xp + 4 * it) = t[u];     // [part][K] order: it = part * k4n + k4
+    }
+    __syncthreads();
+    for (int k = tid; k < g.K; k += 256) {
+        float v = g.xb ? bf16_to_f32(g.xb[k]) : 0.f;
+        for (int sidx = 0; sidx < g.x_parts; ++sidx) v += xp[sidx * g.K + k];
+        xl[k] = v;
+    }
+    __syncthreads();
+    constexpr int CH = 3;                             // K <= 1536: up to 3 chunks of 8 elements per lane
+    float xr[CH][8];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int k = (lane + 64 * c) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xr[c][i] = (k < g.K) ? xl[k + i] : 0.f;
+    }
+    const int nwaves = n_aux * 4, w_id = aux_idx * 4 + wave;
+    constexpr int CB = 4;
+    for (int n0 = w_id * CB; n0 < g.N; n0 += nwaves * CB) {
+        u32x4 wv[CB][CH];
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            const int n = n0 + j < g.N ? n0 + j : g.N - 1;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int k = (lane + 64 * c) * 8;
+                wv[j][c] = (k < g.K) ? *reinterpret_cast<const u32x4*>(g.w + (long)n * g.K + k) : u32x4{0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc = fmaf(bf16lo_to_f32(wv[j][c][i]), xr[c][2 * i], acc);
+                    acc = fmaf(bf16hi_to_f32(wv[j][c][i]), xr[c][2 * i + 1], acc);
+                }
+            acc = wave_sum(acc);
+            const int n = n0 + j;
+            if (lane == 0 && n < g.N) {
+                float v = acc + (g.b ? bf16_to_f32(g.b[n]) : 0.f);
+                if (g.act == HICOM_ACT_GELU) v = gelu_erf(v);
+                if (g.res) v += bf16_to_f32(g.res[n]);
+                g.y[n] = v;
+            }
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void r16_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int kRRing>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void readout16_gemm_kernel(R16Params p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // [kRRing][kRStage]
+    if ((int)blockIdx.x >= p.n_gemm) {
+        aux_gemv_role(p.aux, (int)blockIdx.x - p.n_gemm, (int)gridDim.x - p.n_gemm, lds);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int nbx = (p.N + kRN - 1) / kRN, nby = (p.M + kRM - 1) / kRM;
+    // XCD-balanced order (speed only): workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md "Workgroup dispatch"); every
+    // XCD gets a contiguous run of ~tiles/8 tiles in row-major tile order, i.e. ~2 row tiles whose A rows stay in ITS L2,
+    // and -- the point -- the same number of busy CUs, so that the aux workgroups (dealt round-robin too) find a free CU
+    // on their XCD at once instead of queueing behind a 10-us tile (measured: +6 us per launch with whole row tiles per XCD)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tiles = nbx * nby;
+    const int t_lo = (tiles * xcd) >> 3, t_hi = (tiles * (xcd + 1)) >> 3;
+    if (slot >= t_hi - t_lo) return;
+    const int tile = t_lo + slot;
+    const int by = tile / nbx, bx = tile - by * nbx;
+    const int m0 = by * kRM, n0 = bx * kRN;
+    const int ns = p.K >> 6;
+
+    // DMA assignment: a stage is 20 one-KiB pieces (8 rows x 128 B): 12 of A, 8 of W; wave w issues pieces w, w+4, ...
+    const int prow = lane >> 3, cpos = lane & 7;
+    const _Float16* src[kRPW];
+    int dst_off[kRPW];
+#pragma unroll
+    for (int i = 0; i < kRPW; ++i) {
+        const int pi = wave + 4 * i;
+        if (pi < 12) {
+            const int row = 8 * pi + prow;
+            int m = m0 + row;
+            m = m < p.M ? m : p.M - 1;
+            src[i] = p.a + (long)m * p.K + 8 * (cpos ^ ((row >> 1) & 7));
+        } else {
+            const int row = 8 * (pi - 12) + prow;
+            int n = n0 + row;
+            n = n < p.N ? n : p.N - 1;
+            src[i] = p.w + (long)n * p.K + 8 * (cpos ^ ((row >> 1) & 7));
+        }
+        dst_off[i] = pi * 1024;
+    }
+    auto issue = [&](int s, int ring_slot) {
+        char* base = lds + ring_slot * kRStage;
+#pragma unroll
+        for (int i = 0; i < kRPW; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + 64 * s),
+                                             (__attribute__((address_space(3))) void*)(base + dst_off[i]), 16, 0, 0);
+    };
+    auto wait_stages = [&](int k) {      // at most k of this wave's stages still in flight
+        if (k >= 6) r16_wait_vm<6 * kRPW>();
+        else if (k == 5) r16_wait_vm<5 * kRPW>();
+        else if (k == 4) r16_wait_vm<4 * kRPW>();
+        else if (k == 3) r16_wait_vm<3 * kRPW>();
+        else if (k == 2) r16_wait_vm<2 * kRPW>();
+        else if (k == 1) r16_wait_vm<kRPW>();
+        else r16_wait_vm<0>();
+    };
+
+    // fragments of one BK = 64 stage: two K = 32 steps x (2 W blocks of this wave's 32 columns, 3 A blocks of its 48 rows)
+    struct Frags {
+        half8 w[2][2], a[2][3];
+    };
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(lds);
+    const int swz = (r16 >> 1) & 7;
+    const int f0off = r16 * 128 + 16 * (kg ^ swz), f1off = r16 * 128 + 16 * ((4 + kg) ^ swz);
+    const int a_base = 48 * wr * 128, w_base = kRImgA + 32 * wc * 128;
+#define HICOM_LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    auto read = [&](int ring_slot, Frags& f) {
+        const unsigned st = lds0 + ring_slot * kRStage;
+        const unsigned a0 = st + a_base + f0off, a1 = st + a_base + f1off, w0 = st + w_base + f0off, w1 = st + w_base + f1off;
+        HICOM_LDS_RD(f.w[0][0], w0, 0);
+        HICOM_LDS_RD(f.w[0][1], w0, 2048);
+        HICOM_LDS_RD(f.a[0][0], a0, 0);
+        HICOM_LDS_RD(f.a[0][1], a0, 2048);
+        HICOM_LDS_RD(f.a[0][2], a0, 4096);
+        HICOM_LDS_RD(f.w[1][0], w1, 0);
+        HICOM_LDS_RD(f.w[1][1], w1, 2048);
+        HICOM_LDS_RD(f.a[1][0], a1, 0);
+        HICOM_LDS_RD(f.a[1][1], a1, 2048);
+        HICOM_LDS_RD(f.a[1][2], a1, 4096);
+    };
+#undef HICOM_LDS_RD
+    auto land = [&](Frags& f) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(f.w[0][0]), "+v"(f.w[0][1]), "+v"(f.w[1][0]), "+v"(f.w[1][1]), "+v"(f.a[0][0]), "+v"(f.a[0][1]),
+                       "+v"(f.a[0][2]), "+v"(f.a[1][0]), "+v"(f.a[1][1]), "+v"(f.a[1][2])::"memory");
+    };
+    f32x4 acc[2][3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](const Frags& f) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[ks][j], f.a[ks][i], acc[j][i], 0, 0, 0);
+    };
+
+    // prologue: stages 0 .. kRRing-2 in flight, stage 0 landed, its fragments on the way
+    const int npro = ns < kRRing - 1 ? ns : kRRing - 1;
+    for (int s = 0; s < npro; ++s) issue(s, s);
+    // the bias of this wave's columns, fetched now (one vector load per column block)
+    uint2 braw[2] = {make_uint2(0, 0), make_uint2(0, 0)};
+    float4 brawf[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    bool bpre[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nb = n0 + 32 * wc + 16 * j + 4 * kg;
+        bpre[j] = p.b && p.bvec && nb + 3 < p.N;
+        if (bpre[j]) {
+            if (p.b_f32) brawf[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.b) + nb);
+            else braw[j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.b) + nb);
+        }
+    }
+    if (npro == kRRing - 1) r16_wait_vm<(kRRing - 2) * kRPW>();
+    else wait_stages(npro - 1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    Frags f0, f1;
+    read(0, f0);
+    land(f0);
+    int slot_next = 1;                 // ring slot of stage s+1
+    int slot_issue = kRRing - 1;       // ring slot of stage s+kRRing-1 (= the slot of stage s-1)
+    auto step = [&](auto steady, int s, const Frags& cur, Frags& nxt) {
+        if constexpr (decltype(steady)::value) {
+            r16_wait_vm<(kRRing - 3) * kRPW>();         // stage s+1 landed (this wave's pieces); s+2 .. s+kRRing-2 may fly
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue(s + kRRing - 1, slot_issue);
+        } else {
+            const int ahead = (ns - 1 < s + kRRing - 2 ? ns - 1 : s + kRRing - 2) - (s + 1);
+            wait_stages(ahead);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (s + kRRing - 1 < ns) issue(s + kRRing - 1, slot_issue);
+        }
+        read(slot_next, nxt);
+        __builtin_amdgcn_sched_barrier(0);      // the reads of stage s+1 fly under the MFMAs of stage s
+        compute(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        land(nxt);
+        slot_next = slot_next + 1 == kRRing ? 0 : slot_next + 1;
+        slot_issue = slot_issue + 1 == kRRing ? 0 : slot_issue + 1;
+    };
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
+    int s = 0;
+    for (; s + kRRing < ns; s += 2) {
+        step(Yes{}, s, f0, f1);
+        step(Yes{}, s + 1, f1, f0);
+    }
+    for (; s + 2 < ns; s += 2) {
+        step(No{}, s, f0, f1);
+        step(No{}, s + 1, f1, f0);
+    }
+    if (ns - s == 2) {
+        step(No{}, s, f0, f1);
+        compute(f1);
+    } else {
+        compute(f0);
+    }
+    // MFMA results -> VALU reads (CDNA4 ISA §4.1 "XDL write VGPR -> VALU read": do not rely on hipcc's padding, see fused_ring.hip)
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+
+    // epilogue.  Transposed product: lane holds columns n .. n+3 (4 * kg + q) of row m = r16 of each block.
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + 32 * wc + 16 * j + 4 * kg;
+        if (n >= p.N) continue;
+        float bias[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bpre[j]) {
+            if (p.b_f32) {
+                bias[0] = brawf[j].x; bias[1] = brawf[j].y; bias[2] = brawf[j].z; bias[3] = brawf[j].w;
+            } else {
+                bias[0] = bf16lo_to_f32(braw[j].x); bias[1] = bf16hi_to_f32(braw[j].x);
+                bias[2] = bf16lo_to_f32(braw[j].y); bias[3] = bf16hi_to_f32(braw[j].y);
+            }
+        } else if (p.b) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nn = n + q < p.N ? n + q : p.N - 1;
+                bias[q] = p.b_f32 ? reinterpret_cast<const float*>(p.b)[nn] : bf16_to_f32(reinterpret_cast<const uint16_t*>(p.b)[nn]);
+            }
+        }
+        const bool vec = p.vec && n + 3 < p.N;
+#pragma unroll
+        for (int im = 0; im < 3; ++im) {
+            const int m = m0 + 48 * wr + 16 * im + r16;
+            if (m >= p.M) continue;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[q] = acc[j][im][q] + bias[q];
+                if (p.act == HICOM_ACT_GELU) v[q] = gelu_erf(v[q]);
+            }
+            if (p.o16) {
+                _Float16* oh = p.o16 + (long)m * p.N + n;
+                if (vec) {
+                    *reinterpret_cast<half4*>(oh) = half4{to_f16_sat(v[0]), to_f16_sat(v[1]), to_f16_sat(v[2]), to_f16_sat(v[3])};
+                } else {
+                    for (int q = 0; q < 4 && n + q < p.N; ++q) oh[q] = to_f16_sat(v[q]);
+                }
+            }
+            if (p.y) {
+                const long orow = p.row0 + m + (p.nl_group > 0 ? m / p.nl_group : 0);
+                if (p.y_f32) {
+                    float* yo = reinterpret_cast<float*>(p.y) + orow * p.ldy + n;
+                    if (vec) *reinterpret_cast<float4*>(yo) = make_float4(v[0], v[1], v[2], v[3]);
+                    else
+                        for (int q = 0; q < 4 && n + q < p.N; ++q) yo[q] = v[q];
+                } else {
+                    uint16_t* yo = reinterpret_cast<uint16_t*>(p.y) + orow * p.ldy + n;
+                    if (vec) {
+                        const uint32_t u0 = f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                        const uint32_t u1 = f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                        *reinterpret_cast<uint2*>(yo) = make_uint2(u0, u1);
+                    } else {
+                        for (int q = 0; q < 4 && n + q < p.N; ++q) yo[q] = f32_to_bf16(v[q]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// bf16 -> fp16 (weights, once per weight version) and f32 -> fp16 (saturating) conversions
+__global__ __launch_bounds__(256) void to_f16_kernel(const void* src, int src_f32, _Float16* dst, long n) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (i + q < n) {
+            const float v = src_f32 ? reinterpret_cast<const float*>(src)[i + q] : bf16_to_f32(reinterpret_cast<const uint16_t*>(src)[i + q]);
+            dst[i + q] = to_f16_sat(v);
+        }
+}
+
+}  // namespace hicom
+
+using namespace hicom;
+
+extern "C" int hicom_to_f16_fwd(const void* src, int32_t src_dt, void* dst, int64_t n, void* stream) {
+    HICOM_REQUIRE(src && dst && n > 0, HICOM_EINVAL, "to_f16: bad arguments");
+    hipLaunchKernelGGL(to_f16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, src,
+                       src_dt == HICOM_DT_F32, (_Float16*)dst, (long)n);
+    return hicom_host::check_launch("to_f16");
+}
+
+extern "C" int hicom_readout16_gemm_fwd(const void* a, const void* w, const void* b, int32_t b_dt,
+                                        int32_t M, int32_t N, int32_t K, int32_t act, void* out_f16,
+                                        void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group,
+                                        const hicom_aux_gemv* aux, void* stream) {
+    HICOM_REQUIRE(a && w, HICOM_EINVAL, "readout16_gemm: NULL pointer");
+    HICOM_REQUIRE(out_f16 || y, HICOM_EINVAL, "readout16_gemm: no output");
+    HICOM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, HICOM_EINVAL, "readout16_gemm: bad shape M=%d N=%d K=%d (K %% 64)", M, N, K);
+    HICOM_REQUIRE(!y || (ldy >= N && row0 >= 0 && nl_group >= 0), HICOM_EINVAL, "readout16_gemm: bad output layout");
+    HICOM_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)w % 16 == 0) && M < (1 << 30), HICOM_EINVAL, "readout16_gemm: alignment");
+    const bool vec = N % 4 == 0 && (!out_f16 || ((uintptr_t)out_f16 % 8 == 0)) && (!y || (ldy % 4 == 0 && (uintptr_t)y % 16 == 0));
+    R16Params p;
+    p.a = (const _Float16*)a; p.w = (const _Float16*)w; p.b = b; p.b_f32 = b_dt == HICOM_DT_F32;
+    p.M = M; p.N = N; p.K = K; p.act = act; p.o16 = (_Float16*)out_f16; p.y = y; p.y_f32 = y_dt == HICOM_DT_F32;
+    p.ldy = (long)ldy; p.row0 = (long)row0; p.nl_group = nl_group; p.vec = vec ? 1 : 0; p.bvec = (b && (uintptr_t)b % 16 == 0) ? 1 : 0;
+    const int nbx = (N + kRN - 1) / kRN, nby = (M + kRM - 1) / kRM;
+    p.n_gemm = 8 * ((nbx * nby + 7) / 8);
+    int n_aux = 0;
+    p.aux = AuxGemv{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr};
+    if (aux && aux->N > 0) {
+        HICOM_REQUIRE(aux->xs && aux->w && aux->y && aux->x_parts > 0 && aux->K > 0 && aux->K % 8 == 0 && aux->K <= 1536 && aux->x_stride % 4 == 0 && ((uintptr_t)aux->xs % 16 == 0) &&
+                          (long)aux->x_parts * aux->K <= 28 * 1024 && (1536 + (long)aux->x_parts * aux->K) * 4 <= 6 * kRStage, HICOM_EINVAL, "readout16_gemm: aux GEMV arguments");
+        p.aux = AuxGemv{aux->xs, aux->x_parts, (long)aux->x_stride, (const uint16_t*)aux->xb, (const uint16_t*)aux->w,
+                        (const uint16_t*)aux->b, (const uint16_t*)aux->res, aux->N, aux->K, aux->act, aux->y};
+        // the CUs the tile grid leaves idle (one workgroup per CU: the ring takes 120 KB of LDS), at least 16
+        n_aux = (256 - p.n_gemm) / 8 * 8;                // the same number on every XCD
+        if (n_aux < 16) n_aux = 16;
+        if (n_aux > 72) n_aux = 72;
+    }
+    static int ring = 0;
+    if (ring == 0) {
+        const char* e = getenv("HICOM_R16_RING");            // dev switch for A/B runs; default = 8 stages (160 KB)
+        ring = (e && e[0] == '6') ? 6 : 8;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(readout16_gemm_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * kRStage);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(readout16_gemm_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kRStage);
+    }
+    // aux workgroups first in dispatch order would delay tiles on their CUs; they go last and land on the free CUs
+    if (ring == 6) HICOM_LAUNCH(readout16_gemm_kernel<6>, dim3((unsigned)(p.n_gemm + n_aux)), dim3(256), 6 * kRStage, (hipStream_t)stream, p);
+    else HICOM_LAUNCH(readout16_gemm_kernel<8>, dim3((unsigned)(p.n_gemm + n_aux)), dim3(256), 8 * kRStage, (hipStream_t)stream, p);
+    return hicom_host::check_launch("readout16_gemm");
+}

@@ -109,6 +109,9 @@ def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, 
             a.lq = None                                               # pooled per-window query, made natively
         a.lw0, a.lb0 = _w(lc.readout[0])
         a.lw2, a.lb2 = _w(lc.readout[2])
+        w0_16, w2_16 = lc.readout_f16()                               # fp16 copies, cached per weight version
+        a.lw0_f16, a.lw2_f16 = w0_16.data_ptr(), w2_16.data_ptr()
+        keep += [w0_16, w2_16]
     if gc is not None:
         gc._check_native(proj.global_logit)
         q_in, n_rows = gc.injected_queries(guide_embed)

@@ -15,7 +15,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 # HICOM_NATIVE_LIB: dev override (instrumented builds from tools/); the product loads the in-tree library
 LIB_PATH = os.environ.get("HICOM_NATIVE_LIB") or os.path.join(HERE, "libhicom_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 DT_BF16, DT_F32 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
@@ -28,7 +28,7 @@ EXPORTS = (
     "hicom_global_combine_strided_fwd", "hicom_compressor_workspace_bytes", "hicom_compressor_zero_prefix_bytes", "hicom_compressor_is_fused",
     "hicom_compressor_fwd", "hicom_linear_to_rows_fwd", "hicom_fused_stream_fwd", "hicom_fused_stream_nparts",
     "hicom_planes_gemm_fwd", "hicom_row_ln_fwd", "hicom_small_mha_fwd", "hicom_place_blocks_fwd",
-    "hicom_global_stream_bwd",
+    "hicom_global_stream_bwd", "hicom_readout16_gemm_fwd", "hicom_to_f16_fwd", "hicom_merge_vproj_fwd",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -43,6 +43,12 @@ class Axis(C.Structure):
     _fields_ = [("n", C.c_int32), ("k", C.c_int32), ("nwin", C.c_int32), ("nfull", C.c_int32)]
 
 
+class AuxGemv(C.Structure):
+    """hicom_aux_gemv (include/hicom_hip.h): a single-row linear layer that rides in a readout GEMM's launch."""
+    _fields_ = [("xs", C.c_void_p), ("x_parts", C.c_int32), ("x_stride", C.c_int64), ("xb", C.c_void_p), ("w", C.c_void_p),
+                ("b", C.c_void_p), ("res", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32), ("act", C.c_int32), ("y", C.c_void_p)]
+
+
 class CompressorArgs(C.Structure):
     """hicom_compressor_args (include/hicom_hip.h) -- field order and types must match the header."""
     _fields_ = [
@@ -53,6 +59,7 @@ class CompressorArgs(C.Structure):
         ("lq", C.c_void_p), ("lq_dt", C.c_int32), ("l2norm", C.c_int32), ("lq_stride", C.c_int64),
         ("l_scale", C.c_float), ("l_bias", C.c_float),
         ("lw0", C.c_void_p), ("lb0", C.c_void_p), ("lw2", C.c_void_p), ("lb2", C.c_void_p),
+        ("lw0_f16", C.c_void_p), ("lw2_f16", C.c_void_p),
         ("gq", C.c_void_p), ("nq", C.c_int32), ("nh", C.c_int32), ("n_global_rows", C.c_int32), ("P", C.c_int32),
         ("wq", C.c_void_p), ("bq", C.c_void_p), ("wk", C.c_void_p), ("wv", C.c_void_p), ("bv", C.c_void_p),
         ("wo", C.c_void_p), ("bo", C.c_void_p),
@@ -107,7 +114,10 @@ def lib() -> C.CDLL:
                                          vp, vp, vp, i32, vp]
     L.hicom_linear_to_rows_fwd.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i64, i64, i32, vp]
     L.hicom_fused_stream_fwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, f32, vp, i32, vp, vp, i32, i32, i32,
-                                         vp, vp, vp, i32, vp, vp, vp, vp]
+                                         vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.hicom_readout16_gemm_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i64, i64, i32, C.POINTER(AuxGemv), vp]
+    L.hicom_to_f16_fwd.argtypes = [vp, i32, vp, i64, vp]
+    L.hicom_merge_vproj_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.hicom_fused_stream_nparts.argtypes = [i32]
     L.hicom_planes_gemm_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i64, i64, i32, vp]
     L.hicom_row_ln_fwd.argtypes = [vp, i32, i64, vp, i64, vp, i64, vp, vp, i32, vp, i32, i64, vp, i32, f32, vp, i32, i64,
@@ -153,6 +163,8 @@ def _dt(t: torch.Tensor) -> int:
         return DT_BF16
     if t.dtype == torch.float32:
         return DT_F32
+    if t.dtype == torch.float16:
+        return 2                            # (only ever passed where the C side ignores the dtype code)
     raise HicomNativeError(f"unsupported dtype {t.dtype} (bf16 or f32 only)")
 
 
@@ -302,7 +314,7 @@ def fused_stream_nparts(n_windows: int) -> int:
 
 
 def fused_stream(ff, fe, kt, ks, qhi, qlo, rows, l_scale, l_bias, pos_a, pe_hi, pe_lo, t0i, y0i, x0i, part_m, part_l,
-                 part_acc, ctx_local, ctx_hi=None, ctx_lo=None):
+                 part_acc, ctx_local, ctx_hi=None, ctx_lo=None, ctx_f16=None):
     """pos_a f32 [16, P] + pe_hi / pe_lo bf16 [P, E] (all three or none): the kernel folds the value-side
     pos-emb into part_acc."""
     T, H, W, E = ff.shape
@@ -310,7 +322,7 @@ def fused_stream(ff, fe, kt, ks, qhi, qlo, rows, l_scale, l_bias, pos_a, pe_hi, 
                                         l_bias, _ptr(pos_a), pos_a.shape[1] if pos_a is not None else 0,
                                         _ptr(pe_hi), _ptr(pe_lo), t0i, y0i, x0i,
                                         _ptr(part_m), _ptr(part_l), _ptr(part_acc), part_m.shape[0], _ptr(ctx_local),
-                                        _ptr(ctx_hi), _ptr(ctx_lo), _stream()),
+                                        _ptr(ctx_hi), _ptr(ctx_lo), _ptr(ctx_f16), _stream()),
            "hicom_fused_stream_fwd")
 
 
@@ -321,6 +333,41 @@ def planes_gemm(a_hi, a_lo, w, b, act=ACT_NONE, out_hi=None, out_lo=None, y=None
                                        act, _ptr(out_hi), _ptr(out_lo), _ptr(y), _dt(y) if y is not None else 0,
                                        y.shape[-1] if y is not None else 0, row0, nl_group, _stream()),
            "hicom_planes_gemm_fwd")
+
+
+def to_f16(src, dst=None):
+    """Saturating cast of a bf16 / f32 tensor to fp16 (weights of the fp16 readout path; activations in tests)."""
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.float16, device=src.device)
+    _check(lib().hicom_to_f16_fwd(_ptr(src), _dt(src), _ptr(dst), src.numel(), _stream()), "hicom_to_f16_fwd")
+    return dst
+
+
+def readout16_gemm(a16, w16, b, act=ACT_NONE, out_f16=None, y=None, row0=0, nl_group=0, aux=None):
+    """aux: dict(xs f32 [parts, K], xb bf16 [K] | None, w bf16 [N, K], b bf16 [N] | None, res bf16 [N] | None, act, y f32 [N])"""
+    N, K = w16.shape
+    M = a16.shape[0]
+    ag = None
+    if aux is not None:
+        ag = AuxGemv()
+        xs = aux["xs"].reshape(-1, aux["w"].shape[1])
+        ag.xs, ag.x_parts, ag.x_stride = xs.data_ptr(), xs.shape[0], xs.shape[1]
+        ag.xb = None if aux.get("xb") is None else aux["xb"].data_ptr()
+        ag.w, ag.N, ag.K = aux["w"].data_ptr(), aux["w"].shape[0], aux["w"].shape[1]
+        ag.b = None if aux.get("b") is None else aux["b"].data_ptr()
+        ag.res = None if aux.get("res") is None else aux["res"].data_ptr()
+        ag.act, ag.y = aux.get("act", ACT_NONE), aux["y"].data_ptr()
+    _check(lib().hicom_readout16_gemm_fwd(_ptr(a16), _ptr(w16), _ptr(b), _dt(b) if b is not None else 0, M, N, K, act,
+                                          _ptr(out_f16), _ptr(y), _dt(y) if y is not None else 0, y.shape[-1] if y is not None else 0,
+                                          row0, nl_group, C.byref(ag) if ag is not None else None, _stream()),
+           "hicom_readout16_gemm_fwd")
+
+
+def merge_vproj(part_m, part_l, part_acc, rows, w_v, po, out_ml=None, out_ctx=None):
+    nparts, rows_pad = part_m.shape
+    E = part_acc.shape[-1]
+    _check(lib().hicom_merge_vproj_fwd(_ptr(part_m), _ptr(part_l), _ptr(part_acc), nparts, rows, rows_pad, E, _ptr(w_v), _ptr(po),
+                                       _ptr(out_ml), _ptr(out_ctx), _stream()), "hicom_merge_vproj_fwd")
 
 
 def row_ln(x, norm, out, mul=None, add=None, src=None, alpha=None, eps=1e-6):

@@ -317,6 +317,18 @@ class LocalCompressor(nn.Module):
         nv.local_attn(key, value, axes, q.reshape(nw, D), D, scale, bias, l2norm, ctx)
         return ctx, grid
 
+    def readout_f16(self):
+        """fp16 copies of the two readout weights for hicom_readout16_gemm_fwd (bf16 -> fp16 is exact down to 6e-5), rebuilt
+        when a weight is replaced or modified in place -- a weight-only cache like the reference's pos_embed buffer."""
+        w0, w2 = self.readout[0].weight, self.readout[2].weight
+        _require_bf16_cuda("readout weight", w0)
+        stamp = (w0.data_ptr(), w0._version, w2.data_ptr(), w2._version)
+        hit = self.__dict__.get("_f16_cache")
+        if hit is None or hit[0] != stamp:
+            hit = (stamp, nv.to_f16(w0.detach()), nv.to_f16(w2.detach()))
+            self.__dict__["_f16_cache"] = hit
+        return hit[1], hit[2]
+
     def readout_into(self, ctx, out, row0: int, nl_group: int):
         """out[row0 + packed(m), :] = readout(ctx[m, :]) -- both Linear layers on matrix cores."""
         w0, b0 = _linear_params(self.readout[0])

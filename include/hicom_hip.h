@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HICOM_ABI_VERSION 2
+#define HICOM_ABI_VERSION 3
 
 #define HICOM_OK         0
 #define HICOM_EINVAL    -1   /* bad argument (shape, alignment, NULL)        */
@@ -180,14 +180,15 @@ int hicom_global_stream_nparts(int64_t N, int32_t rows_pad);
  *   part_*      : as hicom_global_stream_fwd with rows_pad = 16; nparts from
  *                 hicom_fused_stream_nparts(number of windows)
  *   ctx_local   : f32 [Nw, E], window order (t1,h1,w1), and/or ctx_hi + ctx_lo: the same contexts as
- *                 bf16 planes (hi + lo) for hicom_planes_gemm_fwd; unused outputs NULL */
+ *                 bf16 planes (hi + lo) for hicom_planes_gemm_fwd, and/or ctx_f16: one fp16 plane (saturating) for
+ *                 hicom_readout16_gemm_fwd; unused outputs NULL */
 int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T, int32_t H, int32_t W, int32_t E,
                            int32_t kt, int32_t ks, const void* q_hi, const void* q_lo, int32_t rows,
                            float l_scale, float l_bias, const float* pos_a, int32_t pos_stride,
                            const void* pe_hi, const void* pe_lo,
                            int32_t t_index0, int32_t y_index0, int32_t x_index0,
                            float* part_m, float* part_l, float* part_acc, int32_t nparts, float* ctx_local,
-                           void* ctx_hi, void* ctx_lo, void* stream);
+                           void* ctx_hi, void* ctx_lo, void* ctx_f16, void* stream);
 int hicom_fused_stream_nparts(int32_t n_windows);
 
 /* ---- merge the partials (+ the value-side positional term) --------------------------------
@@ -228,6 +229,41 @@ int hicom_readout_gemm_fwd(const float* x, const void* w, const void* b, int32_t
 int hicom_planes_gemm_fwd(const void* a_hi, const void* a_lo, const void* w, const void* b, int32_t b_dt,
                           int32_t M, int32_t N, int32_t K, int32_t act, void* out_hi, void* out_lo,
                           void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group, void* stream);
+
+/* ---- hot-path readout GEMM: ONE fp16 plane, with an optional co-scheduled GEMV ---------------------------------
+ * y[out_row(m), :] / out_f16[m, :] = act(a[m,:] . w^T + b): a fp16 [M,K] (window contexts / hidden activations written
+ * by the producing kernel), w fp16 [N,K] (hicom_to_f16_fwd of the bf16 nn.Linear weight, cached per weight version by the
+ * caller), b bf16|f32 [N].  fp16 keeps 11 significand bits of the activation (<= 2^-12 relative, against the 1e-3
+ * budget) at half the operand bytes and MFMAs of the hi/lo bf16 planes.  K % 64 == 0.
+ * aux (may be NULL): a single-row linear layer executed by extra workgroups of the SAME launch on the CUs the tile grid
+ * leaves idle -- the global compressor's out_proj / readout layers ride under the two local readout GEMMs:
+ *   y[n] = act(sum_k w[n,k] x[k] + b[n]) + res[n],  x[k] = sum_{s < x_parts} xs[s * x_stride + k] + xb[k]
+ * (w, b, xb, res bf16; xs, y f32; K <= 1536, K % 8 == 0). */
+typedef struct hicom_aux_gemv {
+    const float* xs;
+    int32_t x_parts;
+    int64_t x_stride;
+    const void* xb;
+    const void* w;
+    const void* b;
+    const void* res;
+    int32_t N, K, act;
+    float* y;
+} hicom_aux_gemv;
+int hicom_readout16_gemm_fwd(const void* a, const void* w, const void* b, int32_t b_dt,
+                             int32_t M, int32_t N, int32_t K, int32_t act, void* out_f16,
+                             void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group,
+                             const hicom_aux_gemv* aux, void* stream);
+/* dst fp16 [n] = saturating cast of src (bf16 or f32) */
+int hicom_to_f16_fwd(const void* src, int32_t src_dt, void* dst, int64_t n, void* stream);
+
+/* Release recipe, one query row per head: merge of the ring kernel's partial states fused with v_proj
+ * (projector.py:182,215 after folding).  po f32 [E/64][E]: partial v_proj outputs per 64-channel slab of the context,
+ * summed in slab order by the consumer (hicom_readout16_gemm_fwd's aux GEMV with x_parts = E/64).  out_ml [rows][2] and
+ * out_ctx [rows][E] (normalised contexts) may be NULL. */
+int hicom_merge_vproj_fwd(const float* part_m, const float* part_l, const float* part_acc, int32_t nparts,
+                          int32_t rows, int32_t rows_pad, int32_t E, const void* w_v, float* po,
+                          float* out_ml, float* out_ctx, void* stream);
 
 /* Row copy / broadcast with dtype conversion into the packed output:
  *   dst[row0 + i*row_step + (nl_group ? i / nl_group : 0), :] = src[(i % src_rows), :],  i in [0,count)
@@ -306,6 +342,9 @@ typedef struct hicom_compressor_args {
     int64_t lq_stride;
     float l_scale, l_bias;
     const void *lw0, *lb0, *lw2, *lb2;          /* readout Linear(E,hidden), Linear(hidden,hidden): bf16 */
+    const void *lw0_f16, *lw2_f16;              /* fp16 copies of lw0 / lw2 (hicom_to_f16_fwd, cached by the caller per weight
+                                                   version): the release recipe then runs its readout on one fp16 plane
+                                                   (hicom_readout16_gemm_fwd); NULL = bf16 hi/lo planes (hicom_planes_gemm_fwd) */
     /* global compressor */
     const void* gq;            /* bf16 [nq, E] injected queries (1 row in "direct" mode) */
     int32_t nq, nh, n_global_rows, P;

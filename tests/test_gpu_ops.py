@@ -443,3 +443,75 @@ def test_local_attn_fp32_streams():
     ctx = f32((4, D))
     nv.local_attn(torch.from_numpy(key).cuda(), torch.from_numpy(val).cuda(), axes, bf(x["g"]), 0, 1 / math.sqrt(D), 0.0, 0, ctx)
     assert maxabs(ctx, want.reshape(4, D)) <= 2e-5
+
+
+# ---- round 2: fp16 readout GEMM (+ co-scheduled GEMV), fused merge + v_proj -------------------------------------------
+@pytest.mark.parametrize("M,N,K,act", [(8, 64, 1152, 1), (81, 896, 1152, 1), (130, 64, 64, 0), (1296, 896, 896, 0), (1296, 896, 1152, 1),
+                                       (648, 3584, 1152, 1), (97, 200, 128, 0)])
+def test_readout16_gemm_matches_torch(M, N, K, act):
+    """fp16-plane GEMM against fp64 torch on the SAME fp16-rounded operands (the kernel's arithmetic: exact products,
+    fp32 accumulation), both output forms (fp16 plane, packed rows with a newline gap)."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = (torch.randn(M, K, generator=g) * 0.7).cuda()
+    w = bf(torch.randn(N, K, generator=g) * 0.02)                               # bf16, on the GPU
+    b = bf(torch.randn(N, generator=g) * 0.02)
+    a16 = nv.to_f16(x)
+    w16 = nv.to_f16(w)
+    # bf16 -> fp16 is exact down to |w| = 2^-17 (fp16 subnormals carry multiples of 2^-24); below: <= 2^-25 absolute
+    big = w.float().abs() >= 2.0 ** -17
+    assert torch.equal(w16.float()[big], w.float()[big]) and float((w16.float() - w.float()).abs().max()) <= 2.0 ** -25
+    ref = a16.double() @ w16.double().t() + b.double()
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    o16 = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    y = torch.full((M + M // 9 + 3, N), float("nan"), device="cuda")
+    nv.readout16_gemm(a16, w16, b, act=act, out_f16=o16, y=y, row0=2, nl_group=9)
+    torch.cuda.synchronize()
+    rows = (2 + torch.arange(M) + torch.arange(M) // 9).cuda()
+    assert maxabs(y[rows], ref) <= 3e-6 * max(1.0, float(ref.abs().max()))
+    assert maxabs(o16, ref) <= 2 ** -11 * float(ref.abs().max()) + 1e-6
+    untouched = torch.ones(y.shape[0], dtype=torch.bool, device="cuda")
+    untouched[rows] = False
+    assert bool(torch.isnan(y[untouched]).all())
+
+
+def test_readout16_aux_gemv_and_merge_vproj():
+    """The GEMV that rides in the GEMM launch (x summed from partial vectors + bias, bf16 weights, residual, GELU) and the
+    fused merge + v_proj kernel against the separate merge / per-head linear chain they replace."""
+    g = torch.Generator().manual_seed(5)
+    E, nh, nparts = 1152, 9, 216
+    pm = torch.randn(nparts, 16, generator=g).cuda()
+    pl = (torch.rand(nparts, 16, generator=g) + 0.5).cuda()
+    pacc = torch.randn(nparts, 16, E, generator=g).cuda()
+    wv = bf(torch.randn(E, E, generator=g) * 0.02)
+    bv = bf(torch.randn(E, generator=g) * 0.02)
+    po = torch.empty(E // 64, E, device="cuda")
+    ml, ctx = torch.empty(nh, 2, device="cuda"), torch.empty(nh, E, device="cuda")
+    nv.merge_vproj(pm, pl, pacc, nh, wv, po, ml, ctx)
+    # reference chain: merge (normalised) then the per-head linear
+    ml2, ctx2 = torch.empty(nh, 2, device="cuda"), torch.empty(nh, E, device="cuda")
+    nv.global_merge(pm, pl, pacc, nh, None, 1, 1, 1, None, 0, 0, 0, None, ml2, ctx2, normalize=True)
+    o2 = torch.empty(1, E, device="cuda")
+    nv.linear(ctx2, wv, None, o2, head_rows=nh, head_dim=E // nh)
+    torch.cuda.synchronize()
+    assert maxabs(ctx, ctx2) <= 1e-5 and maxabs(ml, ml2) <= 1e-5
+    assert maxabs(po.sum(0), o2[0]) <= 2e-5
+    # aux GEMV under a GEMM launch: y = W_o (sum po + b_v) + b_o + res
+    wo = bf(torch.randn(E, E, generator=g) * 0.02)
+    bo = bf(torch.randn(E, generator=g) * 0.02)
+    res = bf(torch.randn(E, generator=g))
+    yv = torch.full((E,), float("nan"), device="cuda")
+    a16 = nv.to_f16(torch.randn(200, 128, generator=g).cuda())
+    w16 = nv.to_f16(torch.randn(64, 128, generator=g).cuda())
+    o16 = torch.empty(200, 64, dtype=torch.float16, device="cuda")
+    nv.readout16_gemm(a16, w16, None, out_f16=o16, aux=dict(xs=po, xb=bv, w=wo, b=bo, res=res, act=nv.ACT_NONE, y=yv))
+    want = (po.sum(0).double() + bv.double()) @ wo.double().t() + bo.double() + res.double()
+    torch.cuda.synchronize()
+    assert maxabs(yv, want) <= 2e-5
+    assert maxabs(o16, a16.double() @ w16.double().t()) <= 2 ** -10 * float((a16.double() @ w16.double().t()).abs().max())
+    # GELU + a non-multiple-of-4 column count
+    w3 = bf(torch.randn(897 - 1, E, generator=g) * 0.02)
+    y3 = torch.empty(896, device="cuda")
+    nv.readout16_gemm(a16, w16, None, out_f16=o16, aux=dict(xs=yv.view(1, -1), w=w3, act=nv.ACT_GELU, y=y3))
+    torch.cuda.synchronize()
+    assert maxabs(y3, torch.nn.functional.gelu(want.float().double() @ w3.double().t())) <= 2e-5 * max(1.0, float(want.abs().max()))

@@ -56,3 +56,24 @@ if "pgemm" in which or len(sys.argv) == 1:
     hh = torch.empty(1296, HID, device=dev, dtype=torch.bfloat16); hl = torch.empty_like(hh); out = torch.empty(1296, HID, device=dev, dtype=torch.bfloat16)
     t1 = timeit(lambda: nv.planes_gemm(ah, al, w0, b0, act=1, out_hi=hh, out_lo=hl)); t2 = timeit(lambda: nv.planes_gemm(hh, hl, w2, b0, y=out))
     print("planes gemm1 %.1f us (%.0f TF incl hi/lo)  gemm2 %.1f us" % (t1, 2 * 2 * 1296 * HID * E / t1 / 1e6, t2))
+
+if "r16" in which:
+    x = torch.randn(1296, E, device=dev); w0 = (torch.randn(HID, E, device=dev) * 0.02).bfloat16(); b0 = torch.zeros(HID, device=dev).bfloat16()
+    w2 = (torch.randn(HID, HID, device=dev) * 0.02).bfloat16()
+    a16 = nv.to_f16(x); w0_16 = nv.to_f16(w0); w2_16 = nv.to_f16(w2)
+    h16 = torch.empty(1296, HID, device=dev, dtype=torch.float16); out = torch.empty(1296, HID, device=dev, dtype=torch.bfloat16)
+    t1 = timeit(lambda: nv.readout16_gemm(a16, w0_16, b0, act=1, out_f16=h16)); t2 = timeit(lambda: nv.readout16_gemm(h16, w2_16, b0, y=out))
+    print("readout16 gemm1 %.1f us (%.0f TF)  gemm2 %.1f us" % (t1, 2 * 1296 * HID * E / t1 / 1e6, t2))
+    nparts = 216
+    pm, pl, pacc = torch.randn(nparts, 16, device=dev), torch.rand(nparts, 16, device=dev) + 0.5, torch.randn(nparts, 16, E, device=dev)
+    wv = (torch.randn(E, E, device=dev) * 0.02).bfloat16(); bv = torch.zeros(E, device=dev).bfloat16()
+    po = torch.empty(E // 64, E, device=dev); pre = torch.empty(E, device=dev); hid = torch.empty(HID, device=dev)
+    t = timeit(lambda: nv.merge_vproj(pm, pl, pacc, 9, wv, po))
+    print("merge_vproj %.1f us" % t)
+    gw0 = (torch.randn(HID, E, device=dev) * 0.02).bfloat16()
+    t1 = timeit(lambda: nv.readout16_gemm(a16, w0_16, b0, act=1, out_f16=h16, aux=dict(xs=po, xb=bv, w=wv, b=bv, res=bv, y=pre)))
+    t2 = timeit(lambda: nv.readout16_gemm(h16, w2_16, b0, y=out, aux=dict(xs=pre.view(1, -1), w=gw0, b=b0, act=1, y=hid)))
+    print("readout16 gemm1+aux(out_proj) %.1f us  gemm2+aux(readout0) %.1f us" % (t1, t2))
+    tok = torch.empty(32, HID, device=dev, dtype=torch.bfloat16)
+    t = timeit(lambda: nv.linear_to_rows(hid.view(1, -1), w2, b0, tok, 0, 32))
+    print("linear_to_rows (M=1) %.1f us" % t)
