@@ -68,11 +68,31 @@ __device__ __forceinline__ _Float16 to_f16_sat(float v) {
     return (_Float16)v;
 }
 
-// ---- aux role: one GEMV over `n_aux` workgroups; a wave handles batches of 4 columns with all loads in flight ----
+// ---- aux role: one GEMV over `n_aux` workgroups.  A wave owns up to CB = 6 columns (1152 columns over 56 x 4 waves = one
+// batch) and requests ALL of their weight rows first; the partial vectors of x are requested right behind them, so the two
+// cold-memory latencies of the role overlap instead of adding up.
 __device__ __forceinline__ void aux_gemv_role(const AuxGemv& g, int aux_idx, int n_aux, char* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* xl = reinterpret_cast<float*>(lds);       // [K]   x
     float* xp = xl + 1536;                            // [x_parts][K] staged partial vectors
+    constexpr int CH = 3;                             // K <= 1536: up to 3 chunks of 8 elements per lane
+    constexpr int CB = 6;
+    const int nwaves = n_aux * 4, w_id = aux_idx * 4 + wave;
+    const int per = (g.N + nwaves - 1) / nwaves;      // columns per wave (contiguous)
+    u32x4 wv[CB][CH];
+    auto load_w = [&](int n0) {
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            const int n = n0 + j < g.N ? n0 + j : g.N - 1;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int k = (lane + 64 * c) * 8;
+                wv[j][c] = (k < g.K) ? *reinterpret_cast<const u32x4*>(g.w + (long)n * g.K + k) : u32x4{0, 0, 0, 0};
+            }
+        }
+    };
+    const int n_first = w_id * per;
+    load_w(n_first < g.N ? n_first : 0);
     // x = sum of the partial vectors (+ bias).  Phase 1: every float4 of every part is requested at once (a serial
     // loop over the parts is x_parts dependent L2 round trips: 20 us for 18 parts) and parked in LDS; phase 2 sums
     // each column over the parts in part order -- deterministic, no atomics.
@@ -97,7 +117,6 @@ __device__ __forceinline__ void aux_gemv_role(const AuxGemv& g, int aux_idx, int
         xl[k] = v;
     }
     __syncthreads();
-    constexpr int CH = 3;                             // K <= 1536: up to 3 chunks of 8 elements per lane
     float xr[CH][8];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -105,19 +124,8 @@ __device__ __forceinline__ void aux_gemv_role(const AuxGemv& g, int aux_idx, int
 #pragma unroll
         for (int i = 0; i < 8; ++i) xr[c][i] = (k < g.K) ? xl[k + i] : 0.f;
     }
-    const int nwaves = n_aux * 4, w_id = aux_idx * 4 + wave;
-    constexpr int CB = 4;
-    for (int n0 = w_id * CB; n0 < g.N; n0 += nwaves * CB) {
-        u32x4 wv[CB][CH];
-#pragma unroll
-        for (int j = 0; j < CB; ++j) {
-            const int n = n0 + j < g.N ? n0 + j : g.N - 1;
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                const int k = (lane + 64 * c) * 8;
-                wv[j][c] = (k < g.K) ? *reinterpret_cast<const u32x4*>(g.w + (long)n * g.K + k) : u32x4{0, 0, 0, 0};
-            }
-        }
+    for (int n0 = n_first; n0 < min(g.N, n_first + per); n0 += CB) {
+        if (n0 != n_first) load_w(n0);
 #pragma unroll
         for (int j = 0; j < CB; ++j) {
             float acc = 0.f;
@@ -130,7 +138,7 @@ __device__ __forceinline__ void aux_gemv_role(const AuxGemv& g, int aux_idx, int
                 }
             acc = wave_sum(acc);
             const int n = n0 + j;
-            if (lane == 0 && n < g.N) {
+            if (lane == 0 && n < min(g.N, n_first + per)) {
                 float v = acc + (g.b ? bf16_to_f32(g.b[n]) : 0.f);
                 if (g.act == HICOM_ACT_GELU) v = gelu_erf(v);
                 if (g.res) v += bf16_to_f32(g.res[n]);

@@ -77,3 +77,18 @@ if "r16" in which:
     tok = torch.empty(32, HID, device=dev, dtype=torch.bfloat16)
     t = timeit(lambda: nv.linear_to_rows(hid.view(1, -1), w2, b0, tok, 0, 32))
     print("linear_to_rows (M=1) %.1f us" % t)
+
+if "aux" in which:
+    # the GEMV role alone: a one-tile GEMM carries it
+    a1 = nv.to_f16(torch.randn(96, 64, device=dev)); w1 = nv.to_f16(torch.randn(64, 64, device=dev)); o1 = torch.empty(96, 64, device=dev, dtype=torch.float16)
+    wv = (torch.randn(E, E, device=dev) * 0.02).bfloat16(); bv = torch.zeros(E, device=dev).bfloat16()
+    po = torch.randn(E // 64, E, device=dev); pre = torch.empty(E, device=dev); hid = torch.empty(HID, device=dev)
+    gw0 = (torch.randn(HID, E, device=dev) * 0.02).bfloat16()
+    t0 = timeit(lambda: nv.readout16_gemm(a1, w1, None, out_f16=o1))
+    t1 = timeit(lambda: nv.readout16_gemm(a1, w1, None, out_f16=o1, aux=dict(xs=po, xb=bv, w=wv, b=bv, res=bv, y=pre)))
+    t2 = timeit(lambda: nv.readout16_gemm(a1, w1, None, out_f16=o1, aux=dict(xs=po[:1], xb=bv, w=wv, b=bv, res=bv, y=pre)))
+    t3 = timeit(lambda: nv.readout16_gemm(a1, w1, None, out_f16=o1, aux=dict(xs=pre.view(1, -1), w=gw0, act=1, y=hid)))
+    print("one-tile gemm %.1f us | + aux out_proj (18 parts) %.1f | (1 part) %.1f | + aux readout0 %.1f" % (t0, t1, t2, t3))
+    x1 = torch.randn(1, E, device=dev); y1 = torch.empty(1, E, device=dev)
+    t4 = timeit(lambda: nv.linear(x1, wv, bv, y1))
+    print("linear_rows M=1 1152x1152: %.1f us" % t4)
