@@ -1,0 +1,318 @@
+// Dense 16-bit MFMA GEMM over ALL tokens:  C[M,N] = epilogue(A[M,K] . W[N,K]^T + b)   (M = T*729 ~ 46 656 rows)
+//
+// The compressor's neighbours and adaptors that are genuinely matrix-core bound:
+//   * the SigLIP pooling-head projection in front of the key stream, frames_embed = x + head.mlp(head.layernorm(x))
+//     (reference encoder.py:284-286; HF SiglipMLP: fc1 -> gelu_pytorch_tanh -> fc2): 925 GFLOP at 64 frames;
+//   * the k / v adaptor MLPs of `local43_adaptkv_global32` over all tokens (reference projector.py:533-534);
+//   * the key norms ||W_k x + b_k|| of the clip-scale global stage (reference projector.py:184-186).
+// Both operands are K-contiguous (nn.Linear keeps W as [N,K]): an NT GEMM, fragments read along K by ds_read_b128.
+//
+// Structure: 128 x 128 output tile per 256-thread workgroup (2 x 2 waves of 64 x 64 = 4 x 4 MFMA blocks), BK = 64, both
+// operand tiles HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) into ONE 32-KB stage with the chunk ^ (row >> 1) swizzle on the
+// DMA source and the fragment read, two barriers per K step; three to four workgroups are resident per CU (<= 168 VGPR,
+// 32 KB of LDS each) and it is the interleaving of THEIR phases that overlaps staging with MFMA work
+// (cdna_hip_programming.md §5 "Measured: the optimization ladder": the 128^2 two-barrier structure, ~0.9 PF on that
+// guide's box; the 256^2 8-phase schedule is the next step up and is not built here).  XCD-aware tile order: one
+// XCD walks a contiguous run of tiles that share A rows.  Product computed transposed (W fragment as the MFMA A
+// operand): a lane holds 4 consecutive output columns of one row -> 8-byte fp16 / bf16, 16-byte fp32 stores.
+// fp16 operands for normalised activations (11 significand bits; bf16 weights convert exactly), bf16 operands when A is
+// the raw bf16 token stream.
+#include "common.hpp"
+
+namespace hicom {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+#define HICOM_ACT_GELU_TANH 2
+
+struct DenseParams {
+    const uint16_t* a;      // [M, lda] 16-bit (fp16 or bf16 bit patterns)
+    const uint16_t* w;      // [N, ldw]
+    long lda, ldw;
+    const void* b;          // bias [N] (bf16 | f32) or NULL
+    int b_f32;
+    int M, N, K, act;
+    // outputs (any subset)
+    _Float16* o16;          // fp16 [M, ldo]; columns [N, n_store) are written as zeros (K padding of the next GEMM)
+    long ldo;
+    int n_store;
+    void* y;                // bf16 | f32 [M, ldy]: value + residual
+    int y_f32;
+    long ldy;
+    const uint16_t* res;    // bf16 [M, ldr] residual added before the y store (or NULL)
+    long ldr;
+    float* ssq;             // [2 * tiles_n][M] partial row sums of squares of (acc + b) (or NULL)
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float e = __builtin_amdgcn_exp2f(u * 2.8853900817779268f);        // e^(2u)
+    return 0.5f * x * (2.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e));      // 0.5 x (1 + tanh u)
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256, 3) void dense16_gemm_kernel(DenseParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[32768];     // A image [128][128 B] | W image [128][128 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r16 = lane & 15, kg = lane >> 4;
+    // XCD-aware bijective remap (cdna_hip_programming.md §5 "XCD swizzle must be bijective")
+    const int nwg = p.tiles_m * p.tiles_n, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int bm = wg / p.tiles_n, bn = wg - bm * p.tiles_n;
+    const int m0 = bm * 128, n0 = bn * 128;
+
+    // DMA: 32 one-KiB pieces (8 rows x 128 B) per stage, wave w issues pieces w, w+4, ...: 4 of A, 4 of W
+    const int prow = lane >> 3, cpos = lane & 7;
+    unsigned soff[8];                                   // element offsets (< 2^32: the largest operand here is 406 MB)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int pi = wave + 4 * i;                    // i < 4: A piece, i >= 4: W piece
+        const int row = 8 * (pi & 15) + prow;
+        if (i < 4) {
+            int m = m0 + row;
+            m = m < p.M ? m : p.M - 1;
+            soff[i] = (unsigned)((long)m * p.lda + 8 * (cpos ^ ((row >> 1) & 7)));
+        } else {
+            int n = n0 + row;
+            n = n < p.N ? n : p.N - 1;
+            soff[i] = (unsigned)((long)n * p.ldw + 8 * (cpos ^ ((row >> 1) & 7)));
+        }
+    }
+    const int swz = (r16 >> 1) & 7;
+    const char* a_rd = lds + (64 * wr + r16) * 128;
+    const char* w_rd = lds + 16384 + (64 * wc + r16) * 128;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ns = p.K >> 6;
+    for (int s = 0; s < ns; ++s) {
+        lds_barrier();                                        // every wave is done reading the previous stage
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((i < 4 ? p.a : p.w) + soff[i] + 64 * s),
+                                             (__attribute__((address_space(3))) void*)(lds + (wave + 4 * i) * 1024), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int off = 16 * ((4 * ks + kg) ^ swz);
+            if constexpr (BF16) {
+                bf16x8 af[4], wf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    af[i] = *reinterpret_cast<const bf16x8*>(a_rd + i * 2048 + off);
+                    wf[i] = *reinterpret_cast<const bf16x8*>(w_rd + i * 2048 + off);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+            } else {
+                half8 af[4], wf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    af[i] = *reinterpret_cast<const half8*>(a_rd + i * 2048 + off);
+                    wf[i] = *reinterpret_cast<const half8*>(w_rd + i * 2048 + off);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[j][i], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: lane holds columns n .. n+3 (n = n0 + 64 wc + 16 j + 4 kg) of row m = m0 + 64 wr + 16 i + r16
+    float rss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + 64 * wc + 16 * j + 4 * kg;
+        float bias[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.b) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int nn = n + qq < p.N ? n + qq : p.N - 1;
+                bias[qq] = p.b_f32 ? reinterpret_cast<const float*>(p.b)[nn] : bf16_to_f32(reinterpret_cast<const uint16_t*>(p.b)[nn]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + 64 * wr + 16 * i + r16;
+            float v[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                v[qq] = (n + qq < p.N) ? acc[j][i][qq] + bias[qq] : 0.f;
+                if (p.ssq) rss[i] = fmaf(v[qq], v[qq], rss[i]);
+                if (p.act == HICOM_ACT_GELU) v[qq] = gelu_erf(v[qq]);
+                else if (p.act == HICOM_ACT_GELU_TANH) v[qq] = gelu_tanh(v[qq]);
+            }
+            if (m >= p.M) continue;
+            if (p.o16 && n < p.n_store) {
+                half4 hv;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) hv[qq] = (_Float16)fminf(fmaxf((n + qq < p.N) ? v[qq] : 0.f, -65504.f), 65504.f);
+                *reinterpret_cast<half4*>(p.o16 + (long)m * p.ldo + n) = hv;       // (ldo, n_store multiples of 4: host-checked)
+            }
+            if (p.y && n < p.N) {
+                if (p.res) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(p.res + (long)m * p.ldr + n);
+                    v[0] += bf16lo_to_f32(rr.x); v[1] += bf16hi_to_f32(rr.x); v[2] += bf16lo_to_f32(rr.y); v[3] += bf16hi_to_f32(rr.y);
+                }
+                if (p.y_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (long)m * p.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (long)m * p.ldy + n) =
+                        make_uint2(f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16), f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16));
+            }
+        }
+    }
+    if (p.ssq) {
+        // sum over this wave's 64 columns: the 4 k-groups of a row live in lanes r16 + 16 kg
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float sacc = rss[i];
+            sacc += __shfl_xor(sacc, 16, 64);
+            sacc += __shfl_xor(sacc, 32, 64);
+            const int m = m0 + 64 * wr + 16 * i + r16;
+            if (kg == 0 && m < p.M) p.ssq[(long)(2 * bn + wc) * p.M + m] = sacc;
+        }
+    }
+}
+
+// ---- row-wise LayerNorm over the token stream, 16-byte accesses (E % 8 == 0, E <= 1536) -----------------------------
+//   out = (1 - alpha) * src + alpha * (LN(x) * gamma + beta);   x: fp16 | bf16 | f32 [M, ldx];  src: bf16 [M, E] or NULL;
+//   out: fp16 | bf16 [M, E].   SigLIP head layernorm (encoder.py:284) and the adaptor blend (projector.py:533-534).
+struct LnStreamParams {
+    const void* x; int x_dt; long ldx;
+    const uint16_t* gamma; const uint16_t* beta;
+    const uint16_t* src;
+    const void* alpha; int alpha_dt;
+    float eps;
+    void* out; int out_f16;
+    int M, E;
+};
+
+__device__ __forceinline__ void ld8(const void* base, int dt, long off, float (&v)[8]) {
+    if (dt == HICOM_DT_F32) {
+        const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+        const float4 c = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+    } else if (dt == HICOM_DT_BF16) {
+        const u32x4 g = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(base) + off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = bf16lo_to_f32(g[i]); v[2 * i + 1] = bf16hi_to_f32(g[i]); }
+    } else {
+        const half8 h = *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(base) + off);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_stream_kernel(LnStreamParams p) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= p.M) return;
+    const int nch = p.E >> 3;
+    float v[3][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) ld8(p.x, p.x_dt, m * p.ldx + 8 * ch, v[c]);
+        else
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sum += v[c][i];
+    }
+    const float mean = wave_sum(sum) / (float)p.E;
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        if (lane + 64 * c < nch)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mean; var = fmaf(d, d, var); }
+    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)p.E + p.eps);
+    float alpha = 1.0f;
+    if (p.alpha) alpha = p.alpha_dt == HICOM_DT_F32 ? *reinterpret_cast<const float*>(p.alpha) : bf16_to_f32(*reinterpret_cast<const uint16_t*>(p.alpha));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch >= nch) continue;
+        float g[8], b[8], y[8];
+        ld8(p.gamma, HICOM_DT_BF16, 8 * ch, g);
+        ld8(p.beta, HICOM_DT_BF16, 8 * ch, b);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] = (v[c][i] - mean) * rstd * g[i] + b[i];
+        if (p.src) {
+            float sv[8];
+            ld8(p.src, HICOM_DT_BF16, m * (long)p.E + 8 * ch, sv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) y[i] = (1.0f - alpha) * sv[i] + alpha * y[i];
+        }
+        if (p.out_f16) {
+            half8 h;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) h[i] = (_Float16)fminf(fmaxf(y[i], -65504.f), 65504.f);
+            *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(p.out) + m * (long)p.E + 8 * ch) = h;
+        } else {
+            u32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = f32_to_bf16(y[2 * i]) | ((uint32_t)f32_to_bf16(y[2 * i + 1]) << 16);
+            *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.out) + m * (long)p.E + 8 * ch) = o;
+        }
+    }
+}
+
+}  // namespace hicom
+
+using namespace hicom;
+
+extern "C" int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w, int64_t ldw, int32_t operand_dt,
+                                      const void* b, int32_t b_dt, int32_t M, int32_t N, int32_t K, int32_t act,
+                                      void* out_f16, int64_t ldo, int32_t n_store,
+                                      void* y, int32_t y_dt, int64_t ldy, const void* res, int64_t ldr,
+                                      float* ssq, void* stream) {
+    HICOM_REQUIRE(a && w && (out_f16 || y || ssq), HICOM_EINVAL, "dense16_gemm: NULL pointer / no output");
+    HICOM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, HICOM_EINVAL,
+                  "dense16_gemm: bad shape M=%d N=%d K=%d (K %% 64, leading dimensions %% 8)", M, N, K);
+    HICOM_REQUIRE(operand_dt == HICOM_DT_BF16 || operand_dt == HICOM_DT_F16, HICOM_EINVAL, "dense16_gemm: operands are bf16 or fp16");
+    HICOM_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)w % 16 == 0), HICOM_EINVAL, "dense16_gemm: alignment");
+    HICOM_REQUIRE((long)M * lda < (1L << 32) && (long)N * ldw < (1L << 32), HICOM_EUNSUP, "dense16_gemm: operand larger than 2^32 elements");
+    HICOM_REQUIRE(N % 4 == 0, HICOM_EUNSUP, "dense16_gemm: N %% 4");
+    if (out_f16) HICOM_REQUIRE(ldo % 4 == 0 && n_store % 4 == 0 && n_store >= N && n_store <= ldo && (uintptr_t)out_f16 % 8 == 0 &&
+                                   n_store <= ((N + 127) / 128) * 128, HICOM_EINVAL, "dense16_gemm: fp16 output layout");
+    if (y) HICOM_REQUIRE(ldy % 4 == 0 && ldy >= N && (uintptr_t)y % 16 == 0 && (!res || (ldr % 4 == 0 && (uintptr_t)res % 8 == 0)), HICOM_EINVAL,
+                         "dense16_gemm: packed output layout");
+    DenseParams p;
+    p.a = (const uint16_t*)a; p.w = (const uint16_t*)w; p.lda = lda; p.ldw = ldw; p.b = b; p.b_f32 = b_dt == HICOM_DT_F32;
+    p.M = M; p.N = N; p.K = K; p.act = act; p.o16 = (_Float16*)out_f16; p.ldo = ldo; p.n_store = out_f16 ? n_store : 0;
+    p.y = y; p.y_f32 = y_dt == HICOM_DT_F32; p.ldy = ldy; p.res = (const uint16_t*)res; p.ldr = ldr; p.ssq = ssq;
+    p.tiles_m = (M + 127) / 128; p.tiles_n = (N + 127) / 128;
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+    if (operand_dt == HICOM_DT_BF16) hipLaunchKernelGGL(dense16_gemm_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(dense16_gemm_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return hicom_host::check_launch("dense16_gemm");
+}
+
+extern "C" int hicom_ln_stream_fwd(const void* x, int32_t x_dt, int64_t ldx, const void* gamma, const void* beta,
+                                   const void* src, const void* alpha, int32_t alpha_dt, float eps,
+                                   void* out, int32_t out_dt, int32_t M, int32_t E, void* stream) {
+    HICOM_REQUIRE(x && gamma && beta && out, HICOM_EINVAL, "ln_stream: NULL pointer");
+    HICOM_REQUIRE(M > 0 && E > 0 && E % 8 == 0 && E <= 1536 && ldx >= E && ldx % 8 == 0, HICOM_EINVAL, "ln_stream: bad shape");
+    HICOM_REQUIRE(out_dt == HICOM_DT_BF16 || out_dt == HICOM_DT_F16, HICOM_EINVAL, "ln_stream: out is bf16 or fp16");
+    HICOM_REQUIRE(src || !alpha, HICOM_EINVAL, "ln_stream: alpha without a blend source");
+    LnStreamParams p{x, x_dt, (long)ldx, (const uint16_t*)gamma, (const uint16_t*)beta, (const uint16_t*)src, alpha, alpha_dt, eps,
+                     out, out_dt == HICOM_DT_F16, M, E};
+    hipLaunchKernelGGL(ln_stream_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    return hicom_host::check_launch("ln_stream");
+}

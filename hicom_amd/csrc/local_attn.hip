@@ -22,7 +22,7 @@ struct __attribute__((packed, aligned(4))) Seg12 { uint32_t a, b, c; };
 struct LocalParams {
     const void* key;
     const void* value;
-    int key_f32, value_f32;      // adapted (alpha-blended) streams arrive as fp32, raw tokens as bf16
+    int key_f32, value_f32;      // stream dtype code: 0 = bf16 (raw tokens), 1 = fp32, 2 = fp16 (alpha-blended adaptor outputs)
     const void* query;
     int query_f32;
     long query_stride;
@@ -55,9 +55,21 @@ __device__ __forceinline__ void load_row_f32(const float* row, int lane, float (
 }
 
 template <int NV>
-__device__ __forceinline__ void load_stream_row(const void* base, int is_f32, long token, int lane, float (&v)[NV][6]) {
+__device__ __forceinline__ void load_row_f16(const _Float16* row, int lane, float (&v)[NV][6]) {
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int s = 0; s < NV; ++s) {
+        const Seg12 g = *reinterpret_cast<const Seg12*>(row + 384 * s + 6 * lane);
+        const half2_t a = __builtin_bit_cast(half2_t, g.a), b = __builtin_bit_cast(half2_t, g.b), c = __builtin_bit_cast(half2_t, g.c);
+        v[s][0] = (float)a[0]; v[s][1] = (float)a[1]; v[s][2] = (float)b[0]; v[s][3] = (float)b[1]; v[s][4] = (float)c[0]; v[s][5] = (float)c[1];
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ void load_stream_row(const void* base, int dt, long token, int lane, float (&v)[NV][6]) {
     constexpr int D = NV * 384;
-    if (is_f32) load_row_f32<NV>(reinterpret_cast<const float*>(base) + token * D, lane, v);
+    if (dt == 1) load_row_f32<NV>(reinterpret_cast<const float*>(base) + token * D, lane, v);
+    else if (dt == 2) load_row_f16<NV>(reinterpret_cast<const _Float16*>(base) + token * D, lane, v);
     else load_row<NV>(reinterpret_cast<const uint16_t*>(base) + token * D, lane, v);
 }
 
@@ -231,6 +243,7 @@ extern "C" int hicom_local_attn_fwd(const void* key, int32_t key_dt, const void*
     HICOM_REQUIRE(key && value && query && ctx, HICOM_EINVAL, "local_attn: NULL pointer");
     HICOM_REQUIRE(D == 1152 || D == 768, HICOM_EUNSUP, "local_attn: D=%d (only 1152 / 768)", D);
     HICOM_REQUIRE(query_dt == HICOM_DT_BF16 || query_dt == HICOM_DT_F32, HICOM_EINVAL, "local_attn: query dtype");
+    HICOM_REQUIRE(key_dt >= 0 && key_dt <= 2 && value_dt >= 0 && value_dt <= 2, HICOM_EINVAL, "local_attn: stream dtype");
     for (const hicom_axis* a : {&at, &ay, &ax}) {
         HICOM_REQUIRE(a->n > 0 && a->k > 0 && a->nwin > 0 && a->nfull >= 0 && a->nfull <= a->nwin && a->k <= a->n,
                       HICOM_EINVAL, "local_attn: bad axis n=%d k=%d nwin=%d nfull=%d", a->n, a->k, a->nwin, a->nfull);
@@ -241,7 +254,7 @@ extern "C" int hicom_local_attn_fwd(const void* key, int32_t key_dt, const void*
     HICOM_REQUIRE(win <= 4096, HICOM_EUNSUP, "local_attn: window of %ld tokens is too large", win);
     const long nwin = (long)at.nwin * ay.nwin * ax.nwin;
     HICOM_REQUIRE(nwin < (1L << 31), HICOM_EINVAL, "local_attn: too many windows");
-    LocalParams p{key, value, key_dt == HICOM_DT_F32, value_dt == HICOM_DT_F32, query, query_dt == HICOM_DT_F32,
+    LocalParams p{key, value, key_dt, value_dt, query, query_dt == HICOM_DT_F32,
                   (long)query_stride, at, ay, ax, scale, bias, l2norm, ctx};
     const size_t smem = (((size_t)win + 3) & ~(size_t)3) * 4 + 4 * (size_t)D * 4;
     hipStream_t s = (hipStream_t)stream;

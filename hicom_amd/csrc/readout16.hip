@@ -397,9 +397,25 @@ __global__ __launch_bounds__(256) void to_f16_kernel(const void* src, int src_f3
         }
 }
 
+__global__ __launch_bounds__(256) void to_f16_padded_kernel(const void* src, int src_f32, long rows, long cols, _Float16* dst, long ld) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * ld) return;
+    const long r = i / ld, c = i - r * ld;
+    float v = 0.f;
+    if (c < cols) v = src_f32 ? reinterpret_cast<const float*>(src)[r * cols + c] : bf16_to_f32(reinterpret_cast<const uint16_t*>(src)[r * cols + c]);
+    dst[i] = to_f16_sat(v);
+}
+
 }  // namespace hicom
 
 using namespace hicom;
+
+extern "C" int hicom_to_f16_padded_fwd(const void* src, int32_t src_dt, int64_t rows, int64_t cols, void* dst, int64_t ld_dst, void* stream) {
+    HICOM_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_dst >= cols, HICOM_EINVAL, "to_f16_padded: bad arguments");
+    hipLaunchKernelGGL(to_f16_padded_kernel, dim3((unsigned)((rows * ld_dst + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       src_dt == HICOM_DT_F32, (long)rows, (long)cols, (_Float16*)dst, (long)ld_dst);
+    return hicom_host::check_launch("to_f16_padded");
+}
 
 extern "C" int hicom_to_f16_fwd(const void* src, int32_t src_dt, void* dst, int64_t n, void* stream) {
     HICOM_REQUIRE(src && dst && n > 0, HICOM_EINVAL, "to_f16: bad arguments");

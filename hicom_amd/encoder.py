@@ -1,0 +1,60 @@
+"""MI355X-native form of the step right in front of the compressor: the per-patch SigLIP
+pooling-head projection that produces `frames_embed`,
+
+    image_embeds = head.layernorm(last_hidden_state)
+    image_embeds = last_hidden_state + head.mlp(image_embeds)                  (reference hicom/model/encoder.py:284-286)
+
+over all T*729 tokens: a LayerNorm and a 1152 -> 4304 -> 1152 MLP (925 GFLOP at 64 frames -- nine times the flops of the
+whole compressor), i.e. matrix-core work.  `head` is whatever the reference hands over: HF's
+SiglipMultiheadAttentionPoolingHead (or any object with .layernorm = nn.LayerNorm and .mlp.fc1 / .mlp.fc2 = nn.Linear).
+
+HIP path: hicom_ln_stream_fwd (LayerNorm -> fp16, 16-byte accesses) -> hicom_dense16_gemm_fwd (fc1 + tanh-GELU -> fp16
+hidden, K zero-padded to 4352) -> hicom_dense16_gemm_fwd (fc2 + bias + residual -> bf16).  fp16 operands: the normalised
+activations keep 11 significand bits, the bf16 weights convert exactly (cached per weight version).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import native as nv
+
+_ACTS = {"gelu_pytorch_tanh": nv.ACT_GELU_TANH, "gelu": nv.ACT_GELU}
+
+
+def _head_cache(head):
+    fc1, fc2 = head.mlp.fc1, head.mlp.fc2
+    stamp = (fc1.weight.data_ptr(), fc1.weight._version, fc2.weight.data_ptr(), fc2.weight._version)
+    hit = head.__dict__.get("_hicom_f16")
+    if hit is None or hit[0] != stamp:
+        kpad = (fc2.weight.shape[1] + 63) // 64 * 64
+        hit = (stamp, nv.to_f16(fc1.weight.detach()), nv.to_f16_padded(fc2.weight.detach(), kpad), kpad)
+        head.__dict__["_hicom_f16"] = hit
+    return hit[1], hit[2], hit[3]
+
+
+def siglip_head_embed(last_hidden_state: torch.Tensor, head, hidden_act: str = None, out_dtype=None) -> torch.Tensor:
+    """[..., D] bf16 tokens -> x + head.mlp(head.layernorm(x)), same shape (bf16; out_dtype=torch.float32 for parity tests)."""
+    from .projector import _require_bf16_cuda
+    x = last_hidden_state
+    _require_bf16_cuda("last_hidden_state", x)
+    if torch.is_grad_enabled() and any(p.requires_grad for p in head.parameters()):
+        raise RuntimeError("siglip_head_embed builds no autograd graph (the head trains only in stage 3 of the reference): call "
+                           "it under torch.no_grad()")
+    ln, fc1, fc2 = head.layernorm, head.mlp.fc1, head.mlp.fc2
+    for t in (ln.weight, ln.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias):
+        _require_bf16_cuda("head parameter", t)
+    if hidden_act is None:
+        hidden_act = getattr(getattr(head.mlp, "config", None), "hidden_act", "gelu_pytorch_tanh")
+    if hidden_act not in _ACTS:
+        raise NotImplementedError(f"siglip_head_embed: hidden_act={hidden_act!r}")
+    D = x.shape[-1]
+    x2 = x.contiguous().view(-1, D)
+    M = x2.shape[0]
+    w1, w2, kpad = _head_cache(head)
+    a16 = torch.empty((M, D), dtype=torch.float16, device=x.device)
+    nv.ln_stream(x2, ln.weight.detach(), ln.bias.detach(), a16, eps=ln.eps)
+    hid = torch.empty((M, kpad), dtype=torch.float16, device=x.device)
+    nv.dense16_gemm(a16, w1, fc1.bias.detach(), act=_ACTS[hidden_act], out_f16=hid, n_store=kpad)
+    out = torch.empty((M, D), dtype=out_dtype or x.dtype, device=x.device)
+    nv.dense16_gemm(hid, w2, fc2.bias.detach(), N=D, K=kpad, y=out, res=x2)
+    return out.view(x.shape)

@@ -90,22 +90,35 @@ def inject(inj, mode, visual, guide):
     raise NotImplementedError(f"use_guide={mode!r}")
 
 
+def _f16_weight(lin):
+    """fp16 copy of an nn.Linear weight (bf16 -> fp16 is exact), cached on the module per weight version."""
+    w = lin.weight
+    stamp = (w.data_ptr(), w._version)
+    hit = lin.__dict__.get("_hicom_f16")
+    if hit is None or hit[0] != stamp:
+        hit = (stamp, nv.to_f16(w.detach()))
+        lin.__dict__["_hicom_f16"] = hit
+    return hit[1]
+
+
 def adapt_stream(x, mlp, norm, alpha):
-    """(1 - a) x + a LN(MLP(x)) over ALL tokens (adapt_k / adapt_v, ref :533-534): x bf16 [T,h,w,D] ->
-    f32 [T,h,w,D].  Two MFMA GEMMs on bf16 planes (the raw tokens are exact bf16: no lo plane for the
-    first one) and a row-wise LayerNorm blend."""
+    """(1 - a) x + a LN(MLP(x)) over ALL tokens (adapt_k / adapt_v, ref :533-534): x bf16 [T,h,w,D] -> fp16 [T,h,w,D].
+    Two dense MFMA GEMMs (hicom_dense16_gemm_fwd: raw tokens x bf16 weights, then fp16 hidden x fp16 weights) and the
+    vectorised LayerNorm blend (hicom_ln_stream_fwd); no fp32 [N, D] stream is written -- the adapted stream travels as ONE
+    fp16 plane (11 significand bits) into the window-attention kernel."""
     D = x.shape[-1]
     x2 = x.reshape(-1, D).contiguous()
     N = x2.shape[0]
     w0, b0 = _wb(mlp[0])
     w2, b2 = _wb(mlp[2])
-    hid_hi = torch.empty((N, w0.shape[0]), dtype=torch.bfloat16, device=x.device)
-    hid_lo = torch.empty_like(hid_hi)
-    nv.planes_gemm(x2, None, w0, b0, act=nv.ACT_GELU, out_hi=hid_hi, out_lo=hid_lo)
-    y = _f32((N, w2.shape[0]), x.device)
-    nv.planes_gemm(hid_hi, hid_lo, w2, b2, y=y)
-    out = _f32((N, D), x.device)
-    nv.row_ln(y, norm, out, src=x2, alpha=alpha.detach())
+    if w0.shape[1] % 64 or w2.shape[1] % 64:
+        raise NotImplementedError("adapt_stream: widths must be multiples of 64")
+    hid = torch.empty((N, w0.shape[0]), dtype=torch.float16, device=x.device)
+    nv.dense16_gemm(x2, w0, b0, act=nv.ACT_GELU, out_f16=hid)
+    y = torch.empty((N, w2.shape[0]), dtype=torch.float16, device=x.device)
+    nv.dense16_gemm(hid, _f16_weight(mlp[2]), b2, out_f16=y)
+    out = torch.empty((N, D), dtype=torch.float16, device=x.device)
+    nv.ln_stream(y, norm.weight.detach(), norm.bias.detach(), out, src=x2, alpha=alpha.detach(), eps=norm.eps)
     return out.reshape(x.shape)
 
 

@@ -17,8 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HICOM_NATIVE_LIB") or os.path.join(HERE, "libhicom_hip.so")
 ABI_VERSION = 3
 
-DT_BF16, DT_F32 = 0, 1
-ACT_NONE, ACT_GELU = 0, 1
+DT_BF16, DT_F32, DT_F16 = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_GELU_TANH = 0, 1, 2
 
 EXPORTS = (
     "hicom_abi_version", "hicom_last_error", "hicom_local_attn_fwd", "hicom_trilinear_pool_fwd",
@@ -29,6 +29,7 @@ EXPORTS = (
     "hicom_compressor_fwd", "hicom_linear_to_rows_fwd", "hicom_fused_stream_fwd", "hicom_fused_stream_nparts",
     "hicom_planes_gemm_fwd", "hicom_row_ln_fwd", "hicom_small_mha_fwd", "hicom_place_blocks_fwd",
     "hicom_global_stream_bwd", "hicom_readout16_gemm_fwd", "hicom_to_f16_fwd", "hicom_merge_vproj_fwd",
+    "hicom_dense16_gemm_fwd", "hicom_ln_stream_fwd", "hicom_to_f16_padded_fwd",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -117,6 +118,9 @@ def lib() -> C.CDLL:
                                          vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.hicom_readout16_gemm_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i64, i64, i32, C.POINTER(AuxGemv), vp]
     L.hicom_to_f16_fwd.argtypes = [vp, i32, vp, i64, vp]
+    L.hicom_to_f16_padded_fwd.argtypes = [vp, i32, i64, i64, vp, i64, vp]
+    L.hicom_dense16_gemm_fwd.argtypes = [vp, i64, vp, i64, i32, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, i32, i64, vp, i64, vp, vp]
+    L.hicom_ln_stream_fwd.argtypes = [vp, i32, i64, vp, vp, vp, vp, i32, f32, vp, i32, i32, i32, vp]
     L.hicom_merge_vproj_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.hicom_fused_stream_nparts.argtypes = [i32]
     L.hicom_planes_gemm_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i64, i64, i32, vp]
@@ -164,7 +168,7 @@ def _dt(t: torch.Tensor) -> int:
     if t.dtype == torch.float32:
         return DT_F32
     if t.dtype == torch.float16:
-        return 2                            # (only ever passed where the C side ignores the dtype code)
+        return DT_F16
     raise HicomNativeError(f"unsupported dtype {t.dtype} (bf16 or f32 only)")
 
 
@@ -341,6 +345,36 @@ def to_f16(src, dst=None):
         dst = torch.empty(src.shape, dtype=torch.float16, device=src.device)
     _check(lib().hicom_to_f16_fwd(_ptr(src), _dt(src), _ptr(dst), src.numel(), _stream()), "hicom_to_f16_fwd")
     return dst
+
+
+def to_f16_padded(src, ld):
+    """fp16 copy of a [rows, cols] bf16 / f32 matrix with its rows zero-padded to `ld` columns (K padding of a GEMM operand)."""
+    rows, cols = src.shape
+    dst = torch.empty((rows, ld), dtype=torch.float16, device=src.device)
+    _check(lib().hicom_to_f16_padded_fwd(_ptr(src), _dt(src), rows, cols, _ptr(dst), ld, _stream()), "hicom_to_f16_padded_fwd")
+    return dst
+
+
+def dense16_gemm(a, w, b, N=None, K=None, act=ACT_NONE, out_f16=None, n_store=None, y=None, res=None, ssq=None):
+    """C = epi(A . W^T + b) on matrix cores; a [M, lda], w [N, ldw] both fp16 or both bf16 (see include/hicom_hip.h)."""
+    if a.dtype != w.dtype or a.dtype not in (torch.float16, torch.bfloat16):
+        raise HicomNativeError("dense16_gemm: operands are both fp16 or both bf16")
+    M = a.shape[0]
+    N = w.shape[0] if N is None else N
+    K = w.shape[1] if K is None else K
+    _check(lib().hicom_dense16_gemm_fwd(_ptr(a), a.shape[1], _ptr(w), w.shape[1], _dt(a), _ptr(b), _dt(b) if b is not None else 0,
+                                        M, N, K, act, _ptr(out_f16), out_f16.shape[1] if out_f16 is not None else 0,
+                                        (out_f16.shape[1] if n_store is None else n_store) if out_f16 is not None else 0,
+                                        _ptr(y), _dt(y) if y is not None else 0, y.shape[1] if y is not None else 0,
+                                        _ptr(res), res.shape[1] if res is not None else 0, _ptr(ssq), _stream()),
+           "hicom_dense16_gemm_fwd")
+
+
+def ln_stream(x, gamma, beta, out, src=None, alpha=None, eps=1e-6):
+    M, E = out.shape
+    _check(lib().hicom_ln_stream_fwd(_ptr(x), _dt(x), x.shape[1], _ptr(gamma), _ptr(beta), _ptr(src), _ptr(alpha),
+                                     _dt(alpha) if alpha is not None else 0, eps, _ptr(out), _dt(out), M, E, _stream()),
+           "hicom_ln_stream_fwd")
 
 
 def readout16_gemm(a16, w16, b, act=ACT_NONE, out_f16=None, y=None, row0=0, nl_group=0, aux=None):

@@ -35,10 +35,12 @@ extern "C" {
 
 #define HICOM_DT_BF16 0
 #define HICOM_DT_F32  1
+#define HICOM_DT_F16  2      /* IEEE half: activations that feed matrix cores (11 significand bits), accepted where noted */
 
 /* activation / epilogue flags for the linear + GEMM entry points */
 #define HICOM_ACT_NONE 0
 #define HICOM_ACT_GELU 1     /* exact erf GELU (nn.GELU() default, projector.py:310) */
+#define HICOM_ACT_GELU_TANH 2 /* tanh GELU (HF "gelu_pytorch_tanh": the SigLIP MLP, encoder.py:285) */
 
 int hicom_abi_version(void);
 const char* hicom_last_error(void);
@@ -54,7 +56,7 @@ typedef struct hicom_axis {
 /* ---- local compressor: windowed single-head cross-attention ------------------------------
  * Replaces projector.py:544-558 (divide_feature x3, bmm, softmax, bmm, un-window) and, with
  * l2norm != 0, the clip-scale normalisation at :527-529,549.
- *   key, value : [T,H,W,D] bf16 (frames_embed / frames_feature; key may alias value) or f32 (the
+ *   key, value : [T,H,W,D] bf16 (frames_embed / frames_feature; key may alias value), or f32 / fp16 (the
  *                alpha-blended adaptor outputs of projector.py:533-534); dtype key_dt / value_dt
  *   query      : [D] shared by every window (query_stride == 0, GuideInjector "direct",
  *                projector.py:352-368) or [Nw, D] with row stride query_stride elements;
@@ -254,8 +256,9 @@ int hicom_readout16_gemm_fwd(const void* a, const void* w, const void* b, int32_
                              int32_t M, int32_t N, int32_t K, int32_t act, void* out_f16,
                              void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group,
                              const hicom_aux_gemv* aux, void* stream);
-/* dst fp16 [n] = saturating cast of src (bf16 or f32) */
+/* dst fp16 [rows, ld_dst] = saturating cast of src (bf16 or f32) [rows, cols]; columns [cols, ld_dst) are zero-filled */
 int hicom_to_f16_fwd(const void* src, int32_t src_dt, void* dst, int64_t n, void* stream);
+int hicom_to_f16_padded_fwd(const void* src, int32_t src_dt, int64_t rows, int64_t cols, void* dst, int64_t ld_dst, void* stream);
 
 /* Release recipe, one query row per head: merge of the ring kernel's partial states fused with v_proj
  * (projector.py:182,215 after folding).  po f32 [E/64][E]: partial v_proj outputs per 64-channel slab of the context,
@@ -264,6 +267,28 @@ int hicom_to_f16_fwd(const void* src, int32_t src_dt, void* dst, int64_t n, void
 int hicom_merge_vproj_fwd(const float* part_m, const float* part_l, const float* part_acc, int32_t nparts,
                           int32_t rows, int32_t rows_pad, int32_t E, const void* w_v, float* po,
                           float* out_ml, float* out_ctx, void* stream);
+
+/* ---- dense 16-bit MFMA GEMM over all tokens (M = T*729) ------------------------------------------------------------
+ * C = epilogue(A[M,K] . W[N,K]^T + b): A, W both fp16 or both bf16 (operand_dt), leading dimensions lda / ldw elements,
+ * K % 64 == 0 (pad with zero columns), fp32 accumulation; act NONE | GELU (erf) | GELU_TANH.  Outputs, any subset:
+ *   out_f16 [M, ldo] fp16 (saturating): the activated value; columns [N, n_store) are written as zeros (the K padding
+ *           of a following GEMM);
+ *   y [M, ldy] bf16 | f32: value + res[m, n] (res bf16 [M, ldr] or NULL);
+ *   ssq f32 [2 * ceil(N/128)][M]: partial row sums of squares of (acc + b), summed by the consumer (key norms of the
+ *           clip-scale global stage, projector.py:184-186).
+ * The matrix-core-bound neighbours of the compressor: the SigLIP pooling-head projection that produces frames_embed
+ * (encoder.py:284-286), the k / v adaptor MLPs (projector.py:533-534). */
+int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w, int64_t ldw, int32_t operand_dt,
+                           const void* b, int32_t b_dt, int32_t M, int32_t N, int32_t K, int32_t act,
+                           void* out_f16, int64_t ldo, int32_t n_store,
+                           void* y, int32_t y_dt, int64_t ldy, const void* res, int64_t ldr,
+                           float* ssq, void* stream);
+/* out[m,:] = (1 - alpha) src[m,:] + alpha (LayerNorm_eps(x[m,:]) gamma + beta) over all tokens with 16-byte accesses:
+ * x fp16 | bf16 | f32 [M, ldx]; gamma, beta, src (may be NULL) bf16; alpha device scalar or NULL (= 1); out fp16 | bf16
+ * [M, E]; E % 8 == 0, E <= 1536.  head.layernorm of encoder.py:284 and the adaptor blend of projector.py:533-534. */
+int hicom_ln_stream_fwd(const void* x, int32_t x_dt, int64_t ldx, const void* gamma, const void* beta,
+                        const void* src, const void* alpha, int32_t alpha_dt, float eps,
+                        void* out, int32_t out_dt, int32_t M, int32_t E, void* stream);
 
 /* Row copy / broadcast with dtype conversion into the packed output:
  *   dst[row0 + i*row_step + (nl_group ? i / nl_group : 0), :] = src[(i % src_rows), :],  i in [0,count)

@@ -541,3 +541,25 @@ def make_config(**kw) -> SimpleNamespace:
                 hidden_size=896, max_num_frames=32)
     base.update(kw)
     return SimpleNamespace(**base)
+
+
+# ---------------------------------------------------------------------------------------------
+# Upstream neighbour of the path: the per-patch SigLIP pooling-head projection that
+# produces frames_embed,
+#     image_embeds = head.layernorm(last_hidden_state); image_embeds = last_hidden_state + head.mlp(image_embeds)
+# (reference hicom/model/encoder.py:284-286).  `head` is HF transformers' SiglipMultiheadAttentionPoolingHead (a
+# third-party dependency of the reference, README.md:21 pins transformers 4.45-class; here 5.15): layernorm = nn.LayerNorm
+# (eps = config.layer_norm_eps = 1e-6), mlp = SiglipMLP: fc1 -> ACT2FN[config.hidden_act] -> fc2 with
+# hidden_act = "gelu_pytorch_tanh" and intermediate_size 4304 for siglip-so400m-patch14-384 (HF config values, not in
+# the reference).  Pinned by tests/golden/make_golden_head.py, which evaluates those two reference lines on the HF modules.
+def gelu_tanh(x: Tensor) -> Tensor:
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
+
+
+def siglip_head_embed(x: Tensor, sd: Dict[str, Tensor], prefix: str = "head", eps: float = 1e-6, act: str = "gelu_pytorch_tanh") -> Tensor:
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    h = (x - mu) / torch.sqrt(var + eps) * sd[prefix + ".layernorm.weight"] + sd[prefix + ".layernorm.bias"]
+    h = linear(h, sd, prefix + ".mlp.fc1")
+    h = gelu_tanh(h) if act == "gelu_pytorch_tanh" else gelu_erf(h)
+    return x + linear(h, sd, prefix + ".mlp.fc2")
