@@ -17,6 +17,8 @@
 // operand): a lane holds 4 consecutive output columns of one row -> 8-byte fp16 / bf16, 16-byte fp32 stores.
 // fp16 operands for normalised activations (11 significand bits; bf16 weights convert exactly), bf16 operands when A is
 // the raw bf16 token stream.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace hicom {
@@ -44,6 +46,11 @@ struct DenseParams {
     long ldr;
     float* ssq;             // [2 * tiles_n][M] partial row sums of squares of (acc + b) (or NULL)
     int tiles_m, tiles_n;
+    // optional per-row additive term from three table rows (the projected positional embedding W . pos of token m):
+    //   + tab[t0 + m / (H*W)][n] + tab[y0 + (m / W) % H][n] + tab[x0 + m % W][n],   tab f32 [*, tab_ld]
+    const float* tab;
+    long tab_ld;
+    int H, W, t0, y0, x0;
 };
 
 __device__ __forceinline__ float gelu_tanh(float x) {
@@ -52,9 +59,11 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     return 0.5f * x * (2.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e));      // 0.5 x (1 + tanh u)
 }
 
-template <bool BF16>
-__global__ __launch_bounds__(256, 3) void dense16_gemm_kernel(DenseParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[32768];     // A image [128][128 B] | W image [128][128 B]
+// DB = true: two 32-KB stages; the LDS-DMA of tile k+1 is issued (inline asm: hipcc would drain an LDS-DMA it knows of in
+// front of the next ds_read) before the MFMAs of tile k, one barrier per K step, two workgroups per CU.
+template <bool BF16, bool DB>
+__global__ __launch_bounds__(256, DB ? 2 : 3) void dense16_gemm_kernel(DenseParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[DB ? 65536 : 32768];     // per stage: A image [128][128 B] | W image [128][128 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
@@ -63,7 +72,12 @@ __global__ __launch_bounds__(256, 3) void dense16_gemm_kernel(DenseParams p) {
     const int nwg = p.tiles_m * p.tiles_n, orig = blockIdx.x;
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    const int bm = wg / p.tiles_n, bn = wg - bm * p.tiles_n;
+    // super-tile order inside the run: blocks of RM row tiles, column-major inside a block, so that the ~96 tiles an XCD
+    // has in flight share RM A panels and a dozen W panels in ITS L2 instead of streaming all of W once per row tile
+    constexpr int RM = 8;
+    const int per_blk = RM * p.tiles_n, blk = wg / per_blk, rem = wg - blk * per_blk;
+    const int rows_in = min(RM, p.tiles_m - blk * RM);
+    const int bn = rem / rows_in, bm = blk * RM + (rem - bn * rows_in);
     const int m0 = bm * 128, n0 = bn * 128;
 
     // DMA: 32 one-KiB pieces (8 rows x 128 B) per stage, wave w issues pieces w, w+4, ...: 4 of A, 4 of W
@@ -94,15 +108,25 @@ __global__ __launch_bounds__(256, 3) void dense16_gemm_kernel(DenseParams p) {
         for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ns = p.K >> 6;
-    for (int s = 0; s < ns; ++s) {
-        lds_barrier();                                        // every wave is done reading the previous stage
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(lds));
+    auto issue = [&](int s, int buf) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((i < 4 ? p.a : p.w) + soff[i] + 64 * s),
-                                             (__attribute__((address_space(3))) void*)(lds + (wave + 4 * i) * 1024), 16, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        for (int i = 0; i < 8; ++i) {
+            const uint16_t* src = (i < 4 ? p.a : p.w) + soff[i] + 64 * s;
+            if constexpr (DB) {
+                const unsigned dst = lds_base + buf * 32768 + (wave + 4 * i) * 1024;
+                unsigned keep_m0;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep_m0) : "v"(src), "s"(dst) : "memory");
+            } else {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
+                                                 (__attribute__((address_space(3))) void*)(lds + (wave + 4 * i) * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto compute = [&](int buf) {
+        const char* a_b = a_rd + buf * 32768;
+        const char* w_b = w_rd + buf * 32768;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int off = 16 * ((4 * ks + kg) ^ swz);
@@ -110,8 +134,8 @@ __global__ __launch_bounds__(256, 3) void dense16_gemm_kernel(DenseParams p) {
                 bf16x8 af[4], wf[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    af[i] = *reinterpret_cast<const bf16x8*>(a_rd + i * 2048 + off);
-                    wf[i] = *reinterpret_cast<const bf16x8*>(w_rd + i * 2048 + off);
+                    af[i] = *reinterpret_cast<const bf16x8*>(a_b + i * 2048 + off);
+                    wf[i] = *reinterpret_cast<const bf16x8*>(w_b + i * 2048 + off);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -121,14 +145,35 @@ __global__ __launch_bounds__(256, 3) void dense16_gemm_kernel(DenseParams p) {
                 half8 af[4], wf[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    af[i] = *reinterpret_cast<const half8*>(a_rd + i * 2048 + off);
-                    wf[i] = *reinterpret_cast<const half8*>(w_rd + i * 2048 + off);
+                    af[i] = *reinterpret_cast<const half8*>(a_b + i * 2048 + off);
+                    wf[i] = *reinterpret_cast<const half8*>(w_b + i * 2048 + off);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[j][i], 0, 0, 0);
             }
+        }
+    };
+    if constexpr (DB) {
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        for (int s = 0; s < ns; ++s) {
+            if (s + 1 < ns) issue(s + 1, (s + 1) & 1);
+            compute(s & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile s+1 landed (this wave's pieces) ...
+            lds_barrier();                                          // ... for every wave; every wave is done reading tile s
+        }
+    } else {
+        for (int s = 0; s < ns; ++s) {
+            lds_barrier();                                        // every wave is done reading the previous stage
+            issue(s, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            compute(0);
         }
     }
 
@@ -149,6 +194,15 @@ __global__ __launch_bounds__(256, 3) void dense16_gemm_kernel(DenseParams p) {
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + 64 * wr + 16 * i + r16;
             float v[4];
+            if (p.tab && n < p.N) {
+                const int mm = m < p.M ? m : p.M - 1;
+                const int t = mm / (p.H * p.W), rem = mm - t * (p.H * p.W), yy = rem / p.W, xx = rem - yy * p.W;
+                const float4 a0 = *reinterpret_cast<const float4*>(p.tab + (long)(p.t0 + t) * p.tab_ld + n);
+                const float4 a1 = *reinterpret_cast<const float4*>(p.tab + (long)(p.y0 + yy) * p.tab_ld + n);
+                const float4 a2 = *reinterpret_cast<const float4*>(p.tab + (long)(p.x0 + xx) * p.tab_ld + n);
+                acc[j][i][0] += a0.x + a1.x + a2.x; acc[j][i][1] += a0.y + a1.y + a2.y;
+                acc[j][i][2] += a0.z + a1.z + a2.z; acc[j][i][3] += a0.w + a1.w + a2.w;
+            }
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
                 v[qq] = (n + qq < p.N) ? acc[j][i][qq] + bias[qq] : 0.f;
@@ -281,8 +335,11 @@ extern "C" int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w,
                                       const void* b, int32_t b_dt, int32_t M, int32_t N, int32_t K, int32_t act,
                                       void* out_f16, int64_t ldo, int32_t n_store,
                                       void* y, int32_t y_dt, int64_t ldy, const void* res, int64_t ldr,
-                                      float* ssq, void* stream) {
+                                      float* ssq, const float* row_tab, int64_t row_tab_ld, int32_t tab_H, int32_t tab_W,
+                                      int32_t tab_t0, int32_t tab_y0, int32_t tab_x0, void* stream) {
     HICOM_REQUIRE(a && w && (out_f16 || y || ssq), HICOM_EINVAL, "dense16_gemm: NULL pointer / no output");
+    if (row_tab) HICOM_REQUIRE(tab_H > 0 && tab_W > 0 && row_tab_ld >= N && row_tab_ld % 4 == 0 && (uintptr_t)row_tab % 16 == 0 &&
+                                   M % (tab_H * tab_W) == 0, HICOM_EINVAL, "dense16_gemm: positional table layout");
     HICOM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, HICOM_EINVAL,
                   "dense16_gemm: bad shape M=%d N=%d K=%d (K %% 64, leading dimensions %% 8)", M, N, K);
     HICOM_REQUIRE(operand_dt == HICOM_DT_BF16 || operand_dt == HICOM_DT_F16, HICOM_EINVAL, "dense16_gemm: operands are bf16 or fp16");
@@ -298,9 +355,20 @@ extern "C" int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w,
     p.M = M; p.N = N; p.K = K; p.act = act; p.o16 = (_Float16*)out_f16; p.ldo = ldo; p.n_store = out_f16 ? n_store : 0;
     p.y = y; p.y_f32 = y_dt == HICOM_DT_F32; p.ldy = ldy; p.res = (const uint16_t*)res; p.ldr = ldr; p.ssq = ssq;
     p.tiles_m = (M + 127) / 128; p.tiles_n = (N + 127) / 128;
+    p.tab = row_tab; p.tab_ld = row_tab_ld; p.H = tab_H; p.W = tab_W; p.t0 = tab_t0; p.y0 = tab_y0; p.x0 = tab_x0;
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
-    if (operand_dt == HICOM_DT_BF16) hipLaunchKernelGGL(dense16_gemm_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(dense16_gemm_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    static int db = -1;
+    if (db < 0) {
+        const char* e = getenv("HICOM_DENSE_DB");                  // dev switch for A/B runs
+        db = (e && e[0] == '1') ? 1 : 0;                           // default: one stage, three workgroups per CU (A/B: equal)
+    }
+    if (db) {
+        if (operand_dt == HICOM_DT_BF16) hipLaunchKernelGGL((dense16_gemm_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((dense16_gemm_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        if (operand_dt == HICOM_DT_BF16) hipLaunchKernelGGL((dense16_gemm_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((dense16_gemm_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
     return hicom_host::check_launch("dense16_gemm");
 }
 

@@ -48,6 +48,9 @@ struct StreamParams {
     const float* s_in;     // [rows_pad][score_stride] raw logits S written by the forward pass
     const float* ml;       // [rows][2] (M, L) of the forward softmax
     const float* delta;    // [rows] dctx_r . ctx_r
+    // clip-scale variant (forward): logit = (qt . x + pos + row_const[r]) * inv_norm[n]
+    const float* inv_norm; // [N] or NULL
+    const float* row_const;// [rows_pad] or NULL
 };
 
 // bit rotation of the row index used as the 16-byte-chunk swizzle (bijective on 0..15)
@@ -148,9 +151,15 @@ __global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
     // backward: the forward's logits of (row r16, tokens 4*sig(kg)..+3), fetched one tile ahead like the positional terms
     f32x4 s_next = f32x4{0.f, 0.f, 0.f, 0.f};
     float bw_m = 0.f, bw_linv = 0.f, bw_delta = 0.f;
+    const float crow = (!BWD && p.row_const) ? p.row_const[row_glob] : 0.f;
     auto fetch_s = [&](int tile) {
-        if constexpr (BWD)
+        if constexpr (BWD) {
             s_next = *reinterpret_cast<const f32x4*>(p.s_in + row_glob * p.score_stride + (long)tile * 16 + 4 * sig(kg));
+        } else if (p.inv_norm) {        // per-token key norms of this lane's 4 tokens (tail tile: clamped, masked later)
+            const long nb = (long)tile * 16 + 4 * sig(kg);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_next[j] = p.inv_norm[nb + j < p.N ? nb + j : p.N - 1];
+        }
     };
     if constexpr (BWD) {
         if (row_glob < p.rows) {
@@ -210,6 +219,10 @@ __global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
         const long n0 = (long)tile * 16 + 4 * sig(kg);
 #pragma unroll
         for (int j = 0; j < 4; ++j) lg[j] += padd[j];
+        if (!BWD && p.inv_norm) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lg[j] = (lg[j] + crow) * s_cur[j];
+        }
         float pr[4];
         if constexpr (BWD) {
             // dS = softmax weight x (dP - delta); padded rows (state 0, 0, 0) and tail tokens contribute nothing
@@ -542,13 +555,13 @@ extern "C" int hicom_global_stream_nparts(int64_t N, int32_t rows_pad) {
     return (int)(want < cap ? want : cap);
 }
 
-extern "C" int hicom_global_stream_fwd(const void* x, int64_t N, int32_t E,
+static int global_stream_launch(const void* x, int64_t N, int32_t E,
                                        const void* qt_hi, const void* qt_lo, int32_t rows, int32_t rows_pad,
                                        const float* pos_a, int32_t pos_stride,
                                        int32_t H, int32_t W, int32_t t_index0, int32_t y_index0, int32_t x_index0,
                                        float* scores, int64_t score_stride,
                                        float* part_m, float* part_l, float* part_acc, int32_t nparts,
-                                       void* stream) {
+                                       const float* inv_norm, const float* row_const, void* stream) {
     HICOM_REQUIRE(x && qt_hi && qt_lo && scores && part_m && part_l && part_acc, HICOM_EINVAL, "global_stream: NULL pointer");
     HICOM_REQUIRE(E == 1152 || E == 768, HICOM_EUNSUP, "global_stream: E=%d (only 1152 / 768)", E);
     HICOM_REQUIRE(N > 0 && N < (1L << 31), HICOM_EINVAL, "global_stream: N out of range");
@@ -569,13 +582,14 @@ extern "C" int hicom_global_stream_fwd(const void* x, int64_t N, int32_t E,
     p.part_m = part_m; p.part_l = part_l; p.part_acc = part_acc; p.rows_pad = rows_pad; p.rows = rows;
     p.ntiles = (int)((N + 15) / 16);
     p.s_in = nullptr; p.ml = nullptr; p.delta = nullptr;
+    p.inv_norm = inv_norm; p.row_const = row_const;
     dim3 grid((unsigned)nparts, (unsigned)(rows_pad / 16));
     hipStream_t s = (hipStream_t)stream;
     // many rows: the wide form (two row groups per workgroup, three-deep ring) when its limits hold
     const long tiles_per_part = (p.ntiles + nparts - 1) / nparts + 1;
     const bool span_ok = !pos_a || (tiles_per_part * 16 + p.HW - 1) / p.HW + 1 <= kWideFrames;
     const char* force_narrow = getenv("HICOM_GLOBAL_NARROW");      // dev / test switch: always take the one-row-group kernel
-    if (!(force_narrow && force_narrow[0] == '1') && E == 1152 && rows_pad > 16 && rows_pad % (16 * kWideRG) == 0 && (!pos_a || (H <= 64 && W <= 64)) && span_ok) {
+    if (!inv_norm && !(force_narrow && force_narrow[0] == '1') && E == 1152 && rows_pad > 16 && rows_pad % (16 * kWideRG) == 0 && (!pos_a || (H <= 64 && W <= 64)) && span_ok) {
         const int S = kWideFrames + (pos_a ? H + W : 0);
         const size_t smem = (size_t)kWideBuf * 9 * 4096 + (size_t)kWideRG * 4 * 1024 + 64 + (size_t)kWideRG * 16 * S * 4;
         static bool wide_attr = false;
@@ -603,6 +617,29 @@ extern "C" int hicom_global_stream_fwd(const void* x, int64_t N, int32_t E,
     return hicom_host::check_launch("global_stream");
 }
 
+extern "C" int hicom_global_stream_fwd(const void* x, int64_t N, int32_t E,
+                                       const void* qt_hi, const void* qt_lo, int32_t rows, int32_t rows_pad,
+                                       const float* pos_a, int32_t pos_stride,
+                                       int32_t H, int32_t W, int32_t t_index0, int32_t y_index0, int32_t x_index0,
+                                       float* scores, int64_t score_stride,
+                                       float* part_m, float* part_l, float* part_acc, int32_t nparts,
+                                       void* stream) {
+    return global_stream_launch(x, N, E, qt_hi, qt_lo, rows, rows_pad, pos_a, pos_stride, H, W, t_index0, y_index0, x_index0, scores,
+                                score_stride, part_m, part_l, part_acc, nparts, nullptr, nullptr, stream);
+}
+
+extern "C" int hicom_global_stream_clip_fwd(const void* x, int64_t N, int32_t E,
+                                            const void* qt_hi, const void* qt_lo, int32_t rows, int32_t rows_pad,
+                                            const float* pos_a, int32_t pos_stride,
+                                            int32_t H, int32_t W, int32_t t_index0, int32_t y_index0, int32_t x_index0,
+                                            const float* inv_norm, const float* row_const,
+                                            float* scores, int64_t score_stride,
+                                            float* part_m, float* part_l, float* part_acc, int32_t nparts, void* stream) {
+    HICOM_REQUIRE(inv_norm && row_const, HICOM_EINVAL, "global_stream_clip: NULL pointer");
+    return global_stream_launch(x, N, E, qt_hi, qt_lo, rows, rows_pad, pos_a, pos_stride, H, W, t_index0, y_index0, x_index0, scores,
+                                score_stride, part_m, part_l, part_acc, nparts, inv_norm, row_const, stream);
+}
+
 // ---- attention backward over the stream (training path) --------------------------------------------
 // dctx_hi / dctx_lo : bf16 [rows_pad, E] hi / lo planes of the upstream gradients of the per-head contexts (rows >= rows zero)
 // pos_b             : f32 [rows_pad, pos_stride] = dctx . PE^T (score-side table of dP), or NULL
@@ -628,7 +665,7 @@ extern "C" int hicom_global_stream_bwd(const void* x, int64_t N, int32_t E, cons
     p.scores = ds_out; p.score_stride = score_stride;
     p.part_m = nullptr; p.part_l = nullptr; p.part_acc = part_acc; p.rows_pad = rows_pad; p.rows = rows;
     p.ntiles = (int)((N + 15) / 16);
-    p.s_in = s_in; p.ml = ml; p.delta = delta;
+    p.s_in = s_in; p.ml = ml; p.delta = delta; p.inv_norm = nullptr; p.row_const = nullptr;
     dim3 grid((unsigned)nparts, (unsigned)(rows_pad / 16));
     hipStream_t s = (hipStream_t)stream;
     if (E == 1152) {

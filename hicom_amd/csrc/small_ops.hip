@@ -271,9 +271,51 @@ __global__ __launch_bounds__(256) void place_blocks_kernel(const char* src, int 
     for (int c = lane * 16; c < row_bytes; c += 64 * 16) *reinterpret_cast<u32x4*>(d + c) = *reinterpret_cast<const u32x4*>(s + c);
 }
 
+// clip-scale global stage: L2-normalise the projected queries (reference projector.py:185) and form the key-bias constants
+__global__ __launch_bounds__(256) void clip_query_prep_kernel(float* qp, const uint16_t* bk, int nh, int E, float scale, float* c) {
+    __shared__ float red[4];
+    const int q = blockIdx.x, tid = threadIdx.x, hd = E / nh;
+    float ss = 0.f;
+    for (int i = tid; i < E; i += 256) { const float v = qp[(long)q * E + i]; ss = fmaf(v, v, ss); }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float inv = 1.0f / sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    for (int i = tid; i < E; i += 256) qp[(long)q * E + i] *= inv;
+    __syncthreads();
+    const int lane = tid & 63;
+    for (int h = tid >> 6; h < nh; h += 4) {
+        float d = 0.f;
+        if (bk)
+            for (int j = lane; j < hd; j += 64) d = fmaf(qp[(long)q * E + h * hd + j], bf16_to_f32(bk[h * hd + j]), d);
+        d = wave_sum(d);
+        if (lane == 0) c[q * nh + h] = scale * d;
+    }
+}
+
+__global__ __launch_bounds__(256) void inv_norm_kernel(const float* ssq, int parts, long M, float* inv) {
+    const long m = (long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float s = 0.f;
+    for (int k = 0; k < parts; ++k) s += ssq[(long)k * M + m];
+    inv[m] = 1.0f / sqrtf(s);
+}
+
 }  // namespace hicom
 
 using namespace hicom;
+
+extern "C" int hicom_clip_query_prep_fwd(float* qp, const void* b_k, int32_t nq, int32_t nh, int32_t E, float scale, float* c, void* stream) {
+    HICOM_REQUIRE(qp && c && nq > 0 && nh > 0 && E > 0 && E % nh == 0, HICOM_EINVAL, "clip_query_prep: bad arguments");
+    hipLaunchKernelGGL(clip_query_prep_kernel, dim3((unsigned)nq), dim3(256), 0, (hipStream_t)stream, qp, (const uint16_t*)b_k, nh, E, scale, c);
+    return hicom_host::check_launch("clip_query_prep");
+}
+
+extern "C" int hicom_inv_norm_fwd(const float* ssq, int32_t parts, int64_t M, float* inv, void* stream) {
+    HICOM_REQUIRE(ssq && inv && parts > 0 && M > 0, HICOM_EINVAL, "inv_norm: bad arguments");
+    hipLaunchKernelGGL(inv_norm_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ssq, parts, (long)M, inv);
+    return hicom_host::check_launch("inv_norm");
+}
 
 static int launch_linear(const LinearParams& p, void* stream) {
     const int M = p.M, N = p.N;

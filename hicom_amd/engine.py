@@ -113,7 +113,9 @@ def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, 
         a.lw0_f16, a.lw2_f16 = w0_16.data_ptr(), w2_16.data_ptr()
         keep += [w0_16, w2_16]
     if gc is not None:
-        gc._check_native(proj.global_logit)
+        gc._check_native(None)
+        if proj.global_logit is not None:
+            raise NotImplementedError("the one-call executor has no clip-scale global stage (use forward_stepwise)")
         q_in, n_rows = gc.injected_queries(guide_embed)
         keep.append(q_in)
         att = gc.attn_layer

@@ -29,7 +29,8 @@ EXPORTS = (
     "hicom_compressor_fwd", "hicom_linear_to_rows_fwd", "hicom_fused_stream_fwd", "hicom_fused_stream_nparts",
     "hicom_planes_gemm_fwd", "hicom_row_ln_fwd", "hicom_small_mha_fwd", "hicom_place_blocks_fwd",
     "hicom_global_stream_bwd", "hicom_readout16_gemm_fwd", "hicom_to_f16_fwd", "hicom_merge_vproj_fwd",
-    "hicom_dense16_gemm_fwd", "hicom_ln_stream_fwd", "hicom_to_f16_padded_fwd",
+    "hicom_dense16_gemm_fwd", "hicom_ln_stream_fwd", "hicom_to_f16_padded_fwd", "hicom_clip_query_prep_fwd", "hicom_inv_norm_fwd",
+    "hicom_global_stream_clip_fwd",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -119,7 +120,12 @@ def lib() -> C.CDLL:
     L.hicom_readout16_gemm_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i64, i64, i32, C.POINTER(AuxGemv), vp]
     L.hicom_to_f16_fwd.argtypes = [vp, i32, vp, i64, vp]
     L.hicom_to_f16_padded_fwd.argtypes = [vp, i32, i64, i64, vp, i64, vp]
-    L.hicom_dense16_gemm_fwd.argtypes = [vp, i64, vp, i64, i32, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, i32, i64, vp, i64, vp, vp]
+    L.hicom_dense16_gemm_fwd.argtypes = [vp, i64, vp, i64, i32, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, i32, i64, vp, i64, vp,
+                                         vp, i64, i32, i32, i32, i32, i32, vp]
+    L.hicom_clip_query_prep_fwd.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp]
+    L.hicom_inv_norm_fwd.argtypes = [vp, i32, i64, vp, vp]
+    L.hicom_global_stream_clip_fwd.argtypes = [vp, i64, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64,
+                                               vp, vp, vp, i32, vp]
     L.hicom_ln_stream_fwd.argtypes = [vp, i32, i64, vp, vp, vp, vp, i32, f32, vp, i32, i32, i32, vp]
     L.hicom_merge_vproj_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.hicom_fused_stream_nparts.argtypes = [i32]
@@ -355,7 +361,7 @@ def to_f16_padded(src, ld):
     return dst
 
 
-def dense16_gemm(a, w, b, N=None, K=None, act=ACT_NONE, out_f16=None, n_store=None, y=None, res=None, ssq=None):
+def dense16_gemm(a, w, b, N=None, K=None, act=ACT_NONE, out_f16=None, n_store=None, y=None, res=None, ssq=None, row_tab=None):
     """C = epi(A . W^T + b) on matrix cores; a [M, lda], w [N, ldw] both fp16 or both bf16 (see include/hicom_hip.h)."""
     if a.dtype != w.dtype or a.dtype not in (torch.float16, torch.bfloat16):
         raise HicomNativeError("dense16_gemm: operands are both fp16 or both bf16")
@@ -366,8 +372,28 @@ def dense16_gemm(a, w, b, N=None, K=None, act=ACT_NONE, out_f16=None, n_store=No
                                         M, N, K, act, _ptr(out_f16), out_f16.shape[1] if out_f16 is not None else 0,
                                         (out_f16.shape[1] if n_store is None else n_store) if out_f16 is not None else 0,
                                         _ptr(y), _dt(y) if y is not None else 0, y.shape[1] if y is not None else 0,
-                                        _ptr(res), res.shape[1] if res is not None else 0, _ptr(ssq), _stream()),
+                                        _ptr(res), res.shape[1] if res is not None else 0, _ptr(ssq),
+                                        _ptr(row_tab[0]) if row_tab else None, row_tab[0].shape[1] if row_tab else 0,
+                                        *(row_tab[1:] if row_tab else (0, 0, 0, 0, 0)), _stream()),
            "hicom_dense16_gemm_fwd")
+
+
+def clip_query_prep(qp, b_k, nh, scale, c):
+    nq, E = qp.shape
+    _check(lib().hicom_clip_query_prep_fwd(_ptr(qp), _ptr(b_k), nq, nh, E, scale, _ptr(c), _stream()), "hicom_clip_query_prep_fwd")
+
+
+def inv_norm(ssq, inv):
+    parts, M = ssq.shape
+    _check(lib().hicom_inv_norm_fwd(_ptr(ssq), parts, M, _ptr(inv), _stream()), "hicom_inv_norm_fwd")
+
+
+def global_stream_clip(x, N, qhi, qlo, pos_a, H, W, t0i, y0i, x0i, inv, row_const, scores, part_m, part_l, part_acc, rows):
+    E = x.shape[-1]
+    _check(lib().hicom_global_stream_clip_fwd(_ptr(x), N, E, _ptr(qhi), _ptr(qlo), rows, qhi.shape[0], _ptr(pos_a),
+                                              pos_a.shape[1] if pos_a is not None else 0, H, W, t0i, y0i, x0i, _ptr(inv), _ptr(row_const),
+                                              _ptr(scores), scores.shape[1], _ptr(part_m), _ptr(part_l), _ptr(part_acc),
+                                              part_m.shape[0], _stream()), "hicom_global_stream_clip_fwd")
 
 
 def ln_stream(x, gamma, beta, out, src=None, alpha=None, eps=1e-6):

@@ -174,9 +174,15 @@ def _linear_params(lin: nn.Linear):
     return lin.weight.detach(), (lin.bias.detach() if lin.bias is not None else None)
 
 
-def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i):
+def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i, clip=None, kpe_t=None):
     """Streams the tokens x2 [N, E] (bf16) once against the folded queries of q_in [nq, E]: returns the un-normalised
-    online-softmax state (ml [R,2], acc [R,E]), R = nq * heads (ref :180-215 restated)."""
+    online-softmax state (ml [R,2], acc [R,E]), R = nq * heads (ref :180-215 restated).
+
+    clip = log logit_scale (a float): the clip-scale variant (ref :184-191).  Queries and keys are L2-normalised over the
+    full projected width before the heads are split, so  logit_h(n) = e^ls (qhat_h . k_h(n)) / ||k(n)|| + logit_bias
+    (the bias is a per-row shift: softmax cancels it).  k(n) = W_k (x_n + pos_n) + b_k never exists in memory: its norm
+    comes from a dense MFMA GEMM with a row-sum-of-squares epilogue (hicom_dense16_gemm_fwd, the positional part as
+    three rows of kpe_t = PE . W_k^T per token), the numerator from the usual folded queries."""
     E, nh = att.embed_dim, att.num_heads
     _require_bf16_cuda("key / value tokens", x2)
     N, dev = x2.shape[0], x2.device
@@ -188,7 +194,22 @@ def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i):
     qp = _f32((nq, E), dev)
     nv.linear(q_in, wq, bq, qp)
     qt = _f32((R, E), dev)
-    nv.fold_query(qp, wk, nh, att.scale, qt)
+    inv = row_const = None
+    if clip is not None:
+        scale = math.exp(clip)
+        row_const = torch.zeros((rows_pad,), dtype=torch.float32, device=dev)
+        nv.clip_query_prep(qp, att.k_proj.bias.detach() if att.k_proj.bias is not None else None, nh, scale, row_const)
+        nv.fold_query(qp, wk, nh, scale, qt)                   # qp is now qhat
+        ntile = (E + 127) // 128
+        ssq = _f32((2 * ntile, N), dev)
+        tab = None
+        if pe is not None:
+            tab = (kpe_t, H, W, t0i, y0i, x0i)
+        nv.dense16_gemm(x2, wk, att.k_proj.bias.detach() if att.k_proj.bias is not None else None, ssq=ssq, row_tab=tab)
+        inv = _f32((N,), dev)
+        nv.inv_norm(ssq, inv)
+    else:
+        nv.fold_query(qp, wk, nh, att.scale, qt)
     qhi = torch.empty((rows_pad, E), dtype=torch.bfloat16, device=dev)
     qlo = torch.empty_like(qhi)
     nv.split_bf16(qt, rows_pad, qhi, qlo)
@@ -203,7 +224,10 @@ def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i):
     scores = _f32((rows_pad, stride), dev)
     part_m, part_l = _f32((nparts, rows_pad), dev), _f32((nparts, rows_pad), dev)
     part_acc = _f32((nparts, rows_pad, E), dev)
-    nv.global_stream(x2, N, qhi, qlo, pos_a, H, W, t0i, y0i, x0i, scores, part_m, part_l, part_acc, rows=R)
+    if inv is not None:
+        nv.global_stream_clip(x2, N, qhi, qlo, pos_a, H, W, t0i, y0i, x0i, inv, row_const, scores, part_m, part_l, part_acc, R)
+    else:
+        nv.global_stream(x2, N, qhi, qlo, pos_a, H, W, t0i, y0i, x0i, scores, part_m, part_l, part_acc, rows=R)
     ml, acc = _f32((R, 2), dev), _f32((R, E), dev)
     T = N // (H * W)
     scratch = _f32((R * T * (H + W + 2),), dev) if pe is not None else None
@@ -433,9 +457,8 @@ class GlobalCompressor(nn.Module):
     def _check_native(self, logit_scale):
         if self.use_guide not in (None, "off", "direct", "coarse", "fine"):
             raise NotImplementedError(f"GlobalCompressor: use_guide={self.use_guide!r}")
-        if logit_scale is not None:
-            raise NotImplementedError("GlobalCompressor: the clip-scale variant normalises the PROJECTED keys "
-                                      "(ref :184-186), which does not fold into the queries; no HIP path yet")
+        # (clip-scale, logit_scale given: the operator-by-operator path -- _stream_attention(clip=...) -- has it; the
+        # one-call executor does not, HIComProjector.forward routes such projectors to forward_stepwise)
 
     def injected_queries(self, guide_embed) -> Tuple[torch.Tensor, int]:
         """[nq_eff, E] distinct injected query rows (bf16 or f32) and how many output rows they stand for.
@@ -454,7 +477,22 @@ class GlobalCompressor(nn.Module):
         q, shared = inj.inject(self.guide_injector, self.use_guide, self.query.detach(), guide_embed)
         return q.reshape(-1, self.embed_dim).contiguous(), self.num_queries
 
-    def partial_context(self, frames_feature, q_in, t_offset: int = 0):
+    def pos_kpe_t(self, t_cap: int, H: int, W: int, device):
+        """kpe_t [P, E] = PE . W_k^T: the projected positional embedding per table row (clip-scale key norms); weight-only,
+        cached like kpe."""
+        pe, cap = self.pos_tables(t_cap, H, W, device)
+        wk = self.attn_layer.k_proj.weight
+        key = ("kpe_t", H, W, cap, str(device))
+        stamp = (wk.data_ptr(), wk._version, pe.data_ptr())
+        hit = self._pe_cache.get(key)
+        if hit is None or hit[1] != stamp:
+            t = _f32((pe.shape[0], self.embed_dim), device)
+            nv.linear(pe, wk.detach(), None, t)
+            hit = (t, stamp)
+            self._pe_cache[key] = hit
+        return hit[0]
+
+    def partial_context(self, frames_feature, q_in, t_offset: int = 0, logit_scale=None):
         """Streams this call's frames once: returns (ml [R,2], acc [R,E], raw logits [rows_pad, N']) -- the un-normalised
         online-softmax state for R = nq_eff * num_heads folded query rows (ref :180-215 restated)."""
         ff = frames_feature.contiguous()
@@ -465,7 +503,11 @@ class GlobalCompressor(nn.Module):
         if self.use_pos_emb:
             pe, cap = self.pos_tables(t_offset + T, H, W, ff.device)
             t0i, y0i, x0i = t_offset, cap, cap + H
-        return _stream_attention(self.attn_layer, ff.view(T * H * W, E), q_in, pe, H, W, t0i, y0i, x0i)
+        clip, kpe_t = None, None
+        if logit_scale is not None:
+            clip = float(logit_scale)
+            kpe_t = self.pos_kpe_t(t_offset + T, H, W, ff.device) if self.use_pos_emb else None
+        return _stream_attention(self.attn_layer, ff.view(T * H * W, E), q_in, pe, H, W, t0i, y0i, x0i, clip, kpe_t)
 
     def finish(self, ml_sets, acc_sets, q_in, out, row0: int, n_rows: int):
         """Combine shard states, apply v_proj per head, out_proj + residual, readout, and write
@@ -496,7 +538,7 @@ class GlobalCompressor(nn.Module):
     def forward_into(self, frames_feature, guide_embed, logit_scale, out, row0: int, logit_bias=None):
         self._check_native(logit_scale)
         q_in, n_rows = self.injected_queries(guide_embed)
-        ml, acc, _ = self.partial_context(frames_feature, q_in)
+        ml, acc, _ = self.partial_context(frames_feature, q_in, logit_scale=logit_scale)
         self.finish(ml.unsqueeze(0), acc.unsqueeze(0), q_in, out, row0, n_rows)
 
     def forward(self, frames_feature, frames_embed, guide_embed, modal, logit_scale=None, logit_bias=None):
@@ -585,7 +627,7 @@ class HIComProjector(nn.Module):
             from . import autograd
             return autograd.forward_with_grad(self, frames_feature, frames_embed, guide_embed, modal, image_newline)
         plain = all(c is None or c.is_plain for c in (self.local_compressor, self.global_compressor))
-        if self.use_executor and plain and not isinstance(frames_feature, dict):
+        if self.use_executor and plain and self.global_logit is None and not isinstance(frames_feature, dict):
             from . import engine
             return engine.run_dense(self, frames_feature, frames_embed, guide_embed, modal, image_newline,
                                     _out_dtype(self))
@@ -602,7 +644,7 @@ class HIComProjector(nn.Module):
             raise RuntimeError("forward_deferred is an inference API: call it under torch.no_grad() / inference_mode(), "
                                "or use forward() for training")
         plain = all(c is None or c.is_plain for c in (self.local_compressor, self.global_compressor))
-        if not plain or isinstance(frames_feature, dict):
+        if not plain or self.global_logit is not None or isinstance(frames_feature, dict):
             raise NotImplementedError("forward_deferred: dense inputs of the plain recipes")
         from . import engine
         return engine.run_dense(self, frames_feature, frames_embed, guide_embed, modal, image_newline, _out_dtype(self),

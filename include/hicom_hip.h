@@ -146,6 +146,16 @@ int hicom_global_stream_fwd(const void* x, int64_t N, int32_t E,
                             float* scores, int64_t score_stride,
                             float* part_m, float* part_l, float* part_acc, int32_t nparts,
                             void* stream);
+/* Same pass for the clip-scale variant (projector.py:184-191): logit[r, n] = (qt_r . x_n + pos terms + row_const[r]) *
+ * inv_norm[n], inv_norm f32 [N] = 1 / ||k_proj(x_n + pos_n)|| (hicom_inv_norm_fwd), row_const f32 [rows_pad]
+ * (hicom_clip_query_prep_fwd; padding rows 0).  One 16-row group per workgroup (any row count). */
+int hicom_global_stream_clip_fwd(const void* x, int64_t N, int32_t E,
+                                 const void* qt_hi, const void* qt_lo, int32_t rows, int32_t rows_pad,
+                                 const float* pos_a, int32_t pos_stride,
+                                 int32_t H, int32_t W, int32_t t_index0, int32_t y_index0, int32_t x_index0,
+                                 const float* inv_norm, const float* row_const,
+                                 float* scores, int64_t score_stride,
+                                 float* part_m, float* part_l, float* part_acc, int32_t nparts, void* stream);
 
 /* ---- backward of the global attention over the token stream (training) ------
  * Autograd through projector.py:197-215 in the folded form: with the forward's logits S (the `scores`
@@ -276,13 +286,25 @@ int hicom_merge_vproj_fwd(const float* part_m, const float* part_l, const float*
  *   y [M, ldy] bf16 | f32: value + res[m, n] (res bf16 [M, ldr] or NULL);
  *   ssq f32 [2 * ceil(N/128)][M]: partial row sums of squares of (acc + b), summed by the consumer (key norms of the
  *           clip-scale global stage, projector.py:184-186).
+ * row_tab (may be NULL): f32 [*, row_tab_ld] table whose rows tab_t0 + m / (H*W), tab_y0 + (m / W) % H, tab_x0 + m % W are
+ *           added to row m before bias / ssq / activation: the projected positional embedding W . pos(m) of token m,
+ *           separable per axis (projector.py:57-101 through k_proj), so that x + pos is never formed.
  * The matrix-core-bound neighbours of the compressor: the SigLIP pooling-head projection that produces frames_embed
  * (encoder.py:284-286), the k / v adaptor MLPs (projector.py:533-534). */
 int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w, int64_t ldw, int32_t operand_dt,
                            const void* b, int32_t b_dt, int32_t M, int32_t N, int32_t K, int32_t act,
                            void* out_f16, int64_t ldo, int32_t n_store,
                            void* y, int32_t y_dt, int64_t ldy, const void* res, int64_t ldr,
-                           float* ssq, void* stream);
+                           float* ssq, const float* row_tab, int64_t row_tab_ld, int32_t tab_H, int32_t tab_W,
+                           int32_t tab_t0, int32_t tab_y0, int32_t tab_x0, void* stream);
+
+/* ---- clip-scale on the global stage (projector.py:184-191) ---------------------------------------------------------
+ * hicom_clip_query_prep_fwd: qp f32 [nq, E] (q_proj output) is L2-normalised in place over E; c[q*nh + h] =
+ *   scale * sum_j qhat[q, h*hd + j] * b_k[h*hd + j]  (the key-bias part of the logit, which no longer cancels once
+ *   every key is divided by its own norm).  b_k bf16 [E] or NULL.
+ * hicom_inv_norm_fwd: inv[m] = 1 / sqrt(sum_{s < parts} ssq[s * M + m])  (key norms from hicom_dense16_gemm_fwd's ssq). */
+int hicom_clip_query_prep_fwd(float* qp, const void* b_k, int32_t nq, int32_t nh, int32_t E, float scale, float* c, void* stream);
+int hicom_inv_norm_fwd(const float* ssq, int32_t parts, int64_t M, float* inv, void* stream);
 /* out[m,:] = (1 - alpha) src[m,:] + alpha (LayerNorm_eps(x[m,:]) gamma + beta) over all tokens with 16-byte accesses:
  * x fp16 | bf16 | f32 [M, ldx]; gamma, beta, src (may be NULL) bf16; alpha device scalar or NULL (= 1); out fp16 | bf16
  * [M, E]; E % 8 == 0, E <= 1536.  head.layernorm of encoder.py:284 and the adaptor blend of projector.py:533-534. */

@@ -56,15 +56,40 @@ def test_clip_scale_local_matches_golden(golden):
     assert got.shape == ref.shape and np.abs(got - ref).max() <= TOL
 
 
-def test_unsupported_variant_fails_loudly():
-    """No silent fallback: the one variant without a HIP path (clip-scale on the GLOBAL stage, which
-    normalises the projected keys) raises instead of computing with PyTorch."""
-    case = cases.build_case("G1_direct_T8")
+def test_clip_scale_global_matches_golden(golden):
+    """Clip-scale on the GLOBAL stage (reference projector.py:184-191: queries and PROJECTED keys L2-normalised over the full
+    width, logits * exp(logit_scale) + logit_bias): G8's stored `global` vector, direct compressor call as the fixture makes it."""
+    case = cases.build_case("G8_clip_scale")
     m = build_module(case)
-    m.set_clip_logits(glob=(torch.tensor(1.5, device="cuda"), torch.tensor(-2.0, device="cuda")))
     ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
-    with pytest.raises(NotImplementedError):
-        m(ff, fe, g, "video", None)
+    gs, gb = (torch.tensor(v, device="cuda") for v in case.logit["glob"])
+    with torch.no_grad():
+        got = m.global_compressor(ff, fe, g, case.modal, gs, gb)
+    ref = golden["G8_clip_scale/global"]
+    assert tuple(got.shape) == ref.shape and np.abs(got.float().cpu().numpy() - ref).max() <= TOL
+
+
+def test_use_clip_scale_config_constructs_and_runs(golden):
+    """A projector configured with use_clip_scale='local,global' constructs (the reference reads the logits from the SigLIP
+    checkpoint there), refuses to run before set_clip_logits(), and then reproduces G8's local and global vectors through
+    HIComProjector.forward."""
+    import hicom_amd
+    case = cases.build_case("G8_clip_scale")
+    case.cfg.use_clip_scale = "local,global"
+    m = hicom_amd.build_vision_projector(case.cfg)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd.items()}, strict=True)
+    m = m.to(torch.bfloat16).cuda().eval()
+    m.return_fp32 = True
+    ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError):
+            m(ff, fe, g, case.modal, None)
+        m.set_clip_logits(local=case.logit["local"], glob=case.logit["glob"])
+        out = m(ff, fe, g, case.modal, None).float().cpu().numpy()
+    loc, glo = golden["G8_clip_scale/local"], golden["G8_clip_scale/global"]
+    nl = loc.reshape(-1, loc.shape[-1]).shape[0]
+    assert out.shape[0] == nl + glo.shape[0]
+    assert np.abs(out[:nl] - loc.reshape(nl, -1)).max() <= TOL and np.abs(out[nl:] - glo).max() <= TOL
 
 
 @pytest.mark.parametrize("name", ["G3b_direct_T5_raises", "G4c_image_T2_raises"])
