@@ -30,7 +30,7 @@ EXPORTS = (
     "hicom_planes_gemm_fwd", "hicom_row_ln_fwd", "hicom_small_mha_fwd", "hicom_place_blocks_fwd",
     "hicom_global_stream_bwd", "hicom_readout16_gemm_fwd", "hicom_to_f16_fwd", "hicom_merge_vproj_fwd",
     "hicom_dense16_gemm_fwd", "hicom_ln_stream_fwd", "hicom_to_f16_padded_fwd", "hicom_clip_query_prep_fwd", "hicom_inv_norm_fwd",
-    "hicom_global_stream_clip_fwd",
+    "hicom_global_stream_clip_fwd", "hicom_splice_rows_fwd", "hicom_splice_labels_fwd",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -119,6 +119,8 @@ def lib() -> C.CDLL:
                                          vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.hicom_readout16_gemm_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i64, i64, i32, C.POINTER(AuxGemv), vp]
     L.hicom_to_f16_fwd.argtypes = [vp, i32, vp, i64, vp]
+    L.hicom_splice_rows_fwd.argtypes = [vp, i64, i32, vp, vp]
+    L.hicom_splice_labels_fwd.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i64, vp, vp, vp]
     L.hicom_to_f16_padded_fwd.argtypes = [vp, i32, i64, i64, vp, i64, vp]
     L.hicom_dense16_gemm_fwd.argtypes = [vp, i64, vp, i64, i32, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, i32, i64, vp, i64, vp,
                                          vp, i64, i32, i32, i32, i32, i32, vp]
@@ -428,6 +430,20 @@ def merge_vproj(part_m, part_l, part_acc, rows, w_v, po, out_ml=None, out_ctx=No
     E = part_acc.shape[-1]
     _check(lib().hicom_merge_vproj_fwd(_ptr(part_m), _ptr(part_l), _ptr(part_acc), nparts, rows, rows_pad, E, _ptr(w_v), _ptr(po),
                                        _ptr(out_ml), _ptr(out_ctx), _stream()), "hicom_merge_vproj_fwd")
+
+
+def splice_rows(row_src, dst):
+    """dst [nrows, hidden] <- rows at the device addresses in row_src (int64 device tensor; 0 = zero row)."""
+    nrows = row_src.numel()
+    _check(lib().hicom_splice_rows_fwd(_ptr(row_src), nrows, dst.shape[-1] * dst.element_size(), _ptr(dst), _stream()),
+           "hicom_splice_rows_fwd")
+
+
+def splice_labels(labels, mask, idx_map, new_len, S, ignore_index, new_labels, new_mask):
+    B, Lmax = idx_map.shape
+    _check(lib().hicom_splice_labels_fwd(_ptr(labels), _ptr(mask), mask.element_size() if mask is not None else 0, _ptr(idx_map),
+                                         _ptr(new_len), B, S, Lmax, ignore_index, _ptr(new_labels), _ptr(new_mask), _stream()),
+           "hicom_splice_labels_fwd")
 
 
 def row_ln(x, norm, out, mul=None, add=None, src=None, alpha=None, eps=1e-6):

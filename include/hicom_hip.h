@@ -352,6 +352,19 @@ int hicom_row_ln_fwd(const void* x, int32_t x_dt, int64_t x_stride,
 int hicom_small_mha_fwd(const float* q, const float* k, const float* v, int32_t M, int32_t L,
                         int32_t nh, int32_t hd, float* out, void* stream);
 
+/* ---- splice of the compressed tokens into the LLM input embeddings (hicom_arch.py:271-373) ----------------------------
+ * hicom_splice_rows_fwd: dst [nrows, row_bytes] <- row r copied from the DEVICE address row_src[r] (uint64 table on the
+ *   device; 0 = a zero row: right padding).  Sources are rows of embed_tokens.weight and of the compressed-token tensors;
+ *   the host (hicom_amd/splice.py) plans the table from the token ids.  row_bytes % 16 == 0.
+ * hicom_splice_labels_fwd: new_labels int64 [B, Lmax] = labels[b, map[b,p]] where map >= 0, else ignore_index (visual
+ *   tokens and padding, :309-311,:344-348); new_mask [B, Lmax] = ones for the first new_len[b] - S positions, then the
+ *   original mask row, then zeros (:350-366); mask elements 1 (torch.bool) or 8 (torch.long) bytes.  labels / new_labels or
+ *   mask / new_mask may be NULL. */
+int hicom_splice_rows_fwd(const void* row_src, int64_t nrows, int32_t row_bytes, void* dst, void* stream);
+int hicom_splice_labels_fwd(const void* labels, const void* mask, int32_t mask_elem_bytes, const int32_t* map,
+                            const int32_t* new_len, int32_t B, int32_t S, int32_t Lmax, int64_t ignore_index,
+                            void* new_labels, void* new_mask, void* stream);
+
 /* ---- whole-forward executor ------------------------------------------------------------------
  * hicom_compressor_fwd enqueues HIComProjector.forward (projector.py:676-708) for one dense
  * [T,H,W,E] input as a fixed plan of kernel launches over a caller-owned workspace: the local

@@ -1,0 +1,121 @@
+"""the splice of compressed visual tokens into the LLM input embeddings (reference
+hicom_arch.py:271-373).  Integer / byte work: every comparison is bit-exact.
+
+CPU part: the oracle restatement against the fixture made by the reference's own method (golden_splice_v1.npz), and the
+product's host-side layout plan against the oracle.  GPU part: the HIP row placement + label / mask kernels."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import make_golden_splice as mg
+from oracle import splice_oracle as so
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def golden_splice():
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_splice_v1.npz"))
+
+
+@pytest.mark.parametrize("name", list(mg.SPLICE_CASES))
+def test_oracle_matches_reference_method(name, golden_splice):
+    ids, weight, feats, labels, mask = mg.build(name)
+    if mask is not None and labels is None and name == "never":
+        pytest.skip("")
+    m, e, l = so.splice(weight, ids, mask, labels, feats)
+    assert np.array_equal(e.numpy(), golden_splice[name + "/embeds"])
+    if labels is not None:
+        assert np.array_equal(l.numpy(), golden_splice[name + "/labels"])
+    if mask is not None:
+        assert np.array_equal(m.numpy().astype(np.int64), golden_splice[name + "/mask"])
+
+
+@pytest.mark.parametrize("name", list(mg.SPLICE_CASES))
+def test_host_plan_matches_oracle(name):
+    """plan_layout (pure integer host logic of the product) reproduces the oracle's row sources and lengths."""
+    from hicom_amd.splice import plan_layout
+    ids, weight, feats, labels, mask = mg.build(name)
+    kind, feat, new_len, Lmax = plan_layout(ids.numpy(), [f.shape[0] for f in feats])
+    _, e, _ = so.splice(weight, ids, None, None, feats)
+    assert e.shape[1] == Lmax
+    for b in range(ids.shape[0]):
+        for p in range(Lmax):
+            if kind[b, p] >= 0:
+                want = weight[ids[b, kind[b, p]]]
+            elif kind[b, p] == -1:
+                want = feats[feat[b, p, 0]][feat[b, p, 1]]
+            else:
+                want = torch.zeros(weight.shape[1])
+            assert torch.equal(e[b, p], want), (b, p)
+
+
+def test_text_only_and_decode_step_pass_through():
+    from hicom_amd.splice import prepare_inputs_labels_for_multimodal
+    ids = torch.tensor([[1, 2, 3]])
+    assert prepare_inputs_labels_for_multimodal(None, ids, None, "pkv", None, None) == (ids, None, "pkv", None, None)
+    one = torch.tensor([[5]])
+    out = prepare_inputs_labels_for_multimodal(None, one, None, None, None, [torch.zeros(1, 4)])
+    assert out[0] is one and out[3] is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(mg.SPLICE_CASES))
+def test_hip_splice_matches_reference_fixture(name, golden_splice):
+    from hicom_amd.splice import prepare_inputs_labels_for_multimodal
+    ids, weight, feats, labels, mask = mg.build(name)
+    emb = torch.nn.Embedding(mg.VOCAB, mg.HIDDEN).to(torch.bfloat16).cuda()
+    emb.weight.data.copy_(weight)
+    d = lambda t: None if t is None else t.cuda()
+    r_ids, r_mask, r_pkv, r_emb, r_lab = prepare_inputs_labels_for_multimodal(emb, d(ids), d(mask), "pkv", d(labels),
+                                                                              [f.to(torch.bfloat16).cuda() for f in feats])
+    torch.cuda.synchronize()
+    assert r_ids is None and r_pkv == "pkv"
+    assert np.array_equal(r_emb.float().cpu().numpy(), golden_splice[name + "/embeds"])     # values are bf16-representable
+    if labels is not None:
+        assert r_lab.dtype == torch.int64 and np.array_equal(r_lab.cpu().numpy(), golden_splice[name + "/labels"])
+    else:
+        assert r_lab is None
+    if mask is not None:
+        assert r_mask.dtype == mask.dtype and np.array_equal(r_mask.cpu().numpy().astype(np.int64), golden_splice[name + "/mask"])
+    else:
+        assert r_mask is None
+
+
+@pytest.mark.gpu
+def test_hip_splice_c4_shape_and_errors():
+    """BASELINE configs[3] shape: 680 compressed tokens of width 3584 (32 frames, Qwen2.5-7B) into two 2048-token prompts, one
+    of them text-only -> ragged batch; bit-exact against the oracle; the reference's failure modes."""
+    import time
+    from hicom_amd.splice import prepare_inputs_labels_for_multimodal
+    g = torch.Generator().manual_seed(1)
+    V, H, S = 4096, 3584, 2048
+    weight = torch.randn(V, H, generator=g).to(torch.bfloat16)
+    feats = [torch.randn(680, H, generator=g).to(torch.bfloat16), torch.randn(680, H, generator=g).to(torch.bfloat16)]
+    ids = torch.randint(0, V, (2, S), generator=g)
+    ids[0, 17] = -201
+    labels = torch.where(ids >= 0, ids, torch.full_like(ids, -100))
+    mask = torch.ones(2, S, dtype=torch.long)
+    mask[1, -5:] = 0
+    wm, we, wl = so.splice(weight.float(), ids, mask, labels, [f.float() for f in feats])
+    emb = torch.nn.Embedding(V, H).to(torch.bfloat16).cuda()
+    emb.weight.data.copy_(weight)
+    args = (emb, ids.cuda(), mask.cuda(), None, labels.cuda(), [f.cuda() for f in feats])
+    _, m, _, e, l = prepare_inputs_labels_for_multimodal(*args)
+    torch.cuda.synchronize()
+    assert e.shape == (2, S - 1 + 680, H)
+    assert torch.equal(e.float().cpu(), we) and torch.equal(l.cpu(), wl) and torch.equal(m.cpu(), wm)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        prepare_inputs_labels_for_multimodal(*args)
+    torch.cuda.synchronize()
+    print(f"\n[splice] C4 shape: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms per call ({e.numel() * 2 / 1e6:.1f} MB of rows)")
+    with pytest.raises(UnboundLocalError):                      # ragged batch with a mask but no labels (reference :352)
+        prepare_inputs_labels_for_multimodal(emb, ids.cuda(), mask.cuda(), None, None, [f.cuda() for f in feats])
+    with pytest.raises(IndexError):                             # more placeholders than feature tensors
+        prepare_inputs_labels_for_multimodal(emb, ids.cuda(), mask.cuda(), None, labels.cuda(), [feats[0].cuda()])
+    from hicom_amd import native as nv
+    with pytest.raises(nv.HicomNativeError):                    # no CPU path
+        prepare_inputs_labels_for_multimodal(torch.nn.Embedding(V, 8), ids, None, None, None, [torch.zeros(3, 8)])
