@@ -11,7 +11,7 @@ root, out = sys.argv[1], sys.argv[2]
 tot, disp = defaultdict(lambda: defaultdict(float)), defaultdict(lambda: defaultdict(set))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "hicom" not in r["Kernel_Name"]:
+        if "hicom::" not in r["Kernel_Name"]:
             continue
         k = r["Kernel_Name"].split("hicom::")[1].split("(")[0]
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"])

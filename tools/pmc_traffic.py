@@ -11,7 +11,7 @@ def per_kernel(sub, counter):
     tot, n = defaultdict(float), defaultdict(set)
     for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and "hicom" in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and "hicom::" in r["Kernel_Name"]:
                 k = r["Kernel_Name"].split("hicom::")[1].split("<")[0].split("(")[0]
                 tot[k] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
     return {k: (tot[k] / len(n[k]), len(n[k])) for k in tot}
