@@ -12,7 +12,8 @@ gradient checkpointing wants):
   dense weight gradients plain library GEMMs / outer products through torch (rocBLAS) in fp32 on the small
                          [Nw, 1152] / [9, 1152] tensors -- dW = dY^T X is not a kernel worth hand-writing
 
-Scope: the release recipe (`use_guide="direct"`, no adaptors, no clip-scale), dense video / image inputs, gradients of
+Scope: the release recipes of the training script -- `use_guide="direct"` (stage 2) and guide off (stage 1: pooled
+per-window queries, 32 learnable global queries) -- without adaptors or clip-scale, dense video / image inputs, gradients of
 every projector parameter and of `image_newline`.  Gradients w.r.t. the visual features and the guide embedding
 (stage 3 of the release script, where the SigLIP head and the guide encoder train too) are not built: asking for
 them raises instead of returning None silently.  Other recipes raise NotImplementedError.
@@ -36,7 +37,7 @@ def _gelu_grad(x):
 def _supported(proj) -> bool:
     lc, gc = proj.local_compressor, proj.global_compressor
     for c in (lc, gc):
-        if c is not None and not (c.is_plain and c.use_guide == "direct"):
+        if c is not None and not (c.is_plain and c.use_guide in ("direct", None, "off")):
             return False
     return proj.local_logit is None and proj.global_logit is None
 
@@ -107,36 +108,39 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout):
     if gc is not None:
         att = gc.attn_layer
         nh, hd = att.num_heads, att.head_dim
-        q_in, n_rows = gc.injected_queries(guide)                          # direct: the guide itself, one row
-        ml, acc, scores = gc.partial_context(ff, q_in)                     # HIP: forward logits + softmax state
+        # injected queries: the guide itself, one row ("direct": 32 identical output rows), or the 32 learnable queries
+        # (guide off, reference stage 1: IdentityMap injector, :586-587)
+        q_in, n_rows = gc.injected_queries(guide)
+        nq = q_in.shape[0]
+        ml, acc, scores = gc.partial_context(ff, q_in)                     # HIP: forward logits + softmax state, rows q*nh + h
         R = ml.shape[0]
-        ctxg = acc / ml[:, 1:2]                                            # per-head contexts [9, E]
-        g32 = q_in.float().reshape(-1)
+        ctxg = (acc / ml[:, 1:2]).view(nq, nh, E)                          # per-(query, head) contexts
+        q32 = q_in.float()
         Wq, bq = att.q_proj.weight.float(), att.q_proj.bias.float()
         Wk = att.k_proj.weight.float()
         Wv, bv = att.v_proj.weight.float(), att.v_proj.bias.float()
         Wo, bo = att.out_proj.weight.float(), att.out_proj.bias.float()
         G0, gb0 = gc.readout[0].weight.float(), gc.readout[0].bias.float()
         G2 = gc.readout[2].weight.float()
-        o = torch.einsum("hje,he->hj", Wv.view(nh, hd, E), ctxg).reshape(E) + bv          # ref :182,:215 after folding
-        pre = Wo @ o + bo + g32                                            # out_proj + residual with the injected query (:646)
-        a1 = G0 @ pre + gb0
+        o = torch.einsum("hje,qhe->qhj", Wv.view(nh, hd, E), ctxg).reshape(nq, E) + bv    # ref :182,:215 after folding
+        pre = o @ Wo.t() + bo + q32                                        # out_proj + residual with the injected query (:646)
+        a1 = pre @ G0.t() + gb0
         hid = torch.nn.functional.gelu(a1)
-        dtok = dout[n_local:n_local + n_rows].sum(0)                       # the 32 global rows are copies of one row
+        dtok = dout[n_local:n_local + n_rows].view(n_rows // nq, nq, -1).sum(0)   # direct: the 32 global rows are copies of one row
         P = "global_compressor."
-        grads[P + "readout.2.weight"] = torch.outer(dtok, hid)
-        grads[P + "readout.2.bias"] = dtok
-        da1 = (G2.t() @ dtok) * _gelu_grad(a1)
-        grads[P + "readout.0.weight"] = torch.outer(da1, pre)
-        grads[P + "readout.0.bias"] = da1
-        dpre = G0.t() @ da1
-        grads[P + "attn_layer.out_proj.weight"] = torch.outer(dpre, o)
-        grads[P + "attn_layer.out_proj.bias"] = dpre
-        do = Wo.t() @ dpre
-        grads[P + "attn_layer.v_proj.bias"] = do
-        grads[P + "attn_layer.v_proj.weight"] = (do.view(nh, hd, 1) * ctxg.view(nh, 1, E)).reshape(E, E)
-        dctx = torch.einsum("hje,hj->he", Wv.view(nh, hd, E), do.view(nh, hd)).contiguous()   # [9, E]
-        delta = (dctx * ctxg).sum(1).contiguous()
+        grads[P + "readout.2.weight"] = dtok.t() @ hid
+        grads[P + "readout.2.bias"] = dtok.sum(0)
+        da1 = (dtok @ G2) * _gelu_grad(a1)
+        grads[P + "readout.0.weight"] = da1.t() @ pre
+        grads[P + "readout.0.bias"] = da1.sum(0)
+        dpre = da1 @ G0
+        grads[P + "attn_layer.out_proj.weight"] = dpre.t() @ o
+        grads[P + "attn_layer.out_proj.bias"] = dpre.sum(0)
+        do = dpre @ Wo                                                     # [nq, E]
+        grads[P + "attn_layer.v_proj.bias"] = do.sum(0)
+        grads[P + "attn_layer.v_proj.weight"] = torch.einsum("qhj,qhe->hje", do.view(nq, nh, hd), ctxg).reshape(E, E)
+        dctx = torch.einsum("hje,qhj->qhe", Wv.view(nh, hd, E), do.view(nq, nh, hd)).reshape(R, E).contiguous()
+        delta = (dctx * ctxg.reshape(R, E)).sum(1).contiguous()
         # ---- attention backward over the token stream (HIP) ------------------------------------------------
         rows_pad = (R + 15) // 16 * 16
         dhi = torch.empty((rows_pad, E), dtype=torch.bfloat16, device=dev)
@@ -152,7 +156,7 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout):
             pos_b = torch.zeros((rows_pad, pe.shape[0]), dtype=torch.float32, device=dev)
             nv.linear(dctx, pe, None, pos_b, M=R)
         ds = torch.empty_like(scores)
-        nparts = nv.global_stream_nparts(N, rows_pad)
+        nparts = nv.global_stream_nparts(N, 16)
         part = torch.empty((nparts, rows_pad, E), dtype=torch.float32, device=dev)
         nv.global_stream_bwd(ff.view(N, E), N, dhi, dlo, pos_b, H if pe is not None else 1, W if pe is not None else N,
                              t0i, y0i, x0i, scores, ml, delta, ds, part, R)
@@ -160,15 +164,18 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout):
         if pe is not None:
             dS = ds[:R, :N].view(R, T, H, W)
             dqt = dqt + dS.sum((2, 3)) @ pe[t0i:t0i + T] + dS.sum((1, 3)) @ pe[y0i:y0i + H] + dS.sum((1, 2)) @ pe[x0i:x0i + W]
-        # ---- through the fold: qt_h = scale W_k,h^T (W_q g + b_q)_h  (ref :180-181,:193-197) -----------------
+        dqt = dqt.view(nq, nh, E)
+        # ---- through the fold: qt[q,h] = scale W_k,h^T (W_q q + b_q)[q, h-slice]  (ref :180-181,:193-197) ---------
         scale = att.scale
-        qp = Wq @ g32 + bq
-        grads[P + "attn_layer.k_proj.weight"] = scale * (qp.view(nh, hd, 1) * dqt.view(nh, 1, E)).reshape(E, E)
+        qp = (q32 @ Wq.t() + bq).view(nq, nh, hd)
+        grads[P + "attn_layer.k_proj.weight"] = scale * torch.einsum("qhj,qhe->hje", qp, dqt).reshape(E, E)
         grads[P + "attn_layer.k_proj.bias"] = torch.zeros(E, device=dev)   # a per-row logit shift: softmax cancels it exactly
-        dqp = scale * torch.einsum("hje,he->hj", Wk.view(nh, hd, E), dqt).reshape(E)
-        grads[P + "attn_layer.q_proj.weight"] = torch.outer(dqp, g32)
-        grads[P + "attn_layer.q_proj.bias"] = dqp
-        # global_compressor.query does not enter the direct recipe (ref :352-368: only its shape is used): no gradient
+        dqp = scale * torch.einsum("hje,qhe->qhj", Wk.view(nh, hd, E), dqt).reshape(nq, E)
+        grads[P + "attn_layer.q_proj.weight"] = dqp.t() @ q32
+        grads[P + "attn_layer.q_proj.bias"] = dqp.sum(0)
+        if gc.use_guide in (None, "off"):
+            grads[P + "query"] = dqp @ Wq + dpre                           # the learnable queries: through q_proj and the residual
+        # (direct: global_compressor.query does not enter the forward, ref :352-368 uses only its shape: no gradient)
     return grads, d_nl
 
 
@@ -177,11 +184,11 @@ def forward_with_grad(proj, frames_feature, frames_embed, guide_embed, modal, im
     some = frames_feature["patch"] if isinstance(frames_feature, dict) else frames_feature
     _require_bf16_cuda("frames_feature", some)
     if isinstance(frames_feature, dict) or not _supported(proj):
-        raise NotImplementedError("hicom_amd: the backward pass covers the release recipe (use_guide='direct', no adaptors, no "
-                                  "clip-scale, dense inputs); run other recipes under torch.no_grad() / inference_mode() -- "
+        raise NotImplementedError("hicom_amd: the backward pass covers use_guide='direct' and guide off without adaptors or "
+                                  "clip-scale, dense inputs; run other recipes under torch.no_grad() / inference_mode() -- "
                                   "forward() never returns a silently detached tensor")
     names, params = zip(*[(n, p) for n, p in proj.named_parameters()])
     ff = frames_feature.contiguous()
     fe = frames_embed.contiguous() if frames_embed is not None else None
-    return _CompressorFn.apply(proj, ff, fe, guide_embed.contiguous(), modal,
+    return _CompressorFn.apply(proj, ff, fe, guide_embed.contiguous() if guide_embed is not None else None, modal,
                                image_newline.contiguous() if image_newline is not None else None, names, *params)

@@ -22,7 +22,7 @@ from hicom_amd import synth            # noqa: E402
 import cases                            # noqa: E402
 
 GRAD_CASES = ["G1_direct_T8", "G4b_image_newline", "G9_grid", "G9_frame", "G10_peaky_direct", "G9_local_only", "G9_global_only",
-              "G3_direct_T7"]
+              "G3_direct_T7", "G2_off_T8", "G2b_off_string", "G10b_peaky_off", "G12_clip768_direct", "G12b_clip768_off", "G9_local22"]
 
 
 def cotangent(name, shape):

@@ -30,7 +30,8 @@ def _grad_cases():
 
 
 @pytest.mark.parametrize("name", ["G1_direct_T8", "G4b_image_newline", "G9_grid", "G9_frame", "G10_peaky_direct", "G9_local_only",
-                                  "G9_global_only", "G3_direct_T7"])
+                                  "G9_global_only", "G3_direct_T7", "G2_off_T8", "G2b_off_string", "G10b_peaky_off",
+                                  "G12_clip768_direct", "G12b_clip768_off", "G9_local22"])
 def test_parameter_gradients_match_reference_autograd(name, golden_grad):
     import make_golden_grad as mg
     from hicom_amd import autograd as hag
@@ -73,9 +74,9 @@ def test_parameter_gradients_match_reference_autograd(name, golden_grad):
 
 
 def test_unsupported_recipes_and_input_grads_refuse():
-    """Guide off / coarse have no backward yet, and gradients w.r.t. the inputs are not built: both must raise, never
+    """coarse / fine / adaptors have no backward yet, and gradients w.r.t. the inputs are not built: both must raise, never
     return a detached tensor or a silent None."""
-    for name in ("G2_off_T8", "G6_coarse"):
+    for name in ("G6_coarse", "G5_adaptkv"):
         case = cases.build_case(name)
         m = build_module(case).train()
         ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
