@@ -301,7 +301,7 @@ def main():
                 extras[k]["median"] = float(t.item())
 
     # ---- roofline of the dominant kernel (HIP events on the stream it is launched on) ----------
-    roofline = dominant_kernel_roofline(module, ff, fe, guide, args.steps)
+    roofline = dominant_kernel_roofline(module, sets, args.steps)
 
     alg_step = 3359232 * fpg + 18046976 * (args.hidden == 896) + n_out * args.hidden * 2 + 2304
     result = {
@@ -437,10 +437,13 @@ def secondary_sweep(args, device, ff, fe, guide):
                                                      "note": "joined forwards, best of 3 batches of 10; two-kernel path (local windows || wide global stream kernel)"}}
 
 
-def dominant_kernel_roofline(module, ff, fe, guide, iters):
+def dominant_kernel_roofline(module, sets, iters):
     """fused_ring_kernel reads both visual tensors (frames_embed + frames_feature) exactly once and
     produces the local contexts and the global partial state: its algorithmic bytes are SURVEY.md
-    §8(d)'s 3,359,232 B per frame x frames (+ the fp32 local contexts it writes)."""
+    §8(d)'s 3,359,232 B per frame x frames (+ the fp16 local contexts it writes).  The launches rotate through the same
+    distinct input sets as the timed loop: the kernel is measured reading HBM, as it runs in the step, not re-reading
+    one Infinity-Cache-resident set."""
+    ff, fe, guide = sets[0]
     lc, gc = module.local_compressor, module.global_compressor
     T, H, W, _ = ff.shape
     dev = ff.device
@@ -461,8 +464,14 @@ def dominant_kernel_roofline(module, ff, fe, guide, iters):
     chi = torch.empty(nw, D, device=dev, dtype=torch.bfloat16)
     clo = torch.empty_like(chi)
 
+    c16 = torch.empty(nw, D, device=dev, dtype=torch.float16)
+    turn = [0]
+
     def launch():
-        nv.fused_stream(ff, fe, at.k, ay.k, qhi, qlo, R, 1.0 / D ** 0.5, 0.0, pos_a, pe_hi, pe_lo, 0, T, T + H, pm, pl, pacc, None, chi, clo)
+        a, b, _ = sets[turn[0] % len(sets)]
+        turn[0] += 1
+        nv.fused_stream(a, b, at.k, ay.k, qhi, qlo, R, 1.0 / D ** 0.5, 0.0, pos_a, pe_hi, pe_lo, 0, T, T + H, pm, pl, pacc, None,
+                        ctx_f16=c16)
 
     # HIP events on the stream the kernel is launched on (torch's current stream).  The launches are queued
     # back to back in batches, so the host's per-launch cost (ctypes, ~10 us) hides behind the running kernel
@@ -482,7 +491,7 @@ def dominant_kernel_roofline(module, ff, fe, guide, iters):
     torch.cuda.synchronize()
     ms = sorted(a.elapsed_time(b) / batch for a, b in evs)
     mean_ms = sum(ms) / len(ms)
-    alg_bytes = 3359232 * T + nw * D * 4
+    alg_bytes = 3359232 * T + nw * D * 2
     achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
     traffic = None
     try:   # HBM bytes per launch from the newest committed PMC pass of this same workload (profiles/)

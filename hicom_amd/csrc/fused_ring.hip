@@ -48,6 +48,12 @@ __device__ unsigned long long g_fused_trace[1024 * 3 * 256];
 #define HICOM_TR(who) do {} while (0)
 #endif
 
+// cache policy of the token stream's LDS-DMA loads: every token is read exactly once per call, so the loads are
+// non-temporal (aux = 2: MI355X_MICROARCH.md "nt-weights": streamed once-read bytes) and leave L2 / Infinity Cache to the
+// weights and partial states of the kernels that follow
+#ifndef HICOM_RING_AUX
+#define HICOM_RING_AUX 2
+#endif
 constexpr int kRingC = 8;                 // compute waves
 constexpr int kRingL = 4;                 // loader waves
 constexpr int kRingThreads = 64 * (kRingC + kRingL);
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
 #pragma unroll
             for (int i = 0; i < PPL; ++i)                               // piece (block i, row group l)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 256),
-                                                 (__attribute__((address_space(3))) void*)(img + (4 * i + l) * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(img + (4 * i + l) * 1024), 16, 0, HICOM_RING_AUX);
         };
         // Past the token stream the ring carries the value-side pos-emb: "tile" ntile + b holds the pe rows of
         // compact slot tile b -- hi plane where frames_embed goes, lo plane where frames_feature goes -- so the
