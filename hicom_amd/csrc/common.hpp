@@ -67,6 +67,10 @@ __device__ __forceinline__ float xrow4_sum(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// whole-wave sum without LDS: DPP row rotations (16-lane rows), then the two gfx950 row swaps.  __shfl_xor compiles to
+// ds_bpermute_b32, an LDS round trip per step: six dependent ones per reduction.
+__device__ __forceinline__ float wave_sum_fast(float v) { return xrow4_sum(row16_sum(v)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -99,11 +99,17 @@ __device__ __forceinline__ void aux_gemv_role(const AuxGemv& g, int aux_idx, int
     const int k4n = g.K >> 2, items = g.x_parts * k4n;
     constexpr int XR = 28;                            // x_parts * K / 4 <= 28 * 256 (host-checked)
     float4 t[XR];
+    {
+        int sidx = tid / k4n, k4 = tid - sidx * k4n;                        // (part, float4 column) of item tid; then += 256 items
+        const int dq = 256 / k4n, dr = 256 - dq * k4n;
 #pragma unroll
-    for (int u = 0; u < XR; ++u) {
-        const int it = tid + 256 * u < items ? tid + 256 * u : 0;       // (clamped: the loads are unconditional)
-        const int sidx = it / k4n, k4 = it - sidx * k4n;
-        t[u] = *reinterpret_cast<const float4*>(g.xs + (long)sidx * g.x_stride + 4 * k4);
+        for (int u = 0; u < XR; ++u) {
+            const bool in = tid + 256 * u < items;                           // (clamped: the loads are unconditional)
+            t[u] = *reinterpret_cast<const float4*>(g.xs + (long)(in ? sidx : 0) * g.x_stride + 4 * (in ? k4 : 0));
+            sidx += dq;
+            k4 += dr;
+            if (k4 >= k4n) { k4 -= k4n; ++sidx; }
+        }
     }
 #pragma unroll
     for (int u = 0; u < XR; ++u) {
@@ -113,7 +119,15 @@ __device__ __forceinline__ void aux_gemv_role(const AuxGemv& g, int aux_idx, int
     __syncthreads();
     for (int k = tid; k < g.K; k += 256) {
         float v = g.xb ? bf16_to_f32(g.xb[k]) : 0.f;
-        for (int sidx = 0; sidx < g.x_parts; ++sidx) v += xp[sidx * g.K + k];
+        int sidx = 0;
+        for (; sidx + 6 <= g.x_parts; sidx += 6) {                          // six LDS reads in flight; summed in part order
+            float r[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) r[u] = xp[(sidx + u) * g.K + k];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) v += r[u];
+        }
+        for (; sidx < g.x_parts; ++sidx) v += xp[sidx * g.K + k];
         xl[k] = v;
     }
     __syncthreads();
@@ -136,7 +150,7 @@ __device__ __forceinline__ void aux_gemv_role(const AuxGemv& g, int aux_idx, int
                     acc = fmaf(bf16lo_to_f32(wv[j][c][i]), xr[c][2 * i], acc);
                     acc = fmaf(bf16hi_to_f32(wv[j][c][i]), xr[c][2 * i + 1], acc);
                 }
-            acc = wave_sum(acc);
+            acc = wave_sum_fast(acc);
             const int n = n0 + j;
             if (lane == 0 && n < min(g.N, n_first + per)) {
                 float v = acc + (g.b ? bf16_to_f32(g.b[n]) : 0.f);
@@ -448,7 +462,14 @@ extern "C" int hicom_readout16_gemm_fwd(const void* a, const void* w, const void
         p.aux = AuxGemv{aux->xs, aux->x_parts, (long)aux->x_stride, (const uint16_t*)aux->xb, (const uint16_t*)aux->w,
                         (const uint16_t*)aux->b, (const uint16_t*)aux->res, aux->N, aux->K, aux->act, aux->y};
         // the CUs the tile grid leaves idle (one workgroup per CU: the ring takes 120 KB of LDS), at least 16
-        n_aux = (256 - p.n_gemm) / 8 * 8;                // the same number on every XCD
+        // the same number on every XCD, and ONE CU per XCD left free: with every CU of an XCD spoken for (25 tiles + 7 aux
+        // = 32) an aux workgroup was seen queueing behind a 12-us tile (GEMM 1 in situ: 16.6 us with aux, 12.2 without)
+        static int aux_per_xcd = -1;
+        if (aux_per_xcd < 0) {
+            const char* e = getenv("HICOM_R16_AUX_PER_XCD");     // dev switch
+            aux_per_xcd = e ? atoi(e) : 0;
+        }
+        n_aux = aux_per_xcd > 0 ? 8 * aux_per_xcd : ((256 - p.n_gemm) / 8 - 1) * 8;
         if (n_aux < 16) n_aux = 16;
         if (n_aux > 72) n_aux = 72;
     }
