@@ -44,7 +44,7 @@ struct DenseParams {
     long ldy;
     const uint16_t* res;    // bf16 [M, ldr] residual added before the y store (or NULL)
     long ldr;
-    float* ssq;             // [2 * tiles_n][M] partial row sums of squares of (acc + b) (or NULL)
+    float* ssq;             // [ceil(N / 64)][M] partial row sums of squares of (acc + b), one row per 64-column slice (or NULL)
     int tiles_m, tiles_n;
     // optional per-row additive term from three table rows (the projected positional embedding W . pos of token m):
     //   + tab[t0 + m / (H*W)][n] + tab[y0 + (m / W) % H][n] + tab[x0 + m % W][n],   tab f32 [*, tab_ld]
@@ -59,99 +59,118 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     return 0.5f * x * (2.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e));      // 0.5 x (1 + tanh u)
 }
 
-// DB = true: two 32-KB stages; the LDS-DMA of tile k+1 is issued (inline asm: hipcc would drain an LDS-DMA it knows of in
-// front of the next ds_read) before the MFMAs of tile k, one barrier per K step, two workgroups per CU.
-template <bool BF16, bool DB>
-__global__ __launch_bounds__(256, DB ? 2 : 3) void dense16_gemm_kernel(DenseParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[DB ? 65536 : 32768];     // per stage: A image [128][128 B] | W image [128][128 B]
+// Tile shapes (template): WR x WC waves, each 16*MI rows x 64 columns.
+//   small  2 x 2 waves, MI = 4: 128 x 128 tile, ONE 32-KB stage, two barriers per K step, three workgroups per CU overlap each
+//          other's staging (the guide's "128^2 two-barrier" structure).  Needs 64 B/clk of L2 -> LDS fill per CU at full MFMA
+//          rate, ~2x what a CU sustains (~70 GB/s): measured MFMA busy 34 %.
+//   big    2 x 4 waves, MI = 8: 256 x 256 tile, 512 threads, two 64-KB stages (DB): the LDS-DMA of K step k+1 is issued (inline
+//          asm: hipcc would drain an LDS-DMA it knows of in front of the next ds_read) before the MFMAs of step k, one barrier
+//          per K step.  Half the fill bytes per flop (32 B/clk per CU at full rate).
+template <bool BF16, bool DB, int WR, int WC, int MI>
+__global__ __launch_bounds__(64 * WR * WC, (DB ? 2 : 3) * 256 / (64 * WR * WC) > 0 ? (DB ? 2 : 3) * 256 / (64 * WR * WC) : 1)
+void dense16_gemm_kernel(DenseParams p) {
+    constexpr int NWAVE = WR * WC, TM = WR * 16 * MI, TN = WC * 64;
+    constexpr int STAGE = (TM + TN) * 128;                     // A image [TM][128 B] | W image [TN][128 B]
+    constexpr int PPW = (TM + TN) / 8 / NWAVE;                  // one-KiB DMA pieces (8 rows x 128 B) per wave and stage
+    constexpr int PA = TM / 8 / NWAVE;                          // ... of which the first PA are A pieces
+    static_assert((TM / 8) % NWAVE == 0 && (TN / 8) % NWAVE == 0, "pieces are dealt evenly");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WC, wc = wave - wr * WC;
     const int r16 = lane & 15, kg = lane >> 4;
     // XCD-aware bijective remap (cdna_hip_programming.md §5 "XCD swizzle must be bijective")
     const int nwg = p.tiles_m * p.tiles_n, orig = blockIdx.x;
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    // super-tile order inside the run: blocks of RM row tiles, column-major inside a block, so that the ~96 tiles an XCD
-    // has in flight share RM A panels and a dozen W panels in ITS L2 instead of streaming all of W once per row tile
+    // super-tile order inside the run: blocks of RM row tiles, column-major inside a block, so that the tiles an XCD has in
+    // flight share RM A panels and a few W panels in ITS L2 instead of streaming all of W once per row tile
     constexpr int RM = 8;
     const int per_blk = RM * p.tiles_n, blk = wg / per_blk, rem = wg - blk * per_blk;
     const int rows_in = min(RM, p.tiles_m - blk * RM);
     const int bn = rem / rows_in, bm = blk * RM + (rem - bn * rows_in);
-    const int m0 = bm * 128, n0 = bn * 128;
+    const int m0 = bm * TM, n0 = bn * TN;
 
-    // DMA: 32 one-KiB pieces (8 rows x 128 B) per stage, wave w issues pieces w, w+4, ...: 4 of A, 4 of W
     const int prow = lane >> 3, cpos = lane & 7;
-    unsigned soff[8];                                   // element offsets (< 2^32: the largest operand here is 406 MB)
+    unsigned soff[PPW];                                 // element offsets (< 2^32: the largest operand here is 406 MB)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int pi = wave + 4 * i;                    // i < 4: A piece, i >= 4: W piece
-        const int row = 8 * (pi & 15) + prow;
-        if (i < 4) {
+    for (int i = 0; i < PPW; ++i) {
+        if (i < PA) {
+            const int row = 8 * (wave + NWAVE * i) + prow;
             int m = m0 + row;
             m = m < p.M ? m : p.M - 1;
             soff[i] = (unsigned)((long)m * p.lda + 8 * (cpos ^ ((row >> 1) & 7)));
         } else {
+            const int row = 8 * (wave + NWAVE * (i - PA)) + prow;
             int n = n0 + row;
             n = n < p.N ? n : p.N - 1;
             soff[i] = (unsigned)((long)n * p.ldw + 8 * (cpos ^ ((row >> 1) & 7)));
         }
     }
     const int swz = (r16 >> 1) & 7;
-    const char* a_rd = lds + (64 * wr + r16) * 128;
-    const char* w_rd = lds + 16384 + (64 * wc + r16) * 128;
+    const char* a_rd = lds + (16 * MI * wr + r16) * 128;
+    const char* w_rd = lds + TM * 128 + (64 * wc + r16) * 128;
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][MI];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ns = p.K >> 6;
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(lds));
     auto issue = [&](int s, int buf) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint16_t* src = (i < 4 ? p.a : p.w) + soff[i] + 64 * s;
+        for (int i = 0; i < PPW; ++i) {
+            const uint16_t* src = (i < PA ? p.a : p.w) + soff[i] + 64 * s;
+            const int piece = i < PA ? wave + NWAVE * i : TM / 8 + wave + NWAVE * (i - PA);
             if constexpr (DB) {
-                const unsigned dst = lds_base + buf * 32768 + (wave + 4 * i) * 1024;
+                const unsigned dst = lds_base + buf * STAGE + piece * 1024;
                 unsigned keep_m0;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep_m0) : "v"(src), "s"(dst) : "memory");
             } else {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
-                                                 (__attribute__((address_space(3))) void*)(lds + (wave + 4 * i) * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(lds + piece * 1024), 16, 0, 0);
             }
         }
     };
     auto compute = [&](int buf) {
-        const char* a_b = a_rd + buf * 32768;
-        const char* w_b = w_rd + buf * 32768;
+        const char* a_b = a_rd + buf * STAGE;
+        const char* w_b = w_rd + buf * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int off = 16 * ((4 * ks + kg) ^ swz);
+            // A fragments in groups of 4 row blocks (16 VGPRs): the 256-row tile would otherwise hold 8 of them beside its
+            // 128 accumulator registers and spill
             if constexpr (BF16) {
-                bf16x8 af[4], wf[4];
+                bf16x8 wf[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    af[i] = *reinterpret_cast<const bf16x8*>(a_b + i * 2048 + off);
-                    wf[i] = *reinterpret_cast<const bf16x8*>(w_b + i * 2048 + off);
+                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(w_b + i * 2048 + off);
+#pragma unroll
+                for (int i0 = 0; i0 < MI; i0 += 4) {
+                    bf16x8 af[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a_b + (i0 + i) * 2048 + off);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j][i0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i0 + i], 0, 0, 0);
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
             } else {
-                half8 af[4], wf[4];
+                half8 wf[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    af[i] = *reinterpret_cast<const half8*>(a_b + i * 2048 + off);
-                    wf[i] = *reinterpret_cast<const half8*>(w_b + i * 2048 + off);
+                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const half8*>(w_b + i * 2048 + off);
+#pragma unroll
+                for (int i0 = 0; i0 < MI; i0 += 4) {
+                    half8 af[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const half8*>(a_b + (i0 + i) * 2048 + off);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j][i0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[j][i0 + i], 0, 0, 0);
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[j][i], 0, 0, 0);
             }
         }
     };
@@ -177,8 +196,10 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void dense16_gemm_kernel(DensePara
         }
     }
 
-    // epilogue: lane holds columns n .. n+3 (n = n0 + 64 wc + 16 j + 4 kg) of row m = m0 + 64 wr + 16 i + r16
-    float rss[4] = {0.f, 0.f, 0.f, 0.f};
+    // epilogue: lane holds columns n .. n+3 (n = n0 + 64 wc + 16 j + 4 kg) of row m = m0 + 16 MI wr + 16 i + r16
+    float rss[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) rss[i] = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = n0 + 64 * wc + 16 * j + 4 * kg;
@@ -191,12 +212,12 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void dense16_gemm_kernel(DensePara
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + 64 * wr + 16 * i + r16;
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + 16 * MI * wr + 16 * i + r16;
             float v[4];
             if (p.tab && n < p.N) {
                 const int mm = m < p.M ? m : p.M - 1;
-                const int t = mm / (p.H * p.W), rem = mm - t * (p.H * p.W), yy = rem / p.W, xx = rem - yy * p.W;
+                const int t = mm / (p.H * p.W), rem2 = mm - t * (p.H * p.W), yy = rem2 / p.W, xx = rem2 - yy * p.W;
                 const float4 a0 = *reinterpret_cast<const float4*>(p.tab + (long)(p.t0 + t) * p.tab_ld + n);
                 const float4 a1 = *reinterpret_cast<const float4*>(p.tab + (long)(p.y0 + yy) * p.tab_ld + n);
                 const float4 a2 = *reinterpret_cast<const float4*>(p.tab + (long)(p.x0 + xx) * p.tab_ld + n);
@@ -230,14 +251,14 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void dense16_gemm_kernel(DensePara
         }
     }
     if (p.ssq) {
-        // sum over this wave's 64 columns: the 4 k-groups of a row live in lanes r16 + 16 kg
+        // sum over this wave's 64 columns (slice (n0 + 64 wc) / 64 of the row): the 4 k-groups of a row live in lanes r16 + 16 kg
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
             float sacc = rss[i];
             sacc += __shfl_xor(sacc, 16, 64);
             sacc += __shfl_xor(sacc, 32, 64);
-            const int m = m0 + 64 * wr + 16 * i + r16;
-            if (kg == 0 && m < p.M) p.ssq[(long)(2 * bn + wc) * p.M + m] = sacc;
+            const int m = m0 + 16 * MI * wr + 16 * i + r16;
+            if (kg == 0 && m < p.M && n0 + 64 * wc < p.N) p.ssq[(long)((n0 + 64 * wc) >> 6) * p.M + m] = sacc;
         }
     }
 }
@@ -347,27 +368,41 @@ extern "C" int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w,
     HICOM_REQUIRE((long)M * lda < (1L << 32) && (long)N * ldw < (1L << 32), HICOM_EUNSUP, "dense16_gemm: operand larger than 2^32 elements");
     HICOM_REQUIRE(N % 4 == 0, HICOM_EUNSUP, "dense16_gemm: N %% 4");
     if (out_f16) HICOM_REQUIRE(ldo % 4 == 0 && n_store % 4 == 0 && n_store >= N && n_store <= ldo && (uintptr_t)out_f16 % 8 == 0 &&
-                                   n_store <= ((N + 127) / 128) * 128, HICOM_EINVAL, "dense16_gemm: fp16 output layout");
+                                   n_store <= ((N + 127) / 128) * 128 + 128, HICOM_EINVAL, "dense16_gemm: fp16 output layout");
     if (y) HICOM_REQUIRE(ldy % 4 == 0 && ldy >= N && (uintptr_t)y % 16 == 0 && (!res || (ldr % 4 == 0 && (uintptr_t)res % 8 == 0)), HICOM_EINVAL,
                          "dense16_gemm: packed output layout");
     DenseParams p;
     p.a = (const uint16_t*)a; p.w = (const uint16_t*)w; p.lda = lda; p.ldw = ldw; p.b = b; p.b_f32 = b_dt == HICOM_DT_F32;
     p.M = M; p.N = N; p.K = K; p.act = act; p.o16 = (_Float16*)out_f16; p.ldo = ldo; p.n_store = out_f16 ? n_store : 0;
     p.y = y; p.y_f32 = y_dt == HICOM_DT_F32; p.ldy = ldy; p.res = (const uint16_t*)res; p.ldr = ldr; p.ssq = ssq;
-    p.tiles_m = (M + 127) / 128; p.tiles_n = (N + 127) / 128;
     p.tab = row_tab; p.tab_ld = row_tab_ld; p.H = tab_H; p.W = tab_W; p.t0 = tab_t0; p.y0 = tab_y0; p.x0 = tab_x0;
-    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
-    static int db = -1;
-    if (db < 0) {
-        const char* e = getenv("HICOM_DENSE_DB");                  // dev switch for A/B runs
-        db = (e && e[0] == '1') ? 1 : 0;                           // default: one stage, three workgroups per CU (A/B: equal)
+    static int force = -1;
+    if (force < 0) {
+        const char* e = getenv("HICOM_DENSE_TILE");                // dev switch for A/B runs: "small" / "big"
+        force = !e ? 0 : (e[0] == 's' ? 1 : 2);
     }
-    if (db) {
-        if (operand_dt == HICOM_DT_BF16) hipLaunchKernelGGL((dense16_gemm_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((dense16_gemm_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    // default: the small tile (A/B at the head-projection shape: 610 vs 596 TFLOP/s; MFMA busy 34 % both -- the 256^2 tile
+    // halves the staged bytes per flop and did not move the needle: the loop is latency-, not fill-bound)
+    const bool big = force == 2;
+    hipStream_t st = (hipStream_t)stream;
+    if (big) {
+        p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
+        constexpr int smem = 2 * (256 + 256) * 128;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(dense16_gemm_kernel<true, true, 2, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(dense16_gemm_kernel<false, true, 2, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            attr_set = true;
+        }
+        const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+        if (operand_dt == HICOM_DT_BF16) hipLaunchKernelGGL((dense16_gemm_kernel<true, true, 2, 4, 8>), grid, dim3(512), smem, st, p);
+        else hipLaunchKernelGGL((dense16_gemm_kernel<false, true, 2, 4, 8>), grid, dim3(512), smem, st, p);
     } else {
-        if (operand_dt == HICOM_DT_BF16) hipLaunchKernelGGL((dense16_gemm_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((dense16_gemm_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        p.tiles_m = (M + 127) / 128; p.tiles_n = (N + 127) / 128;
+        constexpr int smem = (128 + 128) * 128;
+        const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+        if (operand_dt == HICOM_DT_BF16) hipLaunchKernelGGL((dense16_gemm_kernel<true, false, 2, 2, 4>), grid, dim3(256), smem, st, p);
+        else hipLaunchKernelGGL((dense16_gemm_kernel<false, false, 2, 2, 4>), grid, dim3(256), smem, st, p);
     }
     return hicom_host::check_launch("dense16_gemm");
 }

@@ -200,8 +200,7 @@ def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i, clip=None, kpe_t=N
         row_const = torch.zeros((rows_pad,), dtype=torch.float32, device=dev)
         nv.clip_query_prep(qp, att.k_proj.bias.detach() if att.k_proj.bias is not None else None, nh, scale, row_const)
         nv.fold_query(qp, wk, nh, scale, qt)                   # qp is now qhat
-        ntile = (E + 127) // 128
-        ssq = _f32((2 * ntile, N), dev)
+        ssq = _f32(((E + 63) // 64, N), dev)
         tab = None
         if pe is not None:
             tab = (kpe_t, H, W, t0i, y0i, x0i)

@@ -284,7 +284,7 @@ int hicom_merge_vproj_fwd(const float* part_m, const float* part_l, const float*
  *   out_f16 [M, ldo] fp16 (saturating): the activated value; columns [N, n_store) are written as zeros (the K padding
  *           of a following GEMM);
  *   y [M, ldy] bf16 | f32: value + res[m, n] (res bf16 [M, ldr] or NULL);
- *   ssq f32 [2 * ceil(N/128)][M]: partial row sums of squares of (acc + b), summed by the consumer (key norms of the
+ *   ssq f32 [ceil(N/64)][M]: partial row sums of squares of (acc + b) per 64-column slice, summed by the consumer (key norms of the
  *           clip-scale global stage, projector.py:184-186).
  * row_tab (may be NULL): f32 [*, row_tab_ld] table whose rows tab_t0 + m / (H*W), tab_y0 + (m / W) % H, tab_x0 + m % W are
  *           added to row m before bias / ssq / activation: the projected positional embedding W . pos(m) of token m,
