@@ -14,7 +14,13 @@
 // (cdna_hip_programming.md §5 "Measured: the optimization ladder": the 128^2 two-barrier structure, ~0.9 PF on that
 // guide's box; the 256^2 8-phase schedule is the next step up and is not built here).  XCD-aware tile order: one
 // XCD walks a contiguous run of tiles that share A rows.  Product computed transposed (W fragment as the MFMA A
-// operand): a lane holds 4 consecutive output columns of one row -> 8-byte fp16 / bf16, 16-byte fp32 stores.
+// operand): a lane holds 4 consecutive output columns of one row; the epilogue regroups them through LDS into 8 consecutive
+// columns per lane so that stores, bias and residual accesses are whole 128-byte lines (dense_epilogue_rows).
+// What was measured on the way (head projection, 46 656 x 4 352 x 1 152, fp16; DESIGN.md §3.4 has the table): the 8-byte
+// MFMA-layout stores were 185-210 us of an 800-us launch; a persistent 256 x 256 x 32 four-stage LDS-DMA ring (one
+// workgroup per CU) ran its K loop at 0.9-1.0 PFLOP/s but lost it again in an epilogue nothing overlaps (tanh-GELU is ~25
+// VALU ops per output against 2 304 MFMA flops at K = 1 152) and in the ~130 clocks per 1-KB DMA piece that the issuing
+// COMPUTE waves queue behind the CU's address path -- it ended 15 % slower than this kernel and is not kept.
 // fp16 operands for normalised activations (11 significand bits; bf16 weights convert exactly), bf16 operands when A is
 // the raw bf16 token stream.
 #include <stdlib.h>
@@ -59,22 +65,211 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     return 0.5f * x * (2.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e));      // 0.5 x (1 + tanh u)
 }
 
-// Tile shapes (template): WR x WC waves, each 16*MI rows x 64 columns.
-//   small  2 x 2 waves, MI = 4: 128 x 128 tile, ONE 32-KB stage, two barriers per K step, three workgroups per CU overlap each
-//          other's staging (the guide's "128^2 two-barrier" structure).  Needs 64 B/clk of L2 -> LDS fill per CU at full MFMA
-//          rate, ~2x what a CU sustains (~70 GB/s): measured MFMA busy 34 %.
-//   big    2 x 4 waves, MI = 8: 256 x 256 tile, 512 threads, two 64-KB stages (DB): the LDS-DMA of K step k+1 is issued (inline
-//          asm: hipcc would drain an LDS-DMA it knows of in front of the next ds_read) before the MFMAs of step k, one barrier
-//          per K step.  Half the fill bytes per flop (32 B/clk per CU at full rate).
-template <bool BF16, bool DB, int WR, int WC, int MI>
-__global__ __launch_bounds__(64 * WR * WC, (DB ? 2 : 3) * 256 / (64 * WR * WC) > 0 ? (DB ? 2 : 3) * 256 / (64 * WR * WC) : 1)
-void dense16_gemm_kernel(DenseParams p) {
-    constexpr int NWAVE = WR * WC, TM = WR * 16 * MI, TN = WC * 64;
-    constexpr int STAGE = (TM + TN) * 128;                     // A image [TM][128 B] | W image [TN][128 B]
+// Epilogue of one wave's [16 MI rows] x [16 NJ columns] block at (mw, nw): the lane holds columns n .. n+3 (n = nw + 16 j + 4 kg)
+// of row m = mw + 16 i + r16.  bias, positional-table term, activation, fp16 / packed stores, row sums of squares per
+// 64-column slice.
+template <int MI, int NJ>
+__device__ __forceinline__ void dense_epilogue(const DenseParams& p, f32x4 (&acc)[NJ][MI], int mw, int nw, int r16, int kg) {
+    float rss[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) rss[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = nw + 16 * j + 4 * kg;
+        float bias[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.b) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int nn = n + qq < p.N ? n + qq : p.N - 1;
+                bias[qq] = p.b_f32 ? reinterpret_cast<const float*>(p.b)[nn] : bf16_to_f32(reinterpret_cast<const uint16_t*>(p.b)[nn]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = mw + 16 * i + r16;
+            float v[4];
+            if (p.tab && n < p.N) {
+                const int mm = m < p.M ? m : p.M - 1;
+                const int t = mm / (p.H * p.W), rem2 = mm - t * (p.H * p.W), yy = rem2 / p.W, xx = rem2 - yy * p.W;
+                const float4 a0 = *reinterpret_cast<const float4*>(p.tab + (long)(p.t0 + t) * p.tab_ld + n);
+                const float4 a1 = *reinterpret_cast<const float4*>(p.tab + (long)(p.y0 + yy) * p.tab_ld + n);
+                const float4 a2 = *reinterpret_cast<const float4*>(p.tab + (long)(p.x0 + xx) * p.tab_ld + n);
+                acc[j][i][0] += a0.x + a1.x + a2.x; acc[j][i][1] += a0.y + a1.y + a2.y;
+                acc[j][i][2] += a0.z + a1.z + a2.z; acc[j][i][3] += a0.w + a1.w + a2.w;
+            }
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                v[qq] = (n + qq < p.N) ? acc[j][i][qq] + bias[qq] : 0.f;
+                if (p.ssq) rss[i] = fmaf(v[qq], v[qq], rss[i]);
+                if (p.act == HICOM_ACT_GELU) v[qq] = gelu_erf(v[qq]);
+                else if (p.act == HICOM_ACT_GELU_TANH) v[qq] = gelu_tanh(v[qq]);
+            }
+            if (m >= p.M) continue;
+            if (p.o16 && n < p.n_store) {
+                half4 hv;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) hv[qq] = (_Float16)fminf(fmaxf((n + qq < p.N) ? v[qq] : 0.f, -65504.f), 65504.f);
+                *reinterpret_cast<half4*>(p.o16 + (long)m * p.ldo + n) = hv;       // (ldo, n_store multiples of 4: host-checked)
+            }
+            if (p.y && n < p.N) {
+                if (p.res) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(p.res + (long)m * p.ldr + n);
+                    v[0] += bf16lo_to_f32(rr.x); v[1] += bf16hi_to_f32(rr.x); v[2] += bf16lo_to_f32(rr.y); v[3] += bf16hi_to_f32(rr.y);
+                }
+                if (p.y_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (long)m * p.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (long)m * p.ldy + n) =
+                        make_uint2(f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16), f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16));
+            }
+        }
+        if (p.ssq && (j & 3) == 3) {
+            // sum over the 64-column slice (nw + 16 (j - 3)) / 64 of the row: its 4 k-groups live in lanes r16 + 16 kg
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                float sacc = rss[i];
+                sacc += __shfl_xor(sacc, 16, 64);
+                sacc += __shfl_xor(sacc, 32, 64);
+                const int m = mw + 16 * i + r16, nb = nw + 16 * (j - 3);
+                if (kg == 0 && m < p.M && nb < p.N) p.ssq[(long)(nb >> 6) * p.M + m] = sacc;
+                rss[i] = 0.f;
+            }
+        }
+    }
+}
+
+// Row-contiguous epilogue through a wave-private 4-KB LDS staging block.  The MFMA layout gives a lane 4 columns of one row
+// (8-byte fp16 stores, 32 contiguous bytes per row and instruction: measured 185-210 us of an 800-us launch at the head
+// projection's shapes, tools/gpu_dense_ring.sh).  Here each [16 rows x 64 columns] fp32 block goes to LDS (ds_write_b128,
+// chunk c of row r at c ^ r: the 8 lanes of a store group hit 8 distinct bank quads) and comes back with 8 consecutive
+// columns of one row per lane (rows 8h + lane / 8, two ds_read_b128 at chunks (2q, 2q+1) ^ row: conflict-free in the
+// b128 lane groups), so that bias / residual / table loads are 16- or 32-byte reads and every store instruction writes
+// eight whole 128-byte lines (16-bit outputs) or 256 contiguous bytes per row (fp32).  Same-wave LDS operations execute in
+// issue order: no barrier between the staging writes and reads.
+// bias_staged: the wave's bias slice (columns nw .. nw + 16 NJ, raw fp32 / bf16) already lies at the head of `stage` (the ring
+// kernel's loaders put it there by LDS-DMA a few K steps earlier): read before the first staging write, no global latency.
+template <int MI, int NJ>
+__device__ __forceinline__ void dense_epilogue_rows(const DenseParams& p, f32x4 (&acc)[NJ][MI], int mw, int nw, int lane, float* stage,
+                                                    bool bias_staged = false) {
+    static_assert(NJ % 4 == 0, "64-column slices");
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int q = lane & 7, rr = lane >> 3;
+    float sbias[NJ / 4][8];
+    if (bias_staged) {
+#pragma unroll
+        for (int jq = 0; jq < NJ / 4; ++jq) {
+            if (p.b_f32) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(stage + 64 * jq + 8 * q);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(stage + 64 * jq + 8 * q + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sbias[jq][e] = b0[e]; sbias[jq][4 + e] = b1[e]; }
+            } else {
+                const u32x4 g = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(stage) + 64 * jq + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sbias[jq][2 * e] = bf16lo_to_f32(g[e]); sbias[jq][2 * e + 1] = bf16hi_to_f32(g[e]); }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int jq = 0; jq < NJ / 4; ++jq) {
+        const int n = nw + 64 * jq + 8 * q;                // this lane's 8 columns after the regroup
+        const bool n_ok = n < p.N;                          // N % 8 == 0 (host-checked): a chunk is inside or outside as a whole
+        float bias[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+        if (bias_staged) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias[e] = sbias[jq][e];
+        } else if (p.b && n_ok) {
+            if (p.b_f32) {
+                const float4 b0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.b) + n);
+                const float4 b1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.b) + n + 4);
+                bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+            } else {
+                const u32x4 g = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(p.b) + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bias[2 * e] = bf16lo_to_f32(g[e]); bias[2 * e + 1] = bf16hi_to_f32(g[e]); }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                *reinterpret_cast<f32x4*>(stage + r16 * 64 + 4 * ((4 * jj + kg) ^ r16)) = acc[4 * jq + jj][i];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = 8 * h + rr, m = mw + 16 * i + row;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(stage + row * 64 + 4 * ((2 * q) ^ row));
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(stage + row * 64 + 4 * ((2 * q + 1) ^ row));
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                const int mm = m < p.M ? m : p.M - 1;
+                if (p.tab && n_ok) {
+                    const int t = mm / (p.H * p.W), rem2 = mm - t * (p.H * p.W), yy = rem2 / p.W, xx = rem2 - yy * p.W;
+                    const float* t0 = p.tab + (long)(p.t0 + t) * p.tab_ld + n;
+                    const float* t1 = p.tab + (long)(p.y0 + yy) * p.tab_ld + n;
+                    const float* t2 = p.tab + (long)(p.x0 + xx) * p.tab_ld + n;
+#pragma unroll
+                    for (int e4 = 0; e4 < 2; ++e4) {
+                        const float4 a0 = *reinterpret_cast<const float4*>(t0 + 4 * e4);
+                        const float4 a1 = *reinterpret_cast<const float4*>(t1 + 4 * e4);
+                        const float4 a2 = *reinterpret_cast<const float4*>(t2 + 4 * e4);
+                        v[4 * e4 + 0] += a0.x + a1.x + a2.x; v[4 * e4 + 1] += a0.y + a1.y + a2.y;
+                        v[4 * e4 + 2] += a0.z + a1.z + a2.z; v[4 * e4 + 3] += a0.w + a1.w + a2.w;
+                    }
+                }
+                float rss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[e] = n_ok ? v[e] + bias[e] : 0.f;
+                    rss = fmaf(v[e], v[e], rss);
+                    if (p.act == HICOM_ACT_GELU) v[e] = gelu_erf(v[e]);
+                    else if (p.act == HICOM_ACT_GELU_TANH) v[e] = gelu_tanh(v[e]);
+                }
+                if (p.ssq) {
+                    // the 8 lanes of a row hold its 64-column slice
+                    rss += __shfl_xor(rss, 1, 64);
+                    rss += __shfl_xor(rss, 2, 64);
+                    rss += __shfl_xor(rss, 4, 64);
+                    const int nb = nw + 64 * jq;
+                    if (q == 0 && m < p.M && nb < p.N) p.ssq[(long)(nb >> 6) * p.M + m] = rss;
+                }
+                if (m >= p.M) continue;
+                if (p.o16 && n < p.n_store) {
+                    half8 hv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hv[e] = (_Float16)fminf(fmaxf(v[e], -65504.f), 65504.f);
+                    *reinterpret_cast<half8*>(p.o16 + (long)m * p.ldo + n) = hv;
+                }
+                if (p.y && n_ok) {
+                    if (p.res) {
+                        const u32x4 g = *reinterpret_cast<const u32x4*>(p.res + (long)m * p.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[2 * e] += bf16lo_to_f32(g[e]); v[2 * e + 1] += bf16hi_to_f32(g[e]); }
+                    }
+                    if (p.y_f32) {
+                        float* yp = reinterpret_cast<float*>(p.y) + (long)m * p.ldy + n;
+                        *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    } else {
+                        u32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16);
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.y) + (long)m * p.ldy + n) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// 128 x 128 tile, 2 x 2 waves of 64 x 64, ONE 32-KB stage, two barriers per K step; the workgroups resident on a CU (four at
+// 112 VGPRs with the row epilogue) overlap each other's staging, MFMA and epilogue phases.
+template <bool BF16, bool ROWS>
+__global__ __launch_bounds__(256, 3) void dense16_gemm_kernel(DenseParams p) {
+    constexpr int NWAVE = 4, WC = 2, MI = 4, TM = 128, TN = 128;
     constexpr int PPW = (TM + TN) / 8 / NWAVE;                  // one-KiB DMA pieces (8 rows x 128 B) per wave and stage
     constexpr int PA = TM / 8 / NWAVE;                          // ... of which the first PA are A pieces
-    static_assert((TM / 8) % NWAVE == 0 && (TN / 8) % NWAVE == 0, "pieces are dealt evenly");
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // A image [TM][128 B] | W image [TN][128 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave - wr * WC;
@@ -118,148 +313,50 @@ void dense16_gemm_kernel(DenseParams p) {
         for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ns = p.K >> 6;
-    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(lds));
-    auto issue = [&](int s, int buf) {
+    for (int s = 0; s < ns; ++s) {
+        lds_barrier();                                        // every wave is done reading the previous stage
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const uint16_t* src = (i < PA ? p.a : p.w) + soff[i] + 64 * s;
             const int piece = i < PA ? wave + NWAVE * i : TM / 8 + wave + NWAVE * (i - PA);
-            if constexpr (DB) {
-                const unsigned dst = lds_base + buf * STAGE + piece * 1024;
-                unsigned keep_m0;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep_m0) : "v"(src), "s"(dst) : "memory");
-            } else {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
-                                                 (__attribute__((address_space(3))) void*)(lds + piece * 1024), 16, 0, 0);
-            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
+                                             (__attribute__((address_space(3))) void*)(lds + piece * 1024), 16, 0, 0);
         }
-    };
-    auto compute = [&](int buf) {
-        const char* a_b = a_rd + buf * STAGE;
-        const char* w_b = w_rd + buf * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int off = 16 * ((4 * ks + kg) ^ swz);
-            // A fragments in groups of 4 row blocks (16 VGPRs): the 256-row tile would otherwise hold 8 of them beside its
-            // 128 accumulator registers and spill
-            if constexpr (BF16) {
-                bf16x8 wf[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(w_b + i * 2048 + off);
-#pragma unroll
-                for (int i0 = 0; i0 < MI; i0 += 4) {
-                    bf16x8 af[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a_b + (i0 + i) * 2048 + off);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[j][i0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i0 + i], 0, 0, 0);
-                }
-            } else {
-                half8 wf[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const half8*>(w_b + i * 2048 + off);
-#pragma unroll
-                for (int i0 = 0; i0 < MI; i0 += 4) {
-                    half8 af[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const half8*>(a_b + (i0 + i) * 2048 + off);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[j][i0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[j][i0 + i], 0, 0, 0);
-                }
-            }
-        }
-    };
-    if constexpr (DB) {
-        issue(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        for (int s = 0; s < ns; ++s) {
-            if (s + 1 < ns) issue(s + 1, (s + 1) & 1);
-            compute(s & 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile s+1 landed (this wave's pieces) ...
-            lds_barrier();                                          // ... for every wave; every wave is done reading tile s
-        }
-    } else {
-        for (int s = 0; s < ns; ++s) {
-            lds_barrier();                                        // every wave is done reading the previous stage
-            issue(s, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            compute(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int off = 16 * ((4 * ks + kg) ^ swz);
+            if constexpr (BF16) {
+                bf16x8 wf[4], af[MI];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(w_rd + i * 2048 + off);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a_rd + i * 2048 + off);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+            } else {
+                half8 wf[4], af[MI];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const half8*>(w_rd + i * 2048 + off);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const half8*>(a_rd + i * 2048 + off);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[j][i], 0, 0, 0);
+            }
         }
     }
 
-    // epilogue: lane holds columns n .. n+3 (n = n0 + 64 wc + 16 j + 4 kg) of row m = m0 + 16 MI wr + 16 i + r16
-    float rss[MI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) rss[i] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + 64 * wc + 16 * j + 4 * kg;
-        float bias[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.b) {
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const int nn = n + qq < p.N ? n + qq : p.N - 1;
-                bias[qq] = p.b_f32 ? reinterpret_cast<const float*>(p.b)[nn] : bf16_to_f32(reinterpret_cast<const uint16_t*>(p.b)[nn]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = m0 + 16 * MI * wr + 16 * i + r16;
-            float v[4];
-            if (p.tab && n < p.N) {
-                const int mm = m < p.M ? m : p.M - 1;
-                const int t = mm / (p.H * p.W), rem2 = mm - t * (p.H * p.W), yy = rem2 / p.W, xx = rem2 - yy * p.W;
-                const float4 a0 = *reinterpret_cast<const float4*>(p.tab + (long)(p.t0 + t) * p.tab_ld + n);
-                const float4 a1 = *reinterpret_cast<const float4*>(p.tab + (long)(p.y0 + yy) * p.tab_ld + n);
-                const float4 a2 = *reinterpret_cast<const float4*>(p.tab + (long)(p.x0 + xx) * p.tab_ld + n);
-                acc[j][i][0] += a0.x + a1.x + a2.x; acc[j][i][1] += a0.y + a1.y + a2.y;
-                acc[j][i][2] += a0.z + a1.z + a2.z; acc[j][i][3] += a0.w + a1.w + a2.w;
-            }
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                v[qq] = (n + qq < p.N) ? acc[j][i][qq] + bias[qq] : 0.f;
-                if (p.ssq) rss[i] = fmaf(v[qq], v[qq], rss[i]);
-                if (p.act == HICOM_ACT_GELU) v[qq] = gelu_erf(v[qq]);
-                else if (p.act == HICOM_ACT_GELU_TANH) v[qq] = gelu_tanh(v[qq]);
-            }
-            if (m >= p.M) continue;
-            if (p.o16 && n < p.n_store) {
-                half4 hv;
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) hv[qq] = (_Float16)fminf(fmaxf((n + qq < p.N) ? v[qq] : 0.f, -65504.f), 65504.f);
-                *reinterpret_cast<half4*>(p.o16 + (long)m * p.ldo + n) = hv;       // (ldo, n_store multiples of 4: host-checked)
-            }
-            if (p.y && n < p.N) {
-                if (p.res) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(p.res + (long)m * p.ldr + n);
-                    v[0] += bf16lo_to_f32(rr.x); v[1] += bf16hi_to_f32(rr.x); v[2] += bf16lo_to_f32(rr.y); v[3] += bf16hi_to_f32(rr.y);
-                }
-                if (p.y_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (long)m * p.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
-                else
-                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (long)m * p.ldy + n) =
-                        make_uint2(f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16), f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16));
-            }
-        }
-    }
-    if (p.ssq) {
-        // sum over this wave's 64 columns (slice (n0 + 64 wc) / 64 of the row): the 4 k-groups of a row live in lanes r16 + 16 kg
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            float sacc = rss[i];
-            sacc += __shfl_xor(sacc, 16, 64);
-            sacc += __shfl_xor(sacc, 32, 64);
-            const int m = m0 + 16 * MI * wr + 16 * i + r16;
-            if (kg == 0 && m < p.M && n0 + 64 * wc < p.N) p.ssq[(long)((n0 + 64 * wc) >> 6) * p.M + m] = sacc;
-        }
+    if constexpr (!ROWS) {
+        dense_epilogue<MI, 4>(p, acc, m0 + 16 * MI * wr, n0 + 64 * wc, r16, kg);
+    } else {
+        lds_barrier();                                        // every wave is done reading the last stage: the buffer becomes staging space
+        dense_epilogue_rows<MI, 4>(p, acc, m0 + 16 * MI * wr, n0 + 64 * wc, lane, reinterpret_cast<float*>(lds) + wave * 1024);
     }
 }
 
@@ -376,34 +473,19 @@ extern "C" int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w,
     p.M = M; p.N = N; p.K = K; p.act = act; p.o16 = (_Float16*)out_f16; p.ldo = ldo; p.n_store = out_f16 ? n_store : 0;
     p.y = y; p.y_f32 = y_dt == HICOM_DT_F32; p.ldy = ldy; p.res = (const uint16_t*)res; p.ldr = ldr; p.ssq = ssq;
     p.tab = row_tab; p.tab_ld = row_tab_ld; p.H = tab_H; p.W = tab_W; p.t0 = tab_t0; p.y0 = tab_y0; p.x0 = tab_x0;
-    static int force = -1;
-    if (force < 0) {
-        const char* e = getenv("HICOM_DENSE_TILE");                // dev switch for A/B runs: "small" / "big"
-        force = !e ? 0 : (e[0] == 's' ? 1 : 2);
-    }
-    // default: the small tile (A/B at the head-projection shape: 610 vs 596 TFLOP/s; MFMA busy 34 % both -- the 256^2 tile
-    // halves the staged bytes per flop and did not move the needle: the loop is latency-, not fill-bound)
-    const bool big = force == 2;
+    // the row-contiguous epilogue moves 8 columns per lane: 16-byte accesses on every output / bias / residual row
+    const bool rows = N % 8 == 0 && (!b || (uintptr_t)b % 16 == 0) &&
+                      (!out_f16 || (ldo % 8 == 0 && n_store % 8 == 0 && (uintptr_t)out_f16 % 16 == 0)) &&
+                      (!y || y_dt == HICOM_DT_F32 || ldy % 8 == 0) && (!res || (ldr % 8 == 0 && (uintptr_t)res % 16 == 0));
     hipStream_t st = (hipStream_t)stream;
-    if (big) {
-        p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
-        constexpr int smem = 2 * (256 + 256) * 128;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(dense16_gemm_kernel<true, true, 2, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(dense16_gemm_kernel<false, true, 2, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            attr_set = true;
-        }
-        const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
-        if (operand_dt == HICOM_DT_BF16) hipLaunchKernelGGL((dense16_gemm_kernel<true, true, 2, 4, 8>), grid, dim3(512), smem, st, p);
-        else hipLaunchKernelGGL((dense16_gemm_kernel<false, true, 2, 4, 8>), grid, dim3(512), smem, st, p);
-    } else {
-        p.tiles_m = (M + 127) / 128; p.tiles_n = (N + 127) / 128;
-        constexpr int smem = (128 + 128) * 128;
-        const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
-        if (operand_dt == HICOM_DT_BF16) hipLaunchKernelGGL((dense16_gemm_kernel<true, false, 2, 2, 4>), grid, dim3(256), smem, st, p);
-        else hipLaunchKernelGGL((dense16_gemm_kernel<false, false, 2, 2, 4>), grid, dim3(256), smem, st, p);
-    }
+    p.tiles_m = (M + 127) / 128; p.tiles_n = (N + 127) / 128;
+    constexpr int smem = (128 + 128) * 128;
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+    const bool bf = operand_dt == HICOM_DT_BF16;
+    if (bf && rows) hipLaunchKernelGGL((dense16_gemm_kernel<true, true>), grid, dim3(256), smem, st, p);
+    else if (bf) hipLaunchKernelGGL((dense16_gemm_kernel<true, false>), grid, dim3(256), smem, st, p);
+    else if (rows) hipLaunchKernelGGL((dense16_gemm_kernel<false, true>), grid, dim3(256), smem, st, p);
+    else hipLaunchKernelGGL((dense16_gemm_kernel<false, false>), grid, dim3(256), smem, st, p);
     return hicom_host::check_launch("dense16_gemm");
 }
 

@@ -14,6 +14,7 @@ python3 tools/pmc_traffic.py $O/pmc $R/gpurun_out/${TAG}_pmc_hbm_traffic.json 64
 # MFMA utilisation: release recipe (ring kernel, planes GEMMs) + guide-off recipe (wide global stream kernel), own PMC passes
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma/direct -- python3 bench.py --steps 10 --warmup 3 --no-extras > $O/mfma1.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma/off -- python3 tools/modes_one.py off > $O/mfma2.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma/head -- python3 -m pytest tests/test_gpu_head.py -q -k benchmark > $O/mfma3.log 2>&1
 python3 tools/pmc_mfma.py $O/mfma $R/gpurun_out/${TAG}_mfma_util.json
 timeout 900 python3 bench.py 2> $O/bench.err | grep '^{' > $R/gpurun_out/${TAG}_bench.json
 cut -c1-600 $R/gpurun_out/${TAG}_bench.json
