@@ -12,11 +12,13 @@ gradient checkpointing wants):
   dense weight gradients plain library GEMMs / outer products through torch (rocBLAS) in fp32 on the small
                          [Nw, 1152] / [9, 1152] tensors -- dW = dY^T X is not a kernel worth hand-writing
 
-Scope: the release recipes of the training script -- `use_guide="direct"` (stage 2) and guide off (stage 1: pooled
+Scope: the release recipes of the training script -- `use_guide="direct"` (stages 2-3) and guide off (stage 1: pooled
 per-window queries, 32 learnable global queries) -- without adaptors or clip-scale, dense video / image inputs, gradients of
-every projector parameter and of `image_newline`.  Gradients w.r.t. the visual features and the guide embedding
-(stage 3 of the release script, where the SigLIP head and the guide encoder train too) are not built: asking for
-them raises instead of returning None silently.  Other recipes raise NotImplementedError.
+every projector parameter and of `image_newline`.  Stage 3 also trains the SigLIP head and the guide encoder
+(train.py:717-726), i.e. it needs the gradients w.r.t. `frames_embed` (the head's output, key stream of the local windows)
+and `guide_embed`: built for the direct recipe (hicom_local_attn_bwd: one more pass over both streams, d frames_embed written
+as bf16).  `frames_feature` comes from the frozen tower body: asking for its gradient raises instead of returning None
+silently, and so do input gradients of the guide-off recipe and every other recipe.
 """
 from __future__ import annotations
 
@@ -57,28 +59,41 @@ class _CompressorFn(torch.autograd.Function):
     def backward(ctx, dout):
         ff, fe, guide, nl = ctx.saved_tensors
         need = ctx.needs_input_grad            # (proj, ff, fe, guide, modal, nl, names, *params)
-        if need[1] or need[2] or need[3]:
-            raise NotImplementedError("hicom_amd backward: gradients w.r.t. frames_feature / frames_embed / guide_embed are "
-                                      "not built (projector-only training, reference stages 1-2); detach them")
+        if need[1]:
+            raise NotImplementedError("hicom_amd backward: the gradient w.r.t. frames_feature is not built (the tower body is "
+                                      "frozen in every stage of the reference's script, train.py:703); detach it")
         with torch.no_grad():
-            grads, d_nl = compressor_backward(ctx.proj, ff, fe, guide, ctx.modal, nl, dout)
+            grads, d_nl, d_fe, d_guide = compressor_backward(ctx.proj, ff, fe, guide, ctx.modal, nl, dout,
+                                                             want_fe=bool(need[2]), want_guide=bool(need[3]))
         global LAST_FP32_GRADS
-        LAST_FP32_GRADS = grads
+        LAST_FP32_GRADS = dict(grads)
+        if d_guide is not None:
+            LAST_FP32_GRADS["__guide_embed__"] = d_guide
         plist = dict(ctx.proj.named_parameters())
         out = []
         for k, name in enumerate(ctx.names):
             g = grads.get(name) if need[7 + k] else None
             out.append(None if g is None else g.to(plist[name].dtype).reshape(plist[name].shape))
-        return (None, None, None, None, None, (d_nl.to(nl.dtype) if (nl is not None and need[5] and d_nl is not None) else None),
-                None, *out)
+        return (None, None, d_fe, (d_guide.to(guide.dtype).reshape(guide.shape) if d_guide is not None else None), None,
+                (d_nl.to(nl.dtype) if (nl is not None and need[5] and d_nl is not None) else None), None, *out)
 
 
-def compressor_backward(proj, ff, fe, guide, modal, nl, dout):
-    """fp32 gradients {parameter name: tensor} of sum(out * dout) and d image_newline, for the direct recipe.
-    Restates autograd through reference projector.py:524-559 (local), :634-646 + :166-228 (global) and
-    mm_utils.py:92-140 (packing)."""
+def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, want_guide=False):
+    """(fp32 gradients {parameter name: tensor} of sum(out * dout), d image_newline, d frames_embed (bf16) or None,
+    d guide_embed (fp32) or None).  Restates autograd through reference projector.py:524-559 (local), :634-646 + :166-228
+    (global) and mm_utils.py:92-140 (packing).  The input gradients exist for the direct recipe only."""
     lc, gc = proj.local_compressor, proj.global_compressor
     dev = ff.device
+    d_fe = d_guide = None
+    if want_fe or want_guide:
+        for c in (lc, gc):
+            if c is not None and c.use_guide != "direct":
+                raise NotImplementedError("hicom_amd backward: gradients w.r.t. frames_embed / guide_embed are built for "
+                                          "use_guide='direct' only (stage 3 of the reference's script)")
+        if want_guide:
+            d_guide = torch.zeros(guide.numel(), dtype=torch.float32, device=dev)
+        if want_fe and lc is None:
+            want_fe = False            # without a local stage frames_embed does not enter the forward: no gradient (None), as in the reference
     dout = dout.float()
     T, H, W, E = ff.shape
     grads = {}
@@ -105,6 +120,20 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout):
         dpre = (dY @ W2) * _gelu_grad(pre)
         grads["local_compressor.readout.0.weight"] = dpre.t() @ ctx_l
         grads["local_compressor.readout.0.bias"] = dpre.sum(0)
+        if want_fe or want_guide:
+            # ---- attention backward of the windows (HIP): dq per window and d frames_embed ---------------------
+            if want_fe and any(a.nwin * a.k != a.n for a in (at, ay, ax)):
+                raise NotImplementedError("hicom_amd backward: d frames_embed needs an exact window partition "
+                                          f"(T, H, W = {T}, {H}, {W} against kernel {at.k}, {ay.k}, {ax.k})")
+            axes = tuple(nv.Axis(a.n, a.k, a.nwin, a.nfull) for a in (at, ay, ax))
+            dctx_l = (dpre @ W0).contiguous()
+            dq_w = torch.empty((nw, E), dtype=torch.float32, device=dev)
+            if want_fe:
+                d_fe = torch.empty_like(fe)
+            key = fe if fe is not None else ff
+            nv.local_attn_bwd(key, ff, axes, guide.reshape(-1).contiguous(), 0, 1.0 / math.sqrt(lc.qk_dim), 0.0, dctx_l, dq_w, d_fe)
+            if want_guide:
+                d_guide += dq_w.sum(0)
     if gc is not None:
         att = gc.attn_layer
         nh, hd = att.num_heads, att.head_dim
@@ -175,8 +204,10 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout):
         grads[P + "attn_layer.q_proj.bias"] = dqp.sum(0)
         if gc.use_guide in (None, "off"):
             grads[P + "query"] = dqp @ Wq + dpre                           # the learnable queries: through q_proj and the residual
+        elif want_guide:
+            d_guide += (dqp @ Wq + dpre).sum(0)                            # direct: the injected query IS the guide (:352-368)
         # (direct: global_compressor.query does not enter the forward, ref :352-368 uses only its shape: no gradient)
-    return grads, d_nl
+    return grads, d_nl, d_fe, d_guide
 
 
 def forward_with_grad(proj, frames_feature, frames_embed, guide_embed, modal, image_newline):

@@ -190,6 +190,158 @@ __global__ __launch_bounds__(256) void local_attn_kernel(LocalParams p) {
     for (int c = tid; c < D; c += 256) out[c] = (part[c] + part[D + c]) + (part[2 * D + c] + part[3 * D + c]);
 }
 
+// ---- backward of the windowed attention (training path; stage 3 of the reference's script trains the
+// SigLIP head and the guide encoder too: train.py:717-726, so the gradients w.r.t. the KEY stream frames_embed and the query
+// are needed; frames_feature comes from the frozen tower body).  Per window, autograd through projector.py:550-553:
+//     s_i = scale q.k_i + bias,  p = softmax(s),  ctx = sum_i p_i v_i
+//     dP_i = dctx . v_i,  dS_i = p_i (dP_i - sum_j p_j dP_j),  dq = scale sum_i dS_i k_i,  dk_i = scale dS_i q
+// Same mapping as the forward kernel: one 4-wave workgroup per window, a token row over the 64 lanes; the key rows are read
+// twice (scores, then dq), the value rows once.  dkey is written by plain stores: the caller guarantees an exact partition
+// (every token in exactly one window).
+struct LocalBwdParams {
+    const uint16_t* key;
+    const uint16_t* value;
+    const void* query;
+    int query_f32;
+    long query_stride;
+    hicom_axis at, ay, ax;
+    float scale, bias;
+    const float* dctx;     // [Nw, D]
+    float* dq;             // [Nw, D]
+    uint16_t* dkey;        // bf16 [N, D] or NULL
+};
+
+template <int NV>
+__global__ __launch_bounds__(256) void local_attn_bwd_kernel(LocalBwdParams p) {
+    constexpr int D = NV * 384;
+    extern __shared__ __attribute__((aligned(16))) float lsm[];
+    const int ks2 = p.ay.k * p.ax.k;
+    const int WIN = p.at.k * ks2;
+    const int WP = (WIN + 3) & ~3;
+    float* sc = lsm;                              // [WIN] scores, then dS
+    float* dp = lsm + WP;                         // [WIN] dP
+    float* part = lsm + 2 * WP;                   // [4][D] partial dq
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int win = blockIdx.x;
+    const int w1 = win % p.ax.nwin;
+    const int h1 = (win / p.ax.nwin) % p.ay.nwin;
+    const int t1 = win / (p.ax.nwin * p.ay.nwin);
+    const int t0 = axis_start(p.at, t1), y0 = axis_start(p.ay, h1), x0 = axis_start(p.ax, w1);
+    const int H = p.ay.n, W = p.ax.n;
+
+    float q[NV][6], g[NV][6];
+    if (p.query_f32) {
+        const float* qp = reinterpret_cast<const float*>(p.query) + (long)win * p.query_stride;
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) q[s][j] = qp[384 * s + 6 * lane + j];
+    } else {
+        load_row<NV>(reinterpret_cast<const uint16_t*>(p.query) + (long)win * p.query_stride, lane, q);
+    }
+    load_row_f32<NV>(p.dctx + (long)win * D, lane, g);
+
+    auto token_of = [&](int i) -> long {
+        const int t2 = i / ks2, r = i - t2 * ks2;
+        const int h2 = r / p.ax.k, w2 = r - h2 * p.ax.k;
+        return ((long)(t0 + t2) * H + (y0 + h2)) * W + (x0 + w2);
+    };
+
+    // ---- phase 1: scores and dP ------------------------------------------------------------------
+    for (int i0 = wave; i0 < WIN; i0 += 8) {      // 2 tokens (key + value rows) in flight per wave
+        float k[2][NV][6], v[2][NV][6];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + 4 * u;
+            if (i < WIN) {
+                const long tok = token_of(i);
+                load_row<NV>(p.key + tok * D, lane, k[u]);
+                load_row<NV>(p.value + tok * D, lane, v[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + 4 * u;
+            if (i < WIN) {
+                float dot = 0.f, dd = 0.f;
+#pragma unroll
+                for (int s = 0; s < NV; ++s)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        dot = fmaf(q[s][j], k[u][s][j], dot);
+                        dd = fmaf(g[s][j], v[u][s][j], dd);
+                    }
+                dot = wave_sum(dot);
+                dd = wave_sum(dd);
+                if (lane == 0) { sc[i] = dot * p.scale + p.bias; dp[i] = dd; }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- softmax statistics and delta (every wave redundantly; WIN is tiny) ----------------------------
+    float mx = -3.0e38f;
+    for (int i = lane; i < WIN; i += 64) mx = fmaxf(mx, sc[i]);
+    mx = wave_max(mx);
+    float sum = 0.f, pd = 0.f;
+    for (int i = lane; i < WIN; i += 64) {
+        const float e = expf(sc[i] - mx);
+        sum += e;
+        pd = fmaf(e, dp[i], pd);
+    }
+    const float inv_sum = 1.0f / wave_sum(sum);
+    const float delta = wave_sum(pd) * inv_sum;
+    __syncthreads();                               // every wave has read sc / dp as scores
+    if (wave == 0)
+        for (int i = lane; i < WIN; i += 64) sc[i] = expf(sc[i] - mx) * inv_sum * (dp[i] - delta);     // dS
+    __syncthreads();
+
+    // ---- phase 2: dq = scale sum_i dS_i k_i ;  dkey_i = scale dS_i q -----------------------------------------
+    float acc[NV][6];
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[s][j] = 0.f;
+    for (int i0 = wave; i0 < WIN; i0 += 12) {
+        float k[3][NV][6];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int i = i0 + 4 * u;
+            if (i < WIN) load_row<NV>(p.key + token_of(i) * D, lane, k[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int i = i0 + 4 * u;
+            if (i < WIN) {
+                const float ds = sc[i] * p.scale;
+#pragma unroll
+                for (int s = 0; s < NV; ++s)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc[s][j] = fmaf(ds, k[u][s][j], acc[s][j]);
+                if (p.dkey) {
+                    uint16_t* o = p.dkey + token_of(i) * D;
+#pragma unroll
+                    for (int s = 0; s < NV; ++s) {
+                        Seg12 w;
+                        w.a = f32_to_bf16(ds * q[s][0]) | ((uint32_t)f32_to_bf16(ds * q[s][1]) << 16);
+                        w.b = f32_to_bf16(ds * q[s][2]) | ((uint32_t)f32_to_bf16(ds * q[s][3]) << 16);
+                        w.c = f32_to_bf16(ds * q[s][4]) | ((uint32_t)f32_to_bf16(ds * q[s][5]) << 16);
+                        *reinterpret_cast<Seg12*>(o + 384 * s + 6 * lane) = w;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) part[wave * D + 384 * s + 6 * lane + j] = acc[s][j];
+    __syncthreads();
+    float* out = p.dq + (long)win * D;
+    for (int c = tid; c < D; c += 256) out[c] = (part[c] + part[D + c]) + (part[2 * D + c] + part[3 * D + c]);
+}
+
 // ---- pooled per-window query (trilinear, align_corners=False; projector.py:539-540) ----------
 struct PoolParams {
     const uint16_t* x;
@@ -261,6 +413,34 @@ extern "C" int hicom_local_attn_fwd(const void* key, int32_t key_dt, const void*
     if (D == 1152) hipLaunchKernelGGL(local_attn_kernel<3>, dim3((unsigned)nwin), dim3(256), smem, s, p);
     else hipLaunchKernelGGL(local_attn_kernel<2>, dim3((unsigned)nwin), dim3(256), smem, s, p);
     return hicom_host::check_launch("local_attn");
+}
+
+extern "C" int hicom_local_attn_bwd(const void* key, const void* value, int32_t D,
+                                    hicom_axis at, hicom_axis ay, hicom_axis ax,
+                                    const void* query, int32_t query_dt, int64_t query_stride,
+                                    float scale, float bias, const float* dctx, float* dq, void* dkey, void* stream) {
+    HICOM_REQUIRE(key && value && query && dctx && dq, HICOM_EINVAL, "local_attn_bwd: NULL pointer");
+    HICOM_REQUIRE(D == 1152 || D == 768, HICOM_EUNSUP, "local_attn_bwd: D=%d (only 1152 / 768)", D);
+    HICOM_REQUIRE(query_dt == HICOM_DT_BF16 || query_dt == HICOM_DT_F32, HICOM_EINVAL, "local_attn_bwd: query dtype");
+    for (const hicom_axis* a : {&at, &ay, &ax}) {
+        HICOM_REQUIRE(a->n > 0 && a->k > 0 && a->nwin > 0 && a->nfull >= 0 && a->nfull <= a->nwin && a->k <= a->n,
+                      HICOM_EINVAL, "local_attn_bwd: bad axis n=%d k=%d nwin=%d nfull=%d", a->n, a->k, a->nwin, a->nfull);
+        const int last = axis_start(*a, a->nwin - 1);
+        HICOM_REQUIRE(last >= 0 && last + a->k <= a->n, HICOM_EINVAL, "local_attn_bwd: window runs off the axis");
+        // dkey is written with plain stores: windows must not overlap
+        if (dkey) HICOM_REQUIRE((long)a->nwin * a->k == a->n, HICOM_EUNSUP, "local_attn_bwd: dkey needs an exact window partition (n=%d k=%d)", a->n, a->k);
+    }
+    const long win = (long)at.k * ay.k * ax.k;
+    HICOM_REQUIRE(win <= 4096, HICOM_EUNSUP, "local_attn_bwd: window of %ld tokens is too large", win);
+    const long nwin = (long)at.nwin * ay.nwin * ax.nwin;
+    HICOM_REQUIRE(nwin < (1L << 31), HICOM_EINVAL, "local_attn_bwd: too many windows");
+    LocalBwdParams p{(const uint16_t*)key, (const uint16_t*)value, query, query_dt == HICOM_DT_F32, (long)query_stride, at, ay, ax,
+                     scale, bias, dctx, dq, (uint16_t*)dkey};
+    const size_t smem = 2 * (((size_t)win + 3) & ~(size_t)3) * 4 + 4 * (size_t)D * 4;
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 1152) hipLaunchKernelGGL(local_attn_bwd_kernel<3>, dim3((unsigned)nwin), dim3(256), smem, s, p);
+    else hipLaunchKernelGGL(local_attn_bwd_kernel<2>, dim3((unsigned)nwin), dim3(256), smem, s, p);
+    return hicom_host::check_launch("local_attn_bwd");
 }
 
 extern "C" int hicom_trilinear_pool_fwd(const void* x, int32_t T, int32_t H, int32_t W, int32_t D,

@@ -21,7 +21,7 @@ DT_BF16, DT_F32, DT_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_GELU_TANH = 0, 1, 2
 
 EXPORTS = (
-    "hicom_abi_version", "hicom_last_error", "hicom_local_attn_fwd", "hicom_trilinear_pool_fwd",
+    "hicom_abi_version", "hicom_last_error", "hicom_local_attn_fwd", "hicom_local_attn_bwd", "hicom_trilinear_pool_fwd",
     "hicom_linear_fwd", "hicom_fold_query_fwd", "hicom_split_bf16_fwd", "hicom_global_stream_fwd",
     "hicom_global_stream_nparts", "hicom_global_merge_fwd", "hicom_global_combine_fwd",
     "hicom_readout_gemm_fwd", "hicom_scatter_rows_fwd", "hicom_fold_query_split_fwd",
@@ -103,6 +103,7 @@ def lib() -> C.CDLL:
         raise HicomNativeError(f"ABI mismatch: library {L.hicom_abi_version()} vs binding {ABI_VERSION}; rebuild")
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     L.hicom_local_attn_fwd.argtypes = [vp, i32, vp, i32, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32, i32, vp, vp]
+    L.hicom_local_attn_bwd.argtypes = [vp, vp, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32, vp, vp, vp, vp]
     L.hicom_trilinear_pool_fwd.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.hicom_linear_fwd.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.hicom_fold_query_fwd.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp]
@@ -191,6 +192,13 @@ def local_attn(key, value, axes, query, query_stride, scale, bias, l2norm, ctx):
     D = value.shape[-1]
     _check(lib().hicom_local_attn_fwd(_ptr(key), _dt(key), _ptr(value), _dt(value), D, axes[0], axes[1], axes[2], _ptr(query), _dt(query),
                                       query_stride, scale, bias, l2norm, _ptr(ctx), _stream()), "hicom_local_attn_fwd")
+
+
+def local_attn_bwd(key, value, axes, query, query_stride, scale, bias, dctx, dq, dkey=None):
+    D = value.shape[-1]
+    assert key.dtype == torch.bfloat16 and value.dtype == torch.bfloat16 and dctx.dtype == torch.float32 and dq.dtype == torch.float32
+    _check(lib().hicom_local_attn_bwd(_ptr(key), _ptr(value), D, axes[0], axes[1], axes[2], _ptr(query), _dt(query), query_stride,
+                                      scale, bias, _ptr(dctx), _ptr(dq), _ptr(dkey), _stream()), "hicom_local_attn_bwd")
 
 
 def trilinear_pool(x, out):

@@ -72,6 +72,17 @@ int hicom_local_attn_fwd(const void* key, int32_t key_dt, const void* value, int
                          float scale, float bias, int32_t l2norm,
                          float* ctx, void* stream);
 
+/* ---- backward of the windowed attention (training path; autograd through projector.py:550-553) ----------
+ * For the reference's stage 3 (train.py:717-726: the SigLIP head and the guide encoder train too) the gradients
+ * w.r.t. the key stream frames_embed and the query are needed.
+ *   key, value : bf16 [T,H,W,D];  query as in hicom_local_attn_fwd;  dctx : f32 [Nw, D] upstream gradient of ctx
+ *   dq         : f32 [Nw, D]  scale * sum_i dS_i k_i per window (a shared query's gradient is the sum over windows)
+ *   dkey       : bf16 [T,H,W,D] scale * dS_i * q, or NULL; needs an exact window partition (plain stores) */
+int hicom_local_attn_bwd(const void* key, const void* value, int32_t D,
+                         hicom_axis at, hicom_axis ay, hicom_axis ax,
+                         const void* query, int32_t query_dt, int64_t query_stride,
+                         float scale, float bias, const float* dctx, float* dq, void* dkey, void* stream);
+
 /* ---- pooled per-window query: F.interpolate(..., 'trilinear', align_corners=False) --------
  * Replaces projector.py:539-540.  x bf16 [T,H,W,D] -> out f32 [t',h',w',D]. */
 int hicom_trilinear_pool_fwd(const void* x, int32_t T, int32_t H, int32_t W, int32_t D,

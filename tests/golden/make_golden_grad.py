@@ -1,4 +1,4 @@
-"""Generates tests/golden/golden_grad_v1.npz: parameter gradients of the REFERENCE (imported in place from
+"""Generates tests/golden/golden_grad_v1.npz: parameter (and, for the direct recipe, guide_embed / frames_embed) gradients of the REFERENCE (imported in place from
 /root/reference through oracle/ref_shim.py, float32 autograd) for loss = sum(out * R), R a fixed synthetic cotangent.
 
 Run in the build container only:  python tests/golden/make_golden_grad.py
@@ -44,6 +44,13 @@ def main():
         module.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd.items()}, strict=True)
         t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))
         ff, fe, g = t(case.ff), t(case.fe), t(case.g)
+        # stage 3 of the reference's script also trains what produces frames_embed and guide_embed (train.py:717-726):
+        # record their gradients for the direct recipe
+        direct = getattr(case.cfg, "use_guide", None) == "direct" and g is not None
+        if direct:
+            g = g.clone().requires_grad_(True)
+            if fe is not None:
+                fe = fe.clone().requires_grad_(True)
         nl = None
         if case.newline is not None:
             nl = torch.nn.Parameter(t(case.newline))
@@ -53,6 +60,10 @@ def main():
         items = [(k, p.grad) for k, p in module.named_parameters()]
         if nl is not None:
             items.append(("image_newline", nl.grad))
+        if direct:
+            items.append(("__guide_embed__", g.grad))
+            if fe is not None:
+                items.append(("__frames_embed__", fe.grad))
         for k, gr in items:
             if gr is None:
                 blobs[f"{name}/{k}/none"] = np.zeros(1, dtype=np.uint8)

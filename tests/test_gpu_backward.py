@@ -44,6 +44,16 @@ def test_parameter_gradients_match_reference_autograd(name, golden_grad):
         nl = torch.nn.Parameter(dev_bf16(case.newline))
     with torch.no_grad():
         want_out = m(ff, fe, g, case.modal, nl).clone()
+    # direct recipe: the fixture also holds the reference's d guide_embed / d frames_embed (stage 3 trains their producers)
+    inputs = []
+    if f"{name}/__guide_embed__/samples" in golden_grad:
+        g.requires_grad_(True)
+        inputs.append(("__guide_embed__", g))
+        lc = m.local_compressor
+        exact = lc is None or all(a.nwin * a.k == a.n for a in lc.tilings(*ff.shape[:3], case.modal))
+        if fe is not None and exact:
+            fe.requires_grad_(True)
+            inputs.append(("__frames_embed__", fe))
     out = m(ff, fe, g, case.modal, nl)
     assert out.requires_grad and torch.equal(out.detach(), want_out)        # same kernels, same bits as inference
     R = torch.from_numpy(mg.cotangent(name, out.shape)).cuda()
@@ -52,6 +62,7 @@ def test_parameter_gradients_match_reference_autograd(name, golden_grad):
     items = [(k, p) for k, p in m.named_parameters()]
     if nl is not None:
         items.append(("image_newline", nl))
+    items += inputs
     checked = 0
     mx_case = max(float(golden_grad[f][2]) for f in golden_grad.files if f.startswith(name + "/") and f.endswith("/sums"))
     for k, p in items:
@@ -70,24 +81,56 @@ def test_parameter_gradients_match_reference_autograd(name, golden_grad):
             assert abs(float(fp32[k].double().sum()) - s) <= 2e-3 * sabs + tol * p.numel() ** 0.5, k
         assert np.abs(got16 - want).max() <= 2 ** -7 * mx + tol, k              # the bf16 cast of it
         checked += 1
-    assert checked >= 4
+    assert checked >= 4 + len(inputs)
 
 
 def test_unsupported_recipes_and_input_grads_refuse():
-    """coarse / fine / adaptors have no backward yet, and gradients w.r.t. the inputs are not built: both must raise, never
-    return a detached tensor or a silent None."""
+    """coarse / fine / adaptors have no backward yet; the gradient w.r.t. frames_feature (frozen tower body) is not built, nor
+    are input gradients of the guide-off recipe or d frames_embed over overlapping windows: all must raise, never return a
+    detached tensor or a silent None."""
     for name in ("G6_coarse", "G5_adaptkv"):
         case = cases.build_case(name)
         m = build_module(case).train()
         ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
         with pytest.raises(NotImplementedError):
             m(ff, fe, g, case.modal, None)
-    case = cases.build_case("G1_direct_T8")
-    m = build_module(case).train()
-    ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g).requires_grad_(True)
-    out = m(ff, fe, g, case.modal, None)
-    with pytest.raises(NotImplementedError):
-        out.sum().backward()
+    for name, which in (("G1_direct_T8", "ff"), ("G2_off_T8", "fe"), ("G3_direct_T7", "fe")):
+        case = cases.build_case(name)
+        m = build_module(case).train()
+        t = {"ff": dev_bf16(case.ff), "fe": dev_bf16(case.fe), "g": dev_bf16(case.g)}
+        t[which].requires_grad_(True)
+        out = m(t["ff"], t["fe"], t["g"], case.modal, None)
+        with pytest.raises(NotImplementedError):
+            out.sum().backward()
+
+
+def test_input_gradients_at_benchmark_size():
+    """C2: d frames_embed / d guide_embed at full size through properties of the softmax Jacobian: every window's dS sums to
+    zero, so d frames_embed[n] = s_n q with sum over a window's s_n = 0 (checked through a channel where q != 0), and a
+    cotangent that is zero on the local rows gives d frames_embed = 0 exactly."""
+    from types import SimpleNamespace
+    from hicom_amd import synth
+    from oracle import hicom_oracle as orc
+    cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "hidden_size": 896, "max_num_frames": 64})
+    sd = synth.synth_state_dict(orc.param_shapes(cfg), tag="c2")
+    x = synth.synth_inputs(64, 27, 27, 1152, tag="c2")
+    m = build_module(SimpleNamespace(cfg=cfg, sd=sd)).train()
+    ff, fe, g = dev_bf16(x["ff"]), dev_bf16(x["fe"]).requires_grad_(True), dev_bf16(x["g"]).requires_grad_(True)
+    out = m(ff, fe, g, "video", None)
+    R = torch.randn(out.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    (out * R).sum().backward()
+    assert fe.grad.shape == fe.shape and fe.grad.dtype == fe.dtype and bool(torch.isfinite(fe.grad.float()).all())
+    assert g.grad.shape == g.shape and float(g.grad.float().abs().max()) > 0
+    c = int(torch.argmax(g.detach().float().abs()))
+    s = fe.grad.float()[..., c] / float(g.detach().float().reshape(-1)[c])              # s_n up to bf16 rounding
+    win = s.view(16, 4, 9, 3, 9, 3).sum((1, 3, 5))                                      # per-window sums
+    assert float(win.abs().max()) <= 2e-2 * float(s.abs().max()) * 36 ** 0.5 + 1e-9
+    fe.grad = None
+    R2 = R.clone()
+    R2[:1296] = 0
+    out = m(ff, fe, g, "video", None)
+    (out * R2).sum().backward()
+    assert float(fe.grad.float().abs().max()) == 0.0
 
 
 def test_backward_at_benchmark_size():

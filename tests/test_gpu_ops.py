@@ -515,3 +515,46 @@ def test_readout16_aux_gemv_and_merge_vproj():
     nv.readout16_gemm(a16, w16, None, out_f16=o16, aux=dict(xs=yv.view(1, -1), w=w3, act=nv.ACT_GELU, y=y3))
     torch.cuda.synchronize()
     assert maxabs(y3, torch.nn.functional.gelu(want.float().double() @ w3.double().t())) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("T,H,W,kt,ks,shared_query", [(8, 6, 6, 4, 3, True), (7, 7, 5, 4, 3, False), (4, 6, 6, 4, 3, False)])
+def test_local_attn_bwd_matches_torch_autograd(T, H, W, kt, ks, shared_query):
+    """dq per window (any geometry, overlapping windows included) and d key (exact partitions) of the windowed attention against
+    torch autograd on the oracle's window gather (double precision)."""
+    x = synth.synth_inputs(T, H, W, D, tag=f"lb{T}{H}{W}")
+    at, ay, ax = geo.axis_tiling(T, kt), geo.axis_tiling(H, ks), geo.axis_tiling(W, ks)
+    axes = tuple(nv.Axis(a.n, a.k, a.nwin, a.nfull) for a in (at, ay, ax))
+    nw = at.nwin * ay.nwin * ax.nwin
+    exact = all(a.nwin * a.k == a.n for a in (at, ay, ax))
+    kb, vb = bf(x["fe"]), bf(x["ff"])
+    idx = orc.window_token_index(T, H, W, kt, ks).cuda()                              # [nw, win] token ids
+    key = kb.double().reshape(-1, D).requires_grad_(True)
+    val = vb.double().reshape(-1, D)
+    if shared_query:
+        qd = bf(x["g"])
+        q = qd.double().reshape(1, D).requires_grad_(True)
+        qw = q.expand(nw, D)
+    else:
+        qd = torch.from_numpy(synth.normal_like((nw, D), 77)).cuda()
+        q = qd.double().requires_grad_(True)
+        qw = q
+    scale = 1 / math.sqrt(D)
+    s = torch.einsum("wd,wnd->wn", qw, key[idx]) * scale
+    ctx = torch.einsum("wn,wnd->wd", torch.softmax(s, dim=1), val[idx])
+    dctx = torch.from_numpy(synth.normal_like((nw, D), 78)).cuda()
+    (ctx * dctx.double()).sum().backward()
+    dq = f32((nw, D))
+    dkey = torch.zeros_like(kb) if exact else None
+    nv.local_attn_bwd(kb, vb, axes, qd.reshape(-1) if shared_query else qd, 0 if shared_query else D, scale, 0.0, dctx, dq, dkey)
+    torch.cuda.synchronize()
+    want_dq = q.grad if not shared_query else None
+    if shared_query:
+        assert maxabs(dq.sum(0), q.grad.reshape(-1)) <= 2e-5 * max(1.0, float(q.grad.abs().max()))
+    else:
+        assert maxabs(dq, want_dq) <= 2e-5 * max(1.0, float(want_dq.abs().max()))
+    if exact:
+        mx = float(key.grad.abs().max())
+        assert maxabs(dkey.float().reshape(-1, D), key.grad) <= 2 ** -8 * mx + 1e-7       # bf16 store of the fp32 value
+    else:
+        with pytest.raises(nv.HicomNativeError):
+            nv.local_attn_bwd(kb, vb, axes, qd, D, scale, 0.0, dctx, dq, torch.zeros_like(kb))
