@@ -395,6 +395,28 @@ def neighbours_sweep(args, device):
         out["c4_compressor_plus_splice"] = {"compressor_ms": dt_c * 1e3, "splice_ms": dt_s * 1e3, "compressed_tokens": int(tok.shape[0]),
                                             "embeds_shape": list(res[3].shape),
                                             "note": "32 frames, hidden 3584 (Qwen2.5-7B width); SigLIP tower and LLM prefill not included (no weights offline)"}
+    # f4: one training step of the projector at the benchmark shape (forward with a graph + backward), release recipe:
+    # projector parameters only (stages 1-2 of the reference's script) and with d frames_embed / d guide_embed (stage 3)
+    cfg = release_config(args.hidden, args.frames_per_gpu)
+    m = make_projector(cfg, device).train()
+    ff = torch.randn(args.frames_per_gpu, GRID, GRID, D, device=device, generator=gen).to(torch.bfloat16)
+    fe = torch.randn(args.frames_per_gpu, GRID, GRID, D, device=device, generator=gen).to(torch.bfloat16)
+    g = torch.randn(D, device=device, generator=gen).to(torch.bfloat16)
+    cot = None
+
+    def train_step(inputs_too):
+        nonlocal cot
+        fe_, g_ = (fe.detach().requires_grad_(True), g.detach().requires_grad_(True)) if inputs_too else (fe, g)
+        o = m(ff, fe_, g_, "video", None)
+        if cot is None:
+            cot = torch.randn(o.shape, device=device, generator=gen).to(o.dtype)
+        o.backward(cot)
+        return o
+
+    for flag, key in ((False, "params_only_ms"), (True, "with_input_grads_ms")):
+        train_step(flag)
+        dt, _ = best(lambda: train_step(flag), n=5)
+        out.setdefault("train_step", {"workload": f"{args.frames_per_gpu} frames, hidden {args.hidden}, use_guide=direct: forward() under autograd + backward (recompute-based, hicom_amd/autograd.py)"})[key] = dt * 1e3
     return out
 
 
