@@ -84,21 +84,25 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(LinearParams p) {
 #pragma unroll
     for (int r = 0; r < MR; ++r) acc[r] = 0.f;
     const int head = p.head_dim > 0 ? n / p.head_dim : 0;
-#pragma unroll 3
+    // x rows of this pass (rows past M re-read the last one and are dropped at the store): their loads are unconditional, so
+    // all MR of them and the weight chunk are in flight together -- with a branch around each row the compiler kept the loads
+    // serial and a 32-row call cost MR L2 round trips per K chunk (20 us at 32 x 1152 x 1152)
+    long xoff[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        const int m = m0 + r < p.M ? m0 + r : p.M - 1;
+        xoff[r] = (p.head_dim > 0 ? (long)m * p.head_rows + head : (long)m) * p.K;
+    }
+#pragma unroll 2
     for (int k = lane * 8; k < p.K; k += 512) {
-        float wv[8];
+        float wv[8], xv[MR][8];
         load8<WF32>(p.w, (long)n * p.K + k, wv);
 #pragma unroll
-        for (int r = 0; r < MR; ++r) {
-            const int m = m0 + r;
-            if (m < p.M) {
-                const long xr = p.head_dim > 0 ? (long)m * p.head_rows + head : m;
-                float xv[8];
-                load8<XF32>(p.x, xr * p.K + k, xv);
+        for (int r = 0; r < MR; ++r) load8<XF32>(p.x, xoff[r] + k, xv[r]);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[r] = fmaf(xv[i], wv[i], acc[r]);
-            }
-        }
+        for (int r = 0; r < MR; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[r] = fmaf(xv[r][i], wv[i], acc[r]);
     }
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
@@ -119,6 +123,105 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(LinearParams p) {
                     const long o = (p.row0 + m + (long)k * p.M) * p.ldd + n;
                     if (p.dst_f32) reinterpret_cast<float*>(p.dst)[o] = v;
                     else reinterpret_cast<uint16_t*>(p.dst)[o] = f32_to_bf16(v);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same linear for 2 .. 64 rows on the matrix cores: y[M <= 64, N] = act(x . w^T + b) + res, bf16 weights.
+// The GEMV form above re-reads every weight row once per 8 rows and spends ~150 VALU ops per lane and K chunk on bf16
+// unpacking and shuffle reductions: 13-19 us for a 32..64-row call at 1152 x 1152, and the guide-off / coarse / fine recipes
+// make 6-12 such calls per forward.  Here a workgroup owns 16 output columns; its 4 waves take every fourth K step of 32
+// (B fragment = 16 weight rows x 64 B straight from global memory, A fragments = the x rows, fp32 inputs split into bf16
+// hi + lo: two MFMAs per block), the four partial tiles meet in LDS and wave i finishes row block i.
+// ---------------------------------------------------------------------------------------------
+template <bool XF32, int MB>
+__global__ __launch_bounds__(256) void linear_mfma_kernel(LinearParams p) {
+    __shared__ __attribute__((aligned(16))) float red[4][MB][256];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int head = p.head_dim > 0 ? n0 / p.head_dim : 0;
+    const uint16_t* wrow = reinterpret_cast<const uint16_t*>(p.w) + (long)(n0 + r16) * p.K + 8 * kg;
+    long xoff[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int m = 16 * i + r16 < p.M ? 16 * i + r16 : p.M - 1;
+        xoff[i] = (p.head_dim > 0 ? (long)m * p.head_rows + head : (long)m) * p.K + 8 * kg;
+    }
+    f32x4 acc[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nks = p.K >> 5;
+    // K steps whose loads are in flight together: all 9 of a wave's share at K = 1152 where the registers allow (one memory
+    // round trip per call instead of three)
+    constexpr int U = XF32 ? (MB > 2 ? 3 : 9) : 9;
+    for (int base = wave; base < nks; base += 4 * U) {
+        bf16x8 wf[U];
+        float xa[U][MB][8];
+        bf16x8 xb[U][MB];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ks = base + 4 * u < nks ? base + 4 * u : nks - 1;       // (clamped: a repeated step is zeroed below)
+            wf[u] = *reinterpret_cast<const bf16x8*>(wrow + 32 * ks);
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                if constexpr (XF32) load8<true>(p.x, xoff[i] + 32 * ks, xa[u][i]);
+                else xb[u][i] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const uint16_t*>(p.x) + xoff[i] + 32 * ks);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                    // every load above is issued before the first use below
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (base + 4 * u >= nks) wf[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};     // a clamped (repeated) step adds nothing; no branch
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                if constexpr (XF32) {
+                    bf16x8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        uint16_t h, l;
+                        split_bf16(xa[u][i][e], h, l);
+                        hi[e] = (short)h;
+                        lo[e] = (short)l;
+                    }
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, wf[u], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, wf[u], acc[i], 0, 0, 0);
+                } else {
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[u][i], wf[u], acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) *reinterpret_cast<f32x4*>(&red[wave][i][4 * lane]) = acc[i];
+    __syncthreads();
+    for (int i = wave; i < MB; i += 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][i][4 * lane]);
+        v += *reinterpret_cast<const f32x4*>(&red[1][i][4 * lane]);
+        v += *reinterpret_cast<const f32x4*>(&red[2][i][4 * lane]);
+        v += *reinterpret_cast<const f32x4*>(&red[3][i][4 * lane]);
+        const int n = n0 + r16;
+        float bias = 0.f;
+        if (p.b) bias = p.b_f32 ? reinterpret_cast<const float*>(p.b)[n] : bf16_to_f32(reinterpret_cast<const uint16_t*>(p.b)[n]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = 16 * i + 4 * kg + q;
+            if (m >= p.M) continue;
+            float o = v[q] + bias;
+            if (p.act == HICOM_ACT_GELU) o = gelu_erf(o);
+            if (p.res) {
+                const long ri = ((p.res_flags & 1) ? 0 : (long)m * p.N) + n;
+                o += (p.res_flags & 2) ? bf16_to_f32(reinterpret_cast<const uint16_t*>(p.res)[ri]) : reinterpret_cast<const float*>(p.res)[ri];
+            }
+            if (p.y) p.y[(long)m * p.N + n] = o;
+            if (p.dst) {
+                for (int k = 0; k < p.reps; ++k) {
+                    const long off = (p.row0 + m + (long)k * p.M) * p.ldd + n;
+                    if (p.dst_f32) reinterpret_cast<float*>(p.dst)[off] = o;
+                    else reinterpret_cast<uint16_t*>(p.dst)[off] = f32_to_bf16(o);
                 }
             }
         }
@@ -328,7 +431,22 @@ static int launch_linear(const LinearParams& p, void* stream) {
         else if (p.w_f32) HICOM_LAUNCH((linear_rows_kernel<false, true, MR>), grid, dim3(256), 0, s, p);                \
         else HICOM_LAUNCH((linear_rows_kernel<false, false, MR>), grid, dim3(256), 0, s, p);                            \
     } while (0)
-    if (M == 1) HICOM_LAUNCH_LINEAR(1);     // GEMV: one shuffle reduction per column instead of eight
+    const bool mfma = M >= 2 && M <= 64 && !p.w_f32 && p.K % 32 == 0 && N % 16 == 0 && (p.head_dim == 0 || p.head_dim % 16 == 0) &&
+                      (uintptr_t)p.x % 16 == 0 && (uintptr_t)p.w % 16 == 0;
+    if (mfma) {
+        const dim3 grid((unsigned)(N / 16));
+        const int mb = (M + 15) / 16;
+#define HICOM_LAUNCH_MFMA(MB)                                                                                           \
+    do {                                                                                                               \
+        if (p.x_f32) HICOM_LAUNCH((linear_mfma_kernel<true, MB>), grid, dim3(256), 0, s, p);                            \
+        else HICOM_LAUNCH((linear_mfma_kernel<false, MB>), grid, dim3(256), 0, s, p);                                   \
+    } while (0)
+        if (mb == 1) HICOM_LAUNCH_MFMA(1);
+        else if (mb == 2) HICOM_LAUNCH_MFMA(2);
+        else if (mb == 3) HICOM_LAUNCH_MFMA(3);
+        else HICOM_LAUNCH_MFMA(4);
+#undef HICOM_LAUNCH_MFMA
+    } else if (M == 1) HICOM_LAUNCH_LINEAR(1);     // GEMV: one shuffle reduction per column instead of eight
     else HICOM_LAUNCH_LINEAR(8);
 #undef HICOM_LAUNCH_LINEAR
     return hicom_host::check_launch("linear");

@@ -74,7 +74,9 @@ def test_local_attn_clip_scale_and_uniform():
 
 
 @pytest.mark.parametrize("M,N,K,xdt,wdt", [(1, 1152, 1152, "bf16", "bf16"), (32, 1152, 1152, "f32", "bf16"),
-                                           (9, 118, 1152, "f32", "f32"), (3, 64, 1152, "f32", "bf16"), (32, 896, 896, "f32", "bf16")])
+                                           (9, 118, 1152, "f32", "f32"), (3, 64, 1152, "f32", "bf16"), (32, 896, 896, "f32", "bf16"),
+                                           (64, 1152, 1152, "bf16", "bf16"), (17, 1152, 1152, "f32", "bf16"), (50, 48, 96, "f32", "bf16"),
+                                           (2, 2304, 1152, "bf16", "bf16"), (65, 1152, 1152, "f32", "bf16")])
 def test_linear_matches_torch(M, N, K, xdt, wdt):
     x = synth.normal_like((M, K), 11)
     w = synth.normal_like((N, K), 12, 0.05)
@@ -418,8 +420,9 @@ def test_row_ln_variants_match_torch():
     assert maxabs(out, 0.5 * src.double().cpu() + 0.5 * ln(x.cpu())) <= 2e-5
 
 
-def test_small_mha_matches_torch():
-    M, L, nh, hd = 21, 64, 9, 128
+@pytest.mark.parametrize("M,L,nh,hd", [(21, 64, 9, 128), (1296, 64, 9, 128), (100, 37, 12, 64), (70, 5, 6, 96), (65, 64, 3, 256)])
+def test_small_mha_matches_torch(M, L, nh, hd):
+    """both forms: the LDS-staged one (head dim <= 128) and one wave per (row, head) for wider heads"""
     E = nh * hd
     q, k, v = (torch.from_numpy(synth.normal_like(s, sd, 0.3)).cuda() for s, sd in (((M, E), 111), ((L, E), 112), ((L, E), 113)))
     out = f32((M, E))
