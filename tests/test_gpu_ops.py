@@ -396,8 +396,10 @@ def test_planes_gemm_matches_torch(M, N, K, act):
     assert maxabs(o_hi.float() + o_lo.float(), want_hi) <= tol
 
 
-def test_row_ln_variants_match_torch():
-    M, E = 37, 1152
+@pytest.mark.parametrize("E", [1152, 768, 100, 1528])
+def test_row_ln_variants_match_torch(E):
+    """E % 8 == 0: the 8-wide kernel (E = 1528: a partly filled third chunk); E = 100: the scalar form"""
+    M = 37
     x = torch.from_numpy(synth.normal_like((M, E), 101)).cuda()
     mul = torch.from_numpy(synth.normal_like((1, E), 102, 0.3)).cuda()
     add = torch.from_numpy(synth.normal_like((M, E), 103)).cuda()
