@@ -67,6 +67,14 @@ __device__ __forceinline__ float xrow4_sum(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// sum over the 32 lanes of a half wave (rows {0,1} or {2,3}): DPP rows, then one v_permlane16_swap
+__device__ __forceinline__ float half32_sum(float v) {
+    v = row16_sum(v);
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+__device__ __forceinline__ float wave_max_fast(float v) { return xrow4_max(row16_max(v)); }
+
 // whole-wave sum without LDS: DPP row rotations (16-lane rows), then the two gfx950 row swaps.  __shfl_xor compiles to
 // ds_bpermute_b32, an LDS round trip per step: six dependent ones per reduction.
 __device__ __forceinline__ float wave_sum_fast(float v) { return xrow4_sum(row16_sum(v)); }

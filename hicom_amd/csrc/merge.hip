@@ -23,13 +23,35 @@ __global__ __launch_bounds__(256) void frame_marginals_kernel(const float* score
     const float* s = scores + (long)r * score_stride + (long)t * HW;
     float* fy = e + HW;
     float* wred = fy + H;
+    // the frame's logits stay in registers between the max and the exp pass (H * W <= 1024: 4 per thread, loads in flight
+    // together); larger grids re-read them
+    float sv[4];
     float mx = -1.0e30f;
-    for (int i = threadIdx.x; i < HW; i += 256) mx = fmaxf(mx, s[i]);
+    const bool small = HW <= 1024;
+    if (small) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            sv[u] = i < HW ? s[i] : -1.0e30f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mx = fmaxf(mx, sv[u]);
+    } else {
+        for (int i = threadIdx.x; i < HW; i += 256) mx = fmaxf(mx, s[i]);
+    }
     mx = wave_max(mx);
     if (lane == 0) wred[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
-    for (int i = threadIdx.x; i < HW; i += 256) e[i] = expf(s[i] - mx);
+    if (small) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            if (i < HW) e[i] = expf(sv[u] - mx);
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += 256) e[i] = expf(s[i] - mx);
+    }
     __syncthreads();
     float* out = scratch + ((long)r * T + t) * (H + W + 2);
     for (int j = threadIdx.x; j < H + W; j += 256) {
@@ -47,6 +69,51 @@ __global__ __launch_bounds__(256) void frame_marginals_kernel(const float* score
         float a = 0.f;
         for (int y = 0; y < H; ++y) a += fy[y];
         out[H + W] = a;
+        out[H + W + 1] = mx;
+    }
+}
+
+// Wave form for grids up to 32 x 32 (27 x 27 here): one wave per (row, frame), no LDS and no block barrier.  Half-wave h owns
+// the grid rows y = 2k + h, lane x of a half the grid column x: all of a lane's <= 16 logits are loaded together, the column
+// marginal is a register sum (+ one cross-half shuffle), a row marginal a 32-lane butterfly.  The block form above keeps
+// 256 threads around three barriers for 54 short serial sums: 37 us for 288 x 64 frames; it stays for larger grids.
+__global__ __launch_bounds__(256) void frame_marginals_wave_kernel(const float* scores, long score_stride,
+                                                                   int R, int T, int H, int W, float* scratch) {
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (long)R * T) return;
+    const int r = (int)(wid / T), t = (int)(wid - (long)r * T);
+    const int half = lane >> 5, x = lane & 31;
+    const float* s = scores + (long)r * score_stride + (long)t * H * W;
+    float v[16];
+    float mx = -1.0e30f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int y = 2 * k + half;
+        v[k] = (x < W && y < H) ? s[y * W + x] : -1.0e30f;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mx = fmaxf(mx, v[k]);
+    mx = wave_max_fast(mx);
+    float* out = scratch + ((long)r * T + t) * (H + W + 2);
+    float xm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int y = 2 * k + half;
+        const float e = (x < W && y < H) ? expf(v[k] - mx) : 0.f;
+        xm += e;
+        const float ys = half32_sum(e);                       // (DPP + row swap: a shuffle butterfly is 5 LDS round trips per row)
+        if (x == 0 && y < H) out[y] = ys;
+    }
+    {
+        auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(xm), __float_as_uint(xm), false, false);
+        xm = __uint_as_float(b[0]) + __uint_as_float(b[1]);   // both halves of the column
+    }
+    if (half == 0 && x < W) out[H + x] = xm;
+    float tot = half == 0 ? xm : 0.f;
+    tot = wave_sum_fast(tot);
+    if (lane == 0) {
+        out[H + W] = tot;
         out[H + W + 1] = mx;
     }
 }
@@ -81,6 +148,12 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
 
 constexpr int kTC = 64;   // frames of marginals staged in LDS per pass (one pass for T <= 64)
 
+// MODE 0: one kernel does it all (no positional term: the weights are a few exps per workgroup).
+// With the positional term the row's weights (M, L, partial weights, the T + H + W positional weights out of the frame
+// marginals) cost more than the 32-column slab they are applied to, and every one of the E / 32 workgroups of a row used to
+// recompute them: MODE 1 (grid = rows) computes them once and leaves them at the head of the row's scratch region, MODE 2
+// (grid = rows x E / 32) applies them.
+template <int MODE>
 __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
     // LDS: [16*64] column partials | [4] | [nparts] partial weights | [T] frame weights |
     //      [T+H+W] positional weights | [kTC * S] staged marginals
@@ -104,11 +177,21 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
     const float* base = p.part_acc + (long)r * p.E + c4;
     const long pstride = (long)p.rows_pad * p.E;
     float4 v0[8];
-    const bool have0 = c4 < p.E && pgp + 32 * 7 < p.nparts;
+    const bool have0 = MODE != 1 && c4 < p.E && pgp + 32 * 7 < p.nparts;
     if (have0) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) v0[u] = *reinterpret_cast<const float4*>(base + (long)(pgp + 32 * u) * pstride);
     }
+    float M, L;
+    const bool has_pos = sc != nullptr;
+    if constexpr (MODE == 2) {
+        // weights left by the MODE 1 launch: [M, L | nparts partial weights | T + H + W positional weights]
+        float* wrow = const_cast<float*>(sc);
+        for (int i = tid; i < p.nparts; i += 256) wp[i] = wrow[2 + i];
+        for (int i = tid; i < p.T + HW2; i += 256) wpos[i] = wrow[2 + p.nparts + i];
+        M = wrow[0];
+        L = wrow[1];
+    } else {
     if (sc) {
         const int nt = min(kTC, p.T);
         for (int i = tid; i < nt * S; i += 256) tile[i] = sc[i];
@@ -117,16 +200,15 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
     // (M, L) of this row from the partials
     float mx = -1.0e30f;
     for (int i = tid; i < p.nparts; i += 256) mx = fmaxf(mx, p.part_m[(long)i * p.rows_pad + r]);
-    const float M = block_reduce_max(mx, red);
+    M = block_reduce_max(mx, red);
     float l = 0.f;
     for (int i = tid; i < p.nparts; i += 256) {
         const float w = expf(p.part_m[(long)i * p.rows_pad + r] - M);
         wp[i] = w;
         l += w * p.part_l[(long)i * p.rows_pad + r];
     }
-    const float L = block_reduce_sum(l, red);
+    L = block_reduce_sum(l, red);
 
-    const bool has_pos = sc != nullptr;
     if (sc) {
         float ay[4] = {0.f, 0.f, 0.f, 0.f};      // up to 4 * 256 spatial marginals per thread
         for (int t0 = 0; t0 < p.T; t0 += kTC) {
@@ -155,7 +237,21 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
             if (j < HW2) wpos[p.T + j] = ay[u];
         }
     }
+    }   // MODE != 2
     __syncthreads();
+    if constexpr (MODE == 1) {
+        // every read of the row's scratch region is behind the barrier above: its head becomes the weight record
+        float* wrow = const_cast<float*>(sc);
+        for (int i = tid; i < p.nparts; i += 256) wrow[2 + i] = wp[i];
+        for (int i = tid; i < p.T + HW2; i += 256) wrow[2 + p.nparts + i] = wpos[i];
+        if (tid == 0) {
+            wrow[0] = M;
+            wrow[1] = L;
+            p.out_ml[2 * r] = M;
+            p.out_ml[2 * r + 1] = L;
+        }
+        return;
+    }
 
     // context columns: 32 partial-groups x 8 lanes x float4 (32-column slab -> R * E/32 workgroups fill
     // the chip), 8 independent loads in flight per thread
@@ -186,11 +282,23 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
             a.x = fmaf(w, v.x, a.x); a.y = fmaf(w, v.y, a.y); a.z = fmaf(w, v.z, a.z); a.w = fmaf(w, v.w, a.w);
         }
         if (has_pos) {
-            for (int j = pgp; j < p.T + HW2; j += 32) {
-                const int row = j < p.T ? p.t0i + j : (j < p.T + p.H ? p.y0i + (j - p.T) : p.x0i + (j - p.T - p.H));
-                const float4 v = *reinterpret_cast<const float4*>(p.pe + (long)row * p.E + c4);
-                const float w = wpos[j];
-                a.x = fmaf(w, v.x, a.x); a.y = fmaf(w, v.y, a.y); a.z = fmaf(w, v.z, a.z); a.w = fmaf(w, v.w, a.w);
+            // four pe rows of this thread in flight together (T + H + W = 118 at C2: one batch)
+            const int npos = p.T + HW2;
+            for (int j0 = pgp; j0 < npos; j0 += 128) {
+                float4 v[4];
+                float w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + 32 * u;
+                    const int jc = j < npos ? j : npos - 1;
+                    const int row = jc < p.T ? p.t0i + jc : (jc < p.T + p.H ? p.y0i + (jc - p.T) : p.x0i + (jc - p.T - p.H));
+                    v[u] = *reinterpret_cast<const float4*>(p.pe + (long)row * p.E + c4);
+                    w[u] = j < npos ? wpos[jc] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a.x = fmaf(w[u], v[u].x, a.x); a.y = fmaf(w[u], v[u].y, a.y); a.z = fmaf(w[u], v[u].z, a.z); a.w = fmaf(w[u], v[u].w, a.w);
+                }
             }
         }
     }
@@ -206,7 +314,7 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
             p.out_acc[(long)r * p.E + c] = v;
         }
     }
-    if (blockIdx.y == 0 && tid == 0) {
+    if (MODE == 0 && blockIdx.y == 0 && tid == 0) {
         p.out_ml[2 * r] = M;
         p.out_ml[2 * r + 1] = L;
     }
@@ -334,15 +442,24 @@ extern "C" int hicom_global_merge_fwd(const float* part_m, const float* part_l, 
         T = (int)(N / ((long)H * W));
         const size_t smem = ((size_t)H * W + H + 4) * 4;
         HICOM_REQUIRE(smem <= 60000, HICOM_EUNSUP, "global_merge: grid %dx%d too large for the marginal kernel", H, W);
-        hipLaunchKernelGGL(frame_marginals_kernel, dim3((unsigned)rows, (unsigned)T), dim3(256), smem, s, scores,
-                           (long)score_stride, T, H, W, scratch);
+        if (H <= 32 && W <= 32)
+            hipLaunchKernelGGL(frame_marginals_wave_kernel, dim3((unsigned)(((long)rows * T + 3) / 4)), dim3(256), 0, s, scores,
+                               (long)score_stride, rows, T, H, W, scratch);
+        else
+            hipLaunchKernelGGL(frame_marginals_kernel, dim3((unsigned)rows, (unsigned)T), dim3(256), smem, s, scores,
+                               (long)score_stride, T, H, W, scratch);
     }
     MergeCtxParams p{part_m, part_l, part_acc, nparts, rows_pad, E, pe ? scratch : nullptr, pe,
                      T, H, W, t_index0, y_index0, x_index0, out_ml, out_acc, normalize};
     HICOM_REQUIRE(E % 4 == 0 && (!pe || H + W <= 1024), HICOM_EUNSUP, "global_merge: E %% 4 and H + W <= 1024");
     const size_t smem2 = ((size_t)nparts + (pe ? (size_t)2 * T + H + W + (size_t)kTC * (H + W + 2) : 0) + 16 * 64 + 4) * 4;
     HICOM_REQUIRE(smem2 <= 60000, HICOM_EUNSUP, "global_merge: too many partials/frames for one pass");
-    HICOM_LAUNCH(merge_ctx_kernel, dim3((unsigned)rows, (unsigned)((E + 31) / 32)), dim3(256), smem2, s, p);
+    if (pe && (long)nparts + T + H + W + 2 <= (long)min(kTC, T) * (H + W + 2)) {
+        HICOM_LAUNCH(merge_ctx_kernel<1>, dim3((unsigned)rows), dim3(256), smem2, s, p);
+        HICOM_LAUNCH(merge_ctx_kernel<2>, dim3((unsigned)rows, (unsigned)((E + 31) / 32)), dim3(256), smem2, s, p);
+    } else {
+        HICOM_LAUNCH(merge_ctx_kernel<0>, dim3((unsigned)rows, (unsigned)((E + 31) / 32)), dim3(256), smem2, s, p);
+    }
     return hicom_host::check_launch("global_merge");
 }
 
