@@ -262,9 +262,8 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
             CHK(hicom_merge_vproj_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E, a.wv, F(w.po),
                                       F(w.ml), F(w.ctx_g), sm));
             hicom_aux_gemv ax1{F(w.po), a.E / 64, a.E, a.bv, a.wo, a.bo, a.gq, a.E, a.E, HICOM_ACT_NONE, F(w.pre)};
-            static const bool dbg_noaux1 = getenv("HICOM_DBG_NOAUX1") != nullptr;     // dev timing probe (wrong global rows)
             CHK(hicom_readout16_gemm_fwd(ws + w.ctx_hi, a.lw0_f16, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E, HICOM_ACT_GELU,
-                                         ws + w.hid_hi, nullptr, 0, 0, 0, 0, dbg_noaux1 ? nullptr : &ax1, sm));
+                                         ws + w.hid_hi, nullptr, 0, 0, 0, 0, &ax1, sm));
             hicom_aux_gemv ax2{F(w.pre), 1, a.E, nullptr, a.gw0, a.gb0, nullptr, a.hidden, a.E, HICOM_ACT_GELU, F(w.hid_g)};
             CHK(hicom_readout16_gemm_fwd(ws + w.hid_hi, a.lw2_f16, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden, HICOM_ACT_NONE,
                                          nullptr, a.local_out ? a.local_out : a.out, a.out_dt, a.local_out ? a.hidden : a.ldo,

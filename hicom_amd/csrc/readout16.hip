@@ -464,24 +464,17 @@ extern "C" int hicom_readout16_gemm_fwd(const void* a, const void* w, const void
         // the CUs the tile grid leaves idle (one workgroup per CU: the ring takes 120 KB of LDS), at least 16
         // the same number on every XCD, and ONE CU per XCD left free: with every CU of an XCD spoken for (25 tiles + 7 aux
         // = 32) an aux workgroup was seen queueing behind a 12-us tile (GEMM 1 in situ: 16.6 us with aux, 12.2 without)
-        static int aux_per_xcd = -1;
-        if (aux_per_xcd < 0) {
-            const char* e = getenv("HICOM_R16_AUX_PER_XCD");     // dev switch
-            aux_per_xcd = e ? atoi(e) : 0;
-        }
-        n_aux = aux_per_xcd > 0 ? 8 * aux_per_xcd : ((256 - p.n_gemm) / 8 - 1) * 8;
+        n_aux = ((256 - p.n_gemm) / 8 - 1) * 8;
         if (n_aux < 16) n_aux = 16;
         if (n_aux > 72) n_aux = 72;
     }
-    static int ring = 0;
-    if (ring == 0) {
-        const char* e = getenv("HICOM_R16_RING");            // dev switch for A/B runs; default = 8 stages (160 KB)
-        ring = (e && e[0] == '6') ? 6 : 8;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(readout16_gemm_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * kRStage);
+    // 8 ring stages (160 KB: one workgroup per CU); 6 stages measured 0.5 us slower per GEMM (tools/gpu_round_c.sh, round 2)
+    static bool attr_set = false;
+    if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(readout16_gemm_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kRStage);
+        attr_set = true;
     }
     // aux workgroups first in dispatch order would delay tiles on their CUs; they go last and land on the free CUs
-    if (ring == 6) HICOM_LAUNCH(readout16_gemm_kernel<6>, dim3((unsigned)(p.n_gemm + n_aux)), dim3(256), 6 * kRStage, (hipStream_t)stream, p);
-    else HICOM_LAUNCH(readout16_gemm_kernel<8>, dim3((unsigned)(p.n_gemm + n_aux)), dim3(256), 8 * kRStage, (hipStream_t)stream, p);
+    HICOM_LAUNCH(readout16_gemm_kernel<8>, dim3((unsigned)(p.n_gemm + n_aux)), dim3(256), 8 * kRStage, (hipStream_t)stream, p);
     return hicom_host::check_launch("readout16_gemm");
 }

@@ -30,7 +30,6 @@ struct GemmParams {
     int y_f32;
     long ldy, row0;
     int nl_group;
-    int dbg;   // developer ablation switches (HICOM_GEMM_DBG): 1 skip MFMA phase, 2 skip LDS staging, 4 skip global loads
 };
 
 constexpr int kRowB = 144;                 // bytes per 64-element bf16 row (128 B data + 16 B pad)
@@ -153,11 +152,11 @@ __global__ __launch_bounds__(256, 2) void readout_gemm_kernel(GemmParams p) {
 #define HICOM_GEMM_STEP(S, NXT, FREE)                                                     \
     do {                                                                                  \
         const int kl = 64 * ((S) + 3);                                                    \
-        if (!(p.dbg & 4)) stage_load(st[FREE], xa, wb, kl < last_k ? kl : last_k);        \
+        stage_load(st[FREE], xa, wb, kl < last_k ? kl : last_k);                                  \
         __builtin_amdgcn_sched_barrier(0);                                                \
-        if ((S) < ns && !(p.dbg & 1)) compute(lds + ((S)&1) * kBufB);                     \
+        if ((S) < ns) compute(lds + ((S)&1) * kBufB);                                       \
         __builtin_amdgcn_sched_barrier(0);                                                \
-        if (!(p.dbg & 2)) stage_store(st[NXT], lds + (((S) + 1) & 1) * kBufB, tid);       \
+        stage_store(st[NXT], lds + (((S) + 1) & 1) * kBufB, tid);                         \
         __syncthreads();                                                                  \
     } while (0)
     for (int s = 0; s < ns; s += 3) {
@@ -203,7 +202,7 @@ extern "C" int hicom_readout_gemm_fwd(const float* x, const void* w, const void*
     HICOM_REQUIRE(ldy >= N && row0 >= 0 && nl_group >= 0, HICOM_EINVAL, "readout_gemm: bad output layout");
     HICOM_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0), HICOM_EINVAL, "readout_gemm: alignment");
     GemmParams p{x, (const uint16_t*)w, b, b_dt == HICOM_DT_F32, M, N, K, act, y, y_dt == HICOM_DT_F32,
-                 (long)ldy, (long)row0, nl_group, getenv("HICOM_GEMM_DBG") ? atoi(getenv("HICOM_GEMM_DBG")) : 0};
+                 (long)ldy, (long)row0, nl_group};
     const int nbx = (N + 63) / 64, nby = (M + 63) / 64;
     dim3 grid((unsigned)(8 * nbx * ((nby + 7) / 8)));
     static bool attr_set = false;

@@ -3,7 +3,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/rc; rm -rf $O; mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -k "readout16 or merge_vproj" > $O/ops.log 2>&1; tail -4 $O/ops.log
 echo "ring 8:"; python tools/kbench.py r16 2>&1 | tail -5
-echo "ring 6:"; HICOM_R16_RING=6 python tools/kbench.py r16 2>&1 | tail -5
+
 timeout 600 python bench.py --no-secondary --no-cpu-baseline > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 python3 - <<'PY'
 import json,os
