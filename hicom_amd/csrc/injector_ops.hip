@@ -184,10 +184,9 @@ __global__ __launch_bounds__(256) void small_mha_kernel(const float* q, const fl
 
 // ---- small MHA, LDS form (head dim 64 / 96 / 128): a workgroup owns one head and a block of query rows, stages that head's K and V
 // slices ([L <= 64][hd] fp32, 64 KB) in LDS once and serves its rows from there.  Scores: lane = key token, K rows padded to
-// hd + 1 words (column walk without bank conflicts), the query element of step c comes from a lane of the row's registers
-// (v_readlane); weighted sum: lane = channel pair, the weight of token t again by v_readlane.  The form above (one wave per
+// hd + 4 words; weighted sum: lane = channel pair, the weight of token t by v_readlane.  The form above (one wave per
 // (row, head), K and V read from L2 with a 4.6-KB stride between lanes) took 208 us for the 1 296 x 9 x 64 problem of the
-// fine-grained injector; this one is bounded by the ~800 clocks of LDS reads per (row, head).
+// fine-grained injector.
 constexpr int kMhaRows = 32;          // query rows per workgroup (4 waves x 8)
 
 template <int hd>
@@ -195,8 +194,10 @@ __global__ __launch_bounds__(256) void small_mha_lds_kernel(const float* q, cons
                                                             int nh, float scale, float* out) {
     static_assert(hd % 4 == 0 && hd <= 128, "head dim");
     extern __shared__ __attribute__((aligned(16))) float msm[];
-    float* Ks = msm;                          // [64][hd + 1]
-    float* Vs = msm + ((64 * (hd + 1) + 3) & ~3);          // [64][hd], 16-byte aligned
+    constexpr int KP = hd + 4;                // K row pitch: 16-byte aligned rows; lane t's chunk starts at bank 4 t + c (mod 64):
+                                              // the 16 lanes of a ds_read_b128 pass cover all 64 banks
+    float* Ks = msm;                          // [64][KP]
+    float* Vs = msm + 64 * KP;                // [64][hd]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x, E = nh * hd;
     {
@@ -214,45 +215,63 @@ __global__ __launch_bounds__(256) void small_mha_lds_kernel(const float* q, cons
         for (int u = 0; u < 8; ++u) {
             const int i = tid + 256 * u, t = i / q4, c = 4 * (i - t * q4);
             if (i < 64 * q4) {
-                float* kd = Ks + t * (hd + 1) + c;
-                kd[0] = kv[u].x; kd[1] = kv[u].y; kd[2] = kv[u].z; kd[3] = kv[u].w;
+                *reinterpret_cast<float4*>(Ks + t * KP + c) = kv[u];
                 *reinterpret_cast<float4*>(Vs + t * hd + c) = vv[u];
             }
         }
     }
     __syncthreads();
-    const float* krow = Ks + lane * (hd + 1);
-    for (int r = wave; r < kMhaRows; r += 4) {
-        const long m = (long)blockIdx.y * kMhaRows + r;
-        if (m >= M) break;
-        const float* qh = q + m * E + h * hd;
-        const float q0 = lane < hd ? qh[lane] : 0.f;
-        const float q1 = lane + 64 < hd ? qh[lane + 64] : 0.f;
-        // (compile-time trip counts and no branch in the bodies: the LDS reads of an unrolled group are in flight together;
-        // with a runtime head dim every read waited for its own round trip -- 23k clocks per row)
-        float d = 0.f;
-#pragma unroll 16
-        for (int c = 0; c < (hd < 64 ? hd : 64); ++c)
-            d = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(q0), c)), krow[c], d);
-#pragma unroll 16
-        for (int c = 64; c < hd; ++c)
-            d = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(q1), c - 64)), krow[c], d);
-        const float s = lane < L ? d * scale : -1.0e30f;
-        const float mx = wave_max(s);
-        const float e = lane < L ? expf(s - mx) : 0.f;
-        const float pr = e / wave_sum(e);
-        float a0 = 0.f, a1 = 0.f;
-        const bool c0 = lane < hd, c1 = lane + 64 < hd;
-        const float* v0 = Vs + (c0 ? lane : 0);
-        const float* v1 = Vs + (c1 ? lane + 64 : 0);
-#pragma unroll 16
-        for (int t = 0; t < 64; ++t) {
-            const float pt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pr), t));
-            a0 = fmaf(pt, v0[t * hd], a0);
-            if (hd > 64) a1 = fmaf(pt, v1[t * hd], a1);
+    // Each wave takes its 8 rows TOGETHER: one K row chunk from LDS (ds_read_b128, lane = key token) serves 8 dot products,
+    // the 8 query rows come by wave-uniform (scalar) loads; one V element pair serves 8 weighted sums.  One row at a time the
+    // kernel was bound by LDS reads (384 wave-level reads per row; 35 us for 1 296 rows x 9 heads).
+    const int mb = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * kMhaRows + wave * 8));
+    if (mb >= M) return;
+    const float* krow = Ks + lane * KP;
+    const float* __restrict__ qrow[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) qrow[r] = q + (long)(mb + r < M ? mb + r : M - 1) * E + h * hd;
+    float d[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) d[r] = 0.f;
+#pragma unroll 4
+    for (int c = 0; c < hd; c += 4) {
+        const f32x4 kq = *reinterpret_cast<const f32x4*>(krow + c);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const f32x4 qq = *reinterpret_cast<const f32x4*>(qrow[r] + c);     // same address in every lane
+            d[r] = fmaf(qq[0], kq[0], fmaf(qq[1], kq[1], fmaf(qq[2], kq[2], fmaf(qq[3], kq[3], d[r]))));
         }
-        if (c0) out[m * E + h * hd + lane] = a0;
-        if (c1) out[m * E + h * hd + lane + 64] = a1;
+    }
+    float pr[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float sc = lane < L ? d[r] * scale : -1.0e30f;
+        const float mx = wave_max_fast(sc);
+        const float e = lane < L ? expf(sc - mx) : 0.f;
+        pr[r] = e / wave_sum_fast(e);
+    }
+    float a0[8], a1[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a0[r] = a1[r] = 0.f;
+    const bool c0 = lane < hd, c1 = lane + 64 < hd;
+    const float* v0 = Vs + (c0 ? lane : 0);
+    const float* v1 = Vs + (c1 ? lane + 64 : 0);
+#pragma unroll 8
+    for (int t = 0; t < 64; ++t) {
+        const float x0 = v0[t * hd], x1 = hd > 64 ? v1[t * hd] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float pt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pr[r]), t));
+            a0[r] = fmaf(pt, x0, a0[r]);
+            if (hd > 64) a1[r] = fmaf(pt, x1, a1[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const long m = mb + r;
+        if (m >= M) break;
+        if (c0) out[m * E + h * hd + lane] = a0[r];
+        if (c1) out[m * E + h * hd + lane + 64] = a1[r];
     }
 }
 
@@ -292,10 +311,10 @@ extern "C" int hicom_small_mha_fwd(const float* q, const float* k, const float* 
     HICOM_REQUIRE(q && k && v && out, HICOM_EINVAL, "small_mha: NULL pointer");
     HICOM_REQUIRE(M > 0 && L > 0 && L <= 64 && nh > 0 && hd > 0, HICOM_EUNSUP, "small_mha: L=%d (<= 64 keys supported)", L);
     if ((hd == 128 || hd == 96 || hd == 64) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0)) {
-        const size_t smem = (size_t)(((64 * (hd + 1) + 3) & ~3) + 64 * hd) * 4;
+        const size_t smem = (size_t)(64 * (hd + 4) + 64 * hd) * 4;
         static bool attr_set = false;
         if (!attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(small_mha_lds_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (64 * 129 + 3 + 64 * 128) * 4);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(small_mha_lds_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (64 * 132 + 64 * 128) * 4);
             attr_set = true;
         }
         const dim3 grid((unsigned)nh, (unsigned)((M + kMhaRows - 1) / kMhaRows));
