@@ -356,6 +356,14 @@ class LocalCompressor(nn.Module):
         """out[row0 + packed(m), :] = readout(ctx[m, :]) -- both Linear layers on matrix cores."""
         w0, b0 = _linear_params(self.readout[0])
         w2, b2 = _linear_params(self.readout[2])
+        if ctx.shape[1] % 64 == 0 and w0.shape[0] % 64 == 0:
+            # the hot path's GEMM (one fp16 plane per activation, cached fp16 weights): 12 us per layer at 1296 rows against
+            # 25 for the fp32-input form, same 2^-12 activation rounding as the one-call executor
+            w0h, w2h = self.readout_f16()
+            hid16 = torch.empty((ctx.shape[0], w0.shape[0]), dtype=torch.float16, device=ctx.device)
+            nv.readout16_gemm(nv.to_f16(ctx), w0h, b0, act=nv.ACT_GELU, out_f16=hid16)
+            nv.readout16_gemm(hid16, w2h, b2, y=out, row0=row0, nl_group=nl_group)
+            return
         hid = _f32((ctx.shape[0], w0.shape[0]), ctx.device)
         nv.readout_gemm(ctx, w0, b0, hid, act=nv.ACT_GELU)
         nv.readout_gemm(hid, w2, b2, out, row0=row0, nl_group=nl_group)
