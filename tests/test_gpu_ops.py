@@ -563,3 +563,44 @@ def test_local_attn_bwd_matches_torch_autograd(T, H, W, kt, ks, shared_query):
     else:
         with pytest.raises(nv.HicomNativeError):
             nv.local_attn_bwd(kb, vb, axes, qd, D, scale, 0.0, dctx, dq, torch.zeros_like(kb))
+
+
+def test_small_op_dispatch_boundaries_random_sweep():
+    """Seeded sweep across the dispatch boundaries of the small operators (GEMV / MFMA / 8-row linears, 8-wide / scalar LayerNorm,
+    LDS / per-wave MHA): every shape against a float64 torch reference."""
+    rng = np.random.default_rng(20250614)
+    for it in range(24):
+        M = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 70]))
+        N = int(rng.choice([16, 48, 100, 118, 128, 896, 1152]))
+        K = int(rng.choice([8, 24, 32, 64, 96, 1152]))
+        xdt = str(rng.choice(["f32", "bf16"]))
+        x = synth.normal_like((M, K), 1000 + it)
+        w = synth.normal_like((N, K), 2000 + it, 0.05)
+        b = synth.normal_like((N,), 3000 + it, 0.1)
+        dx = bf(x) if xdt == "bf16" else torch.from_numpy(x).cuda()
+        dw, db = bf(w), bf(b)
+        y = f32((M, N))
+        nv.linear(dx, dw, db, y, act=nv.ACT_GELU)
+        ref = dx.double().cpu() @ dw.double().cpu().t() + db.double().cpu()
+        ref = 0.5 * ref * (1 + torch.erf(ref / math.sqrt(2)))
+        assert maxabs(y, ref) <= 3e-5 * max(1.0, float(ref.abs().max())), (M, N, K, xdt)
+    for E in (8, 64, 100, 768, 1152, 1160, 1536, 2048):
+        M = int(rng.integers(1, 40))
+        x = torch.from_numpy(synth.normal_like((M, E), 4000 + E)).cuda()
+        add = torch.from_numpy(synth.normal_like((M, E), 5000 + E)).cuda()
+        norm = torch.nn.LayerNorm(E, eps=1e-6).to(torch.bfloat16).cuda()
+        with torch.no_grad():
+            norm.weight.copy_(torch.from_numpy(1 + synth.normal_like((E,), 6000 + E, 0.1)))
+            norm.bias.copy_(torch.from_numpy(synth.normal_like((E,), 7000 + E, 0.1)))
+        out = f32((M, E))
+        nv.row_ln(x, norm, out, add=add)
+        ref = torch.nn.functional.layer_norm((x + add).double().cpu(), (E,), norm.weight.detach().double().cpu(), norm.bias.detach().double().cpu(), 1e-6)
+        assert maxabs(out, ref) <= 3e-5, E
+    for (M, L, nh, hd) in ((1, 1, 9, 128), (7, 64, 9, 128), (8, 63, 9, 128), (9, 2, 12, 64), (33, 17, 8, 96), (40, 64, 4, 32)):
+        E = nh * hd
+        q, k, v = (torch.from_numpy(synth.normal_like(s, sd, 0.3)).cuda() for s, sd in (((M, E), 8100 + M), ((L, E), 8200 + M), ((L, E), 8300 + M)))
+        out = f32((M, E))
+        nv.small_mha(q, k, v, nh, out)
+        qh, kh, vh = (t.double().cpu().reshape(-1, nh, hd).permute(1, 0, 2) for t in (q, k, v))
+        pr = torch.softmax(qh @ kh.transpose(1, 2) * hd ** -0.5, dim=-1)
+        assert maxabs(out, (pr @ vh).permute(1, 0, 2).reshape(M, E)) <= 1e-5, (M, L, nh, hd)
