@@ -5,7 +5,8 @@ from .projector import (GlobalCompressor, GuideInjector, HIComProjector, Identit
 from .mm_utils import post_process_visual_feature  # noqa: F401
 from .encoder import siglip_head_embed  # noqa: F401
 from .splice import prepare_inputs_labels_for_multimodal  # noqa: F401
+from .native import invalidate_weight_caches  # noqa: F401
 
 __all__ = ["build_vision_projector", "HIComProjector", "LocalCompressor", "GlobalCompressor", "GuideInjector",
            "MultiheadAttention", "IdentityMap", "build_mlp", "post_process_visual_feature", "siglip_head_embed",
-           "prepare_inputs_labels_for_multimodal"]
+           "prepare_inputs_labels_for_multimodal", "invalidate_weight_caches"]

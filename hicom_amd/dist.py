@@ -258,6 +258,14 @@ def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: in
     lc, gc = projector.local_compressor, projector.global_compressor
     if lc is None or gc is None:
         raise NotImplementedError("sharded_forward expects both compressors")
+    if not (lc.is_plain and gc.is_plain):
+        # coarse / fine / adaptor recipes compute their injected queries per call from the guide; the shard plans patch only
+        # the fields that alias the guide tensor itself (direct) -- refuse instead of running a stale query
+        raise NotImplementedError("sharded_forward: use_guide in (None, 'off', 'direct') without adaptors (the recipes of the "
+                                  "one-call executor); other recipes run unsharded through HIComProjector.forward")
+    projector._check_clip_logits()
+    if projector.global_logit is not None:
+        raise NotImplementedError("sharded_forward: no clip-scale global stage (use forward_stepwise, unsharded)")
     if torch.is_grad_enabled() and projector._needs_grad(ff_shard, fe_shard, guide_embed, image_newline):
         raise RuntimeError("sharded_forward is an inference path: call it under torch.no_grad() / inference_mode()")
     if not all(t is None or t.is_contiguous() for t in (ff_shard, fe_shard, guide_embed, image_newline)):
@@ -301,9 +309,12 @@ def _comm_step(plan, st, out, image_newline, group, restore=None):
     finally:
         if restore is not None:
             _set_stream(restore)
-    nv.compressor_fwd(st.a_finish)
+    nv.compressor_fwd(st.a_finish)                 # (records ev_tok = its ev_done behind the token placement, from C)
+    fenced = bool(st.a_finish.ev_done)
     if plan.lay.newline_rows:
         first = plan.lay.newline_rows[0]
         step = plan.lay.newline_rows[1] - first if len(plan.lay.newline_rows) > 1 else 1
         nv.scatter_rows(image_newline.view(1, -1), out, first, len(plan.lay.newline_rows), row_step=step, stream=comm.cuda_stream)
-        st.ev_tok.record(comm)
+        fenced = False                             # the newline rows were written behind the C call's record
+    if not fenced:
+        st.ev_tok.record(comm)                     # ev_tok always covers the LAST write of the step into `out`

@@ -10,7 +10,9 @@ SiglipMultiheadAttentionPoolingHead (or any object with .layernorm = nn.LayerNor
 
 HIP path: hicom_ln_stream_fwd (LayerNorm -> fp16, 16-byte accesses) -> hicom_dense16_gemm_fwd (fc1 + tanh-GELU -> fp16
 hidden, K zero-padded to 4352) -> hicom_dense16_gemm_fwd (fc2 + bias + residual -> bf16).  fp16 operands: the normalised
-activations keep 11 significand bits, the bf16 weights convert exactly (cached per weight version).
+activations keep 11 significand bits (LayerNorm output and tanh-GELU hidden: far inside the fp16 range whatever outlier
+channels the raw hidden states carry -- the residual is added from the bf16 input in fp32); the bf16 weights convert exactly
+above 2^-14 (nv.f16_weight_copy: range checked when the copy is first built; cached per weight state).
 """
 from __future__ import annotations
 
@@ -23,11 +25,11 @@ _ACTS = {"gelu_pytorch_tanh": nv.ACT_GELU_TANH, "gelu": nv.ACT_GELU}
 
 def _head_cache(head):
     fc1, fc2 = head.mlp.fc1, head.mlp.fc2
-    stamp = (fc1.weight.data_ptr(), fc1.weight._version, fc2.weight.data_ptr(), fc2.weight._version)
+    stamp = nv.weight_stamp(fc1.weight, fc2.weight)
     hit = head.__dict__.get("_hicom_f16")
     if hit is None or hit[0] != stamp:
         kpad = (fc2.weight.shape[1] + 63) // 64 * 64
-        hit = (stamp, nv.to_f16(fc1.weight.detach()), nv.to_f16_padded(fc2.weight.detach(), kpad), kpad)
+        hit = (stamp, nv.f16_weight_copy(fc1.weight), nv.f16_weight_copy(fc2.weight, kpad), kpad)
         head.__dict__["_hicom_f16"] = hit
     return hit[1], hit[2], hit[3]
 

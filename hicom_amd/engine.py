@@ -208,13 +208,14 @@ def _param_list(proj):
 def weights_sig(proj):
     """State of everything a plan has baked in besides the per-call pointers: identity of the module, generation of its
     parameter list, every parameter's storage pointer (`p.data = ...` swaps it without touching the version counter) and
-    in-place version counter, the generation of the cached device tables, the clip-scale logits."""
+    in-place version counter, the global weights epoch (training forwards / invalidate_weight_caches(): writes that bypass
+    the version counter), the generation of the cached device tables, the clip-scale logits."""
     gen, params = _param_list(proj)
     acc = 0
     for p in params:
         acc += p.data_ptr() + p._version * 1000003
     gc = proj.global_compressor
-    return (id(proj), gen, acc, 0 if gc is None else gc._cache_gen, proj.local_logit, proj.global_logit)
+    return (id(proj), gen, acc, nv.weights_epoch(), 0 if gc is None else gc._cache_gen, proj.local_logit, proj.global_logit)
 
 
 def _evict_one(plans: dict):
@@ -248,7 +249,8 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
     nl = image_newline.contiguous() if image_newline is not None else None
     graph = bool(getattr(proj, "graph_replay", False)) and not deferred
     res = _resources(dev)
-    key = (tuple(ff.shape), fe is not None, None if guide is None else tuple(guide.shape), modal, nl is not None, out_dtype,
+    key = (tuple(ff.shape), None if fe is None else tuple(fe.shape), None if guide is None else tuple(guide.shape), modal,
+           None if nl is None else tuple(nl.shape), out_dtype,
            torch.cuda.current_stream(dev).cuda_stream,
            (ff.data_ptr(), _p(fe), _p(guide), _p(nl)) if graph else None)
     plans = proj.__dict__.setdefault("_engine_plans", {})

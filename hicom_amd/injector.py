@@ -91,12 +91,13 @@ def inject(inj, mode, visual, guide):
 
 
 def _f16_weight(lin):
-    """fp16 copy of an nn.Linear weight (bf16 -> fp16 is exact), cached on the module per weight version."""
+    """fp16 copy of an nn.Linear weight (nv.f16_weight_copy: exact above 2^-14, range checked when first built), cached on
+    the module per weight state (nv.weight_stamp)."""
     w = lin.weight
-    stamp = (w.data_ptr(), w._version)
+    stamp = nv.weight_stamp(w)
     hit = lin.__dict__.get("_hicom_f16")
     if hit is None or hit[0] != stamp:
-        hit = (stamp, nv.to_f16(w.detach()))
+        hit = (stamp, nv.f16_weight_copy(w))
         lin.__dict__["_hicom_f16"] = hit
     return hit[1]
 

@@ -363,6 +363,52 @@ def to_f16(src, dst=None):
     return dst
 
 
+# ---- weight-derived device caches ---------------------------------------------------------------------------------------
+# fp16 copies of nn.Linear weights, kpe = W_k . PE^T, the plans of engine.py ... are keyed by every source weight's
+# (storage pointer, in-place version counter).  That sees `p.data = new`, optimizer steps through torch ops, load_state_dict
+# and .to(); it does NOT see writes that bypass the version counter: `p.data.copy_(...)` and writes through an alias of the
+# storage (DeepSpeed's bf16 optimizer updates its flat buffer exactly like that).  Hence a global EPOCH in every stamp:
+#   * every training-mode forward (HIComProjector.forward with autograd on and trainable parameters) bumps it, so the
+#     forward always reads the live weights and the first inference forward after training rebuilds once;
+#   * `hicom_amd.invalidate_weight_caches()` bumps it by hand (after modifying weights behind torch's back at inference).
+_WEIGHTS_EPOCH = [0]
+
+
+def weights_epoch() -> int:
+    return _WEIGHTS_EPOCH[0]
+
+
+def invalidate_weight_caches() -> None:
+    """Every weight-derived device cache (fp16 weight copies, positional products, executor plans) is rebuilt on next use."""
+    _WEIGHTS_EPOCH[0] += 1
+
+
+def weight_stamp(*weights):
+    return (_WEIGHTS_EPOCH[0],) + tuple(v for w in weights for v in (w.data_ptr(), w._version))
+
+
+_F16_MAX = 65504.0
+_RANGE_CHECKED = set()
+
+
+def f16_weight_copy(w, ld=None):
+    """fp16 copy of a bf16 weight for the fp16-operand GEMMs.  bf16 -> fp16 is exact for 2^-14 <= |w| < 65504; smaller
+    magnitudes land on fp16 subnormals (absolute error <= 2^-25 = 3e-8) and larger ones would saturate, so the range is
+    checked ONCE per weight storage (one device reduction + host read when the copy is first built; rebuilds of the same
+    storage -- training -- are not re-checked)."""
+    w = w.detach()
+    key = (w.data_ptr(), tuple(w.shape))
+    if key not in _RANGE_CHECKED:
+        amax = float(w.abs().max())
+        if not amax < _F16_MAX:
+            raise NotImplementedError(f"hicom_amd: a weight of magnitude {amax:.3g} does not fit fp16 (the fp16-operand GEMM path "
+                                      "saturates at 65504); no bf16-operand fallback for this layer")
+        if len(_RANGE_CHECKED) > 4096:
+            _RANGE_CHECKED.clear()
+        _RANGE_CHECKED.add(key)
+    return to_f16(w) if ld is None else to_f16_padded(w, ld)
+
+
 def to_f16_padded(src, ld):
     """fp16 copy of a [rows, cols] bf16 / f32 matrix with its rows zero-padded to `ld` columns (K padding of a GEMM operand)."""
     rows, cols = src.shape

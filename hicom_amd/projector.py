@@ -341,14 +341,15 @@ class LocalCompressor(nn.Module):
         return ctx, grid
 
     def readout_f16(self):
-        """fp16 copies of the two readout weights for hicom_readout16_gemm_fwd (bf16 -> fp16 is exact down to 6e-5), rebuilt
-        when a weight is replaced or modified in place -- a weight-only cache like the reference's pos_embed buffer."""
+        """fp16 copies of the two readout weights for hicom_readout16_gemm_fwd (nv.f16_weight_copy: exact above 2^-14, range
+        checked), rebuilt when a weight is replaced or modified in place, on every training-mode forward and after
+        hicom_amd.invalidate_weight_caches() (nv.weight_stamp) -- a weight-only cache like the reference's pos_embed buffer."""
         w0, w2 = self.readout[0].weight, self.readout[2].weight
         _require_bf16_cuda("readout weight", w0)
-        stamp = (w0.data_ptr(), w0._version, w2.data_ptr(), w2._version)
+        stamp = nv.weight_stamp(w0, w2)
         hit = self.__dict__.get("_f16_cache")
         if hit is None or hit[0] != stamp:
-            hit = (stamp, nv.to_f16(w0.detach()), nv.to_f16(w2.detach()))
+            hit = (stamp, nv.f16_weight_copy(w0), nv.f16_weight_copy(w2))
             self.__dict__["_f16_cache"] = hit
         return hit[1], hit[2]
 
@@ -433,7 +434,7 @@ class GlobalCompressor(nn.Module):
         wk = self.attn_layer.k_proj.weight
         _require_bf16_cuda("k_proj.weight", wk)
         key = ("kpe", H, W, cap, str(device))
-        stamp = (wk.data_ptr(), wk._version)
+        stamp = nv.weight_stamp(wk)
         hit = self._pe_cache.get(key)
         if hit is None or hit[1] != stamp:
             kpe = _f32((self.embed_dim, pe.shape[0]), device)
@@ -490,7 +491,7 @@ class GlobalCompressor(nn.Module):
         pe, cap = self.pos_tables(t_cap, H, W, device)
         wk = self.attn_layer.k_proj.weight
         key = ("kpe_t", H, W, cap, str(device))
-        stamp = (wk.data_ptr(), wk._version, pe.data_ptr())
+        stamp = nv.weight_stamp(wk) + (pe.data_ptr(),)
         hit = self._pe_cache.get(key)
         if hit is None or hit[1] != stamp:
             t = _f32((pe.shape[0], self.embed_dim), device)
@@ -631,6 +632,10 @@ class HIComProjector(nn.Module):
     def forward(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None):
         self._check_clip_logits()
         if self._needs_grad(frames_feature, frames_embed, guide_embed, image_newline):
+            # training: an optimizer step lies between two forwards, and DeepSpeed's bf16 optimizer writes the weights
+            # through `p.data.copy_` / a flat alias, which no version counter sees -> every weight-derived cache is
+            # rebuilt from the live weights on each training forward (native.py "weight-derived device caches")
+            nv.invalidate_weight_caches()
             from . import autograd
             return autograd.forward_with_grad(self, frames_feature, frames_embed, guide_embed, modal, image_newline)
         plain = all(c is None or c.is_plain for c in (self.local_compressor, self.global_compressor))

@@ -389,6 +389,46 @@ def global_forward(spec: dict, mode, sd, prefix: str, ff: Tensor, guide: Optiona
     return out
 
 
+def global_forward_chunked(spec: dict, mode, sd, prefix: str, ff: Tensor, guide: Optional[Tensor],
+                           chunk_frames: int = 32, use_pos_emb: bool = True):
+    """global_forward for clips whose K / V states do not fit host memory at once (1024 frames = 746k keys): the same
+    un-folded reference formulation -- k = k_proj(x + pos), v = v_proj(x + pos) per token (:180-182, :636-640) -- evaluated
+    `chunk_frames` frames at a time, the softmax over ALL keys (:213) carried across chunks as a running (max, sum,
+    weighted sum) triple.  Mathematically identical to global_forward (checked against it in tests/test_oracle_golden.py);
+    no clip-scale."""
+    T, H, W, D = ff.shape
+    query = guide_inject(mode, sd[prefix + ".query"], guide, sd, prefix + ".guide_injector", spec["adapt_guide"])   # :642
+    nh = D // 128
+    hd = D // nh
+    att_p = prefix + ".attn_layer"
+    q = linear(query, sd, att_p + ".q_proj")                       # :180
+    Lq = q.shape[0]
+    qh = q.reshape(Lq, nh, hd).permute(1, 0, 2)                    # [nh, Lq, hd]
+    m_run = torch.full((nh, Lq), -float("inf"), dtype=torch.float32)
+    l_run = torch.zeros((nh, Lq), dtype=torch.float32)
+    o_run = torch.zeros((nh, Lq, hd), dtype=torch.float32)
+    pt, ph, pw = (pos_axis_table(n, D) for n in (T, H, W))
+    for t0 in range(0, T, chunk_frames):
+        t1 = min(T, t0 + chunk_frames)
+        x = ff[t0:t1]
+        if use_pos_emb:
+            pos = pt[t0:t1, None, None, :] + ph[None, :, None, :] + pw[None, None, :, :]        # float64 sum (:95-99)
+            x = x + torch.from_numpy(pos).float().to(ff.dtype)                                # fp32 buffer cast to the input dtype
+        kv = x.reshape(-1, D)
+        k = linear(kv, sd, att_p + ".k_proj").reshape(-1, nh, hd).permute(1, 0, 2)             # :181
+        v = linear(kv, sd, att_p + ".v_proj").reshape(-1, nh, hd).permute(1, 0, 2)             # :182
+        s = torch.matmul(qh, k.transpose(1, 2)).float() * hd ** -0.5                          # :197
+        m_new = torch.maximum(m_run, s.max(dim=-1).values)
+        alpha = torch.exp(m_run - m_new)
+        p = torch.exp(s - m_new[..., None])
+        l_run = l_run * alpha + p.sum(dim=-1)
+        o_run = o_run * alpha[..., None] + torch.matmul(p, v.float())
+        m_run = m_new
+    o = (o_run / l_run[..., None]).permute(1, 0, 2).reshape(Lq, D).to(q.dtype)                  # :215, :223-224
+    att = linear(o, sd, att_p + ".out_proj")                       # :226
+    return mlp2(query + att, sd, prefix + ".readout")              # :646
+
+
 # --------------------------------------------------------------------------
 # post_process_visual_feature                      (mm_utils.py:92-140)
 # --------------------------------------------------------------------------

@@ -1,0 +1,227 @@
+"""Reference-signature surfaces and robustness contracts that round 2 left without a test (VERDICT r2 "Missing" #6,
+"Next round" #1):
+
+  * MultiheadAttention.forward (reference projector.py:166-228): the <= 64-key branch and the streamed long-key branch;
+  * GuideInjector.forward (reference :344-397): direct / coarse / fine on 2-D and 4-D visual_embed;
+  * the chained C4 segment  siglip_head_embed -> HIComProjector.forward (T=32, H=3584) -> prepare_inputs_labels_for_multimodal
+    against the oracle chain (reference encoder.py:284-286 -> projector.py:676-708 -> hicom_arch.py:271-373);
+  * plan key / weight-cache / sharded-path guards.
+
+Tolerance: 1e-3 max-abs on fp32 results against the fp32 oracle (BASELINE.json north_star); labels / masks / row placement bit-exact.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from gpu_util import build_module, dev_bf16
+from oracle import hicom_oracle as orc
+from oracle import splice_oracle as so
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _module_and_sd(name):
+    case = cases.build_case(name)
+    return build_module(case), {k: torch.from_numpy(v) for k, v in case.sd.items()}, case
+
+
+def _bf16_cuda(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).cuda()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# MultiheadAttention.forward
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kv_len", [64, 7])
+def test_mha_forward_small_key_branch(kv_len):
+    """[B, q, E] x [B, kv <= 64, E] (the text tokens of "fine" injection): projected states + hicom_small_mha_fwd; key and
+    value are different tensors here (the small-key path projects them separately)."""
+    m, sd, _ = _module_and_sd("G7_fine")
+    att = m.local_compressor.guide_injector.fine_proj
+    att.return_fp32 = True
+    B, q_len, E = 2, 5, 1152
+    q, k, v = _bf16_cuda((B, q_len, E), 1), _bf16_cuda((B, kv_len, E), 2), _bf16_cuda((B, kv_len, E), 3)
+    with torch.no_grad():
+        out, weights = att(q, k, v)
+    torch.cuda.synchronize()
+    assert weights is None and out.shape == (B, q_len, E) and out.dtype == torch.float32
+    for b in range(B):
+        want = orc.mha(q[b].float().cpu(), k[b].float().cpu(), v[b].float().cpu(), sd, "local_compressor.guide_injector.fine_proj", 9)
+        assert float((out[b].cpu() - want).abs().max()) <= TOL, b
+    att.return_fp32 = False
+    with torch.no_grad():
+        assert att(q, k, v)[0].dtype == torch.bfloat16                      # module dtype, as the reference returns it
+    with pytest.raises(ValueError):
+        att(q[0], k, v)                                                      # "Batch x Time x Channel" (ref :170-172)
+    with pytest.raises(NotImplementedError):
+        att(q, k, v, attention_mask=torch.zeros(B, 1, q_len, kv_len).cuda())
+
+
+@pytest.mark.parametrize("q_len,kv_len", [(1, 300), (4, 1000), (32, 333)])
+def test_mha_forward_long_key_stream_branch(q_len, kv_len):
+    """key is value (bf16), more than 64 keys: k_proj / v_proj folded around the raw tokens, one streaming pass without
+    positional terms (H, W = 1, N), combine, v_proj per head, out_proj -- against the reference's un-folded form."""
+    m, sd, _ = _module_and_sd("G2_off_T8")
+    att = m.global_compressor.attn_layer
+    att.return_fp32 = True
+    E = 1152
+    q, x = _bf16_cuda((1, q_len, E), 5, 0.5), _bf16_cuda((1, kv_len, E), 6)
+    with torch.no_grad():
+        out, _ = att(q, x, x)
+    torch.cuda.synchronize()
+    want = orc.mha(q[0].float().cpu(), x[0].float().cpu(), x[0].float().cpu(), sd, "global_compressor.attn_layer", 9)
+    assert out.shape == (1, q_len, E)
+    assert float((out[0].cpu() - want).abs().max()) <= TOL
+    att.return_fp32 = False
+    with pytest.raises(NotImplementedError):
+        att(q, x, x.clone())                                                 # long keys: key must BE value (folded projections)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GuideInjector.forward
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,mode", [("G1_direct_T8", "direct"), ("G6_coarse", "coarse"), ("G7_fine", "fine")])
+@pytest.mark.parametrize("shape", [(10, 1152), (2, 3, 3, 1152)])
+@pytest.mark.parametrize("vis_dtype", [torch.float32, torch.bfloat16])
+def test_guide_injector_forward(name, mode, shape, vis_dtype):
+    m, sd, case = _module_and_sd(name)
+    inj = m.local_compressor.guide_injector
+    assert inj.use_guide == mode
+    g = torch.Generator().manual_seed(7)
+    vis = torch.randn(*shape, generator=g).to(torch.bfloat16)              # bf16-representable values in either dtype
+    guide = torch.from_numpy(case.g).to(torch.bfloat16)
+    with torch.no_grad():
+        got = inj(vis.to(vis_dtype).cuda(), guide.cuda())
+    torch.cuda.synchronize()
+    want = orc.guide_inject(mode, vis.float(), guide.float(), sd, "local_compressor.guide_injector", False)
+    assert got.shape == want.shape
+    if mode == "direct":
+        # the guide broadcast to the visual shape (ref :352-368) as a stride-0 view: nothing is materialised
+        assert torch.equal(got.float().cpu(), want) and got.stride()[0] == 0
+    else:
+        assert got.dtype == torch.float32 and float((got.cpu() - want).abs().max()) <= TOL
+    with pytest.raises(ValueError):
+        inj(vis.view(1, *shape).cuda(), guide.cuda())                        # "Invalid input shape for guide embedding." (:350)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# chained C4 segment (BASELINE configs[3] without the tower body and the LLM)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_c4_chain_head_compressor_splice_matches_oracle_chain():
+    import make_golden_head as mh
+    from hicom_amd import prepare_inputs_labels_for_multimodal, siglip_head_embed, synth
+    from test_gpu_head import _Head
+    T, HID, S, V = 32, 3584, 2048, 4096
+    head_sd = mh.head_state_dict()
+    head = _Head(head_sd).to(torch.bfloat16).cuda().eval()
+    head_sd_t = {k: torch.from_numpy(v) for k, v in head_sd.items()}
+    cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "hidden_size": HID, "max_num_frames": T})
+    sd = synth.synth_state_dict(orc.param_shapes(cfg), tag="c4")
+    m = build_module(SimpleNamespace(cfg=cfg, sd=sd))
+    x = synth.synth_inputs(T, 27, 27, 1152, tag="c4")
+    hidden_states, guide = dev_bf16(x["ff"]), dev_bf16(x["g"])           # tower output = frames_feature (encoder.py:277-283)
+    gen = torch.Generator().manual_seed(9)
+    weight = torch.randn(V, HID, generator=gen).to(torch.bfloat16)
+    ids = torch.randint(0, V, (2, S), generator=gen)
+    ids[0, 41] = -201                                                    # <video> in sample 0; sample 1 is text-only
+    labels = torch.where(ids >= 0, ids, torch.full_like(ids, -100))
+    mask = torch.ones(2, S, dtype=torch.long)
+    mask[1, -9:] = 0
+    emb = torch.nn.Embedding(V, HID).to(torch.bfloat16).cuda()
+    emb.weight.data.copy_(weight)
+    with torch.no_grad():
+        fe = siglip_head_embed(hidden_states, head)                        # bf16, as the tower hands it on
+        out32 = m(hidden_states, fe, guide, "video", None)                 # fp32 (return_fp32): the compressed tokens
+        feats = [out32.to(torch.bfloat16), torch.zeros(3, HID, dtype=torch.bfloat16, device="cuda")]
+        _, new_mask, _, embeds, new_labels = prepare_inputs_labels_for_multimodal(emb, ids.cuda(), mask.cuda(), None, labels.cuda(), feats)
+    torch.cuda.synchronize()
+    # oracle chain: head (fp32) -> bf16 interface (the model dtype between tower and projector) -> compressor (fp32)
+    fe_ref = orc.siglip_head_embed(hidden_states.float().cpu().view(-1, 1152), head_sd_t).view(T, 27, 27, 1152)
+    assert float((fe.float().cpu() - fe_ref).abs().max()) <= 2 ** -8 * float(fe_ref.abs().max())   # bf16 cast of a <= 1e-3 result
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    want = orc.projector_forward(cfg, sdt, hidden_states.float().cpu(), fe_ref.to(torch.bfloat16).float(), guide.float().cpu(), "video", None)
+    assert out32.shape == want.shape == (T // 4 * 81 + 32, HID)
+    assert float((out32.cpu() - want).abs().max()) <= TOL
+    # splice of the product's own bf16 tokens: every row, label and mask element bit-exact against the oracle placement
+    wm, we, wl = so.splice(weight.float(), ids, mask, labels, [f.float().cpu() for f in feats])
+    assert embeds.shape == (2, S - 1 + out32.shape[0], HID)
+    assert torch.equal(embeds.float().cpu(), we) and torch.equal(new_labels.cpu(), wl) and torch.equal(new_mask.cpu(), wm)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# plan key, weight caches, sharded-path guards
+# ---------------------------------------------------------------------------------------------------------------------
+def test_plan_key_includes_frames_embed_shape():
+    """a second call with the same frames_feature shape and a differently shaped frames_embed must not hit the
+    cached plan (it would patch in a pointer the kernel reads out of bounds): it raises like the first call would."""
+    m, _, case = _module_and_sd("G1_direct_T8")
+    ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+    with torch.no_grad():
+        m(ff, fe, g, "video", None)
+        with pytest.raises(ValueError):
+            m(ff, fe[:4].contiguous(), g, "video", None)
+        with pytest.raises(ValueError):
+            m(ff, fe[:, :3].contiguous(), g, "video", None)
+        assert bool(torch.isfinite(m(ff, fe, g, "video", None)).all())
+
+
+def test_weight_writes_that_bypass_the_version_counter():
+    """DeepSpeed's bf16 optimizer updates parameters with `p.data.copy_(...)` / through a flat alias, which
+    bumps no version counter.  Training-mode forwards rebuild every weight-derived cache (fp16 readout copies, kpe, plans)
+    from the live weights; at inference `hicom_amd.invalidate_weight_caches()` does."""
+    import hicom_amd
+    m, _, case = _module_and_sd("G1_direct_T8")
+    ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+    w = m.local_compressor.readout[0].weight
+    wk = m.global_compressor.attn_layer.k_proj.weight
+    with torch.no_grad():
+        base = m(ff, fe, g, "video", None).clone()
+    v0 = (w._version, wk._version)
+    w.data.copy_(w.data * 1.5)                                           # no version bump, same storage
+    wk.data.copy_(wk.data * -1.0)
+    assert (w._version, wk._version) == v0
+    # training path (autograd on, trainable parameters): sees the live weights at once
+    trained = m(ff, fe, g, "video", None).detach().clone()
+    assert float((trained[:-32] - base[:-32]).abs().max()) > 1e-3           # local rows: readout weight changed
+    assert float((trained[-32:] - base[-32:]).abs().max()) > 1e-4           # global rows: k_proj changed (folded queries, kpe)
+    with torch.no_grad():
+        # the first inference forward after training rebuilds once and agrees with the training forward
+        assert float((m(ff, fe, g, "video", None) - trained).abs().max()) <= 2e-4
+        w.data.copy_(w.data / 1.5)
+        wk.data.copy_(wk.data * -1.0)
+        stale = m(ff, fe, g, "video", None).clone()                        # documented: inference caches cannot see this write
+        assert float((stale - trained).abs().max()) <= 2e-4
+        hicom_amd.invalidate_weight_caches()
+        assert float((m(ff, fe, g, "video", None) - base).abs().max()) <= 2e-4
+
+
+def test_f16_weight_copy_range_check():
+    from hicom_amd import native as nv
+    w = torch.full((4, 64), 7.0e4, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(NotImplementedError):
+        nv.f16_weight_copy(w)
+    ok = torch.full((4, 64), 3.0e-6, dtype=torch.bfloat16, device="cuda")   # an fp16 subnormal: kept to 2^-25 absolute
+    c = nv.f16_weight_copy(ok)
+    torch.cuda.synchronize()
+    assert float((c.float() - ok.float()).abs().max()) <= 2.0 ** -25
+
+
+def test_sharded_forward_refuses_recipes_it_cannot_patch():
+    """coarse / fine / adaptor recipes derive their queries from the guide per call; the shard plans only
+    patch guide ALIASES, so those recipes must raise instead of reusing a freed / stale query."""
+    from hicom_amd.dist import sharded_forward
+    for name in ("G6_coarse", "G5_adaptkv"):
+        m, _, case = _module_and_sd(name)
+        ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+        with torch.no_grad(), pytest.raises(NotImplementedError):
+            sharded_forward(m, ff, fe, g, ff.shape[0])
+    m, _, case = _module_and_sd("G1_direct_T8")
+    m.config.use_clip_scale = "local"
+    m.local_use_clip_scale = True
+    with torch.no_grad(), pytest.raises(RuntimeError):
+        sharded_forward(m, dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g), 8)

@@ -119,3 +119,72 @@ def test_hip_splice_c4_shape_and_errors():
     from hicom_amd import native as nv
     with pytest.raises(nv.HicomNativeError):                    # no CPU path
         prepare_inputs_labels_for_multimodal(torch.nn.Embedding(V, 8), ids, None, None, None, [torch.zeros(3, 8)])
+
+
+def test_host_plan_zero_row_feature_and_positions():
+    """A feature with zero rows shortens its sample (the reference cats an empty tensor, :314); feat_at records where every
+    placed feature starts (the backward's gather ranges)."""
+    from hicom_amd.splice import plan_layout
+    ids = np.array([[5, -201, 7, -200], [1, 2, 3, 4], [-202, 9, 9, 9]], dtype=np.int64)
+    plan = plan_layout(ids, [0, 3, 2, 4])          # sample 1 is text-only: consumes feature 2 without placing it
+    kind, feat, new_len, Lmax = plan
+    assert new_len.tolist() == [2 + 0 + 3, 4, 3 + 4] and Lmax == 7
+    assert kind[0].tolist() == [0, 2, -1, -1, -1, -2, -2]
+    assert feat[0, 2:5].tolist() == [[1, 0], [1, 1], [1, 2]]
+    assert kind[2].tolist() == [-1, -1, -1, -1, 1, 2, 3] and feat[2, :4, 0].tolist() == [3] * 4
+    assert plan.feat_at.tolist() == [[0, 1, 0], [0, 2, 3], [0, 0, 0], [2, 0, 4]]
+    with pytest.raises(IndexError):
+        plan_layout(ids, [0, 3, 2])
+
+
+@pytest.mark.gpu
+def test_hip_splice_gradients_match_reference_autograd():
+    """the splice sits inside every training forward (hicom_arch.py:313-330: embed_tokens + torch.cat), so
+    gradients must reach the compressed tokens and the embedding table.  Expected values: the oracle restatement (plain
+    indexing + cat) under torch autograd on the CPU, fp32."""
+    from hicom_amd.splice import prepare_inputs_labels_for_multimodal
+    g = torch.Generator().manual_seed(3)
+    V, H, S = 64, 32, 12
+    weight = torch.randn(V, H, generator=g)
+    feats = [torch.randn(5, H, generator=g), torch.randn(0, H, generator=g), torch.randn(3, H, generator=g), torch.randn(4, H, generator=g)]
+    ids = torch.randint(0, V, (3, S), generator=g)
+    ids[0, 2], ids[0, 9] = -201, -200           # two placeholders (the second takes the zero-row feature)
+    ids[2, 0] = -202                            # sample 1 stays text-only and consumes feature 2
+    ids[0, 4] = ids[0, 5]                       # a repeated token: two rows add into one embedding row
+    w_ref = weight.clone().requires_grad_(True)
+    f_ref = [f.clone().requires_grad_(True) for f in feats]
+    _, e_ref, _ = so.splice(w_ref, ids, None, None, f_ref)
+    d_out = torch.randn(e_ref.shape, generator=g)
+    e_ref.backward(d_out)
+    w = weight.clone().cuda().requires_grad_(True)
+    f = [t.clone().cuda().requires_grad_(True) for t in feats]
+    _, _, _, e, _ = prepare_inputs_labels_for_multimodal(w, ids.cuda(), None, None, None, f)
+    assert e.requires_grad and torch.equal(e.detach().cpu(), e_ref.detach())
+    e.backward(d_out.cuda())
+    assert torch.allclose(w.grad.cpu(), w_ref.grad, atol=1e-6)
+    for k in (0, 2, 3):
+        want = f_ref[k].grad if f_ref[k].grad is not None else torch.zeros_like(feats[k])
+        assert torch.allclose(f[k].grad.cpu(), want, atol=0), k
+    # no graph when nothing requires grad / under no_grad
+    with torch.no_grad():
+        assert not prepare_inputs_labels_for_multimodal(w, ids.cuda(), None, None, None, f)[3].requires_grad
+
+
+@pytest.mark.gpu
+def test_hip_splice_input_validation():
+    """3-D features, views at odd storage offsets, zero-row features against a mask."""
+    from hicom_amd.splice import prepare_inputs_labels_for_multimodal
+    V, H, S = 32, 24, 6                           # 24 bf16 = 48-byte rows: every row 16-byte aligned
+    emb = torch.nn.Embedding(V, H).to(torch.bfloat16).cuda()
+    ids = torch.tensor([[1, -201, 2, 3, 4, 5]]).cuda()
+    with pytest.raises(ValueError):
+        prepare_inputs_labels_for_multimodal(emb, ids, None, None, None, [torch.zeros(2, 3, H, dtype=torch.bfloat16).cuda()])
+    base = torch.randn(4 * H + 4).to(torch.bfloat16).cuda()
+    view = base[4:4 + 3 * H].view(3, H)           # storage offset 8 bytes: not 16-byte aligned
+    assert view.data_ptr() % 16 != 0
+    out = prepare_inputs_labels_for_multimodal(emb, ids, None, None, None, [view])[3]
+    torch.cuda.synchronize()
+    assert torch.equal(out[0, 1:4], view)
+    mask = torch.ones(1, S, dtype=torch.long).cuda()
+    with pytest.raises(RuntimeError, match="negative dimension"):
+        prepare_inputs_labels_for_multimodal(emb, ids, mask, None, ids.clamp(min=0), [torch.zeros(0, H, dtype=torch.bfloat16).cuda()])
