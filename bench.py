@@ -61,7 +61,8 @@ def cpu_baseline(cfg, module, frames: int, budget_s: float = 20.0):
     """Times the CPU oracle on the same workload shape (fp32, all host cores)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import hicom_oracle as orc
-    torch.set_num_threads(min(os.cpu_count() or 1, 64))   # one socket's worth; more threads only adds contention
+    host_cores = os.cpu_count() or 1
+    torch.set_num_threads(min(host_cores, 64))   # one socket's worth; more threads only adds contention
     g = torch.Generator().manual_seed(1)
     ff = torch.randn(frames, GRID, GRID, D, generator=g).bfloat16().float()
     fe = torch.randn(frames, GRID, GRID, D, generator=g).bfloat16().float()
@@ -80,7 +81,8 @@ def cpu_baseline(cfg, module, frames: int, budget_s: float = 20.0):
             times.append(time.perf_counter() - t0)
     assert out.shape[0] == n_out
     best = min(times)
-    return {"value": n_out / best, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": n_out / best, "unit": "tokens/s", "cores": torch.get_num_threads(), "threads": torch.get_num_threads(),
+            "host_cpu_count": host_cores, "kind": "port",
             "sample": f"{len(times)} forwards of the full {frames}x729x1152 fp32 workload ({sum(times):.1f} s of CPU work; value = best, "
                       f"{best * 1e3:.0f} ms) by oracle/hicom_oracle.py on torch-CPU"}
 
@@ -99,6 +101,7 @@ def parity_probe(device):
             "workload": "4x729x1152, H=896, direct (BASELINE configs[0]) vs fp32 CPU oracle"}
 
 
+PRE_WARMUP_STEPS = 300   # untimed steps a fresh process runs BEFORE the --warmup steps (reported in the JSON line)
 N_INPUT_SETS = 3      # distinct (frames_feature, frames_embed, guide) sets rotated through the timed loop: 3 x 215 MB per
                       # GPU do not fit the 256 MiB Infinity Cache, so every step reads its inputs from HBM
 
@@ -241,14 +244,14 @@ def main():
     with torch.no_grad():
         # a step is ~0.1 ms: a fresh process needs a few hundred of them before clocks, caches of lazily loaded code
         # objects and the allocator have settled (a cold 50-step run measured 151 us/step, the next one 88)
-        for _ in range(300):
+        for _ in range(PRE_WARMUP_STEPS):
             step()
         fence()
-        for _ in range(args.warmup):
-            out = step()
-        assert out.shape == (n_out, args.hidden)
         gc.collect()
         gc.disable()                       # no collector pause inside the timed region (a step is ~0.1 ms)
+        for _ in range(args.warmup):       # the W warm-up steps run right in front of the timed region (the collector pass above
+            out = step()                   # idles the GPU for tens of ms, long enough for its clocks to drop)
+        assert out.shape == (n_out, args.hidden)
         # N = 1: the drop-in call, joined.  N > 1: there is no reference call to be a drop-in for (the reference never
         # shards a video); the metric is a throughput, so the timed loop is the steady-state serving loop of the frame-
         # sharded path -- sharded_forward(deferred=True), the token exchange of step i under the streaming of step i + 1,
@@ -306,7 +309,7 @@ def main():
     alg_step = 3359232 * fpg + 18046976 * (args.hidden == 896) + n_out * args.hidden * 2 + 2304
     result = {
         "metric": "compressed_video_tokens_per_sec", "value": n_out / (ms_per_step * 1e-3), "unit": "tokens/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "pre_warmup_steps": PRE_WARMUP_STEPS, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{total_frames} frames x 729 SigLIP tokens x 1152 bf16 ({fpg}/GPU), local43+global32, "
                                f"use_guide=direct, hidden {args.hidden} -> {n_out} compressed tokens",
@@ -322,6 +325,8 @@ def main():
         **extras,
         "roofline": roofline,
     }
+    if args.hidden == 896 and "ms_per_step_batches" in extras:
+        result["whole_step_hbm_frac_median"] = alg_step / (extras["ms_per_step_batches"]["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS
     mu = mfma_util_from_profiles()
     if mu is not None:
         result["mfma_util"] = mu
@@ -513,8 +518,8 @@ def dominant_kernel_roofline(module, sets, iters):
     torch.cuda.synchronize()
     ms = sorted(a.elapsed_time(b) / batch for a, b in evs)
     mean_ms = sum(ms) / len(ms)
-    alg_bytes = 3359232 * T + nw * D * 2
-    achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
+    alg_bytes = 3359232 * T            # bytes per frame x frames of one launch (the 3 MB of fp16 window contexts
+    achieved = alg_bytes / (mean_ms * 1e-3) / 1e9   # and 9 MB of partial states the kernel also WRITES are not counted)
     traffic = None
     try:   # HBM bytes per launch from the newest committed PMC pass of this same workload (profiles/)
         import glob
@@ -525,7 +530,8 @@ def dominant_kernel_roofline(module, sets, iters):
         pass
     return {"kernel": "hicom::fused_ring_kernel<9>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": mean_ms, "min_launch_ms": ms[0]}
+            "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_frame": 3359232, "frames_per_launch": T,
+            "mean_launch_ms": mean_ms, "min_launch_ms": ms[0]}
 
 
 if __name__ == "__main__":

@@ -34,11 +34,17 @@ struct AuxGemv {
     int x_parts;
     long x_stride;
     const uint16_t* xb;     // bf16 [K] added to x (the bias of the producing layer), or NULL
-    const uint16_t* w;      // bf16 [N, K]
-    const uint16_t* b;      // bf16 [N] or NULL
+    const void* w;          // bf16 or f32 [N, K]
+    const void* b;          // bf16 or f32 [N] or NULL
     const uint16_t* res;    // bf16 [N] or NULL
     int N, K, act;
-    float* y;
+    float* y;               // f32 [N] or NULL
+    int w_f32, b_f32;
+    // optional packed destination: the result row replicated to rows row0 .. row0 + reps - 1 of dst [*, ldd] (the 32
+    // identical global rows of "direct" mode, projector.py:646,707)
+    void* dst;
+    int dst_f32, reps;
+    long ldd, row0;
 };
 
 struct R16Params {
@@ -71,6 +77,7 @@ __device__ __forceinline__ _Float16 to_f16_sat(float v) {
 // ---- aux role: one GEMV over `n_aux` workgroups.  A wave owns up to CB = 6 columns (1152 columns over 56 x 4 waves = one
 // batch) and requests ALL of their weight rows first; the partial vectors of x are requested right behind them, so the two
 // cold-memory latencies of the role overlap instead of adding up.
+template <bool WF32>
 __device__ __forceinline__ void aux_gemv_role(const AuxGemv& g, int aux_idx, int n_aux, char* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* xl = reinterpret_cast<float*>(lds);       // [K]   x
@@ -79,7 +86,9 @@ __device__ __forceinline__ void aux_gemv_role(const AuxGemv& g, int aux_idx, int
     constexpr int CB = 6;
     const int nwaves = n_aux * 4, w_id = aux_idx * 4 + wave;
     const int per = (g.N + nwaves - 1) / nwaves;      // columns per wave (contiguous)
-    u32x4 wv[CB][CH];
+    u32x4 wv[CB][CH];                    // bf16 weights: 8 per chunk
+    u32x4 wv2[WF32 ? CB : 1][CH];        // f32 weights: the chunk's second four
+    constexpr bool wf32 = WF32;
     auto load_w = [&](int n0) {
 #pragma unroll
         for (int j = 0; j < CB; ++j) {
@@ -87,7 +96,13 @@ __device__ __forceinline__ void aux_gemv_role(const AuxGemv& g, int aux_idx, int
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 const int k = (lane + 64 * c) * 8;
-                wv[j][c] = (k < g.K) ? *reinterpret_cast<const u32x4*>(g.w + (long)n * g.K + k) : u32x4{0, 0, 0, 0};
+                if constexpr (wf32) {
+                    const float* wr = reinterpret_cast<const float*>(g.w) + (long)n * g.K + k;
+                    wv[j][c] = (k < g.K) ? *reinterpret_cast<const u32x4*>(wr) : u32x4{0, 0, 0, 0};
+                    wv2[j][c] = (k < g.K) ? *reinterpret_cast<const u32x4*>(wr + 4) : u32x4{0, 0, 0, 0};
+                } else {
+                    wv[j][c] = (k < g.K) ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(g.w) + (long)n * g.K + k) : u32x4{0, 0, 0, 0};
+                }
             }
         }
     };
@@ -138,8 +153,10 @@ __device__ __forceinline__ void aux_gemv_role(const AuxGemv& g, int aux_idx, int
 #pragma unroll
         for (int i = 0; i < 8; ++i) xr[c][i] = (k < g.K) ? xl[k + i] : 0.f;
     }
-    for (int n0 = n_first; n0 < min(g.N, n_first + per); n0 += CB) {
+    const int n_end = min(g.N, n_first + per);
+    for (int n0 = n_first; n0 < n_end; n0 += CB) {
         if (n0 != n_first) load_w(n0);
+        float vout[CB];
 #pragma unroll
         for (int j = 0; j < CB; ++j) {
             float acc = 0.f;
@@ -147,16 +164,33 @@ __device__ __forceinline__ void aux_gemv_role(const AuxGemv& g, int aux_idx, int
             for (int c = 0; c < CH; ++c)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    acc = fmaf(bf16lo_to_f32(wv[j][c][i]), xr[c][2 * i], acc);
-                    acc = fmaf(bf16hi_to_f32(wv[j][c][i]), xr[c][2 * i + 1], acc);
+                    if constexpr (wf32) {
+                        acc = fmaf(__uint_as_float(wv[j][c][i]), xr[c][i], acc);
+                        acc = fmaf(__uint_as_float(wv2[j][c][i]), xr[c][4 + i], acc);
+                    } else {
+                        acc = fmaf(bf16lo_to_f32(wv[j][c][i]), xr[c][2 * i], acc);
+                        acc = fmaf(bf16hi_to_f32(wv[j][c][i]), xr[c][2 * i + 1], acc);
+                    }
                 }
-            acc = wave_sum_fast(acc);
-            const int n = n0 + j;
-            if (lane == 0 && n < min(g.N, n_first + per)) {
-                float v = acc + (g.b ? bf16_to_f32(g.b[n]) : 0.f);
-                if (g.act == HICOM_ACT_GELU) v = gelu_erf(v);
-                if (g.res) v += bf16_to_f32(g.res[n]);
-                g.y[n] = v;
+            acc = wave_sum_fast(acc);                                        // (every lane holds the sum)
+            const int n = n0 + j < g.N ? n0 + j : g.N - 1;
+            float v = acc;
+            if (g.b) v += g.b_f32 ? reinterpret_cast<const float*>(g.b)[n] : bf16_to_f32(reinterpret_cast<const uint16_t*>(g.b)[n]);
+            if (g.act == HICOM_ACT_GELU) v = gelu_erf(v);
+            if (g.res) v += bf16_to_f32(g.res[n]);
+            vout[j] = v;
+            if (lane == 0 && n0 + j < n_end && g.y) g.y[n] = v;
+        }
+        if (g.dst) {
+            // lane r writes this batch's columns of replica row r
+            for (int r = lane; r < g.reps; r += 64) {
+                const long o = (g.row0 + r) * g.ldd + n0;
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+                    if (n0 + j < n_end) {
+                        if (g.dst_f32) reinterpret_cast<float*>(g.dst)[o + j] = vout[j];
+                        else reinterpret_cast<uint16_t*>(g.dst)[o + j] = f32_to_bf16(vout[j]);
+                    }
             }
         }
     }
@@ -171,7 +205,8 @@ template <int kRRing>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void readout16_gemm_kernel(R16Params p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [kRRing][kRStage]
     if ((int)blockIdx.x >= p.n_gemm) {
-        aux_gemv_role(p.aux, (int)blockIdx.x - p.n_gemm, (int)gridDim.x - p.n_gemm, lds);
+        if (p.aux.w_f32) aux_gemv_role<true>(p.aux, (int)blockIdx.x - p.n_gemm, (int)gridDim.x - p.n_gemm, lds);
+        else aux_gemv_role<false>(p.aux, (int)blockIdx.x - p.n_gemm, (int)gridDim.x - p.n_gemm, lds);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63;
@@ -455,12 +490,14 @@ extern "C" int hicom_readout16_gemm_fwd(const void* a, const void* w, const void
     const int nbx = (N + kRN - 1) / kRN, nby = (M + kRM - 1) / kRM;
     p.n_gemm = 8 * ((nbx * nby + 7) / 8);
     int n_aux = 0;
-    p.aux = AuxGemv{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr};
+    p.aux = AuxGemv{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, 0, 0, 0};
     if (aux && aux->N > 0) {
-        HICOM_REQUIRE(aux->xs && aux->w && aux->y && aux->x_parts > 0 && aux->K > 0 && aux->K % 8 == 0 && aux->K <= 1536 && aux->x_stride % 4 == 0 && ((uintptr_t)aux->xs % 16 == 0) &&
-                          (long)aux->x_parts * aux->K <= 28 * 1024 && (1536 + (long)aux->x_parts * aux->K) * 4 <= 6 * kRStage, HICOM_EINVAL, "readout16_gemm: aux GEMV arguments");
-        p.aux = AuxGemv{aux->xs, aux->x_parts, (long)aux->x_stride, (const uint16_t*)aux->xb, (const uint16_t*)aux->w,
-                        (const uint16_t*)aux->b, (const uint16_t*)aux->res, aux->N, aux->K, aux->act, aux->y};
+        HICOM_REQUIRE(aux->xs && aux->w && (aux->y || aux->rows_dst) && aux->x_parts > 0 && aux->K > 0 && aux->K % 8 == 0 && aux->K <= 1536 && aux->x_stride % 4 == 0 && ((uintptr_t)aux->xs % 16 == 0) &&
+                          ((uintptr_t)aux->w % 16 == 0) && (long)aux->x_parts * aux->K <= 28 * 1024 && (1536 + (long)aux->x_parts * aux->K) * 4 <= 6 * kRStage, HICOM_EINVAL, "readout16_gemm: aux GEMV arguments");
+        HICOM_REQUIRE(!aux->rows_dst || (aux->rows_reps > 0 && aux->rows_ld >= aux->N && aux->rows_row0 >= 0), HICOM_EINVAL, "readout16_gemm: aux row destination");
+        p.aux = AuxGemv{aux->xs, aux->x_parts, (long)aux->x_stride, (const uint16_t*)aux->xb, aux->w,
+                        aux->b, (const uint16_t*)aux->res, aux->N, aux->K, aux->act, aux->y, aux->w_dt == HICOM_DT_F32, aux->b_dt == HICOM_DT_F32,
+                        aux->rows_dst, aux->rows_dt == HICOM_DT_F32, aux->rows_dst ? aux->rows_reps : 0, (long)aux->rows_ld, (long)aux->rows_row0};
         // the CUs the tile grid leaves idle (one workgroup per CU: the ring takes 120 KB of LDS), at least 16
         // the same number on every XCD, and ONE CU per XCD left free: with every CU of an XCD spoken for (25 tiles + 7 aux
         // = 32) an aux workgroup was seen queueing behind a 12-us tile (GEMM 1 in situ: 16.6 us with aux, 12.2 without)

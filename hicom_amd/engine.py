@@ -128,6 +128,11 @@ def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, 
         a.wo, a.bo = _w(att.out_proj)
         a.gw0, a.gb0 = _w(gc.readout[0])
         a.gw2, a.gb2 = _w(gc.readout[2])
+        a.gc0 = None
+        if gc.use_guide == "direct" and q_in.shape[0] == 1 and gc.readout[0].bias is not None and att.out_proj.bias is not None:
+            c0 = gc.readout_over_out_proj()                           # weight-only product: the five-launch step of the release recipe
+            a.gc0 = c0.data_ptr()
+            keep.append(c0)
         if gc.use_pos_emb:
             pe, kpe, cap = gc.pos_and_kpe(t_offset + T, H, W, ff.device)
             pe_hi, pe_lo = gc.pos_planes(t_offset + T, H, W, ff.device)

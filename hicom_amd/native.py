@@ -15,7 +15,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 # HICOM_NATIVE_LIB: dev override (instrumented builds from tools/); the product loads the in-tree library
 LIB_PATH = os.environ.get("HICOM_NATIVE_LIB") or os.path.join(HERE, "libhicom_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 DT_BF16, DT_F32, DT_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_GELU_TANH = 0, 1, 2
@@ -31,6 +31,7 @@ EXPORTS = (
     "hicom_global_stream_bwd", "hicom_readout16_gemm_fwd", "hicom_to_f16_fwd", "hicom_merge_vproj_fwd",
     "hicom_dense16_gemm_fwd", "hicom_ln_stream_fwd", "hicom_to_f16_padded_fwd", "hicom_clip_query_prep_fwd", "hicom_inv_norm_fwd",
     "hicom_global_stream_clip_fwd", "hicom_splice_rows_fwd", "hicom_splice_labels_fwd",
+    "hicom_query_prep_fwd", "hicom_query_prep_state_bytes",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -48,7 +49,9 @@ class Axis(C.Structure):
 class AuxGemv(C.Structure):
     """hicom_aux_gemv (include/hicom_hip.h): a single-row linear layer that rides in a readout GEMM's launch."""
     _fields_ = [("xs", C.c_void_p), ("x_parts", C.c_int32), ("x_stride", C.c_int64), ("xb", C.c_void_p), ("w", C.c_void_p),
-                ("b", C.c_void_p), ("res", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32), ("act", C.c_int32), ("y", C.c_void_p)]
+                ("b", C.c_void_p), ("res", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32), ("act", C.c_int32), ("y", C.c_void_p),
+                ("w_dt", C.c_int32), ("b_dt", C.c_int32), ("rows_dst", C.c_void_p), ("rows_dt", C.c_int32), ("rows_reps", C.c_int32),
+                ("rows_ld", C.c_int64), ("rows_row0", C.c_int64)]
 
 
 class CompressorArgs(C.Structure):
@@ -79,6 +82,7 @@ class CompressorArgs(C.Structure):
         ("ev_merge", C.c_void_p), ("defer_join", C.c_int32), ("reserved_", C.c_int32),
         ("place_src", C.c_void_p), ("place_block_stride", C.c_int64), ("place_block_rows", C.c_int32), ("place_nblocks", C.c_int32),
         ("ev_done", C.c_void_p), ("stream_next", C.c_void_p),
+        ("gc0", C.c_void_p),
     ]
 
 
@@ -132,6 +136,9 @@ def lib() -> C.CDLL:
     L.hicom_ln_stream_fwd.argtypes = [vp, i32, i64, vp, vp, vp, vp, i32, f32, vp, i32, i32, i32, vp]
     L.hicom_merge_vproj_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.hicom_fused_stream_nparts.argtypes = [i32]
+    L.hicom_query_prep_state_bytes.argtypes = [i32]
+    L.hicom_query_prep_state_bytes.restype = i64
+    L.hicom_query_prep_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp]
     L.hicom_planes_gemm_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i64, i64, i32, vp]
     L.hicom_row_ln_fwd.argtypes = [vp, i32, i64, vp, i64, vp, i64, vp, vp, i32, vp, i32, i64, vp, i32, f32, vp, i32, i64,
                                    i32, i32, vp]
@@ -460,7 +467,8 @@ def ln_stream(x, gamma, beta, out, src=None, alpha=None, eps=1e-6):
 
 
 def readout16_gemm(a16, w16, b, act=ACT_NONE, out_f16=None, y=None, row0=0, nl_group=0, aux=None):
-    """aux: dict(xs f32 [parts, K], xb bf16 [K] | None, w bf16 [N, K], b bf16 [N] | None, res bf16 [N] | None, act, y f32 [N])"""
+    """aux: dict(xs f32 [parts, K], xb bf16 [K] | None, w bf16 | f32 [N, K], b bf16 | f32 [N] | None, res bf16 [N] | None, act,
+    y f32 [N] | None, rows=(dst [*, ld], row0, reps) | None)"""
     N, K = w16.shape
     M = a16.shape[0]
     ag = None
@@ -472,11 +480,30 @@ def readout16_gemm(a16, w16, b, act=ACT_NONE, out_f16=None, y=None, row0=0, nl_g
         ag.w, ag.N, ag.K = aux["w"].data_ptr(), aux["w"].shape[0], aux["w"].shape[1]
         ag.b = None if aux.get("b") is None else aux["b"].data_ptr()
         ag.res = None if aux.get("res") is None else aux["res"].data_ptr()
-        ag.act, ag.y = aux.get("act", ACT_NONE), aux["y"].data_ptr()
+        ag.act, ag.y = aux.get("act", ACT_NONE), (None if aux.get("y") is None else aux["y"].data_ptr())
+        ag.w_dt = _dt(aux["w"])
+        ag.b_dt = 0 if aux.get("b") is None else _dt(aux["b"])
+        if aux.get("rows") is not None:
+            dst, row0_, reps = aux["rows"]
+            ag.rows_dst, ag.rows_dt, ag.rows_reps, ag.rows_ld, ag.rows_row0 = dst.data_ptr(), _dt(dst), reps, dst.shape[-1], row0_
     _check(lib().hicom_readout16_gemm_fwd(_ptr(a16), _ptr(w16), _ptr(b), _dt(b) if b is not None else 0, M, N, K, act,
                                           _ptr(out_f16), _ptr(y), _dt(y) if y is not None else 0, y.shape[-1] if y is not None else 0,
                                           row0, nl_group, C.byref(ag) if ag is not None else None, _stream()),
            "hicom_readout16_gemm_fwd")
+
+
+def query_prep_state(E, device):
+    """Zeroed state block of hicom_query_prep_fwd (epoch word + granules), private to one stream of calls."""
+    return torch.zeros(int(lib().hicom_query_prep_state_bytes(E)), dtype=torch.uint8, device=device)
+
+
+def query_prep(guide, local_q, w_q, b_q, w_k, kpe, nh, scale, qhi, qlo, pos_a, state, g_w0=None, g_b0=None, b_o=None, r0=None):
+    """One-launch q_proj + fold (+ positional table, local query rows, r0) of the direct recipe; see include/hicom_hip.h."""
+    E = w_q.shape[0]
+    _check(lib().hicom_query_prep_fwd(_ptr(guide), _ptr(local_q), _ptr(w_q), _ptr(b_q), _ptr(w_k), _ptr(kpe), nh, E,
+                                      kpe.shape[1] if kpe is not None else 0, scale, _ptr(qhi), _ptr(qlo), _ptr(pos_a),
+                                      pos_a.shape[1] if pos_a is not None else 0, nh, _ptr(g_w0), _ptr(g_b0), _ptr(b_o),
+                                      g_w0.shape[0] if g_w0 is not None else 0, _ptr(r0), _ptr(state), _stream()), "hicom_query_prep_fwd")
 
 
 def merge_vproj(part_m, part_l, part_acc, rows, w_v, po, out_ml=None, out_ctx=None):

@@ -444,6 +444,23 @@ class GlobalCompressor(nn.Module):
             self._cache_gen += 1
         return pe, hit[0], cap
 
+    def readout_over_out_proj(self):
+        """C [hidden, E] f32 = readout[0].weight . attn_layer.out_proj.weight: the first global readout layer folded over
+        out_proj, so that GELU(G0 (W_o o + b_o + q) + b0) (ref :226, :646, :307-312) is GELU(C o + r0) with the guide-dependent
+        r0 = G0 (b_o + q) + b0 made by hicom_query_prep_fwd -- one dependent stage fewer behind the streaming kernel.
+        Weight-only, cached per weight state like kpe."""
+        g0, wo = self.readout[0].weight, self.attn_layer.out_proj.weight
+        _require_bf16_cuda("readout weight", g0)
+        stamp = nv.weight_stamp(g0, wo)
+        hit = self._pe_cache.get("gc0")
+        if hit is None or hit[1] != stamp:
+            c = _f32((g0.shape[0], wo.shape[1]), g0.device)
+            nv.linear(g0.detach(), wo.detach().t().contiguous(), None, c)      # C[n, e] = sum_k G0[n, k] W_o[k, e]
+            hit = (c, stamp)
+            self._pe_cache["gc0"] = hit
+            self._cache_gen += 1
+        return hit[0]
+
     def pos_planes(self, t_cap: int, H: int, W: int, device):
         """bf16 hi / lo planes of the pe table (the fused kernel multiplies them on matrix cores), cached with it."""
         pe, cap = self.pos_tables(t_cap, H, W, device)

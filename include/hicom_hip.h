@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HICOM_ABI_VERSION 3
+#define HICOM_ABI_VERSION 4
 
 #define HICOM_OK         0
 #define HICOM_EINVAL    -1   /* bad argument (shape, alignment, NULL)        */
@@ -129,6 +129,23 @@ int hicom_fold_query_split_fwd(const float* qp, const void* w_k, const float* kp
                                int32_t E, int32_t P, float scale, void* qt_hi, void* qt_lo,
                                float* pos_a, int32_t pos_stride, const void* fill_row, int32_t fill_row0,
                                int32_t fill_rows, void* stream);
+
+/* Release recipe, use_guide = "direct" (ONE injected query row = the guide): q_proj, the fold, the score-side positional
+ * table, the local query rows of hicom_fused_stream_fwd's operand and the guide-dependent part of the global readout in ONE
+ * launch (the q_proj -> fold hand-off travels inside the grid as tagged 8-byte granules):
+ *   qt_hi / qt_lo rows h < nh : bf16 hi / lo of  scale * w_k[h]^T (w_q guide + b_q)[h]       (projector.py:180-181,193-197)
+ *   qt_hi rows nh .. 15       : local_q bf16 [E], the shared local query (= the guide, :352-368); qt_lo rows stay as
+ *                               the caller zeroed them
+ *   pos_a[h, p]               : scale * kpe[h]^T (w_q guide + b_q)[h]   (kpe f32 [E, P] = w_k . PE^T, or NULL)
+ *   r0 f32 [hidden]           : g_w0 (b_o + guide) + g_b0  -- with C = g_w0 . w_o (cached by the caller) the tail
+ *                               GELU(g_w0 (w_o o + b_o + guide) + g_b0) of :226,:646,:307-312 is GELU(C o + r0); g_w0 NULL = no r0
+ * state: hicom_query_prep_state_bytes(E) bytes of caller-owned device memory, zeroed ONCE, private to one stream of
+ * calls (epoch word + granules; the kernel maintains it). */
+int64_t hicom_query_prep_state_bytes(int32_t E);
+int hicom_query_prep_fwd(const void* guide, const void* local_q, const void* w_q, const void* b_q, const void* w_k, const float* kpe,
+                         int32_t nh, int32_t E, int32_t P, float scale, void* qt_hi, void* qt_lo, float* pos_a,
+                         int32_t pos_stride, int32_t rows, const void* g_w0, const void* g_b0, const void* b_o,
+                         int32_t hidden, float* r0, void* state, void* stream);
 
 /* Split f32 rows into bf16 hi + lo parts (x ~= hi + lo to 2^-16), zero-padding the row count
  * to rows_pad: the MFMA operand format for fp32 intermediates (SURVEY.md §7 strategy B). */
@@ -261,7 +278,7 @@ int hicom_planes_gemm_fwd(const void* a_hi, const void* a_lo, const void* w, con
  * aux (may be NULL): a single-row linear layer executed by extra workgroups of the SAME launch on the CUs the tile grid
  * leaves idle -- the global compressor's out_proj / readout layers ride under the two local readout GEMMs:
  *   y[n] = act(sum_k w[n,k] x[k] + b[n]) + res[n],  x[k] = sum_{s < x_parts} xs[s * x_stride + k] + xb[k]
- * (w, b, xb, res bf16; xs, y f32; K <= 1536, K % 8 == 0). */
+ * (xb, res bf16; w, b bf16 or f32 (w_dt / b_dt); xs, y f32; K <= 1536, K % 8 == 0). */
 typedef struct hicom_aux_gemv {
     const float* xs;
     int32_t x_parts;
@@ -271,7 +288,13 @@ typedef struct hicom_aux_gemv {
     const void* b;
     const void* res;
     int32_t N, K, act;
-    float* y;
+    float* y;                  /* f32 [N]; may be NULL when rows_dst is given */
+    int32_t w_dt, b_dt;        /* HICOM_DT_BF16 | HICOM_DT_F32 (f32: products of weight matrices cached by the caller) */
+    /* optional: the result row replicated into rows rows_row0 .. rows_row0 + rows_reps - 1 of rows_dst [*, rows_ld]
+     * (dtype rows_dt): the 32 identical global rows of "direct" mode (projector.py:646,707) */
+    void* rows_dst;
+    int32_t rows_dt, rows_reps;
+    int64_t rows_ld, rows_row0;
 } hicom_aux_gemv;
 int hicom_readout16_gemm_fwd(const void* a, const void* w, const void* b, int32_t b_dt,
                              int32_t M, int32_t N, int32_t K, int32_t act, void* out_f16,
@@ -378,9 +401,11 @@ int hicom_splice_labels_fwd(const void* labels, const void* mask, int32_t mask_e
 
 /* ---- whole-forward executor ------------------------------------------------------------------
  * hicom_compressor_fwd enqueues HIComProjector.forward (projector.py:676-708) for one dense
- * [T,H,W,E] input as a fixed plan of kernel launches over a caller-owned workspace: the local
- * chain on stream_main, the global chain on stream_side (fork/join through ev_fork / ev_join),
- * so the two streaming kernels and the two small-kernel tails overlap.
+ * [T,H,W,E] input as a fixed plan of kernel launches over a caller-owned workspace.  Release recipe
+ * (use_guide = "direct", exact window partition, solo call): everything in order on stream_main -- query prep, the
+ * fused stream kernel, merge + v_proj, the two readout GEMMs with the global tail's GEMVs riding in their launches;
+ * no side stream, no events.  Generic recipes and the deferred / frame-sharded forms: the local chain on stream_main,
+ * the global chain on stream_side (fork/join through ev_fork / ev_join).
  *
  * phases: HICOM_PHASE_STREAM = everything that touches the frames (local tokens, and the
  *         global online-softmax state); HICOM_PHASE_FINISH = the 32 global rows from the state.
@@ -459,6 +484,11 @@ typedef struct hicom_compressor_args {
     int64_t place_block_stride;
     int32_t place_block_rows, place_nblocks;
     void *ev_done, *stream_next;
+    /* gc0: f32 [hidden, E] = gw0 . wo, the first global readout layer folded over out_proj (weight-only, cached by the
+     * caller per weight state like kpe), or NULL.  With it the release recipe's step is five launches:
+     * hicom_query_prep_fwd | fused stream | merge + v_proj | readout GEMM 1 (+ GELU(gc0 o + r0)) | readout GEMM 2 (+ the
+     * last global readout layer -> the 32 global rows). */
+    const float* gc0;
 } hicom_compressor_args;
 
 /* 1 when hicom_compressor_fwd takes the release-recipe (single streaming kernel) path for these arguments. */

