@@ -263,7 +263,7 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                                      w.R, tail5 ? a.gw0 : nullptr, a.gb0, a.bo, a.hidden, F(w.r0), ws + w.prep_state, sm));
         else CHK(query_prep(sm, true));
         if (fold_ev && !merge_on_next && !single) hicom_host::set_stop_event(a.ev_fork);      // "record ev_fork" rides on the launch
-        CHK(hicom_fused_stream_fwd(a.ff, a.fe ? a.fe : a.ff, a.T, a.H, a.W, a.E, a.at.k, a.ay.k, ws + w.qhi, ws + w.qlo,
+        CHK(hicom_fused_stream_fwd(a.ff, a.fe ? a.fe : a.ff, a.local_logits, a.T, a.H, a.W, a.E, a.at.k, a.ay.k, ws + w.qhi, ws + w.qlo,
                                    w.R, a.l_scale, a.l_bias, a.pe ? F(w.pos_a) : nullptr, a.P, a.pe ? a.pe_hi : nullptr, a.pe ? a.pe_lo : nullptr, a.t_index0, a.y_index0,
                                    a.x_index0, F(w.part_m), F(w.part_l), F(w.part_acc),
                                    w.nparts, nullptr, f16 ? nullptr : ws + w.ctx_hi, f16 ? nullptr : ws + w.ctx_lo, f16 ? ws + w.ctx_hi : nullptr, sm));

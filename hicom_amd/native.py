@@ -82,7 +82,7 @@ class CompressorArgs(C.Structure):
         ("ev_merge", C.c_void_p), ("defer_join", C.c_int32), ("reserved_", C.c_int32),
         ("place_src", C.c_void_p), ("place_block_stride", C.c_int64), ("place_block_rows", C.c_int32), ("place_nblocks", C.c_int32),
         ("ev_done", C.c_void_p), ("stream_next", C.c_void_p),
-        ("gc0", C.c_void_p),
+        ("gc0", C.c_void_p), ("local_logits", C.c_void_p),
     ]
 
 
@@ -120,7 +120,7 @@ def lib() -> C.CDLL:
     L.hicom_global_merge_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, i64, i64, i32, i32, vp, i32, i32, i32,
                                          vp, vp, vp, i32, vp]
     L.hicom_linear_to_rows_fwd.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i64, i64, i32, vp]
-    L.hicom_fused_stream_fwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, f32, vp, i32, vp, vp, i32, i32, i32,
+    L.hicom_fused_stream_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, f32, vp, i32, vp, vp, i32, i32, i32,
                                          vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.hicom_readout16_gemm_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i64, i64, i32, C.POINTER(AuxGemv), vp]
     L.hicom_to_f16_fwd.argtypes = [vp, i32, vp, i64, vp]
@@ -341,11 +341,11 @@ def fused_stream_nparts(n_windows: int) -> int:
 
 
 def fused_stream(ff, fe, kt, ks, qhi, qlo, rows, l_scale, l_bias, pos_a, pe_hi, pe_lo, t0i, y0i, x0i, part_m, part_l,
-                 part_acc, ctx_local, ctx_hi=None, ctx_lo=None, ctx_f16=None):
+                 part_acc, ctx_local, ctx_hi=None, ctx_lo=None, ctx_f16=None, local_logits=None):
     """pos_a f32 [16, P] + pe_hi / pe_lo bf16 [P, E] (all three or none): the kernel folds the value-side
-    pos-emb into part_acc."""
+    pos-emb into part_acc.  local_logits f32 [T*H*W] (fe . local query per token) replaces the frames_embed stream."""
     T, H, W, E = ff.shape
-    _check(lib().hicom_fused_stream_fwd(_ptr(ff), _ptr(fe), T, H, W, E, kt, ks, _ptr(qhi), _ptr(qlo), rows, l_scale,
+    _check(lib().hicom_fused_stream_fwd(_ptr(ff), _ptr(fe), _ptr(local_logits), T, H, W, E, kt, ks, _ptr(qhi), _ptr(qlo), rows, l_scale,
                                         l_bias, _ptr(pos_a), pos_a.shape[1] if pos_a is not None else 0,
                                         _ptr(pe_hi), _ptr(pe_lo), t0i, y0i, x0i,
                                         _ptr(part_m), _ptr(part_l), _ptr(part_acc), part_m.shape[0], _ptr(ctx_local),

@@ -32,61 +32,75 @@ MODAL_INDEX_MAP = {"<image>": -200, "<video>": -201, "<audio>": -202}  # referen
 class SplicePlan:
     """Integer plan of hicom_arch.py:283-372 for one batch of ids.
 
-    src_kind [B, Lmax] int32 : >= 0 position in the sample's ids | -1 visual row | -2 padding
-    src_feat [B, Lmax, 2] int32 : (feature index, row) for visual rows
+    segments : (sample b, first output position o, first id position p0, text ids nt, feature k, feature rows n) -- a run of
+               text ids followed by the rows of feature k (k = -1, n = 0: the trailing text run)
     new_len [B] int32, Lmax
     feat_at [K, 3] int64 : (sample, first output position, rows) of every feature that was placed (rows may be 0); features a
                            text-only sample consumes without placing them (:289-299) have rows = 0 there too
+    src_kind [B, Lmax] int32 : >= 0 position in the sample's ids | -1 visual row | -2 padding      (built on first use)
+    src_feat [B, Lmax, 2] int32 : (feature index, row) for visual rows                             (built on first use)
     """
-    __slots__ = ("src_kind", "src_feat", "new_len", "Lmax", "feat_at")
+    __slots__ = ("new_len", "Lmax", "feat_at", "segments", "B", "_kind", "_feat")
+
+    def _maps(self):
+        kind = np.full((self.B, self.Lmax), -2, dtype=np.int32)
+        feat = np.zeros((self.B, self.Lmax, 2), dtype=np.int32)
+        for b, o, p0, nt, k, n in self.segments:
+            if nt:
+                kind[b, o:o + nt] = np.arange(p0, p0 + nt, dtype=np.int32)
+            if n:
+                kind[b, o + nt:o + nt + n] = -1
+                feat[b, o + nt:o + nt + n, 0] = k
+                feat[b, o + nt:o + nt + n, 1] = np.arange(n, dtype=np.int32)
+        self._kind, self._feat = kind, feat
+
+    @property
+    def src_kind(self):
+        if self._kind is None:
+            self._maps()
+        return self._kind
+
+    @property
+    def src_feat(self):
+        if self._feat is None:
+            self._maps()
+        return self._feat
 
     def __iter__(self):                                               # (kind, feat, new_len, Lmax) = plan_layout(...)
         return iter((self.src_kind, self.src_feat, self.new_len, self.Lmax))
 
 
 def plan_layout(ids: np.ndarray, feat_rows: List[int]) -> SplicePlan:
-    """Vectorised (numpy cumsum / repeat) layout plan; see SplicePlan.  ids [B, S] int64 (host), feat_rows[k] = rows of
-    mm_features[k]."""
+    """Layout plan by SEGMENTS (text run | feature block | text run ...): a handful of numpy slice assignments per
+    placeholder instead of per-position work -- prompts carry one or two placeholders among thousands of ids.  See SplicePlan.
+    ids [B, S] int64 (host), feat_rows[k] = rows of mm_features[k]."""
     B, S = ids.shape
     K = len(feat_rows)
-    rows_k = np.asarray(feat_rows, dtype=np.int64)
-    is_mm = (ids == -200) | (ids == -201) | (ids == -202)
-    nmm = is_mm.sum(axis=1)
+    bb, pp = np.nonzero((ids <= -200) & (ids >= -202))                # placeholders, sample-major then position
+    counts = np.bincount(bb, minlength=B)
     # a pure-text sample still consumes one feature slot, of which it takes zero rows (:289-299)
-    slots = np.where(nmm == 0, 1, nmm)
+    slots = np.where(counts == 0, 1, counts)
     first = np.cumsum(slots) - slots                                  # first feature index of each sample
     if int(first[-1] + slots[-1]) > K:
         raise IndexError("list index out of range")                   # what mm_features[cur_mm_idx] raises in the reference
-    # feature index of every placeholder: first[b] + its rank among the sample's placeholders
-    rank = np.cumsum(is_mm, axis=1) - 1
-    k_of = np.where(is_mm, first[:, None] + rank, 0)
-    lens = np.where(is_mm, rows_k[k_of] if K else 0, 1).astype(np.int64)   # output rows each input position expands to
-    new_len = lens.sum(axis=1)
-    Lmax = int(new_len.max())
-    start = np.cumsum(lens, axis=1) - lens                            # first output position of each input position
-    flat_lens = lens.ravel()
-    total = int(flat_lens.sum())
-    src = np.repeat(np.arange(B * S, dtype=np.int64), flat_lens)      # input position (flattened) of every output row
-    b_of = src // S
-    p_of = src - b_of * S
-    row0 = np.cumsum(new_len) - new_len                               # first output row (flattened, unpadded) of each sample
-    within = np.arange(total, dtype=np.int64) - row0[b_of]            # output position inside the sample
-    dest = b_of * Lmax + within
-    mm_row = is_mm.ravel()[src]
-    r_of = within - start.ravel()[src]                                # row inside the feature for visual rows
-    plan = SplicePlan()
-    kind = np.full(B * Lmax, -2, dtype=np.int32)
-    kind[dest] = np.where(mm_row, -1, p_of).astype(np.int32)
-    feat = np.zeros((B * Lmax, 2), dtype=np.int32)
-    feat[dest, 0] = np.where(mm_row, k_of.ravel()[src], 0)
-    feat[dest, 1] = np.where(mm_row, r_of, 0)
-    plan.src_kind, plan.src_feat = kind.reshape(B, Lmax), feat.reshape(B, Lmax, 2)
-    plan.new_len, plan.Lmax = new_len.astype(np.int32), Lmax
+    start_of = np.cumsum(counts) - counts                             # index of each sample's first placeholder in bb / pp
+    new_len = np.full(B, S, dtype=np.int64)
+    segs = []                                                         # (b, out0, p0, n_text, k, n_rows): a text run, then feature k
     fa = np.zeros((K, 3), dtype=np.int64)
-    bb, pp = np.nonzero(is_mm)
-    kk = k_of[bb, pp]
-    fa[kk, 0], fa[kk, 1], fa[kk, 2] = bb, start[bb, pp], rows_k[kk] if K else 0
-    plan.feat_at = fa
+    for b in range(B):
+        cur, p0 = 0, 0
+        for m in range(int(start_of[b]), int(start_of[b] + counts[b])):
+            p, k = int(pp[m]), int(first[b] + m - start_of[b])
+            n = int(feat_rows[k])
+            segs.append((b, cur, p0, p - p0, k, n))
+            fa[k] = (b, cur + p - p0, n)
+            cur += p - p0 + n
+            p0 = p + 1
+        segs.append((b, cur, p0, S - p0, -1, 0))                      # trailing text (the whole sample when it has no placeholder)
+        new_len[b] = cur + S - p0
+    plan = SplicePlan()
+    plan.B, plan.new_len, plan.Lmax, plan.feat_at, plan.segments = B, new_len.astype(np.int32), int(new_len.max()), fa, segs
+    plan._kind = plan._feat = None
     return plan
 
 
@@ -157,7 +171,7 @@ def prepare_inputs_labels_for_multimodal(embed_tokens, input_ids, attention_mask
         raise ValueError("splice: attention_mask must be torch.bool or torch.long")
     ids = input_ids.detach().cpu().numpy().astype(np.int64, copy=False)   # the one host read (the output shape depends on it)
     plan = plan_layout(ids, [f.shape[0] for f in feats])
-    src_kind, src_feat, new_len, Lmax = plan
+    new_len, Lmax = plan.new_len, plan.Lmax
     ragged = bool((new_len != new_len[0]).any())
     if ragged and attention_mask is not None and labels is None:
         # the reference's ragged branch builds the mask from `_new_labels`, which only exists when labels were given (:345,:352)
@@ -165,30 +179,31 @@ def prepare_inputs_labels_for_multimodal(embed_tokens, input_ids, attention_mask
     if attention_mask is not None and int(new_len.min()) < S:
         # zero-row features: the reference's left mask padding is torch.full((new_len - S,), True) (:355, :370)
         raise RuntimeError(f"Trying to create tensor with negative dimension {int(new_len.min()) - S}")
-    # device-pointer table of the output rows + label map + lengths: ONE packed upload
-    text = src_kind >= 0
-    tok = ids[np.nonzero(text)[0], src_kind[text]]
-    if tok.size and (int(tok.min()) < 0 or int(tok.max()) >= weight.shape[0]):
-        raise IndexError("index out of range in self")                # nn.Embedding's error for a bad id
+    # device-pointer table of the output rows + label map + lengths: ONE packed upload, filled segment by segment
     n = B * Lmax
     need_maps = labels is not None or attention_mask is not None
     packed = np.zeros(n * 8 + (n * 4 + (B * 4 + 15) // 16 * 16 if need_maps else 0), dtype=np.uint8)
     table = packed[:n * 8].view(np.int64).reshape(B, Lmax)
-    table[text] = weight.data_ptr() + tok * row_bytes
-    vis = src_kind == -1
-    if vis.any():
-        fbase = np.array([f.data_ptr() for f in feats], dtype=np.int64)
-        table[vis] = fbase[src_feat[..., 0][vis]] + src_feat[..., 1][vis].astype(np.int64) * row_bytes
+    wptr, vocab = weight.data_ptr(), weight.shape[0]
+    for b, o, p0, nt, k, nrows in plan.segments:
+        if nt:
+            tk = ids[b, p0:p0 + nt]
+            if int(tk.min()) < 0 or int(tk.max()) >= vocab:
+                raise IndexError("index out of range in self")        # nn.Embedding's error for a bad id
+            table[b, o:o + nt] = wptr + tk * row_bytes
+        if nrows:
+            table[b, o + nt:o + nt + nrows] = feats[k].data_ptr() + np.arange(nrows, dtype=np.int64) * row_bytes
     if need_maps:
-        packed[n * 8:n * 12].view(np.int32)[:] = src_kind.ravel()
+        packed[n * 8:n * 12].view(np.int32)[:] = plan.src_kind.ravel()
         packed[n * 12:n * 12 + B * 4].view(np.int32)[:] = new_len
     packed_d = torch.from_numpy(packed).to(dev)
     table_d = packed_d[:n * 8].view(torch.int64).view(B, Lmax)
     needs_grad = torch.is_grad_enabled() and (weight.requires_grad or any(f.requires_grad for f in feats))
     if needs_grad:
+        text = plan.src_kind >= 0
         flat_rows = np.nonzero(text.ravel())[0]
         text_rows = torch.from_numpy(flat_rows).to(dev)
-        text_tok = torch.from_numpy(np.ascontiguousarray(tok)).to(dev)
+        text_tok = torch.from_numpy(np.ascontiguousarray(ids[np.nonzero(text)[0], plan.src_kind[text]])).to(dev)
         new_input_embeds = _SpliceRows.apply(weight, table_d, (B, Lmax, hidden), text_rows, text_tok, plan.feat_at, *feats)
     else:
         new_input_embeds = torch.empty((B, Lmax, hidden), dtype=weight.dtype, device=dev)

@@ -208,8 +208,11 @@ int hicom_global_stream_nparts(int64_t N, int32_t rows_pad);
  * (projector.py:193-215): each visual tensor is read from HBM exactly once.
  * Requirements: windows partition the grid exactly (T % kt == H % ks == W % ks == 0), 16 <= kt*ks*ks
  * <= 64, rows <= 12 global folded rows, E == 1152.
+ *   fe          : frames_embed bf16 [T,H,W,E] -- enters only through the local logit fe_n . local query per token
+ *   local_logits: reserved, must be NULL (f32 [T*H*W] = fe_n . local query computed by the producer of frames_embed, so that
+ *                 the kernel need not read frames_embed at all: round-3 work in progress, returns HICOM_EUNSUP)
  *   q_hi / q_lo : bf16 [16, E]; rows < `rows` = folded global queries (hi / lo), rows >= `rows` =
- *                 the local query in q_hi (exact bf16) and zeros in q_lo
+ *                 the local query in q_hi (exact bf16; row `rows` is the one the kernel reads) and zeros in q_lo
  *   pos_a       : f32 [16, pos_stride] score-side pos-emb  a[r, p] = qt_r . pe[p]  (hicom_fold_query_split_fwd),
  *                 or NULL (no pos-emb)
  *   pe_hi/pe_lo : bf16 [P, E] hi / lo planes of the per-axis sinusoid table pe (hicom_split_bf16_fwd of the f32
@@ -222,7 +225,7 @@ int hicom_global_stream_nparts(int64_t N, int32_t rows_pad);
  *   ctx_local   : f32 [Nw, E], window order (t1,h1,w1), and/or ctx_hi + ctx_lo: the same contexts as
  *                 bf16 planes (hi + lo) for hicom_planes_gemm_fwd, and/or ctx_f16: one fp16 plane (saturating) for
  *                 hicom_readout16_gemm_fwd; unused outputs NULL */
-int hicom_fused_stream_fwd(const void* ff, const void* fe, int32_t T, int32_t H, int32_t W, int32_t E,
+int hicom_fused_stream_fwd(const void* ff, const void* fe, const float* local_logits, int32_t T, int32_t H, int32_t W, int32_t E,
                            int32_t kt, int32_t ks, const void* q_hi, const void* q_lo, int32_t rows,
                            float l_scale, float l_bias, const float* pos_a, int32_t pos_stride,
                            const void* pe_hi, const void* pe_lo,
@@ -489,6 +492,8 @@ typedef struct hicom_compressor_args {
      * hicom_query_prep_fwd | fused stream | merge + v_proj | readout GEMM 1 (+ GELU(gc0 o + r0)) | readout GEMM 2 (+ the
      * last global readout layer -> the 32 global rows). */
     const float* gc0;
+    /* local_logits: reserved, NULL (see hicom_fused_stream_fwd) */
+    const float* local_logits;
 } hicom_compressor_args;
 
 /* 1 when hicom_compressor_fwd takes the release-recipe (single streaming kernel) path for these arguments. */
