@@ -455,7 +455,11 @@ class GlobalCompressor(nn.Module):
         hit = self._pe_cache.get("gc0")
         if hit is None or hit[1] != stamp:
             c = _f32((g0.shape[0], wo.shape[1]), g0.device)
-            nv.linear(g0.detach(), wo.detach().t().contiguous(), None, c)      # C[n, e] = sum_k G0[n, k] W_o[k, e]
+            wot = wo.detach().t().contiguous()
+            if g0.shape[1] % 64 == 0:
+                nv.dense16_gemm(g0.detach(), wot, None, y=c)                   # C[n, e] = sum_k G0[n, k] W_o[k, e]: bf16 x bf16
+            else:                                                              # products are exact in fp32, fp32 accumulation
+                nv.linear(g0.detach(), wot, None, c)
             hit = (c, stamp)
             self._pe_cache["gc0"] = hit
             self._cache_gen += 1
