@@ -65,7 +65,8 @@ constexpr int kRegroup = 80;               // channels per hop of the completed-
 
 struct RingParams {
     const uint16_t* ff;
-    const uint16_t* fe;
+    const uint16_t* fe;    // frames_embed (fused_ring_kernel) ...
+    const float* llog;     // ... or precomputed local logits fe_n . guide, one per token [T*H*W] (fused_ring_logits_kernel)
     int T, H, W;
     int kt, ks, nwy, nwx, NW, WSZ;
     const uint16_t* qhi;   // [16][E]  rows < R: qt hi ; rows >= R: local query (exact bf16)
@@ -617,6 +618,562 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
     }
 }
 
+template <int N>
+__device__ __forceinline__ void ring_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Variant for PRECOMPUTED local logits (the producer of frames_embed -- the SigLIP head projection,
+// reference encoder.py:284-286 -- hands over fe_n . guide per token from its GEMM epilogue, so frames_embed is never written
+// or read): the same kernel with ONE streamed tensor.  frames_embed entered the computation only through that scalar (the
+// local query is one row for every window, reference projector.py:352-368, :549-551).
+//   * the LDS ring holds FOUR frames_feature images (the two frames_embed slots of the kernel above become look-ahead):
+//     everything of tile t+3 is requested right behind barrier [B] of tile t;
+//   * the compute waves fetch the 4 logits of their token slots themselves, one tile ahead, with ordinary loads (they issue
+//     no LDS-DMA, so the compiler's own wait counting is exact);
+//   * no local score MFMAs, no frames_embed fragment reads.
+// Past the token stream the ring carries the value-side pos-emb as image pairs (hi plane, lo plane) of the same cadence.
+template <int NB>
+__global__ __launch_bounds__(kRingThreads, 1) void fused_ring_logits_kernel(RingParams p) {
+    constexpr int E = NB * 128;
+    constexpr int SLICE = E / kRingC;              // channels per compute wave
+    constexpr int KS = SLICE / 16;                 // 16-column blocks of the P.x product per wave
+    constexpr int K32 = SLICE / 32;                // score K-steps of 32 channels
+    constexpr bool KTAIL = (SLICE % 32) != 0;      // + one K-step of 16 channels
+    constexpr int TILE_BYTES = NB * 4096;          // one 16-token image
+    constexpr int PIECES = NB * 4;                 // 1-KiB DMA pieces per image: (128-channel block, 4-token row group)
+    constexpr int PPL = PIECES / kRingL;           // pieces per loader wave and image
+    constexpr int NSLOT = 4;                       // ring slots
+    static_assert(E % (16 * kRingC) == 0 && PIECES % kRingL == 0 && kRingL == 4, "slice / piece split");
+    static_assert(SLICE % 16 == 0 && kRegroup % 16 == 0 && kRegroup / 4 <= 64, "row regroup: hops of kRegroup channels, one float4 per lane");
+    static_assert(3 * PPL <= 63, "vmcnt is a 6-bit counter");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ffbuf = smem;                                                // [NSLOT][TILE_BYTES] frames_feature ring
+    float* red = reinterpret_cast<float*>(smem + NSLOT * TILE_BYTES); // [kRingC + 1][16][16] logit partials (channel slices) + the score-side pos-emb
+    float* cscr = red + (kRingC + 1) * 256;                                  // [kRingC][kRegroup] wave-private regroup scratch of a completed row
+    float* alpha_s = cscr + kRingC * kRegroup;                            // [kRingC][16] wave-private rescale factors in accumulator-row order
+    int* win_txy = reinterpret_cast<int*>(alpha_s + kRingC * 16);   // [64] packed in-window coords (t2 << 16 | h2 << 8 | w2)
+    int* wtxy = win_txy + 64;                                          // [kMaxWinPerWg] packed window base coords (frame offset << 16 | y0 << 8 | x0)
+    int* slot_row = wtxy + kMaxWinPerWg;                               // [64] pe row of a compact pos-emb slot; [64] = number of slots
+    unsigned char* ymap = reinterpret_cast<unsigned char*>(slot_row + 65);   // [64] grid row -> compact slot (255: not touched by this workgroup)
+    unsigned char* xmap = ymap + 64;                                   // [64] grid column -> compact slot
+    int* tokslot = reinterpret_cast<int*>(xmap + 64);                  // [16] compact pos-emb slots (frame | row << 8 | column << 16) of this tile's tokens
+    int* wbase = tokslot + 16;                                         // [kMaxWinPerWg] token index of each window's first token
+    int* win_off = wbase + kMaxWinPerWg;                               // [64] token-index offset of in-window position i
+    float* a_pos = reinterpret_cast<float*>(win_off + 64);            // [R][kMaxFramesPerWg | H | W] score-side pos-emb per row
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tr_n = 0; (void)tr_n;
+    const int part = blockIdx.x;
+    const int wb = part * p.wpw;
+    const int we = min(p.NW, wb + p.wpw);
+    const int nwin = we - wb;
+    const int total = nwin * p.WSZ;                 // tokens of this workgroup's stream
+    const int ntile = (total + 15) >> 4;
+    const int R = p.R, NLOC = 16 - R;
+    const int ks2 = p.ks * p.ks, per_t = p.nwy * p.nwx;
+    const unsigned wsz_magic = (65536u + p.WSZ - 1) / p.WSZ;    // s / WSZ by multiply-shift: exact for s < 2^16
+
+    // =========================================================================================
+    // LOADER waves
+    // =========================================================================================
+    if (wave >= kRingC) {
+        const int l = wave - kRingC;
+        const int row = 4 * l + (lane >> 4), cpos = lane & 15;          // token slot of this lane, 16-byte chunk in the row
+        const int lane_off = 16 * (cpos ^ fswz(row));
+        // stream slot -> token index (slots past the end of the last tile re-read its last token).  Prologue form: plain
+        // index arithmetic (five runtime divisions, ~120 instructions); the tile loop uses the two tables the compute waves
+        // build before barrier [P] (window base + in-window offset: two LDS reads).
+        auto tok_slow = [&](int s) -> long {
+            s = s < total ? s : total - 1;
+            int wr = (int)(((unsigned)s * wsz_magic) >> 16);
+            int i = s - wr * p.WSZ;
+            if (i < 0) { i += p.WSZ; wr -= 1; }
+            const int w = wb + wr;
+            const int t1 = w / per_t, r = w - t1 * per_t, h1 = r / p.nwx, w1 = r - h1 * p.nwx;
+            const int t2 = i / ks2, ri = i - t2 * ks2, h2 = ri / p.ks, w2 = ri - h2 * p.ks;
+            return ((long)(t1 * p.kt + t2) * p.H + (h1 * p.ks + h2)) * p.W + (w1 * p.ks + w2);
+        };
+        auto tok_fast = [&](int s) -> long {
+            s = s < total ? s : total - 1;
+            int wr = (int)(((unsigned)s * wsz_magic) >> 16);
+            int i = s - wr * p.WSZ;
+            if (i < 0) { i += p.WSZ; wr -= 1; }
+            return (long)(wbase[wr] + win_off[i]);
+        };
+        auto issue = [&](const uint16_t* base, long off, char* img) {
+            const char* src = reinterpret_cast<const char*>(base) + off;
+#pragma unroll
+            for (int i = 0; i < PPL; ++i)                               // piece (block i, row group l)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 256),
+                                                 (__attribute__((address_space(3))) void*)(img + (4 * i + l) * 1024), 16, 0, HICOM_RING_AUX);
+        };
+        // Past the token stream the ring carries the value-side pos-emb: images ntile + 2 b (hi plane) and ntile + 2 b + 1
+        // (lo plane) hold the pe rows of compact slot tile b, so the request cadence, the slots and the counted waits stay
+        // exactly those of the stream, and the first pe images are in flight while the last token tiles are consumed.
+        int ntot = ntile, nsl = 0;
+        // byte offset of this lane's source row for ring image `img`
+        auto off_of = [&](int img, auto tok_of) -> long {
+            if (img < ntile) return tok_of(img * 16 + row) * (long)(E * 2) + lane_off;
+            const int s = 16 * ((img - ntile) >> 1) + row;              // compact pos-emb slot
+            return (long)slot_row[s < nsl ? s : 0] * (long)(E * 2) + lane_off;
+        };
+        auto img_base = [&](int img) -> const uint16_t* { return img < ntile ? p.ff : (((img - ntile) & 1) ? p.pe_lo : p.pe_hi); };
+        // Request order (vmcnt retires in issue order): ff(0) ff(1) ff(2) | [P] | iteration t: ff(t+3).  At the top of
+        // iteration t image t has to be complete; images t+1 and t+2 may stay in flight.
+        auto wait_allow = [&](int n) {                                  // at most n of the youngest operations still in flight
+            if (n >= 2 * PPL) ring_wait_vm<2 * PPL>();
+            else if (n >= PPL) ring_wait_vm<PPL>();
+            else ring_wait_vm<0>();
+        };
+        issue(p.ff, off_of(0, tok_slow), ffbuf);
+        if (ntile > 1) issue(p.ff, off_of(1, tok_slow), ffbuf + TILE_BYTES);
+        if (ntile > 2) issue(p.ff, off_of(2, tok_slow), ffbuf + 2 * TILE_BYTES);
+        HICOM_TR(2);   // prologue requests issued
+        __builtin_amdgcn_s_barrier();                                  // [P] (the compute waves' tables)
+        if (p.pe_hi) {
+            nsl = slot_row[64];
+            ntot = ntile + 2 * ((nsl + 15) >> 4);
+        }
+        // images 1 and 2 when they are pe images (a stream of one or two tiles): their rows are tabled only now
+        if (ntile <= 1 && ntot > 1) issue(img_base(1), off_of(1, tok_fast), ffbuf + TILE_BYTES);
+        if (ntile <= 2 && ntot > 2) issue(img_base(2), off_of(2, tok_fast), ffbuf + 2 * TILE_BYTES);
+        for (int t = 0; t < ntot; ++t) {
+            wait_allow((t + 1 < ntot ? PPL : 0) + (t + 2 < ntot ? PPL : 0));
+            HICOM_TR(2);   // tile: data landed
+            __builtin_amdgcn_s_barrier();                              // [A] image t published; the slot of image t-1 released
+            if (t == ntile) __builtin_amdgcn_s_barrier();              // [A'] (the compute waves table their marginals)
+            HICOM_TR(2);   // tile: past [A]
+            if (p.pe_hi && l == 0 && t < ntile && lane < 16) {
+                // compact pos-emb slots of this tile's 16 tokens, for the marginal MFMA of the compute waves (read
+                // after [B]): the table walk costs a loader lane nothing that matters
+                const int s = t * 16 + lane;
+                int wr = (int)(((unsigned)s * wsz_magic) >> 16), i = s - wr * p.WSZ;
+                if (i < 0) { i += p.WSZ; wr -= 1; }
+                int v = 0xFFFFFF;
+                if (s < total) {
+                    const int txy = win_txy[i], base = wtxy[wr];
+                    const int f = (base >> 16) + (txy >> 16), y = ((base >> 8) & 255) + ((txy >> 8) & 255), x = (base & 255) + (txy & 255);
+                    v = f | ((int)ymap[y] << 8) | ((int)xmap[x] << 16);
+                }
+                tokslot[lane] = v;
+            }
+            if (p.pos_a && l >= 1 && t < ntile) {
+                // score-side pos-emb of the R x 16 (row, token) pairs of this tile: the ninth "partial" of the
+                // logit exchange, tabled here (three loader waves) so that no compute wave walks the tables
+                const int q = (l - 1) * 64 + lane;                      // 0 .. 16 R - 1
+                if (q < 16 * R) {
+                    const int prow = q >> 4, pos = q & 15;
+                    const int slot = 4 * fsig(fxg(prow, pos >> 2)) + (pos & 3);   // token slot held at exchange position `pos`
+                    const int s = t * 16 + slot;
+                    int wr = (int)(((unsigned)s * wsz_magic) >> 16), i = s - wr * p.WSZ;
+                    if (i < 0) { i += p.WSZ; wr -= 1; }
+                    const int txy = win_txy[i], base = wtxy[s < total ? wr : 0];
+                    const int f = (base >> 16) + (txy >> 16), y = ((base >> 8) & 255) + ((txy >> 8) & 255), x = (base & 255) + (txy & 255);
+                    const float* ap = a_pos + prow * (kMaxFramesPerWg + p.H + p.W);
+                    red[kRingC * 256 + q] = ap[f] + ap[kMaxFramesPerWg + y] + ap[kMaxFramesPerWg + p.H + x];
+                }
+            }
+            const long o_nx = t + 3 < ntot ? off_of(t + 3, tok_fast) : 0;   // address math ahead of the barrier
+            lds_barrier();                                             // [B] tables of tile t visible
+            HICOM_TR(2);   // tile: past [B]
+            if (t + 3 < ntot) issue(img_base(t + 3), o_nx, ffbuf + ((t + 3) & (NSLOT - 1)) * TILE_BYTES);
+            HICOM_TR(2);   // tile: next image requested
+        }
+        __builtin_amdgcn_s_barrier();                                  // [E] ring idle (nothing is in flight any more)
+        return;
+    }
+
+    // =========================================================================================
+    // COMPUTE waves
+    // =========================================================================================
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int ctid = tid;                                              // compute threads are 0 .. 511
+
+    // ---- A operand (hi / lo) of this wave's channel slice: lane (query row r16, k group kg) -------
+    // SLICE = K32 steps of 32 channels (v_mfma_f32_16x16x32_bf16, the full-rate instruction) + an optional
+    // 16-channel tail (v_mfma_f32_16x16x16_bf16 runs at half the rate per flop).  Only the global rows (< R) matter:
+    // the local logits come from the loader waves.
+    bf16x8 ahi[K32], alo[K32];
+    bf16x4 ahi_t = bf16x4{0, 0, 0, 0}, alo_t = bf16x4{0, 0, 0, 0};
+    {
+        const long off = (long)r16 * E + SLICE * wave;
+#pragma unroll
+        for (int s = 0; s < K32; ++s) {
+            ahi[s] = *reinterpret_cast<const bf16x8*>(p.qhi + off + 32 * s + 8 * kg);
+            alo[s] = *reinterpret_cast<const bf16x8*>(p.qlo + off + 32 * s + 8 * kg);
+        }
+        if (KTAIL) {
+            ahi_t = *reinterpret_cast<const bf16x4*>(p.qhi + off + 32 * K32 + 4 * kg);
+            alo_t = *reinterpret_cast<const bf16x4*>(p.qlo + off + 32 * K32 + 4 * kg);
+        }
+    }
+    // ---- per-workgroup tables ---------------------------------------------------------------------
+    const int t1_first = wb / per_t;
+    if (ctid < p.WSZ) {
+        const int t2 = ctid / ks2, r = ctid - t2 * ks2, h2 = r / p.ks, w2 = r - h2 * p.ks;
+        win_txy[ctid] = (t2 << 16) | (h2 << 8) | w2;
+        win_off[ctid] = (t2 * p.H + h2) * p.W + w2;
+    }
+    if (ctid < nwin) {
+        const int w = wb + ctid;
+        const int t1 = w / per_t, r = w - t1 * per_t, h1 = r / p.nwx, w1 = r - h1 * p.nwx;
+        wtxy[ctid] = (((t1 - t1_first) * p.kt) << 16) | ((h1 * p.ks) << 8) | (w1 * p.ks);
+        wbase[ctid] = (t1 * p.kt * p.H + h1 * p.ks) * p.W + w1 * p.ks;
+    }
+    if (p.pe_hi && wave == 0) {
+        // Compact pos-emb slots of this workgroup: the 8 frames from its first frame group, then only the grid
+        // rows and columns its windows touch (a few of the H + W): fewer pe rows to multiply after the stream.
+        ymap[lane] = 0;
+        xmap[lane] = 0;
+        if (lane < nwin) {
+            const int w = wb + lane;
+            const int t1 = w / per_t, r = w - t1 * per_t, h1 = r / p.nwx, w1 = r - h1 * p.nwx;
+            for (int j = 0; j < p.ks; ++j) {
+                ymap[h1 * p.ks + j] = 1;
+                xmap[w1 * p.ks + j] = 1;
+            }
+        }
+        const bool yu = lane < p.H && ymap[lane] != 0, xu = lane < p.W && xmap[lane] != 0;
+        const unsigned long long ym = __ballot(yu), xm = __ballot(xu), below = (1ull << lane) - 1ull;
+        const int ny = __popcll(ym);
+        const int cy = kMaxFramesPerWg + __popcll(ym & below), cx = kMaxFramesPerWg + ny + __popcll(xm & below);
+        ymap[lane] = yu ? (unsigned char)cy : (unsigned char)255;
+        xmap[lane] = xu ? (unsigned char)cx : (unsigned char)255;
+        if (lane < kMaxFramesPerWg) slot_row[lane] = p.t0i + min(t1_first * p.kt + lane, p.T - 1);
+        if (yu) slot_row[cy] = p.y0i + lane;
+        if (xu) slot_row[cx] = p.x0i + lane;
+        if (lane == 0) slot_row[64] = kMaxFramesPerWg + ny + __popcll(xm);
+    }
+    if (p.pos_a) {
+        const int S = kMaxFramesPerWg + p.H + p.W, n_all = R * S;
+#pragma unroll
+        for (int u = 0; u < kPosPerThread; ++u) {
+            const int e = ctid + 64 * kRingC * u;
+            if (e < n_all) {
+                const int r = e / S, c = e - r * S;
+                const int t = t1_first * p.kt + c;
+                const int col = c < kMaxFramesPerWg ? p.t0i + t
+                                                    : (c < kMaxFramesPerWg + p.H ? p.y0i + (c - kMaxFramesPerWg) : p.x0i + (c - kMaxFramesPerWg - p.H));
+                a_pos[e] = (c >= kMaxFramesPerWg || t < p.T) ? p.pos_a[(long)r * p.pos_stride + col] : 0.f;
+            }
+        }
+    }
+
+    f32x4 acc[KS];
+#pragma unroll
+    for (int cb = 0; cb < KS; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Online-softmax state of query row r16, replicated in the four lanes (kg = 0..3) that hold its tokens
+    // and in every compute wave: the scores are computed TRANSPOSED (S^T = x . q^T), which leaves each lane
+    // with (row r16, token slots 4*sig(kg) .. +3) -- exactly the A-operand layout of P for the P.x MFMAs.
+    // The softmax therefore runs in registers in all waves at once: no shared P, no third barrier.
+    float m_run = -1.0e30f, l_run = 0.f;
+    f32x4 mgacc = f32x4{0.f, 0.f, 0.f, 0.f};   // waves < nslot_tiles: marginals (rows 4 kg + j, slot 16 wave + r16) of the global weights
+
+    const int q4 = (lane >> 2) & 3, pp = lane & 3;
+    const int trow = 4 * fsig(kg) + q4;
+    const int prow16 = 4 * fsig(r16 >> 2) + (r16 & 3);                      // token slot read as A-row r16 of the score MFMA
+    const int rd_row = prow16 * 256, rd_swz = fswz(prow16);                 // row read: chunk c of the row sits at position c ^ swz
+    const int tr_row_off = trow * 256 + 8 * (pp & 1), tr_swz = fswz(trow);
+    const int ch_base = SLICE * wave;
+    const int ts0 = 4 * fsig(kg);                                            // first token slot of this lane
+    float* ascr = alpha_s + 16 * wave;                                       // wave-private: alpha in accumulator-row order
+
+    // one P.x step over a 16-row image: ACC[u] += A(16 rows x [hi | lo of 16 rows' weights]) . [x ; x] per 16-channel block
+    constexpr int PG = (KS % 6 == 0 && KS > 9) ? 6 : KS;               // blocks whose fragments are in flight together
+    auto px_step = [&](unsigned img_lds, const bf16x8& a_op, f32x4 (&accr)[KS]) {
+#pragma unroll
+        for (int g0 = 0; g0 < KS; g0 += PG) {
+            bf16x4 bv[PG];
+#pragma unroll
+            for (int u = 0; u < PG; ++u) {
+                const int ch0 = ch_base + 16 * (g0 + u);
+                const unsigned addr = img_lds + (ch0 >> 7) * 4096 + tr_row_off + 16 * ((((ch0 & 127) >> 3) + (pp >> 1)) ^ tr_swz);
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(bv[u]) : "v"(addr));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < PG; ++u) {
+                const bf16x8 b2 = bf16x8{bv[u][0], bv[u][1], bv[u][2], bv[u][3], bv[u][0], bv[u][1], bv[u][2], bv[u][3]};
+                accr[g0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_op, b2, accr[g0 + u], 0, 0, 0);
+            }
+        }
+    };
+    HICOM_TR(0); HICOM_TR(1);   // prologue done (this wave)
+    lds_barrier();                                                     // [P] tables ready
+    // raw local logits of this lane's 4 token slots, fetched one tile ahead (slots past the stream re-read its last token)
+    auto fetch_logits = [&](int tile) -> f32x4 {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int s = tile * 16 + ts0 + j;
+            s = s < total ? s : total - 1;
+            int wr = (int)(((unsigned)s * wsz_magic) >> 16), i = s - wr * p.WSZ;
+            if (i < 0) { i += p.WSZ; wr -= 1; }
+            v[j] = p.llog[wbase[wr] + win_off[i]];
+        }
+        return v;
+    };
+    f32x4 el_next = fetch_logits(0);
+    const int nslot_tiles = p.pe_hi ? (__builtin_amdgcn_readfirstlane(slot_row[64]) + 15) >> 4 : 0;   // 16-slot tiles of the compact pos-emb slots
+
+    for (int tile = 0; tile < ntile; ++tile) {
+        const int s0 = tile * 16;
+        HICOM_TR(0); HICOM_TR(1);   // tile: arrive [A]
+        lds_barrier();                                                 // [A] image of this tile landed; red free
+        HICOM_TR(0); HICOM_TR(1);   // tile: past [A]
+        const char* ffimg = ffbuf + (tile & (NSLOT - 1)) * TILE_BYTES;
+        const f32x4 el = el_next;                                       // raw local logits of this lane's 4 tokens
+        if (tile + 1 < ntile) el_next = fetch_logits(tile + 1);       // lands under this tile's MFMAs
+
+        // window bookkeeping of this tile (wave-uniform)
+        int wr0 = (int)(((unsigned)s0 * wsz_magic) >> 16), i0 = s0 - wr0 * p.WSZ;
+        if (i0 < 0) { i0 += p.WSZ; wr0 -= 1; }
+        const int rowA = R + (wb + wr0) % NLOC;                        // local rows of the (at most two) windows in this tile
+        const int rowB = (rowA + 1 < 16) ? rowA + 1 : R;
+
+        // ---- global logits, transposed: A = token rows of the image, B = the query fragments (hi and lo planes) ----------
+        // fragment reads in groups of KG K-steps, each group's reads in flight together
+        constexpr int KG = (K32 % 3 == 0 && K32 > 4) ? 3 : K32;
+        bf16x4 bff_t;
+        if (KTAIL) {
+            const int cc = ((ch_base + 32 * K32) >> 3) + (kg >> 1);
+            const int off = (cc >> 4) * 4096 + rd_row + 16 * ((cc & 15) ^ rd_swz) + 8 * (kg & 1);
+            bff_t = *reinterpret_cast<const bf16x4*>(ffimg + off);
+        }
+        f32x4 f0 = f32x4{0.f, 0.f, 0.f, 0.f}, f1 = f0;
+#pragma unroll
+        for (int g0 = 0; g0 < K32; g0 += KG) {
+            bf16x8 bff[KG];
+#pragma unroll
+            for (int u = 0; u < KG; ++u) {
+                const int cc = ((ch_base + 32 * (g0 + u)) >> 3) + kg;   // 16-byte chunk of this lane over the whole row
+                const int off = (cc >> 4) * 4096 + rd_row + 16 * ((cc & 15) ^ rd_swz);
+                bff[u] = *reinterpret_cast<const bf16x8*>(ffimg + off);
+            }
+            if (KG < K32) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < KG; ++u) {
+                f0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bff[u], ahi[g0 + u], f0, 0, 0, 0);
+                f1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bff[u], alo[g0 + u], f1, 0, 0, 0);
+            }
+            if (KG < K32) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (KTAIL) {
+            f0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bff_t, ahi_t, f0, 0, 0, 0);
+            f1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bff_t, alo_t, f1, 0, 0, 0);
+        }
+        // The accumulators are read by VALU right away.  Required software wait states, CDNA4 ISA §4.1 (data-hazard table,
+        // "XDL write VGPR -> VALU read / write of that VGPR"; summarised in cdna_hip_programming.md §5.7 item 2): an 8-pass
+        // XDL op (32x32x16) needs 12, the 4-pass 16x16x32 / 16x16x16 forms used here fewer.  hipcc inserts them from its
+        // own table, but for the K = 16 tail (v_mfma_f32_16x16x16_bf16) its padding proved too short under load on
+        // gfx950 / ROCm 7.2 (logits of single tiles read stale whenever a co-resident wave delayed the matrix pipe;
+        // tools/dbg_async.py reproduces it on the unpadded build).  16 explicit states = the table's largest entry
+        // for any shape in this file, independent of the compiler's model.
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+        *reinterpret_cast<f32x4*>(red + wave * 256 + r16 * 16 + 4 * fxg(r16, kg)) = f0 + f1;
+        HICOM_TR(0); HICOM_TR(1);   // tile: arrive [B]
+        lds_barrier();                                                 // [B] channel-slice partials exchanged; local logits tabled
+        HICOM_TR(0); HICOM_TR(1);   // tile: past [B]
+
+        // ---- softmax of (row r16, 4 token slots) in registers, identically in every wave ---------------
+        f32x4 lg = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < kRingC; ++k) lg += *reinterpret_cast<const f32x4*>(red + k * 256 + r16 * 16 + 4 * fxg(r16, kg));
+        if (p.pos_a && r16 < R) lg += *reinterpret_cast<const f32x4*>(red + kRingC * 256 + r16 * 16 + 4 * fxg(r16, kg));
+        float pr[4];
+        float tmax = -1.0e30f;
+        bool valid[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = s0 + ts0 + j < total;
+            if (r16 < R) {
+                valid[j] = in;
+            } else {
+                const int row_of = (i0 + ts0 + j >= p.WSZ) ? rowB : rowA;
+                valid[j] = in && r16 == row_of;
+                lg[j] = el[j] * p.l_scale + p.l_bias;
+            }
+            tmax = fmaxf(tmax, valid[j] ? lg[j] : -1.0e30f);
+        }
+        tmax = xrow4_max(tmax);
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = fast_exp(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pr[j] = valid[j] ? fast_exp(lg[j] - m_new) : 0.f;
+            psum += pr[j];
+        }
+        l_run = l_run * alpha + xrow4_sum(psum);
+        m_run = m_new;
+        // P as ONE K=32 A operand: k = 8 kg + u carries the hi plane of this lane's token u, k = 8 kg + 4 + u its
+        // lo plane; the B operand then holds the lane's 4 transposed x values twice.  One full-rate
+        // v_mfma_f32_16x16x32_bf16 per 16-channel block instead of two half-rate 16x16x16.
+        bf16x8 pw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint16_t h, l;
+            split_bf16(pr[j], h, l);
+            pw[j] = (short)h;
+            pw[4 + j] = (short)l;
+        }
+        // accumulator rows are indexed 4 kg + j: fetch their rescale factors through a wave-private LDS hop,
+        // only in the (rare, after the first tiles) case that some running max moved
+        f32x4 al = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (__any(alpha != 1.0f)) {
+            if (kg == 0) ascr[r16] = alpha;
+            al = *reinterpret_cast<const f32x4*>(ascr + 4 * kg);
+#pragma unroll
+            for (int cb = 0; cb < KS; ++cb) {
+                acc[cb][0] *= al[0]; acc[cb][1] *= al[1]; acc[cb][2] *= al[2]; acc[cb][3] *= al[3];
+            }
+        }
+        // ---- value-side pos-emb, part 1 (reference projector.py:57-101 with :176-179): the context of a row is
+        // sum_n p_n (x_n + pe_t[t_n] + pe_y[y_n] + pe_x[x_n]).  The pe part only needs the t / y / x MARGINALS of
+        // the weights: MG += P . onehot(slot of each token) over the slots  frame (relative to this workgroup's
+        // first frame) | grid row | grid column -- one more MFMA per tile on the wave that owns the 16-slot
+        // block.  Rescaled by alpha like ACC.  Part 2 (after the stream) multiplies MG by the pe rows.
+        if (p.pe_hi && wave < nslot_tiles) {
+            const int col = 16 * wave + r16;
+            bf16x4 bm;
+            const int4 tsl = *reinterpret_cast<const int4*>(tokslot + ts0);   // slots of this lane's 4 tokens (tabled by a loader wave)
+            const int tsv[4] = {tsl.x, tsl.y, tsl.z, tsl.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool hit = col == (tsv[u] & 255) || col == ((tsv[u] >> 8) & 255) || col == (tsv[u] >> 16);
+                bm[u] = hit ? (short)0x3F80 : (short)0;
+            }
+            const bf16x8 bm2 = bf16x8{bm[0], bm[1], bm[2], bm[3], bm[0], bm[1], bm[2], bm[3]};
+            const f32x4 mg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pw, bm2, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");             // MFMA -> VALU read, as above
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mgacc[j] = fmaf(mgacc[j], al[j], mg[j]);
+        }
+        // ---- ACC += P . x: the transposed fragment reads in groups of PG blocks in flight, then their MFMAs --------
+        {
+            const unsigned img_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(ffimg);
+            px_step(img_lds, pw, acc);
+        }
+
+        HICOM_TR(0); HICOM_TR(1);   // tile: P.x issued
+        // ---- a window completed in this tile: emit its local context, recycle its row ------------
+        if (i0 + 16 >= p.WSZ) {
+            const int w = wb + wr0;
+            const int row = __builtin_amdgcn_readfirstlane(rowA);
+            const float linv = 1.0f / __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l_run), row));
+            const int rk = row >> 2, rj = row & 3;
+            // The row sits in 16 lanes as KS values 16 channels apart.  A hop through a wave-private scratch
+            // regroups it so that SLICE/4 lanes hold 4 consecutive channels each: one 16-byte (fp32) or 8-byte
+            // (bf16 / fp16 plane) store per lane.
+            int lane_c = lane;                           // opaque copy: keeps this block's address math out of the loop-invariant registers
+            asm volatile("" : "+v"(lane_c));
+            // (two hops of <= kRegroup channels: the scratch has to fit beside the ring)
+            float* wsc = cscr + wave * kRegroup;
+#pragma unroll
+            for (int c0 = 0; c0 < KS; c0 += kRegroup / 16) {
+                constexpr int NBLK = kRegroup / 16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j == rj) {
+                        if (kg == rk) {
+#pragma unroll
+                            for (int c = 0; c < NBLK; ++c)
+                                if (c0 + c < KS) {
+                                    wsc[16 * c + r16] = acc[c0 + c][j] * linv;
+                                    acc[c0 + c][j] = 0.f;
+                                }
+                        }
+                    }
+                }
+                const int nch = (KS - c0 < NBLK ? KS - c0 : NBLK) * 16;        // channels of this hop
+                if (4 * lane_c < nch) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(wsc + 4 * lane_c);
+                    const long o = (long)w * E + ch_base + 16 * c0 + 4 * lane_c;
+                    if (p.ctx_local) *reinterpret_cast<f32x4*>(p.ctx_local + o) = v;
+                    if (p.ctx_hi) {
+                        uint16_t h[4], l[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) split_bf16(v[u], h[u], l[u]);
+                        *reinterpret_cast<uint2*>(p.ctx_hi + o) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+                        *reinterpret_cast<uint2*>(p.ctx_lo + o) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+                    }
+                    if (p.ctx_f16) {
+                        typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+                        half4_t hv;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) hv[u] = (_Float16)fminf(fmaxf(v[u], -65504.f), 65504.f);
+                        *reinterpret_cast<half4_t*>(p.ctx_f16 + o) = hv;
+                    }
+                }
+            }
+            if (r16 == row) { m_run = -1.0e30f; l_run = 0.f; }   // every copy of the row's state is recycled
+        }
+    }
+
+    if (p.pe_hi) {
+        // ---- value-side pos-emb, part 2: ACC += MG . pe, as P.x steps over the pe images that follow the token
+        // stream in the ring (hi plane, then lo plane of each 16-slot tile).  MG (fp32, in the accumulator layout of the
+        // waves that own the slot blocks) is tabled in LDS ([slot][row], in `red`) and re-read in the A-operand layout;
+        // hi + lo planes of MG in one K = 32 operand.
+        float* mgs = red;                                              // [64 slots][16 rows]  (red: 9 x 256 floats)
+        for (int b = 0; b < nslot_tiles; ++b) {
+            bf16x8 pwp;                                                // marginals of slot tile b as the A operand (hi | lo)
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane) {
+                const int t = ntile + 2 * b + plane;
+                lds_barrier();                                         // [A] pe image landed; red idle
+                if (t == ntile) {
+                    if (wave < nslot_tiles) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) mgs[(16 * wave + r16) * 16 + 4 * kg + j] = (4 * kg + j < R) ? mgacc[j] : 0.f;
+                    }
+                    lds_barrier();                                     // [A'] table complete
+                }
+                if (plane == 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        uint16_t h, l;
+                        split_bf16(mgs[(16 * b + ts0 + u) * 16 + r16], h, l);
+                        pwp[u] = (short)h;
+                        pwp[4 + u] = (short)l;
+                    }
+                }
+                const char* img = ffbuf + (t & (NSLOT - 1)) * TILE_BYTES;
+                const unsigned img_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(img);
+                px_step(img_lds, pwp, acc);
+                lds_barrier();                                         // [B]
+            }
+        }
+    }
+    lds_barrier();                                                     // [E] every wave done with the ring
+    // ---- partial global state of this workgroup --------------------------------------------------
+    const long prow = (long)part * 16;
+    if (wave == 0 && kg == 0 && r16 < R) {
+        p.part_m[prow + r16] = m_run;
+        p.part_l[prow + r16] = l_run;
+    }
+    // The accumulator rows go out through the (now idle) ring, regrouped so that every lane stores 16
+    // contiguous bytes.
+    {
+        float* est = reinterpret_cast<float*>(smem) + wave * (R * SLICE);          // wave-private [R][SLICE]
+#pragma unroll
+        for (int cb = 0; cb < KS; ++cb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * kg + j < R) est[(4 * kg + j) * SLICE + 16 * cb + r16] = acc[cb][j];
+        const int n4 = R * (SLICE / 4);
+        for (int it = lane; it < n4; it += 64) {
+            const int row = it / (SLICE / 4), c4 = it - row * (SLICE / 4);
+            *reinterpret_cast<f32x4*>(p.part_acc + (prow + row) * E + ch_base + 4 * c4) = *reinterpret_cast<const f32x4*>(est + 4 * it);
+        }
+    }
+}
+
 }  // namespace hicom
 
 using namespace hicom;
@@ -659,9 +1216,8 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, const floa
                                       float* part_m, float* part_l,
                                       float* part_acc, int32_t nparts, float* ctx_local, void* ctx_hi,
                                       void* ctx_lo, void* ctx_f16, void* stream) {
-    HICOM_REQUIRE(ff && fe && q_hi && q_lo && part_m && part_l && part_acc && ((pe_hi && pe_lo) || !pos_a) && (pos_a || !pe_hi), HICOM_EINVAL,
+    HICOM_REQUIRE(ff && (fe || local_logits) && q_hi && q_lo && part_m && part_l && part_acc && ((pe_hi && pe_lo) || !pos_a) && (pos_a || !pe_hi), HICOM_EINVAL,
                   "fused_stream: NULL pointer");
-    HICOM_REQUIRE(!local_logits, HICOM_EUNSUP, "fused_stream: precomputed local logits are not built yet (stream frames_embed)");
     HICOM_REQUIRE(ctx_local || (ctx_hi && ctx_lo) || ctx_f16, HICOM_EINVAL, "fused_stream: no local output");
     HICOM_REQUIRE(!ctx_hi == !ctx_lo, HICOM_EINVAL, "fused_stream: ctx_hi and ctx_lo go together");
     HICOM_REQUIRE(E == 1152, HICOM_EUNSUP, "fused_stream: E=%d (only 1152)", E);
@@ -687,10 +1243,10 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, const floa
                       "fused_stream: %d windows per workgroup touch too many pos-emb slots", wpw);
     }
     HICOM_REQUIRE(rows * (kMaxFramesPerWg + H + W) <= 64 * kRingC * kPosPerThread, HICOM_EUNSUP, "fused_stream: pos-emb table too large");
-    const size_t smem = ring_lds_bytes(rows, H, W);
+    const size_t smem = ring_lds_bytes(rows, H, W) + (local_logits ? (size_t)(kMaxWinPerWg + 64) * 4 : 0);   // (+ the token-index tables)
     HICOM_REQUIRE(smem <= 163840, HICOM_EUNSUP, "fused_stream: H + W = %d does not fit the LDS budget", H + W);
     RingParams p;
-    p.ff = (const uint16_t*)ff; p.fe = (const uint16_t*)fe; p.T = T; p.H = H; p.W = W;
+    p.ff = (const uint16_t*)ff; p.fe = (const uint16_t*)fe; p.llog = local_logits; p.T = T; p.H = H; p.W = W;
     p.kt = kt; p.ks = ks; p.nwy = H / ks; p.nwx = W / ks; p.NW = NW; p.WSZ = wsz;
     p.qhi = (const uint16_t*)q_hi; p.qlo = (const uint16_t*)q_lo; p.R = rows;
     p.l_scale = l_scale; p.l_bias = l_bias;
@@ -700,10 +1256,14 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, const floa
     static bool attr_set = false;
     if (!attr_set) {
         HICOM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_ring_kernel<9>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 163840) == hipSuccess,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 163840) == hipSuccess &&
+                          hipFuncSetAttribute(reinterpret_cast<const void*>(fused_ring_logits_kernel<9>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 163840) == hipSuccess,
                       HICOM_ELAUNCH, "fused_stream: 160 KiB of LDS per workgroup not available");
         attr_set = true;
     }
-    HICOM_LAUNCH(fused_ring_kernel<9>, dim3((unsigned)nparts), dim3(kRingThreads), smem, (hipStream_t)stream, p);
+    // precomputed local logits win over frames_embed when both are given: frames_embed is then not read at all
+    if (local_logits) HICOM_LAUNCH(fused_ring_logits_kernel<9>, dim3((unsigned)nparts), dim3(kRingThreads), smem, (hipStream_t)stream, p);
+    else HICOM_LAUNCH(fused_ring_kernel<9>, dim3((unsigned)nparts), dim3(kRingThreads), smem, (hipStream_t)stream, p);
     return hicom_host::check_launch("fused_stream");
 }

@@ -208,9 +208,10 @@ int hicom_global_stream_nparts(int64_t N, int32_t rows_pad);
  * (projector.py:193-215): each visual tensor is read from HBM exactly once.
  * Requirements: windows partition the grid exactly (T % kt == H % ks == W % ks == 0), 16 <= kt*ks*ks
  * <= 64, rows <= 12 global folded rows, E == 1152.
- *   fe          : frames_embed bf16 [T,H,W,E] -- enters only through the local logit fe_n . local query per token
- *   local_logits: reserved, must be NULL (f32 [T*H*W] = fe_n . local query computed by the producer of frames_embed, so that
- *                 the kernel need not read frames_embed at all: round-3 work in progress, returns HICOM_EUNSUP)
+ *   fe          : frames_embed bf16 [T,H,W,E] -- enters only through the local logit fe_n . local query per token -- or
+ *   local_logits: f32 [T*H*W] = fe_n . local query already computed by the producer of frames_embed
+ *                 (hicom_dense16_gemm_fwd's row-dot epilogue on the SigLIP head projection, encoder.py:284-286): the
+ *                 kernel then does not read frames_embed at all (half the HBM bytes); NULL = stream fe
  *   q_hi / q_lo : bf16 [16, E]; rows < `rows` = folded global queries (hi / lo), rows >= `rows` =
  *                 the local query in q_hi (exact bf16; row `rows` is the one the kernel reads) and zeros in q_lo
  *   pos_a       : f32 [16, pos_stride] score-side pos-emb  a[r, p] = qt_r . pe[p]  (hicom_fold_query_split_fwd),
@@ -492,7 +493,7 @@ typedef struct hicom_compressor_args {
      * hicom_query_prep_fwd | fused stream | merge + v_proj | readout GEMM 1 (+ GELU(gc0 o + r0)) | readout GEMM 2 (+ the
      * last global readout layer -> the 32 global rows). */
     const float* gc0;
-    /* local_logits: reserved, NULL (see hicom_fused_stream_fwd) */
+    /* local_logits: f32 [T*H*W] = frames_embed_n . guide per token, or NULL (release recipe only; see hicom_fused_stream_fwd) */
     const float* local_logits;
 } hicom_compressor_args;
 

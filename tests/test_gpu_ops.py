@@ -358,6 +358,17 @@ def test_fused_stream_matches_separate_kernels(T, H, W, kt, ks):
         nv.fused_stream(ff, fe, kt, ks, qhi_f, qlo, R, 1 / math.sqrt(E), 0.0, pos_a, pe_hi, pe_lo, 0, cap, cap + H, pm1, pl1, pa2, ctx)
         nv.global_merge(pm1, pl1, pa2, R, None, N, H, W, None, 0, 0, 0, None, ml, acc2, normalize=True)
         assert torch.equal(pa1[:, :R], pa2[:, :R]) and torch.equal(acc, acc2), (nparts, "determinism")
+        # precomputed local logits (one f32 per token: fe_n . guide, what the head projection's row-dot epilogue hands over)
+        # instead of the frames_embed stream (fused_ring_logits_kernel): same windows, same global state
+        if lds + (32 + 64) * 4 <= 163840:
+            llog = (fe.view(N, E).float() @ g.float()).contiguous()
+            ctx3 = torch.full((nw, E), float("nan"), dtype=torch.float32, device="cuda")
+            pa3 = torch.empty_like(pa1)
+            nv.fused_stream(ff, None, kt, ks, qhi_f, qlo, R, 1 / math.sqrt(E), 0.0, pos_a, pe_hi, pe_lo, 0, cap, cap + H, pm1, pl1, pa3, ctx3,
+                            local_logits=llog)
+            torch.cuda.synchronize()
+            assert maxabs(ctx3, ctx_ref) <= 5e-5 * max(1.0, float(ctx_ref.abs().max())), (nparts, "local from logits")
+            assert maxabs(pa3[:, :R], pa1[:, :R]) <= 1e-5 * max(1.0, float(pa1[:, :R].abs().max())), (nparts, "global state with logits")
     assert ran
 
 
