@@ -383,6 +383,39 @@ def neighbours_sweep(args, device):
         out["siglip_head_projection"] = {"ms": dt * 1e3, "tflops": flops / dt / 1e12, "frac_of_dense_fp16_peak": flops / dt / 2.5e15,
                                          "workload": f"{x.shape[0]}x729 tokens, LayerNorm + 1152->4304->1152 MLP + residual (encoder.py:284-286)",
                                          "kernels": "ln_stream + 2 x dense16_gemm (fp16 operands, fp32 accumulate)"}
+        # f2 completed: head projection + compressor as ONE segment at the benchmark shape.  two_tensor: the head writes
+        # frames_embed (bf16) and the compressor streams both visual tensors; logits: the fc2 launch dots its rows with the guide
+        # (siglip_head_scores) and the compressor streams frames_feature only.
+        from hicom_amd.encoder import siglip_head_scores
+        T = args.frames_per_gpu
+        mc = make_projector(release_config(args.hidden, T), device)
+        hs = x.view(T, GRID, GRID, D)
+        gv = torch.randn(D, device=device, generator=gen).to(torch.bfloat16)
+
+        def two_tensor():
+            return mc(hs, siglip_head_embed(hs, head), gv, "video", None)
+
+        def with_logits():
+            return mc(hs, None, gv, "video", None, local_logits=siglip_head_scores(hs, head, gv))
+
+        for f in (two_tensor, with_logits):
+            for _ in range(3):
+                f()
+        dt2, o2 = best(two_tensor, n=5)
+        dtl, ol = best(with_logits, n=5)
+        ll = siglip_head_scores(hs, head, gv)
+        dt_cl, _ = best(lambda: mc(hs, None, gv, "video", None, local_logits=ll), n=20)
+        ntok = T * GRID * GRID
+        tensor_b = ntok * D * 2
+        out["head_plus_compressor"] = {
+            "workload": f"{T} frames: head.layernorm + head.mlp + residual (encoder.py:284-286) -> HIComProjector.forward (release recipe, hidden {args.hidden})",
+            "two_tensor_ms": dt2 * 1e3, "logits_ms": dtl * 1e3, "compressor_alone_with_logits_ms": dt_cl * 1e3,
+            # algorithmic HBM bytes of the segment behind the hidden layer: fc2 residual read, frames_embed write + re-read,
+            # frames_feature read (two_tensor) | fc2 residual read, 18 x 4-byte partials per token + 4-byte logit, frames_feature read
+            "bytes_two_tensor": 4 * tensor_b, "bytes_logits": 2 * tensor_b + ntok * (18 * 4 * 2 + 4 * 2),
+            "max_abs_diff_between_paths": float((o2.float() - ol.float()).abs().max()),
+            "note": "frames_embed enters the direct-mode compressor only through guide . frames_embed_n (projector.py:542-551): "
+                    "the logits path never writes it"}
         # C4 segment: compressor at T = 32 / hidden 3584, then the splice into a 2048-token prompt
         cfg = release_config(3584, 32)
         m = make_projector(cfg, device)

@@ -51,6 +51,10 @@ struct DenseParams {
     const uint16_t* res;    // bf16 [M, ldr] residual added before the y store (or NULL)
     long ldr;
     float* ssq;             // [ceil(N / 64)][M] partial row sums of squares of (acc + b), one row per 64-column slice (or NULL)
+    // row-dot output (row-contiguous epilogue only): rdot[(n / 64) * M + m] = sum over the 64-column slice of dotv[n] * (value + res)[m, n]
+    const void* dotv;       // [N] bf16 | f32
+    int dotv_f32;
+    float* rdot;            // [ceil(N / 64)][M] (or NULL)
     int tiles_m, tiles_n;
     // optional per-row additive term from three table rows (the projected positional embedding W . pos of token m):
     //   + tab[t0 + m / (H*W)][n] + tab[y0 + (m / W) % H][n] + tab[x0 + m % W][n],   tab f32 [*, tab_ld]
@@ -191,6 +195,20 @@ __device__ __forceinline__ void dense_epilogue_rows(const DenseParams& p, f32x4 
                 for (int e = 0; e < 4; ++e) { bias[2 * e] = bf16lo_to_f32(g[e]); bias[2 * e + 1] = bf16hi_to_f32(g[e]); }
             }
         }
+        float dv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dv[e] = 0.f;
+        if (p.rdot && n_ok) {
+            if (p.dotv_f32) {
+                const float4 d0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.dotv) + n);
+                const float4 d1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.dotv) + n + 4);
+                dv[0] = d0.x; dv[1] = d0.y; dv[2] = d0.z; dv[3] = d0.w; dv[4] = d1.x; dv[5] = d1.y; dv[6] = d1.z; dv[7] = d1.w;
+            } else {
+                const u32x4 g = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(p.dotv) + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { dv[2 * e] = bf16lo_to_f32(g[e]); dv[2 * e + 1] = bf16hi_to_f32(g[e]); }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -233,19 +251,30 @@ __device__ __forceinline__ void dense_epilogue_rows(const DenseParams& p, f32x4 
                     const int nb = nw + 64 * jq;
                     if (q == 0 && m < p.M && nb < p.N) p.ssq[(long)(nb >> 6) * p.M + m] = rss;
                 }
-                if (m >= p.M) continue;
-                if (p.o16 && n < p.n_store) {
+                if (m < p.M && p.o16 && n < p.n_store) {
                     half8 hv;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) hv[e] = (_Float16)fminf(fmaxf(v[e], -65504.f), 65504.f);
                     *reinterpret_cast<half8*>(p.o16 + (long)m * p.ldo + n) = hv;
                 }
-                if (p.y && n_ok) {
-                    if (p.res) {
-                        const u32x4 g = *reinterpret_cast<const u32x4*>(p.res + (long)m * p.ldr + n);
+                if (!p.y && !p.rdot) continue;
+                if (p.res && n_ok) {
+                    const u32x4 g = *reinterpret_cast<const u32x4*>(p.res + (long)mm * p.ldr + n);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[2 * e] += bf16lo_to_f32(g[e]); v[2 * e + 1] += bf16hi_to_f32(g[e]); }
-                    }
+                    for (int e = 0; e < 4; ++e) { v[2 * e] += bf16lo_to_f32(g[e]); v[2 * e + 1] += bf16hi_to_f32(g[e]); }
+                }
+                if (p.rdot) {
+                    // the 8 lanes of a row hold its 64-column slice (dv is zero outside N)
+                    float d = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d = fmaf(dv[e], v[e], d);
+                    d += __shfl_xor(d, 1, 64);
+                    d += __shfl_xor(d, 2, 64);
+                    d += __shfl_xor(d, 4, 64);
+                    const int nb = nw + 64 * jq;
+                    if (q == 0 && m < p.M && nb < p.N) p.rdot[(long)(nb >> 6) * p.M + m] = d;
+                }
+                if (p.y && n_ok && m < p.M) {
                     if (p.y_f32) {
                         float* yp = reinterpret_cast<float*>(p.y) + (long)m * p.ldy + n;
                         *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -454,8 +483,9 @@ extern "C" int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w,
                                       void* out_f16, int64_t ldo, int32_t n_store,
                                       void* y, int32_t y_dt, int64_t ldy, const void* res, int64_t ldr,
                                       float* ssq, const float* row_tab, int64_t row_tab_ld, int32_t tab_H, int32_t tab_W,
-                                      int32_t tab_t0, int32_t tab_y0, int32_t tab_x0, void* stream) {
-    HICOM_REQUIRE(a && w && (out_f16 || y || ssq), HICOM_EINVAL, "dense16_gemm: NULL pointer / no output");
+                                      int32_t tab_t0, int32_t tab_y0, int32_t tab_x0,
+                                      const void* dot_vec, int32_t dot_vec_dt, float* row_dot, void* stream) {
+    HICOM_REQUIRE(a && w && (out_f16 || y || ssq || row_dot), HICOM_EINVAL, "dense16_gemm: NULL pointer / no output");
     if (row_tab) HICOM_REQUIRE(tab_H > 0 && tab_W > 0 && row_tab_ld >= N && row_tab_ld % 4 == 0 && (uintptr_t)row_tab % 16 == 0 &&
                                    M % (tab_H * tab_W) == 0, HICOM_EINVAL, "dense16_gemm: positional table layout");
     HICOM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, HICOM_EINVAL,
@@ -477,6 +507,11 @@ extern "C" int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w,
     const bool rows = N % 8 == 0 && (!b || (uintptr_t)b % 16 == 0) &&
                       (!out_f16 || (ldo % 8 == 0 && n_store % 8 == 0 && (uintptr_t)out_f16 % 16 == 0)) &&
                       (!y || y_dt == HICOM_DT_F32 || ldy % 8 == 0) && (!res || (ldr % 8 == 0 && (uintptr_t)res % 16 == 0));
+    if (row_dot)
+        HICOM_REQUIRE(rows && dot_vec && (uintptr_t)dot_vec % 16 == 0 && (dot_vec_dt == HICOM_DT_BF16 || dot_vec_dt == HICOM_DT_F32) &&
+                          (!res || ((uintptr_t)res % 16 == 0 && ldr % 8 == 0)), HICOM_EINVAL,
+                      "dense16_gemm: the row-dot output needs the row-contiguous epilogue (N %% 8, 16-byte aligned rows) and a bf16 | f32 vector");
+    p.dotv = dot_vec; p.dotv_f32 = dot_vec_dt == HICOM_DT_F32; p.rdot = row_dot;
     hipStream_t st = (hipStream_t)stream;
     p.tiles_m = (M + 127) / 128; p.tiles_n = (N + 127) / 128;
     constexpr int smem = (128 + 128) * 128;

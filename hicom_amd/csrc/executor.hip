@@ -192,6 +192,7 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
     const bool both = a.has_local && a.has_global;
     const bool do_stream = a.phases & HICOM_PHASE_STREAM, do_finish = a.phases & HICOM_PHASE_FINISH;
     const bool fused = do_stream && can_fuse(a);
+    HICOM_REQUIRE(!a.local_logits || fused, HICOM_EINVAL, "compressor: local_logits is an input of the fused stream kernel only (release recipe)");
     const bool merge_on_next = fused && (a.phases & HICOM_PHASE_MERGE_ON_NEXT);
     // event records folded into the launches they follow (release recipe); HICOM_FOLD_EVENTS=0 keeps separate records
     static const bool fold_env = !(getenv("HICOM_FOLD_EVENTS") && getenv("HICOM_FOLD_EVENTS")[0] == '0');

@@ -404,9 +404,23 @@ __global__ __launch_bounds__(256) void inv_norm_kernel(const float* ssq, int par
     inv[m] = 1.0f / sqrtf(s);
 }
 
+__global__ __launch_bounds__(256) void partials_sum_kernel(const float* parts, int nparts, long M, float* out) {
+    const long m = (long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float s = 0.f;
+    for (int k = 0; k < nparts; ++k) s += parts[(long)k * M + m];     // slice order: deterministic
+    out[m] = s;
+}
+
 }  // namespace hicom
 
 using namespace hicom;
+
+extern "C" int hicom_partials_sum_fwd(const float* parts, int32_t nparts, int64_t M, float* out, void* stream) {
+    HICOM_REQUIRE(parts && out && nparts > 0 && M > 0, HICOM_EINVAL, "partials_sum: bad arguments");
+    hipLaunchKernelGGL(partials_sum_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, parts, nparts, (long)M, out);
+    return hicom_host::check_launch("partials_sum");
+}
 
 extern "C" int hicom_clip_query_prep_fwd(float* qp, const void* b_k, int32_t nq, int32_t nh, int32_t E, float scale, float* c, void* stream) {
     HICOM_REQUIRE(qp && c && nq > 0 && nh > 0 && E > 0 && E % nh == 0, HICOM_EINVAL, "clip_query_prep: bad arguments");

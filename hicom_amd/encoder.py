@@ -13,6 +13,10 @@ hidden, K zero-padded to 4352) -> hicom_dense16_gemm_fwd (fc2 + bias + residual 
 activations keep 11 significand bits (LayerNorm output and tanh-GELU hidden: far inside the fp16 range whatever outlier
 channels the raw hidden states carry -- the residual is added from the bf16 input in fp32); the bf16 weights convert exactly
 above 2^-14 (nv.f16_weight_copy: range checked when the copy is first built; cached per weight state).
+
+`siglip_head_scores` is the same chain for the release recipe (use_guide = "direct"), where frames_embed enters the compressor
+ONLY through the local logit frames_embed_n . guide (reference projector.py:542-551 with the guide as the shared query, :352-368):
+the fc2 launch dots its fp32 rows (value + residual) with the guide in its epilogue and frames_embed is never written.
 """
 from __future__ import annotations
 
@@ -36,6 +40,24 @@ def _head_cache(head):
 
 def siglip_head_embed(last_hidden_state: torch.Tensor, head, hidden_act: str = None, out_dtype=None) -> torch.Tensor:
     """[..., D] bf16 tokens -> x + head.mlp(head.layernorm(x)), same shape (bf16; out_dtype=torch.float32 for parity tests)."""
+    return _head_chain(last_hidden_state, head, hidden_act, out_dtype, None, True)[0]
+
+
+def siglip_head_scores(last_hidden_state: torch.Tensor, head, guide_embed: torch.Tensor, hidden_act: str = None,
+                       return_embed: bool = False):
+    """[..., D] bf16 tokens, guide [D] bf16 -> fp32 [...] raw local logits  guide . (x_n + head.mlp(head.layernorm(x_n)))
+    (the dot products of reference projector.py:551 before the 1/sqrt(D) scale, which the compressor applies), for
+    `HIComProjector.forward(frames_feature, None, guide, modal, local_logits=...)`.  Nothing of frames_embed reaches HBM
+    unless return_embed=True (then: (logits, frames_embed bf16), e.g. to cross-check)."""
+    from .projector import _require_bf16_cuda
+    _require_bf16_cuda("guide_embed", guide_embed)
+    if guide_embed.ndim != 1 or guide_embed.shape[0] != last_hidden_state.shape[-1]:
+        raise ValueError("siglip_head_scores takes the [D] guide embedding of use_guide='direct'")
+    out, logits = _head_chain(last_hidden_state, head, hidden_act, None, guide_embed.contiguous(), return_embed)
+    return (logits, out) if return_embed else logits
+
+
+def _head_chain(last_hidden_state, head, hidden_act, out_dtype, guide, want_embed):
     from .projector import _require_bf16_cuda
     x = last_hidden_state
     _require_bf16_cuda("last_hidden_state", x)
@@ -57,6 +79,11 @@ def siglip_head_embed(last_hidden_state: torch.Tensor, head, hidden_act: str = N
     nv.ln_stream(x2, ln.weight.detach(), ln.bias.detach(), a16, eps=ln.eps)
     hid = torch.empty((M, kpad), dtype=torch.float16, device=x.device)
     nv.dense16_gemm(a16, w1, fc1.bias.detach(), act=_ACTS[hidden_act], out_f16=hid, n_store=kpad)
-    out = torch.empty((M, D), dtype=out_dtype or x.dtype, device=x.device)
-    nv.dense16_gemm(hid, w2, fc2.bias.detach(), N=D, K=kpad, y=out, res=x2)
-    return out.view(x.shape)
+    out = torch.empty((M, D), dtype=out_dtype or x.dtype, device=x.device) if want_embed else None
+    parts = torch.empty(((D + 63) // 64, M), dtype=torch.float32, device=x.device) if guide is not None else None
+    nv.dense16_gemm(hid, w2, fc2.bias.detach(), N=D, K=kpad, y=out, res=x2, row_dot=(guide, parts) if guide is not None else None)
+    logits = None
+    if guide is not None:
+        logits = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+        nv.partials_sum(parts, logits.view(-1))
+    return (out.view(x.shape) if want_embed else None), logits

@@ -234,7 +234,7 @@ def _evict_one(plans: dict):
         ws.record_stream(res.side)
 
 
-def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferred: bool = False):
+def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferred: bool = False, local_logits=None):
     """HIComProjector.forward for a dense [T,H,W,E] input through hicom_compressor_fwd.
 
     With `proj.graph_replay = True` the launch sequence of a plan is captured into a hipGraph on its second use and
@@ -252,12 +252,13 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
     fe = fe.contiguous() if fe is not None else None
     guide = guide_embed.contiguous() if guide_embed is not None else None
     nl = image_newline.contiguous() if image_newline is not None else None
+    ll = local_logits.contiguous() if local_logits is not None else None
     graph = bool(getattr(proj, "graph_replay", False)) and not deferred
     res = _resources(dev)
     key = (tuple(ff.shape), None if fe is None else tuple(fe.shape), None if guide is None else tuple(guide.shape), modal,
            None if nl is None else tuple(nl.shape), out_dtype,
            torch.cuda.current_stream(dev).cuda_stream,
-           (ff.data_ptr(), _p(fe), _p(guide), _p(nl)) if graph else None)
+           (ff.data_ptr(), _p(fe), _p(guide), _p(nl), _p(ll)) if graph else None, ll is not None)
     plans = proj.__dict__.setdefault("_engine_plans", {})
     plan = plans.get(key)
     sig = weights_sig(proj)
@@ -276,6 +277,11 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
         hidden = (lc or gc).readout[2].out_features
         probe = torch.empty((n_local + n_global, hidden), dtype=out_dtype, device=dev)
         a = build_args(proj, ff, fe, guide, modal, nl, probe, layout, global_row0=n_local)
+        if ll is not None:
+            a.local_logits = ll.data_ptr()
+            if not nv.compressor_is_fused(a):
+                raise NotImplementedError("local_logits=: this geometry does not run on the fused stream kernel (windows must "
+                                          "partition the grid; see hicom_fused_stream_fwd in include/hicom_hip.h)")
         ws = attach_execution(a, dev, res=res)
         a._keep = None                 # the plan does not pin the caller's tensors: their pointers are patched per call
         sig = weights_sig(proj)        # (build_args may have (re)built the cached positional tables)
@@ -288,6 +294,8 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
     a.ff = ff.data_ptr()
     if fe is not None:
         a.fe = fe.data_ptr()
+    if ll is not None:
+        a.local_logits = ll.data_ptr()
     if guide is not None:
         gp = guide.data_ptr()
         for f in plan.guide_fields:

@@ -15,7 +15,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 # HICOM_NATIVE_LIB: dev override (instrumented builds from tools/); the product loads the in-tree library
 LIB_PATH = os.environ.get("HICOM_NATIVE_LIB") or os.path.join(HERE, "libhicom_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 DT_BF16, DT_F32, DT_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_GELU_TANH = 0, 1, 2
@@ -31,7 +31,7 @@ EXPORTS = (
     "hicom_global_stream_bwd", "hicom_readout16_gemm_fwd", "hicom_to_f16_fwd", "hicom_merge_vproj_fwd",
     "hicom_dense16_gemm_fwd", "hicom_ln_stream_fwd", "hicom_to_f16_padded_fwd", "hicom_clip_query_prep_fwd", "hicom_inv_norm_fwd",
     "hicom_global_stream_clip_fwd", "hicom_splice_rows_fwd", "hicom_splice_labels_fwd",
-    "hicom_query_prep_fwd", "hicom_query_prep_state_bytes",
+    "hicom_query_prep_fwd", "hicom_query_prep_state_bytes", "hicom_partials_sum_fwd",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -128,7 +128,8 @@ def lib() -> C.CDLL:
     L.hicom_splice_labels_fwd.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i64, vp, vp, vp]
     L.hicom_to_f16_padded_fwd.argtypes = [vp, i32, i64, i64, vp, i64, vp]
     L.hicom_dense16_gemm_fwd.argtypes = [vp, i64, vp, i64, i32, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, i32, i64, vp, i64, vp,
-                                         vp, i64, i32, i32, i32, i32, i32, vp]
+                                         vp, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp]
+    L.hicom_partials_sum_fwd.argtypes = [vp, i32, i64, vp, vp]
     L.hicom_clip_query_prep_fwd.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp]
     L.hicom_inv_norm_fwd.argtypes = [vp, i32, i64, vp, vp]
     L.hicom_global_stream_clip_fwd.argtypes = [vp, i64, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64,
@@ -424,8 +425,10 @@ def to_f16_padded(src, ld):
     return dst
 
 
-def dense16_gemm(a, w, b, N=None, K=None, act=ACT_NONE, out_f16=None, n_store=None, y=None, res=None, ssq=None, row_tab=None):
-    """C = epi(A . W^T + b) on matrix cores; a [M, lda], w [N, ldw] both fp16 or both bf16 (see include/hicom_hip.h)."""
+def dense16_gemm(a, w, b, N=None, K=None, act=ACT_NONE, out_f16=None, n_store=None, y=None, res=None, ssq=None, row_tab=None,
+                 row_dot=None):
+    """C = epi(A . W^T + b) on matrix cores; a [M, lda], w [N, ldw] both fp16 or both bf16 (see include/hicom_hip.h).
+    row_dot = (vec [N] bf16 | f32, parts f32 [ceil(N/64), M]): per-slice partials of vec . (value + res) per row."""
     if a.dtype != w.dtype or a.dtype not in (torch.float16, torch.bfloat16):
         raise HicomNativeError("dense16_gemm: operands are both fp16 or both bf16")
     M = a.shape[0]
@@ -437,8 +440,15 @@ def dense16_gemm(a, w, b, N=None, K=None, act=ACT_NONE, out_f16=None, n_store=No
                                         _ptr(y), _dt(y) if y is not None else 0, y.shape[1] if y is not None else 0,
                                         _ptr(res), res.shape[1] if res is not None else 0, _ptr(ssq),
                                         _ptr(row_tab[0]) if row_tab else None, row_tab[0].shape[1] if row_tab else 0,
-                                        *(row_tab[1:] if row_tab else (0, 0, 0, 0, 0)), _stream()),
+                                        *(row_tab[1:] if row_tab else (0, 0, 0, 0, 0)),
+                                        _ptr(row_dot[0]) if row_dot else None, _dt(row_dot[0]) if row_dot else 0,
+                                        _ptr(row_dot[1]) if row_dot else None, _stream()),
            "hicom_dense16_gemm_fwd")
+
+
+def partials_sum(parts, out):
+    n, M = parts.shape
+    _check(lib().hicom_partials_sum_fwd(_ptr(parts), n, M, _ptr(out), _stream()), "hicom_partials_sum_fwd")
 
 
 def clip_query_prep(qp, b_k, nh, scale, c):

@@ -650,8 +650,13 @@ class HIComProjector(nn.Module):
                     return True
         return False
 
-    def forward(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None):
+    def forward(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None, *, local_logits=None):
+        """Reference signature (projector.py:676).  Extension for the producer of frames_embed:
+        `local_logits` = fp32 [T,H,W] raw dot products frames_embed_n . guide from `hicom_amd.siglip_head_scores`, passed with
+        frames_embed=None -- the release recipe then streams frames_feature only (half the bytes)."""
         self._check_clip_logits()
+        if local_logits is not None:
+            return self._forward_with_logits(frames_feature, frames_embed, guide_embed, modal, image_newline, local_logits)
         if self._needs_grad(frames_feature, frames_embed, guide_embed, image_newline):
             # training: an optimizer step lies between two forwards, and DeepSpeed's bf16 optimizer writes the weights
             # through `p.data.copy_` / a flat alias, which no version counter sees -> every weight-derived cache is
@@ -665,6 +670,24 @@ class HIComProjector(nn.Module):
             return engine.run_dense(self, frames_feature, frames_embed, guide_embed, modal, image_newline,
                                     _out_dtype(self))
         return self.forward_stepwise(frames_feature, frames_embed, guide_embed, modal, image_newline)
+
+    def _forward_with_logits(self, frames_feature, frames_embed, guide_embed, modal, image_newline, local_logits):
+        lc = self.local_compressor
+        if frames_embed is not None:
+            raise ValueError("local_logits replaces frames_embed: pass frames_embed=None")
+        if self._needs_grad(frames_feature, guide_embed, image_newline, local_logits):
+            raise RuntimeError("local_logits= is an inference path (no autograd graph): call it under torch.no_grad()")
+        plain = all(c is None or c.is_plain for c in (lc, self.global_compressor))
+        if (lc is None or self.global_compressor is None or lc.use_guide != "direct" or not plain or self.local_logit is not None
+                or self.global_logit is not None or isinstance(frames_feature, dict) or not self.use_executor):
+            raise NotImplementedError("local_logits= is built for the release recipe only (local + global compressor, "
+                                      "use_guide='direct', no adaptors, no clip scale, dense video input)")
+        if (not isinstance(local_logits, torch.Tensor) or local_logits.dtype != torch.float32 or not local_logits.is_cuda
+                or tuple(local_logits.shape) != tuple(frames_feature.shape[:-1])):
+            raise ValueError("local_logits: fp32 device tensor of shape frames_feature.shape[:-1]")
+        from . import engine
+        return engine.run_dense(self, frames_feature, None, guide_embed, modal, image_newline, _out_dtype(self),
+                                local_logits=local_logits)
 
     def forward_deferred(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None):
         """forward() without the final join of the side stream: returns (out, event).  The local rows of `out`

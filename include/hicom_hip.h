@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HICOM_ABI_VERSION 4
+#define HICOM_ABI_VERSION 5
 
 #define HICOM_OK         0
 #define HICOM_EINVAL    -1   /* bad argument (shape, alignment, NULL)        */
@@ -324,6 +324,10 @@ int hicom_merge_vproj_fwd(const float* part_m, const float* part_l, const float*
  *   y [M, ldy] bf16 | f32: value + res[m, n] (res bf16 [M, ldr] or NULL);
  *   ssq f32 [ceil(N/64)][M]: partial row sums of squares of (acc + b) per 64-column slice, summed by the consumer (key norms of the
  *           clip-scale global stage, projector.py:184-186).
+ *   row_dot f32 [ceil(N/64)][M]: partial dot products sum_n dot_vec[n] * (value + res)[m, n] per 64-column slice (dot_vec bf16 | f32
+ *           [N], 16-byte aligned; needs N % 8 == 0 and 16-byte aligned rows).  With the guide embedding as dot_vec on the fc2
+ *           launch of the SigLIP head projection (encoder.py:284-286) the sum over slices IS the local logit frames_embed_n . guide
+ *           of projector.py:551 before scaling: y may then be NULL and frames_embed is never written.
  * row_tab (may be NULL): f32 [*, row_tab_ld] table whose rows tab_t0 + m / (H*W), tab_y0 + (m / W) % H, tab_x0 + m % W are
  *           added to row m before bias / ssq / activation: the projected positional embedding W . pos(m) of token m,
  *           separable per axis (projector.py:57-101 through k_proj), so that x + pos is never formed.
@@ -334,7 +338,11 @@ int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w, int64_t ld
                            void* out_f16, int64_t ldo, int32_t n_store,
                            void* y, int32_t y_dt, int64_t ldy, const void* res, int64_t ldr,
                            float* ssq, const float* row_tab, int64_t row_tab_ld, int32_t tab_H, int32_t tab_W,
-                           int32_t tab_t0, int32_t tab_y0, int32_t tab_x0, void* stream);
+                           int32_t tab_t0, int32_t tab_y0, int32_t tab_x0,
+                           const void* dot_vec, int32_t dot_vec_dt, float* row_dot, void* stream);
+/* out[m] = sum_{s < nparts} parts[s * M + m], in slice order (the row_dot partials of hicom_dense16_gemm_fwd -> the per-token
+ * local logits hicom_fused_stream_fwd / hicom_compressor_args.local_logits take). */
+int hicom_partials_sum_fwd(const float* parts, int32_t nparts, int64_t M, float* out, void* stream);
 
 /* ---- clip-scale on the global stage (projector.py:184-191) ---------------------------------------------------------
  * hicom_clip_query_prep_fwd: qp f32 [nq, E] (q_proj output) is L2-normalised in place over E; c[q*nh + h] =

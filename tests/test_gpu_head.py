@@ -95,3 +95,91 @@ def test_dense16_gemm_matches_torch(M, N, K, dt):
     assert float((o16[:, :N].double() - act).abs().max()) <= 2 ** -11 * scale + 1e-6
     assert float(o16[:, N:].abs().max()) == 0.0 if npad > N else True
     assert float((ssq.sum(0).double() - (ref ** 2).sum(1)).abs().max()) <= 1e-4 * float((ref ** 2).sum(1).max())
+
+
+@pytest.mark.parametrize("vec_dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K,with_y", [(200, 136, 128, True), (1000, 1152, 192, False), (4099, 1152, 128, True)])
+def test_dense16_row_dot_epilogue(M, N, K, with_y, vec_dt):
+    """row_dot partials: sum over the 64-column slices = vec . (A W^T + b + res) per row, in fp32 from the accumulators -- with and
+    without the packed output beside it (y = NULL: nothing but the [N/64, M] partials is written)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.float16).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.float16).cuda()
+    b = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16).cuda()
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    vec = torch.randn(N, generator=g).to(vec_dt).cuda()
+    parts = torch.full(((N + 63) // 64, M), float("nan"), device="cuda")
+    y = torch.empty(M, N, device="cuda") if with_y else None
+    nv.dense16_gemm(a, w, b, y=y, res=res, row_dot=(vec, parts))
+    out = torch.empty(M, device="cuda")
+    nv.partials_sum(parts, out)
+    torch.cuda.synchronize()
+    ref = a.double() @ w.double().t() + b.double() + res.double()
+    want = ref @ vec.double()
+    scale = float((ref.abs() @ vec.double().abs()).max())
+    assert float((out.double() - want).abs().max()) <= 2e-6 * scale
+    assert float((parts.sum(0).double() - want).abs().max()) <= 2e-6 * scale
+    if with_y:
+        assert float((y.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    with pytest.raises(nv.HicomNativeError):
+        nv.dense16_gemm(a, w, b, N=N - 4, y=None, res=None, row_dot=(vec, parts))     # N % 8 != 0: no row-contiguous epilogue
+
+
+def test_head_scores_feed_the_compressor_c2(head):
+    """SURVEY §8 row f2 completed (reference encoder.py:277-286 -> projector.py:542-551, use_guide='direct'): the head projection
+    emits only the per-token logits guide . frames_embed_n, the compressor streams frames_feature alone.  C2 shape (T=64, 27x27,
+    H=896) against the ORACLE CHAIN head (fp32) -> projector_forward (fp32), 1e-3 max-abs; and against the two-tensor path."""
+    from types import SimpleNamespace
+    import cases
+    from gpu_util import build_module, dev_bf16
+    from hicom_amd import siglip_head_embed, siglip_head_scores, synth
+    m_head, head_sd = head
+    T = 64
+    cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "hidden_size": 896, "max_num_frames": T})
+    sd = synth.synth_state_dict(orc.param_shapes(cfg), tag="c2h")
+    m = build_module(SimpleNamespace(cfg=cfg, sd=sd))
+    x = synth.synth_inputs(T, 27, 27, 1152, tag="c2h")
+    hs, guide = dev_bf16(x["ff"]), dev_bf16(x["g"])
+    with torch.no_grad():
+        logits = siglip_head_scores(hs, m_head, guide)
+        out = m(hs, None, guide, "video", None, local_logits=logits)
+        logits2, fe = siglip_head_scores(hs, m_head, guide, return_embed=True)
+        out_two = m(hs, fe, guide, "video", None)
+        fe_plain = siglip_head_embed(hs, m_head)
+    torch.cuda.synchronize()
+    assert logits.shape == (T, 27, 27) and logits.dtype == torch.float32 and torch.equal(logits, logits2)
+    assert torch.equal(fe, fe_plain)
+    fe_ref = orc.siglip_head_embed(hs.float().cpu().view(-1, 1152), head_sd).view(T, 27, 27, 1152)
+    s_ref = (fe_ref.double() @ guide.double().cpu()) / 1152 ** 0.5
+    assert float((logits.double().cpu() / 1152 ** 0.5 - s_ref).abs().max()) <= 1e-3       # the scaled logits the softmax sees
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    want = orc.projector_forward(cfg, sdt, hs.float().cpu(), fe_ref, guide.float().cpu(), "video", None)
+    assert out.shape == want.shape == (T // 4 * 81 + 32, 896)
+    assert float((out.float().cpu() - want).abs().max()) <= 1e-3
+    assert float((out.float() - out_two.float()).abs().max()) <= 1e-3                      # (fe rounded to bf16 on that path)
+    assert torch.equal(out[-32:], out_two[-32:])                                          # the global rows never saw frames_embed
+
+
+def test_local_logits_argument_checks(head):
+    from types import SimpleNamespace
+    import cases
+    from gpu_util import build_module, dev_bf16
+    from hicom_amd import siglip_head_scores
+    m_head, _ = head
+    case = cases.build_case("G1_direct_T8")
+    m = build_module(case)
+    ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+    with torch.no_grad():
+        ll = siglip_head_scores(ff, m_head, g)
+        assert bool(torch.isfinite(m(ff, None, g, "video", None, local_logits=ll)).all())
+        with pytest.raises(ValueError):
+            m(ff, fe, g, "video", None, local_logits=ll)                     # both given
+        with pytest.raises(ValueError):
+            m(ff, None, g, "video", None, local_logits=ll[:4])               # shape
+        with pytest.raises(ValueError):
+            m(ff, None, g, "video", None, local_logits=ll.double())          # dtype
+        with pytest.raises(ValueError):
+            siglip_head_scores(ff, m_head, g.view(1, -1))
+        mc = build_module(cases.build_case("G6_coarse"))
+        with pytest.raises(NotImplementedError):
+            mc(ff, None, g, "video", None, local_logits=ll)                  # not the release recipe
