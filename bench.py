@@ -51,9 +51,11 @@ def make_projector(cfg, device):
     m = hicom_amd.build_vision_projector(cfg)
     with torch.no_grad():
         m.global_compressor.query.normal_(0, 0.02)
-        for p in m.parameters():
+        for name, p in m.named_parameters():
             if p.ndim == 1 and p.numel() > 1:
                 p.normal_(0, 0.02)
+            elif name.endswith("_alpha"):
+                p.fill_(0.5)                         # the reference initialises the blends at 0: numerically dead branches
     return m.to(torch.bfloat16).to(device).eval()
 
 
@@ -551,26 +553,51 @@ def mfma_util_from_profiles():
 
 
 def secondary_sweep(args, device, ff, fe, guide):
-    """SURVEY.md §8(d) secondary sweep: the generic mode (use_guide=None: 32 distinct learnable queries x 9 heads =
-    288 folded rows, where the global QK^T / PV contraction is dense MFMA work), same shapes, plain joined forwards."""
-    cfg = release_config(args.hidden, args.frames_per_gpu)
-    cfg.mm_projector_type, cfg.use_guide = "local43_global32", None
-    m = make_projector(cfg, device)
-    with torch.no_grad():
-        for _ in range(5):
-            out = m(ff, fe, guide, "video", None)
+    """SURVEY.md §8(d) secondary sweep, same shapes, plain joined forwards: the generic mode (use_guide=None: 32 distinct learnable
+    queries x 9 heads = 288 folded rows, where the global QK^T / PV contraction is dense MFMA work) and the §8 f1 recipes (k / v
+    adaptors, coarse and fine injection), with the training step of the recipes the backward covers."""
+    def best_of(fn, n=10, reps=3):
+        for _ in range(3):
+            out = fn()
         dts = []
-        for _ in range(3):                      # best of three batches: a shared box throws the odd 20-ms stall
+        for _ in range(reps):                   # best of three batches: a shared box throws the odd 20-ms stall
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            n = 10
             for _ in range(n):
-                out = m(ff, fe, guide, "video", None)
+                out = fn()
             torch.cuda.synchronize()
             dts.append((time.perf_counter() - t0) / n)
-        dt = min(dts)
-    return {"use_guide=None (32 distinct queries)": {"ms_per_forward": dt * 1e3, "tokens_per_sec": out.shape[0] / dt,
-                                                     "note": "joined forwards, best of 3 batches of 10; two-kernel path (local windows || wide global stream kernel)"}}
+        return min(dts), out
+
+    res = {}
+    gen = torch.Generator(device=device).manual_seed(123)
+    guide_tokens = torch.randn(64, D, device=device, generator=gen).to(torch.bfloat16)       # "fine": the 64 SigLIP text tokens
+    recipes = (("use_guide=None (32 distinct queries)", "local43_global32", None, guide,
+                "two-kernel path (local windows || wide global stream kernel)"),
+               ("local43_adaptkv_global32 (second released recipe)", "local43_adaptkv_global32", "direct", guide,
+                "k / v adaptors over all tokens: 4 dense16 GEMMs + 2 LayerNorm blends in front of the window attention"),
+               ("use_guide=coarse", "local43_global32", "coarse", guide, "FiLM injection of the pooled / learnable queries"),
+               ("use_guide=fine", "local43_global32", "fine", guide_tokens, "64-token cross-attention injection"))
+    for label, ptype, ug, gd, note in recipes:
+        cfg = release_config(args.hidden, args.frames_per_gpu)
+        cfg.mm_projector_type, cfg.use_guide = ptype, ug
+        m = make_projector(cfg, device)
+        with torch.no_grad():
+            dt, out = best_of(lambda: m(ff, fe, gd, "video", None))
+        res[label] = {"ms_per_forward": dt * 1e3, "tokens_per_sec": out.shape[0] / dt, "note": "joined forwards, best of 3 batches of 10; " + note}
+        if ug in ("direct", "coarse"):
+            # f4: one training step of this recipe (forward under autograd + recompute-based backward, hicom_amd/autograd.py)
+            m.train()
+            cot = torch.randn(out.shape, device=device, generator=gen).to(out.dtype)
+
+            def train_step():
+                o = m(ff, fe, gd, "video", None)
+                o.backward(cot)
+                return o
+            dt_t, _ = best_of(train_step, n=3)
+            res[label]["train_step_ms"] = dt_t * 1e3
+        del m
+    return res
 
 
 def dominant_kernel_roofline(module, sets, iters):

@@ -37,11 +37,115 @@ def _gelu_grad(x):
 
 
 def _supported(proj) -> bool:
+    """direct / off / coarse injection, k / v adaptors; not: fine injection, adapt_q, adapt_guide, text2qk projections, clip-scale."""
+    from .projector import _plain_injector
     lc, gc = proj.local_compressor, proj.global_compressor
     for c in (lc, gc):
-        if c is not None and not (c.is_plain and c.use_guide in ("direct", None, "off")):
+        if c is None:
+            continue
+        if c.use_guide not in ("direct", None, "off", "coarse") or not _plain_injector(c.guide_injector) or c.adapt_guide:
             return False
+    if lc is not None and lc.adapt_q:
+        return False
     return proj.local_logit is None and proj.global_logit is None
+
+
+def _is_plain(proj) -> bool:
+    return all(c is None or c.is_plain for c in (proj.local_compressor, proj.global_compressor))
+
+
+def _ln_backward(g, xhat, rstd):
+    """d input of y = xhat (row-normalised) given g = d y: rstd (g - mean g - xhat mean(g xhat))."""
+    return rstd * (g - g.mean(-1, keepdim=True) - xhat * (g * xhat).mean(-1, keepdim=True))
+
+
+def _ln_stats(x, eps):
+    mu = x.mean(-1, keepdim=True)
+    rstd = torch.rsqrt(x.var(-1, unbiased=False, keepdim=True) + eps)
+    return (x - mu) * rstd, rstd
+
+
+class _AdaptorTape:
+    """(1 - a) x + a LN(MLP(x)) over all tokens (adapt_k / adapt_v, reference projector.py:533-534) recomputed in fp32 with its
+    intermediates, and its backward: library GEMMs on [N, D] fp32 tensors (dW = dY^T X, dX = dY W)."""
+
+    def __init__(self, x, mlp, norm, alpha):
+        self.mlp, self.norm, self.alpha = mlp, norm, alpha.detach().float()
+        self.x = x.reshape(-1, x.shape[-1]).float()
+        self.W1, self.W2 = mlp[0].weight.detach().float(), mlp[2].weight.detach().float()
+        self.h1 = torch.addmm(mlp[0].bias.detach().float(), self.x, self.W1.t())
+        self.a = torch.nn.functional.gelu(self.h1)
+        h2 = torch.addmm(mlp[2].bias.detach().float(), self.a, self.W2.t())
+        self.nhat, self.rstd = _ln_stats(h2, norm.eps)
+        self.gamma = norm.weight.detach().float()
+        self.n = self.nhat * self.gamma + norm.bias.detach().float()
+        self.out = (1.0 - self.alpha) * self.x + self.alpha * self.n
+
+    def backward(self, d_out, prefix, which, grads, want_x):
+        """prefix 'local_compressor.', which 'k' | 'v'; returns d x (fp32 [N, D]) when want_x."""
+        grads[f"{prefix}{which}_alpha"] = (d_out * (self.n - self.x)).sum().reshape(1)
+        dn = self.alpha * d_out
+        grads[f"{prefix}{which}_norm.weight"] = (dn * self.nhat).sum(0)
+        grads[f"{prefix}{which}_norm.bias"] = dn.sum(0)
+        dh2 = _ln_backward(dn * self.gamma, self.nhat, self.rstd)
+        grads[f"{prefix}{which}_proj.2.weight"] = dh2.t() @ self.a
+        grads[f"{prefix}{which}_proj.2.bias"] = dh2.sum(0)
+        dh1 = (dh2 @ self.W2) * _gelu_grad(self.h1)
+        grads[f"{prefix}{which}_proj.0.weight"] = dh1.t() @ self.x
+        grads[f"{prefix}{which}_proj.0.bias"] = dh1.sum(0)
+        return (1.0 - self.alpha) * d_out + dh1 @ self.W1 if want_x else None
+
+
+def _coarse_backward(inj, prefix, vis, guide, dq, grads):
+    """Backward of the FiLM injection q = LN(vis (1 + scale) + shift), (scale | shift) = coarse_proj(guide) (reference
+    projector.py:369-372) for vis fp32 [M, D], guide [D]: fills the injector's parameter gradients, returns (d vis, d guide)."""
+    D = vis.shape[-1]
+    g = guide.reshape(-1).float()
+    W1, b1 = inj.coarse_proj[0].weight.detach().float(), inj.coarse_proj[0].bias.detach().float()
+    W2, b2 = inj.coarse_proj[2].weight.detach().float(), inj.coarse_proj[2].bias.detach().float()
+    h1 = W1 @ g + b1
+    a = torch.nn.functional.gelu(h1)
+    cs = W2 @ a + b2
+    sc, sh = cs[:D], cs[D:]
+    zhat, rstd = _ln_stats(vis * (1.0 + sc) + sh, inj.coarse_norm.eps)
+    grads[prefix + "coarse_norm.weight"] = (dq * zhat).sum(0)
+    grads[prefix + "coarse_norm.bias"] = dq.sum(0)
+    dz = _ln_backward(dq * inj.coarse_norm.weight.detach().float(), zhat, rstd)
+    dcs = torch.cat([(dz * vis).sum(0), dz.sum(0)])
+    grads[prefix + "coarse_proj.2.weight"] = torch.outer(dcs, a)
+    grads[prefix + "coarse_proj.2.bias"] = dcs
+    dh1 = (W2.t() @ dcs) * _gelu_grad(h1)
+    grads[prefix + "coarse_proj.0.weight"] = torch.outer(dh1, g)
+    grads[prefix + "coarse_proj.0.bias"] = dh1
+    return dz * (1.0 + sc), W1.t() @ dh1
+
+
+def _to_windows(x, at, ay, ax):
+    """[T, H, W, D] -> [Nw, kt ks ks, D] in the reference's window / in-window order (projector.py:473-499), exact partition."""
+    D = x.shape[-1]
+    return (x.reshape(at.nwin, at.k, ay.nwin, ay.k, ax.nwin, ax.k, D).permute(0, 2, 4, 1, 3, 5, 6)
+            .reshape(at.nwin * ay.nwin * ax.nwin, at.k * ay.k * ax.k, D))
+
+
+def _from_windows(xw, at, ay, ax):
+    D = xw.shape[-1]
+    return (xw.reshape(at.nwin, ay.nwin, ax.nwin, at.k, ay.k, ax.k, D).permute(0, 3, 1, 4, 2, 5, 6)
+            .reshape(at.n * ay.n * ax.n, D))
+
+
+def _window_attention_backward(K, V, q, scale, dctx, tilings, want_k, want_v):
+    """Autograd through reference projector.py:550-553 on fp32 streams K, V [T,H,W,D] (adaptor outputs): q [D] shared or
+    [Nw, D]; returns (dq [Nw, D], dK [N, D] | None, dV [N, D] | None)."""
+    at, ay, ax = tilings
+    Kw, Vw = _to_windows(K, at, ay, ax), _to_windows(V, at, ay, ax)
+    qw = q.reshape(1, -1).expand(Kw.shape[0], -1) if q.ndim == 1 or q.shape[0] == 1 else q
+    p = torch.softmax(torch.einsum("wnd,wd->wn", Kw, qw) * scale, dim=-1)
+    dP = torch.einsum("wnd,wd->wn", Vw, dctx)
+    ds = p * (dP - (p * dP).sum(-1, keepdim=True)) * scale
+    dq = torch.einsum("wn,wnd->wd", ds, Kw)
+    dK = _from_windows(ds.unsqueeze(-1) * qw.unsqueeze(1), at, ay, ax) if want_k else None
+    dV = _from_windows(p.unsqueeze(-1) * dctx.unsqueeze(1), at, ay, ax) if want_v else None
+    return dq, dK, dV
 
 
 class _CompressorFn(torch.autograd.Function):
@@ -50,7 +154,10 @@ class _CompressorFn(torch.autograd.Function):
         from . import engine
         from .projector import _out_dtype
         with torch.no_grad():
-            out = engine.run_dense(proj, ff, fe, guide, modal, nl, _out_dtype(proj))
+            if _is_plain(proj):
+                out = engine.run_dense(proj, ff, fe, guide, modal, nl, _out_dtype(proj))
+            else:                                                      # adaptors / coarse injection: operator by operator
+                out = proj.forward_stepwise(ff, fe, guide, modal, nl)
         ctx.proj, ctx.modal, ctx.names = proj, modal, names
         ctx.save_for_backward(ff, fe, guide, nl)
         return out
@@ -86,10 +193,9 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
     dev = ff.device
     d_fe = d_guide = None
     if want_fe or want_guide:
-        for c in (lc, gc):
-            if c is not None and c.use_guide != "direct":
-                raise NotImplementedError("hicom_amd backward: gradients w.r.t. frames_embed / guide_embed are built for "
-                                          "use_guide='direct' only (stage 3 of the reference's script)")
+        if not any(c is not None and c.use_guide in ("direct", "coarse") for c in (lc, gc)):
+            raise NotImplementedError("hicom_amd backward: gradients w.r.t. frames_embed / guide_embed are built for "
+                                      "use_guide='direct' and 'coarse' (stage 3 of the reference's script)")
         if want_guide:
             d_guide = torch.zeros(guide.numel(), dtype=torch.float32, device=dev)
         if want_fe and lc is None:
@@ -120,20 +226,53 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         dpre = (dY @ W2) * _gelu_grad(pre)
         grads["local_compressor.readout.0.weight"] = dpre.t() @ ctx_l
         grads["local_compressor.readout.0.bias"] = dpre.sum(0)
-        if want_fe or want_guide:
-            # ---- attention backward of the windows (HIP): dq per window and d frames_embed ---------------------
-            if want_fe and any(a.nwin * a.k != a.n for a in (at, ay, ax)):
-                raise NotImplementedError("hicom_amd backward: d frames_embed needs an exact window partition "
-                                          f"(T, H, W = {T}, {H}, {W} against kernel {at.k}, {ay.k}, {ax.k})")
+        mode = lc.use_guide if lc.use_guide not in (None, "off") else None
+        adapt = lc.adapt_k or lc.adapt_v
+        if want_fe or adapt or mode == "coarse" or (want_guide and mode == "direct"):
+            # ---- attention backward of the windows: dq per window, d key stream, d value stream -------------------------
+            exact = all(a.nwin * a.k == a.n for a in (at, ay, ax))
+            if (want_fe or adapt) and not exact:
+                raise NotImplementedError("hicom_amd backward: d frames_embed / the adaptor gradients need an exact window "
+                                          f"partition (T, H, W = {T}, {H}, {W} against kernel {at.k}, {ay.k}, {ax.k})")
             axes = tuple(nv.Axis(a.n, a.k, a.nwin, a.nfull) for a in (at, ay, ax))
             dctx_l = (dpre @ W0).contiguous()
-            dq_w = torch.empty((nw, E), dtype=torch.float32, device=dev)
-            if want_fe:
-                d_fe = torch.empty_like(fe)
+            scale = 1.0 / math.sqrt(lc.qk_dim)
             key = fe if fe is not None else ff
-            nv.local_attn_bwd(key, ff, axes, guide.reshape(-1).contiguous(), 0, 1.0 / math.sqrt(lc.qk_dim), 0.0, dctx_l, dq_w, d_fe)
-            if want_guide:
+            pooled = None
+            if mode == "direct":
+                q = guide.reshape(-1).contiguous()
+            else:
+                pooled = torch.empty((*grid, E), dtype=torch.float32, device=dev)
+                nv.trilinear_pool(ff, pooled)                              # HIP: the per-window query (ref :539-540)
+                pooled = pooled.view(nw, E)
+                q = pooled
+                if mode == "coarse":
+                    from . import injector as inj
+                    q, _ = inj.inject(lc.guide_injector, "coarse", pooled, guide.contiguous())    # HIP: LN(q (1 + scale) + shift)
+            if adapt:
+                tape_k = _AdaptorTape(key, lc.k_proj, lc.k_norm, lc.k_alpha) if lc.adapt_k else None
+                tape_v = _AdaptorTape(ff, lc.v_proj, lc.v_norm, lc.v_alpha) if lc.adapt_v else None
+                K = (tape_k.out if tape_k else key.float()).view(T, H, W, E)
+                V = (tape_v.out if tape_v else ff.float()).view(T, H, W, E)
+                dq_w, dK, dV = _window_attention_backward(K, V, q.float(), scale, dctx_l, (at, ay, ax),
+                                                          want_fe or lc.adapt_k, lc.adapt_v)
+                if tape_v:
+                    tape_v.backward(dV, "local_compressor.", "v", grads, False)
+                if tape_k:
+                    dK = tape_k.backward(dK, "local_compressor.", "k", grads, want_fe and fe is not None)
+                if want_fe and fe is not None:
+                    d_fe = dK.to(fe.dtype).view(fe.shape)
+            else:
+                dq_w = torch.empty((nw, E), dtype=torch.float32, device=dev)
+                if want_fe and fe is not None:
+                    d_fe = torch.empty_like(fe)
+                nv.local_attn_bwd(key, ff, axes, q, 0 if mode == "direct" else E, scale, 0.0, dctx_l, dq_w, d_fe)
+            if mode == "direct" and want_guide:
                 d_guide += dq_w.sum(0)
+            elif mode == "coarse":
+                _, dg = _coarse_backward(lc.guide_injector, "local_compressor.guide_injector.", pooled, guide, dq_w, grads)
+                if want_guide:
+                    d_guide += dg
     if gc is not None:
         att = gc.attn_layer
         nh, hd = att.num_heads, att.head_dim
@@ -204,6 +343,12 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         grads[P + "attn_layer.q_proj.bias"] = dqp.sum(0)
         if gc.use_guide in (None, "off"):
             grads[P + "query"] = dqp @ Wq + dpre                           # the learnable queries: through q_proj and the residual
+        elif gc.use_guide == "coarse":                                     # injected = LN(query (1 + scale) + shift) (:369-372)
+            dvis, dg = _coarse_backward(gc.guide_injector, P + "guide_injector.", gc.query.detach().float(), guide,
+                                        dqp @ Wq + dpre, grads)
+            grads[P + "query"] = dvis
+            if want_guide:
+                d_guide += dg
         elif want_guide:
             d_guide += (dqp @ Wq + dpre).sum(0)                            # direct: the injected query IS the guide (:352-368)
         # (direct: global_compressor.query does not enter the forward, ref :352-368 uses only its shape: no gradient)
@@ -215,9 +360,10 @@ def forward_with_grad(proj, frames_feature, frames_embed, guide_embed, modal, im
     some = frames_feature["patch"] if isinstance(frames_feature, dict) else frames_feature
     _require_bf16_cuda("frames_feature", some)
     if isinstance(frames_feature, dict) or not _supported(proj):
-        raise NotImplementedError("hicom_amd: the backward pass covers use_guide='direct' and guide off without adaptors or "
-                                  "clip-scale, dense inputs; run other recipes under torch.no_grad() / inference_mode() -- "
-                                  "forward() never returns a silently detached tensor")
+        raise NotImplementedError("hicom_amd: the backward pass covers use_guide='direct' / 'coarse' / off with or without the "
+                                  "k / v adaptors, dense inputs, no clip-scale; run other recipes (fine injection, adapt_q, "
+                                  "adapt_guide) under torch.no_grad() / inference_mode() -- forward() never returns a "
+                                  "silently detached tensor")
     names, params = zip(*[(n, p) for n, p in proj.named_parameters()])
     ff = frames_feature.contiguous()
     fe = frames_embed.contiguous() if frames_embed is not None else None

@@ -31,7 +31,8 @@ def _grad_cases():
 
 @pytest.mark.parametrize("name", ["G1_direct_T8", "G4b_image_newline", "G9_grid", "G9_frame", "G10_peaky_direct", "G9_local_only",
                                   "G9_global_only", "G3_direct_T7", "G2_off_T8", "G2b_off_string", "G10b_peaky_off",
-                                  "G12_clip768_direct", "G12b_clip768_off", "G9_local22"])
+                                  "G12_clip768_direct", "G12b_clip768_off", "G9_local22",
+                                  "G5_adaptkv", "G6_coarse", "G7b_guide_override"])
 def test_parameter_gradients_match_reference_autograd(name, golden_grad):
     import make_golden_grad as mg
     from hicom_amd import autograd as hag
@@ -85,10 +86,10 @@ def test_parameter_gradients_match_reference_autograd(name, golden_grad):
 
 
 def test_unsupported_recipes_and_input_grads_refuse():
-    """coarse / fine / adaptors have no backward yet; the gradient w.r.t. frames_feature (frozen tower body) is not built, nor
-    are input gradients of the guide-off recipe or d frames_embed over overlapping windows: all must raise, never return a
+    """fine injection / adapt_q / adapt_guide have no backward; the gradient w.r.t. frames_feature (frozen tower body) is not built,
+    nor are input gradients of the guide-off recipe or d frames_embed over overlapping windows: all must raise, never return a
     detached tensor or a silent None."""
-    for name in ("G6_coarse", "G5_adaptkv"):
+    for name in ("G7_fine", "G5b_adaptqkvg_off"):
         case = cases.build_case(name)
         m = build_module(case).train()
         ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
@@ -163,3 +164,41 @@ def test_backward_at_benchmark_size():
         assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max())
     assert float(gr["global_compressor.attn_layer.k_proj.bias"].abs().max()) == 0.0
     assert float(gr["global_compressor.attn_layer.q_proj.weight"].abs().max()) > 0.0
+
+
+def test_adaptor_gradients_at_27x27_by_finite_differences():
+    """Second released recipe (local43_adaptkv_global32) on the real 27x27 grid, T=16, H=896: d loss / d k_alpha and d v_alpha from
+    the backward against central finite differences of the inference forward (fp32 result) -- a size-independent check of the
+    whole adaptor chain (window softmax -> blend -> LayerNorm -> MLP) beyond the 6x6 fixture."""
+    from types import SimpleNamespace
+    from hicom_amd import autograd as hag
+    from hicom_amd import synth
+    from oracle import hicom_oracle as orc
+    T = 16
+    cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "hidden_size": 896, "max_num_frames": T, "mm_projector_type": "local43_adaptkv_global32"})
+    sd = synth.synth_state_dict(orc.param_shapes(cfg), tag="adaptkv27")
+    x = synth.synth_inputs(T, 27, 27, 1152, tag="adaptkv27")
+    m = build_module(SimpleNamespace(cfg=cfg, sd=sd)).train()
+    ff, fe, g = dev_bf16(x["ff"]), dev_bf16(x["fe"]), dev_bf16(x["g"])
+    out = m(ff, fe, g, "video", None)
+    R = torch.randn(out.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))
+    (out.float() * R).sum().backward()
+    fp32 = dict(hag.LAST_FP32_GRADS)
+    lc = m.local_compressor
+    m.return_fp32 = True
+    for which in ("k", "v"):
+        p = getattr(lc, which + "_alpha")
+        a0 = float(p.detach().float())
+        eps = 1.0 / 16                                                         # bf16-exact steps around alpha = 0.5
+        vals = []
+        for a in (a0 + eps, a0 - eps):
+            with torch.no_grad():
+                p.data.fill_(a)
+                from hicom_amd import invalidate_weight_caches
+                invalidate_weight_caches()
+                vals.append(float((m(ff, fe, g, "video", None).double() * R.double()).sum()))
+        with torch.no_grad():
+            p.data.fill_(a0)
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        got = float(fp32[f"local_compressor.{which}_alpha"])
+        assert abs(got - fd) <= 0.05 * abs(fd) + 1e-3, (which, got, fd)
