@@ -64,9 +64,10 @@ struct DenseParams {
 };
 
 __device__ __forceinline__ float gelu_tanh(float x) {
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    const float e = __builtin_amdgcn_exp2f(u * 2.8853900817779268f);        // e^(2u)
-    return 0.5f * x * (2.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e));      // 0.5 x (1 + tanh u)
+    // 0.5 x (1 + tanh u) = x / (1 + e^(-2u)),  u = 0.79788456 (x + 0.044715 x^3):  -2u log2(e) = x (c0 + c1 x^2)
+    const float t = x * x;
+    const float arg = x * fmaf(t, -0.10294324f, -2.3022082f);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(arg));
 }
 
 // Epilogue of one wave's [16 MI rows] x [16 NJ columns] block at (mw, nw): the lane holds columns n .. n+3 (n = nw + 16 j + 4 kg)
@@ -513,10 +514,10 @@ extern "C" int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w,
                       "dense16_gemm: the row-dot output needs the row-contiguous epilogue (N %% 8, 16-byte aligned rows) and a bf16 | f32 vector");
     p.dotv = dot_vec; p.dotv_f32 = dot_vec_dt == HICOM_DT_F32; p.rdot = row_dot;
     hipStream_t st = (hipStream_t)stream;
+    const bool bf = operand_dt == HICOM_DT_BF16;
     p.tiles_m = (M + 127) / 128; p.tiles_n = (N + 127) / 128;
     constexpr int smem = (128 + 128) * 128;
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
-    const bool bf = operand_dt == HICOM_DT_BF16;
     if (bf && rows) hipLaunchKernelGGL((dense16_gemm_kernel<true, true>), grid, dim3(256), smem, st, p);
     else if (bf) hipLaunchKernelGGL((dense16_gemm_kernel<true, false>), grid, dim3(256), smem, st, p);
     else if (rows) hipLaunchKernelGGL((dense16_gemm_kernel<false, true>), grid, dim3(256), smem, st, p);

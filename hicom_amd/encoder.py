@@ -33,9 +33,13 @@ def _head_cache(head):
     hit = head.__dict__.get("_hicom_f16")
     if hit is None or hit[0] != stamp:
         kpad = (fc2.weight.shape[1] + 63) // 64 * 64
-        hit = (stamp, nv.f16_weight_copy(fc1.weight), nv.f16_weight_copy(fc2.weight, kpad), kpad)
+        # row pitch of the hidden activations and of fc2's weight copy: K + 192 elements.  At a pitch of 4 352 elements (68 lines of
+        # 128 B) the 128 rows of an operand tile fall on a quarter of the L2 channels at every K step: 780 -> 915 TFLOP/s on
+        # fc2 with the padded pitch (tools/dense_ld.py); K = 1 152 shows no such effect
+        ld = kpad + (192 if kpad > 2048 else 0)
+        hit = (stamp, nv.f16_weight_copy(fc1.weight), nv.f16_weight_copy(fc2.weight, ld), kpad, ld)
         head.__dict__["_hicom_f16"] = hit
-    return hit[1], hit[2], hit[3]
+    return hit[1], hit[2], hit[3], hit[4]
 
 
 def siglip_head_embed(last_hidden_state: torch.Tensor, head, hidden_act: str = None, out_dtype=None) -> torch.Tensor:
@@ -74,10 +78,10 @@ def _head_chain(last_hidden_state, head, hidden_act, out_dtype, guide, want_embe
     D = x.shape[-1]
     x2 = x.contiguous().view(-1, D)
     M = x2.shape[0]
-    w1, w2, kpad = _head_cache(head)
+    w1, w2, kpad, ld = _head_cache(head)
     a16 = torch.empty((M, D), dtype=torch.float16, device=x.device)
     nv.ln_stream(x2, ln.weight.detach(), ln.bias.detach(), a16, eps=ln.eps)
-    hid = torch.empty((M, kpad), dtype=torch.float16, device=x.device)
+    hid = torch.empty((M, ld), dtype=torch.float16, device=x.device)
     nv.dense16_gemm(a16, w1, fc1.bias.detach(), act=_ACTS[hidden_act], out_f16=hid, n_store=kpad)
     out = torch.empty((M, D), dtype=out_dtype or x.dtype, device=x.device) if want_embed else None
     parts = torch.empty(((D + 63) // 64, M), dtype=torch.float32, device=x.device) if guide is not None else None
