@@ -448,6 +448,7 @@ def neighbours_sweep(args, device):
     def train_step(inputs_too):
         nonlocal cot
         fe_, g_ = (fe.detach().requires_grad_(True), g.detach().requires_grad_(True)) if inputs_too else (fe, g)
+        m.zero_grad(set_to_none=True)                  # as every training loop does (torch's default since 2.0)
         o = m(ff, fe_, g_, "video", None)
         if cot is None:
             cot = torch.randn(o.shape, device=device, generator=gen).to(o.dtype)
@@ -591,6 +592,7 @@ def secondary_sweep(args, device, ff, fe, guide):
             cot = torch.randn(out.shape, device=device, generator=gen).to(out.dtype)
 
             def train_step():
+                m.zero_grad(set_to_none=True)
                 o = m(ff, fe, gd, "video", None)
                 o.backward(cot)
                 return o

@@ -50,6 +50,18 @@ def _supported(proj) -> bool:
     return proj.local_logit is None and proj.global_logit is None
 
 
+def _f32_params(proj):
+    """{name: fp32 copy} of every projector parameter through ONE concatenation + ONE cast (two launches instead of one per
+    tensor: the backward is launch-bound, a step changes every weight, so per-tensor cached casts would be rebuilt every step)."""
+    items = list(proj.named_parameters())
+    flat = torch.cat([p.detach().reshape(-1) for _, p in items]).float()
+    out, o = {}, 0
+    for n, p in items:
+        out[n] = flat[o:o + p.numel()].view(p.shape)
+        o += p.numel()
+    return out
+
+
 def _is_plain(proj) -> bool:
     return all(c is None or c.is_plain for c in (proj.local_compressor, proj.global_compressor))
 
@@ -177,10 +189,19 @@ class _CompressorFn(torch.autograd.Function):
         if d_guide is not None:
             LAST_FP32_GRADS["__guide_embed__"] = d_guide
         plist = dict(ctx.proj.named_parameters())
-        out = []
-        for k, name in enumerate(ctx.names):
-            g = grads.get(name) if need[7 + k] else None
-            out.append(None if g is None else g.to(plist[name].dtype).reshape(plist[name].shape))
+        # the parameter gradients leave as views of ONE buffer cast once (one concatenation + one cast instead of a cast per tensor)
+        wanted = [(k, name) for k, name in enumerate(ctx.names) if need[7 + k] and grads.get(name) is not None]
+        out = [None] * len(ctx.names)
+        by_dtype = {}
+        for k, name in wanted:
+            by_dtype.setdefault(plist[name].dtype, []).append((k, name))
+        for dt, group in by_dtype.items():
+            flat = torch.cat([grads[name].reshape(-1) for _, name in group]).to(dt)
+            o = 0
+            for k, name in group:
+                n = plist[name].numel()
+                out[k] = flat[o:o + n].view(plist[name].shape)
+                o += n
         return (None, None, d_fe, (d_guide.to(guide.dtype).reshape(guide.shape) if d_guide is not None else None), None,
                 (d_nl.to(nl.dtype) if (nl is not None and need[5] and d_nl is not None) else None), None, *out)
 
@@ -201,6 +222,7 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         if want_fe and lc is None:
             want_fe = False            # without a local stage frames_embed does not enter the forward: no gradient (None), as in the reference
     dout = dout.float()
+    f32 = _f32_params(proj)
     T, H, W, E = ff.shape
     grads = {}
     d_nl = None
@@ -217,8 +239,8 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         if lay.newline_rows:
             d_nl = dout[torch.tensor(lay.newline_rows, device=dev)].sum(0)
         ctx_l, _ = lc.window_context(ff, fe, guide, modal, None, None)     # HIP: [Nw, E] fp32 window contexts
-        W0, b0 = lc.readout[0].weight.float(), lc.readout[0].bias.float()
-        W2 = lc.readout[2].weight.float()
+        W0, b0 = f32["local_compressor.readout.0.weight"], f32["local_compressor.readout.0.bias"]
+        W2 = f32["local_compressor.readout.2.weight"]
         pre = torch.addmm(b0, ctx_l, W0.t())
         h = torch.nn.functional.gelu(pre)
         grads["local_compressor.readout.2.weight"] = dY.t() @ h
@@ -284,12 +306,13 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         R = ml.shape[0]
         ctxg = (acc / ml[:, 1:2]).view(nq, nh, E)                          # per-(query, head) contexts
         q32 = q_in.float()
-        Wq, bq = att.q_proj.weight.float(), att.q_proj.bias.float()
-        Wk = att.k_proj.weight.float()
-        Wv, bv = att.v_proj.weight.float(), att.v_proj.bias.float()
-        Wo, bo = att.out_proj.weight.float(), att.out_proj.bias.float()
-        G0, gb0 = gc.readout[0].weight.float(), gc.readout[0].bias.float()
-        G2 = gc.readout[2].weight.float()
+        A = "global_compressor.attn_layer."
+        Wq, bq = f32[A + "q_proj.weight"], f32[A + "q_proj.bias"]
+        Wk = f32[A + "k_proj.weight"]
+        Wv, bv = f32[A + "v_proj.weight"], f32[A + "v_proj.bias"]
+        Wo, bo = f32[A + "out_proj.weight"], f32[A + "out_proj.bias"]
+        G0, gb0 = f32["global_compressor.readout.0.weight"], f32["global_compressor.readout.0.bias"]
+        G2 = f32["global_compressor.readout.2.weight"]
         o = torch.einsum("hje,qhe->qhj", Wv.view(nh, hd, E), ctxg).reshape(nq, E) + bv    # ref :182,:215 after folding
         pre = o @ Wo.t() + bo + q32                                        # out_proj + residual with the injected query (:646)
         a1 = pre @ G0.t() + gb0

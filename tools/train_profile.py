@@ -15,6 +15,7 @@ cot = None
 
 def step():
     global cot
+    m.zero_grad(set_to_none=True)
     o = m(ff, fe, g, "video", None)
     if cot is None:
         cot = torch.randn(o.shape, device=dev, generator=gen).to(o.dtype)
