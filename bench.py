@@ -385,6 +385,25 @@ def neighbours_sweep(args, device):
         out["siglip_head_projection"] = {"ms": dt * 1e3, "tflops": flops / dt / 1e12, "frac_of_dense_fp16_peak": flops / dt / 2.5e15,
                                          "workload": f"{x.shape[0]}x729 tokens, LayerNorm + 1152->4304->1152 MLP + residual (encoder.py:284-286)",
                                          "kernels": "ln_stream + 2 x dense16_gemm (fp16 operands, fp32 accumulate)"}
+        # stage 3 of the reference's script trains the head (train.py:717-720): forward under autograd + backward of the projection
+        head.train()
+        for p_ in head.parameters():
+            p_.requires_grad_(True)
+        cot_h = torch.randn(x.shape, device=device, generator=gen).to(torch.bfloat16)
+
+        def head_train_step():
+            for p_ in head.parameters():
+                p_.grad = None
+            with torch.enable_grad():
+                siglip_head_embed(x, head).backward(cot_h)
+
+        head_train_step()
+        dt_h, _ = best(head_train_step, n=3)
+        out["siglip_head_projection"]["train_step_ms"] = dt_h * 1e3
+        for p_ in head.parameters():
+            p_.requires_grad_(False)
+            p_.grad = None
+        head.eval()
         # f2 completed: head projection + compressor as ONE segment at the benchmark shape.  two_tensor: the head writes
         # frames_embed (bf16) and the compressor streams both visual tensors; logits: the fc2 launch dots its rows with the guide
         # (siglip_head_scores) and the compressor streams frames_feature only.

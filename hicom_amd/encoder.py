@@ -43,8 +43,106 @@ def _head_cache(head):
 
 
 def siglip_head_embed(last_hidden_state: torch.Tensor, head, hidden_act: str = None, out_dtype=None) -> torch.Tensor:
-    """[..., D] bf16 tokens -> x + head.mlp(head.layernorm(x)), same shape (bf16; out_dtype=torch.float32 for parity tests)."""
+    """[..., D] bf16 tokens -> x + head.mlp(head.layernorm(x)), same shape (bf16; out_dtype=torch.float32 for parity tests).
+    With autograd on and trainable head parameters (stage 3 of the reference's script trains "vision_model_head", train.py:717-720)
+    the result carries a graph: gradients of layernorm / fc1 / fc2 (`_HeadFn`); the tokens come from the frozen tower body
+    (train.py:703): asking for THEIR gradient raises."""
+    if torch.is_grad_enabled() and (last_hidden_state.requires_grad or any(p.requires_grad for p in _head_params(head))):
+        if out_dtype not in (None, last_hidden_state.dtype):
+            raise NotImplementedError("siglip_head_embed: out_dtype with autograd")
+        return _HeadFn.apply(last_hidden_state, head, hidden_act, *_head_params(head))
     return _head_chain(last_hidden_state, head, hidden_act, out_dtype, None, True)[0]
+
+
+def _head_params(head):
+    return (head.layernorm.weight, head.layernorm.bias, head.mlp.fc1.weight, head.mlp.fc1.bias, head.mlp.fc2.weight, head.mlp.fc2.bias)
+
+
+LAST_FP32_GRADS = None      # test hook: the fp32 gradients of the last head backward (before the cast to the parameter dtype)
+
+
+class _HeadFn(torch.autograd.Function):
+    """Forward = the inference chain (same kernels, same bits).  Backward is recompute-based (the reference's scripts run with
+    gradient checkpointing): LayerNorm output and the pre-activation hidden layer come back from the HIP forward kernels
+    (hicom_ln_stream_fwd, hicom_dense16_gemm_fwd without activation); d hidden = dY . W2 runs on the dense16 kernel as well (NT
+    form); the two weight gradients dW = dY^T X contract over the TOKEN axis -- the TN form, which dense16.hip does not have -- and
+    go through the vendor GEMM ("plain library GEMMs", bf16 operands, fp32 accumulation)."""
+
+    @staticmethod
+    def forward(ctx, x, head, hidden_act, *params):
+        with torch.no_grad():
+            out = _head_chain(x, head, hidden_act, None, None, True)[0]
+        ctx.head, ctx.hidden_act = head, hidden_act
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        global LAST_FP32_GRADS
+        (x,) = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("siglip_head_embed backward: the gradient w.r.t. the tower's hidden states is not built (the "
+                                      "tower body is frozen in every stage of the reference's script, train.py:703); detach them")
+        head = ctx.head
+        ln, fc1, fc2 = head.layernorm, head.mlp.fc1, head.mlp.fc2
+        hidden_act = ctx.hidden_act or getattr(getattr(head.mlp, "config", None), "hidden_act", "gelu_pytorch_tanh")
+        with torch.no_grad():
+            D = x.shape[-1]
+            x2 = x.contiguous().view(-1, D)
+            M = x2.shape[0]
+            w1, w2, kpad, ld = _head_cache(head)
+            inter = fc1.weight.shape[0]
+            dY = d_out.contiguous().view(M, D)
+            # ---- recompute (HIP): normalised tokens, pre-activation hidden layer ------------------------------------------
+            n16 = torch.empty((M, D), dtype=torch.float16, device=x.device)
+            nv.ln_stream(x2, ln.weight.detach(), ln.bias.detach(), n16, eps=ln.eps)
+            h1 = torch.empty((M, ld), dtype=torch.float16, device=x.device)
+            nv.dense16_gemm(n16, w1, fc1.bias.detach(), act=nv.ACT_NONE, out_f16=h1, n_store=kpad)
+            h1 = h1[:, :inter].float()
+            a = torch.nn.functional.gelu(h1, approximate="tanh" if hidden_act == "gelu_pytorch_tanh" else "none")
+            # ---- fc2: dW2 = dY^T a, db2, d a = dY W2 --------------------------------------------------------------------------
+            dYb = dY.to(torch.bfloat16)
+            grads = {}
+            grads["mlp.fc2.weight"] = _mm_f32(dYb.t(), a.to(torch.bfloat16))
+            grads["mlp.fc2.bias"] = dY.float().sum(0)
+            w2t = fc2.weight.detach().t().contiguous()                      # [inter, D] bf16: the NT form's "weight"
+            da = torch.empty((M, inter), dtype=torch.float32, device=x.device)
+            if D % 64 == 0 and inter % 8 == 0:
+                nv.dense16_gemm(dYb, w2t, None, y=da)                        # HIP: bf16 x bf16, fp32 accumulate
+            else:
+                da = dYb.float() @ fc2.weight.detach().float()
+            # ---- activation, fc1: dW1 = dh1^T n, db1, d n = dh1 W1 ---------------------------------------------------------------
+            if hidden_act == "gelu_pytorch_tanh":
+                u = 0.7978845608028654 * (h1 + 0.044715 * h1 ** 3)
+                th = torch.tanh(u)
+                dact = 0.5 * (1.0 + th) + 0.5 * h1 * (1.0 - th * th) * 0.7978845608028654 * (1.0 + 3 * 0.044715 * h1 * h1)
+            else:
+                dact = 0.5 * (1.0 + torch.erf(h1 * 0.7071067811865476)) + h1 * torch.exp(-0.5 * h1 * h1) * 0.3989422804014327
+            dh1 = da * dact
+            dh1b = dh1.to(torch.bfloat16)
+            nb = n16.to(torch.bfloat16)
+            grads["mlp.fc1.weight"] = _mm_f32(dh1b.t(), nb)
+            grads["mlp.fc1.bias"] = dh1.sum(0)
+            dn = _mm_f32(dh1b, fc1.weight.detach())                         # [M, D]
+            # ---- LayerNorm affine: n = nhat gamma + beta ---------------------------------------------------------------------------
+            xf = x2.float()
+            mu = xf.mean(-1, keepdim=True)
+            nhat = (xf - mu) * torch.rsqrt(xf.var(-1, unbiased=False, keepdim=True) + ln.eps)
+            grads["layernorm.weight"] = (dn * nhat).sum(0)
+            grads["layernorm.bias"] = dn.sum(0)
+        LAST_FP32_GRADS = grads
+        names = ("layernorm.weight", "layernorm.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
+        plist = _head_params(head)
+        outs = [grads[n].to(p.dtype).view(p.shape) if ctx.needs_input_grad[3 + i] else None for i, (n, p) in enumerate(zip(names, plist))]
+        return (None, None, None, *outs)
+
+
+def _mm_f32(a, b):
+    """a @ b for bf16 operands with an fp32 result (vendor GEMM: fp32 accumulation; out_dtype where the build has it)."""
+    try:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    except (TypeError, RuntimeError):
+        return torch.mm(a.float(), b.float())
 
 
 def siglip_head_scores(last_hidden_state: torch.Tensor, head, guide_embed: torch.Tensor, hidden_act: str = None,
@@ -65,9 +163,9 @@ def _head_chain(last_hidden_state, head, hidden_act, out_dtype, guide, want_embe
     from .projector import _require_bf16_cuda
     x = last_hidden_state
     _require_bf16_cuda("last_hidden_state", x)
-    if torch.is_grad_enabled() and any(p.requires_grad for p in head.parameters()):
-        raise RuntimeError("siglip_head_embed builds no autograd graph (the head trains only in stage 3 of the reference): call "
-                           "it under torch.no_grad()")
+    if guide is not None and torch.is_grad_enabled() and any(p.requires_grad for p in _head_params(head)):
+        raise RuntimeError("siglip_head_scores builds no autograd graph (inference path): call it under torch.no_grad(); "
+                           "siglip_head_embed is the differentiable form")
     ln, fc1, fc2 = head.layernorm, head.mlp.fc1, head.mlp.fc2
     for t in (ln.weight, ln.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias):
         _require_bf16_cuda("head parameter", t)

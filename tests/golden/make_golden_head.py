@@ -41,6 +41,15 @@ def tokens(tag="head"):
     return synth.round_to_bf16(x)
 
 
+def sample_positions(n, count=512):
+    k = np.arange(count, dtype=np.int64)
+    return (k * 2654435761 + 12345) % n
+
+
+def cotangent(tag="head"):
+    return synth.normal_like((TOKENS, D), synth.seed_of(tag + ":cotangent"), 1.0)
+
+
 def main():
     from transformers import SiglipVisionConfig
     from transformers.models.siglip.modeling_siglip import SiglipMultiheadAttentionPoolingHead
@@ -53,8 +62,24 @@ def main():
     with torch.no_grad():
         image_embeds = head.layernorm(x)                     # encoder.py:284
         image_embeds = x + head.mlp(image_embeds)            # encoder.py:285
+    blobs = {"out": image_embeds.numpy().astype(np.float32)}
+    # stage 3 of the reference's script trains "vision_model_head" (train.py:717-720; release scripts :175): gradients of the six
+    # parameters those two lines touch, for loss = sum(out * R), by the reference modules' own fp32 autograd
+    head.train()
+    for p_ in head.parameters():
+        p_.requires_grad_(True)
+    out = x + head.mlp(head.layernorm(x))
+    R = torch.from_numpy(cotangent())
+    (out * R).sum().backward()
+    for k in sd:
+        mod = head
+        for part in k[len("head."):].split("."):
+            mod = getattr(mod, part)
+        v = mod.grad.numpy().astype(np.float32).reshape(-1)            # 512 sampled entries + (sum, abs-sum, max) per parameter
+        blobs["grad/" + k + "/samples"] = v[sample_positions(v.size)]
+        blobs["grad/" + k + "/sums"] = np.array([v.astype(np.float64).sum(), np.abs(v.astype(np.float64)).sum(), np.abs(v).max()])
     path = os.path.join(HERE, "golden_head_v1.npz")
-    np.savez_compressed(path, out=image_embeds.numpy().astype(np.float32))
+    np.savez_compressed(path, **blobs)
     print("wrote", path, os.path.getsize(path), "bytes; absmax", float(image_embeds.abs().max()))
 
 

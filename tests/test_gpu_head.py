@@ -47,8 +47,7 @@ def test_head_projection_matches_reference_fixture(head):
     assert float((got32.cpu() - want).abs().max()) <= 1e-3
     assert got16.dtype == torch.bfloat16 and got16.shape == (8, 8, mh.D)
     assert torch.equal(got16.view(-1, mh.D), got32.to(torch.bfloat16))
-    with pytest.raises(RuntimeError):
-        siglip_head_embed(x, m)                       # grad mode + trainable head: refuse, never detach silently
+    assert siglip_head_embed(x, m).requires_grad      # grad mode + trainable head: a graph (stage 3), never a silently detached tensor
 
 
 def test_head_projection_at_benchmark_size(head):
@@ -183,3 +182,66 @@ def test_local_logits_argument_checks(head):
         mc = build_module(cases.build_case("G6_coarse"))
         with pytest.raises(NotImplementedError):
             mc(ff, None, g, "video", None, local_logits=ll)                  # not the release recipe
+
+
+def test_head_backward_matches_reference_autograd(head):
+    """Stage 3 of the reference's script trains "vision_model_head" (train.py:717-720; release scripts :175): gradients of the six
+    parameters encoder.py:284-285 touches, for loss = sum(out * R), against the fixture made by the HF module's own fp32 autograd
+    (512 samples + sums per parameter).  Tolerance 2e-3 of each parameter's largest gradient entry (bf16 GEMM operands, fp32
+    accumulation), the .grad tensors are the bf16 casts."""
+    from hicom_amd import encoder
+    m, _ = head
+    m = m.train()
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "golden_head_v1.npz"))
+    x = torch.from_numpy(mh.tokens()).to(torch.bfloat16).cuda()
+    for p_ in m.parameters():
+        p_.grad = None
+    with torch.no_grad():
+        want_out = encoder.siglip_head_embed(x, m)
+    out = encoder.siglip_head_embed(x, m)
+    assert out.requires_grad and torch.equal(out.detach(), want_out)            # same kernels, same bits as inference
+    R = torch.from_numpy(mh.cotangent()).cuda()
+    (out.float() * R).sum().backward()
+    fp32 = dict(encoder.LAST_FP32_GRADS)
+    names = {"layernorm.weight": m.layernorm.weight, "layernorm.bias": m.layernorm.bias, "mlp.fc1.weight": m.mlp.fc1.weight,
+             "mlp.fc1.bias": m.mlp.fc1.bias, "mlp.fc2.weight": m.mlp.fc2.weight, "mlp.fc2.bias": m.mlp.fc2.bias}
+    for k, p_ in names.items():
+        want = gold[f"grad/head.{k}/samples"]
+        s, sabs, mx = gold[f"grad/head.{k}/sums"]
+        pos = torch.from_numpy(mh.sample_positions(p_.numel())).cuda()
+        got = fp32[k].reshape(-1)[pos].cpu().numpy()
+        tol = 2e-3 * mx + 1e-6
+        assert np.abs(got - want).max() <= tol, (k, float(np.abs(got - want).max()), tol)
+        assert abs(float(fp32[k].double().sum()) - s) <= 2e-3 * sabs + tol * p_.numel() ** 0.5, k
+        assert p_.grad is not None and p_.grad.dtype == p_.dtype and p_.grad.shape == p_.shape
+        assert np.abs(p_.grad.float().reshape(-1)[pos].cpu().numpy() - want).max() <= 2 ** -7 * mx + tol, k
+    xg = x.clone().requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        encoder.siglip_head_embed(xg, m).sum().backward()                       # frozen tower body: no d tokens, and never a silent None
+    for p_ in m.parameters():
+        p_.grad = None
+    m.eval()
+
+
+def test_stage3_chain_head_into_compressor_backward(head):
+    """head (trainable) -> frames_embed -> HIComProjector.forward -> loss: the compressor's d frames_embed flows into the head's
+    backward; every head parameter and every projector parameter ends up with a finite gradient of its own dtype."""
+    import cases
+    from gpu_util import build_module, dev_bf16
+    from hicom_amd import siglip_head_embed
+    m_head, _ = head
+    m_head.train()
+    case = cases.build_case("G1_direct_T8")
+    m = build_module(case).train()
+    ff, g = dev_bf16(case.ff), dev_bf16(case.g)
+    fe = siglip_head_embed(ff, m_head)                                          # the tower's hidden states double as frames_feature
+    assert fe.requires_grad
+    out = m(ff, fe, g, case.modal, None)
+    out.float().square().sum().backward()
+    for p_ in list(m_head.layernorm.parameters()) + list(m_head.mlp.parameters()):
+        assert p_.grad is not None and bool(torch.isfinite(p_.grad.float()).all()) and float(p_.grad.float().abs().max()) > 0
+        p_.grad = None
+    for n, p_ in m.named_parameters():
+        if n != "global_compressor.query":
+            assert p_.grad is not None and bool(torch.isfinite(p_.grad.float()).all()), n
+    m_head.eval()
