@@ -12,13 +12,14 @@ gradient checkpointing wants):
   dense weight gradients plain library GEMMs / outer products through torch (rocBLAS) in fp32 on the small
                          [Nw, 1152] / [9, 1152] tensors -- dW = dY^T X is not a kernel worth hand-writing
 
-Scope: the release recipes of the training script -- `use_guide="direct"` (stages 2-3) and guide off (stage 1: pooled
-per-window queries, 32 learnable global queries) -- without adaptors or clip-scale, dense video / image inputs, gradients of
-every projector parameter and of `image_newline`.  Stage 3 also trains the SigLIP head and the guide encoder
-(train.py:717-726), i.e. it needs the gradients w.r.t. `frames_embed` (the head's output, key stream of the local windows)
-and `guide_embed`: built for the direct recipe (hicom_local_attn_bwd: one more pass over both streams, d frames_embed written
-as bf16).  `frames_feature` comes from the frozen tower body: asking for its gradient raises instead of returning None
-silently, and so do input gradients of the guide-off recipe and every other recipe.
+Scope: every injection mode (direct, coarse, fine, off) and every adaptor (adapt q / k / v / guide) of dense video / image inputs,
+gradients of every projector parameter and of `image_newline`; stage 3 also trains the SigLIP head and the guide encoder
+(train.py:717-726), i.e. it needs the gradients w.r.t. `frames_embed` (the head's output, key stream of the local windows) and
+`guide_embed`: built for direct / coarse / fine (hicom_local_attn_bwd: one more pass over both streams, d frames_embed written as
+bf16; with k / v adaptors the window backward and the adaptor chain run as fp32 tensor algebra + library GEMMs).  The query chain
+(adapt_q, adapt_guide, coarse / fine injection) acts on small tensors only and is differentiated as a torch graph
+(_query_chain_backward).  `frames_feature` comes from the frozen tower body: asking for its gradient raises instead of returning
+None silently, and so do input gradients of the guide-off recipe, clip-scale projectors and text2qk projections.
 """
 from __future__ import annotations
 
@@ -37,16 +38,14 @@ def _gelu_grad(x):
 
 
 def _supported(proj) -> bool:
-    """direct / off / coarse injection, k / v adaptors; not: fine injection, adapt_q, adapt_guide, text2qk projections, clip-scale."""
+    """Every injection mode and adaptor; not: text2qk projections (text width != query width), clip-scale."""
     from .projector import _plain_injector
     lc, gc = proj.local_compressor, proj.global_compressor
     for c in (lc, gc):
         if c is None:
             continue
-        if c.use_guide not in ("direct", None, "off", "coarse") or not _plain_injector(c.guide_injector) or c.adapt_guide:
+        if c.use_guide not in ("direct", None, "off", "coarse", "fine") or not _plain_injector(c.guide_injector):
             return False
-    if lc is not None and lc.adapt_q:
-        return False
     return proj.local_logit is None and proj.global_logit is None
 
 
@@ -132,6 +131,83 @@ def _coarse_backward(inj, prefix, vis, guide, dq, grads):
     return dz * (1.0 + sc), W1.t() @ dh1
 
 
+def _query_chain_backward(stage, prefix, vis, guide, d_inj, f32, grads, want_guide, vis_param=None):
+    """Backward of the QUERY side of a compressor stage: the adapt_q blend (reference projector.py:541), the adapt_guide blend
+    (:365 / :389) and direct / coarse / fine injection (:352-397).  These act on small tensors only -- the [Nw | 32, D] queries and
+    the 1..64 guide rows, never the token stream -- and are restated here as a torch graph over fp32 leaf copies of the stage's
+    parameters, differentiated by torch.autograd.grad.  vis: fp32 [M, D] pooled queries / learnable queries (None for direct);
+    d_inj: gradient of the injected queries ([M, D]; [1, D] for the shared direct query).  Fills `grads`, returns (d vis, d guide)."""
+    F = torch.nn.functional
+    inj = stage.guide_injector
+    mode = stage.use_guide if stage.use_guide not in (None, "off") else None
+    eps = 1e-6
+    leaves = {}
+
+    def leaf(name):
+        if name not in leaves:
+            leaves[name] = f32[prefix + name].detach().clone().requires_grad_(True)
+        return leaves[name]
+
+    def mlp2(x, base):
+        return F.linear(F.gelu(F.linear(x, leaf(base + ".0.weight"), leaf(base + ".0.bias"))), leaf(base + ".2.weight"), leaf(base + ".2.bias"))
+
+    def ln(x, base):
+        return F.layer_norm(x, (x.shape[-1],), leaf(base + ".weight"), leaf(base + ".bias"), eps)
+
+    with torch.enable_grad():
+        v = None
+        if vis is not None:
+            v = vis.detach().clone().requires_grad_(vis_param is not None)
+            vq = v
+            if getattr(stage, "adapt_q", False):                                   # (1 - a) q + a LN(q W^T)  (:541; Linear without bias)
+                qa = leaf("q_alpha")
+                vq = (1 - qa) * vq + qa * ln(F.linear(vq, leaf("q_proj.weight")), "q_norm")
+        g = None
+        if mode is not None:
+            g = guide.detach().float().clone().requires_grad_(bool(want_guide))
+            ga = g
+            if getattr(stage, "adapt_guide", False):                               # (:365 / :389)
+                al = leaf("guide_injector.guide_alpha")
+                ga = (1 - al) * ga + al * ln(mlp2(ga, "guide_injector.guide_proj"), "guide_injector.guide_norm")
+        if mode is None:
+            q = vq
+        elif mode == "direct":
+            q = ga.reshape(1, -1)
+        elif mode == "coarse":
+            cs = mlp2(ga.reshape(1, -1), "guide_injector.coarse_proj")
+            D = vq.shape[-1]
+            q = ln(vq * (1 + cs[:, :D]) + cs[:, D:], "guide_injector.coarse_norm")
+        else:                                                                      # fine (:374-397): LN(q + MHA(q, G, G))
+            att = inj.fine_proj
+            nh, hd = att.num_heads, att.head_dim
+            P = "guide_injector.fine_proj."
+            qp = F.linear(vq, leaf(P + "q_proj.weight"), leaf(P + "q_proj.bias")).view(-1, nh, hd).permute(1, 0, 2)
+            kp = F.linear(ga, leaf(P + "k_proj.weight"), leaf(P + "k_proj.bias")).view(-1, nh, hd).permute(1, 0, 2)
+            vp = F.linear(ga, leaf(P + "v_proj.weight"), leaf(P + "v_proj.bias")).view(-1, nh, hd).permute(1, 0, 2)
+            pr = torch.softmax(torch.matmul(qp, kp.transpose(1, 2)) * att.scale, dim=-1)
+            o = torch.matmul(pr, vp).permute(1, 0, 2).reshape(vq.shape[0], nh * hd)
+            q = ln(vq + F.linear(o, leaf(P + "out_proj.weight"), leaf(P + "out_proj.bias")), "guide_injector.fine_norm")
+        wrt = list(leaves.values())
+        names = list(leaves.keys())
+        extra = []
+        if g is not None and want_guide:
+            extra.append(g)
+        if v is not None and vis_param is not None:
+            extra.append(v)
+        if not wrt and not extra:
+            return None, None
+        got = torch.autograd.grad(q, wrt + extra, grad_outputs=d_inj.reshape(q.shape), allow_unused=True)
+    for n, gr in zip(names, got[:len(names)]):
+        if gr is not None:
+            grads[prefix + n] = gr
+    rest = list(got[len(names):])
+    d_guide = rest.pop(0) if (g is not None and want_guide) else None
+    d_vis = rest.pop(0) if (v is not None and vis_param is not None) else None
+    if d_vis is not None:
+        grads[prefix + vis_param] = d_vis
+    return d_vis, d_guide
+
+
 def _to_windows(x, at, ay, ax):
     """[T, H, W, D] -> [Nw, kt ks ks, D] in the reference's window / in-window order (projector.py:473-499), exact partition."""
     D = x.shape[-1]
@@ -214,11 +290,11 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
     dev = ff.device
     d_fe = d_guide = None
     if want_fe or want_guide:
-        if not any(c is not None and c.use_guide in ("direct", "coarse") for c in (lc, gc)):
-            raise NotImplementedError("hicom_amd backward: gradients w.r.t. frames_embed / guide_embed are built for "
-                                      "use_guide='direct' and 'coarse' (stage 3 of the reference's script)")
+        if not any(c is not None and c.use_guide in ("direct", "coarse", "fine") for c in (lc, gc)):
+            raise NotImplementedError("hicom_amd backward: gradients w.r.t. frames_embed / guide_embed need a recipe that uses them "
+                                      "(use_guide = direct / coarse / fine; stage 3 of the reference's script)")
         if want_guide:
-            d_guide = torch.zeros(guide.numel(), dtype=torch.float32, device=dev)
+            d_guide = torch.zeros(guide.shape, dtype=torch.float32, device=dev)
         if want_fe and lc is None:
             want_fe = False            # without a local stage frames_embed does not enter the forward: no gradient (None), as in the reference
     dout = dout.float()
@@ -250,8 +326,11 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         grads["local_compressor.readout.0.bias"] = dpre.sum(0)
         mode = lc.use_guide if lc.use_guide not in (None, "off") else None
         adapt = lc.adapt_k or lc.adapt_v
-        if want_fe or adapt or mode == "coarse" or (want_guide and mode == "direct"):
+        plain_q = not (lc.adapt_q or lc.adapt_guide)                       # plain direct / coarse / off: the hand-written paths below
+        query_params = mode in ("coarse", "fine") or lc.adapt_q or lc.adapt_guide
+        if want_fe or adapt or query_params or (want_guide and mode is not None):
             # ---- attention backward of the windows: dq per window, d key stream, d value stream -------------------------
+            from . import injector as inj
             exact = all(a.nwin * a.k == a.n for a in (at, ay, ax))
             if (want_fe or adapt) and not exact:
                 raise NotImplementedError("hicom_amd backward: d frames_embed / the adaptor gradients need an exact window "
@@ -262,15 +341,17 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
             key = fe if fe is not None else ff
             pooled = None
             if mode == "direct":
-                q = guide.reshape(-1).contiguous()
+                q, _ = inj.inject(lc.guide_injector, "direct", None, guide.contiguous())       # the (adapted) guide, one row
+                q = q.reshape(-1).contiguous()
             else:
                 pooled = torch.empty((*grid, E), dtype=torch.float32, device=dev)
                 nv.trilinear_pool(ff, pooled)                              # HIP: the per-window query (ref :539-540)
                 pooled = pooled.view(nw, E)
                 q = pooled
-                if mode == "coarse":
-                    from . import injector as inj
-                    q, _ = inj.inject(lc.guide_injector, "coarse", pooled, guide.contiguous())    # HIP: LN(q (1 + scale) + shift)
+                if lc.adapt_q:
+                    q = inj.adapt_query(q, lc.q_proj, lc.q_norm, lc.q_alpha)                    # HIP (ref :541)
+                if mode in ("coarse", "fine"):
+                    q, _ = inj.inject(lc.guide_injector, mode, q.reshape(nw, E), guide.contiguous())   # HIP (ref :369-397)
             if adapt:
                 tape_k = _AdaptorTape(key, lc.k_proj, lc.k_norm, lc.k_alpha) if lc.adapt_k else None
                 tape_v = _AdaptorTape(ff, lc.v_proj, lc.v_norm, lc.v_alpha) if lc.adapt_v else None
@@ -289,12 +370,18 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
                 if want_fe and fe is not None:
                     d_fe = torch.empty_like(fe)
                 nv.local_attn_bwd(key, ff, axes, q, 0 if mode == "direct" else E, scale, 0.0, dctx_l, dq_w, d_fe)
-            if mode == "direct" and want_guide:
-                d_guide += dq_w.sum(0)
-            elif mode == "coarse":
+            if mode == "direct" and plain_q:
+                if want_guide:
+                    d_guide += dq_w.sum(0)
+            elif mode == "coarse" and plain_q:
                 _, dg = _coarse_backward(lc.guide_injector, "local_compressor.guide_injector.", pooled, guide, dq_w, grads)
                 if want_guide:
                     d_guide += dg
+            elif query_params or (want_guide and mode is not None):
+                d_inj = dq_w.sum(0, keepdim=True) if mode == "direct" else dq_w
+                _, dg = _query_chain_backward(lc, "local_compressor.", pooled, guide, d_inj, f32, grads, want_guide)
+                if want_guide and dg is not None:
+                    d_guide += dg.reshape(d_guide.shape)
     if gc is not None:
         att = gc.attn_layer
         nh, hd = att.num_heads, att.head_dim
@@ -366,6 +453,14 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         grads[P + "attn_layer.q_proj.bias"] = dqp.sum(0)
         if gc.use_guide in (None, "off"):
             grads[P + "query"] = dqp @ Wq + dpre                           # the learnable queries: through q_proj and the residual
+        elif gc.use_guide == "fine" or gc.adapt_guide:                     # fine injection / adapted guide: the small-tensor graph
+            d_in = dqp @ Wq + dpre
+            direct_g = gc.use_guide == "direct"
+            _, dg = _query_chain_backward(gc, P, None if direct_g else gc.query.detach().float(), guide,
+                                          d_in.sum(0, keepdim=True) if direct_g else d_in, f32, grads, want_guide,
+                                          vis_param=None if direct_g else "query")
+            if want_guide and dg is not None:
+                d_guide += dg.reshape(d_guide.shape)
         elif gc.use_guide == "coarse":                                     # injected = LN(query (1 + scale) + shift) (:369-372)
             dvis, dg = _coarse_backward(gc.guide_injector, P + "guide_injector.", gc.query.detach().float(), guide,
                                         dqp @ Wq + dpre, grads)
@@ -383,10 +478,9 @@ def forward_with_grad(proj, frames_feature, frames_embed, guide_embed, modal, im
     some = frames_feature["patch"] if isinstance(frames_feature, dict) else frames_feature
     _require_bf16_cuda("frames_feature", some)
     if isinstance(frames_feature, dict) or not _supported(proj):
-        raise NotImplementedError("hicom_amd: the backward pass covers use_guide='direct' / 'coarse' / off with or without the "
-                                  "k / v adaptors, dense inputs, no clip-scale; run other recipes (fine injection, adapt_q, "
-                                  "adapt_guide) under torch.no_grad() / inference_mode() -- forward() never returns a "
-                                  "silently detached tensor")
+        raise NotImplementedError("hicom_amd: the backward pass covers every injection mode and adaptor on dense inputs, without "
+                                  "clip-scale and without a text2qk projection; run other configurations under torch.no_grad() / "
+                                  "inference_mode() -- forward() never returns a silently detached tensor")
     names, params = zip(*[(n, p) for n, p in proj.named_parameters()])
     ff = frames_feature.contiguous()
     fe = frames_embed.contiguous() if frames_embed is not None else None

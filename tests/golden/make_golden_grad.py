@@ -24,7 +24,9 @@ import cases                            # noqa: E402
 GRAD_CASES = ["G1_direct_T8", "G4b_image_newline", "G9_grid", "G9_frame", "G10_peaky_direct", "G9_local_only", "G9_global_only",
               "G3_direct_T7", "G2_off_T8", "G2b_off_string", "G10b_peaky_off", "G12_clip768_direct", "G12b_clip768_off", "G9_local22",
               # the second released recipe (k / v adaptors over all tokens) and coarse (FiLM) injection, incl. a mixed override
-              "G5_adaptkv", "G6_coarse", "G7b_guide_override"]
+              "G5_adaptkv", "G6_coarse", "G7b_guide_override",
+              # fine (64 text tokens) injection; every adaptor at once (adapt q / k / v / guide, coarse)
+              "G7_fine", "G5b_adaptqkvg_off"]
 
 
 def cotangent(name, shape):
@@ -47,8 +49,8 @@ def main():
         t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))
         ff, fe, g = t(case.ff), t(case.fe), t(case.g)
         # stage 3 of the reference's script also trains what produces frames_embed and guide_embed (train.py:717-726):
-        # record their gradients for the direct and coarse recipes
-        direct = getattr(case.cfg, "use_guide", None) in ("direct", "coarse") and g is not None
+        # record their gradients for the direct, coarse and fine recipes
+        direct = getattr(case.cfg, "use_guide", None) in ("direct", "coarse", "fine") and g is not None
         if direct:
             g = g.clone().requires_grad_(True)
             if fe is not None:

@@ -32,7 +32,7 @@ def _grad_cases():
 @pytest.mark.parametrize("name", ["G1_direct_T8", "G4b_image_newline", "G9_grid", "G9_frame", "G10_peaky_direct", "G9_local_only",
                                   "G9_global_only", "G3_direct_T7", "G2_off_T8", "G2b_off_string", "G10b_peaky_off",
                                   "G12_clip768_direct", "G12b_clip768_off", "G9_local22",
-                                  "G5_adaptkv", "G6_coarse", "G7b_guide_override"])
+                                  "G5_adaptkv", "G6_coarse", "G7b_guide_override", "G7_fine", "G5b_adaptqkvg_off"])
 def test_parameter_gradients_match_reference_autograd(name, golden_grad):
     import make_golden_grad as mg
     from hicom_amd import autograd as hag
@@ -86,15 +86,18 @@ def test_parameter_gradients_match_reference_autograd(name, golden_grad):
 
 
 def test_unsupported_recipes_and_input_grads_refuse():
-    """fine injection / adapt_q / adapt_guide have no backward; the gradient w.r.t. frames_feature (frozen tower body) is not built,
-    nor are input gradients of the guide-off recipe or d frames_embed over overlapping windows: all must raise, never return a
-    detached tensor or a silent None."""
-    for name in ("G7_fine", "G5b_adaptqkvg_off"):
-        case = cases.build_case(name)
-        m = build_module(case).train()
-        ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
-        with pytest.raises(NotImplementedError):
-            m(ff, fe, g, case.modal, None)
+    """clip-scale has no backward; the gradient w.r.t. frames_feature (frozen tower body) is not built, nor are input gradients of
+    the guide-off recipe or d frames_embed over overlapping windows: all must raise, never return a detached tensor or a silent
+    None."""
+    import hicom_amd
+    case = cases.build_case("G8_clip_scale")
+    case.cfg.use_clip_scale = "local,global"
+    m = hicom_amd.build_vision_projector(case.cfg)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd.items()}, strict=True)
+    m = m.to(torch.bfloat16).cuda().train()
+    m.set_clip_logits(local=case.logit["local"], glob=case.logit["glob"])
+    with pytest.raises(NotImplementedError):
+        m(dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g), case.modal, None)
     for name, which in (("G1_direct_T8", "ff"), ("G2_off_T8", "fe"), ("G3_direct_T7", "fe")):
         case = cases.build_case(name)
         m = build_module(case).train()
