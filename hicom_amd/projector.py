@@ -310,13 +310,25 @@ class LocalCompressor(nn.Module):
         grid = (at.nwin, ay.nwin, ax.nwin)
         nw = grid[0] * grid[1] * grid[2]
         l2norm = 0
+        guide_n = None                                                # clip-scale with an injector: the guide rows L2-normalised FIRST
         if logit_scale is not None:                                   # ref :527-529, :549
             scale, bias = math.exp(float(logit_scale)), float(logit_bias)
             if frames_embed is not None:
-                if self.adapt_k or self.use_guide not in (None, "off", "direct"):
-                    raise NotImplementedError("LocalCompressor: clip-scale together with adapt_k / coarse / fine "
-                                              "normalises BEFORE the adaptor (ref :527-533); no HIP path yet")
-                l2norm = 1 | (2 if self.use_guide == "direct" else 0)
+                if self.adapt_k:
+                    raise NotImplementedError("LocalCompressor: clip-scale together with adapt_k normalises frames_embed BEFORE the "
+                                              "adaptor (ref :527-533); no HIP path yet")
+                l2norm = 1                                            # every key row, inside the window kernel
+                if self.use_guide == "direct" and not self.adapt_guide:
+                    l2norm |= 2                                       # ... and the shared query (= the guide) as well
+                elif self.use_guide in ("direct", "coarse", "fine"):
+                    # the reference normalises guide_embed and THEN injects / adapts it (:529 before :542): the query that comes out
+                    # of the injector is not normalised again
+                    _require_bf16_cuda("guide_embed", guide_embed)
+                    g2 = guide_embed.contiguous().reshape(-1, D)
+                    guide_n = _f32(g2.shape, ff.device)
+                    nv.scatter_rows(g2, guide_n, 0, g2.shape[0])      # bf16 -> f32 rows
+                    nv.clip_query_prep(guide_n, None, 1, 1.0, _f32((g2.shape[0],), ff.device))   # rows / ||row||
+                    guide_n = guide_n.reshape(guide_embed.shape)
         else:
             scale, bias = 1.0 / math.sqrt(self.qk_dim), 0.0            # ref :551
         value = ff
@@ -327,7 +339,7 @@ class LocalCompressor(nn.Module):
         ctx = _f32((nw, D), ff.device)
         if self.use_guide == "direct":                                 # query := guide for every window (:352-368)
             _require_bf16_cuda("guide_embed", guide_embed)
-            q, _ = inj.inject(self.guide_injector, "direct", None, guide_embed.contiguous())
+            q, _ = inj.inject(self.guide_injector, "direct", None, guide_n if guide_n is not None else guide_embed.contiguous())
             nv.local_attn(key, value, axes, q.reshape(-1).contiguous(), 0, scale, bias, l2norm, ctx)
             return ctx, grid
         q = _f32((*grid, D), ff.device)                                # pooled per-window query (ref :539-540)
@@ -336,7 +348,8 @@ class LocalCompressor(nn.Module):
             q = inj.adapt_query(q, self.q_proj, self.q_norm, self.q_alpha)
         if self.use_guide in ("coarse", "fine"):
             _require_bf16_cuda("guide_embed", guide_embed)
-            q, _ = inj.inject(self.guide_injector, self.use_guide, q.reshape(nw, D), guide_embed.contiguous())
+            q, _ = inj.inject(self.guide_injector, self.use_guide, q.reshape(nw, D),
+                              guide_n if guide_n is not None else guide_embed.contiguous())
         nv.local_attn(key, value, axes, q.reshape(nw, D), D, scale, bias, l2norm, ctx)
         return ctx, grid
 

@@ -37,6 +37,11 @@ CASES = {
                                T=4, h=6, w=6),
     # clip-scale path (direct compressor calls with logit tensors)
     "G8_clip_scale": dict(cfg=dict(), T=4, h=6, w=6, logit=dict(local=(2.0, -3.0), glob=(1.5, -2.0))),
+    # ... with an injector: the guide is normalised BEFORE it is injected (projector.py:527-529 in front of :542)
+    "G8b_clip_coarse": dict(cfg=dict(use_guide="coarse"), T=4, h=6, w=6, logit=dict(local=(2.0, -3.0), glob=(1.5, -2.0))),
+    "G8c_clip_fine": dict(cfg=dict(use_guide="fine"), T=4, h=6, w=6, guide_len=64, logit=dict(local=(2.0, -3.0), glob=(1.5, -2.0))),
+    "G8d_clip_direct_adaptg": dict(cfg=dict(mm_projector_type="local43_adaptg_global32_adaptg"), T=4, h=6, w=6,
+                                   logit=dict(local=(2.0, -3.0), glob=(1.5, -2.0))),
     # packing variants
     "G9_grid": dict(cfg=dict(mm_newline_position="grid"), T=8, h=6, w=6, newline=True),
     "G9_frame": dict(cfg=dict(mm_newline_position="frame"), T=8, h=6, w=6, newline=True),

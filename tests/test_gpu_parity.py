@@ -49,23 +49,28 @@ def test_matches_reference_golden(name, golden):
     assert err <= TOL, f"{name}: max-abs {err:.3e}"
 
 
-def test_clip_scale_local_matches_golden(golden):
-    case = cases.build_case("G8_clip_scale")
+@pytest.mark.parametrize("name", ["G8_clip_scale", "G8b_clip_coarse", "G8c_clip_fine", "G8d_clip_direct_adaptg"])
+def test_clip_scale_local_matches_golden(golden, name):
+    """Clip-scale on the LOCAL stage (reference projector.py:527-529, :549); with an injector or an adapted guide the guide rows are
+    normalised BEFORE injection and the injected query is not normalised again (G8b / G8c / G8d)."""
+    case = cases.build_case(name)
     got = run_native(case)["local"].float().cpu().numpy()
-    ref = golden["G8_clip_scale/local"]
+    ref = golden[f"{name}/local"]
     assert got.shape == ref.shape and np.abs(got - ref).max() <= TOL
 
 
-def test_clip_scale_global_matches_golden(golden):
+@pytest.mark.parametrize("name", ["G8_clip_scale", "G8b_clip_coarse", "G8c_clip_fine", "G8d_clip_direct_adaptg"])
+def test_clip_scale_global_matches_golden(golden, name):
     """Clip-scale on the GLOBAL stage (reference projector.py:184-191: queries and PROJECTED keys L2-normalised over the full
-    width, logits * exp(logit_scale) + logit_bias): G8's stored `global` vector, direct compressor call as the fixture makes it."""
-    case = cases.build_case("G8_clip_scale")
+    width, logits * exp(logit_scale) + logit_bias): the stored `global` vector, direct compressor call as the fixture makes it;
+    G8b / G8c: 32 distinct injected queries (coarse / fine), G8d: the adapted guide."""
+    case = cases.build_case(name)
     m = build_module(case)
     ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
     gs, gb = (torch.tensor(v, device="cuda") for v in case.logit["glob"])
     with torch.no_grad():
         got = m.global_compressor(ff, fe, g, case.modal, gs, gb)
-    ref = golden["G8_clip_scale/global"]
+    ref = golden[f"{name}/global"]
     assert tuple(got.shape) == ref.shape and np.abs(got.float().cpu().numpy() - ref).max() <= TOL
 
 
