@@ -475,6 +475,37 @@ __global__ __launch_bounds__(256) void ln_stream_kernel(LnStreamParams p) {
     }
 }
 
+// out[m, :] = x[m, :] / ||x[m, :]||_2 over the token stream (bf16 in, bf16 out, 16-byte accesses): frames_embed of the clip-scale
+// local stage when the k adaptor follows (reference projector.py:527-529 in front of :533).
+__global__ __launch_bounds__(256) void l2norm_stream_kernel(const uint16_t* x, uint16_t* out, long M, int E) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int nch = E >> 3;
+    float v[3][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) ld8(x, HICOM_DT_BF16, m * (long)E + 8 * ch, v[c]);
+        else
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss = fmaf(v[c][i], v[c][i], ss);
+    }
+    const float inv = 1.0f / sqrtf(wave_sum(ss));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch >= nch) continue;
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = f32_to_bf16(v[c][2 * i] * inv) | ((uint32_t)f32_to_bf16(v[c][2 * i + 1] * inv) << 16);
+        *reinterpret_cast<u32x4*>(out + m * (long)E + 8 * ch) = o;
+    }
+}
+
 }  // namespace hicom
 
 using namespace hicom;
@@ -536,4 +567,12 @@ extern "C" int hicom_ln_stream_fwd(const void* x, int32_t x_dt, int64_t ldx, con
                      out, out_dt == HICOM_DT_F16, M, E};
     hipLaunchKernelGGL(ln_stream_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
     return hicom_host::check_launch("ln_stream");
+}
+
+extern "C" int hicom_l2norm_stream_fwd(const void* x, void* out, int64_t M, int32_t E, void* stream) {
+    HICOM_REQUIRE(x && out && M > 0 && E > 0 && E % 8 == 0 && E <= 1536, HICOM_EINVAL, "l2norm_stream: bad arguments (E %% 8, E <= 1536)");
+    HICOM_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0), HICOM_EINVAL, "l2norm_stream: 16-byte alignment");
+    hipLaunchKernelGGL(l2norm_stream_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)out,
+                       (long)M, E);
+    return hicom_host::check_launch("l2norm_stream");
 }

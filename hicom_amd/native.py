@@ -15,7 +15,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 # HICOM_NATIVE_LIB: dev override (instrumented builds from tools/); the product loads the in-tree library
 LIB_PATH = os.environ.get("HICOM_NATIVE_LIB") or os.path.join(HERE, "libhicom_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 DT_BF16, DT_F32, DT_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_GELU_TANH = 0, 1, 2
@@ -31,7 +31,7 @@ EXPORTS = (
     "hicom_global_stream_bwd", "hicom_readout16_gemm_fwd", "hicom_to_f16_fwd", "hicom_merge_vproj_fwd",
     "hicom_dense16_gemm_fwd", "hicom_ln_stream_fwd", "hicom_to_f16_padded_fwd", "hicom_clip_query_prep_fwd", "hicom_inv_norm_fwd",
     "hicom_global_stream_clip_fwd", "hicom_splice_rows_fwd", "hicom_splice_labels_fwd",
-    "hicom_query_prep_fwd", "hicom_query_prep_state_bytes", "hicom_partials_sum_fwd",
+    "hicom_query_prep_fwd", "hicom_query_prep_state_bytes", "hicom_partials_sum_fwd", "hicom_l2norm_stream_fwd",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -130,6 +130,7 @@ def lib() -> C.CDLL:
     L.hicom_dense16_gemm_fwd.argtypes = [vp, i64, vp, i64, i32, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, i32, i64, vp, i64, vp,
                                          vp, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp]
     L.hicom_partials_sum_fwd.argtypes = [vp, i32, i64, vp, vp]
+    L.hicom_l2norm_stream_fwd.argtypes = [vp, vp, i64, i32, vp]
     L.hicom_clip_query_prep_fwd.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp]
     L.hicom_inv_norm_fwd.argtypes = [vp, i32, i64, vp, vp]
     L.hicom_global_stream_clip_fwd.argtypes = [vp, i64, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64,
@@ -444,6 +445,11 @@ def dense16_gemm(a, w, b, N=None, K=None, act=ACT_NONE, out_f16=None, n_store=No
                                         _ptr(row_dot[0]) if row_dot else None, _dt(row_dot[0]) if row_dot else 0,
                                         _ptr(row_dot[1]) if row_dot else None, _stream()),
            "hicom_dense16_gemm_fwd")
+
+
+def l2norm_stream(x, out):
+    M, E = x.shape
+    _check(lib().hicom_l2norm_stream_fwd(_ptr(x), _ptr(out), M, E, _stream()), "hicom_l2norm_stream_fwd")
 
 
 def partials_sum(parts, out):

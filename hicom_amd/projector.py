@@ -315,9 +315,12 @@ class LocalCompressor(nn.Module):
             scale, bias = math.exp(float(logit_scale)), float(logit_bias)
             if frames_embed is not None:
                 if self.adapt_k:
-                    raise NotImplementedError("LocalCompressor: clip-scale together with adapt_k normalises frames_embed BEFORE the "
-                                              "adaptor (ref :527-533); no HIP path yet")
-                l2norm = 1                                            # every key row, inside the window kernel
+                    # the keys are normalised BEFORE the adaptor MLP (ref :527-529 in front of :533) and not again behind it
+                    kn = torch.empty_like(key)
+                    nv.l2norm_stream(key.view(-1, D), kn.view(-1, D))
+                    key = kn
+                else:
+                    l2norm = 1                                        # every key row, inside the window kernel
                 if self.use_guide == "direct" and not self.adapt_guide:
                     l2norm |= 2                                       # ... and the shared query (= the guide) as well
                 elif self.use_guide in ("direct", "coarse", "fine"):

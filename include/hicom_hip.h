@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HICOM_ABI_VERSION 5
+#define HICOM_ABI_VERSION 6
 
 #define HICOM_OK         0
 #define HICOM_EINVAL    -1   /* bad argument (shape, alignment, NULL)        */
@@ -351,6 +351,9 @@ int hicom_partials_sum_fwd(const float* parts, int32_t nparts, int64_t M, float*
  * hicom_inv_norm_fwd: inv[m] = 1 / sqrt(sum_{s < parts} ssq[s * M + m])  (key norms from hicom_dense16_gemm_fwd's ssq). */
 int hicom_clip_query_prep_fwd(float* qp, const void* b_k, int32_t nq, int32_t nh, int32_t E, float scale, float* c, void* stream);
 int hicom_inv_norm_fwd(const float* ssq, int32_t parts, int64_t M, float* inv, void* stream);
+/* out[m,:] = x[m,:] / ||x[m,:]||_2, bf16 [M, E] -> bf16 [M, E] (E % 8 == 0, E <= 1536): frames_embed of the clip-scale local stage
+ * when the k adaptor follows it (projector.py:527-529 in front of :533; without adaptor the window kernel normalises in place). */
+int hicom_l2norm_stream_fwd(const void* x, void* out, int64_t M, int32_t E, void* stream);
 /* out[m,:] = (1 - alpha) src[m,:] + alpha (LayerNorm_eps(x[m,:]) gamma + beta) over all tokens with 16-byte accesses:
  * x fp16 | bf16 | f32 [M, ldx]; gamma, beta, src (may be NULL) bf16; alpha device scalar or NULL (= 1); out fp16 | bf16
  * [M, E]; E % 8 == 0, E <= 1536.  head.layernorm of encoder.py:284 and the adaptor blend of projector.py:533-534. */

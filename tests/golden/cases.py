@@ -40,6 +40,8 @@ CASES = {
     # ... with an injector: the guide is normalised BEFORE it is injected (projector.py:527-529 in front of :542)
     "G8b_clip_coarse": dict(cfg=dict(use_guide="coarse"), T=4, h=6, w=6, logit=dict(local=(2.0, -3.0), glob=(1.5, -2.0))),
     "G8c_clip_fine": dict(cfg=dict(use_guide="fine"), T=4, h=6, w=6, guide_len=64, logit=dict(local=(2.0, -3.0), glob=(1.5, -2.0))),
+    "G8e_clip_adaptkv": dict(cfg=dict(mm_projector_type="local43_adaptkv_global32"), T=4, h=6, w=6,
+                             logit=dict(local=(2.0, -3.0), glob=(1.5, -2.0))),
     "G8d_clip_direct_adaptg": dict(cfg=dict(mm_projector_type="local43_adaptg_global32_adaptg"), T=4, h=6, w=6,
                                    logit=dict(local=(2.0, -3.0), glob=(1.5, -2.0))),
     # packing variants

@@ -49,7 +49,7 @@ def test_matches_reference_golden(name, golden):
     assert err <= TOL, f"{name}: max-abs {err:.3e}"
 
 
-@pytest.mark.parametrize("name", ["G8_clip_scale", "G8b_clip_coarse", "G8c_clip_fine", "G8d_clip_direct_adaptg"])
+@pytest.mark.parametrize("name", ["G8_clip_scale", "G8b_clip_coarse", "G8c_clip_fine", "G8d_clip_direct_adaptg", "G8e_clip_adaptkv"])
 def test_clip_scale_local_matches_golden(golden, name):
     """Clip-scale on the LOCAL stage (reference projector.py:527-529, :549); with an injector or an adapted guide the guide rows are
     normalised BEFORE injection and the injected query is not normalised again (G8b / G8c / G8d)."""
