@@ -478,6 +478,15 @@ def neighbours_sweep(args, device):
         train_step(flag)
         dt, _ = best(lambda: train_step(flag), n=5)
         out.setdefault("train_step", {"workload": f"{args.frames_per_gpu} frames, hidden {args.hidden}, use_guide=direct: forward() under autograd + backward (recompute-based, hicom_amd/autograd.py)"})[key] = dt * 1e3
+    # opt-in: the backward as a captured hipGraph (same input buffers step after step, as a training loop's allocator hands them out)
+    m.graph_backward = True
+    for _ in range(3):
+        train_step(False)
+    dt, _ = best(lambda: train_step(False), n=5)
+    out["train_step"]["params_only_graph_backward_ms"] = dt * 1e3
+    ent = next(iter(m.__dict__.get("_bwd_graphs", {}).values()), {})
+    out["train_step"]["graph_backward_captured"] = "graph" in ent
+    m.graph_backward = False
     return out
 
 

@@ -257,29 +257,86 @@ class _CompressorFn(torch.autograd.Function):
         if need[1]:
             raise NotImplementedError("hicom_amd backward: the gradient w.r.t. frames_feature is not built (the tower body is "
                                       "frozen in every stage of the reference's script, train.py:703); detach it")
-        with torch.no_grad():
-            grads, d_nl, d_fe, d_guide = compressor_backward(ctx.proj, ff, fe, guide, ctx.modal, nl, dout,
-                                                             want_fe=bool(need[2]), want_guide=bool(need[3]))
-        global LAST_FP32_GRADS
-        LAST_FP32_GRADS = dict(grads)
-        if d_guide is not None:
-            LAST_FP32_GRADS["__guide_embed__"] = d_guide
-        plist = dict(ctx.proj.named_parameters())
-        # the parameter gradients leave as views of ONE buffer cast once (one concatenation + one cast instead of a cast per tensor)
-        wanted = [(k, name) for k, name in enumerate(ctx.names) if need[7 + k] and grads.get(name) is not None]
+        proj = ctx.proj
+        want = tuple(bool(need[7 + k]) for k in range(len(ctx.names)))
+        args = (proj, ff, fe, guide, ctx.modal, nl, ctx.names, want, bool(need[2]), bool(need[3]), bool(nl is not None and need[5]))
+        if getattr(proj, "graph_backward", False) and nl is None and _is_plain(proj):
+            res = _graphed_backward(dout, *args)
+        else:
+            with torch.no_grad():
+                res = _backward_outputs(dout, *args)
+        flats, d_fe, d_guide, d_nl = res
+        plist = dict(proj.named_parameters())
         out = [None] * len(ctx.names)
-        by_dtype = {}
-        for k, name in wanted:
-            by_dtype.setdefault(plist[name].dtype, []).append((k, name))
-        for dt, group in by_dtype.items():
-            flat = torch.cat([grads[name].reshape(-1) for _, name in group]).to(dt)
+        for dt, (flat, group) in flats.items():                    # views of ONE buffer per parameter dtype
             o = 0
             for k, name in group:
                 n = plist[name].numel()
                 out[k] = flat[o:o + n].view(plist[name].shape)
                 o += n
-        return (None, None, d_fe, (d_guide.to(guide.dtype).reshape(guide.shape) if d_guide is not None else None), None,
-                (d_nl.to(nl.dtype) if (nl is not None and need[5] and d_nl is not None) else None), None, *out)
+        return (None, None, d_fe, d_guide, None, d_nl, None, *out)
+
+
+def _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl):
+    """({dtype: (flat gradient buffer, [(argument index, parameter name)])}, d frames_embed, d guide_embed, d image_newline) in
+    the dtypes autograd hands on.  The parameter gradients leave as views of one buffer cast once (one concatenation + one cast
+    instead of a cast per tensor)."""
+    global LAST_FP32_GRADS
+    grads, d_nl, d_fe, d_guide = compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=want_fe, want_guide=want_guide)
+    LAST_FP32_GRADS = dict(grads)
+    if d_guide is not None:
+        LAST_FP32_GRADS["__guide_embed__"] = d_guide
+    plist = dict(proj.named_parameters())
+    by_dtype = {}
+    for k, name in enumerate(names):
+        if want[k] and grads.get(name) is not None:
+            by_dtype.setdefault(plist[name].dtype, []).append((k, name))
+    flats = {dt: (torch.cat([grads[name].reshape(-1) for _, name in group]).to(dt), group) for dt, group in by_dtype.items()}
+    return (flats, d_fe, (d_guide.to(guide.dtype).reshape(guide.shape) if d_guide is not None else None),
+            (d_nl.to(nl.dtype) if (want_nl and d_nl is not None) else None))
+
+
+_MAX_BWD_GRAPHS = 4
+
+
+def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl):
+    """Opt-in (`proj.graph_backward = True`): the backward of a plain recipe as a captured hipGraph.  The backward is ~130 small
+    launches behind 1.4 ms of Python at the benchmark shape; its shapes are static, so the second backward with the same input
+    BUFFERS (a training loop's caching allocator hands the same blocks back step after step) is captured and later ones are one
+    graph launch.  Keyed by the addresses the captured kernels read (frames, guide, parameters) and by what is asked for; the
+    upstream gradient is copied into a static buffer, the results are cloned out of the graph's pool (gradient accumulation adds
+    into .grad in place: handing out the static buffers would alias them).  Falls back to the eager backward on any capture error."""
+    cache = proj.__dict__.setdefault("_bwd_graphs", {})
+    key = (ff.data_ptr(), tuple(ff.shape), None if fe is None else fe.data_ptr(), None if guide is None else guide.data_ptr(), modal,
+           tuple(dout.shape), dout.dtype, want, want_fe, want_guide, tuple(p.data_ptr() for p in proj.parameters()),
+           torch.cuda.current_stream(ff.device).cuda_stream)
+    ent = cache.get(key)
+    if ent is None:                                                # first sight: eager (also the warm-up a capture needs)
+        if len(cache) >= _MAX_BWD_GRAPHS:
+            cache.pop(next(iter(cache)))
+        cache[key] = {"seen": 1}
+        with torch.no_grad():
+            return _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl)
+    if "graph" not in ent:
+        if ent.get("failed"):
+            with torch.no_grad():
+                return _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl)
+        try:
+            static_dout = dout.detach().clone()
+            torch.cuda.current_stream(ff.device).synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g):
+                outs = _backward_outputs(static_dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl)
+            ent.update(graph=g, dout=static_dout, outs=outs)
+        except Exception as e:  # noqa: BLE001
+            ent["failed"] = repr(e)
+            with torch.no_grad():
+                return _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl)
+    ent["dout"].copy_(dout)
+    ent["graph"].replay()
+    flats, d_fe, d_guide, d_nl = ent["outs"]
+    return ({dt: (flat.clone(), group) for dt, (flat, group) in flats.items()}, None if d_fe is None else d_fe.clone(),
+            None if d_guide is None else d_guide.clone(), None)
 
 
 def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, want_guide=False):

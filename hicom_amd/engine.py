@@ -184,7 +184,7 @@ def attach_execution(a: nv.CompressorArgs, device, main_stream=None, res=None) -
 class _Plan:
     """A filled argument block for one (projector state, problem shape) combination and the workspace it owns, plus --
     in graph mode -- the captured hipGraph of its launch sequence and the static buffer it writes."""
-    __slots__ = ("args", "ws", "rows", "hidden", "graph", "static_out", "hits", "fused", "sig", "guide_fields", "res")
+    __slots__ = ("args", "ws", "rows", "hidden", "graph", "static_out", "hits", "fused", "sig", "guide_fields", "res", "fresh", "refresh")
 
     def __init__(self, args, ws, rows, hidden, sig, res):
         self.args, self.ws, self.rows, self.hidden, self.sig, self.res = args, ws, rows, hidden, sig, res
@@ -193,6 +193,8 @@ class _Plan:
         self.graph = None
         self.static_out = None
         self.hits = 0
+        self.fresh = None          # weight CONTENT state (versions, epoch) the derived device caches were last built from
+        self.refresh = None        # callable that rebuilds them in place
 
 
 _MAX_PLANS = 16      # per projector; plans live ON the module (they point into its cached device tables)
@@ -208,6 +210,27 @@ def _param_list(proj):
         cached = (gen, [p for p in proj.parameters()])
         d["_engine_params"] = cached
     return cached
+
+
+def plan_sig(proj):
+    """What a plan has baked in as ADDRESSES: identity of the module, generation of its parameter list, every parameter's storage
+    pointer, the generation of the cached device tables (bumped when one is reallocated), the clip-scale logits."""
+    gen, params = _param_list(proj)
+    acc = 0
+    for p in params:
+        acc += p.data_ptr()
+    gc = proj.global_compressor
+    return (id(proj), gen, acc, 0 if gc is None else gc._cache_gen, proj.local_logit, proj.global_logit)
+
+
+def content_sig(proj):
+    """Weight CONTENT state: in-place version counters + the global weights epoch (training forwards,
+    invalidate_weight_caches()).  When it moves, the weight-derived device caches are re-run IN PLACE and the plan stays."""
+    _, params = _param_list(proj)
+    acc = 0
+    for p in params:
+        acc += p._version
+    return (acc, nv.weights_epoch())
 
 
 def weights_sig(proj):
@@ -261,7 +284,15 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
            (ff.data_ptr(), _p(fe), _p(guide), _p(nl), _p(ll)) if graph else None, ll is not None)
     plans = proj.__dict__.setdefault("_engine_plans", {})
     plan = plans.get(key)
-    sig = weights_sig(proj)
+    sig = plan_sig(proj)
+    if plan is not None and plan.sig == sig:
+        fresh = content_sig(proj)
+        if plan.fresh != fresh:
+            # the weights changed under a plan whose addresses are all still valid (an optimizer step): re-run the producers of
+            # the weight-derived tables into their existing buffers instead of rebuilding the plan
+            plan.refresh()
+            sig = plan_sig(proj)                   # (a table that had to be reallocated bumps the cache generation)
+            plan.fresh = fresh
     if plan is not None and plan.sig != sig:
         plans.pop(key)
         plan = None
@@ -284,10 +315,22 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
                                           "partition the grid; see hicom_fused_stream_fwd in include/hicom_hip.h)")
         ws = attach_execution(a, dev, res=res)
         a._keep = None                 # the plan does not pin the caller's tensors: their pointers are patched per call
-        sig = weights_sig(proj)        # (build_args may have (re)built the cached positional tables)
+        sig = plan_sig(proj)           # (build_args may have (re)built the cached positional tables)
         if len(plans) >= _MAX_PLANS:
             _evict_one(plans)
         plan = plans[key] = _Plan(a, ws, n_local + n_global, hidden, sig, res)
+        plan.fresh = content_sig(proj)
+        use_gc0 = bool(a.gc0)
+
+        def refresh(lc=lc, gc=gc, T=T, H=H, W=W, dev=dev, use_gc0=use_gc0):
+            if lc is not None:
+                lc.readout_f16()
+            if gc is not None:
+                if gc.use_pos_emb:
+                    gc.pos_and_kpe(T, H, W, dev)
+                if use_gc0:
+                    gc.readout_over_out_proj()
+        plan.refresh = refresh
     plan.hits += 1
     a = plan.args
     # per-call pointers

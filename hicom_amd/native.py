@@ -400,7 +400,7 @@ _F16_MAX = 65504.0
 _RANGE_CHECKED = set()
 
 
-def f16_weight_copy(w, ld=None):
+def f16_weight_copy(w, ld=None, out=None):
     """fp16 copy of a bf16 weight for the fp16-operand GEMMs.  bf16 -> fp16 is exact for 2^-14 <= |w| < 65504; smaller
     magnitudes land on fp16 subnormals (absolute error <= 2^-25 = 3e-8) and larger ones would saturate, so the range is
     checked ONCE per weight storage (one device reduction + host read when the copy is first built; rebuilds of the same
@@ -415,13 +415,18 @@ def f16_weight_copy(w, ld=None):
         if len(_RANGE_CHECKED) > 4096:
             _RANGE_CHECKED.clear()
         _RANGE_CHECKED.add(key)
-    return to_f16(w) if ld is None else to_f16_padded(w, ld)
+    # out: a previous copy of the same shape is refreshed IN PLACE (its address is baked into executor plans: a training step
+    # then re-runs the cast, not the plan build)
+    if out is not None and (out.dtype != torch.float16 or tuple(out.shape) != ((w.shape[0], ld) if ld is not None else tuple(w.shape))):
+        out = None
+    return to_f16(w, out) if ld is None else to_f16_padded(w, ld, out)
 
 
-def to_f16_padded(src, ld):
+def to_f16_padded(src, ld, dst=None):
     """fp16 copy of a [rows, cols] bf16 / f32 matrix with its rows zero-padded to `ld` columns (K padding of a GEMM operand)."""
     rows, cols = src.shape
-    dst = torch.empty((rows, ld), dtype=torch.float16, device=src.device)
+    if dst is None:
+        dst = torch.empty((rows, ld), dtype=torch.float16, device=src.device)
     _check(lib().hicom_to_f16_padded_fwd(_ptr(src), _dt(src), rows, cols, _ptr(dst), ld, _stream()), "hicom_to_f16_padded_fwd")
     return dst
 

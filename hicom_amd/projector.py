@@ -365,7 +365,8 @@ class LocalCompressor(nn.Module):
         stamp = nv.weight_stamp(w0, w2)
         hit = self.__dict__.get("_f16_cache")
         if hit is None or hit[0] != stamp:
-            hit = (stamp, nv.f16_weight_copy(w0), nv.f16_weight_copy(w2))
+            old = hit or (None, None, None)                  # refreshed in place where the shapes allow: plans keep their pointers
+            hit = (stamp, nv.f16_weight_copy(w0, out=old[1]), nv.f16_weight_copy(w2, out=old[2]))
             self.__dict__["_f16_cache"] = hit
         return hit[1], hit[2]
 
@@ -453,11 +454,13 @@ class GlobalCompressor(nn.Module):
         stamp = nv.weight_stamp(wk)
         hit = self._pe_cache.get(key)
         if hit is None or hit[1] != stamp:
-            kpe = _f32((self.embed_dim, pe.shape[0]), device)
+            reuse = hit is not None and tuple(hit[0].shape) == (self.embed_dim, pe.shape[0])
+            kpe = hit[0] if reuse else _f32((self.embed_dim, pe.shape[0]), device)      # in place: plans keep their pointers
             nv.linear(wk.detach(), pe, None, kpe)
             hit = (kpe, stamp)
             self._pe_cache[key] = hit
-            self._cache_gen += 1
+            if not reuse:
+                self._cache_gen += 1
         return pe, hit[0], cap
 
     def readout_over_out_proj(self):
@@ -470,7 +473,8 @@ class GlobalCompressor(nn.Module):
         stamp = nv.weight_stamp(g0, wo)
         hit = self._pe_cache.get("gc0")
         if hit is None or hit[1] != stamp:
-            c = _f32((g0.shape[0], wo.shape[1]), g0.device)
+            reuse = hit is not None and tuple(hit[0].shape) == (g0.shape[0], wo.shape[1]) and hit[0].device == g0.device
+            c = hit[0] if reuse else _f32((g0.shape[0], wo.shape[1]), g0.device)          # in place: plans keep their pointers
             wot = wo.detach().t().contiguous()
             if g0.shape[1] % 64 == 0:
                 nv.dense16_gemm(g0.detach(), wot, None, y=c)                   # C[n, e] = sum_k G0[n, k] W_o[k, e]: bf16 x bf16
@@ -478,7 +482,8 @@ class GlobalCompressor(nn.Module):
                 nv.linear(g0.detach(), wot, None, c)
             hit = (c, stamp)
             self._pe_cache["gc0"] = hit
-            self._cache_gen += 1
+            if not reuse:
+                self._cache_gen += 1
         return hit[0]
 
     def pos_planes(self, t_cap: int, H: int, W: int, device):

@@ -226,3 +226,35 @@ def test_sharded_forward_refuses_recipes_it_cannot_patch():
     m.local_use_clip_scale = True
     with torch.no_grad(), pytest.raises(RuntimeError):
         sharded_forward(m, dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g), 8)
+
+
+def test_inplace_weight_update_refreshes_derived_tables_under_the_same_plan():
+    """An optimizer step changes weight CONTENT, not addresses: the executor plan survives, and the weight-derived device tables it
+    points at (fp16 readout copies, kpe = W_k . PE^T, C = G0 . W_o) are re-run in place -- the next forward equals the forward of a
+    freshly built module holding the updated weights, for an in-place update (version counter) and for a `p.data.copy_` write
+    followed by invalidate_weight_caches() (no counter)."""
+    import hicom_amd
+    m, _, case = _module_and_sd("G1_direct_T8")
+    ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+    names = ("local_compressor.readout.0.weight", "global_compressor.attn_layer.k_proj.weight",
+             "global_compressor.attn_layer.out_proj.weight", "global_compressor.readout.0.weight")
+    params = dict(m.named_parameters())
+    with torch.no_grad():
+        m(ff, fe, g, "video", None)
+        plan = next(iter(m.__dict__["_engine_plans"].values()))
+        for step, bypass in enumerate((False, True)):
+            for n in names:
+                new = (params[n].float() * (1.0 + 0.25 * (step + 1))).to(torch.bfloat16)
+                if bypass:
+                    params[n].data.copy_(new)                                  # no version bump (DeepSpeed's flat alias writes like this)
+                else:
+                    params[n].copy_(new)
+            if bypass:
+                hicom_amd.invalidate_weight_caches()
+            got = m(ff, fe, g, "video", None)
+            assert next(iter(m.__dict__["_engine_plans"].values())) is plan    # same plan, same workspace, same table addresses
+            case2 = cases.build_case("G1_direct_T8")
+            fresh = build_module(case2)
+            fresh.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
+            want = fresh(ff, fe, g, "video", None)
+            assert torch.equal(got, want), (step, float((got.float() - want.float()).abs().max()))

@@ -7,6 +7,7 @@ import bench
 dev = torch.device("cuda:0")
 cfg = bench.release_config(896, 64)
 m = bench.make_projector(cfg, dev).train()
+m.graph_backward = os.environ.get("GRAPH_BWD", "0") == "1"
 gen = torch.Generator(device=dev).manual_seed(1)
 ff = torch.randn(64, 27, 27, 1152, device=dev, generator=gen).to(torch.bfloat16)
 fe = torch.randn(64, 27, 27, 1152, device=dev, generator=gen).to(torch.bfloat16)
@@ -41,6 +42,9 @@ for o in outs:
     o.backward(cot)
 torch.cuda.synchronize()
 print(f"backward {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms")
+if m.graph_backward:
+    print("captured:", "graph" in next(iter(m.__dict__.get("_bwd_graphs", {}).values()), {}))
+    sys.exit(0)
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     for _ in range(5):
