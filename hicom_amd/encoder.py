@@ -98,32 +98,32 @@ class _HeadFn(torch.autograd.Function):
             nv.ln_stream(x2, ln.weight.detach(), ln.bias.detach(), n16, eps=ln.eps)
             h1 = torch.empty((M, ld), dtype=torch.float16, device=x.device)
             nv.dense16_gemm(n16, w1, fc1.bias.detach(), act=nv.ACT_NONE, out_f16=h1, n_store=kpad)
-            h1 = h1[:, :inter].float()
-            a = torch.nn.functional.gelu(h1, approximate="tanh" if hidden_act == "gelu_pytorch_tanh" else "none")
+            # the [M, inter] tensors (0.4 GB each in bf16 at 64 frames) are touched as few times as possible: one cast of the
+            # pre-activation, one fused GELU, one fused GELU-backward (fp32 math inside, bf16 in / out), fp32 only in the reductions
+            approx = "tanh" if hidden_act == "gelu_pytorch_tanh" else "none"
+            h1b = h1[:, :inter].to(torch.bfloat16)
+            del h1
+            a_b = torch.nn.functional.gelu(h1b, approximate=approx)
             # ---- fc2: dW2 = dY^T a, db2, d a = dY W2 --------------------------------------------------------------------------
             dYb = dY.to(torch.bfloat16)
             grads = {}
-            grads["mlp.fc2.weight"] = _mm_f32(dYb.t(), a.to(torch.bfloat16))
-            grads["mlp.fc2.bias"] = dY.float().sum(0)
+            grads["mlp.fc2.weight"] = _mm_f32(dYb.t(), a_b)
+            grads["mlp.fc2.bias"] = dY.sum(0, dtype=torch.float32)
+            del a_b
             w2t = fc2.weight.detach().t().contiguous()                      # [inter, D] bf16: the NT form's "weight"
-            da = torch.empty((M, inter), dtype=torch.float32, device=x.device)
             if D % 64 == 0 and inter % 8 == 0:
+                da = torch.empty((M, inter), dtype=torch.bfloat16, device=x.device)
                 nv.dense16_gemm(dYb, w2t, None, y=da)                        # HIP: bf16 x bf16, fp32 accumulate
             else:
-                da = dYb.float() @ fc2.weight.detach().float()
+                da = torch.mm(dYb, fc2.weight.detach())
             # ---- activation, fc1: dW1 = dh1^T n, db1, d n = dh1 W1 ---------------------------------------------------------------
-            if hidden_act == "gelu_pytorch_tanh":
-                u = 0.7978845608028654 * (h1 + 0.044715 * h1 ** 3)
-                th = torch.tanh(u)
-                dact = 0.5 * (1.0 + th) + 0.5 * h1 * (1.0 - th * th) * 0.7978845608028654 * (1.0 + 3 * 0.044715 * h1 * h1)
-            else:
-                dact = 0.5 * (1.0 + torch.erf(h1 * 0.7071067811865476)) + h1 * torch.exp(-0.5 * h1 * h1) * 0.3989422804014327
-            dh1 = da * dact
-            dh1b = dh1.to(torch.bfloat16)
+            dh1b = torch.ops.aten.gelu_backward(da, h1b, approximate=approx)
+            del da, h1b
             nb = n16.to(torch.bfloat16)
             grads["mlp.fc1.weight"] = _mm_f32(dh1b.t(), nb)
-            grads["mlp.fc1.bias"] = dh1.sum(0)
+            grads["mlp.fc1.bias"] = dh1b.sum(0, dtype=torch.float32)
             dn = _mm_f32(dh1b, fc1.weight.detach())                         # [M, D]
+            del dh1b
             # ---- LayerNorm affine: n = nhat gamma + beta ---------------------------------------------------------------------------
             xf = x2.float()
             mu = xf.mean(-1, keepdim=True)
