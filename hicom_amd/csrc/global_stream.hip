@@ -297,23 +297,32 @@ __global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Wide form for many query rows (guide off: 32 queries x 9 heads = 288 folded rows).  The kernel above gives
-// every 16-row group its own pass over the token stream (18 passes = 1.9 GB through the memory system), has one
-// tile of prefetch and does the positional lookups by division and global loads in the compute path: ~6 us per
-// 16-token tile.  Here a 512-thread workgroup (one per CU) owns RG = 2 row groups: waves 0-3 and waves 4-7 are two
-// copies of the 4-wave machine above working on the SAME LDS tile, so the stream is read half as often; the ring is
-// three tiles deep with counted vmcnt (waves 0-3 issue the DMA), the positional tables of the 32 rows sit in LDS
-// (frames this workgroup's tokens can touch | rows | columns) with the tile's token coordinates tabled once per
-// tile by an otherwise idle lane group, and P.x uses one K = 32 MFMA per 16-channel block (P hi | lo against the
-// fragment twice).
-// ---------------------------------------------------------------------------------------------
 constexpr int kWideRG = 2;
-constexpr int kWideBuf = 3;
 constexpr int kWideFrames = 8;      // frames a workgroup's token range may touch
 
+// ---------------------------------------------------------------------------------------------
+// Wide form for many query rows (guide off / coarse / fine: 32 queries x 9 heads = 288 folded rows).  The narrow kernel above gives
+// every 16-row group its own pass over the token stream (18 passes = 1.9 GB through the memory system).  Here a 512-thread
+// workgroup (one per CU) owns RG = 2 row groups: waves 0-3 and waves 4-7 are two copies of the 4-wave machine above working on
+// the SAME LDS tile, so the stream is read half as often; three-tile ring (waves 0-3 issue the DMA), the positional tables of the
+// 32 rows in LDS (frames this workgroup's tokens can touch | rows | columns) with the tile's token coordinates tabled once per
+// tile by an otherwise idle lane group, P.x with one K = 32 MFMA per 16-channel block (P hi | lo against the fragment twice).
+// Software-pipelined (round 3): the round-2 form spent a tile as a serial chain
+//   [A] -> score MFMAs -> partial store -> [B] -> exchange / positional lookups / softmax (VALU) -> P.x MFMAs -> [A]
+// with every wave of the workgroup in lock-step (262 us alone at C2).  Here an iteration holds the work of TWO tiles that do not
+// depend on each other: the score MFMAs of tile i + 1 are issued first and run in the matrix pipe while the same wave's VALU does
+// the exchange / softmax of tile i, then P.x of tile i; the partial logits of tile i + 1 go to the OTHER half of a double-
+// buffered exchange area at the end.  ONE barrier per tile: it publishes the partials of tile i + 1 and the DMA'd tile i + 2
+// (the loading waves wait for their pieces right before it) and retires tile i's buffer, which the next iteration restages.
+// Same ring depth (3 tiles: P.x | scores | in flight), same results bit for bit (same operations in the same order per row):
+// 239 us alone, guide-off forward 414 -> 392 us.  A four-buffer form (two tiles in flight; fits the 160 KiB at 27 x 27 by 128
+// bytes, exchange area single-buffered behind a second barrier) measured the same (242 us) and is not kept: what remains is the
+// latency chain of a tile's softmax inside a wave (LDS exchange -> positional lookups -> max / exp / sum -> hi/lo split -> transposed
+// reads -> P.x) with two waves per SIMD to hide it.
+// ---------------------------------------------------------------------------------------------
 template <int NB>
 __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams p) {
+    constexpr int NBUF = 3, NRED = 2;
     constexpr int E = NB * 128;
     constexpr int SLICE = E / 4;
     constexpr int KSTEPS = SLICE / 32;
@@ -324,10 +333,10 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
     constexpr int RG = kWideRG;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* tilebuf = smem;                                                    // [kWideBuf][TILE_BYTES]
-    float* red = reinterpret_cast<float*>(smem + kWideBuf * TILE_BYTES);    // [RG][4 waves][16 rows][16 tokens]
-    int* tokpos = reinterpret_cast<int*>(red + RG * 4 * 256);               // [16] packed (frame - f_first) << 16 | y << 8 | x of this tile's tokens
-    float* postab = reinterpret_cast<float*>(tokpos + 16);                   // [RG * 16][kWideFrames + H + W]
+    char* tilebuf = smem;                                                    // [NBUF][TILE_BYTES]
+    float* red = reinterpret_cast<float*>(smem + NBUF * TILE_BYTES);        // [NRED][RG][4 waves][16 rows][16 tokens]
+    int* tokpos = reinterpret_cast<int*>(red + NRED * RG * 4 * 256);        // [2][16] packed (frame - f_first) << 16 | y << 8 | x
+    float* postab = reinterpret_cast<float*>(tokpos + 32);                   // [RG * 16][kWideFrames + H + W]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -380,39 +389,19 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
             long tok = (long)tile * 16 + row;
             tok = tok < p.N ? tok : p.N - 1;
             const char* src = reinterpret_cast<const char*>(p.x) + tok * (long)(E * 2) + blk * 256 + 16 * (cpos ^ swz(row));
-            // Issued as inline asm: the compiler then does not know about the outstanding LDS writes and does not put
-            // "s_waitcnt vmcnt(0)" in front of the next LDS read it cannot tell apart from them (which drained the
-            // whole prefetch once per tile).  Ordering is this kernel's own: counted vmcnt + barrier [A].
             const unsigned dst = tile_lds + buf * TILE_BYTES + pi * 1024;          // wave-uniform LDS base of the piece
-            // M0 (the DMA's LDS base) is compiler-reserved and not preserved around an asm statement: save it, write it
-            // and restore it inside ONE statement (cdna_hip_programming.md §5.7, "Operands and clobbers")
             unsigned keep_m0;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep_m0) : "v"(src), "s"(dst) : "memory");
         }
     };
-
     const int q4 = (lane >> 2) & 3, pp = lane & 3;
     const int trow = 4 * sig(kg) + q4;
     const int rd_row_off = r16 * 256, rd_swz = swz(r16);
     const int tr_row_off = trow * 256 + 8 * (pp & 1), tr_swz = swz(trow);
 
-    if (tb < te) stage(tb, 0);
-    if (tb + 1 < te) stage(tb + 1, 1);
-    __syncthreads();                                   // positional tables (the DMA is not waited for here: vmcnt below)
-
-    for (int tile = tb; tile < te; ++tile) {
-        const int cur = (tile - tb) % kWideBuf;
-        // tile `tile` has landed (the younger tile may stay in flight; the score stores of the previous tile are
-        // younger than its pieces as well), every wave is done with the buffer two tiles back and with `red`
-        if (tile + 1 < te) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (tile + 2 < te) stage(tile + 2, (tile + 2 - tb) % kWideBuf);
-        const char* img = tilebuf + cur * TILE_BYTES;
-
-        // ---- partial scores of this wave's row group over its channel slice ----
+    // partial scores of this wave's row group over its channel slice, for the tile in `img` (MFMAs only: nothing waits here)
+    auto scores_of = [&](const char* img) {
         f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
@@ -422,12 +411,14 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
             s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[s], b, s4, 0, 0, 0);
             s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[s], b, s4, 0, 0, 0);
         }
+        return s4;
+    };
+    // publish the partials of `tile` (half `h` of the exchange area) and its token coordinates
+    auto publish = [&](const f32x4& s4, int tile, int h) {
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // MFMA -> VALU read (see fused_ring.hip)
-        {
-            float* rw = red + (grp * 4 + wave) * 256;
+        float* rw = red + (h * RG * 4 + grp * 4 + wave) * 256;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rw[(4 * kg + j) * 16 + r16] = s4[j];
-        }
+        for (int j = 0; j < 4; ++j) rw[(4 * kg + j) * 16 + r16] = s4[j];
         if (p.pos_a && wave8 == 7 && lane < 16) {
             long nn = (long)tile * 16 + lane;
             nn = nn < p.N ? nn : p.N - 1;
@@ -436,21 +427,47 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
             const unsigned y = rem / (unsigned)p.W, xx = rem - y * (unsigned)p.W;
             unsigned tf = t - f_first;
             tf = tf < (unsigned)kWideFrames ? tf : kWideFrames - 1;             // (only masked tail tokens clamp)
-            tokpos[lane] = (int)((tf << 16) | (y << 8) | xx);
+            tokpos[16 * h + lane] = (int)((tf << 16) | (y << 8) | xx);
         }
-        lds_barrier();   // [B]
+    };
+    // the loading waves' pieces of the youngest staged tile have landed (nothing may stay in flight across the barrier: the next
+    // iteration's scores read that tile), then the workgroup barrier
+    auto fence = [&]() {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
 
+    if (tb < te) stage(tb, 0);
+    if (tb + 1 < te) stage(tb + 1, 1);
+    __syncthreads();                                   // positional tables
+    fence();                                           // tiles tb, tb + 1 landed
+    if (tb < te) {
+        const f32x4 s0 = scores_of(tilebuf);
+        publish(s0, tb, 0);
+    }
+    fence();                                           // partials of tile tb published
+
+    for (int tile = tb; tile < te; ++tile) {
+        const int k = tile - tb, cur = k % NBUF, h = k & 1;
+        const bool more = tile + 1 < te;
+        if (tile + NBUF - 1 < te) stage(tile + NBUF - 1, (k + NBUF - 1) % NBUF);     // into the buffer of tile - 1 (retired by the barrier just passed)
+        const char* img = tilebuf + cur * TILE_BYTES;
+        // ---- scores of tile + 1: issued now, needed at the end of the iteration ----
+        f32x4 sn = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (more) sn = scores_of(tilebuf + ((k + 1) % NBUF) * TILE_BYTES);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- exchange / positional terms / online softmax of THIS tile (VALU + LDS, under the MFMAs above) ----
         const long n0 = (long)tile * 16 + 4 * sig(kg);
-        const float* rb = red + grp * 4 * 256 + r16 * 16 + 4 * sig(kg);
+        const float* rb = red + (h * RG * 4 + grp * 4) * 256 + r16 * 16 + 4 * sig(kg);
         f32x4 lg = *reinterpret_cast<const f32x4*>(rb);
         lg += *reinterpret_cast<const f32x4*>(rb + 256);
         lg += *reinterpret_cast<const f32x4*>(rb + 512);
         lg += *reinterpret_cast<const f32x4*>(rb + 768);
         if (p.pos_a) {
-            // (inline asm: hipcc drains vmcnt -- i.e. the tile prefetch -- in front of an LDS read it cannot tell apart
-            // from the LDS-DMA destinations)
             int4 v;
-            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(tokpos_lds + 16 * sig(kg)) : "memory");
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(tokpos_lds + 64 * h + 16 * sig(kg)) : "memory");
             const int tp[4] = {v.x, v.y, v.z, v.w};
             const float* pr_ = postab + (grp * 16 + r16) * S;
 #pragma unroll
@@ -476,10 +493,10 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
         bf16x8 pw;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            uint16_t h, l;
-            split_bf16(pr[j], h, l);
-            pw[j] = (short)h;
-            pw[4 + j] = (short)l;
+            uint16_t hh, ll;
+            split_bf16(pr[j], hh, ll);
+            pw[j] = (short)hh;
+            pw[4 + j] = (short)ll;
         }
         if (__any(alpha != 1.0f)) {
             const float a0 = __shfl(alpha, 4 * kg + 0, 64), a1 = __shfl(alpha, 4 * kg + 1, 64);
@@ -489,6 +506,8 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
                 acc[cb][0] *= a0; acc[cb][1] *= a1; acc[cb][2] *= a2; acc[cb][3] *= a3;
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- P.x of this tile ----
         const unsigned img_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(img);
         constexpr int PGW = (CBLK % 6 == 0) ? 6 : CBLK;      // transposed fragments in flight together
 #pragma unroll
@@ -510,6 +529,9 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // ---- hand the next tile's partials over ----
+        if (more) publish(sn, tile + 1, h ^ 1);
+        fence();                                         // (tile + 2, staged in this iteration, has landed: the next scores read it)
     }
 
     const long prow = (long)part * p.rows_pad + rg * 16;
@@ -591,7 +613,7 @@ static int global_stream_launch(const void* x, int64_t N, int32_t E,
     const char* force_narrow = getenv("HICOM_GLOBAL_NARROW");      // dev / test switch: always take the one-row-group kernel
     if (!inv_norm && !(force_narrow && force_narrow[0] == '1') && E == 1152 && rows_pad > 16 && rows_pad % (16 * kWideRG) == 0 && (!pos_a || (H <= 64 && W <= 64)) && span_ok) {
         const int S = kWideFrames + (pos_a ? H + W : 0);
-        const size_t smem = (size_t)kWideBuf * 9 * 4096 + (size_t)kWideRG * 4 * 1024 + 64 + (size_t)kWideRG * 16 * S * 4;
+        const size_t smem = (size_t)3 * 9 * 4096 + 2 * (size_t)kWideRG * 4 * 1024 + 128 + (size_t)kWideRG * 16 * S * 4;
         static bool wide_attr = false;
         if (!wide_attr) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(global_stream_wide_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
