@@ -190,6 +190,208 @@ __global__ __launch_bounds__(256) void local_attn_kernel(LocalParams p) {
     for (int c = tid; c < D; c += 256) out[c] = (part[c] + part[D + c]) + (part[2 * D + c] + part[3 * D + c]);
 }
 
+// ---- windowed attention with the adaptor blend fused into the row loads ("fused into the K/V tile load") -------
+// adapt_k / adapt_v (reference projector.py:533-534):  key_n = (1 - a_k) x_n + a_k (LN(y_n) gamma_k + beta_k)  with y = k_proj(x) from the
+// two dense GEMMs, likewise for the values.  The blended streams never exist: a wave that holds a token's x row and y row computes
+//   logit_n = (1 - a) q.x_n + a (rstd_n ((q gamma).y_n - mu_n sum(q gamma)) + q.beta)                      (four wave reductions)
+//   ctx     = (1 - a) sum_n p_n v_n + a (gamma (sum_n p_n rstd_n y_n - sum_n p_n rstd_n mu_n) + beta)       (two accumulators)
+// with mu_n, rstd_n the LayerNorm statistics of y_n over D (fp32, from the row in registers).  Saves, per adapted stream, the
+// LayerNorm-blend pass (107 MB fp16 + 107 MB bf16 read, 107 MB written) and costs one more 107-MB row read here.
+struct LocalAdaptParams {
+    const uint16_t* kx;        // key source tokens bf16 [N, D]
+    const _Float16* ky;        // k_proj(kx) fp16 [N, D] or NULL (no key adaptor: key = kx)
+    const uint16_t* kgamma; const uint16_t* kbeta; const void* kalpha;
+    const uint16_t* vx;        // value source tokens bf16 [N, D]
+    const _Float16* vy;        // v_proj(vx) fp16 [N, D] or NULL
+    const uint16_t* vgamma; const uint16_t* vbeta; const void* valpha;
+    int alpha_f32;
+    float eps;
+    const void* query;
+    int query_f32;
+    long query_stride;
+    hicom_axis at, ay, ax;
+    float scale, bias;
+    float* ctx;
+};
+
+template <int NV>
+__global__ __launch_bounds__(256) void local_attn_adapt_kernel(LocalAdaptParams p) {
+    constexpr int D = NV * 384;
+    extern __shared__ __attribute__((aligned(16))) float lsm[];
+    const int ks2 = p.ay.k * p.ax.k;
+    const int WIN = p.at.k * ks2;
+    float* sc = lsm;                              // [WIN] scores
+    float* part = lsm + ((WIN + 3) & ~3);         // [4][D] partial contexts (x part, then y part)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int win = blockIdx.x;
+    const int w1 = win % p.ax.nwin;
+    const int h1 = (win / p.ax.nwin) % p.ay.nwin;
+    const int t1 = win / (p.ax.nwin * p.ay.nwin);
+    const int t0 = axis_start(p.at, t1), y0 = axis_start(p.ay, h1), x0 = axis_start(p.ax, w1);
+    const int H = p.ay.n, W = p.ax.n;
+    auto scalar = [&](const void* a) { return p.alpha_f32 ? *reinterpret_cast<const float*>(a) : bf16_to_f32(*reinterpret_cast<const uint16_t*>(a)); };
+    const float ak = p.ky ? scalar(p.kalpha) : 0.f, av = p.vy ? scalar(p.valpha) : 0.f;
+
+    float q[NV][6];
+    if (p.query_f32) {
+        const float* qp = reinterpret_cast<const float*>(p.query) + (long)win * p.query_stride;
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) q[s][j] = qp[384 * s + 6 * lane + j];
+    } else {
+        load_row<NV>(reinterpret_cast<const uint16_t*>(p.query) + (long)win * p.query_stride, lane, q);
+    }
+    // q gamma_k (the query seen by the normalised y row), sum(q gamma_k), q . beta_k
+    float qg[NV][6];
+    float cg = 0.f, cb = 0.f;
+    if (p.ky) {
+        float g[NV][6], b[NV][6];
+        load_row<NV>(p.kgamma, lane, g);
+        load_row<NV>(p.kbeta, lane, b);
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                qg[s][j] = q[s][j] * g[s][j];
+                cg += qg[s][j];
+                cb = fmaf(q[s][j], b[s][j], cb);
+            }
+        cg = wave_sum(cg);
+        cb = wave_sum(cb);
+    }
+    auto token_of = [&](int i) -> long {
+        const int t2 = i / ks2, r = i - t2 * ks2;
+        const int h2 = r / p.ax.k, w2 = r - h2 * p.ax.k;
+        return ((long)(t0 + t2) * H + (y0 + h2)) * W + (x0 + w2);
+    };
+
+    // ---- phase 1: scores ---------------------------------------------------------------
+    for (int i0 = wave; i0 < WIN; i0 += 8) {      // 2 tokens (x row + y row each) in flight per wave
+        float kx[2][NV][6], ky[2][NV][6];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + 4 * u;
+            if (i < WIN) {
+                const long tok = token_of(i);
+                load_row<NV>(p.kx + tok * D, lane, kx[u]);
+                if (p.ky) load_row_f16<NV>(p.ky + tok * D, lane, ky[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + 4 * u;
+            if (i < WIN) {
+                float dx = 0.f, dy = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int s = 0; s < NV; ++s)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        dx = fmaf(q[s][j], kx[u][s][j], dx);
+                        if (p.ky) {
+                            dy = fmaf(qg[s][j], ky[u][s][j], dy);
+                            s1 += ky[u][s][j];
+                        }
+                    }
+                dx = wave_sum(dx);
+                float logit = dx;
+                if (p.ky) {
+                    dy = wave_sum(dy);
+                    const float mu = wave_sum(s1) * (1.0f / D);
+#pragma unroll
+                    for (int s = 0; s < NV; ++s)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) { const float d = ky[u][s][j] - mu; s2 = fmaf(d, d, s2); }
+                    const float rstd = 1.0f / sqrtf(wave_sum(s2) * (1.0f / D) + p.eps);
+                    logit = (1.0f - ak) * dx + ak * (rstd * (dy - mu * cg) + cb);
+                }
+                if (lane == 0) sc[i] = logit * p.scale + p.bias;
+            }
+        }
+    }
+    __syncthreads();
+    float mx = -3.0e38f;
+    for (int i = lane; i < WIN; i += 64) mx = fmaxf(mx, sc[i]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int i = lane; i < WIN; i += 64) sum += expf(sc[i] - mx);
+    const float inv_sum = 1.0f / wave_sum(sum);
+
+    // ---- phase 2: context ----------------------------------------------------------------
+    float accx[NV][6], accy[NV][6];
+    float smu = 0.f;                                // sum_n p_n rstd_n mu_n (identical in every lane)
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { accx[s][j] = 0.f; accy[s][j] = 0.f; }
+    for (int i0 = wave; i0 < WIN; i0 += 8) {
+        float vx[2][NV][6], vy[2][NV][6];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + 4 * u;
+            if (i < WIN) {
+                const long tok = token_of(i);
+                load_row<NV>(p.vx + tok * D, lane, vx[u]);
+                if (p.vy) load_row_f16<NV>(p.vy + tok * D, lane, vy[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + 4 * u;
+            if (i < WIN) {
+                const float pi = expf(sc[i] - mx) * inv_sum;
+                float w = 0.f;
+                if (p.vy) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int s = 0; s < NV; ++s)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) s1 += vy[u][s][j];
+                    const float mu = wave_sum(s1) * (1.0f / D);
+#pragma unroll
+                    for (int s = 0; s < NV; ++s)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) { const float d = vy[u][s][j] - mu; s2 = fmaf(d, d, s2); }
+                    const float rstd = 1.0f / sqrtf(wave_sum(s2) * (1.0f / D) + p.eps);
+                    w = pi * rstd;
+                    smu = fmaf(w, mu, smu);
+                }
+#pragma unroll
+                for (int s = 0; s < NV; ++s)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        accx[s][j] = fmaf(pi, vx[u][s][j], accx[s][j]);
+                        if (p.vy) accy[s][j] = fmaf(w, vy[u][s][j], accy[s][j]);
+                    }
+            }
+        }
+    }
+    // per-wave blend (linear in the accumulators, so the four waves' results simply add: the beta term once, by wave 0)
+    float out_[NV][6];
+    if (p.vy) {
+        float g[NV][6], b[NV][6];
+        load_row<NV>(p.vgamma, lane, g);
+        load_row<NV>(p.vbeta, lane, b);
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                out_[s][j] = (1.0f - av) * accx[s][j] + av * (g[s][j] * (accy[s][j] - smu) + (wave == 0 ? b[s][j] : 0.f));
+    } else {
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) out_[s][j] = accx[s][j];
+    }
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) part[wave * D + 384 * s + 6 * lane + j] = out_[s][j];
+    __syncthreads();
+    float* out = p.ctx + (long)win * D;
+    for (int c = tid; c < D; c += 256) out[c] = (part[c] + part[D + c]) + (part[2 * D + c] + part[3 * D + c]);
+}
+
 // ---- backward of the windowed attention (training path; stage 3 of the reference's script trains the
 // SigLIP head and the guide encoder too: train.py:717-726, so the gradients w.r.t. the KEY stream frames_embed and the query
 // are needed; frames_feature comes from the frozen tower body).  Per window, autograd through projector.py:550-553:
@@ -413,6 +615,37 @@ extern "C" int hicom_local_attn_fwd(const void* key, int32_t key_dt, const void*
     if (D == 1152) hipLaunchKernelGGL(local_attn_kernel<3>, dim3((unsigned)nwin), dim3(256), smem, s, p);
     else hipLaunchKernelGGL(local_attn_kernel<2>, dim3((unsigned)nwin), dim3(256), smem, s, p);
     return hicom_host::check_launch("local_attn");
+}
+
+extern "C" int hicom_local_attn_adapt_fwd(const void* key_x, const void* key_y, const void* k_gamma, const void* k_beta, const void* k_alpha,
+                                          const void* value_x, const void* value_y, const void* v_gamma, const void* v_beta, const void* v_alpha,
+                                          int32_t alpha_dt, float eps, int32_t D, hicom_axis at, hicom_axis ay, hicom_axis ax,
+                                          const void* query, int32_t query_dt, int64_t query_stride, float scale, float bias,
+                                          float* ctx, void* stream) {
+    HICOM_REQUIRE(key_x && value_x && query && ctx && (key_y || value_y), HICOM_EINVAL, "local_attn_adapt: NULL pointer / no adapted stream");
+    HICOM_REQUIRE(!key_y || (k_gamma && k_beta && k_alpha), HICOM_EINVAL, "local_attn_adapt: key adaptor parameters");
+    HICOM_REQUIRE(!value_y || (v_gamma && v_beta && v_alpha), HICOM_EINVAL, "local_attn_adapt: value adaptor parameters");
+    HICOM_REQUIRE(D == 1152 || D == 768, HICOM_EUNSUP, "local_attn_adapt: D=%d (only 1152 / 768)", D);
+    HICOM_REQUIRE(query_dt == HICOM_DT_BF16 || query_dt == HICOM_DT_F32, HICOM_EINVAL, "local_attn_adapt: query dtype");
+    HICOM_REQUIRE(alpha_dt == HICOM_DT_BF16 || alpha_dt == HICOM_DT_F32, HICOM_EINVAL, "local_attn_adapt: alpha dtype");
+    for (const hicom_axis* a : {&at, &ay, &ax}) {
+        HICOM_REQUIRE(a->n > 0 && a->k > 0 && a->nwin > 0 && a->nfull >= 0 && a->nfull <= a->nwin && a->k <= a->n,
+                      HICOM_EINVAL, "local_attn_adapt: bad axis n=%d k=%d nwin=%d nfull=%d", a->n, a->k, a->nwin, a->nfull);
+        const int last = axis_start(*a, a->nwin - 1);
+        HICOM_REQUIRE(last >= 0 && last + a->k <= a->n, HICOM_EINVAL, "local_attn_adapt: window runs off the axis");
+    }
+    const long win = (long)at.k * ay.k * ax.k;
+    HICOM_REQUIRE(win <= 4096, HICOM_EUNSUP, "local_attn_adapt: window of %ld tokens is too large", win);
+    const long nwin = (long)at.nwin * ay.nwin * ax.nwin;
+    HICOM_REQUIRE(nwin < (1L << 31), HICOM_EINVAL, "local_attn_adapt: too many windows");
+    LocalAdaptParams p{(const uint16_t*)key_x, (const _Float16*)key_y, (const uint16_t*)k_gamma, (const uint16_t*)k_beta, k_alpha,
+                       (const uint16_t*)value_x, (const _Float16*)value_y, (const uint16_t*)v_gamma, (const uint16_t*)v_beta, v_alpha,
+                       alpha_dt == HICOM_DT_F32, eps, query, query_dt == HICOM_DT_F32, (long)query_stride, at, ay, ax, scale, bias, ctx};
+    const size_t smem = (((size_t)win + 3) & ~(size_t)3) * 4 + 4 * (size_t)D * 4;
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 1152) hipLaunchKernelGGL(local_attn_adapt_kernel<3>, dim3((unsigned)nwin), dim3(256), smem, s, p);
+    else hipLaunchKernelGGL(local_attn_adapt_kernel<2>, dim3((unsigned)nwin), dim3(256), smem, s, p);
+    return hicom_host::check_launch("local_attn_adapt");
 }
 
 extern "C" int hicom_local_attn_bwd(const void* key, const void* value, int32_t D,

@@ -102,6 +102,23 @@ def _f16_weight(lin):
     return hit[1]
 
 
+def adapt_stream_y(x, mlp):
+    """MLP(x) over ALL tokens (the two dense GEMMs of adapt_k / adapt_v, ref :533-534): x bf16 [T,h,w,D] -> fp16 [N, D].  The
+    LayerNorm and the alpha blend that follow are fused into the window-attention kernel's row loads (hicom_local_attn_adapt_fwd)."""
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D).contiguous()
+    N = x2.shape[0]
+    w0, b0 = _wb(mlp[0])
+    w2, b2 = _wb(mlp[2])
+    if w0.shape[1] % 64 or w2.shape[1] % 64:
+        raise NotImplementedError("adapt_stream: widths must be multiples of 64")
+    hid = torch.empty((N, w0.shape[0]), dtype=torch.float16, device=x.device)
+    nv.dense16_gemm(x2, w0, b0, act=nv.ACT_GELU, out_f16=hid)
+    y = torch.empty((N, w2.shape[0]), dtype=torch.float16, device=x.device)
+    nv.dense16_gemm(hid, _f16_weight(mlp[2]), b2, out_f16=y)
+    return y
+
+
 def adapt_stream(x, mlp, norm, alpha):
     """(1 - a) x + a LN(MLP(x)) over ALL tokens (adapt_k / adapt_v, ref :533-534): x bf16 [T,h,w,D] -> fp16 [T,h,w,D].
     Two dense MFMA GEMMs (hicom_dense16_gemm_fwd: raw tokens x bf16 weights, then fp16 hidden x fp16 weights) and the

@@ -15,7 +15,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 # HICOM_NATIVE_LIB: dev override (instrumented builds from tools/); the product loads the in-tree library
 LIB_PATH = os.environ.get("HICOM_NATIVE_LIB") or os.path.join(HERE, "libhicom_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 DT_BF16, DT_F32, DT_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_GELU_TANH = 0, 1, 2
@@ -31,7 +31,7 @@ EXPORTS = (
     "hicom_global_stream_bwd", "hicom_readout16_gemm_fwd", "hicom_to_f16_fwd", "hicom_merge_vproj_fwd",
     "hicom_dense16_gemm_fwd", "hicom_ln_stream_fwd", "hicom_to_f16_padded_fwd", "hicom_clip_query_prep_fwd", "hicom_inv_norm_fwd",
     "hicom_global_stream_clip_fwd", "hicom_splice_rows_fwd", "hicom_splice_labels_fwd",
-    "hicom_query_prep_fwd", "hicom_query_prep_state_bytes", "hicom_partials_sum_fwd", "hicom_l2norm_stream_fwd",
+    "hicom_query_prep_fwd", "hicom_query_prep_state_bytes", "hicom_partials_sum_fwd", "hicom_l2norm_stream_fwd", "hicom_local_attn_adapt_fwd",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -131,6 +131,7 @@ def lib() -> C.CDLL:
                                          vp, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp]
     L.hicom_partials_sum_fwd.argtypes = [vp, i32, i64, vp, vp]
     L.hicom_l2norm_stream_fwd.argtypes = [vp, vp, i64, i32, vp]
+    L.hicom_local_attn_adapt_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32, vp, vp]
     L.hicom_clip_query_prep_fwd.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp]
     L.hicom_inv_norm_fwd.argtypes = [vp, i32, i64, vp, vp]
     L.hicom_global_stream_clip_fwd.argtypes = [vp, i64, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64,
@@ -201,6 +202,18 @@ def local_attn(key, value, axes, query, query_stride, scale, bias, l2norm, ctx):
     D = value.shape[-1]
     _check(lib().hicom_local_attn_fwd(_ptr(key), _dt(key), _ptr(value), _dt(value), D, axes[0], axes[1], axes[2], _ptr(query), _dt(query),
                                       query_stride, scale, bias, l2norm, _ptr(ctx), _stream()), "hicom_local_attn_fwd")
+
+
+def local_attn_adapt(key_x, key_y, k_norm, k_alpha, value_x, value_y, v_norm, v_alpha, axes, query, query_stride, scale, bias, ctx, eps=1e-6):
+    """Window attention with the adaptor blends fused into the row loads; key_y / value_y fp16 [N, D] or None (see include/hicom_hip.h)."""
+    D = value_x.shape[-1]
+    alpha = k_alpha if k_alpha is not None else v_alpha
+    _check(lib().hicom_local_attn_adapt_fwd(_ptr(key_x), _ptr(key_y), _ptr(k_norm.weight.detach()) if key_y is not None else None,
+                                            _ptr(k_norm.bias.detach()) if key_y is not None else None, _ptr(k_alpha) if key_y is not None else None,
+                                            _ptr(value_x), _ptr(value_y), _ptr(v_norm.weight.detach()) if value_y is not None else None,
+                                            _ptr(v_norm.bias.detach()) if value_y is not None else None, _ptr(v_alpha) if value_y is not None else None,
+                                            _dt(alpha), eps, D, axes[0], axes[1], axes[2], _ptr(query), _dt(query), query_stride,
+                                            scale, bias, _ptr(ctx), _stream()), "hicom_local_attn_adapt_fwd")
 
 
 def local_attn_bwd(key, value, axes, query, query_stride, scale, bias, dctx, dq, dkey=None):

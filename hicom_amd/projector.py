@@ -335,15 +335,34 @@ class LocalCompressor(nn.Module):
         else:
             scale, bias = 1.0 / math.sqrt(self.qk_dim), 0.0            # ref :551
         value = ff
+        # adaptors: the two dense GEMMs per stream, then -- unless a kernel-side normalisation is in play -- the LayerNorm + alpha
+        # blend fused into the window kernel's row loads (the blended streams are never written)
+        fuse_blend = (self.adapt_k or self.adapt_v) and l2norm == 0
+        ky = vy = None
         if self.adapt_k:                                               # ref :533
-            key = inj.adapt_stream(key, self.k_proj, self.k_norm, self.k_alpha)
+            if fuse_blend:
+                ky = inj.adapt_stream_y(key, self.k_proj)
+            else:
+                key = inj.adapt_stream(key, self.k_proj, self.k_norm, self.k_alpha)
         if self.adapt_v:                                               # ref :534
-            value = inj.adapt_stream(ff, self.v_proj, self.v_norm, self.v_alpha)
+            if fuse_blend:
+                vy = inj.adapt_stream_y(ff, self.v_proj)
+            else:
+                value = inj.adapt_stream(ff, self.v_proj, self.v_norm, self.v_alpha)
         ctx = _f32((nw, D), ff.device)
+
+        def attend(q, q_stride):
+            if fuse_blend:
+                nv.local_attn_adapt(key, ky, self.k_norm if ky is not None else None, self.k_alpha.detach() if ky is not None else None,
+                                    ff, vy, self.v_norm if vy is not None else None, self.v_alpha.detach() if vy is not None else None,
+                                    axes, q, q_stride, scale, bias, ctx,
+                                    eps=(self.k_norm if ky is not None else self.v_norm).eps)
+            else:
+                nv.local_attn(key, value, axes, q, q_stride, scale, bias, l2norm, ctx)
         if self.use_guide == "direct":                                 # query := guide for every window (:352-368)
             _require_bf16_cuda("guide_embed", guide_embed)
             q, _ = inj.inject(self.guide_injector, "direct", None, guide_n if guide_n is not None else guide_embed.contiguous())
-            nv.local_attn(key, value, axes, q.reshape(-1).contiguous(), 0, scale, bias, l2norm, ctx)
+            attend(q.reshape(-1).contiguous(), 0)
             return ctx, grid
         q = _f32((*grid, D), ff.device)                                # pooled per-window query (ref :539-540)
         nv.trilinear_pool(ff, q)
@@ -353,7 +372,7 @@ class LocalCompressor(nn.Module):
             _require_bf16_cuda("guide_embed", guide_embed)
             q, _ = inj.inject(self.guide_injector, self.use_guide, q.reshape(nw, D),
                               guide_n if guide_n is not None else guide_embed.contiguous())
-        nv.local_attn(key, value, axes, q.reshape(nw, D), D, scale, bias, l2norm, ctx)
+        attend(q.reshape(nw, D), D)
         return ctx, grid
 
     def readout_f16(self):

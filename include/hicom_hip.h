@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HICOM_ABI_VERSION 6
+#define HICOM_ABI_VERSION 7
 
 #define HICOM_OK         0
 #define HICOM_EINVAL    -1   /* bad argument (shape, alignment, NULL)        */
@@ -71,6 +71,17 @@ int hicom_local_attn_fwd(const void* key, int32_t key_dt, const void* value, int
                          const void* query, int32_t query_dt, int64_t query_stride,
                          float scale, float bias, int32_t l2norm,
                          float* ctx, void* stream);
+
+/* ---- windowed attention with the k / v adaptor blend fused into its row loads (projector.py:533-534 in front of :544-553) ----
+ *   key_n = (1 - a_k) key_x_n + a_k (LayerNorm_eps(key_y_n) k_gamma + k_beta),  key_y = k_proj(key_x) (the two dense GEMMs of the
+ *   adaptor MLP, fp16 [N, D]); likewise the values.  The blended streams are never materialised: logits and contexts are formed
+ *   from the x and y rows with the LayerNorm statistics computed on the row in registers.  key_y or value_y may be NULL (that stream
+ *   has no adaptor).  key_x / value_x bf16 [T,H,W,D]; gamma / beta bf16 [D]; alpha: device scalar (bf16 | f32).  No clip-scale. */
+int hicom_local_attn_adapt_fwd(const void* key_x, const void* key_y, const void* k_gamma, const void* k_beta, const void* k_alpha,
+                               const void* value_x, const void* value_y, const void* v_gamma, const void* v_beta, const void* v_alpha,
+                               int32_t alpha_dt, float eps, int32_t D, hicom_axis at, hicom_axis ay, hicom_axis ax,
+                               const void* query, int32_t query_dt, int64_t query_stride, float scale, float bias,
+                               float* ctx, void* stream);
 
 /* ---- backward of the windowed attention (training path; autograd through projector.py:550-553) ----------
  * For the reference's stage 3 (train.py:717-726: the SigLIP head and the guide encoder train too) the gradients
