@@ -693,3 +693,52 @@ def test_readout16_aux_gemv_f32_weights_and_row_output():
         tol = 2e-5 if dt == torch.float32 else 2 ** -8 * float(want2.abs().max())
         assert float((out[11].double().cpu() - want2).abs().max()) <= tol
     assert maxabs(o16, a16.double() @ w16.double().t()) <= 2 ** -10 * float((a16.double() @ w16.double().t()).abs().max())
+
+
+@pytest.mark.parametrize("which", ["both", "key", "value"])
+@pytest.mark.parametrize("T,H,W,kt,ks,shared_query", [(4, 6, 6, 4, 3, True), (7, 6, 9, 4, 3, False), (1, 4, 4, 1, 2, False)])
+def test_local_attn_adapt_matches_torch(T, H, W, kt, ks, shared_query, which):
+    """hicom_local_attn_adapt_fwd: the LayerNorm + alpha blend of the k / v adaptors (reference projector.py:533-534) fused into the
+    window attention's row loads, against the materialised blend in torch fp64 followed by the window attention of the oracle
+    geometry (exact and overlapping partitions, shared and per-window queries, either stream alone)."""
+    D = 1152
+    at, ay, ax = geo.axis_tiling(T, kt), geo.axis_tiling(H, ks), geo.axis_tiling(W, ks)
+    axes = tuple(nv.Axis(a.n, a.k, a.nwin, a.nfull) for a in (at, ay, ax))
+    nw = at.nwin * ay.nwin * ax.nwin
+    g = torch.Generator().manual_seed(T * 100 + H + (3 if which == "key" else 0))
+    kx = torch.randn(T, H, W, D, generator=g).to(torch.bfloat16)
+    vx = torch.randn(T, H, W, D, generator=g).to(torch.bfloat16)
+    ky = (torch.randn(T, H, W, D, generator=g) * 1.5 + 0.3).to(torch.float16)
+    vy = (torch.randn(T, H, W, D, generator=g) * 0.7 - 0.2).to(torch.float16)
+    norms = []
+    for _ in range(2):
+        n = torch.nn.LayerNorm(D, eps=1e-6)
+        with torch.no_grad():
+            n.weight.copy_(1 + 0.1 * torch.randn(D, generator=g)); n.bias.copy_(0.1 * torch.randn(D, generator=g))
+        norms.append(n.to(torch.bfloat16).cuda())
+    ak, av = torch.tensor([0.4]).to(torch.bfloat16).cuda(), torch.tensor([0.7]).to(torch.bfloat16).cuda()
+    q = (torch.randn(1 if shared_query else nw, D, generator=g)).to(torch.bfloat16 if shared_query else torch.float32)
+    use_k, use_v = which in ("both", "key"), which in ("both", "value")
+    ctx = torch.empty(nw, D, device="cuda")
+    scale = 1.0 / math.sqrt(D)
+    nv.local_attn_adapt(kx.cuda(), ky.cuda() if use_k else None, norms[0] if use_k else None, ak if use_k else None,
+                        vx.cuda(), vy.cuda() if use_v else None, norms[1] if use_v else None, av if use_v else None,
+                        axes, q.cuda().reshape(-1) if shared_query else q.cuda(), 0 if shared_query else D, scale, 0.0, ctx)
+    torch.cuda.synchronize()
+
+    def blend(x, y, n, a):
+        ln = torch.nn.functional.layer_norm(y.double(), (D,), n.weight.detach().double().cpu(), n.bias.detach().double().cpu(), 1e-6)
+        return (1 - float(a.float())) * x.double() + float(a.float()) * ln
+    K = blend(kx, ky, norms[0], ak) if use_k else kx.double()
+    V = blend(vx, vy, norms[1], av) if use_v else vx.double()
+    want = torch.empty(nw, D, dtype=torch.float64)
+    for w in range(nw):
+        t1, r = divmod(w, ay.nwin * ax.nwin)
+        h1, w1 = divmod(r, ax.nwin)
+        t0, y0, x0 = at.start(t1), ay.start(h1), ax.start(w1)
+        kw = K[t0:t0 + at.k, y0:y0 + ay.k, x0:x0 + ax.k].reshape(-1, D)
+        vw = V[t0:t0 + at.k, y0:y0 + ay.k, x0:x0 + ax.k].reshape(-1, D)
+        qq = q[0 if shared_query else w].double()
+        p = torch.softmax(kw @ qq * scale, 0)
+        want[w] = p @ vw
+    assert float((ctx.double().cpu() - want).abs().max()) <= 2e-4
