@@ -94,7 +94,8 @@ class MultiheadAttention(nn.Module):
             q2, k2, v2 = query[b].contiguous(), key[b].contiguous(), value[b].contiguous()
             if kv_len <= 64:
                 if logit_scale is not None:
-                    raise NotImplementedError("MultiheadAttention: clip-scale on the small-key path")
+                    raise NotImplementedError("MultiheadAttention: clip-scale on the <= 64-key path (the reference never passes it "
+                                              "there: fine injection calls fine_proj without logits, ref :391)")
                 qp, kp, vp = inj.linear_rows(q2, self.q_proj), inj.linear_rows(k2, self.k_proj), inj.linear_rows(v2, self.v_proj)
                 ao = _f32((q_len, self.embed_dim), q2.device)
                 nv.small_mha(qp, kp, vp, self.num_heads, ao)
@@ -102,10 +103,10 @@ class MultiheadAttention(nn.Module):
                 continue
             if key[b].data_ptr() != value[b].data_ptr() or key.shape != value.shape:
                 raise NotImplementedError("MultiheadAttention: long key streams take key is value (k_proj / v_proj folded)")
-            if logit_scale is not None:
-                raise NotImplementedError("MultiheadAttention: clip-scale normalises the PROJECTED keys (ref :184-186); "
-                                          "no HIP path yet")
-            ml, acc, _ = _stream_attention(self, k2, q2, None, 0, 0, 0, 0, 0)
+            # clip-scale (ref :184-191): queries and PROJECTED keys L2-normalised over the full width, logits * exp(logit_scale)
+            # (+ logit_bias, a per-row shift that the softmax cancels): the clip form of the streamed attention
+            ml, acc, _ = _stream_attention(self, k2, q2, None, 0, 0, 0, 0, 0,
+                                           clip=None if logit_scale is None else float(logit_scale))
             ctx = _f32(acc.shape, acc.device)
             nv.global_combine(ml.unsqueeze(0), acc.unsqueeze(0), ctx)
             wv, bv = _linear_params(self.v_proj)

@@ -77,6 +77,13 @@ def test_mha_forward_long_key_stream_branch(q_len, kv_len):
     want = orc.mha(q[0].float().cpu(), x[0].float().cpu(), x[0].float().cpu(), sd, "global_compressor.attn_layer", 9)
     assert out.shape == (1, q_len, E)
     assert float((out[0].cpu() - want).abs().max()) <= TOL
+    # clip-scale through the reference signature (ref :184-191): queries and PROJECTED keys L2-normalised, * exp(logit_scale) + bias
+    ls, lb = torch.tensor(1.5), torch.tensor(-2.0)
+    with torch.no_grad():
+        out_c, _ = att(q, x, x, logit_scale=ls.cuda(), logit_bias=lb.cuda())
+    torch.cuda.synchronize()
+    want_c = orc.mha(q[0].float().cpu(), x[0].float().cpu(), x[0].float().cpu(), sd, "global_compressor.attn_layer", 9, ls, lb)
+    assert float((out_c[0].cpu() - want_c).abs().max()) <= TOL
     att.return_fp32 = False
     with pytest.raises(NotImplementedError):
         att(q, x, x.clone())                                                 # long keys: key must BE value (folded projections)
