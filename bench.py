@@ -614,7 +614,7 @@ def secondary_sweep(args, device, ff, fe, guide):
         with torch.no_grad():
             dt, out = best_of(lambda: m(ff, fe, gd, "video", None))
         res[label] = {"ms_per_forward": dt * 1e3, "tokens_per_sec": out.shape[0] / dt, "note": "joined forwards, best of 3 batches of 10; " + note}
-        if ug in ("direct", "coarse"):
+        if True:
             # f4: one training step of this recipe (forward under autograd + recompute-based backward, hicom_amd/autograd.py)
             m.train()
             cot = torch.randn(out.shape, device=device, generator=gen).to(out.dtype)
