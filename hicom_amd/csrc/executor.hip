@@ -353,7 +353,7 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                                      a.l_bias, a.l2norm, F(w.ctx_local), sm));
         }
         if (a.has_global) {
-            CHK(query_prep(sg, false));
+            if (!a.reuse_queries) CHK(query_prep(sg, false));        // (guide off: weight-only, kept in the workspace across calls)
             CHK(hicom_global_stream_fwd(a.ff, w.N, a.E, ws + w.qhi, ws + w.qlo, w.R, w.rows_pad,
                                         a.pe ? F(w.pos_a) : nullptr, a.P, a.H, a.W, a.t_index0, a.y_index0, a.x_index0,
                                         F(w.scores), w.score_stride, F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, sg));

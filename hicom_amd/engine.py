@@ -291,6 +291,7 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
             # the weights changed under a plan whose addresses are all still valid (an optimizer step): re-run the producers of
             # the weight-derived tables into their existing buffers instead of rebuilding the plan
             plan.refresh()
+            plan.args.reuse_queries = 0            # guide off: the folded learnable queries are weight-derived too
             sig = plan_sig(proj)                   # (a table that had to be reallocated bumps the cache generation)
             plan.fresh = fresh
     if plan is not None and plan.sig != sig:
@@ -370,6 +371,8 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
     else:
         a.ev_join = res.ev_join.cuda_event
     nv.compressor_fwd(a)
+    if gc is not None and gc.use_guide in (None, "off") and not plan.fused:
+        a.reuse_queries = 1                            # q_proj + fold of the learnable queries: weight-only, they stay in the plan's workspace
     if deferred:
         # the side stream is still busy with the 32 global rows: it writes `out` and reads the guide (the residual of
         # out_proj) after this call has returned

@@ -15,7 +15,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 # HICOM_NATIVE_LIB: dev override (instrumented builds from tools/); the product loads the in-tree library
 LIB_PATH = os.environ.get("HICOM_NATIVE_LIB") or os.path.join(HERE, "libhicom_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 DT_BF16, DT_F32, DT_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_GELU_TANH = 0, 1, 2
@@ -82,7 +82,7 @@ class CompressorArgs(C.Structure):
         ("ev_merge", C.c_void_p), ("defer_join", C.c_int32), ("reserved_", C.c_int32),
         ("place_src", C.c_void_p), ("place_block_stride", C.c_int64), ("place_block_rows", C.c_int32), ("place_nblocks", C.c_int32),
         ("ev_done", C.c_void_p), ("stream_next", C.c_void_p),
-        ("gc0", C.c_void_p), ("local_logits", C.c_void_p),
+        ("gc0", C.c_void_p), ("local_logits", C.c_void_p), ("reuse_queries", C.c_int32),
     ]
 
 

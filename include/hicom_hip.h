@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HICOM_ABI_VERSION 7
+#define HICOM_ABI_VERSION 8
 
 #define HICOM_OK         0
 #define HICOM_EINVAL    -1   /* bad argument (shape, alignment, NULL)        */
@@ -517,6 +517,11 @@ typedef struct hicom_compressor_args {
     const float* gc0;
     /* local_logits: f32 [T*H*W] = frames_embed_n . guide per token, or NULL (release recipe only; see hicom_fused_stream_fwd) */
     const float* local_logits;
+    /* reuse_queries != 0 (generic recipes, guide off only): the folded queries / score-side positional table in the workspace are
+     * those of an earlier call with the SAME weights -- the injected queries are the learnable `query` parameter (IdentityMap,
+     * projector.py:586-587), so q_proj + fold are weight-only work like kpe -- and the two prep launches are skipped.  The caller
+     * clears it after a weight update. */
+    int32_t reuse_queries;
 } hicom_compressor_args;
 
 /* 1 when hicom_compressor_fwd takes the release-recipe (single streaming kernel) path for these arguments. */

@@ -265,3 +265,26 @@ def test_inplace_weight_update_refreshes_derived_tables_under_the_same_plan():
             fresh.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
             want = fresh(ff, fe, g, "video", None)
             assert torch.equal(got, want), (step, float((got.float() - want.float()).abs().max()))
+
+
+def test_guide_off_reuses_folded_learnable_queries_until_the_weights_change():
+    """Guide off: the injected queries are the learnable `query` parameter (IdentityMap, reference projector.py:586-587), so q_proj +
+    fold are weight-only work; the executor keeps them in the plan's workspace (hicom_compressor_args.reuse_queries) and redoes them
+    after a weight update.  Second call bit-identical to the first; after in-place updates of `query`, `q_proj` and `k_proj` the
+    result equals a freshly built module's."""
+    m, _, case = _module_and_sd("G2_off_T8")
+    ff, fe = dev_bf16(case.ff), dev_bf16(case.fe)
+    params = dict(m.named_parameters())
+    with torch.no_grad():
+        first = m(ff, fe, None, "video", None).clone()
+        plan = next(iter(m.__dict__["_engine_plans"].values()))
+        assert plan.args.reuse_queries == 1
+        assert torch.equal(m(ff, fe, None, "video", None), first)
+        for n in ("global_compressor.query", "global_compressor.attn_layer.q_proj.weight", "global_compressor.attn_layer.k_proj.weight"):
+            params[n].copy_((params[n].float() * 1.5).to(torch.bfloat16))
+        got = m(ff, fe, None, "video", None)
+        assert next(iter(m.__dict__["_engine_plans"].values())) is plan and plan.args.reuse_queries == 1
+        fresh = build_module(cases.build_case("G2_off_T8"))
+        fresh.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
+        want = fresh(ff, fe, None, "video", None)
+        assert torch.equal(got, want) and not torch.equal(got, first)
