@@ -751,6 +751,9 @@ class HIComProjector(nn.Module):
         """Same result, one C-ABI call per operator (anyres dict inputs; also the cross-check of the
         executor in the tests)."""
         lc, gc = self.local_compressor, self.global_compressor
+        if (lc is not None and gc is not None and not isinstance(frames_feature, dict) and getattr(self, "overlap_stages", True)
+                and not torch.cuda.is_current_stream_capturing()):
+            return self._forward_stepwise_two_streams(frames_feature, frames_embed, guide_embed, modal, image_newline)
         segments = []        # (ctx, layout) per local segment, in output order
         if lc is not None:
             if isinstance(frames_feature, dict):                                 # anyres image (ref :679-689)
@@ -786,6 +789,46 @@ class HIComProjector(nn.Module):
             gff = frames_feature["patch"].unsqueeze(0) if isinstance(frames_feature, dict) else frames_feature
             gc.forward_into(gff, guide_embed, self.global_logit_scale, out, row, self.global_logit_bias)
         return out
+
+
+def _two_stream_forward(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None):
+    """Dense input, both compressors: the local chain (pooled / injected queries, adaptors, window attention, readout GEMMs) on a
+    side stream beside the global chain (injected queries, streamed attention, merge, small linears) on the caller's stream -- the
+    two are independent until the rows are in `out` (reference :691-707), and each is a string of launch-latency-sized kernels
+    around one long one.  Same operators, same results as the one-stream form (`projector.overlap_stages = False`)."""
+    from . import engine
+    lc, gc = self.local_compressor, self.global_compressor
+    ff = frames_feature
+    _require_bf16_cuda("frames_feature", ff)
+    dev = ff.device
+    T, H, W, _ = ff.shape
+    at, ay, ax = lc.tilings(T, H, W, modal)
+    lay = self._layout((at.nwin, ay.nwin, ax.nwin), modal, image_newline is not None, False)
+    hidden = lc.readout[2].out_features
+    out = torch.empty((lay.n_rows + gc.num_queries, hidden), dtype=_out_dtype(self), device=dev)
+    res = engine._resources(dev)
+    main = torch.cuda.current_stream(dev)
+    res.ev_fork.record(main)
+    res.side.wait_event(res.ev_fork)
+    with torch.cuda.stream(res.side):
+        ctx, _ = lc.window_context(ff, frames_embed, guide_embed, modal, self.local_logit_scale, self.local_logit_bias)
+        lc.readout_into(ctx, out, 0, lay.nl_group)
+        if lay.newline_rows:
+            nl = image_newline.contiguous()
+            first = lay.newline_rows[0]
+            step = lay.newline_rows[1] - first if len(lay.newline_rows) > 1 else 1
+            nv.scatter_rows(nl.view(1, -1), out, first, len(lay.newline_rows), row_step=step)
+        res.ev_join.record(res.side)
+    # caller tensors and `out` are used on the side stream: keep the allocator from recycling them under it
+    for t in (ff, frames_embed, guide_embed, image_newline, out):
+        if isinstance(t, torch.Tensor):
+            t.record_stream(res.side)
+    gc.forward_into(ff, guide_embed, self.global_logit_scale, out, lay.n_rows, self.global_logit_bias)
+    main.wait_event(res.ev_join)
+    return out
+
+
+HIComProjector._forward_stepwise_two_streams = _two_stream_forward
 
 
 def build_vision_projector(config, delay_load=False, **kwargs):
