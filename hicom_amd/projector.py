@@ -175,7 +175,7 @@ def _linear_params(lin: nn.Linear):
     return lin.weight.detach(), (lin.bias.detach() if lin.bias is not None else None)
 
 
-def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i, clip=None, kpe_t=None):
+def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i, clip=None, kpe_t=None, kpe=None):
     """Streams the tokens x2 [N, E] (bf16) once against the folded queries of q_in [nq, E]: returns the un-normalised
     online-softmax state (ml [R,2], acc [R,E]), R = nq * heads (ref :180-215 restated).
 
@@ -208,16 +208,23 @@ def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i, clip=None, kpe_t=N
         nv.dense16_gemm(x2, wk, att.k_proj.bias.detach() if att.k_proj.bias is not None else None, ssq=ssq, row_tab=tab)
         inv = _f32((N,), dev)
         nv.inv_norm(ssq, inv)
-    else:
-        nv.fold_query(qp, wk, nh, att.scale, qt)
     qhi = torch.empty((rows_pad, E), dtype=torch.bfloat16, device=dev)
     qlo = torch.empty_like(qhi)
-    nv.split_bf16(qt, rows_pad, qhi, qlo)
     pos_a = None
-    if pe is not None:
-        pos_a = torch.zeros((rows_pad, pe.shape[0]), dtype=torch.float32, device=dev)
-        nv.linear(qt, pe, None, pos_a, M=R)                     # a[r, p] = qt[r] . PE[p]
+    if clip is None and R == rows_pad and (pe is None or kpe is not None):
+        # fold + hi/lo split + score-side positional table in ONE launch (kpe = W_k . PE^T is weight-only and cached); every row
+        # is written (no padding rows), so nothing needs zeroing
+        if pe is not None:
+            pos_a = _f32((rows_pad, pe.shape[0]), dev)
+        nv.fold_query_split(qp, wk, kpe if pe is not None else None, nh, att.scale, qhi, qlo, pos_a)
     else:
+        if clip is None:
+            nv.fold_query(qp, wk, nh, att.scale, qt)
+        nv.split_bf16(qt, rows_pad, qhi, qlo)
+        if pe is not None:
+            pos_a = torch.zeros((rows_pad, pe.shape[0]), dtype=torch.float32, device=dev)
+            nv.linear(qt, pe, None, pos_a, M=R)                 # a[r, p] = qt[r] . PE[p]
+    if pe is None:
         H, W = 1, N                                             # any factorisation of N: no positional terms
     nparts = nv.global_stream_nparts(N, rows_pad)
     stride = (N + 15) // 16 * 16
@@ -570,14 +577,15 @@ class GlobalCompressor(nn.Module):
         T, H, W, E = ff.shape
         pe = None
         t0i = y0i = x0i = 0
+        kpe = None
         if self.use_pos_emb:
-            pe, cap = self.pos_tables(t_offset + T, H, W, ff.device)
+            pe, kpe, cap = self.pos_and_kpe(t_offset + T, H, W, ff.device)
             t0i, y0i, x0i = t_offset, cap, cap + H
         clip, kpe_t = None, None
         if logit_scale is not None:
             clip = float(logit_scale)
             kpe_t = self.pos_kpe_t(t_offset + T, H, W, ff.device) if self.use_pos_emb else None
-        return _stream_attention(self.attn_layer, ff.view(T * H * W, E), q_in, pe, H, W, t0i, y0i, x0i, clip, kpe_t)
+        return _stream_attention(self.attn_layer, ff.view(T * H * W, E), q_in, pe, H, W, t0i, y0i, x0i, clip, kpe_t, kpe)
 
     def finish(self, ml_sets, acc_sets, q_in, out, row0: int, n_rows: int):
         """Combine shard states, apply v_proj per head, out_proj + residual, readout, and write
