@@ -385,6 +385,18 @@ def neighbours_sweep(args, device):
         out["siglip_head_projection"] = {"ms": dt * 1e3, "tflops": flops / dt / 1e12, "frac_of_dense_fp16_peak": flops / dt / 2.5e15,
                                          "workload": f"{x.shape[0]}x729 tokens, LayerNorm + 1152->4304->1152 MLP + residual (encoder.py:284-286)",
                                          "kernels": "ln_stream + 2 x dense16_gemm (fp16 operands, fp32 accumulate)"}
+        # the known-good reference on this hardware for the two GEMM shapes (cdna_hip_programming.md §5.4 rule 10): the vendor
+        # library through torch.mm, plain epilogue (no bias / GELU / residual / fp16 repack), same operand dtype
+        def vendor(M, N, K):
+            a = (torch.randn(M, K, device=device, generator=gen) * 0.5).to(torch.float16)
+            w = (torch.randn(N, K, device=device, generator=gen) * 0.03).to(torch.float16)
+            torch.mm(a, w.t())
+            dtv, _ = best(lambda: torch.mm(a, w.t()), n=5)
+            return 2.0 * M * N * K / dtv / 1e12
+        ntok = x.shape[0] * x.shape[1]
+        out["siglip_head_projection"]["vendor_gemm_reference_tflops"] = {
+            "fc1_shape_plain": vendor(ntok, 4352, D), "fc2_shape_plain": vendor(ntok, D, 4352),
+            "note": "torch.mm (hipBLASLt / rocBLAS) on the same shapes with NO epilogue: what the shapes (K = 1152, N = 1152) allow on this chip"}
         # stage 3 of the reference's script trains the head (train.py:717-720): forward under autograd + backward of the projection
         head.train()
         for p_ in head.parameters():
