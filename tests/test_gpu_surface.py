@@ -288,3 +288,23 @@ def test_guide_off_reuses_folded_learnable_queries_until_the_weights_change():
         fresh.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
         want = fresh(ff, fe, None, "video", None)
         assert torch.equal(got, want) and not torch.equal(got, first)
+
+
+@pytest.mark.parametrize("name", ["G6_coarse", "G7_fine", "G5_adaptkv"])
+def test_two_stream_stepwise_forward_is_bit_stable_and_equals_one_stream(name):
+    """The operator-by-operator path runs the local chain on a side stream beside the global chain (round 3).  Same operators, same
+    bits as the one-stream form, and 200 back-to-back forwards on two alternating input sets -- fresh output tensors every call, no
+    host synchronisation -- reproduce the first results exactly (a missing fence between the streams shows up here)."""
+    m, _, case = _module_and_sd(name)
+    sets = [(dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g))]
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    sets.append(tuple(torch.randn(t.shape, device="cuda", generator=gen).to(torch.bfloat16) for t in sets[0]))
+    with torch.no_grad():
+        m.overlap_stages = False
+        want = [m(a, b, c, case.modal, None).clone() for a, b, c in sets]
+        m.overlap_stages = True
+        bad = torch.zeros((), dtype=torch.int64, device="cuda")
+        for i in range(200):
+            a, b, c = sets[i & 1]
+            bad += (m(a, b, c, case.modal, None) != want[i & 1]).any()
+    assert int(bad) == 0
