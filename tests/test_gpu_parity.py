@@ -592,3 +592,24 @@ def test_release_step_is_bit_stable_over_back_to_back_launches(c2):
     assert int(bad) == 0
     for k in range(3):
         assert float((want_l[k].float() - want[k].float()).abs().max()) <= 2e-2          # bf16 outputs of two summation orders
+
+
+def test_large_video_local_tokens_are_frame_group_local(c2):
+    """256 frames (4x the benchmark; 860 MB of visual tokens): the local tokens of a 4-frame group depend on that group's frames only
+    (reference projector.py:544-558), whatever the partition of the windows over workgroups -- the first 1296 rows of the 256-frame
+    result equal the 64-frame result on the same frames (to 2e-4: two summation orders), the 32 global rows are 32 copies of one row (direct mode) and differ from
+    the 64-frame ones (they see all 256 frames)."""
+    m, ff, fe, g, _ = c2
+    gen = torch.Generator(device="cuda").manual_seed(29)
+    big_ff = torch.cat([ff] + [torch.randn(ff.shape, device="cuda", generator=gen).to(torch.bfloat16) for _ in range(3)])
+    big_fe = torch.cat([fe] + [torch.randn(fe.shape, device="cuda", generator=gen).to(torch.bfloat16) for _ in range(3)])
+    with torch.no_grad():
+        small = m(ff, fe, g, "video", None)
+        big = m(big_ff, big_fe, g, "video", None)
+    torch.cuda.synchronize()
+    assert big.shape == (256 // 4 * 81 + 32, small.shape[1]) and bool(torch.isfinite(big).all())
+    # (a window's 36 tokens fall into different 16-token tiles when a workgroup owns 21 windows instead of 6: the online softmax sums
+    # in another order -- an fp32 difference of ~1e-7 that the fp16 activation plane of the readout can turn into ~5e-5)
+    assert float((big[:1296].float() - small[:1296].float()).abs().max()) <= 2e-4
+    assert all(torch.equal(big[-32], big[-32 + k]) for k in range(1, 32))
+    assert not torch.equal(big[-32:], small[-32:])
