@@ -10,8 +10,7 @@ sys.path.insert(0, ROOT)
 LIB = "/tmp/libhicom_trace.so"
 if "HICOM_NATIVE_LIB" not in os.environ:
     from hicom_amd import build_native as bn
-    subprocess.check_call([bn.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-                           "-DHICOM_TRACE", "-o", LIB, *bn.sources()])
+    bn.build(extra_flags=("-DHICOM_TRACE",), lib_path=LIB, verbose=False)
     os.environ["HICOM_NATIVE_LIB"] = LIB
     sys.exit(subprocess.call([sys.executable, *sys.argv]))
 import numpy as np, torch
