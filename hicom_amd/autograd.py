@@ -330,15 +330,25 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
     graph launch.  Keyed by the addresses the captured kernels read (frames, guide, parameters) and by what is asked for; the
     upstream gradient is copied into a static buffer, the results are cloned out of the graph's pool (gradient accumulation adds
     into .grad in place: handing out the static buffers would alias them).  Falls back to the eager backward on any capture error."""
+    from . import engine
     cache = proj.__dict__.setdefault("_bwd_graphs", {})
     key = (ff.data_ptr(), tuple(ff.shape), None if fe is None else fe.data_ptr(), None if guide is None else guide.data_ptr(), modal,
-           tuple(dout.shape), dout.dtype, want, want_fe, want_guide, tuple(p.data_ptr() for p in proj.parameters()),
-           torch.cuda.current_stream(ff.device).cuda_stream)
+           tuple(dout.shape), dout.dtype, want, want_fe, want_guide, torch.cuda.current_stream(ff.device).cuda_stream)
+    # what else the captured kernels read by ADDRESS: every parameter's storage and the cached device tables (pe / kpe / planes:
+    # `_cache_gen` moves when one is reallocated -- T above the cached cap, a cleared cache, a device move).  A graph whose
+    # signature moved is dropped, never replayed over freed or reused memory.
+    sig = engine.plan_sig(proj)
     ent = cache.get(key)
+    if ent is not None and ent["sig"] != sig:
+        cache.pop(key)
+        ent = None
     if ent is None:                                                # first sight: eager (also the warm-up a capture needs)
         if len(cache) >= _MAX_BWD_GRAPHS:
             cache.pop(next(iter(cache)))
-        cache[key] = {"seen": 1}
+        gc = proj.global_compressor
+        # the entry keeps the buffers the graph will read alive: inputs and the cached tables (a recycled address must not pass
+        # for the tensor the graph was captured over)
+        cache[key] = {"seen": 1, "sig": sig, "refs": (ff, fe, guide, None if gc is None else dict(gc._pe_cache))}
         with torch.no_grad():
             return _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl)
     if "graph" not in ent:
@@ -351,6 +361,8 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
             g = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(g):
                 outs = _backward_outputs(static_dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl)
+            if engine.plan_sig(proj) != sig:                       # (the eager pass inside the capture reallocated a table)
+                raise RuntimeError("cached device tables moved during capture")
             ent.update(graph=g, dout=static_dout, outs=outs)
         except Exception as e:  # noqa: BLE001
             ent["failed"] = repr(e)

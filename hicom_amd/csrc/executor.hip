@@ -1,17 +1,23 @@
 // Native executor: ONE C call enqueues the whole compressor forward for a dense [T,H,W,E] input.
 //
-// The reference runs HIComProjector.forward (projector.py:676-708) as ~60 eager PyTorch ops on
-// one stream.  Here the forward is a fixed plan of <= 14 kernel launches over a caller-owned
-// workspace, issued from C++ (no per-op Python/ctypes/allocator cost) on TWO HIP streams:
+// The reference runs HIComProjector.forward (projector.py:676-708) as ~60 eager PyTorch ops on one stream.  Here the forward
+// is a fixed plan of kernel launches over a caller-owned workspace, issued from C++ (no per-op Python / ctypes / allocator cost).
 //
-//   main stream : local windowed attention -> readout GEMM 1 (GELU) -> readout GEMM 2 -> newline rows
-//   side stream : q_proj -> fold(+pos table, hi/lo split) -> MFMA token stream -> marginals -> merge
-//                 [-> combine of gathered shard states] -> per-head v_proj -> out_proj(+residual)
-//                 -> readout 1 (GELU) -> readout 2 -> 32 global rows
+// Release recipe (use_guide = direct, exact window partition; `can_fuse`): FIVE launches on ONE stream, no events --
 //
-// fork/join uses two caller-provided events, so the whole thing is hipGraph-capturable and keeps
-// no state inside the library.  Phases can be run separately (HICOM_PHASE_*) so that the
-// frame-sharded multi-GPU path can place its RCCL all-gather between them.
+//   query_prep (q_proj -> granule hand-off -> fold: folded queries hi/lo, score-side pos table, local query rows, r0)
+//   -> fused ring kernel (local windows + global attention: frames_embed and frames_feature each read once)
+//   -> merge + v_proj (online-softmax merge of the workgroups' partial states, per-head v_proj as slab partials)
+//   -> readout GEMM 1 (+ aux role: GELU(gc0 . o + r0), the global tail folded over out_proj)
+//   -> readout GEMM 2 (+ aux role: last global readout layer -> the 32 global rows)             [+ newline rows]
+//
+// Other recipes of the plain family (guide off, window overlap, several query rows) take the two-kernel form: local windowed
+// attention -> readout GEMMs on the main stream beside query prep -> MFMA token stream -> marginals / merge -> v_proj ->
+// out_proj (+ residual) -> readout on a side stream, forked / joined through two caller-provided events (hipGraph-capturable,
+// no state inside the library).  Recipes with adaptors (adapt_k / adapt_v: hicom_compressor_args.adapt) run the adaptor GEMMs
+// in front of the local stage inside the same call.
+// Phases can be run separately (HICOM_PHASE_*) so that the frame-sharded multi-GPU path can place its RCCL all-gather between
+// them (STREAM on the main stream, FINISH on the comm stream; MERGE_ON_NEXT puts the merge on the comm stream as well).
 #include <string.h>
 
 #include <stdlib.h>
@@ -48,7 +54,9 @@ bool can_fuse(const hicom_compressor_args& a) {
     const int wpw = (nw + nparts - 1) / nparts;
     // limits of fused_ring.hip: 160 KiB of LDS (ring 4 x 36 KiB + logit partials + tables), <= 32 windows
     // and <= 8 frames per workgroup, <= 1024 pos-emb table entries
-    if (4 * 9 * 4096 + 9 * 1024 + 8 * 80 * 4 + 8 * 64 + (64 + 32 + 65 + 32 + 16) * 4 + R * (8 + a.H + a.W) * 4 > 163840) return false;
+    // (+ the token-index tables of the precomputed-logits variant, as hicom_fused_stream_fwd adds them)
+    if (4 * 9 * 4096 + 9 * 1024 + 8 * 80 * 4 + 8 * 64 + (64 + 32 + 65 + 32 + 16) * 4 + R * (8 + a.H + a.W) * 4 +
+            (a.local_logits ? (32 + 64) * 4 : 0) > 163840) return false;
     if (R * (8 + a.H + a.W) > 1024) return false;
     // compact pos-emb slots a workgroup can touch: 8 frames + the grid rows and columns of its windows (<= 64)
     const int rows_t = ((wpw + a.ax.nwin - 2) / a.ax.nwin + 1) * a.ay.k, cols_t = wpw * a.ax.k;

@@ -49,7 +49,7 @@ struct PrepParams {
     int hidden;
     float* r0;                // [hidden]
     unsigned long long* gran; // [E] granules {tag << 32 | f32 bits}
-    unsigned* state;          // [0..1] 64-bit arrival counter, [2] spin give-ups (diagnostic)
+    unsigned* state;          // [0..1] 64-bit arrival counter, [2] failed hand-offs (sticky count), [3] grid size of the first launch
     int nq_wg, nr_wg, nf_wg, np_wg;      // workgroups per role, in block order: q_proj | r0 | fold-w | fold-pos
 };
 
@@ -205,19 +205,27 @@ __global__ __launch_bounds__(256) void query_prep_kernel(PrepParams p) {
             const int j0 = lane, j1 = lane + 64;
             unsigned long long a = 0, c = 0;
             unsigned spins = 0;
+            // the epoch arithmetic holds only while every launch on this state block has the same grid: word 3 remembers the
+            // first launch's (block 0 records it); a different grid is a failed hand-off like a spin that gave up
+            const unsigned grid0 = __hip_atomic_load((gu32*)p.state + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool failed = grid0 != 0u && grid0 != gridDim.x;
             for (;;) {
                 a = (j0 < hd) ? __hip_atomic_load(gran + h * hd + j0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)epoch << 32);
                 c = (j1 < hd) ? __hip_atomic_load(gran + h * hd + j1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)epoch << 32);
                 const bool ok = (unsigned)(a >> 32) == epoch && (unsigned)(c >> 32) == epoch;
                 if (__all(ok)) break;
-                if (++spins > (1u << 22)) {                           // give up (~seconds): never hang the queue
-                    if (lane == 0) atomicAdd(p.state + 2, 1u);       // (state word 2: give-up count, diagnostic)
+                if (failed || ++spins > (1u << 22)) {                 // give up (~seconds): never hang the queue
+                    failed = true;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
-            if (j0 < hd) qs[j0] = __uint_as_float((unsigned)a);
-            if (j1 < hd) qs[j1] = __uint_as_float((unsigned)c);
+            // A missed hand-off must not pass for a result: the fold outputs of this workgroup become NaN (they reach every
+            // output token through the scores) and the sticky count in state word 2 says why.
+            if (failed && lane == 0) atomicAdd(p.state + 2, 1u);
+            const float poison = __uint_as_float(0x7FC00000u);
+            if (j0 < hd) qs[j0] = failed ? poison : __uint_as_float((unsigned)a);
+            if (j1 < hd) qs[j1] = failed ? poison : __uint_as_float((unsigned)c);
         }
         __syncthreads();
         if (is_w) {
@@ -268,6 +276,8 @@ __global__ __launch_bounds__(256) void query_prep_kernel(PrepParams p) {
     }
     // the arrival: after every wave of the workgroup has read the counter (they all did before their first barrier / store)
     __syncthreads();
+    if (tid == 0 && b == 0 && __hip_atomic_load((gu32*)p.state + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+        __hip_atomic_store((gu32*)p.state + 3, gridDim.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // result unused: no-return atomic
 }
 

@@ -268,6 +268,7 @@ def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: in
         raise NotImplementedError("sharded_forward: no clip-scale global stage (use forward_stepwise, unsharded)")
     if torch.is_grad_enabled() and projector._needs_grad(ff_shard, fe_shard, guide_embed, image_newline):
         raise RuntimeError("sharded_forward is an inference path: call it under torch.no_grad() / inference_mode()")
+    nv.begin_inference()
     if not all(t is None or t.is_contiguous() for t in (ff_shard, fe_shard, guide_embed, image_newline)):
         raise ValueError("sharded_forward: contiguous inputs only")
     dev = ff_shard.device

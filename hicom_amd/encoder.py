@@ -27,7 +27,9 @@ from . import native as nv
 _ACTS = {"gelu_pytorch_tanh": nv.ACT_GELU_TANH, "gelu": nv.ACT_GELU}
 
 
-def _head_cache(head):
+def _head_cache(head, store=True):
+    """fp16 copies of fc1 / fc2 per weight state.  store=False (the backward): a miss rebuilds from the live weights WITHOUT
+    stamping the result -- copies made between a forward and the optimizer step must not pass for post-step weights."""
     fc1, fc2 = head.mlp.fc1, head.mlp.fc2
     stamp = nv.weight_stamp(fc1.weight, fc2.weight)
     hit = head.__dict__.get("_hicom_f16")
@@ -38,7 +40,8 @@ def _head_cache(head):
         # fc2 with the padded pitch (tools/dense_ld.py); K = 1 152 shows no such effect
         ld = kpad + (192 if kpad > 2048 else 0)
         hit = (stamp, nv.f16_weight_copy(fc1.weight), nv.f16_weight_copy(fc2.weight, ld), kpad, ld)
-        head.__dict__["_hicom_f16"] = hit
+        if store:
+            head.__dict__["_hicom_f16"] = hit
     return hit[1], hit[2], hit[3], hit[4]
 
 
@@ -50,7 +53,11 @@ def siglip_head_embed(last_hidden_state: torch.Tensor, head, hidden_act: str = N
     if torch.is_grad_enabled() and (last_hidden_state.requires_grad or any(p.requires_grad for p in _head_params(head))):
         if out_dtype not in (None, last_hidden_state.dtype):
             raise NotImplementedError("siglip_head_embed: out_dtype with autograd")
+        # training: the optimizer may have rewritten fc1 / fc2 behind the version counters since the last forward (DeepSpeed's
+        # bf16 optimizer, `p.data.copy_`): every training forward re-reads the live weights (native.py "weight-derived caches")
+        nv.note_training_forward()
         return _HeadFn.apply(last_hidden_state, head, hidden_act, *_head_params(head))
+    nv.begin_inference()
     return _head_chain(last_hidden_state, head, hidden_act, out_dtype, None, True)[0]
 
 
@@ -90,7 +97,7 @@ class _HeadFn(torch.autograd.Function):
             D = x.shape[-1]
             x2 = x.contiguous().view(-1, D)
             M = x2.shape[0]
-            w1, w2, kpad, ld = _head_cache(head)
+            w1, w2, kpad, ld = _head_cache(head, store=False)
             inter = fc1.weight.shape[0]
             dY = d_out.contiguous().view(M, D)
             # ---- recompute (HIP): normalised tokens, pre-activation hidden layer ------------------------------------------
@@ -155,6 +162,7 @@ def siglip_head_scores(last_hidden_state: torch.Tensor, head, guide_embed: torch
     _require_bf16_cuda("guide_embed", guide_embed)
     if guide_embed.ndim != 1 or guide_embed.shape[0] != last_hidden_state.shape[-1]:
         raise ValueError("siglip_head_scores takes the [D] guide embedding of use_guide='direct'")
+    nv.begin_inference()
     out, logits = _head_chain(last_hidden_state, head, hidden_act, None, guide_embed.contiguous(), return_embed)
     return (logits, out) if return_embed else logits
 

@@ -390,10 +390,16 @@ def to_f16(src, dst=None):
 # (storage pointer, in-place version counter).  That sees `p.data = new`, optimizer steps through torch ops, load_state_dict
 # and .to(); it does NOT see writes that bypass the version counter: `p.data.copy_(...)` and writes through an alias of the
 # storage (DeepSpeed's bf16 optimizer updates its flat buffer exactly like that).  Hence a global EPOCH in every stamp:
-#   * every training-mode forward (HIComProjector.forward with autograd on and trainable parameters) bumps it, so the
-#     forward always reads the live weights and the first inference forward after training rebuilds once;
+#   * every training-mode forward (HIComProjector.forward / siglip_head_embed with autograd on and trainable parameters) bumps
+#     it (`note_training_forward`), so a training forward always reads the live weights;
+#   * a training forward also leaves a DIRTY mark: the tables it (or its backward) built carry the current epoch but pre-date
+#     the optimizer step that follows.  The next INFERENCE entry point (`begin_inference`: HIComProjector.forward under
+#     no_grad, forward_deferred, sharded_forward, the stage modules' forwards, siglip_head_embed / _scores) consumes the mark by
+#     bumping the epoch once more, so Trainer.evaluate / inference after training rebuilds from the post-step weights; the
+#     backward passes never consume it (they run between the forward and the optimizer step);
 #   * `hicom_amd.invalidate_weight_caches()` bumps it by hand (after modifying weights behind torch's back at inference).
 _WEIGHTS_EPOCH = [0]
+_TRAIN_DIRTY = [False]
 
 
 def weights_epoch() -> int:
@@ -403,6 +409,19 @@ def weights_epoch() -> int:
 def invalidate_weight_caches() -> None:
     """Every weight-derived device cache (fp16 weight copies, positional products, executor plans) is rebuilt on next use."""
     _WEIGHTS_EPOCH[0] += 1
+
+
+def note_training_forward() -> None:
+    """Called by every forward that builds an autograd graph over trainable weights."""
+    _WEIGHTS_EPOCH[0] += 1
+    _TRAIN_DIRTY[0] = True
+
+
+def begin_inference() -> None:
+    """Called at every inference entry point: the first one after a training forward rebuilds the weight-derived tables."""
+    if _TRAIN_DIRTY[0]:
+        _TRAIN_DIRTY[0] = False
+        _WEIGHTS_EPOCH[0] += 1
 
 
 def weight_stamp(*weights):

@@ -87,6 +87,8 @@ class MultiheadAttention(nn.Module):
             raise ValueError("MultiheadAttention: inputs are Batch x Time x Channel")
         if attention_mask is not None:
             raise NotImplementedError("MultiheadAttention: attention_mask has no HIP path (never passed by the reference)")
+        if not torch.is_grad_enabled():
+            nv.begin_inference()
         B, q_len, _ = query.shape
         kv_len = key.shape[1]
         outs = []
@@ -147,6 +149,8 @@ class GuideInjector(nn.Module):
         from . import injector as inj
         if visual_embed.ndim not in (2, 4):
             raise ValueError("Invalid input shape for guide embedding.")
+        if not torch.is_grad_enabled():
+            nv.begin_inference()
         shape = visual_embed.shape
         vis = visual_embed.reshape(-1, shape[-1])
         q, shared = inj.inject(self, self.use_guide, vis, guide_embed.contiguous())
@@ -427,6 +431,7 @@ def _refuse_grad(module: nn.Module):
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
         raise RuntimeError(f"{type(module).__name__}.forward builds no autograd graph: call it under torch.no_grad(), or "
                            "go through HIComProjector.forward, which does")
+    nv.begin_inference()
 
 
 def _out_dtype(module: nn.Module) -> torch.dtype:
@@ -710,9 +715,10 @@ class HIComProjector(nn.Module):
             # training: an optimizer step lies between two forwards, and DeepSpeed's bf16 optimizer writes the weights
             # through `p.data.copy_` / a flat alias, which no version counter sees -> every weight-derived cache is
             # rebuilt from the live weights on each training forward (native.py "weight-derived device caches")
-            nv.invalidate_weight_caches()
+            nv.note_training_forward()
             from . import autograd
             return autograd.forward_with_grad(self, frames_feature, frames_embed, guide_embed, modal, image_newline)
+        nv.begin_inference()           # (the first inference forward after training rebuilds the weight-derived tables)
         plain = all(c is None or c.is_plain for c in (self.local_compressor, self.global_compressor))
         if self.use_executor and plain and self.global_logit is None and not isinstance(frames_feature, dict):
             from . import engine
@@ -726,6 +732,7 @@ class HIComProjector(nn.Module):
             raise ValueError("local_logits replaces frames_embed: pass frames_embed=None")
         if self._needs_grad(frames_feature, guide_embed, image_newline, local_logits):
             raise RuntimeError("local_logits= is an inference path (no autograd graph): call it under torch.no_grad()")
+        nv.begin_inference()
         plain = all(c is None or c.is_plain for c in (lc, self.global_compressor))
         if (lc is None or self.global_compressor is None or lc.use_guide != "direct" or not plain or self.local_logit is not None
                 or self.global_logit is not None or isinstance(frames_feature, dict) or not self.use_executor):
@@ -748,6 +755,7 @@ class HIComProjector(nn.Module):
         if self._needs_grad(frames_feature, frames_embed, guide_embed, image_newline):
             raise RuntimeError("forward_deferred is an inference API: call it under torch.no_grad() / inference_mode(), "
                                "or use forward() for training")
+        nv.begin_inference()
         plain = all(c is None or c.is_plain for c in (self.local_compressor, self.global_compressor))
         if not plain or self.global_logit is not None or isinstance(frames_feature, dict):
             raise NotImplementedError("forward_deferred: dense inputs of the plain recipes")

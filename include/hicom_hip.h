@@ -151,7 +151,10 @@ int hicom_fold_query_split_fwd(const float* qp, const void* w_k, const float* kp
  *   r0 f32 [hidden]           : g_w0 (b_o + guide) + g_b0  -- with C = g_w0 . w_o (cached by the caller) the tail
  *                               GELU(g_w0 (w_o o + b_o + guide) + g_b0) of :226,:646,:307-312 is GELU(C o + r0); g_w0 NULL = no r0
  * state: hicom_query_prep_state_bytes(E) bytes of caller-owned device memory, zeroed ONCE, private to one stream of
- * calls (epoch word + granules; the kernel maintains it). */
+ * calls with ONE problem shape (words 0-1 arrival counter, word 2 failed hand-offs, word 3 grid size of the first launch,
+ * then the granules; the kernel maintains it).  A hand-off that fails -- a bounded spin that gave up, or a launch whose grid
+ * differs from the first one on this block -- writes NaN into qt_hi / qt_lo / pos_a (every output token then is NaN) and
+ * counts in word 2: a missed hand-off never passes for a result. */
 int64_t hicom_query_prep_state_bytes(int32_t E);
 int hicom_query_prep_fwd(const void* guide, const void* local_q, const void* w_q, const void* b_q, const void* w_k, const float* kpe,
                          int32_t nh, int32_t E, int32_t P, float scale, void* qt_hi, void* qt_lo, float* pos_a,

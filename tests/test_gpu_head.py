@@ -225,6 +225,39 @@ def test_head_backward_matches_reference_autograd(head):
     m.eval()
 
 
+def test_head_training_forward_reads_the_live_weights_after_a_bypassing_update(head):
+    """stage-3 step n-1's head backward re-stamps the fp16 copies of fc1 / fc2 from PRE-step weights; an
+    optimizer that writes through `p.data.copy_` bumps no version counter, so step n's head forward must not hit them.  Every
+    training forward of the head bumps the weights epoch; inference after training consumes the dirty mark."""
+    import copy
+    from hicom_amd import encoder
+    from hicom_amd import native as nv
+    m, _ = head
+    m = copy.deepcopy(m).train()
+    x = torch.from_numpy(mh.tokens()).to(torch.bfloat16).cuda()
+    for step in range(2):
+        for p_ in m.parameters():
+            p_.grad = None
+        out = encoder.siglip_head_embed(x, m)
+        nv.note_training_forward()                                       # (the projector's training forward of the same step)
+        out.float().square().sum().backward()                            # the head backward rebuilds its copies: pre-step weights
+        for lin in (m.mlp.fc1, m.mlp.fc2):
+            v = lin.weight._version
+            lin.weight.data.copy_((lin.weight.data.float() * 1.5).to(torch.bfloat16))
+            assert lin.weight._version == v
+        if step == 0:
+            got = encoder.siglip_head_embed(x, m).detach()               # next TRAINING forward
+        else:
+            m.eval()
+            with torch.no_grad():
+                got = encoder.siglip_head_embed(x, m)                    # inference right after training
+        fresh = copy.deepcopy(m).eval()
+        fresh.__dict__.pop("_hicom_f16", None)                           # no cached copies: built from the live weights
+        with torch.no_grad():
+            want = encoder.siglip_head_embed(x, fresh)
+        assert torch.equal(got, want), (step, float((got.float() - want.float()).abs().max()))
+
+
 def test_stage3_chain_head_into_compressor_backward(head):
     """head (trainable) -> frames_embed -> HIComProjector.forward -> loss: the compressor's d frames_embed flows into the head's
     backward; every head parameter and every projector parameter ends up with a finite gradient of its own dtype."""

@@ -208,6 +208,32 @@ def test_weight_writes_that_bypass_the_version_counter():
         assert float((m(ff, fe, g, "video", None) - base).abs().max()) <= 2e-4
 
 
+def test_eval_after_a_training_step_whose_optimizer_bypasses_the_version_counter():
+    """the tables built during the LAST training forward / backward carry the current epoch but pre-date the
+    optimizer step.  A version-bypassing step (`p.data.copy_`, DeepSpeed's flat alias) followed by an inference forward
+    (Trainer.evaluate) must rebuild them: the training forward leaves a dirty mark that the next inference entry point consumes."""
+    m, _, case = _module_and_sd("G1_direct_T8")
+    ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+    names = ("local_compressor.readout.0.weight", "local_compressor.readout.2.weight", "global_compressor.attn_layer.k_proj.weight",
+             "global_compressor.attn_layer.out_proj.weight", "global_compressor.readout.0.weight")
+    params = dict(m.named_parameters())
+    m.train()
+    out = m(ff, fe, g, "video", None)                                    # training forward: epoch bump, tables at epoch E
+    out.float().square().sum().backward()                                # backward may rebuild tables (still pre-step weights)
+    v0 = tuple(params[n]._version for n in names)
+    for n in names:                                                      # "optimizer step" behind torch's back
+        params[n].data.copy_((params[n].data.float() * 1.25).to(torch.bfloat16))
+    assert tuple(params[n]._version for n in names) == v0
+    m.eval()
+    with torch.no_grad():
+        got = m(ff, fe, g, "video", None)
+        fresh = build_module(cases.build_case("G1_direct_T8"))
+        fresh.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
+        want = fresh(ff, fe, g, "video", None)
+        assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+        assert torch.equal(m(ff, fe, g, "video", None), want)            # (and the mark is consumed once: later forwards hit)
+
+
 def test_f16_weight_copy_range_check():
     from hicom_amd import native as nv
     w = torch.full((4, 64), 7.0e4, dtype=torch.bfloat16, device="cuda")

@@ -155,3 +155,23 @@ def test_synth_is_bit_stable():
     a = synth.normal_like((4, 5), 123)
     assert a.dtype == np.float32 and np.array_equal(a, synth.round_to_bf16(a))
     assert abs(float(synth.normal_like((200000,), 7).std()) - 1.0) < 0.02
+
+
+def test_weights_epoch_protocol():
+    """Training forwards bump the weights epoch and leave a dirty mark; the first inference entry point afterwards bumps once
+    more (tables built between a forward and the optimizer step must not survive it); later inference calls do not."""
+    from hicom_amd import native as nv
+    nv.begin_inference()                     # (consume a mark an earlier test's training-mode call may have left)
+    e0 = nv.weights_epoch()
+    nv.begin_inference()
+    assert nv.weights_epoch() == e0
+    nv.note_training_forward()
+    assert nv.weights_epoch() == e0 + 1
+    nv.note_training_forward()
+    assert nv.weights_epoch() == e0 + 2
+    nv.begin_inference()
+    assert nv.weights_epoch() == e0 + 3
+    nv.begin_inference()
+    assert nv.weights_epoch() == e0 + 3
+    nv.invalidate_weight_caches()
+    assert nv.weights_epoch() == e0 + 4

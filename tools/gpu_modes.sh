@@ -2,7 +2,6 @@
 # Dev: per-kernel durations (rocprofv3 kernel trace) and wall time of the non-release recipes at C2.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/modes; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-echo skip-tests
 for mode in ${1:-off coarse fine adaptkv}; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$mode -- python3 $R/tools/modes_one.py $mode > $O/$mode.log 2>&1
   python3 - $O/$mode $mode <<'PY2'
