@@ -97,6 +97,22 @@ class PackLayout:
         return buf[:, a:b].contiguous().view(dtype).view(buf.shape[0] * self.token_rows, self.token_cols)
 
 
+class ExchangeSets:
+    """The (send buffer, gathered buffer) pairs of a plan, used in turn: step i fills and gathers pair i mod n while the
+    consumer of step i - 1 (the comm stream's FINISH phase on the GPU) may still be reading the other pair.  Device-agnostic:
+    `sharded_forward` and the world-2 gloo test step through the same object."""
+
+    def __init__(self, lay: "PackLayout", device, world: int, n: int = 2):
+        self.pairs = [(lay.new_buffer(device), lay.new_buffer(device, world)) for _ in range(n)]
+        self.steps = 0
+
+    def advance(self) -> int:
+        """Index of the pair of the step that starts now."""
+        i = self.steps % len(self.pairs)
+        self.steps += 1
+        return i
+
+
 def gather_packed(mine: torch.Tensor, everyone: torch.Tensor, group=None) -> torch.Tensor:
     """THE collective of the path: all-gathers every rank's packed buffer into `everyone` [world, total] (rank-major),
     ordered on the current stream of `mine`'s device."""
@@ -123,7 +139,7 @@ class _ShardSet:
 
 
 class _ShardPlan:
-    __slots__ = ("sets", "n", "comm", "res", "lay", "pack", "nw", "hidden", "odt", "n_rows_total", "world", "rank", "sig",
+    __slots__ = ("sets", "xs", "comm", "res", "lay", "pack", "nw", "hidden", "odt", "n_rows_total", "world", "rank", "sig",
                  "guide_fields")
 
     def set_inputs(self, st: _ShardSet, ff, fe, guide, out):
@@ -184,16 +200,15 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
     plan.res = engine._resources(dev)                  # side stream + fork/join events of the caller's stream
     plan.lay, plan.nw, plan.hidden, plan.odt, plan.world, plan.rank = lay, nw, hidden, odt, world, rank
     plan.n_rows_total = lay.n_rows + n_rows
-    plan.n = 0
     plan.sets = []
     # ONE exchange buffer per rank: [state (M, L) pairs + ACC | local tokens] -> one collective per step (the host cost
     # of a torch.distributed call, not the wire, is what a second collective would add)
     plan.pack = pack = PackLayout(2 * R + R * E, nw, hidden, torch.empty((), dtype=odt).element_size())
     probe = torch.empty((plan.n_rows_total, hidden), dtype=odt, device=dev)      # any valid `out` for the argument blocks
-    for _ in range(2):
+    plan.xs = ExchangeSets(pack, dev, world)
+    for mine, everyone in plan.xs.pairs:
         st = _ShardSet()
-        st.mine = pack.new_buffer(dev)
-        st.everyone = pack.new_buffer(dev, world)
+        st.mine, st.everyone = mine, everyone
         state_mine, tok_mine = pack.state_view(st.mine), pack.tokens_view(st.mine, odt)
         st.a_stream = engine.build_args(projector, ff_shard, fe_shard, guide_embed, "video", None, probe, None, t_offset=t0,
                                         phases=nv.PHASE_STREAM, local_out=tok_mine, state_out=state_mine,
@@ -273,8 +288,7 @@ def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: in
         raise ValueError("sharded_forward: contiguous inputs only")
     dev = ff_shard.device
     plan = _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group)
-    st = plan.sets[plan.n & 1]
-    plan.n += 1
+    st = plan.sets[plan.xs.advance()]
     main, comm = torch.cuda.current_stream(dev), plan.comm
     if deferred:
         # pipelined serving: the result lives in this buffer set (no allocator traffic on the host-bound path) and is

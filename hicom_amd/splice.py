@@ -25,6 +25,9 @@ import torch
 
 from . import native as nv
 
+_PLAN_CACHE: dict = {}       # content hash of (ids, feature rows, embedding table) -> layout plan + pointer table (see below)
+_MAX_PLANS = 8
+
 IGNORE_INDEX = -100                                                   # reference hicom/constants.py:7
 MODAL_INDEX_MAP = {"<image>": -200, "<video>": -201, "<audio>": -202}  # reference hicom/constants.py:30-34
 
@@ -170,7 +173,20 @@ def prepare_inputs_labels_for_multimodal(embed_tokens, input_ids, attention_mask
     if attention_mask is not None and attention_mask.dtype not in (torch.bool, torch.int64):
         raise ValueError("splice: attention_mask must be torch.bool or torch.long")
     ids = input_ids.detach().cpu().numpy().astype(np.int64, copy=False)   # the one host read (the output shape depends on it)
-    plan = plan_layout(ids, [f.shape[0] for f in feats])
+    need_maps = labels is not None or attention_mask is not None
+    feat_rows = tuple(f.shape[0] for f in feats)
+    feat_ptrs = tuple(f.data_ptr() for f in feats)
+    # A serving loop splices the SAME prompt template around every video: the layout plan and the text half of the pointer table
+    # depend on (ids, feature row counts, the embedding table) only and are kept per content hash; a call whose feature tensors
+    # sit at the addresses of the cached call (the caching allocator hands the same blocks back) re-uses the uploaded table too.
+    ckey = (hash(ids.tobytes()), ids.shape, feat_rows, weight.data_ptr(), weight.shape[0], row_bytes, need_maps)
+    hit = _PLAN_CACHE.get(ckey)
+    if hit is not None and not np.array_equal(hit["ids"], ids):        # (hash collision)
+        hit = None
+    if hit is None:
+        plan = plan_layout(ids, list(feat_rows))
+    else:
+        plan = hit["plan"]
     new_len, Lmax = plan.new_len, plan.Lmax
     ragged = bool((new_len != new_len[0]).any())
     if ragged and attention_mask is not None and labels is None:
@@ -181,22 +197,34 @@ def prepare_inputs_labels_for_multimodal(embed_tokens, input_ids, attention_mask
         raise RuntimeError(f"Trying to create tensor with negative dimension {int(new_len.min()) - S}")
     # device-pointer table of the output rows + label map + lengths: ONE packed upload, filled segment by segment
     n = B * Lmax
-    need_maps = labels is not None or attention_mask is not None
-    packed = np.zeros(n * 8 + (n * 4 + (B * 4 + 15) // 16 * 16 if need_maps else 0), dtype=np.uint8)
-    table = packed[:n * 8].view(np.int64).reshape(B, Lmax)
-    wptr, vocab = weight.data_ptr(), weight.shape[0]
-    for b, o, p0, nt, k, nrows in plan.segments:
-        if nt:
-            tk = ids[b, p0:p0 + nt]
-            if int(tk.min()) < 0 or int(tk.max()) >= vocab:
-                raise IndexError("index out of range in self")        # nn.Embedding's error for a bad id
-            table[b, o:o + nt] = wptr + tk * row_bytes
-        if nrows:
-            table[b, o + nt:o + nt + nrows] = feats[k].data_ptr() + np.arange(nrows, dtype=np.int64) * row_bytes
-    if need_maps:
-        packed[n * 8:n * 12].view(np.int32)[:] = plan.src_kind.ravel()
-        packed[n * 12:n * 12 + B * 4].view(np.int32)[:] = new_len
-    packed_d = torch.from_numpy(packed).to(dev)
+    packed_d = None
+    if hit is not None and hit["feat_ptrs"] == feat_ptrs and hit["packed_d"] is not None and hit["packed_d"].device == dev:
+        packed_d = hit["packed_d"]
+    else:
+        if hit is None:
+            packed = np.zeros(n * 8 + (n * 4 + (B * 4 + 15) // 16 * 16 if need_maps else 0), dtype=np.uint8)
+            table = packed[:n * 8].view(np.int64).reshape(B, Lmax)
+            wptr, vocab = weight.data_ptr(), weight.shape[0]
+            for b, o, p0, nt, k, nrows in plan.segments:
+                if nt:
+                    tk = ids[b, p0:p0 + nt]
+                    if int(tk.min()) < 0 or int(tk.max()) >= vocab:
+                        raise IndexError("index out of range in self")    # nn.Embedding's error for a bad id
+                    table[b, o:o + nt] = wptr + tk * row_bytes
+            if need_maps:
+                packed[n * 8:n * 12].view(np.int32)[:] = plan.src_kind.ravel()
+                packed[n * 12:n * 12 + B * 4].view(np.int32)[:] = new_len
+            hit = {"ids": ids.copy(), "plan": plan, "packed": packed, "feat_ptrs": None, "packed_d": None}
+            if len(_PLAN_CACHE) >= _MAX_PLANS:
+                _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+            _PLAN_CACHE[ckey] = hit
+        packed = hit["packed"]                                            # (text half final; the visual rows are re-pointed per call)
+        table = packed[:n * 8].view(np.int64).reshape(B, Lmax)
+        for b, o, p0, nt, k, nrows in plan.segments:
+            if nrows:
+                table[b, o + nt:o + nt + nrows] = feat_ptrs[k] + np.arange(nrows, dtype=np.int64) * row_bytes
+        packed_d = torch.from_numpy(packed).to(dev)                       # (a fresh device buffer: an earlier call's table may be in flight)
+        hit["feat_ptrs"], hit["packed_d"] = feat_ptrs, packed_d
     table_d = packed_d[:n * 8].view(torch.int64).view(B, Lmax)
     needs_grad = torch.is_grad_enabled() and (weight.requires_grad or any(f.requires_grad for f in feats))
     if needs_grad:

@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import cases
-from hicom_amd.dist import FrameShardPlan, PackLayout, exchange, gather_packed
+from hicom_amd.dist import ExchangeSets, FrameShardPlan, PackLayout, exchange, gather_packed
 from oracle import hicom_oracle as orc
 
 
@@ -93,6 +93,61 @@ def _worker(rank, world, port, tmp):
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
+
+
+def _worker_two_steps(rank, world, port, tmp):
+    """Three consecutive steps through the plan's TWO exchange-buffer pairs (`ExchangeSets`, the object sharded_forward steps
+    through): step i gathers into pair i mod 2 while the consumer of step i - 1 still holds VIEWS into the other pair -- what the
+    GPU path's deferred FINISH phase does.  Checks the alternation, that a step never disturbs the previous step's gathered
+    data, and that pair 0 is reused (and correctly refilled) by step 2."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S, rows, cols = 2 * 9 + 9 * 64, 6, 32
+        lay = PackLayout(S, rows, cols, 2)
+        xs = ExchangeSets(lay, "cpu", world)
+        assert len(xs.pairs) == 2
+
+        def payload(step, r):
+            g = torch.Generator().manual_seed(1000 * step + r)
+            return torch.randn(S, generator=g), torch.randn(rows, cols, generator=g).bfloat16()
+
+        held = []                                     # (step, index, state view, token view) of earlier steps: views, not copies
+        for step in range(3):
+            i = xs.advance()
+            assert i == step % 2
+            mine, everyone = xs.pairs[i]
+            st, tk = payload(step, rank)
+            lay.state_view(mine).copy_(st)
+            lay.tokens_view(mine, torch.bfloat16).copy_(tk)
+            gather_packed(mine, everyone)
+            flat = everyone.view(-1)
+            views = []
+            for r in range(world):                    # the offsets the FINISH-phase kernels address (state_set_stride, place_src)
+                st_r = flat[r * lay.total: r * lay.total + lay.state_bytes].view(torch.float32)
+                tk_r = flat[r * lay.total + lay.tok_off: r * lay.total + lay.tok_off + lay.tok_bytes].view(torch.bfloat16).view(rows, cols)
+                want_st, want_tk = payload(step, r)
+                assert torch.equal(st_r, want_st) and torch.equal(tk_r, want_tk)
+                views.append((st_r, tk_r))
+            # the previous step's gathered data (other pair) is untouched by this step's fill + collective
+            for (pstep, pi, pviews) in held[-1:]:
+                assert pi != i
+                for r in range(world):
+                    want_st, want_tk = payload(pstep, r)
+                    assert torch.equal(pviews[r][0], want_st) and torch.equal(pviews[r][1], want_tk)
+            held.append((step, i, views))
+        # step 2 reused pair 0: step 0's views now show step 2's data (the documented lifetime of a deferred result: two steps)
+        assert held[0][1] == held[2][1] == 0
+        assert all(torch.equal(held[0][2][r][0], payload(2, r)[0]) for r in range(world))
+        open(os.path.join(tmp, f"ok2_{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_steps_alternate_buffer_sets(tmp_path):
+    world = 2
+    mp.spawn(_worker_two_steps, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok2_{r}").exists() for r in range(world))
 
 
 def test_two_rank_exchange_and_combine(tmp_path):

@@ -15,7 +15,7 @@ def T(name, t0):
 def step():
     t = time.perf_counter()
     plan = hd._shard_plan(m, ff, fe, g, 64, None, None); t = T("plan lookup", t)
-    st = plan.sets[plan.n & 1]; plan.n += 1
+    st = plan.sets[plan.xs.advance()]
     main, comm = torch.cuda.current_stream(dev), plan.comm; t = T("current_stream", t)
     out = torch.empty((plan.n_rows_total, plan.hidden), dtype=plan.odt, device=dev); t = T("empty", t)
     out.record_stream(comm); t = T("record_stream", t)
