@@ -308,6 +308,11 @@ extern "C" int hicom_row_ln_fwd(const void* x, int32_t x_dt, int64_t x_stride,
 
 extern "C" int hicom_small_mha_fwd(const float* q, const float* k, const float* v, int32_t M, int32_t L,
                                    int32_t nh, int32_t hd, float* out, void* stream) {
+    return hicom_small_mha_scaled_fwd(q, k, v, M, L, nh, hd, hd > 0 ? 1.0f / sqrtf((float)hd) : 0.f, out, stream);
+}
+
+extern "C" int hicom_small_mha_scaled_fwd(const float* q, const float* k, const float* v, int32_t M, int32_t L,
+                                          int32_t nh, int32_t hd, float scale, float* out, void* stream) {
     HICOM_REQUIRE(q && k && v && out, HICOM_EINVAL, "small_mha: NULL pointer");
     HICOM_REQUIRE(M > 0 && L > 0 && L <= 64 && nh > 0 && hd > 0, HICOM_EUNSUP, "small_mha: L=%d (<= 64 keys supported)", L);
     if ((hd == 128 || hd == 96 || hd == 64) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0)) {
@@ -318,7 +323,7 @@ extern "C" int hicom_small_mha_fwd(const float* q, const float* k, const float* 
             attr_set = true;
         }
         const dim3 grid((unsigned)nh, (unsigned)((M + kMhaRows - 1) / kMhaRows));
-        const float sc = 1.0f / sqrtf((float)hd);
+        const float sc = scale;
         hipStream_t st = (hipStream_t)stream;
         if (hd == 128) hipLaunchKernelGGL(small_mha_lds_kernel<128>, grid, dim3(256), smem, st, q, k, v, M, L, nh, sc, out);
         else if (hd == 96) hipLaunchKernelGGL(small_mha_lds_kernel<96>, grid, dim3(256), smem, st, q, k, v, M, L, nh, sc, out);
@@ -327,6 +332,6 @@ extern "C" int hicom_small_mha_fwd(const float* q, const float* k, const float* 
     }
     const long waves = (long)M * nh;
     hipLaunchKernelGGL(small_mha_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, k, v, M, L,
-                       nh, hd, 1.0f / sqrtf((float)hd), out);
+                       nh, hd, scale, out);
     return hicom_host::check_launch("small_mha");
 }

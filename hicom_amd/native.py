@@ -32,6 +32,7 @@ EXPORTS = (
     "hicom_dense16_gemm_fwd", "hicom_ln_stream_fwd", "hicom_to_f16_padded_fwd", "hicom_clip_query_prep_fwd", "hicom_inv_norm_fwd",
     "hicom_global_stream_clip_fwd", "hicom_splice_rows_fwd", "hicom_splice_labels_fwd",
     "hicom_query_prep_fwd", "hicom_query_prep_state_bytes", "hicom_partials_sum_fwd", "hicom_l2norm_stream_fwd", "hicom_local_attn_adapt_fwd",
+    "hicom_small_mha_scaled_fwd",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -146,6 +147,7 @@ def lib() -> C.CDLL:
     L.hicom_row_ln_fwd.argtypes = [vp, i32, i64, vp, i64, vp, i64, vp, vp, i32, vp, i32, i64, vp, i32, f32, vp, i32, i64,
                                    i32, i32, vp]
     L.hicom_small_mha_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    L.hicom_small_mha_scaled_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp]
     L.hicom_fold_query_split_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, i32, vp, i32, i32, vp]
     L.hicom_global_combine_strided_fwd.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
     ap = C.POINTER(CompressorArgs)
@@ -595,7 +597,12 @@ def row_ln(x, norm, out, mul=None, add=None, src=None, alpha=None, eps=1e-6):
                                   _ptr(o2), _dt(o2), E, M, E, _stream()), "hicom_row_ln_fwd")
 
 
-def small_mha(q, k, v, nh, out):
+def small_mha(q, k, v, nh, out, scale=None):
+    """scale None: head_dim^-1/2 (ref :145); a float: the logit scale of the clip form (q, k already L2-normalised, ref :184-191)."""
     M, E = q.shape
-    _check(lib().hicom_small_mha_fwd(_ptr(q), _ptr(k), _ptr(v), M, k.shape[0], nh, E // nh, _ptr(out), _stream()),
-           "hicom_small_mha_fwd")
+    if scale is None:
+        _check(lib().hicom_small_mha_fwd(_ptr(q), _ptr(k), _ptr(v), M, k.shape[0], nh, E // nh, _ptr(out), _stream()),
+               "hicom_small_mha_fwd")
+    else:
+        _check(lib().hicom_small_mha_scaled_fwd(_ptr(q), _ptr(k), _ptr(v), M, k.shape[0], nh, E // nh, float(scale), _ptr(out), _stream()),
+               "hicom_small_mha_scaled_fwd")

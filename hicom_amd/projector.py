@@ -95,12 +95,16 @@ class MultiheadAttention(nn.Module):
         for b in range(B):
             q2, k2, v2 = query[b].contiguous(), key[b].contiguous(), value[b].contiguous()
             if kv_len <= 64:
-                if logit_scale is not None:
-                    raise NotImplementedError("MultiheadAttention: clip-scale on the <= 64-key path (the reference never passes it "
-                                              "there: fine injection calls fine_proj without logits, ref :391)")
                 qp, kp, vp = inj.linear_rows(q2, self.q_proj), inj.linear_rows(k2, self.k_proj), inj.linear_rows(v2, self.v_proj)
                 ao = _f32((q_len, self.embed_dim), q2.device)
-                nv.small_mha(qp, kp, vp, self.num_heads, ao)
+                sc = None
+                if logit_scale is not None:
+                    # clip form (ref :184-191): projected queries and keys L2-normalised over the FULL width before the heads are
+                    # split, logits * exp(logit_scale) (+ logit_bias: a per-row shift, softmax cancels it)
+                    nv.clip_query_prep(qp, None, 1, 1.0, _f32((q_len,), q2.device))
+                    nv.clip_query_prep(kp, None, 1, 1.0, _f32((kv_len,), q2.device))
+                    sc = math.exp(float(logit_scale))
+                nv.small_mha(qp, kp, vp, self.num_heads, ao, scale=sc)
                 outs.append(inj.linear_rows(ao, self.out_proj))
                 continue
             if key[b].data_ptr() != value[b].data_ptr() or key.shape != value.shape:

@@ -414,6 +414,11 @@ int hicom_row_ln_fwd(const void* x, int32_t x_dt, int64_t x_stride,
  * channels, scale hd^-1/2, fp32 softmax; out [M,E] f32 (before out_proj). */
 int hicom_small_mha_fwd(const float* q, const float* k, const float* v, int32_t M, int32_t L,
                         int32_t nh, int32_t hd, float* out, void* stream);
+/* The same with the logit scale given: the clip-scale form of projector.py:184-191 on the short-key branch passes the
+ * L2-normalised projected states (hicom_clip_query_prep_fwd normalises rows in place) and scale = exp(logit_scale); the
+ * additive logit_bias is a per-row shift that the softmax cancels. */
+int hicom_small_mha_scaled_fwd(const float* q, const float* k, const float* v, int32_t M, int32_t L,
+                               int32_t nh, int32_t hd, float scale, float* out, void* stream);
 
 /* ---- splice of the compressed tokens into the LLM input embeddings (hicom_arch.py:271-373) ----------------------------
  * hicom_splice_rows_fwd: dst [nrows, row_bytes] <- row r copied from the DEVICE address row_src[r] (uint64 table on the

@@ -53,6 +53,13 @@ def test_mha_forward_small_key_branch(kv_len):
     for b in range(B):
         want = orc.mha(q[b].float().cpu(), k[b].float().cpu(), v[b].float().cpu(), sd, "local_compressor.guide_injector.fine_proj", 9)
         assert float((out[b].cpu() - want).abs().max()) <= TOL, b
+    # clip-scale on the short-key branch (ref :184-191): L2-normalised projected states, * exp(logit_scale) + bias
+    ls, lb = torch.tensor(1.2), torch.tensor(-3.0)
+    with torch.no_grad():
+        out_c, _ = att(q, k, v, logit_scale=ls.cuda(), logit_bias=lb.cuda())
+    for b in range(B):
+        want = orc.mha(q[b].float().cpu(), k[b].float().cpu(), v[b].float().cpu(), sd, "local_compressor.guide_injector.fine_proj", 9, ls, lb)
+        assert float((out_c[b].cpu() - want).abs().max()) <= TOL, b
     att.return_fp32 = False
     with torch.no_grad():
         assert att(q, k, v)[0].dtype == torch.bfloat16                      # module dtype, as the reference returns it
