@@ -33,7 +33,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct WsLayout {
     size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, qp, qhi, qlo, pos_a, prep_state, scores, part_m, part_l, part_acc, scratch, ml, acc,
-        ctx_g, o, qres, pre, hid_g, tok, po, r0, total;
+        ctx_g, o, qres, pre, hid_g, tok, po, o_fix, r0, total;
     int nw, R, rows_pad, nparts, P;
     long N, score_stride;
 };
@@ -106,6 +106,7 @@ WsLayout make_layout(const hicom_compressor_args& a) {
         w.hid_g = take((size_t)a.nq * a.hidden * 4);
         w.tok = take((size_t)a.nq * a.hidden * 4);
         w.po = take((size_t)(a.E / 64) * a.E * 4);
+        w.o_fix = take((size_t)a.E * 8);
         w.r0 = take((size_t)a.hidden * 4);
     }
     w.total = off;
@@ -275,26 +276,31 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         CHK(hicom_fused_stream_fwd(a.ff, a.fe ? a.fe : a.ff, a.local_logits, a.T, a.H, a.W, a.E, a.at.k, a.ay.k, ws + w.qhi, ws + w.qlo,
                                    w.R, a.l_scale, a.l_bias, a.pe ? F(w.pos_a) : nullptr, a.P, a.pe ? a.pe_hi : nullptr, a.pe ? a.pe_lo : nullptr, a.t_index0, a.y_index0,
                                    a.x_index0, F(w.part_m), F(w.part_l), F(w.part_acc),
-                                   w.nparts, nullptr, f16 ? nullptr : ws + w.ctx_hi, f16 ? nullptr : ws + w.ctx_lo, f16 ? ws + w.ctx_hi : nullptr, sm));
+                                   w.nparts, nullptr, f16 ? nullptr : ws + w.ctx_hi, f16 ? nullptr : ws + w.ctx_lo, f16 ? ws + w.ctx_hi : nullptr,
+                                   single ? ws + w.o_fix : nullptr, single ? (int64_t)a.E * 8 : 0, single ? ws + w.part_acc : nullptr, sm));
         if (single) {
-            CHK(hicom_merge_vproj_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E, a.wv, F(w.po),
-                                      F(w.ml), F(w.ctx_g), sm));
+            // merge + v_proj with the slab sums taken inside the launch (fixed-point accumulators, cleared by the stream kernel):
+            // GEMM 1's aux role reads ONE 9-KB vector instead of E/64 partial vectors (83 KB per workgroup)
+            // (the partial states travel as normalised fp16 contexts in the bytes of the fp32 accumulators: half of them)
+            CHK(hicom_merge_vproj_fixed_fwd(F(w.part_m), F(w.part_l), ws + w.part_acc, HICOM_DT_F16, w.nparts, w.R, w.rows_pad, a.E, a.wv,
+                                            (int64_t*)(ws + w.o_fix), F(w.ml), F(w.ctx_g), sm));
             // GEMM 1 carries the first dependent GEMV of the global tail: out_proj (+ residual), or -- tail5 -- out_proj and the
             // first readout layer as ONE layer, hid = GELU(gc0 . o + r0)
-            hicom_aux_gemv ax1{F(w.po), a.E / 64, a.E, a.bv, a.wo, a.bo, a.gq, a.E, a.E, HICOM_ACT_NONE, F(w.pre),
-                               HICOM_DT_BF16, HICOM_DT_BF16, nullptr, 0, 0, 0, 0};
+            const int64_t* ofx = (const int64_t*)(ws + w.o_fix);
+            hicom_aux_gemv ax1{nullptr, 0, 0, a.bv, a.wo, a.bo, a.gq, a.E, a.E, HICOM_ACT_NONE, F(w.pre),
+                               HICOM_DT_BF16, HICOM_DT_BF16, nullptr, 0, 0, 0, 0, ofx};
             if (tail5)
-                ax1 = hicom_aux_gemv{F(w.po), a.E / 64, a.E, a.bv, a.gc0, F(w.r0), nullptr, a.hidden, a.E, HICOM_ACT_GELU, F(w.hid_g),
-                                     HICOM_DT_F32, HICOM_DT_F32, nullptr, 0, 0, 0, 0};
+                ax1 = hicom_aux_gemv{nullptr, 0, 0, a.bv, a.gc0, F(w.r0), nullptr, a.hidden, a.E, HICOM_ACT_GELU, F(w.hid_g),
+                                     HICOM_DT_F32, HICOM_DT_F32, nullptr, 0, 0, 0, 0, ofx};
             CHK(hicom_readout16_gemm_fwd(ws + w.ctx_hi, a.lw0_f16, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E, HICOM_ACT_GELU,
                                          ws + w.hid_hi, nullptr, 0, 0, 0, 0, &ax1, sm));
             // GEMM 2 carries the next one: the first readout layer, or -- tail5 -- the LAST one, written straight into the
             // 32 global rows of the output
             hicom_aux_gemv ax2{F(w.pre), 1, a.E, nullptr, a.gw0, a.gb0, nullptr, a.hidden, a.E, HICOM_ACT_GELU, F(w.hid_g),
-                               HICOM_DT_BF16, HICOM_DT_BF16, nullptr, 0, 0, 0, 0};
+                               HICOM_DT_BF16, HICOM_DT_BF16, nullptr, 0, 0, 0, 0, nullptr};
             if (ro2_aux)
                 ax2 = hicom_aux_gemv{F(w.hid_g), 1, a.hidden, nullptr, a.gw2, a.gb2, nullptr, a.hidden, a.hidden, HICOM_ACT_NONE, nullptr,
-                                     HICOM_DT_BF16, HICOM_DT_BF16, a.out, a.out_dt, a.n_global_rows, a.ldo, a.global_row0};
+                                     HICOM_DT_BF16, HICOM_DT_BF16, a.out, a.out_dt, a.n_global_rows, a.ldo, a.global_row0, nullptr};
             CHK(hicom_readout16_gemm_fwd(ws + w.hid_hi, a.lw2_f16, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden, HICOM_ACT_NONE,
                                          nullptr, a.local_out ? a.local_out : a.out, a.out_dt, a.local_out ? a.hidden : a.ldo,
                                          a.local_out ? 0 : a.local_row0, a.local_out ? 0 : a.nl_group, (tail5 && !ro2_aux) ? nullptr : &ax2, sm));

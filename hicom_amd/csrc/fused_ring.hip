@@ -77,7 +77,8 @@ struct RingParams {
     int pos_stride, t0i, y0i, x0i;
     float* part_m;
     float* part_l;
-    float* part_acc;       // [nparts][16][E], rows < R
+    float* part_acc;       // [nparts][16][E], rows < R: un-normalised fp32 accumulators ...
+    _Float16* part_ctx16;  // ... or (not NULL) the NORMALISED partial contexts acc / l as one fp16 plane, same shape
     const uint16_t* pe_hi; // [P][E] bf16 hi / lo planes of the per-axis sinusoid tables (value-side pos-emb), or NULL
     const uint16_t* pe_lo;
     float* ctx_local;      // [NW][E] fp32 window contexts (may be NULL)
@@ -85,6 +86,8 @@ struct RingParams {
     uint16_t* ctx_lo;
     _Float16* ctx_f16;     // [NW][E] the same as ONE fp16 plane (saturating) for hicom_readout16_gemm_fwd (may be NULL)
     int wpw;               // windows per workgroup
+    unsigned long long* zero_ptr;   // scratch cleared for the launches behind this one (workgroup 0), or NULL
+    int zero_n;            // ... 8-byte words
 };
 
 // Position of 16-byte chunk c of image row r inside the row: c ^ fswz(r).  The row -> XOR map is chosen so that
@@ -181,6 +184,15 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
         const long o0 = src_off(0);
         issue(p.fe, o0, febuf);
         issue(p.ff, o0, ffbuf);
+        // Both images of tile 1 go out before [P] as well (token tiles need no table and all four ring slots are free at the
+        // start): 144 KB in flight per CU during the launch ramp instead of 72, while the compute waves fetch their operands
+        // (round 4: -0.9 us per launch, tools/gpu_ab.sh)
+        const bool pre1 = ntile > 1;
+        if (pre1) {
+            const long o1 = src_off(1);
+            issue(p.fe, o1, febuf + TILE_BYTES);
+            issue(p.ff, o1, ffbuf + TILE_BYTES);
+        }
         HICOM_TR(2);   // prologue requests issued
         __builtin_amdgcn_s_barrier();                                  // [P] (the compute waves' tables)
         if (p.pe_hi) {
@@ -188,18 +200,20 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
             ntot = ntile + ((nsl + 15) >> 4);
         }
         long o_ff = ntot > 1 ? off_of(1) : 0;                          // offset of tile t+1 (fe, then ff)
-        if (ntot > 1) issue(1 < ntile ? p.fe : p.pe_hi, o_ff, febuf + TILE_BYTES);
+        if (ntot > 1 && !pre1) issue(1 < ntile ? p.fe : p.pe_hi, o_ff, febuf + TILE_BYTES);
         for (int t = 0; t < ntot; ++t) {
             const long o_fe = t + 2 < ntot ? off_of(t + 2) : 0;         // address math ahead of the wait
             HICOM_TR(2);   // tile: addresses ready
-            // in flight, oldest first: fe(t) | ff(t) | fe(t+1): everything but the youngest image has to land
-            if (t + 1 < ntot) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PPL) : "memory");
+            // in flight, oldest first: fe(t) | ff(t) | fe(t+1) (| ff(1) at t = 0 when tile 1 was requested up front): everything
+            // but the youngest image (the two youngest) has to land
+            if (t == 0 && pre1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * PPL) : "memory");
+            else if (t + 1 < ntot) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PPL) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             HICOM_TR(2);   // tile: data landed
             __builtin_amdgcn_s_barrier();                              // [A] tile t published; ff slot of tile t-1 released
             if (t == ntile) __builtin_amdgcn_s_barrier();              // [A'] (the compute waves table their marginals)
             HICOM_TR(2);   // tile: past [A]
-            if (t + 1 < ntot) issue(t + 1 < ntile ? p.ff : p.pe_lo, o_ff, ffbuf + ((t + 1) & 1) * TILE_BYTES);
+            if (t + 1 < ntot && !(t == 0 && pre1)) issue(t + 1 < ntile ? p.ff : p.pe_lo, o_ff, ffbuf + ((t + 1) & 1) * TILE_BYTES);
             HICOM_TR(2);   // tile: ff issued
             if (p.pe_hi && l == 0 && t < ntile && lane < 16) {
                 // compact pos-emb slots of this tile's 16 tokens, for the marginal MFMA of the compute waves (read
@@ -264,6 +278,8 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
             alo_t = *reinterpret_cast<const bf16x4*>(p.qlo + off + 32 * K32 + 4 * kg);
         }
     }
+    if (part == 0 && p.zero_ptr)                                     // (fixed-point accumulators of the merge + v_proj launch behind us)
+        for (int i = ctid; i < p.zero_n; i += 64 * kRingC) p.zero_ptr[i] = 0ull;
     // ---- per-workgroup tables ---------------------------------------------------------------------
     const int t1_first = wb / per_t;
     if (ctid < p.WSZ) {
@@ -605,15 +621,32 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
     // contiguous bytes.
     {
         float* est = reinterpret_cast<float*>(smem) + wave * (R * SLICE);          // wave-private [R][SLICE]
+        // fp16 form: the partial CONTEXT acc / l (the merge weighs it with l e^(m - M)): half the bytes of the 9 MB of partial states
+        // this launch leaves dirty and the merge launch pulls back in.  1 / l of the accumulator rows 4 kg + j through the
+        // wave-private LDS hop of the rescale factors.
+        f32x4 linv = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (p.part_ctx16) {
+            if (kg == 0) ascr[r16] = 1.0f / fmaxf(l_run, 1.0e-30f);
+            linv = *reinterpret_cast<const f32x4*>(ascr + 4 * kg);
+        }
 #pragma unroll
         for (int cb = 0; cb < KS; ++cb)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (4 * kg + j < R) est[(4 * kg + j) * SLICE + 16 * cb + r16] = acc[cb][j];
+                if (4 * kg + j < R) est[(4 * kg + j) * SLICE + 16 * cb + r16] = acc[cb][j] * linv[j];
         const int n4 = R * (SLICE / 4);
         for (int it = lane; it < n4; it += 64) {
             const int row = it / (SLICE / 4), c4 = it - row * (SLICE / 4);
-            *reinterpret_cast<f32x4*>(p.part_acc + (prow + row) * E + ch_base + 4 * c4) = *reinterpret_cast<const f32x4*>(est + 4 * it);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(est + 4 * it);
+            if (p.part_ctx16) {
+                typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+                half4_t hv;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) hv[u] = (_Float16)fminf(fmaxf(v[u], -65504.f), 65504.f);
+                *reinterpret_cast<half4_t*>(p.part_ctx16 + (prow + row) * E + ch_base + 4 * c4) = hv;
+            } else {
+                *reinterpret_cast<f32x4*>(p.part_acc + (prow + row) * E + ch_base + 4 * c4) = v;
+            }
         }
     }
 }
@@ -811,6 +844,8 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_logits_kernel(Ring
             alo_t = *reinterpret_cast<const bf16x4*>(p.qlo + off + 32 * K32 + 4 * kg);
         }
     }
+    if (part == 0 && p.zero_ptr)                                     // (fixed-point accumulators of the merge + v_proj launch behind us)
+        for (int i = ctid; i < p.zero_n; i += 64 * kRingC) p.zero_ptr[i] = 0ull;
     // ---- per-workgroup tables ---------------------------------------------------------------------
     const int t1_first = wb / per_t;
     if (ctid < p.WSZ) {
@@ -1161,15 +1196,32 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_logits_kernel(Ring
     // contiguous bytes.
     {
         float* est = reinterpret_cast<float*>(smem) + wave * (R * SLICE);          // wave-private [R][SLICE]
+        // fp16 form: the partial CONTEXT acc / l (the merge weighs it with l e^(m - M)): half the bytes of the 9 MB of partial states
+        // this launch leaves dirty and the merge launch pulls back in.  1 / l of the accumulator rows 4 kg + j through the
+        // wave-private LDS hop of the rescale factors.
+        f32x4 linv = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (p.part_ctx16) {
+            if (kg == 0) ascr[r16] = 1.0f / fmaxf(l_run, 1.0e-30f);
+            linv = *reinterpret_cast<const f32x4*>(ascr + 4 * kg);
+        }
 #pragma unroll
         for (int cb = 0; cb < KS; ++cb)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (4 * kg + j < R) est[(4 * kg + j) * SLICE + 16 * cb + r16] = acc[cb][j];
+                if (4 * kg + j < R) est[(4 * kg + j) * SLICE + 16 * cb + r16] = acc[cb][j] * linv[j];
         const int n4 = R * (SLICE / 4);
         for (int it = lane; it < n4; it += 64) {
             const int row = it / (SLICE / 4), c4 = it - row * (SLICE / 4);
-            *reinterpret_cast<f32x4*>(p.part_acc + (prow + row) * E + ch_base + 4 * c4) = *reinterpret_cast<const f32x4*>(est + 4 * it);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(est + 4 * it);
+            if (p.part_ctx16) {
+                typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+                half4_t hv;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) hv[u] = (_Float16)fminf(fmaxf(v[u], -65504.f), 65504.f);
+                *reinterpret_cast<half4_t*>(p.part_ctx16 + (prow + row) * E + ch_base + 4 * c4) = hv;
+            } else {
+                *reinterpret_cast<f32x4*>(p.part_acc + (prow + row) * E + ch_base + 4 * c4) = v;
+            }
         }
     }
 }
@@ -1215,8 +1267,8 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, const floa
                                       int32_t t_index0, int32_t y_index0, int32_t x_index0,
                                       float* part_m, float* part_l,
                                       float* part_acc, int32_t nparts, float* ctx_local, void* ctx_hi,
-                                      void* ctx_lo, void* ctx_f16, void* stream) {
-    HICOM_REQUIRE(ff && (fe || local_logits) && q_hi && q_lo && part_m && part_l && part_acc && ((pe_hi && pe_lo) || !pos_a) && (pos_a || !pe_hi), HICOM_EINVAL,
+                                      void* ctx_lo, void* ctx_f16, void* zero_ptr, int64_t zero_bytes, void* part_ctx_f16, void* stream) {
+    HICOM_REQUIRE(ff && (fe || local_logits) && q_hi && q_lo && part_m && part_l && (part_acc || part_ctx_f16) && ((pe_hi && pe_lo) || !pos_a) && (pos_a || !pe_hi), HICOM_EINVAL,
                   "fused_stream: NULL pointer");
     HICOM_REQUIRE(ctx_local || (ctx_hi && ctx_lo) || ctx_f16, HICOM_EINVAL, "fused_stream: no local output");
     HICOM_REQUIRE(!ctx_hi == !ctx_lo, HICOM_EINVAL, "fused_stream: ctx_hi and ctx_lo go together");
@@ -1251,8 +1303,13 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, const floa
     p.qhi = (const uint16_t*)q_hi; p.qlo = (const uint16_t*)q_lo; p.R = rows;
     p.l_scale = l_scale; p.l_bias = l_bias;
     p.pos_a = pos_a; p.pos_stride = pos_stride; p.t0i = t_index0; p.y0i = y_index0; p.x0i = x_index0;
+    HICOM_REQUIRE(!part_ctx_f16 || (uintptr_t)part_ctx_f16 % 8 == 0, HICOM_EINVAL, "fused_stream: part_ctx_f16 alignment");
+    p.part_ctx16 = (_Float16*)part_ctx_f16;
     p.part_m = part_m; p.part_l = part_l; p.part_acc = part_acc; p.pe_hi = (const uint16_t*)pe_hi; p.pe_lo = (const uint16_t*)pe_lo;
     p.ctx_local = ctx_local; p.ctx_hi = (uint16_t*)ctx_hi; p.ctx_lo = (uint16_t*)ctx_lo; p.ctx_f16 = (_Float16*)ctx_f16; p.wpw = wpw;
+    HICOM_REQUIRE(!zero_ptr || (zero_bytes > 0 && zero_bytes % 8 == 0 && (uintptr_t)zero_ptr % 8 == 0 && zero_bytes < (1 << 24)), HICOM_EINVAL,
+                  "fused_stream: zero_ptr / zero_bytes");
+    p.zero_ptr = (unsigned long long*)zero_ptr; p.zero_n = zero_ptr ? (int)(zero_bytes / 8) : 0;
     static bool attr_set = false;
     if (!attr_set) {
         HICOM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_ring_kernel<9>),

@@ -10,6 +10,8 @@
 // partials, so it needs no prior statistics pass), (2) one workgroup per (row, 64-channel slab)
 // that derives (M, L) itself, folds the frame marginals and reduces the partial contexts with
 // 4-way split over the partial index (coalesced 256-B row segments).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace hicom {
@@ -360,7 +362,14 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(MergeVprojParams p) {
     __shared__ __attribute__((aligned(16))) float cpart[16][64];
     __shared__ __attribute__((aligned(16))) float cx[64];
     const int slab = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
-    // raw partial rows first (independent of M): thread = (float4 column c4 of the slab, partial group pg of 16);
+    // the v_proj weights of this (head, slab) first: they depend on nothing in this kernel, and behind the two block reductions
+    // below their (cold) load was a third dependent memory round trip at the end of the launch
+    const int j = tid >> 1, half = tid & 1;
+    u32x4 wreg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        wreg[q] = (j < p.hd) ? *reinterpret_cast<const u32x4*>(p.wv + (long)(h * p.hd + j) * p.E + slab * 64 + 32 * half + 8 * q) : u32x4{0, 0, 0, 0};
+    // raw partial rows (independent of M): thread = (float4 column c4 of the slab, partial group pg of 16);
     // all of a thread's <= 16 loads are in flight together
     const int c4 = tid & 15, pg = tid >> 4;
     const float* base = p.part_acc + (long)h * p.E + slab * 64 + 4 * c4;
@@ -403,13 +412,11 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(MergeVprojParams p) {
     }
     __syncthreads();
     // partial v_proj: thread (j = tid >> 1, half = tid & 1) dots 32 channels of weight row h*hd + j
-    const int j = tid >> 1, half = tid & 1;
     float dot = 0.f;
     if (j < p.hd) {
-        const uint16_t* wr = p.wv + (long)(h * p.hd + j) * p.E + slab * 64 + 32 * half;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const u32x4 g = *reinterpret_cast<const u32x4*>(wr + 8 * q);
+            const u32x4 g = wreg[q];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 dot = fmaf(bf16lo_to_f32(g[i]), cx[32 * half + 8 * q + 2 * i], dot);
@@ -419,6 +426,113 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(MergeVprojParams p) {
     }
     dot += __shfl_xor(dot, 1, 64);
     if (half == 0 && j < p.hd) p.po[(long)slab * p.E + h * p.hd + j] = dot;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same merge + v_proj with the slab sums taken HERE (round 4).  The E/64 partial vectors of the form above cost their
+// consumer -- the GEMV role inside readout GEMM 1's launch, ~48 workgroups on the CUs the tile grid leaves idle -- 83 KB of
+// cold reads per workgroup, and what ONE CU pulls from cold memory (~15-20 GB/s) is what bounds these small kernels: GEMM 1
+// took 15.8 us with the 18 partials against 12.8 us with one vector (profiles/r04_*).  Here every workgroup adds its partial dot
+// products into ONE vector o_fix [E] of 64-bit FIXED-POINT accumulators (value * 2^36, integer atomic adds: associative, so
+// the sum is the same whatever order the workgroups arrive in -- float atomics would make the step's results vary from launch
+// to launch).  o_fix must be zero on entry: hicom_fused_stream_fwd zeroes it (same stream, one launch earlier).
+// Narrower slabs (32 channels, 36 x 9 = 324 workgroups, two or more per CU): the 9 MB of partial states spread evenly over
+// the chip instead of 71 KB on each of 162 CUs.
+constexpr float kMvFixScale = 68719476736.f;          // 2^36: |o| < 2^26 representable, 1.5e-11 resolution
+
+struct MergeVprojFixParams {
+    const float* part_m;
+    const float* part_l;
+    const void* part_acc;   // fp32 un-normalised accumulators, or (F16) fp16 normalised contexts
+    int nparts, rows_pad, E, hd;
+    const uint16_t* wv;     // bf16 [E, E]
+    long long* o_fix;       // [E] fixed-point accumulators (zero on entry)
+    float* out_ml;          // [R][2] or NULL
+    float* out_ctx;         // [R][E] normalised, or NULL
+};
+
+template <int kMvSlab, bool F16>      // channels per workgroup (32 or 64); partials as normalised fp16 contexts
+__global__ __launch_bounds__(256) void merge_vproj_fixed_kernel(MergeVprojFixParams p) {
+    constexpr int NC4 = kMvSlab / 4;             // 4-channel columns of the slab
+    constexpr int NG = 256 / NC4;                // partial groups
+    constexpr int NU = (256 + NG - 1) / NG;      // partials per thread
+    constexpr int WQ = kMvSlab / 16;             // 16-byte weight chunks per thread (the slab halved between a row's two threads)
+    __shared__ float wp[256];
+    __shared__ float red[4];
+    __shared__ __attribute__((aligned(16))) float cpart[NG][kMvSlab];
+    __shared__ __attribute__((aligned(16))) float cx[kMvSlab];
+    const int slab = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    // v_proj weights of this (head, slab) first: independent of everything else here
+    const int j = tid >> 1, half = tid & 1;
+    u32x4 wreg[WQ];
+#pragma unroll
+    for (int q = 0; q < WQ; ++q)
+        wreg[q] = (j < p.hd) ? *reinterpret_cast<const u32x4*>(p.wv + (long)(h * p.hd + j) * p.E + slab * kMvSlab + (kMvSlab / 2) * half + 8 * q) : u32x4{0, 0, 0, 0};
+    // raw partial rows: thread = (float4 column c4 of the slab, partial group pg of NG); all of a thread's <= NU loads in flight
+    const int c4 = tid % NC4, pg = tid / NC4;
+    const long eoff = (long)h * p.E + slab * kMvSlab + 4 * c4;
+    const long pstride = (long)p.rows_pad * p.E;
+    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+    float4 v[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int i = pg + NG * u;
+        if constexpr (F16) {
+            half4_t hv = half4_t{0, 0, 0, 0};
+            if (i < p.nparts) hv = *reinterpret_cast<const half4_t*>(reinterpret_cast<const _Float16*>(p.part_acc) + eoff + (long)i * pstride);
+            v[u] = make_float4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
+        } else {
+            v[u] = (i < p.nparts) ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.part_acc) + eoff + (long)i * pstride)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float pm = tid < p.nparts ? p.part_m[(long)tid * p.rows_pad + h] : -1.0e30f;       // nparts <= 256 (host-checked)
+    const float pl = tid < p.nparts ? p.part_l[(long)tid * p.rows_pad + h] : 0.f;
+    const float M = block_reduce_max(pm, red);
+    const float w = tid < p.nparts ? expf(pm - M) : 0.f;
+    wp[tid] = F16 ? w * pl : w;                          // (normalised contexts are weighed with l e^(m - M))
+    const float L = block_reduce_sum(w * pl, red);       // (barriers inside: wp[] is visible afterwards)
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int i = pg + NG * u;
+        const float wu = i < 256 ? wp[i] : 0.f;
+        a.x = fmaf(wu, v[u].x, a.x); a.y = fmaf(wu, v[u].y, a.y); a.z = fmaf(wu, v[u].z, a.z); a.w = fmaf(wu, v[u].w, a.w);
+    }
+    *reinterpret_cast<float4*>(&cpart[pg][4 * c4]) = a;
+    __syncthreads();
+    if (tid < kMvSlab) {
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) sum += cpart[g][tid];
+        const float val = sum / L;
+        cx[tid] = val;
+        if (p.out_ctx) p.out_ctx[(long)h * p.E + slab * kMvSlab + tid] = val;
+    }
+    if (tid == 0 && slab == 0 && p.out_ml) {
+        p.out_ml[2 * h] = M;
+        p.out_ml[2 * h + 1] = L;
+    }
+    __syncthreads();
+    // partial v_proj: thread (j, half) dots its half of the slab with weight row h*hd + j
+    float dot = 0.f;
+    if (j < p.hd) {
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const u32x4 g = wreg[q];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dot = fmaf(bf16lo_to_f32(g[i]), cx[(kMvSlab / 2) * half + 8 * q + 2 * i], dot);
+                dot = fmaf(bf16hi_to_f32(g[i]), cx[(kMvSlab / 2) * half + 8 * q + 2 * i + 1], dot);
+            }
+        }
+    }
+    dot += __shfl_xor(dot, 1, 64);
+    if (half == 0 && j < p.hd) {
+        const long long q = (long long)rintf(dot * kMvFixScale);
+        __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned long long*)(p.o_fix + h * p.hd + j), (unsigned long long)q,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // result unused: no-return atomic
+    }
 }
 
 }  // namespace hicom
@@ -479,6 +593,21 @@ extern "C" int hicom_global_combine_strided_fwd(const float* ml, const float* ac
     hipLaunchKernelGGL(combine_kernel, dim3((unsigned)rows, (unsigned)((E + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, ml, acc, (long)set_stride, (long)set_stride, nsets, rows, E, ctx);
     return hicom_host::check_launch("global_combine_strided");
+}
+
+extern "C" int hicom_merge_vproj_fixed_fwd(const float* part_m, const float* part_l, const void* part_acc, int32_t part_dt, int32_t nparts,
+                                           int32_t rows, int32_t rows_pad, int32_t E, const void* w_v, int64_t* o_fix,
+                                           float* out_ml, float* out_ctx, void* stream) {
+    HICOM_REQUIRE(part_m && part_l && part_acc && w_v && o_fix, HICOM_EINVAL, "merge_vproj_fixed: NULL pointer");
+    HICOM_REQUIRE(nparts > 0 && nparts <= 256 && rows > 0 && rows <= rows_pad && E > 0 && E % 64 == 0 && E % rows == 0 &&
+                      E / rows <= 128 && ((uintptr_t)o_fix % 8 == 0) && ((uintptr_t)w_v % 16 == 0) && ((uintptr_t)part_acc % 16 == 0),
+                  HICOM_EINVAL, "merge_vproj_fixed: bad shape (nparts <= 256, head dim <= 128, E %% 32) or alignment");
+    MergeVprojFixParams p{part_m, part_l, part_acc, nparts, rows_pad, E, E / rows, (const uint16_t*)w_v, (long long*)o_fix, out_ml, out_ctx};
+    HICOM_REQUIRE(part_dt == HICOM_DT_F32 || part_dt == HICOM_DT_F16, HICOM_EINVAL, "merge_vproj_fixed: part_dt");
+    // (32-channel slabs -- 324 workgroups -- measured 5.9 us against 5.5 us for 64: the atomics, not the partial reads, grow)
+    if (part_dt == HICOM_DT_F16) HICOM_LAUNCH((merge_vproj_fixed_kernel<64, true>), dim3((unsigned)(E / 64), (unsigned)rows), dim3(256), 0, (hipStream_t)stream, p);
+    else HICOM_LAUNCH((merge_vproj_fixed_kernel<64, false>), dim3((unsigned)(E / 64), (unsigned)rows), dim3(256), 0, (hipStream_t)stream, p);
+    return hicom_host::check_launch("merge_vproj_fixed");
 }
 
 extern "C" int hicom_merge_vproj_fwd(const float* part_m, const float* part_l, const float* part_acc, int32_t nparts,

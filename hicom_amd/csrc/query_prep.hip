@@ -53,6 +53,8 @@ struct PrepParams {
     int nq_wg, nr_wg, nf_wg, np_wg;      // workgroups per role, in block order: q_proj | r0 | fold-w | fold-pos
 };
 
+// (round 4: 2 / 4 rows per wave -- 299 workgroups, 18 / 36 KB of cold weights each -- measured 10.9 us against 9.3 us: more than
+// one workgroup per CU puts consumers beside producers, as round 3 found)
 constexpr int kQRows = 4;                // q_proj outputs per wave (72 workgroups at E = 1152: the whole grid stays <= 256 workgroups)
 constexpr int kRRows = 8;                // r0 outputs per wave
 constexpr int kPrepCh = 3;               // 16-byte chunks per lane and row: K <= 1536

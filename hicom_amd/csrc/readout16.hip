@@ -45,6 +45,7 @@ struct AuxGemv {
     void* dst;
     int dst_f32, reps;
     long ldd, row0;
+    const long long* x_fixed;   // alternative x: fixed-point accumulators (value * HICOM_FIXED_SCALE), or NULL
 };
 
 struct R16Params {
@@ -77,7 +78,7 @@ __device__ __forceinline__ _Float16 to_f16_sat(float v) {
 // ---- aux role: one GEMV over `n_aux` workgroups.  A wave owns up to CB = 6 columns (1152 columns over 56 x 4 waves = one
 // batch) and requests ALL of their weight rows first; the partial vectors of x are requested right behind them, so the two
 // cold-memory latencies of the role overlap instead of adding up.
-template <bool WF32>
+template <bool WF32, bool XFIX>
 __device__ __forceinline__ void aux_gemv_role(const AuxGemv& g, int aux_idx, int n_aux, char* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* xl = reinterpret_cast<float*>(lds);       // [K]   x
@@ -111,39 +112,51 @@ __device__ __forceinline__ void aux_gemv_role(const AuxGemv& g, int aux_idx, int
     // x = sum of the partial vectors (+ bias).  Phase 1: every float4 of every part is requested at once (a serial
     // loop over the parts is x_parts dependent L2 round trips: 20 us for 18 parts) and parked in LDS; phase 2 sums
     // each column over the parts in part order -- deterministic, no atomics.
-    const int k4n = g.K >> 2, items = g.x_parts * k4n;
-    constexpr int XR = 28;                            // x_parts * K / 4 <= 28 * 256 (host-checked)
-    float4 t[XR];
-    {
-        int sidx = tid / k4n, k4 = tid - sidx * k4n;                        // (part, float4 column) of item tid; then += 256 items
-        const int dq = 256 / k4n, dr = 256 - dq * k4n;
+    if constexpr (XFIX) {
+        // x from the fixed-point accumulators of hicom_merge_vproj_fixed_fwd: ONE 8-byte value per element (K <= 1536 = 6 per thread)
+        long long xf[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) xf[u] = (tid + 256 * u < g.K) ? g.x_fixed[tid + 256 * u] : 0ll;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int k = tid + 256 * u;
+            if (k < g.K) xl[k] = (float)xf[u] * (1.0f / HICOM_FIXED_SCALE) + (g.xb ? bf16_to_f32(g.xb[k]) : 0.f);
+        }
+    } else {
+        const int k4n = g.K >> 2, items = g.x_parts * k4n;
+        constexpr int XR = 28;                            // x_parts * K / 4 <= 28 * 256 (host-checked)
+        float4 t[XR];
+        {
+            int sidx = tid / k4n, k4 = tid - sidx * k4n;                        // (part, float4 column) of item tid; then += 256 items
+            const int dq = 256 / k4n, dr = 256 - dq * k4n;
+#pragma unroll
+            for (int u = 0; u < XR; ++u) {
+                const bool in = tid + 256 * u < items;                           // (clamped: the loads are unconditional)
+                t[u] = *reinterpret_cast<const float4*>(g.xs + (long)(in ? sidx : 0) * g.x_stride + 4 * (in ? k4 : 0));
+                sidx += dq;
+                k4 += dr;
+                if (k4 >= k4n) { k4 -= k4n; ++sidx; }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < XR; ++u) {
-            const bool in = tid + 256 * u < items;                           // (clamped: the loads are unconditional)
-            t[u] = *reinterpret_cast<const float4*>(g.xs + (long)(in ? sidx : 0) * g.x_stride + 4 * (in ? k4 : 0));
-            sidx += dq;
-            k4 += dr;
-            if (k4 >= k4n) { k4 -= k4n; ++sidx; }
+            const int it = tid + 256 * u;
+            if (it < items) *reinterpret_cast<float4*>(xp + 4 * it) = t[u];     // [part][K] order: it = part * k4n + k4
         }
-    }
+        __syncthreads();
+        for (int k = tid; k < g.K; k += 256) {
+            float v = g.xb ? bf16_to_f32(g.xb[k]) : 0.f;
+            int sidx = 0;
+            for (; sidx + 6 <= g.x_parts; sidx += 6) {                          // six LDS reads in flight; summed in part order
+                float r[6];
 #pragma unroll
-    for (int u = 0; u < XR; ++u) {
-        const int it = tid + 256 * u;
-        if (it < items) *reinterpret_cast<float4*>(xp + 4 * it) = t[u];     // [part][K] order: it = part * k4n + k4
-    }
-    __syncthreads();
-    for (int k = tid; k < g.K; k += 256) {
-        float v = g.xb ? bf16_to_f32(g.xb[k]) : 0.f;
-        int sidx = 0;
-        for (; sidx + 6 <= g.x_parts; sidx += 6) {                          // six LDS reads in flight; summed in part order
-            float r[6];
+                for (int u = 0; u < 6; ++u) r[u] = xp[(sidx + u) * g.K + k];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) r[u] = xp[(sidx + u) * g.K + k];
-#pragma unroll
-            for (int u = 0; u < 6; ++u) v += r[u];
+                for (int u = 0; u < 6; ++u) v += r[u];
+            }
+            for (; sidx < g.x_parts; ++sidx) v += xp[sidx * g.K + k];
+            xl[k] = v;
         }
-        for (; sidx < g.x_parts; ++sidx) v += xp[sidx * g.K + k];
-        xl[k] = v;
     }
     __syncthreads();
     float xr[CH][8];
@@ -205,8 +218,14 @@ template <int kRRing>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void readout16_gemm_kernel(R16Params p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [kRRing][kRStage]
     if ((int)blockIdx.x >= p.n_gemm) {
-        if (p.aux.w_f32) aux_gemv_role<true>(p.aux, (int)blockIdx.x - p.n_gemm, (int)gridDim.x - p.n_gemm, lds);
-        else aux_gemv_role<false>(p.aux, (int)blockIdx.x - p.n_gemm, (int)gridDim.x - p.n_gemm, lds);
+        const int ai = (int)blockIdx.x - p.n_gemm, an = (int)gridDim.x - p.n_gemm;
+        if (p.aux.x_fixed) {
+            if (p.aux.w_f32) aux_gemv_role<true, true>(p.aux, ai, an, lds);
+            else aux_gemv_role<false, true>(p.aux, ai, an, lds);
+        } else {
+            if (p.aux.w_f32) aux_gemv_role<true, false>(p.aux, ai, an, lds);
+            else aux_gemv_role<false, false>(p.aux, ai, an, lds);
+        }
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63;
@@ -490,14 +509,18 @@ extern "C" int hicom_readout16_gemm_fwd(const void* a, const void* w, const void
     const int nbx = (N + kRN - 1) / kRN, nby = (M + kRM - 1) / kRM;
     p.n_gemm = 8 * ((nbx * nby + 7) / 8);
     int n_aux = 0;
-    p.aux = AuxGemv{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, 0, 0, 0};
+    p.aux = AuxGemv{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, 0, 0, 0, nullptr};
     if (aux && aux->N > 0) {
-        HICOM_REQUIRE(aux->xs && aux->w && (aux->y || aux->rows_dst) && aux->x_parts > 0 && aux->K > 0 && aux->K % 8 == 0 && aux->K <= 1536 && aux->x_stride % 4 == 0 && ((uintptr_t)aux->xs % 16 == 0) &&
-                          ((uintptr_t)aux->w % 16 == 0) && (long)aux->x_parts * aux->K <= 28 * 1024 && (1536 + (long)aux->x_parts * aux->K) * 4 <= 6 * kRStage, HICOM_EINVAL, "readout16_gemm: aux GEMV arguments");
+        HICOM_REQUIRE(aux->w && (aux->y || aux->rows_dst) && aux->K > 0 && aux->K % 8 == 0 && aux->K <= 1536 && ((uintptr_t)aux->w % 16 == 0), HICOM_EINVAL,
+                      "readout16_gemm: aux GEMV arguments");
+        if (aux->x_fixed) HICOM_REQUIRE((uintptr_t)aux->x_fixed % 8 == 0, HICOM_EINVAL, "readout16_gemm: aux x_fixed alignment");
+        else HICOM_REQUIRE(aux->xs && aux->x_parts > 0 && aux->x_stride % 4 == 0 && ((uintptr_t)aux->xs % 16 == 0) && (long)aux->x_parts * aux->K <= 28 * 1024 &&
+                               (1536 + (long)aux->x_parts * aux->K) * 4 <= 6 * kRStage, HICOM_EINVAL, "readout16_gemm: aux GEMV partial vectors");
         HICOM_REQUIRE(!aux->rows_dst || (aux->rows_reps > 0 && aux->rows_ld >= aux->N && aux->rows_row0 >= 0), HICOM_EINVAL, "readout16_gemm: aux row destination");
         p.aux = AuxGemv{aux->xs, aux->x_parts, (long)aux->x_stride, (const uint16_t*)aux->xb, aux->w,
                         aux->b, (const uint16_t*)aux->res, aux->N, aux->K, aux->act, aux->y, aux->w_dt == HICOM_DT_F32, aux->b_dt == HICOM_DT_F32,
-                        aux->rows_dst, aux->rows_dt == HICOM_DT_F32, aux->rows_dst ? aux->rows_reps : 0, (long)aux->rows_ld, (long)aux->rows_row0};
+                        aux->rows_dst, aux->rows_dt == HICOM_DT_F32, aux->rows_dst ? aux->rows_reps : 0, (long)aux->rows_ld, (long)aux->rows_row0,
+                        (const long long*)aux->x_fixed};
         // the CUs the tile grid leaves idle (one workgroup per CU: the ring takes 120 KB of LDS), at least 16
         // the same number on every XCD, and ONE CU per XCD left free: with every CU of an XCD spoken for (25 tiles + 7 aux
         // = 32) an aux workgroup was seen queueing behind a 12-us tile (GEMM 1 in situ: 16.6 us with aux, 12.2 without)

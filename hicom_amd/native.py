@@ -15,7 +15,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 # HICOM_NATIVE_LIB: dev override (instrumented builds from tools/); the product loads the in-tree library
 LIB_PATH = os.environ.get("HICOM_NATIVE_LIB") or os.path.join(HERE, "libhicom_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 DT_BF16, DT_F32, DT_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_GELU_TANH = 0, 1, 2
@@ -32,7 +32,7 @@ EXPORTS = (
     "hicom_dense16_gemm_fwd", "hicom_ln_stream_fwd", "hicom_to_f16_padded_fwd", "hicom_clip_query_prep_fwd", "hicom_inv_norm_fwd",
     "hicom_global_stream_clip_fwd", "hicom_splice_rows_fwd", "hicom_splice_labels_fwd",
     "hicom_query_prep_fwd", "hicom_query_prep_state_bytes", "hicom_partials_sum_fwd", "hicom_l2norm_stream_fwd", "hicom_local_attn_adapt_fwd",
-    "hicom_small_mha_scaled_fwd",
+    "hicom_small_mha_scaled_fwd", "hicom_merge_vproj_fixed_fwd",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -52,7 +52,7 @@ class AuxGemv(C.Structure):
     _fields_ = [("xs", C.c_void_p), ("x_parts", C.c_int32), ("x_stride", C.c_int64), ("xb", C.c_void_p), ("w", C.c_void_p),
                 ("b", C.c_void_p), ("res", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32), ("act", C.c_int32), ("y", C.c_void_p),
                 ("w_dt", C.c_int32), ("b_dt", C.c_int32), ("rows_dst", C.c_void_p), ("rows_dt", C.c_int32), ("rows_reps", C.c_int32),
-                ("rows_ld", C.c_int64), ("rows_row0", C.c_int64)]
+                ("rows_ld", C.c_int64), ("rows_row0", C.c_int64), ("x_fixed", C.c_void_p)]
 
 
 class CompressorArgs(C.Structure):
@@ -122,7 +122,7 @@ def lib() -> C.CDLL:
                                          vp, vp, vp, i32, vp]
     L.hicom_linear_to_rows_fwd.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i64, i64, i32, vp]
     L.hicom_fused_stream_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, f32, vp, i32, vp, vp, i32, i32, i32,
-                                         vp, vp, vp, i32, vp, vp, vp, vp, vp]
+                                         vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, vp, vp]
     L.hicom_readout16_gemm_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i64, i64, i32, C.POINTER(AuxGemv), vp]
     L.hicom_to_f16_fwd.argtypes = [vp, i32, vp, i64, vp]
     L.hicom_splice_rows_fwd.argtypes = [vp, i64, i32, vp, vp]
@@ -139,6 +139,7 @@ def lib() -> C.CDLL:
                                                vp, vp, vp, i32, vp]
     L.hicom_ln_stream_fwd.argtypes = [vp, i32, i64, vp, vp, vp, vp, i32, f32, vp, i32, i32, i32, vp]
     L.hicom_merge_vproj_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.hicom_merge_vproj_fixed_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.hicom_fused_stream_nparts.argtypes = [i32]
     L.hicom_query_prep_state_bytes.argtypes = [i32]
     L.hicom_query_prep_state_bytes.restype = i64
@@ -358,7 +359,7 @@ def fused_stream_nparts(n_windows: int) -> int:
 
 
 def fused_stream(ff, fe, kt, ks, qhi, qlo, rows, l_scale, l_bias, pos_a, pe_hi, pe_lo, t0i, y0i, x0i, part_m, part_l,
-                 part_acc, ctx_local, ctx_hi=None, ctx_lo=None, ctx_f16=None, local_logits=None):
+                 part_acc, ctx_local, ctx_hi=None, ctx_lo=None, ctx_f16=None, local_logits=None, zero=None, part_ctx_f16=None):
     """pos_a f32 [16, P] + pe_hi / pe_lo bf16 [P, E] (all three or none): the kernel folds the value-side
     pos-emb into part_acc.  local_logits f32 [T*H*W] (fe . local query per token) replaces the frames_embed stream."""
     T, H, W, E = ff.shape
@@ -366,7 +367,8 @@ def fused_stream(ff, fe, kt, ks, qhi, qlo, rows, l_scale, l_bias, pos_a, pe_hi, 
                                         l_bias, _ptr(pos_a), pos_a.shape[1] if pos_a is not None else 0,
                                         _ptr(pe_hi), _ptr(pe_lo), t0i, y0i, x0i,
                                         _ptr(part_m), _ptr(part_l), _ptr(part_acc), part_m.shape[0], _ptr(ctx_local),
-                                        _ptr(ctx_hi), _ptr(ctx_lo), _ptr(ctx_f16), _stream()),
+                                        _ptr(ctx_hi), _ptr(ctx_lo), _ptr(ctx_f16), _ptr(zero),
+                                        zero.numel() * zero.element_size() if zero is not None else 0, _ptr(part_ctx_f16), _stream()),
            "hicom_fused_stream_fwd")
 
 
@@ -529,8 +531,11 @@ def readout16_gemm(a16, w16, b, act=ACT_NONE, out_f16=None, y=None, row0=0, nl_g
     ag = None
     if aux is not None:
         ag = AuxGemv()
-        xs = aux["xs"].reshape(-1, aux["w"].shape[1])
-        ag.xs, ag.x_parts, ag.x_stride = xs.data_ptr(), xs.shape[0], xs.shape[1]
+        if aux.get("x_fixed") is not None:                    # int64 [K] fixed-point accumulators (merge_vproj_fixed)
+            ag.x_fixed = aux["x_fixed"].data_ptr()
+        else:
+            xs = aux["xs"].reshape(-1, aux["w"].shape[1])
+            ag.xs, ag.x_parts, ag.x_stride = xs.data_ptr(), xs.shape[0], xs.shape[1]
         ag.xb = None if aux.get("xb") is None else aux["xb"].data_ptr()
         ag.w, ag.N, ag.K = aux["w"].data_ptr(), aux["w"].shape[0], aux["w"].shape[1]
         ag.b = None if aux.get("b") is None else aux["b"].data_ptr()
@@ -566,6 +571,14 @@ def merge_vproj(part_m, part_l, part_acc, rows, w_v, po, out_ml=None, out_ctx=No
     E = part_acc.shape[-1]
     _check(lib().hicom_merge_vproj_fwd(_ptr(part_m), _ptr(part_l), _ptr(part_acc), nparts, rows, rows_pad, E, _ptr(w_v), _ptr(po),
                                        _ptr(out_ml), _ptr(out_ctx), _stream()), "hicom_merge_vproj_fwd")
+
+
+def merge_vproj_fixed(part_m, part_l, part_acc, rows, w_v, o_fix, out_ml=None, out_ctx=None):
+    """o_fix int64 [E], zero on entry: fixed-point sums of the partial v_proj outputs (see include/hicom_hip.h)."""
+    nparts, rows_pad = part_m.shape
+    E = part_acc.shape[-1]
+    _check(lib().hicom_merge_vproj_fixed_fwd(_ptr(part_m), _ptr(part_l), _ptr(part_acc), _dt(part_acc), nparts, rows, rows_pad, E, _ptr(w_v), _ptr(o_fix),
+                                             _ptr(out_ml), _ptr(out_ctx), _stream()), "hicom_merge_vproj_fixed_fwd")
 
 
 def splice_rows(row_src, dst):

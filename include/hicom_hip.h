@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HICOM_ABI_VERSION 8
+#define HICOM_ABI_VERSION 9
 
 #define HICOM_OK         0
 #define HICOM_EINVAL    -1   /* bad argument (shape, alignment, NULL)        */
@@ -239,14 +239,20 @@ int hicom_global_stream_nparts(int64_t N, int32_t rows_pad);
  *                 hicom_fused_stream_nparts(number of windows)
  *   ctx_local   : f32 [Nw, E], window order (t1,h1,w1), and/or ctx_hi + ctx_lo: the same contexts as
  *                 bf16 planes (hi + lo) for hicom_planes_gemm_fwd, and/or ctx_f16: one fp16 plane (saturating) for
- *                 hicom_readout16_gemm_fwd; unused outputs NULL */
+ *                 hicom_readout16_gemm_fwd; unused outputs NULL
+ *   part_ctx_f16: not NULL: instead of part_acc (which may then be NULL) the kernel writes the NORMALISED partial contexts
+ *                 acc / l as one fp16 plane [nparts][16][E] (rows < rows), for hicom_merge_vproj_fixed_fwd(part_dt = HICOM_DT_F16):
+ *                 half the bytes of the partial states; the rounding (2^-12 relative per partial) averages over the partials
+ *   zero_ptr    : zero_bytes (multiple of 8, 8-byte aligned) of scratch that the kernel clears for the launches behind it on the
+ *                 stream (the fixed-point accumulators of hicom_merge_vproj_fixed_fwd), or NULL */
 int hicom_fused_stream_fwd(const void* ff, const void* fe, const float* local_logits, int32_t T, int32_t H, int32_t W, int32_t E,
                            int32_t kt, int32_t ks, const void* q_hi, const void* q_lo, int32_t rows,
                            float l_scale, float l_bias, const float* pos_a, int32_t pos_stride,
                            const void* pe_hi, const void* pe_lo,
                            int32_t t_index0, int32_t y_index0, int32_t x_index0,
                            float* part_m, float* part_l, float* part_acc, int32_t nparts, float* ctx_local,
-                           void* ctx_hi, void* ctx_lo, void* ctx_f16, void* stream);
+                           void* ctx_hi, void* ctx_lo, void* ctx_f16, void* zero_ptr, int64_t zero_bytes, void* part_ctx_f16,
+                           void* stream);
 int hicom_fused_stream_nparts(int32_t n_windows);
 
 /* ---- merge the partials (+ the value-side positional term) --------------------------------
@@ -313,6 +319,9 @@ typedef struct hicom_aux_gemv {
     void* rows_dst;
     int32_t rows_dt, rows_reps;
     int64_t rows_ld, rows_row0;
+    /* alternative source of x: x[k] = x_fixed[k] / HICOM_FIXED_SCALE + xb[k] (hicom_merge_vproj_fixed_fwd's accumulators); then xs
+     * may be NULL and x_parts is ignored */
+    const int64_t* x_fixed;
 } hicom_aux_gemv;
 int hicom_readout16_gemm_fwd(const void* a, const void* w, const void* b, int32_t b_dt,
                              int32_t M, int32_t N, int32_t K, int32_t act, void* out_f16,
@@ -329,6 +338,15 @@ int hicom_to_f16_padded_fwd(const void* src, int32_t src_dt, int64_t rows, int64
 int hicom_merge_vproj_fwd(const float* part_m, const float* part_l, const float* part_acc, int32_t nparts,
                           int32_t rows, int32_t rows_pad, int32_t E, const void* w_v, float* po,
                           float* out_ml, float* out_ctx, void* stream);
+/* The same with the slab sums taken inside the launch: o_fix int64 [E] receives sum_slabs po[slab][:] as FIXED-POINT values
+ * (value * 2^36 = HICOM_FIXED_SCALE; integer atomic adds, i.e. bit-identical results whatever the arrival order).  o_fix must be
+ * ZERO on entry (hicom_fused_stream_fwd's zero_ptr: the launch in front of this one clears it).  part_dt HICOM_DT_F32: part_acc
+ * are the un-normalised fp32 accumulators; HICOM_DT_F16: the normalised fp16 contexts (part_ctx_f16).  The consumer reads o_fix through
+ * hicom_aux_gemv.x_fixed: one 9-KB vector instead of E/64 partial vectors per workgroup. */
+#define HICOM_FIXED_SCALE 68719476736.0f
+int hicom_merge_vproj_fixed_fwd(const float* part_m, const float* part_l, const void* part_acc, int32_t part_dt, int32_t nparts,
+                                int32_t rows, int32_t rows_pad, int32_t E, const void* w_v, int64_t* o_fix,
+                                float* out_ml, float* out_ctx, void* stream);
 
 /* ---- dense 16-bit MFMA GEMM over all tokens (M = T*729) ------------------------------------------------------------
  * C = epilogue(A[M,K] . W[N,K]^T + b): A, W both fp16 or both bf16 (operand_dt), leading dimensions lda / ldw elements,

@@ -533,6 +533,72 @@ def test_readout16_aux_gemv_and_merge_vproj():
     assert maxabs(y3, torch.nn.functional.gelu(want.float().double() @ w3.double().t())) <= 2e-5 * max(1.0, float(want.abs().max()))
 
 
+@pytest.mark.parametrize("nparts", [216, 7, 256])
+def test_merge_vproj_fixed_point_accumulators(nparts):
+    """Round 4: merge + v_proj with the slab sums taken inside the launch.  Integer (fixed-point, 2^36) atomic adds: the result
+    equals the slab-ordered float sum of the partial-vector form to ~1e-6, is BIT-IDENTICAL from launch to launch (integer addition
+    is associative: arrival order cannot matter), and the aux GEMV reads it through x_fixed."""
+    g = torch.Generator().manual_seed(50 + nparts)
+    E, nh = 1152, 9
+    pm = torch.randn(nparts, 16, generator=g).cuda() * 3
+    pl = (torch.rand(nparts, 16, generator=g) + 0.5).cuda()
+    pacc = torch.randn(nparts, 16, E, generator=g).cuda()
+    wv = bf(torch.randn(E, E, generator=g) * 0.02)
+    bv = bf(torch.randn(E, generator=g) * 0.02)
+    po = torch.empty(E // 64, E, device="cuda")
+    ml, ctx = torch.empty(nh, 2, device="cuda"), torch.empty(nh, E, device="cuda")
+    nv.merge_vproj(pm, pl, pacc, nh, wv, po, ml, ctx)
+    runs = []
+    for _ in range(3):
+        ofx = torch.zeros(E, dtype=torch.int64, device="cuda")
+        ml2, ctx2 = torch.empty(nh, 2, device="cuda"), torch.empty(nh, E, device="cuda")
+        nv.merge_vproj_fixed(pm, pl, pacc, nh, wv, ofx, ml2, ctx2)
+        runs.append(ofx)
+    torch.cuda.synchronize()
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    o_fixed = runs[0].double() / 2.0 ** 36
+    assert maxabs(ctx2, ctx) <= 1e-5 and maxabs(ml2, ml) <= 1e-5
+    assert maxabs(o_fixed, po.double().sum(0)) <= 5e-6
+    # the partial states as NORMALISED fp16 contexts (what the stream kernel writes on the hot path): acc / l per partial
+    p16 = (pacc / pl[:, :, None]).to(torch.float16)
+    ofx16 = torch.zeros(E, dtype=torch.int64, device="cuda")
+    ctx3 = torch.empty(nh, E, device="cuda")
+    nv.merge_vproj_fixed(pm, pl, p16, nh, wv, ofx16, None, ctx3)
+    torch.cuda.synchronize()
+    assert maxabs(ctx3, ctx) <= 2.0 ** -11 * float(p16.float().abs().max())       # one fp16 rounding per partial, weights sum to 1
+    assert maxabs(ofx16.double() / 2.0 ** 36, po.double().sum(0)) <= 1e-3
+    # the consumer: y = GELU(W (o + b_v) + b) from the fixed-point vector
+    w3 = bf(torch.randn(896, E, generator=g) * 0.02)
+    b3 = torch.randn(896, generator=g).cuda()
+    y3 = torch.empty(896, device="cuda")
+    a16 = nv.to_f16(torch.randn(200, 128, generator=g).cuda())
+    w16 = nv.to_f16(torch.randn(64, 128, generator=g).cuda())
+    o16 = torch.empty(200, 64, dtype=torch.float16, device="cuda")
+    nv.readout16_gemm(a16, w16, None, out_f16=o16, aux=dict(x_fixed=runs[0], xb=bv, w=w3, b=b3, act=nv.ACT_GELU, y=y3))
+    torch.cuda.synchronize()
+    want = torch.nn.functional.gelu((o_fixed + bv.double()) @ w3.double().t() + b3.double())
+    assert maxabs(y3, want) <= 2e-5
+
+
+def test_fused_stream_clears_the_scratch_it_is_given():
+    """hicom_fused_stream_fwd's zero_ptr: workgroup 0 clears the accumulators of the merge + v_proj launch behind it."""
+    T, H, W, kt, ks, R = 8, 6, 6, 4, 3, 9
+    x = synth.synth_inputs(T, H, W, D, tag="fz")
+    ff, fe = bf(x["ff"]), bf(x["fe"])
+    qhi = bf(torch.randn(16, D) * 0.05)
+    qlo = torch.zeros_like(qhi)
+    nw = (T // kt) * (H // ks) * (W // ks)
+    nparts = nv.fused_stream_nparts(nw)
+    pm, pl, pa = torch.empty(nparts, 16, device="cuda"), torch.empty(nparts, 16, device="cuda"), torch.empty(nparts, 16, D, device="cuda")
+    ctx = torch.empty(nw, D, device="cuda")
+    z = torch.full((D,), 0x7FFFFFFF, dtype=torch.int64, device="cuda")
+    guard = torch.full((16,), 77, dtype=torch.int64, device="cuda")
+    buf = torch.cat([guard, z, guard])
+    nv.fused_stream(ff, fe, kt, ks, qhi, qlo, R, 1 / math.sqrt(D), 0.0, None, None, None, 0, T, T + H, pm, pl, pa, ctx, zero=buf[16:16 + D])
+    torch.cuda.synchronize()
+    assert int(buf[16:16 + D].abs().sum()) == 0 and bool((buf[:16] == 77).all()) and bool((buf[-16:] == 77).all())
+
+
 @pytest.mark.parametrize("T,H,W,kt,ks,shared_query", [(8, 6, 6, 4, 3, True), (7, 7, 5, 4, 3, False), (4, 6, 6, 4, 3, False)])
 def test_local_attn_bwd_matches_torch_autograd(T, H, W, kt, ks, shared_query):
     """dq per window (any geometry, overlapping windows included) and d key (exact partitions) of the windowed attention against
