@@ -266,9 +266,9 @@ class _CompressorFn(torch.autograd.Function):
         from . import engine
         from .projector import _out_dtype
         with torch.no_grad():
-            if _is_plain(proj):
+            if proj.use_executor and proj._executor_covers():          # (plain recipes and the k / v adaptors: one C call)
                 out = engine.run_dense(proj, ff, fe, guide, modal, nl, _out_dtype(proj))
-            else:                                                      # adaptors / coarse injection: operator by operator
+            else:                                                      # query-side adaptors / coarse / fine injection: operator by operator
                 out = proj.forward_stepwise(ff, fe, guide, modal, nl)
         ctx.proj, ctx.modal, ctx.names = proj, modal, names
         ctx.save_for_backward(ff, fe, guide, nl)

@@ -32,7 +32,7 @@ namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct WsLayout {
-    size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, qp, qhi, qlo, pos_a, prep_state, scores, part_m, part_l, part_acc, scratch, ml, acc,
+    size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, ad_hid, ad_ky, ad_vy, qp, qhi, qlo, pos_a, prep_state, scores, part_m, part_l, part_acc, scratch, ml, acc,
         ctx_g, o, qres, pre, hid_g, tok, po, o_fix, r0, total;
     int nw, R, rows_pad, nparts, P;
     long N, score_stride;
@@ -42,6 +42,7 @@ struct WsLayout {
 // ("direct"), plain 1/sqrt(d) logits, windows that partition the grid, <= 14 folded global rows.
 bool can_fuse(const hicom_compressor_args& a) {
     if (!(a.has_local && a.has_global) || !a.lq || a.lq_stride != 0 || a.lq_dt != HICOM_DT_BF16 || a.l2norm != 0) return false;
+    if (a.ak.w0 || a.av.w0) return false;         // adapted local streams: the two stages no longer share their tokens
     if (a.E != 1152 || a.nq * a.nh > 12) return false;
     for (const hicom_axis* x : {&a.at, &a.ay, &a.ax})
         if (x->n % x->k != 0 || x->nfull != x->nwin) return false;
@@ -89,6 +90,11 @@ WsLayout make_layout(const hicom_compressor_args& a) {
         w.hid_hi = w.hid_local;
         w.hid_lo = w.hid_local + (size_t)w.nw * a.hidden * 2;
         w.pooled_q = take(a.lq ? 0 : (size_t)w.nw * a.E * 4);
+        // adaptor streams: the hidden layer of the MLP (shared by the two streams, which run one after the other) and y = MLP(x)
+        // per adapted stream, fp16 [N, E]
+        if (a.ak.w0 || a.av.w0) w.ad_hid = take((size_t)w.N * a.E * 2);
+        if (a.ak.w0) w.ad_ky = take((size_t)w.N * a.E * 2);
+        if (a.av.w0) w.ad_vy = take((size_t)w.N * a.E * 2);
     }
     if (a.has_global) {
         w.qp = take((size_t)a.nq * a.E * 4);
@@ -155,6 +161,11 @@ int check_args(const hicom_compressor_args& a) {
     HICOM_REQUIRE(a.T > 0 && a.H > 0 && a.W > 0 && (a.E == 1152 || a.E == 768), HICOM_EINVAL, "compressor: bad input shape");
     HICOM_REQUIRE(a.hidden > 0 && a.hidden % 64 == 0, HICOM_EUNSUP, "compressor: hidden size %d must be a multiple of 64", a.hidden);
     if (a.has_local) HICOM_REQUIRE(a.lw0 && a.lw2, HICOM_EINVAL, "compressor: local readout weights");
+    for (const auto* ad : {&a.ak, &a.av})
+        if (ad->w0) {
+            HICOM_REQUIRE(a.has_local && ad->w2_f16 && ad->gamma && ad->beta && ad->alpha, HICOM_EINVAL, "compressor: adaptor weights");
+            HICOM_REQUIRE(a.l2norm == 0 && a.E % 64 == 0, HICOM_EUNSUP, "compressor: adaptors with clip-scale / E %% 64 != 0 run operator by operator");
+        }
     if (a.has_global) {
         HICOM_REQUIRE(a.gq && a.nq > 0 && a.nh > 0 && a.wq && a.wk && a.wv && a.wo && a.gw0 && a.gw2, HICOM_EINVAL,
                       "compressor: global weights");
@@ -363,8 +374,29 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                 q_dt = HICOM_DT_F32;
                 q_stride = a.E;
             }
-            CHK(hicom_local_attn_fwd(a.fe ? a.fe : a.ff, HICOM_DT_BF16, a.ff, HICOM_DT_BF16, a.E, a.at, a.ay, a.ax, q, q_dt, q_stride, a.l_scale,
-                                     a.l_bias, a.l2norm, F(w.ctx_local), sm));
+            if (a.ak.w0 || a.av.w0) {
+                // k / v adaptors (projector.py:533-534): y = MLP(x) over all tokens on the dense MFMA GEMM (raw bf16 tokens x bf16
+                // weights -> fp16 hidden with GELU -> fp16 y), then the window attention with LayerNorm + alpha blend fused into
+                // its row loads: the blended streams are never written
+                const void* key_x = a.fe ? a.fe : a.ff;
+                auto mlp = [&](const hicom_compressor_args::hicom_adaptor& ad, const void* x, size_t y_off) -> int {
+                    CHK(hicom_dense16_gemm_fwd(x, a.E, ad.w0, a.E, HICOM_DT_BF16, ad.b0, HICOM_DT_BF16, (int32_t)w.N, a.E, a.E, HICOM_ACT_GELU,
+                                               ws + w.ad_hid, a.E, a.E, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0, 0, nullptr, 0,
+                                               nullptr, sm));
+                    return hicom_dense16_gemm_fwd(ws + w.ad_hid, a.E, ad.w2_f16, a.E, HICOM_DT_F16, ad.b2, HICOM_DT_BF16, (int32_t)w.N, a.E, a.E,
+                                                  HICOM_ACT_NONE, ws + y_off, a.E, a.E, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0, 0,
+                                                  nullptr, 0, nullptr, sm);
+                };
+                if (a.ak.w0) CHK(mlp(a.ak, key_x, w.ad_ky));
+                if (a.av.w0) CHK(mlp(a.av, a.ff, w.ad_vy));
+                CHK(hicom_local_attn_adapt_fwd(key_x, a.ak.w0 ? ws + w.ad_ky : nullptr, a.ak.gamma, a.ak.beta, a.ak.alpha,
+                                               a.ff, a.av.w0 ? ws + w.ad_vy : nullptr, a.av.gamma, a.av.beta, a.av.alpha,
+                                               a.adapt_alpha_dt, a.adapt_eps, a.E, a.at, a.ay, a.ax, q, q_dt, q_stride, a.l_scale, a.l_bias,
+                                               F(w.ctx_local), sm));
+            } else {
+                CHK(hicom_local_attn_fwd(a.fe ? a.fe : a.ff, HICOM_DT_BF16, a.ff, HICOM_DT_BF16, a.E, a.at, a.ay, a.ax, q, q_dt, q_stride, a.l_scale,
+                                         a.l_bias, a.l2norm, F(w.ctx_local), sm));
+            }
         }
         if (a.has_global) {
             if (!a.reuse_queries) CHK(query_prep(sg, false));        // (guide off: weight-only, kept in the workspace across calls)

@@ -273,11 +273,12 @@ def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: in
     lc, gc = projector.local_compressor, projector.global_compressor
     if lc is None or gc is None:
         raise NotImplementedError("sharded_forward expects both compressors")
-    if not (lc.is_plain and gc.is_plain):
-        # coarse / fine / adaptor recipes compute their injected queries per call from the guide; the shard plans patch only
-        # the fields that alias the guide tensor itself (direct) -- refuse instead of running a stale query
-        raise NotImplementedError("sharded_forward: use_guide in (None, 'off', 'direct') without adaptors (the recipes of the "
-                                  "one-call executor); other recipes run unsharded through HIComProjector.forward")
+    if not projector._executor_covers():
+        # coarse / fine / query-side adaptor recipes compute their injected queries per call from the guide; the shard plans patch
+        # only the fields that alias the guide tensor itself (direct) -- refuse instead of running a stale query.  The k / v adaptors
+        # act on the tokens (shard-local, like the windows): the second released recipe `local43_adaptkv_global32` shards.
+        raise NotImplementedError("sharded_forward: use_guide in (None, 'off', 'direct'), optionally with k / v adaptors (the recipes "
+                                  "of the one-call executor); other recipes run unsharded through HIComProjector.forward")
     projector._check_clip_logits()
     if projector.global_logit is not None:
         raise NotImplementedError("sharded_forward: no clip-scale global stage (use forward_stepwise, unsharded)")

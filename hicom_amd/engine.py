@@ -112,6 +112,20 @@ def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, 
         w0_16, w2_16 = lc.readout_f16()                               # fp16 copies, cached per weight version
         a.lw0_f16, a.lw2_f16 = w0_16.data_ptr(), w2_16.data_ptr()
         keep += [w0_16, w2_16]
+        if lc.adapt_k or lc.adapt_v:                                  # k / v adaptors (ref :431-457, :533-534)
+            from . import injector as inj
+            if lc.adapt_q or lc.adapt_guide or ls is not None:
+                raise NotImplementedError("the one-call executor takes k / v adaptors without query-side adaptors and without clip-scale")
+            for on, dst, mlp, norm, alpha in ((lc.adapt_k, a.ak, lc.k_proj, lc.k_norm, lc.k_alpha), (lc.adapt_v, a.av, lc.v_proj, lc.v_norm, lc.v_alpha)):
+                if not on:
+                    continue
+                dst.w0, dst.b0 = _w(mlp[0])
+                w2_16a = inj._f16_weight(mlp[2])
+                dst.w2_f16, dst.b2 = w2_16a.data_ptr(), mlp[2].bias.data_ptr()
+                _require_bf16_cuda("adaptor norm", norm.weight)
+                dst.gamma, dst.beta, dst.alpha = norm.weight.data_ptr(), norm.bias.data_ptr(), alpha.data_ptr()
+                a.adapt_alpha_dt, a.adapt_eps = nv._dt(alpha), norm.eps
+                keep.append(w2_16a)
     if gc is not None:
         gc._check_native(None)
         if proj.global_logit is not None:
@@ -326,6 +340,11 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
         def refresh(lc=lc, gc=gc, T=T, H=H, W=W, dev=dev, use_gc0=use_gc0):
             if lc is not None:
                 lc.readout_f16()
+                if lc.adapt_k or lc.adapt_v:
+                    from . import injector as inj
+                    for on, mlp in ((lc.adapt_k, lc.k_proj), (lc.adapt_v, lc.v_proj)):
+                        if on:
+                            inj._f16_weight(mlp[2])
             if gc is not None:
                 if gc.use_pos_emb:
                     gc.pos_and_kpe(T, H, W, dev)

@@ -97,7 +97,9 @@ def _f16_weight(lin):
     stamp = nv.weight_stamp(w)
     hit = lin.__dict__.get("_hicom_f16")
     if hit is None or hit[0] != stamp:
-        hit = (stamp, nv.f16_weight_copy(w))
+        # refreshed IN PLACE where the old copy fits (same device, same shape): executor plans hold its address
+        old = hit[1] if (hit is not None and hit[1].device == w.device) else None
+        hit = (stamp, nv.f16_weight_copy(w, out=old))
         lin.__dict__["_hicom_f16"] = hit
     return hit[1]
 

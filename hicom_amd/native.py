@@ -55,6 +55,12 @@ class AuxGemv(C.Structure):
                 ("rows_ld", C.c_int64), ("rows_row0", C.c_int64), ("x_fixed", C.c_void_p)]
 
 
+class Adaptor(C.Structure):
+    """hicom_compressor_args.ak / .av: one k / v adaptor of the local stage (include/hicom_hip.h)."""
+    _fields_ = [("w0", C.c_void_p), ("b0", C.c_void_p), ("w2_f16", C.c_void_p), ("b2", C.c_void_p), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("alpha", C.c_void_p)]
+
+
 class CompressorArgs(C.Structure):
     """hicom_compressor_args (include/hicom_hip.h) -- field order and types must match the header."""
     _fields_ = [
@@ -84,6 +90,7 @@ class CompressorArgs(C.Structure):
         ("place_src", C.c_void_p), ("place_block_stride", C.c_int64), ("place_block_rows", C.c_int32), ("place_nblocks", C.c_int32),
         ("ev_done", C.c_void_p), ("stream_next", C.c_void_p),
         ("gc0", C.c_void_p), ("local_logits", C.c_void_p), ("reuse_queries", C.c_int32),
+        ("ak", Adaptor), ("av", Adaptor), ("adapt_alpha_dt", C.c_int32), ("adapt_eps", C.c_float),
     ]
 
 

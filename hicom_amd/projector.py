@@ -302,6 +302,13 @@ class LocalCompressor(nn.Module):
         return (self.use_guide in _NATIVE_GUIDE_MODES and _plain_injector(self.guide_injector)
                 and not (self.adapt_q or self.adapt_k or self.adapt_v or self.adapt_guide))
 
+    @property
+    def executor_ok(self) -> bool:
+        """The one-call executor also covers the k / v adaptors (the second released recipe `local43_adaptkv_global32`): guide
+        direct / off, plain injector, no query-side adaptor.  (Clip-scale on the local stage with adaptors: operator by operator.)"""
+        return (self.use_guide in _NATIVE_GUIDE_MODES and _plain_injector(self.guide_injector)
+                and not (self.adapt_q or self.adapt_guide) and self.qk_dim % 64 == 0)
+
     def _check_native(self):
         if self.use_guide not in (None, "off", "direct", "coarse", "fine"):
             raise NotImplementedError(f"LocalCompressor: use_guide={self.use_guide!r}")
@@ -540,6 +547,8 @@ class GlobalCompressor(nn.Module):
     def is_plain(self) -> bool:
         return self.use_guide in _NATIVE_GUIDE_MODES and _plain_injector(self.guide_injector) and not self.adapt_guide
 
+    executor_ok = is_plain
+
     def _check_native(self, logit_scale):
         if self.use_guide not in (None, "off", "direct", "coarse", "fine"):
             raise NotImplementedError(f"GlobalCompressor: use_guide={self.use_guide!r}")
@@ -723,12 +732,19 @@ class HIComProjector(nn.Module):
             from . import autograd
             return autograd.forward_with_grad(self, frames_feature, frames_embed, guide_embed, modal, image_newline)
         nv.begin_inference()           # (the first inference forward after training rebuilds the weight-derived tables)
-        plain = all(c is None or c.is_plain for c in (self.local_compressor, self.global_compressor))
-        if self.use_executor and plain and self.global_logit is None and not isinstance(frames_feature, dict):
+        if self.use_executor and self._executor_covers() and not isinstance(frames_feature, dict):
             from . import engine
             return engine.run_dense(self, frames_feature, frames_embed, guide_embed, modal, image_newline,
                                     _out_dtype(self))
         return self.forward_stepwise(frames_feature, frames_embed, guide_embed, modal, image_newline)
+
+    def _executor_covers(self) -> bool:
+        """Recipes hicom_compressor_fwd runs in one call: guide direct / off with a plain injector, optionally with k / v adaptors
+        on the local stage; no clip-scale on the global stage, none on an adapted local stage."""
+        lc, gc = self.local_compressor, self.global_compressor
+        if not all(c is None or c.executor_ok for c in (lc, gc)) or self.global_logit is not None:
+            return False
+        return not (lc is not None and (lc.adapt_k or lc.adapt_v) and self.local_logit is not None)
 
     def _forward_with_logits(self, frames_feature, frames_embed, guide_embed, modal, image_newline, local_logits):
         lc = self.local_compressor
@@ -760,9 +776,8 @@ class HIComProjector(nn.Module):
             raise RuntimeError("forward_deferred is an inference API: call it under torch.no_grad() / inference_mode(), "
                                "or use forward() for training")
         nv.begin_inference()
-        plain = all(c is None or c.is_plain for c in (self.local_compressor, self.global_compressor))
-        if not plain or self.global_logit is not None or isinstance(frames_feature, dict):
-            raise NotImplementedError("forward_deferred: dense inputs of the plain recipes")
+        if not self._executor_covers() or isinstance(frames_feature, dict):
+            raise NotImplementedError("forward_deferred: dense inputs of the recipes the one-call executor covers")
         from . import engine
         return engine.run_dense(self, frames_feature, frames_embed, guide_embed, modal, image_newline, _out_dtype(self),
                                 deferred=True)

@@ -548,6 +548,19 @@ typedef struct hicom_compressor_args {
      * projector.py:586-587), so q_proj + fold are weight-only work like kpe -- and the two prep launches are skipped.  The caller
      * clears it after a weight update. */
     int32_t reuse_queries;
+    /* k / v adaptors of the local stage (projector.py:431-457, :533-534: key = (1 - a) x + a LN(MLP(x)) over ALL tokens; likewise
+     * the values), the second released recipe `local43_adaptkv_global32`.  ak.w0 / av.w0 NULL = that stream has no adaptor.  The
+     * executor runs the two dense GEMMs per stream (hicom_dense16_gemm_fwd) and the window attention with the LayerNorm + alpha
+     * blend fused into its row loads (hicom_local_attn_adapt_fwd); not with clip-scale (l2norm != 0) and not on the release
+     * recipe's single-kernel path (the local stage then reads adapted streams, the global stage the raw tokens). */
+    struct hicom_adaptor {
+        const void *w0, *b0;       /* Linear(E, E): bf16 [E, E], bf16 [E] */
+        const void *w2_f16, *b2;   /* Linear(E, E): fp16 copy of the weight (cached by the caller per weight state), bf16 bias */
+        const void *gamma, *beta;  /* LayerNorm: bf16 [E] */
+        const void* alpha;         /* device scalar, dtype adapt_alpha_dt */
+    } ak, av;
+    int32_t adapt_alpha_dt;
+    float adapt_eps;
 } hicom_compressor_args;
 
 /* 1 when hicom_compressor_fwd takes the release-recipe (single streaming kernel) path for these arguments. */

@@ -434,6 +434,43 @@ def test_multi_rank_device_path_emulated_on_one_gpu(c2, world):
     assert got.shape == want.shape and float((got - want).abs().max()) <= PATH_TOL
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_adaptkv_recipe_in_the_executor_and_sharded(world):
+    """The second released recipe (`local43_adaptkv_global32`, use_guide = direct: k / v adaptor MLPs + LayerNorm blend over ALL
+    tokens, reference projector.py:431-457, :533-534) is first-class: ONE C call (hicom_compressor_fwd runs the four
+    dense GEMMs and the blend-fused window attention), equal to the operator-by-operator path and to the oracle on every output,
+    and it shards over frames (the adaptors are token-wise: shard-local) -- 2- and 4-rank emulation against the dense forward."""
+    from types import SimpleNamespace
+    from hicom_amd import synth
+    from oracle import hicom_oracle as orc
+    T, H, W = 16, 9, 9
+    cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "mm_projector_type": "local43_adaptkv_global32", "hidden_size": 256, "max_num_frames": T})
+    sd = synth.synth_state_dict(orc.param_shapes(cfg), tag="akv")
+    for k in list(sd):
+        if k.endswith("_alpha"):
+            sd[k] = np.full_like(sd[k], 0.4)                          # (the reference initialises the blends at 0: dead branches)
+    m = build_module(SimpleNamespace(cfg=cfg, sd=sd))
+    gen = torch.Generator(device="cuda").manual_seed(37)
+    ff = torch.randn(T, H, W, 1152, device="cuda", generator=gen).bfloat16()
+    fe = torch.randn(T, H, W, 1152, device="cuda", generator=gen).bfloat16()
+    g = torch.randn(1152, device="cuda", generator=gen).bfloat16()
+    with torch.no_grad():
+        got = m(ff, fe, g, "video", None)
+        assert next(iter(m.__dict__["_engine_plans"].values())).hits == 1        # the one-call executor took it
+        m.use_executor = False
+        step = m(ff, fe, g, "video", None)
+        m.use_executor = True
+        assert torch.equal(m(ff, fe, g, "video", None), got)                      # (second call: plan hit, same bits)
+        shard = _emulate_ranks(m, ff, fe, g, world, world - 1)
+        o, ev = m.forward_deferred(ff, fe, g, "video", None)
+        ev.synchronize()
+    assert float((got - step).abs().max()) <= PATH_TOL and float((o - got).abs().max()) <= PATH_TOL
+    assert shard.shape == got.shape and float((shard - got).abs().max()) <= PATH_TOL
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    want = orc.projector_forward(cfg, sdt, ff.float().cpu(), fe.float().cpu(), g.float().cpu(), "video", None)
+    assert float((got.cpu() - want).abs().max()) <= TOL
+
+
 def test_guide_off_wide_global_kernel_matches_narrow():
     """Guide off at 16 frames of the full grid (288 folded query rows): the wide global stream kernel (two row groups
     per workgroup, three-deep ring) against the one-row-group kernel it replaces, and the 81 x 4 local tokens of the

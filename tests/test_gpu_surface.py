@@ -256,7 +256,7 @@ def test_sharded_forward_refuses_recipes_it_cannot_patch():
     """coarse / fine / adaptor recipes derive their queries from the guide per call; the shard plans only
     patch guide ALIASES, so those recipes must raise instead of reusing a freed / stale query."""
     from hicom_amd.dist import sharded_forward
-    for name in ("G6_coarse", "G5_adaptkv"):
+    for name in ("G6_coarse", "G5b_adaptqkvg_off"):        # (query-side adaptors / injected queries; the k / v adaptors alone DO shard)
         m, _, case = _module_and_sd(name)
         ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
         with torch.no_grad(), pytest.raises(NotImplementedError):
