@@ -390,6 +390,163 @@ __global__ __launch_bounds__(256, 3) void dense16_gemm_kernel(DenseParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// TN form: C[M, N] = A^T B,  A [Kt, lda] (element (k, m)), B [Kt, ldb] (element (k, n)), contraction over the Kt ROWS.
+// The weight gradients of the token-stream layers, dW = dY^T X over all T*729 tokens (training path: the k / v adaptor MLPs,
+// the SigLIP head projection; reference train.py:700-738 through autograd): both operands arrive token-major, i.e. with the
+// contraction index as the SLOW axis, so the K-contiguous fragment reads of the NT kernel above do not apply.  Same skeleton
+// (128 x 128 tile, 2 x 2 waves of 64 x 64, one 32-KB stage of 64 token rows, LDS-DMA, two barriers per stage, 3-4 workgroups per
+// CU), with the fragments fetched by ds_read_b64_tr_b16 (cdna_hip_programming.md T10): a 16-lane group reads a 4-row x
+// 16-column block and each lane receives ITS column's four row values -- the MFMA operand layout with k = token.  Two such
+// reads (rows kb + 4g + e and kb + 16 + 4g + e) fill the 8 k-slots of a 16x16x32 operand; both operands use the same slot -> token
+// map, so the contraction is unaffected by it.  Image: plain 256-byte rows with the chunk XOR ((row & 3) << 2) | ((row >> 2) & 3)
+// of T10 (b), applied on the DMA source side.
+// The output is small (E x E) and the contraction long: the token axis is SPLIT over blockIdx.y and every split writes its own
+// f32 partial tile (deterministic; summed by hicom_partials_sum_fwd), which also gives the launch enough workgroups.
+struct DenseTnParams {
+    const uint16_t* a;
+    const uint16_t* b;
+    long lda, ldb;
+    int M, N, Kt;
+    float* c;               // [splits][M][ldc]
+    long ldc;
+    int tiles_m, tiles_n, splits;
+};
+
+__device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+template <bool BF16>
+__global__ __launch_bounds__(256, 3) void dense16_tn_kernel(DenseTnParams p) {
+    constexpr int NWAVE = 4, MI = 4;
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // A image [64 rows][256 B] | B image [64 rows][256 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r16 = lane & 15, kg = lane >> 4;
+    // Block -> (tile, split), XCD-aware (speed only): block b runs on XCD b % 8, and with a split count that is a multiple of 8 every
+    // XCD works on ITS slices of the token axis only -- the tiles of a slice walk the same token rows at about the same time, so a
+    // slice's operand panels stream through one L2 once instead of through all eight (measured: 389 -> see DESIGN.md §3.4)
+    const int tiles = p.tiles_m * p.tiles_n;
+    int tile, split;
+    if ((p.splits & 7) == 0) {
+        const int idx = blockIdx.x >> 3;
+        split = (blockIdx.x & 7) + 8 * (idx / tiles);
+        tile = idx - (idx / tiles) * tiles;
+    } else {
+        split = blockIdx.x / tiles;
+        tile = blockIdx.x - split * tiles;
+    }
+    const int bm = tile / p.tiles_n, bn = tile - bm * p.tiles_n;
+    const int m0 = bm * 128, n0 = bn * 128;
+    const int ns_total = (p.Kt + 63) >> 6;
+    const int per = (ns_total + p.splits - 1) / p.splits;
+    const int s0 = split * per, s1 = min(ns_total, s0 + per);
+
+    // DMA: a piece = 4 token rows x 256 B; 16 A pieces then 16 B pieces per stage; wave w issues pieces w, w + 4, ... of each
+    const int prow = lane >> 4, pos = lane & 15;
+    long col_off[8];                                     // element offset of this lane's 16-byte chunk inside its source row
+    int lrow[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool isa = i < 4;
+        const int r = 4 * (wave + NWAVE * (i & 3)) + prow;
+        int col = (isa ? m0 : n0) + 8 * (pos ^ tn_swz(r));
+        const int lim = (isa ? p.M : p.N) - 8;           // (columns past the matrix: any valid chunk -- those outputs are not stored)
+        col = col < lim ? col : (lim > 0 ? lim : 0);
+        col_off[i] = col;
+        lrow[i] = r;
+    }
+    // transposed fragment reads: group g = kg reads rows kb + 4 sig(g) + q, q = (lane >> 2) & 3, columns 4 pp .. 4 pp + 3 of the 16-column
+    // block; sig = (0, 2, 1, 3): the two blocks of a 32-lane half sit 8 rows apart (conflict-free on this image, T10), and since
+    // both operands use the same group -> rows map the contraction does not see it
+    const int q = (lane >> 2) & 3, pp = lane & 3;
+    const int sg = ((kg & 1) << 1) | (kg >> 1);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(lds);
+    f32x4 acc[4][MI];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int s = s0; s < s1; ++s) {
+        lds_barrier();                                        // every wave is done reading the previous stage
+        const int valid = p.Kt - 64 * s;                      // token rows of this stage (>= 64 except in the last one)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool isa = i < 4;
+            int kk = 64 * s + lrow[i];
+            kk = kk < p.Kt ? kk : p.Kt - 1;
+            const uint16_t* src = (isa ? p.a + (long)kk * p.lda : p.b + (long)kk * p.ldb) + col_off[i];
+            const int piece = (isa ? 0 : 16) + wave + NWAVE * (i & 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
+                                             (__attribute__((address_space(3))) void*)(lds + piece * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (valid < 64) {                                     // ragged end of the token axis: rows past it contribute zeros
+            for (int c = tid; c < (64 - valid) * 32; c += 256) {
+                const int rr = valid + (c >> 5), w16 = c & 31;          // 32 16-byte chunks per row pair (A row | B row)
+                *reinterpret_cast<u32x4*>(lds + (w16 < 16 ? 0 : 16384) + rr * 256 + 16 * (w16 & 15)) = u32x4{0, 0, 0, 0};
+            }
+            lds_barrier();
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // (the asm results are only valid behind the wait: nothing touches them before it)
+            bf16x4 ra[2][MI], rb[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int row = 32 * ks + 16 * t + 4 * sg + q;
+                const int sw = tn_swz(row);
+                const unsigned rbase = lds0 + row * 256 + 8 * (pp & 1);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const unsigned addr = rbase + 16 * ((8 * wr + 2 * i + (pp >> 1)) ^ sw);
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ra[t][i]) : "v"(addr));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned addr = rbase + 16384 + 16 * ((8 * wc + 2 * j + (pp >> 1)) ^ sw);
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(rb[t][j]) : "v"(addr));
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 wf[4], af[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = bf16x8{ra[0][i][0], ra[0][i][1], ra[0][i][2], ra[0][i][3], ra[1][i][0], ra[1][i][1], ra[1][i][2], ra[1][i][3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = bf16x8{rb[0][j][0], rb[0][j][1], rb[0][j][2], rb[0][j][3], rb[1][j][0], rb[1][j][1], rb[1][j][2], rb[1][j][3]};
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (BF16) {
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+                    } else {
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wf[j]), __builtin_bit_cast(half8, af[i]), acc[j][i], 0, 0, 0);
+                    }
+                }
+        }
+    }
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");          // MFMA results -> VALU / stores (see fused_ring.hip)
+    // lane holds C[m][n .. n + 3]: m = m0 + 64 wr + 16 i + r16, n = n0 + 64 wc + 16 j + 4 kg
+    float* cs = p.c + (long)split * p.M * p.ldc;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + 64 * wr + 16 * i + r16;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + 64 * wc + 16 * j + 4 * kg;
+            if (n + 3 < p.N) *reinterpret_cast<f32x4*>(cs + (long)m * p.ldc + n) = acc[j][i];
+            else
+                for (int e = 0; e < 4 && n + e < p.N; ++e) cs[(long)m * p.ldc + n + e] = acc[j][i][e];
+        }
+    }
+}
+
 // ---- row-wise LayerNorm over the token stream, 16-byte accesses (E % 8 == 0, E <= 1536) -----------------------------
 //   out = (1 - alpha) * src + alpha * (LN(x) * gamma + beta);   x: fp16 | bf16 | f32 [M, ldx];  src: bf16 [M, E] or NULL;
 //   out: fp16 | bf16 [M, E].   SigLIP head layernorm (encoder.py:284) and the adaptor blend (projector.py:533-534).
@@ -575,4 +732,33 @@ extern "C" int hicom_l2norm_stream_fwd(const void* x, void* out, int64_t M, int3
     hipLaunchKernelGGL(l2norm_stream_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)out,
                        (long)M, E);
     return hicom_host::check_launch("l2norm_stream");
+}
+
+
+extern "C" int hicom_dense16_tn_splits(int32_t M, int32_t N, int64_t Kt) {
+    if (M <= 0 || N <= 0 || Kt <= 0) return HICOM_EINVAL;
+    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128), stages = (Kt + 63) / 64;
+    long s = (768 + tiles - 1) / tiles;                  // ~3 workgroups per CU ...
+    if (s > stages) s = stages;
+    if (s >= 6 && stages >= 8) {                         // ... in multiples of 8 where the token axis allows: one XCD per slice (see the kernel)
+        s = (s + 7) / 8 * 8;
+        if (s > stages) s = stages / 8 * 8;
+    }
+    if (s > 64) s = 64;
+    return (int)(s < 1 ? 1 : s);
+}
+
+extern "C" int hicom_dense16_tn_fwd(const void* a, int64_t lda, const void* b, int64_t ldb, int32_t operand_dt, int64_t Kt,
+                                    int32_t M, int32_t N, float* c_parts, int64_t ldc, int32_t splits, void* stream) {
+    HICOM_REQUIRE(a && b && c_parts, HICOM_EINVAL, "dense16_tn: NULL pointer");
+    HICOM_REQUIRE(operand_dt == HICOM_DT_BF16 || operand_dt == HICOM_DT_F16, HICOM_EINVAL, "dense16_tn: operands are both fp16 or both bf16");
+    HICOM_REQUIRE(M >= 8 && N >= 8 && Kt > 0 && Kt < (1L << 31) && splits > 0 && splits <= (Kt + 63) / 64 && lda >= M && ldb >= N && ldc >= N, HICOM_EINVAL,
+                  "dense16_tn: bad shape");
+    HICOM_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && M % 8 == 0 && N % 8 == 0 && ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0) &&
+                      ((uintptr_t)c_parts % 16 == 0), HICOM_EINVAL, "dense16_tn: M, N, leading dimensions multiples of 8 elements, 16-byte aligned bases");
+    DenseTnParams p{(const uint16_t*)a, (const uint16_t*)b, (long)lda, (long)ldb, M, N, (int)Kt, c_parts, (long)ldc, (M + 127) / 128, (N + 127) / 128, splits};
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * splits));
+    if (operand_dt == HICOM_DT_BF16) HICOM_LAUNCH(dense16_tn_kernel<true>, grid, dim3(256), 32768, (hipStream_t)stream, p);
+    else HICOM_LAUNCH(dense16_tn_kernel<false>, grid, dim3(256), 32768, (hipStream_t)stream, p);
+    return hicom_host::check_launch("dense16_tn");
 }

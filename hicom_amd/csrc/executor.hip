@@ -32,7 +32,7 @@ namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct WsLayout {
-    size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, ad_hid, ad_ky, ad_vy, qp, qhi, qlo, pos_a, prep_state, scores, part_m, part_l, part_acc, scratch, ml, acc,
+    size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, ctx16, hid16, ad_hid, ad_ky, ad_vy, qp, qhi, qlo, pos_a, prep_state, scores, part_m, part_l, part_acc, scratch, ml, acc,
         ctx_g, o, qres, pre, hid_g, tok, po, o_fix, r0, total;
     int nw, R, rows_pad, nparts, P;
     long N, score_stride;
@@ -90,6 +90,8 @@ WsLayout make_layout(const hicom_compressor_args& a) {
         w.hid_hi = w.hid_local;
         w.hid_lo = w.hid_local + (size_t)w.nw * a.hidden * 2;
         w.pooled_q = take(a.lq ? 0 : (size_t)w.nw * a.E * 4);
+        w.ctx16 = take((size_t)w.nw * a.E * 2);             // fp16 planes of the two-kernel path's readout (contexts, hidden layer)
+        w.hid16 = take((size_t)w.nw * a.hidden * 2);
         // adaptor streams: the hidden layer of the MLP (shared by the two streams, which run one after the other) and y = MLP(x)
         // per adapted stream, fp16 [N, E]
         if (a.ak.w0 || a.av.w0) w.ad_hid = take((size_t)w.N * a.E * 2);
@@ -248,6 +250,20 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                                       a.x_index0, F(w.scratch), ml_out, acc_out, solo ? 1 : 0, st);
     };
     auto local_readout = [&](hipStream_t st) -> int {
+        if (a.lw0_f16 && a.lw2_f16 && a.E % 64 == 0 && a.hidden % 64 == 0) {
+            // the hot path's GEMM (one fp16 plane per activation, cached fp16 weights): 12 us per layer at 1296 rows against 26 for the
+            // fp32-input form
+            CHK(hicom_to_f16_fwd(F(w.ctx_local), HICOM_DT_F32, ws + w.ctx16, (int64_t)w.nw * a.E, st));
+            CHK(hicom_readout16_gemm_fwd(ws + w.ctx16, a.lw0_f16, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E, HICOM_ACT_GELU, ws + w.hid16, nullptr, 0, 0, 0,
+                                         0, nullptr, st));
+            CHK(hicom_readout16_gemm_fwd(ws + w.hid16, a.lw2_f16, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden, HICOM_ACT_NONE, nullptr,
+                                         a.local_out ? a.local_out : a.out, a.out_dt, a.local_out ? a.hidden : a.ldo,
+                                         a.local_out ? 0 : a.local_row0, a.local_out ? 0 : a.nl_group, nullptr, st));
+            if (a.nl_count > 0 && !a.local_out)
+                CHK(hicom_scatter_rows_fwd(a.newline, a.newline_dt, 1, a.hidden, a.out, a.out_dt, a.ldo, a.nl_first, a.nl_step,
+                                           0, a.nl_count, st));
+            return HICOM_OK;
+        }
         CHK(hicom_readout_gemm_fwd(F(w.ctx_local), a.lw0, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E, HICOM_ACT_GELU,
                                    F(w.hid_local), HICOM_DT_F32, a.hidden, 0, 0, st));
         CHK(hicom_readout_gemm_fwd(F(w.hid_local), a.lw2, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden, HICOM_ACT_NONE,

@@ -32,7 +32,7 @@ EXPORTS = (
     "hicom_dense16_gemm_fwd", "hicom_ln_stream_fwd", "hicom_to_f16_padded_fwd", "hicom_clip_query_prep_fwd", "hicom_inv_norm_fwd",
     "hicom_global_stream_clip_fwd", "hicom_splice_rows_fwd", "hicom_splice_labels_fwd",
     "hicom_query_prep_fwd", "hicom_query_prep_state_bytes", "hicom_partials_sum_fwd", "hicom_l2norm_stream_fwd", "hicom_local_attn_adapt_fwd",
-    "hicom_small_mha_scaled_fwd", "hicom_merge_vproj_fixed_fwd",
+    "hicom_small_mha_scaled_fwd", "hicom_merge_vproj_fixed_fwd", "hicom_dense16_tn_fwd", "hicom_dense16_tn_splits",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -138,6 +138,8 @@ def lib() -> C.CDLL:
     L.hicom_dense16_gemm_fwd.argtypes = [vp, i64, vp, i64, i32, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, i32, i64, vp, i64, vp,
                                          vp, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp]
     L.hicom_partials_sum_fwd.argtypes = [vp, i32, i64, vp, vp]
+    L.hicom_dense16_tn_splits.argtypes = [i32, i32, i64]
+    L.hicom_dense16_tn_fwd.argtypes = [vp, i64, vp, i64, i32, i64, i32, i32, vp, i64, i32, vp]
     L.hicom_l2norm_stream_fwd.argtypes = [vp, vp, i64, i32, vp]
     L.hicom_local_attn_adapt_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32, vp, vp]
     L.hicom_clip_query_prep_fwd.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp]
@@ -493,6 +495,27 @@ def dense16_gemm(a, w, b, N=None, K=None, act=ACT_NONE, out_f16=None, n_store=No
                                         _ptr(row_dot[0]) if row_dot else None, _dt(row_dot[0]) if row_dot else 0,
                                         _ptr(row_dot[1]) if row_dot else None, _stream()),
            "hicom_dense16_gemm_fwd")
+
+
+def dense16_tn(a, b, M=None, N=None, out=None, splits=None):
+    """a^T b over the ROWS of a [Kt, lda] and b [Kt, ldb] (both fp16 or both bf16) -> f32 [M, N]: the weight gradients dW = dY^T X of
+    the token-stream layers on matrix cores (hicom_dense16_tn_fwd + hicom_partials_sum_fwd; see include/hicom_hip.h)."""
+    if a.dtype != b.dtype or a.dtype not in (torch.float16, torch.bfloat16) or a.shape[0] != b.shape[0]:
+        raise HicomNativeError("dense16_tn: operands are both fp16 or both bf16 with the same number of rows")
+    Kt = a.shape[0]
+    M = a.shape[1] if M is None else M
+    N = b.shape[1] if N is None else N
+    if splits is None:
+        splits = lib().hicom_dense16_tn_splits(M, N, Kt)
+    parts = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
+    _check(lib().hicom_dense16_tn_fwd(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _dt(a), Kt, M, N, _ptr(parts), N, splits, _stream()),
+           "hicom_dense16_tn_fwd")
+    if splits == 1:
+        return parts[0] if out is None else out.copy_(parts[0])
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    partials_sum(parts.view(splits, M * N), out.view(-1))
+    return out
 
 
 def l2norm_stream(x, out):

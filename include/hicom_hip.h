@@ -372,6 +372,14 @@ int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w, int64_t ld
                            float* ssq, const float* row_tab, int64_t row_tab_ld, int32_t tab_H, int32_t tab_W,
                            int32_t tab_t0, int32_t tab_y0, int32_t tab_x0,
                            const void* dot_vec, int32_t dot_vec_dt, float* row_dot, void* stream);
+/* TN form: c_parts[s][m][n] = sum over the s-th slice of the Kt rows of a[k][m] * b[k][n] -- the weight gradients dW = dY^T X of the
+ * token-stream layers (a = dY [Kt, lda], b = X [Kt, ldb], both token-major, both fp16 or both bf16; fp32 accumulation).  The
+ * contraction axis is split into `splits` slices (hicom_dense16_tn_splits proposes a count), each writing its own f32 partial
+ * [M][ldc]; hicom_partials_sum_fwd(c_parts, splits, M * ldc, out) adds them in slice order (deterministic).  M, N, lda, ldb
+ * multiples of 8, ldc of 4; Kt arbitrary. */
+int hicom_dense16_tn_splits(int32_t M, int32_t N, int64_t Kt);
+int hicom_dense16_tn_fwd(const void* a, int64_t lda, const void* b, int64_t ldb, int32_t operand_dt, int64_t Kt,
+                         int32_t M, int32_t N, float* c_parts, int64_t ldc, int32_t splits, void* stream);
 /* out[m] = sum_{s < nparts} parts[s * M + m], in slice order (the row_dot partials of hicom_dense16_gemm_fwd -> the per-token
  * local logits hicom_fused_stream_fwd / hicom_compressor_args.local_logits take). */
 int hicom_partials_sum_fwd(const float* parts, int32_t nparts, int64_t M, float* out, void* stream);

@@ -280,3 +280,41 @@ def test_stage3_chain_head_into_compressor_backward(head):
         if n != "global_compressor.query":
             assert p_.grad is not None and bool(torch.isfinite(p_.grad.float()).all()), n
     m_head.eval()
+
+
+@pytest.mark.parametrize("Kt,M,N,dt", [(5832, 1152, 1152, torch.bfloat16), (729, 1152, 256, torch.float16), (200, 136, 72, torch.bfloat16),
+                                        (46656, 1152, 1152, torch.bfloat16)])
+def test_dense16_tn_matches_torch(Kt, M, N, dt):
+    """TN form of the dense MFMA GEMM (round 4): C = A^T B over the token axis, the weight gradients dW = dY^T X of the token-stream
+    layers.  Ragged token counts (not a multiple of the 64-row stage), widths that are not multiples of the 128 x 128 tile, split
+    contraction with partial tiles summed in slice order; bit-stable from launch to launch."""
+    g = torch.Generator(device="cuda").manual_seed(Kt + M)
+    a = (torch.randn(Kt, M, device="cuda", generator=g) * 0.5).to(dt)
+    b = (torch.randn(Kt, N, device="cuda", generator=g) * 0.5).to(dt)
+    c = nv.dense16_tn(a, b)
+    c2 = nv.dense16_tn(a, b)
+    torch.cuda.synchronize()
+    assert c.shape == (M, N) and c.dtype == torch.float32 and torch.equal(c, c2)
+    if Kt > 10000:                                                   # (fp64 reference of sampled rows: the full product is 124 GFLOP)
+        rows = torch.randint(0, M, (64,), device="cuda", generator=g)
+        want = a[:, rows].double().t() @ b.double()
+        got = c[rows]
+    else:
+        want, got = a.double().t() @ b.double(), c
+    tol = 2e-6 * Kt ** 0.5 * 4 + 1e-5 * float(want.abs().max())
+    assert float((got.double() - want).abs().max()) <= tol, (float((got.double() - want).abs().max()), tol)
+    # one split and an explicit split count give the same sums up to association
+    c1 = nv.dense16_tn(a, b, splits=1)
+    torch.cuda.synchronize()
+    assert float((c1 - c).abs().max()) <= tol
+    if Kt > 10000:
+        import time
+        for _ in range(3):
+            nv.dense16_tn(a, b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            nv.dense16_tn(a, b)
+        torch.cuda.synchronize()
+        dt_s = (time.perf_counter() - t0) / 10
+        print(f"\\ndense16_tn {Kt}x{M}x{N}: {dt_s * 1e6:.0f} us = {2.0 * Kt * M * N / dt_s / 1e12:.0f} TFLOP/s (incl. the partial sum)")
