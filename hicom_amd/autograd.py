@@ -16,7 +16,8 @@ Scope: every injection mode (direct, coarse, fine, off) and every adaptor (adapt
 gradients of every projector parameter and of `image_newline`; stage 3 also trains the SigLIP head and the guide encoder
 (train.py:717-726), i.e. it needs the gradients w.r.t. `frames_embed` (the head's output, key stream of the local windows) and
 `guide_embed`: built for direct / coarse / fine (hicom_local_attn_bwd: one more pass over both streams, d frames_embed written as
-bf16; with k / v adaptors the window backward and the adaptor chain run as fp32 tensor algebra + library GEMMs).  The query chain
+bf16; with k / v adaptors hicom_local_attn_adapt_bwd -- the window backward through the LayerNorm blends -- and the adaptor MLPs'
+backward on the dense MFMA GEMM, NT and TN forms: round 4, no token-stream sized torch algebra left).  The query chain
 (adapt_q, adapt_guide, coarse / fine injection) acts on small tensors only and is differentiated as a torch graph
 (_query_chain_backward).  `frames_feature` comes from the frozen tower body: asking for its gradient raises instead of returning
 None silently, and so do input gradients of the guide-off recipe, clip-scale projectors and text2qk projections.
@@ -76,59 +77,46 @@ def _ln_stats(x, eps):
     return (x - mu) * rstd, rstd
 
 
-def _mm(a, b):
-    """a @ b on the vendor GEMM with bf16 operands, fp32 accumulation and an fp32 result (the token-stream GEMMs of the adaptor
-    backward: 124 GFLOP each at 64 frames -- 0.15 ms like this against 1.2 ms in fp32)."""
-    try:
-        return torch.mm(a.to(torch.bfloat16), b.to(torch.bfloat16), out_dtype=torch.float32)
-    except (TypeError, RuntimeError):
-        return torch.mm(a.float(), b.float())
+def _adaptor_recompute(x2, mlp):
+    """Forward of one adaptor MLP over all tokens, recomputed with its intermediates on the forward's own kernels (gradient
+    checkpointing is on in the reference's scripts): h1 = W1 x + b1 (pre-activation, fp16), a = GELU(h1) as fp16 (operand of the second
+    GEMM, exactly the forward's hidden layer) and as bf16 (operand of dW2 = dy^T a), y = W2 a + b2 (fp16, the forward's y)."""
+    from . import injector as inj
+    N, D = x2.shape
+    w1, b1 = mlp[0].weight.detach(), mlp[0].bias.detach()
+    h1 = torch.empty((N, w1.shape[0]), dtype=torch.float16, device=x2.device)
+    nv.dense16_gemm(x2, w1, b1, act=nv.ACT_NONE, out_f16=h1)
+    a16 = torch.empty_like(h1)
+    abf = torch.empty(h1.shape, dtype=torch.bfloat16, device=x2.device)
+    nv.gelu_split(h1, a16, abf)
+    y = torch.empty((N, mlp[2].weight.shape[0]), dtype=torch.float16, device=x2.device)
+    nv.dense16_gemm(a16, inj._f16_weight(mlp[2]), mlp[2].bias.detach(), out_f16=y)
+    return h1, abf, y
 
 
-class _AdaptorTape:
-    """(1 - a) x + a LN(MLP(x)) over all tokens (adapt_k / adapt_v, reference projector.py:533-534) recomputed with its
-    intermediates, and its backward: library GEMMs over [N, D] (dW = dY^T X, dX = dY W; bf16 operands, fp32 accumulate / result),
-    LayerNorm / GELU algebra in fp32."""
-
-    def __init__(self, x, mlp, norm, alpha):
-        self.mlp, self.norm, self.alpha = mlp, norm, alpha.detach().float()
-        self.x = x.reshape(-1, x.shape[-1]).float()
-        self.W1, self.W2 = mlp[0].weight.detach(), mlp[2].weight.detach()
-        D = self.x.shape[-1]
-        if x.dtype == torch.bfloat16 and D % 64 == 0 and self.W1.shape[0] % 64 == 0:
-            # recompute on the forward's own kernels (hicom_dense16_gemm_fwd: exact bf16 products / fp16 operands, fp32 accumulation,
-            # fp16 results = 11 significand bits, like the forward's adapted stream)
-            from . import injector as inj
-            x2 = x.reshape(-1, D).contiguous()
-            h1 = torch.empty((x2.shape[0], self.W1.shape[0]), dtype=torch.float16, device=x.device)
-            nv.dense16_gemm(x2, self.W1, mlp[0].bias.detach(), act=nv.ACT_NONE, out_f16=h1)
-            self.h1 = h1.float()
-            self.a = torch.nn.functional.gelu(self.h1)
-            h2 = torch.empty((x2.shape[0], self.W2.shape[0]), dtype=torch.float16, device=x.device)
-            nv.dense16_gemm(self.a.half(), inj._f16_weight(mlp[2]), mlp[2].bias.detach(), out_f16=h2)
-            h2 = h2.float()
-        else:
-            self.h1 = torch.addmm(mlp[0].bias.detach().float(), self.x, self.W1.float().t())
-            self.a = torch.nn.functional.gelu(self.h1)
-            h2 = torch.addmm(mlp[2].bias.detach().float(), self.a, self.W2.float().t())
-        self.nhat, self.rstd = _ln_stats(h2, norm.eps)
-        self.gamma = norm.weight.detach().float()
-        self.n = self.nhat * self.gamma + norm.bias.detach().float()
-        self.out = (1.0 - self.alpha) * self.x + self.alpha * self.n
-
-    def backward(self, d_out, prefix, which, grads, want_x):
-        """prefix 'local_compressor.', which 'k' | 'v'; returns d x (fp32 [N, D]) when want_x."""
-        grads[f"{prefix}{which}_alpha"] = (d_out * (self.n - self.x)).sum().reshape(1)
-        dn = self.alpha * d_out
-        grads[f"{prefix}{which}_norm.weight"] = (dn * self.nhat).sum(0)
-        grads[f"{prefix}{which}_norm.bias"] = dn.sum(0)
-        dh2 = _ln_backward(dn * self.gamma, self.nhat, self.rstd)
-        grads[f"{prefix}{which}_proj.2.weight"] = _mm(dh2.t(), self.a)
-        grads[f"{prefix}{which}_proj.2.bias"] = dh2.sum(0)
-        dh1 = _mm(dh2, self.W2) * _gelu_grad(self.h1)
-        grads[f"{prefix}{which}_proj.0.weight"] = _mm(dh1.t(), self.x)
-        grads[f"{prefix}{which}_proj.0.bias"] = dh1.sum(0)
-        return (1.0 - self.alpha) * d_out + _mm(dh1, self.W1) if want_x else None
+def _adaptor_mlp_backward(x2, mlp, norm, alpha, rec, coef, vec, vec_stride, axes, prefix, which, grads, want_x):
+    """Backward of (1 - a) x + a LN(MLP(x)) over ALL tokens (adapt_k / adapt_v, reference projector.py:533-534) for the rank-1 upstream
+    gradient coef[tok] * vec[w(tok)] the window attention leaves (hicom_local_attn_adapt_bwd), on HIP kernels: hicom_adapt_dy_fwd (LayerNorm
+    backward per token -> dy bf16), the weight gradients dW = dY^T X on the TN form of the dense MFMA GEMM, d hidden = dy W2 on its NT form,
+    GELU' and the bias sums as streaming kernels.  Returns d x (bf16 [N, D]) when want_x."""
+    h1, abf, y = rec
+    N, D = x2.shape
+    dev = x2.device
+    dy = torch.empty((N, y.shape[1]), dtype=torch.bfloat16, device=dev)
+    r1 = torch.empty((N, D), dtype=torch.bfloat16, device=dev) if want_x else None
+    nv.adapt_dy(y, norm.weight.detach(), vec, vec_stride, coef, alpha.detach(), axes, dy, r1, eps=norm.eps)
+    grads[f"{prefix}{which}_proj.2.weight"] = nv.dense16_tn(dy, abf)                       # dW2[o, h] = sum_n dy[n, o] a[n, h]
+    grads[f"{prefix}{which}_proj.2.bias"] = nv.colsum(dy)
+    da = torch.empty((N, h1.shape[1]), dtype=torch.bfloat16, device=dev)
+    nv.dense16_gemm(dy, mlp[2].weight.detach().t().contiguous(), None, y=da)                # da[n, h] = sum_o dy[n, o] W2[o, h]
+    nv.gelu_bwd_(da, h1)                                                                    # dh1 = da * GELU'(h1), in place
+    grads[f"{prefix}{which}_proj.0.weight"] = nv.dense16_tn(da, x2)                         # dW1[h, i] = sum_n dh1[n, h] x[n, i]
+    grads[f"{prefix}{which}_proj.0.bias"] = nv.colsum(da)
+    if not want_x:
+        return None
+    dx = torch.empty((N, D), dtype=torch.bfloat16, device=dev)
+    nv.dense16_gemm(da, mlp[0].weight.detach().t().contiguous(), None, y=dx, res=r1)        # dx = dh1 W1 + (1 - a) coef vec
+    return dx
 
 
 def _coarse_backward(inj, prefix, vis, guide, dq, grads):
@@ -230,34 +218,6 @@ def _query_chain_backward(stage, prefix, vis, guide, d_inj, f32, grads, want_gui
     if d_vis is not None:
         grads[prefix + vis_param] = d_vis
     return d_vis, d_guide
-
-
-def _to_windows(x, at, ay, ax):
-    """[T, H, W, D] -> [Nw, kt ks ks, D] in the reference's window / in-window order (projector.py:473-499), exact partition."""
-    D = x.shape[-1]
-    return (x.reshape(at.nwin, at.k, ay.nwin, ay.k, ax.nwin, ax.k, D).permute(0, 2, 4, 1, 3, 5, 6)
-            .reshape(at.nwin * ay.nwin * ax.nwin, at.k * ay.k * ax.k, D))
-
-
-def _from_windows(xw, at, ay, ax):
-    D = xw.shape[-1]
-    return (xw.reshape(at.nwin, ay.nwin, ax.nwin, at.k, ay.k, ax.k, D).permute(0, 3, 1, 4, 2, 5, 6)
-            .reshape(at.n * ay.n * ax.n, D))
-
-
-def _window_attention_backward(K, V, q, scale, dctx, tilings, want_k, want_v):
-    """Autograd through reference projector.py:550-553 on fp32 streams K, V [T,H,W,D] (adaptor outputs): q [D] shared or
-    [Nw, D]; returns (dq [Nw, D], dK [N, D] | None, dV [N, D] | None)."""
-    at, ay, ax = tilings
-    Kw, Vw = _to_windows(K, at, ay, ax), _to_windows(V, at, ay, ax)
-    qw = q.reshape(1, -1).expand(Kw.shape[0], -1) if q.ndim == 1 or q.shape[0] == 1 else q
-    p = torch.softmax(torch.einsum("wnd,wd->wn", Kw, qw) * scale, dim=-1)
-    dP = torch.einsum("wnd,wd->wn", Vw, dctx)
-    ds = p * (dP - (p * dP).sum(-1, keepdim=True)) * scale
-    dq = torch.einsum("wn,wnd->wd", ds, Kw)
-    dK = _from_windows(ds.unsqueeze(-1) * qw.unsqueeze(1), at, ay, ax) if want_k else None
-    dV = _from_windows(p.unsqueeze(-1) * dctx.unsqueeze(1), at, ay, ax) if want_v else None
-    return dq, dK, dV
 
 
 class _CompressorFn(torch.autograd.Function):
@@ -446,18 +406,52 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
                 if mode in ("coarse", "fine"):
                     q, _ = inj.inject(lc.guide_injector, mode, q.reshape(nw, E), guide.contiguous())   # HIP (ref :369-397)
             if adapt:
-                tape_k = _AdaptorTape(key, lc.k_proj, lc.k_norm, lc.k_alpha) if lc.adapt_k else None
-                tape_v = _AdaptorTape(ff, lc.v_proj, lc.v_norm, lc.v_alpha) if lc.adapt_v else None
-                K = (tape_k.out if tape_k else key.float()).view(T, H, W, E)
-                V = (tape_v.out if tape_v else ff.float()).view(T, H, W, E)
-                dq_w, dK, dV = _window_attention_backward(K, V, q.float(), scale, dctx_l, (at, ay, ax),
-                                                          want_fe or lc.adapt_k, lc.adapt_v)
-                if tape_v:
-                    tape_v.backward(dV, "local_compressor.", "v", grads, False)
-                if tape_k:
-                    dK = tape_k.backward(dK, "local_compressor.", "k", grads, want_fe and fe is not None)
+                # ---- k / v adaptors: window-attention backward with the blends (two streaming passes over x_k, y_k, x_v, y_v), then
+                # the adaptor MLPs' backward per stream; everything token-stream sized runs on HIP kernels --------------------------
+                N = T * H * W
+                kx2, vx2 = key.reshape(N, E), ff.reshape(N, E)
+                rec_k = _adaptor_recompute(kx2, lc.k_proj) if lc.adapt_k else None
+                rec_v = _adaptor_recompute(vx2, lc.v_proj) if lc.adapt_v else None
+                ds = torch.empty((N,), dtype=torch.float32, device=dev)
+                pw = torch.empty_like(ds)
+                sxk, sxv = torch.empty((nw, E), dtype=torch.float32, device=dev), torch.empty((nw, E), dtype=torch.float32, device=dev)
+                syk = torch.empty_like(sxk) if lc.adapt_k else None
+                syv = torch.empty_like(sxv) if lc.adapt_v else None
+                qc = q.contiguous()
+                shared_q = qc.ndim == 1 or qc.shape[0] == 1
+                q_stride = 0 if shared_q else E
+                nv.local_attn_adapt_bwd(key, rec_k[2] if rec_k else None, lc.k_norm if rec_k else None, lc.k_alpha.detach() if rec_k else None,
+                                        ff, rec_v[2] if rec_v else None, lc.v_norm if rec_v else None, lc.v_alpha.detach() if rec_v else None,
+                                        axes, qc, q_stride, scale, 0.0, dctx_l, ds, pw, sxk, syk, sxv, syv,
+                                        eps=(lc.k_norm if rec_k else lc.v_norm).eps)
+                L = "local_compressor."
+                qf = qc.float().reshape(1 if shared_q else nw, E)
+                d_kx = None
+                if lc.adapt_k:
+                    ak, gk = lc.k_alpha.detach().float(), f32[L + "k_norm.weight"]
+                    dq_w = (1.0 - ak) * sxk + ak * gk * syk
+                    grads[L + "k_alpha"] = (qf * (gk * syk - sxk)).sum().reshape(1)
+                    grads[L + "k_norm.weight"] = ak * (qf * syk).sum(0)
+                    grads[L + "k_norm.bias"] = torch.zeros(E, dtype=torch.float32, device=dev)    # a k sum_w q_w sum_n dS_n: the dS of a window sum to zero
+                    d_kx = _adaptor_mlp_backward(kx2, lc.k_proj, lc.k_norm, lc.k_alpha, rec_k, ds, qc, q_stride, axes, L, "k", grads,
+                                                 want_fe and fe is not None)
+                else:
+                    dq_w = sxk
+                    if want_fe and fe is not None:
+                        # plain key stream beside a value adaptor: d key_n = ds_n q_w, written by the rank-1 branch of hicom_adapt_dy_fwd (alpha = 0)
+                        d_kx = torch.empty((N, E), dtype=torch.bfloat16, device=dev)
+                        junk = torch.empty((N, E), dtype=torch.bfloat16, device=dev)
+                        nv.adapt_dy(rec_v[2], lc.v_norm.weight.detach(), qc, q_stride, ds, torch.zeros(1, dtype=torch.float32, device=dev), axes, junk, d_kx,
+                                    eps=lc.v_norm.eps)
+                        del junk
+                if lc.adapt_v:
+                    av, gv, bvv = lc.v_alpha.detach().float(), f32[L + "v_norm.weight"], f32[L + "v_norm.bias"]
+                    grads[L + "v_alpha"] = (dctx_l * (gv * syv + bvv - sxv)).sum().reshape(1)
+                    grads[L + "v_norm.weight"] = av * (dctx_l * syv).sum(0)
+                    grads[L + "v_norm.bias"] = av * dctx_l.sum(0)
+                    _adaptor_mlp_backward(vx2, lc.v_proj, lc.v_norm, lc.v_alpha, rec_v, pw, dctx_l, E, axes, L, "v", grads, False)
                 if want_fe and fe is not None:
-                    d_fe = dK.to(fe.dtype).view(fe.shape)
+                    d_fe = d_kx.to(fe.dtype).view(fe.shape)
             else:
                 dq_w = torch.empty((nw, E), dtype=torch.float32, device=dev)
                 if want_fe and fe is not None:

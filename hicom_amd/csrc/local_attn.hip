@@ -544,6 +544,370 @@ __global__ __launch_bounds__(256) void local_attn_bwd_kernel(LocalBwdParams p) {
     for (int c = tid; c < D; c += 256) out[c] = (part[c] + part[D + c]) + (part[2 * D + c] + part[3 * D + c]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the windowed attention WITH the k / v adaptor blends (training path of the second released recipe
+// `local43_adaptkv_global32`; autograd through reference projector.py:533-534 + :550-553).  Round 3 ran this half as fp32 torch
+// algebra over window-regrouped [1296, 36, 1152] tensors; here it is two streaming passes over the four token streams
+// (x_k, y_k = k_proj(x_k), x_v, y_v), same mapping as the forward kernel (one 4-wave workgroup per window, a token row over a wave):
+//     K_n = (1 - a_k) x_n + a_k (gamma_k yhat_n + beta_k),   yhat_n = (y_n - mu_n) rstd_n          (likewise V_n)
+//     s_n = scale q.K_n + bias,  p = softmax(s),  dP_n = dctx . V_n,  dS_n = p_n (dP_n - sum_m p_m dP_m)
+// Outputs -- everything the rest of the backward needs, none of it of token-stream size except two scalars per token:
+//     ds[tok] = scale dS_n,  pw[tok] = p_n                     (d K_n = ds q,  d V_n = pw dctx: rank-1 per token, never materialised)
+//     sxk[w] = sum_n ds_n x_k,n    syk[w] = sum_n ds_n yhat_k,n    sxv[w] = sum_n p_n x_v,n    syv[w] = sum_n p_n yhat_v,n      ([Nw, D] f32)
+// from which dq = (1 - a_k) sxk + a_k gamma_k syk, d alpha, d gamma, d beta of both adaptors follow as reductions over the windows
+// (tiny), and the adaptor-MLP backward starts from (ds, q) / (pw, dctx) through hicom_adapt_dy_fwd.
+struct LocalAdaptBwdParams {
+    const uint16_t* kx; const _Float16* ky; const uint16_t* kgamma; const uint16_t* kbeta; const void* kalpha;
+    const uint16_t* vx; const _Float16* vy; const uint16_t* vgamma; const uint16_t* vbeta; const void* valpha;
+    int alpha_f32;
+    float eps;
+    const void* query;
+    int query_f32;
+    long query_stride;
+    hicom_axis at, ay, ax;
+    float scale, bias;
+    const float* dctx;      // [Nw, D]
+    float* ds;              // [N] token-indexed
+    float* pw;              // [N]
+    float* sxk; float* syk; float* sxv; float* syv;     // [Nw, D] (syk / syv NULL when that stream has no adaptor)
+};
+
+template <int NV>
+__global__ __launch_bounds__(256) void local_attn_adapt_bwd_kernel(LocalAdaptBwdParams p) {
+    constexpr int D = NV * 384;
+    extern __shared__ __attribute__((aligned(16))) float lsm[];
+    const int ks2 = p.ay.k * p.ax.k;
+    const int WIN = p.at.k * ks2;
+    const int WP = (WIN + 3) & ~3;
+    float* sc = lsm;                               // [WIN] scores, then ds
+    float* dp = lsm + WP;                          // [WIN] dP, then p
+    float* stk = lsm + 2 * WP;                     // [2][WIN] mu, rstd of y_k
+    float* stv = lsm + 4 * WP;                     // [2][WIN] mu, rstd of y_v
+    float* part = lsm + 6 * WP;                    // [4][D]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int win = blockIdx.x;
+    const int w1 = win % p.ax.nwin;
+    const int h1 = (win / p.ax.nwin) % p.ay.nwin;
+    const int t1 = win / (p.ax.nwin * p.ay.nwin);
+    const int t0 = axis_start(p.at, t1), y0 = axis_start(p.ay, h1), x0 = axis_start(p.ax, w1);
+    const int H = p.ay.n, W = p.ax.n;
+    auto scalar = [&](const void* a) { return p.alpha_f32 ? *reinterpret_cast<const float*>(a) : bf16_to_f32(*reinterpret_cast<const uint16_t*>(a)); };
+    const float ak = p.ky ? scalar(p.kalpha) : 0.f, av = p.vy ? scalar(p.valpha) : 0.f;
+
+    float q[NV][6], g[NV][6];
+    if (p.query_f32) {
+        const float* qp = reinterpret_cast<const float*>(p.query) + (long)win * p.query_stride;
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) q[s][j] = qp[384 * s + 6 * lane + j];
+    } else {
+        load_row<NV>(reinterpret_cast<const uint16_t*>(p.query) + (long)win * p.query_stride, lane, q);
+    }
+    load_row_f32<NV>(p.dctx + (long)win * D, lane, g);
+    // q gamma_k, sum(q gamma_k), q . beta_k  and  g gamma_v, sum(g gamma_v), g . beta_v
+    float qg[NV][6], gg[NV][6];
+    float cgk = 0.f, cbk = 0.f, cgv = 0.f, cbv = 0.f;
+    if (p.ky) {
+        float ga[NV][6], be[NV][6];
+        load_row<NV>(p.kgamma, lane, ga);
+        load_row<NV>(p.kbeta, lane, be);
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { qg[s][j] = q[s][j] * ga[s][j]; cgk += qg[s][j]; cbk = fmaf(q[s][j], be[s][j], cbk); }
+        cgk = wave_sum(cgk);
+        cbk = wave_sum(cbk);
+    }
+    if (p.vy) {
+        float ga[NV][6], be[NV][6];
+        load_row<NV>(p.vgamma, lane, ga);
+        load_row<NV>(p.vbeta, lane, be);
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { gg[s][j] = g[s][j] * ga[s][j]; cgv += gg[s][j]; cbv = fmaf(g[s][j], be[s][j], cbv); }
+        cgv = wave_sum(cgv);
+        cbv = wave_sum(cbv);
+    }
+    auto token_of = [&](int i) -> long {
+        const int t2 = i / ks2, r = i - t2 * ks2;
+        const int h2 = r / p.ax.k, w2 = r - h2 * p.ax.k;
+        return ((long)(t0 + t2) * H + (y0 + h2)) * W + (x0 + w2);
+    };
+    // blended dot product of one stream's token with a (vector, vector * gamma) pair; also leaves the LayerNorm statistics
+    auto blend_dot = [&](const float (&x)[NV][6], const float (&y)[NV][6], bool has_y, const float (&v)[NV][6], const float (&vgm)[NV][6], float cg,
+                         float cb, float a, float& mu_o, float& rstd_o) -> float {
+        float dx = 0.f, dy = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                dx = fmaf(v[s][j], x[s][j], dx);
+                if (has_y) { dy = fmaf(vgm[s][j], y[s][j], dy); s1 += y[s][j]; }
+            }
+        dx = wave_sum(dx);
+        if (!has_y) return dx;
+        dy = wave_sum(dy);
+        const float mu = wave_sum(s1) * (1.0f / D);
+        float s2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { const float d = y[s][j] - mu; s2 = fmaf(d, d, s2); }
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) * (1.0f / D) + p.eps);
+        mu_o = mu; rstd_o = rstd;
+        return (1.0f - a) * dx + a * (rstd * (dy - mu * cg) + cb);
+    };
+
+    // ---- phase 1: scores, dP, LayerNorm statistics (one token per wave in flight: four rows) -----------------------------------
+    for (int i = wave; i < WIN; i += 4) {
+        const long tok = token_of(i);
+        float kx[NV][6], ky[NV][6], vx[NV][6], vy[NV][6];
+        load_row<NV>(p.kx + tok * D, lane, kx);
+        if (p.ky) load_row_f16<NV>(p.ky + tok * D, lane, ky);
+        load_row<NV>(p.vx + tok * D, lane, vx);
+        if (p.vy) load_row_f16<NV>(p.vy + tok * D, lane, vy);
+        float muk = 0.f, rsk = 0.f, muv = 0.f, rsv = 0.f;
+        const float logit = blend_dot(kx, ky, p.ky != nullptr, q, qg, cgk, cbk, ak, muk, rsk);
+        const float dpi = blend_dot(vx, vy, p.vy != nullptr, g, gg, cgv, cbv, av, muv, rsv);
+        if (lane == 0) {
+            sc[i] = logit * p.scale + p.bias;
+            dp[i] = dpi;
+            stk[i] = muk; stk[WP + i] = rsk;
+            stv[i] = muv; stv[WP + i] = rsv;
+        }
+    }
+    __syncthreads();
+    // ---- softmax statistics and delta (every wave redundantly; WIN is tiny) ----------------------------------------------------
+    float mx = -3.0e38f;
+    for (int i = lane; i < WIN; i += 64) mx = fmaxf(mx, sc[i]);
+    mx = wave_max(mx);
+    float sum = 0.f, pd = 0.f;
+    for (int i = lane; i < WIN; i += 64) {
+        const float e = expf(sc[i] - mx);
+        sum += e;
+        pd = fmaf(e, dp[i], pd);
+    }
+    const float inv_sum = 1.0f / wave_sum(sum);
+    const float delta = wave_sum(pd) * inv_sum;
+    __syncthreads();                               // every wave has read sc / dp as scores / dP
+    if (wave == 0)
+        for (int i = lane; i < WIN; i += 64) {
+            const float pi = expf(sc[i] - mx) * inv_sum;
+            const float dsi = pi * (dp[i] - delta) * p.scale;
+            sc[i] = dsi;
+            dp[i] = pi;
+            const long tok = token_of(i);
+            p.ds[tok] = dsi;
+            p.pw[tok] = pi;
+        }
+    __syncthreads();
+    // ---- phase 2: the four weighted sums over the window ------------------------------------------------------------------------
+    float axk[NV][6], ayk[NV][6], axv[NV][6], ayv[NV][6];
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { axk[s][j] = 0.f; ayk[s][j] = 0.f; axv[s][j] = 0.f; ayv[s][j] = 0.f; }
+    for (int i = wave; i < WIN; i += 4) {
+        const long tok = token_of(i);
+        float kx[NV][6], ky[NV][6], vx[NV][6], vy[NV][6];
+        load_row<NV>(p.kx + tok * D, lane, kx);
+        if (p.ky) load_row_f16<NV>(p.ky + tok * D, lane, ky);
+        load_row<NV>(p.vx + tok * D, lane, vx);
+        if (p.vy) load_row_f16<NV>(p.vy + tok * D, lane, vy);
+        const float dsi = sc[i], pi = dp[i];
+        const float muk = stk[i], wk = dsi * stk[WP + i], muv = stv[i], wv = pi * stv[WP + i];
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                axk[s][j] = fmaf(dsi, kx[s][j], axk[s][j]);
+                axv[s][j] = fmaf(pi, vx[s][j], axv[s][j]);
+                if (p.ky) ayk[s][j] = fmaf(wk, ky[s][j] - muk, ayk[s][j]);
+                if (p.vy) ayv[s][j] = fmaf(wv, vy[s][j] - muv, ayv[s][j]);
+            }
+    }
+    auto reduce_out = [&](const float (&a)[NV][6], float* dst) {
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) part[wave * D + 384 * s + 6 * lane + j] = a[s][j];
+        __syncthreads();
+        float* out = dst + (long)win * D;
+        for (int c = tid; c < D; c += 256) out[c] = (part[c] + part[D + c]) + (part[2 * D + c] + part[3 * D + c]);
+    };
+    reduce_out(axk, p.sxk);
+    reduce_out(axv, p.sxv);
+    if (p.ky) reduce_out(ayk, p.syk);
+    if (p.vy) reduce_out(ayv, p.syv);
+}
+
+// ---- d y of one adaptor stream: backward of the LayerNorm blend for a rank-1 upstream gradient ---------------------------------------
+// The gradient w.r.t. the blended row is coef[tok] * vec[w(tok)] (K stream: ds * q, V stream: pw * dctx), so with n = gamma yhat + beta,
+// g = d yhat = alpha coef (vec gamma):  dy = rstd (g - mean(g) - yhat mean(g yhat)).  One wave per token: reads the fp16 y row, writes dy as
+// bf16 (the operand dtype of the GEMMs behind it); optionally also r1[tok] = coef2 coef[tok] vec[w] (the (1 - alpha) x-branch of d
+// frames_embed, stage 3).  Exact window partition (every token in one window).
+struct AdaptDyParams {
+    const _Float16* y;      // [N, D]
+    const uint16_t* gamma;
+    const void* vec;        // f32 | bf16 [Nw | 1, D]
+    int vec_f32;
+    long vec_stride;
+    const float* coef;      // [N]
+    const void* alpha; int alpha_f32;
+    float eps;
+    hicom_axis at, ay, ax;
+    uint16_t* dy;           // bf16 [N, D]
+    uint16_t* r1;           // bf16 [N, D] or NULL
+    long N;
+};
+
+template <int NV>
+__global__ __launch_bounds__(256) void adapt_dy_kernel(AdaptDyParams p) {
+    constexpr int D = NV * 384;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long tok = (long)blockIdx.x * 4 + wave;
+    if (tok >= p.N) return;
+    const int H = p.ay.n, W = p.ax.n;
+    const int t = (int)(tok / ((long)H * W)), rem = (int)(tok - (long)t * H * W), yy = rem / W, xx = rem - yy * W;
+    const long win = ((long)(t / p.at.k) * p.ay.nwin + yy / p.ay.k) * p.ax.nwin + xx / p.ax.k;
+    const float alpha = p.alpha_f32 ? *reinterpret_cast<const float*>(p.alpha) : bf16_to_f32(*reinterpret_cast<const uint16_t*>(p.alpha));
+    const float c = p.coef[tok];
+    float y[NV][6], v[NV][6], ga[NV][6];
+    load_row_f16<NV>(p.y + tok * D, lane, y);
+    if (p.vec_f32) load_row_f32<NV>(reinterpret_cast<const float*>(p.vec) + win * p.vec_stride, lane, v);
+    else load_row<NV>(reinterpret_cast<const uint16_t*>(p.vec) + win * p.vec_stride, lane, v);
+    load_row<NV>(p.gamma, lane, ga);
+    float s1 = 0.f;
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) s1 += y[s][j];
+    const float mu = wave_sum(s1) * (1.0f / D);
+    float s2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { y[s][j] -= mu; s2 = fmaf(y[s][j], y[s][j], s2); }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) * (1.0f / D) + p.eps);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            y[s][j] *= rstd;                         // yhat
+            const float gv = v[s][j] * ga[s][j];
+            m1 += gv;
+            m2 = fmaf(gv, y[s][j], m2);
+            ga[s][j] = gv;                           // (vec gamma)
+        }
+    m1 = wave_sum(m1) * (1.0f / D);
+    m2 = wave_sum(m2) * (1.0f / D);
+    const float k = alpha * c * rstd;
+    uint16_t* o = p.dy + tok * D;
+#pragma unroll
+    for (int s = 0; s < NV; ++s) {
+        float r[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) r[j] = k * (ga[s][j] - m1 - y[s][j] * m2);
+        Seg12 w;
+        w.a = f32_to_bf16(r[0]) | ((uint32_t)f32_to_bf16(r[1]) << 16);
+        w.b = f32_to_bf16(r[2]) | ((uint32_t)f32_to_bf16(r[3]) << 16);
+        w.c = f32_to_bf16(r[4]) | ((uint32_t)f32_to_bf16(r[5]) << 16);
+        *reinterpret_cast<Seg12*>(o + 384 * s + 6 * lane) = w;
+    }
+    if (p.r1) {
+        const float k1 = (1.0f - alpha) * c;
+        uint16_t* o1 = p.r1 + tok * D;
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            Seg12 w;
+            w.a = f32_to_bf16(k1 * v[s][0]) | ((uint32_t)f32_to_bf16(k1 * v[s][1]) << 16);
+            w.b = f32_to_bf16(k1 * v[s][2]) | ((uint32_t)f32_to_bf16(k1 * v[s][3]) << 16);
+            w.c = f32_to_bf16(k1 * v[s][4]) | ((uint32_t)f32_to_bf16(k1 * v[s][5]) << 16);
+            *reinterpret_cast<Seg12*>(o1 + 384 * s + 6 * lane) = w;
+        }
+    }
+}
+
+// ---- elementwise helpers of the adaptor-MLP backward (token-stream sized, 16-byte accesses) ------------------------------------------------
+// erf-GELU derivative Phi(x) + x phi(x), same erf approximation as gelu_erf (A&S 7.1.26)
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);           // exp(-x^2 / 2)
+    const float tail = poly * t * e;                                                    // 1 - erf(z)
+    const float cdf = x >= 0.f ? 1.0f - 0.5f * tail : 0.5f * tail;
+    return fmaf(x * 0.3989422804014327f, e, cdf);
+}
+
+// a16 = GELU(h) as fp16 (operand of the recomputed second GEMM) and abf = GELU(h) as bf16 (operand of dW2 = dy^T a): n elements, n % 8 == 0
+__global__ __launch_bounds__(256) void gelu_split_kernel(const _Float16* h, _Float16* a16, uint16_t* abf, long n8) {
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const half8 hv = reinterpret_cast<const half8*>(h)[i];
+    half8 av;
+    u32x4 bv;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { f[e] = gelu_erf((float)hv[e]); av[e] = (_Float16)fminf(fmaxf(f[e], -65504.f), 65504.f); }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = f32_to_bf16(f[2 * e]) | ((uint32_t)f32_to_bf16(f[2 * e + 1]) << 16);
+    reinterpret_cast<half8*>(a16)[i] = av;
+    reinterpret_cast<u32x4*>(abf)[i] = bv;
+}
+
+// da (bf16, in place) *= GELU'(h)  (h fp16 pre-activation): the gradient through the adaptor's hidden activation
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(uint16_t* da, const _Float16* h, long n8) {
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const half8 hv = reinterpret_cast<const half8*>(h)[i];
+    u32x4 d = reinterpret_cast<const u32x4*>(da)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float lo = bf16lo_to_f32(d[e]) * gelu_erf_grad((float)hv[2 * e]);
+        const float hi = bf16hi_to_f32(d[e]) * gelu_erf_grad((float)hv[2 * e + 1]);
+        d[e] = f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    }
+    reinterpret_cast<u32x4*>(da)[i] = d;
+}
+
+// column sums of a bf16 [N, D] matrix (bias gradients: db = sum over the tokens): partial [gridDim.x][D] f32, a wave per row, rows
+// strided over the grid; summed by hicom_partials_sum_fwd (block order: deterministic)
+template <int NV>
+__global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* x, long N, float* parts) {
+    constexpr int D = NV * 384;
+    __shared__ float red[4][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[NV][6];
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[s][j] = 0.f;
+    for (long r = (long)blockIdx.x * 4 + wave; r < N; r += (long)gridDim.x * 4) {
+        float v[NV][6];
+        load_row<NV>(x + r * D, lane, v);
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[s][j] += v[s][j];
+    }
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) red[wave][384 * s + 6 * lane + j] = acc[s][j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) parts[(long)blockIdx.x * D + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
 // ---- pooled per-window query (trilinear, align_corners=False; projector.py:539-540) ----------
 struct PoolParams {
     const uint16_t* x;
@@ -674,6 +1038,79 @@ extern "C" int hicom_local_attn_bwd(const void* key, const void* value, int32_t 
     if (D == 1152) hipLaunchKernelGGL(local_attn_bwd_kernel<3>, dim3((unsigned)nwin), dim3(256), smem, s, p);
     else hipLaunchKernelGGL(local_attn_bwd_kernel<2>, dim3((unsigned)nwin), dim3(256), smem, s, p);
     return hicom_host::check_launch("local_attn_bwd");
+}
+
+static int check_axes(const char* who, hicom_axis at, hicom_axis ay, hicom_axis ax, bool exact) {
+    for (const hicom_axis* a : {&at, &ay, &ax}) {
+        HICOM_REQUIRE(a->n > 0 && a->k > 0 && a->nwin > 0 && a->nfull >= 0 && a->nfull <= a->nwin && a->k <= a->n,
+                      HICOM_EINVAL, "%s: bad axis n=%d k=%d nwin=%d nfull=%d", who, a->n, a->k, a->nwin, a->nfull);
+        if (exact) HICOM_REQUIRE((long)a->nwin * a->k == a->n, HICOM_EUNSUP, "%s: needs an exact window partition (n=%d k=%d)", who, a->n, a->k);
+    }
+    return HICOM_OK;
+}
+
+extern "C" int hicom_local_attn_adapt_bwd(const void* key_x, const void* key_y, const void* k_gamma, const void* k_beta, const void* k_alpha,
+                                          const void* value_x, const void* value_y, const void* v_gamma, const void* v_beta, const void* v_alpha,
+                                          int32_t alpha_dt, float eps, int32_t D, hicom_axis at, hicom_axis ay, hicom_axis ax,
+                                          const void* query, int32_t query_dt, int64_t query_stride, float scale, float bias,
+                                          const float* dctx, float* ds, float* pw, float* sxk, float* syk, float* sxv, float* syv, void* stream) {
+    HICOM_REQUIRE(key_x && value_x && query && dctx && ds && pw && sxk && sxv && (key_y || value_y), HICOM_EINVAL, "local_attn_adapt_bwd: NULL pointer");
+    HICOM_REQUIRE((!key_y || (k_gamma && k_beta && k_alpha && syk)) && (!value_y || (v_gamma && v_beta && v_alpha && syv)), HICOM_EINVAL,
+                  "local_attn_adapt_bwd: adaptor parameters / outputs");
+    HICOM_REQUIRE(D == 1152 || D == 768, HICOM_EUNSUP, "local_attn_adapt_bwd: D=%d (only 1152 / 768)", D);
+    HICOM_REQUIRE((query_dt == HICOM_DT_BF16 || query_dt == HICOM_DT_F32) && (alpha_dt == HICOM_DT_BF16 || alpha_dt == HICOM_DT_F32), HICOM_EINVAL,
+                  "local_attn_adapt_bwd: query / alpha dtype");
+    if (int rc = check_axes("local_attn_adapt_bwd", at, ay, ax, true)) return rc;      // (ds / pw are written once per token)
+    const long win = (long)at.k * ay.k * ax.k, nwin = (long)at.nwin * ay.nwin * ax.nwin;
+    HICOM_REQUIRE(win <= 1024 && nwin < (1L << 31), HICOM_EUNSUP, "local_attn_adapt_bwd: window of %ld tokens is too large", win);
+    LocalAdaptBwdParams p{(const uint16_t*)key_x, (const _Float16*)key_y, (const uint16_t*)k_gamma, (const uint16_t*)k_beta, k_alpha,
+                          (const uint16_t*)value_x, (const _Float16*)value_y, (const uint16_t*)v_gamma, (const uint16_t*)v_beta, v_alpha,
+                          alpha_dt == HICOM_DT_F32, eps, query, query_dt == HICOM_DT_F32, (long)query_stride, at, ay, ax, scale, bias,
+                          dctx, ds, pw, sxk, syk, sxv, syv};
+    const size_t smem = 6 * (((size_t)win + 3) & ~(size_t)3) * 4 + 4 * (size_t)D * 4;
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 1152) hipLaunchKernelGGL(local_attn_adapt_bwd_kernel<3>, dim3((unsigned)nwin), dim3(256), smem, s, p);
+    else hipLaunchKernelGGL(local_attn_adapt_bwd_kernel<2>, dim3((unsigned)nwin), dim3(256), smem, s, p);
+    return hicom_host::check_launch("local_attn_adapt_bwd");
+}
+
+extern "C" int hicom_adapt_dy_fwd(const void* y, const void* gamma, const void* vec, int32_t vec_dt, int64_t vec_stride, const float* coef,
+                                  const void* alpha, int32_t alpha_dt, float eps, int32_t D, hicom_axis at, hicom_axis ay, hicom_axis ax,
+                                  void* dy, void* r1, void* stream) {
+    HICOM_REQUIRE(y && gamma && vec && coef && alpha && dy, HICOM_EINVAL, "adapt_dy: NULL pointer");
+    HICOM_REQUIRE(D == 1152 || D == 768, HICOM_EUNSUP, "adapt_dy: D=%d (only 1152 / 768)", D);
+    HICOM_REQUIRE((vec_dt == HICOM_DT_BF16 || vec_dt == HICOM_DT_F32) && (alpha_dt == HICOM_DT_BF16 || alpha_dt == HICOM_DT_F32), HICOM_EINVAL, "adapt_dy: dtypes");
+    if (int rc = check_axes("adapt_dy", at, ay, ax, true)) return rc;
+    const long N = (long)at.n * ay.n * ax.n;
+    AdaptDyParams p{(const _Float16*)y, (const uint16_t*)gamma, vec, vec_dt == HICOM_DT_F32, (long)vec_stride, coef, alpha, alpha_dt == HICOM_DT_F32, eps,
+                    at, ay, ax, (uint16_t*)dy, (uint16_t*)r1, N};
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 1152) hipLaunchKernelGGL(adapt_dy_kernel<3>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(adapt_dy_kernel<2>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, p);
+    return hicom_host::check_launch("adapt_dy");
+}
+
+extern "C" int hicom_gelu_split_fwd(const void* h_f16, void* a_f16, void* a_bf16, int64_t n, void* stream) {
+    HICOM_REQUIRE(h_f16 && a_f16 && a_bf16 && n > 0 && n % 8 == 0 && ((uintptr_t)h_f16 % 16 == 0) && ((uintptr_t)a_f16 % 16 == 0) && ((uintptr_t)a_bf16 % 16 == 0),
+                  HICOM_EINVAL, "gelu_split: bad arguments (n %% 8, 16-byte alignment)");
+    hipLaunchKernelGGL(gelu_split_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)h_f16, (_Float16*)a_f16,
+                       (uint16_t*)a_bf16, (long)(n / 8));
+    return hicom_host::check_launch("gelu_split");
+}
+
+extern "C" int hicom_gelu_bwd_fwd(void* da_bf16, const void* h_f16, int64_t n, void* stream) {
+    HICOM_REQUIRE(da_bf16 && h_f16 && n > 0 && n % 8 == 0 && ((uintptr_t)da_bf16 % 16 == 0) && ((uintptr_t)h_f16 % 16 == 0), HICOM_EINVAL,
+                  "gelu_bwd: bad arguments (n %% 8, 16-byte alignment)");
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)da_bf16, (const _Float16*)h_f16,
+                       (long)(n / 8));
+    return hicom_host::check_launch("gelu_bwd");
+}
+
+extern "C" int hicom_colsum_fwd(const void* x_bf16, int64_t N, int32_t D, float* parts, int32_t nparts, void* stream) {
+    HICOM_REQUIRE(x_bf16 && parts && N > 0 && nparts > 0 && (D == 1152 || D == 768), HICOM_EINVAL, "colsum: bad arguments (D 1152 / 768)");
+    if (D == 1152) hipLaunchKernelGGL(colsum_kernel<3>, dim3((unsigned)nparts), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x_bf16, (long)N, parts);
+    else hipLaunchKernelGGL(colsum_kernel<2>, dim3((unsigned)nparts), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x_bf16, (long)N, parts);
+    return hicom_host::check_launch("colsum");
 }
 
 extern "C" int hicom_trilinear_pool_fwd(const void* x, int32_t T, int32_t H, int32_t W, int32_t D,

@@ -72,8 +72,8 @@ class _HeadFn(torch.autograd.Function):
     """Forward = the inference chain (same kernels, same bits).  Backward is recompute-based (the reference's scripts run with
     gradient checkpointing): LayerNorm output and the pre-activation hidden layer come back from the HIP forward kernels
     (hicom_ln_stream_fwd, hicom_dense16_gemm_fwd without activation); d hidden = dY . W2 runs on the dense16 kernel as well (NT
-    form); the two weight gradients dW = dY^T X contract over the TOKEN axis -- the TN form, which dense16.hip does not have -- and
-    go through the vendor GEMM ("plain library GEMMs", bf16 operands, fp32 accumulation)."""
+    form); the two weight gradients dW = dY^T X contract over the TOKEN axis -- the TN form of the same kernel
+    family (hicom_dense16_tn_fwd, round 4: transposed LDS fragment reads, split contraction; bf16 operands, fp32 accumulation)."""
 
     @staticmethod
     def forward(ctx, x, head, hidden_act, *params):
@@ -114,7 +114,7 @@ class _HeadFn(torch.autograd.Function):
             # ---- fc2: dW2 = dY^T a, db2, d a = dY W2 --------------------------------------------------------------------------
             dYb = dY.to(torch.bfloat16)
             grads = {}
-            grads["mlp.fc2.weight"] = _mm_f32(dYb.t(), a_b)
+            grads["mlp.fc2.weight"] = _tn_f32(dYb, a_b)
             grads["mlp.fc2.bias"] = dY.sum(0, dtype=torch.float32)
             del a_b
             w2t = fc2.weight.detach().t().contiguous()                      # [inter, D] bf16: the NT form's "weight"
@@ -127,7 +127,7 @@ class _HeadFn(torch.autograd.Function):
             dh1b = torch.ops.aten.gelu_backward(da, h1b, approximate=approx)
             del da, h1b
             nb = n16.to(torch.bfloat16)
-            grads["mlp.fc1.weight"] = _mm_f32(dh1b.t(), nb)
+            grads["mlp.fc1.weight"] = _tn_f32(dh1b, nb)
             grads["mlp.fc1.bias"] = dh1b.sum(0, dtype=torch.float32)
             dn = _mm_f32(dh1b, fc1.weight.detach())                         # [M, D]
             del dh1b
@@ -142,6 +142,14 @@ class _HeadFn(torch.autograd.Function):
         plist = _head_params(head)
         outs = [grads[n].to(p.dtype).view(p.shape) if ctx.needs_input_grad[3 + i] else None for i, (n, p) in enumerate(zip(names, plist))]
         return (None, None, None, *outs)
+
+
+def _tn_f32(a, b):
+    """a^T @ b over the token rows, bf16 operands -> fp32: the TN form of the dense MFMA GEMM (hicom_dense16_tn_fwd) where the
+    shapes allow (widths multiples of 8), else the library."""
+    if a.shape[0] >= 64 and a.shape[1] % 8 == 0 and b.shape[1] % 8 == 0 and a.is_contiguous() and b.is_contiguous():
+        return nv.dense16_tn(a, b)
+    return _mm_f32(a.t(), b)
 
 
 def _mm_f32(a, b):

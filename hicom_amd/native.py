@@ -33,6 +33,7 @@ EXPORTS = (
     "hicom_global_stream_clip_fwd", "hicom_splice_rows_fwd", "hicom_splice_labels_fwd",
     "hicom_query_prep_fwd", "hicom_query_prep_state_bytes", "hicom_partials_sum_fwd", "hicom_l2norm_stream_fwd", "hicom_local_attn_adapt_fwd",
     "hicom_small_mha_scaled_fwd", "hicom_merge_vproj_fixed_fwd", "hicom_dense16_tn_fwd", "hicom_dense16_tn_splits",
+    "hicom_local_attn_adapt_bwd", "hicom_adapt_dy_fwd", "hicom_gelu_split_fwd", "hicom_gelu_bwd_fwd", "hicom_colsum_fwd",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -142,6 +143,12 @@ def lib() -> C.CDLL:
     L.hicom_dense16_tn_fwd.argtypes = [vp, i64, vp, i64, i32, i64, i32, i32, vp, i64, i32, vp]
     L.hicom_l2norm_stream_fwd.argtypes = [vp, vp, i64, i32, vp]
     L.hicom_local_attn_adapt_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32, vp, vp]
+    L.hicom_local_attn_adapt_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32,
+                                             vp, vp, vp, vp, vp, vp, vp, vp]
+    L.hicom_adapt_dy_fwd.argtypes = [vp, vp, vp, i32, i64, vp, vp, i32, f32, i32, Axis, Axis, Axis, vp, vp, vp]
+    L.hicom_gelu_split_fwd.argtypes = [vp, vp, vp, i64, vp]
+    L.hicom_gelu_bwd_fwd.argtypes = [vp, vp, i64, vp]
+    L.hicom_colsum_fwd.argtypes = [vp, i64, i32, vp, i32, vp]
     L.hicom_clip_query_prep_fwd.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp]
     L.hicom_inv_norm_fwd.argtypes = [vp, i32, i64, vp, vp]
     L.hicom_global_stream_clip_fwd.argtypes = [vp, i64, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64,
@@ -226,6 +233,45 @@ def local_attn_adapt(key_x, key_y, k_norm, k_alpha, value_x, value_y, v_norm, v_
                                             _ptr(v_norm.bias.detach()) if value_y is not None else None, _ptr(v_alpha) if value_y is not None else None,
                                             _dt(alpha), eps, D, axes[0], axes[1], axes[2], _ptr(query), _dt(query), query_stride,
                                             scale, bias, _ptr(ctx), _stream()), "hicom_local_attn_adapt_fwd")
+
+
+def local_attn_adapt_bwd(key_x, key_y, k_norm, k_alpha, value_x, value_y, v_norm, v_alpha, axes, query, query_stride, scale, bias, dctx,
+                         ds, pw, sxk, syk, sxv, syv, eps=1e-6):
+    """Backward of the blend-fused window attention (see include/hicom_hip.h); key_y / value_y fp16 [N, D] or None."""
+    D = value_x.shape[-1]
+    alpha = k_alpha if k_alpha is not None else v_alpha
+    _check(lib().hicom_local_attn_adapt_bwd(_ptr(key_x), _ptr(key_y), _ptr(k_norm.weight.detach()) if key_y is not None else None,
+                                            _ptr(k_norm.bias.detach()) if key_y is not None else None, _ptr(k_alpha) if key_y is not None else None,
+                                            _ptr(value_x), _ptr(value_y), _ptr(v_norm.weight.detach()) if value_y is not None else None,
+                                            _ptr(v_norm.bias.detach()) if value_y is not None else None, _ptr(v_alpha) if value_y is not None else None,
+                                            _dt(alpha), eps, D, axes[0], axes[1], axes[2], _ptr(query), _dt(query), query_stride, scale, bias,
+                                            _ptr(dctx), _ptr(ds), _ptr(pw), _ptr(sxk), _ptr(syk), _ptr(sxv), _ptr(syv), _stream()),
+           "hicom_local_attn_adapt_bwd")
+
+
+def adapt_dy(y, gamma, vec, vec_stride, coef, alpha, axes, dy, r1=None, eps=1e-6):
+    D = y.shape[-1]
+    _check(lib().hicom_adapt_dy_fwd(_ptr(y), _ptr(gamma), _ptr(vec), _dt(vec), vec_stride, _ptr(coef), _ptr(alpha), _dt(alpha), eps, D,
+                                    axes[0], axes[1], axes[2], _ptr(dy), _ptr(r1), _stream()), "hicom_adapt_dy_fwd")
+
+
+def gelu_split(h16, a16, abf):
+    _check(lib().hicom_gelu_split_fwd(_ptr(h16), _ptr(a16), _ptr(abf), h16.numel(), _stream()), "hicom_gelu_split_fwd")
+
+
+def gelu_bwd_(da_bf16, h16):
+    _check(lib().hicom_gelu_bwd_fwd(_ptr(da_bf16), _ptr(h16), da_bf16.numel(), _stream()), "hicom_gelu_bwd_fwd")
+
+
+def colsum(x_bf16, nparts=128):
+    """Column sums of a bf16 [N, D] matrix -> f32 [D] (partials + hicom_partials_sum_fwd: deterministic)."""
+    N, D = x_bf16.shape
+    nparts = max(1, min(nparts, (N + 3) // 4))
+    parts = torch.empty((nparts, D), dtype=torch.float32, device=x_bf16.device)
+    _check(lib().hicom_colsum_fwd(_ptr(x_bf16), N, D, _ptr(parts), nparts, _stream()), "hicom_colsum_fwd")
+    out = torch.empty((D,), dtype=torch.float32, device=x_bf16.device)
+    partials_sum(parts, out)
+    return out
 
 
 def local_attn_bwd(key, value, axes, query, query_stride, scale, bias, dctx, dq, dkey=None):

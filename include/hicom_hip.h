@@ -83,6 +83,29 @@ int hicom_local_attn_adapt_fwd(const void* key_x, const void* key_y, const void*
                                const void* query, int32_t query_dt, int64_t query_stride, float scale, float bias,
                                float* ctx, void* stream);
 
+/* ---- backward of the windowed attention with the k / v adaptor blends (training path of `local43_adaptkv_global32`; autograd
+ * through projector.py:533-534 + :550-553).  Arguments as hicom_local_attn_adapt_fwd plus dctx f32 [Nw, D].  Outputs (exact window
+ * partition required):
+ *   ds [N] f32 = scale dS_n,  pw [N] f32 = p_n       token-indexed: d key_n = ds_n q_w, d value_n = pw_n dctx_w (rank 1, never written)
+ *   sxk, sxv [Nw, D] f32 = sum_n ds_n key_x_n, sum_n pw_n value_x_n;   syk, syv [Nw, D] = sum_n ds_n yhat_k,n, sum_n pw_n yhat_v,n with
+ *   yhat = LayerNorm-normalised y (no affine); syk / syv may be NULL when that stream has no adaptor.
+ * From these: dq_w = (1 - a_k) sxk_w + a_k gamma_k syk_w, and d alpha / d gamma / d beta of both adaptors as sums over the windows.
+ * hicom_adapt_dy_fwd continues into the adaptor MLP: dy[tok] = d/dy of alpha LN(y) gamma for the upstream gradient coef[tok] * vec[w(tok)]
+ * (K: coef = ds, vec = q; V: coef = pw, vec = dctx), written as bf16 [N, D]; r1 (may be NULL) = (1 - alpha) coef[tok] vec[w] as bf16, the
+ * x-branch of d frames_embed.  hicom_gelu_split_fwd / hicom_gelu_bwd_fwd / hicom_colsum_fwd: the elementwise steps of the adaptor-MLP backward
+ * (a = GELU(h) as fp16 and bf16; da *= GELU'(h) in place; partial column sums [nparts][D] for the bias gradients). */
+int hicom_local_attn_adapt_bwd(const void* key_x, const void* key_y, const void* k_gamma, const void* k_beta, const void* k_alpha,
+                               const void* value_x, const void* value_y, const void* v_gamma, const void* v_beta, const void* v_alpha,
+                               int32_t alpha_dt, float eps, int32_t D, hicom_axis at, hicom_axis ay, hicom_axis ax,
+                               const void* query, int32_t query_dt, int64_t query_stride, float scale, float bias,
+                               const float* dctx, float* ds, float* pw, float* sxk, float* syk, float* sxv, float* syv, void* stream);
+int hicom_adapt_dy_fwd(const void* y, const void* gamma, const void* vec, int32_t vec_dt, int64_t vec_stride, const float* coef,
+                       const void* alpha, int32_t alpha_dt, float eps, int32_t D, hicom_axis at, hicom_axis ay, hicom_axis ax,
+                       void* dy, void* r1, void* stream);
+int hicom_gelu_split_fwd(const void* h_f16, void* a_f16, void* a_bf16, int64_t n, void* stream);
+int hicom_gelu_bwd_fwd(void* da_bf16, const void* h_f16, int64_t n, void* stream);
+int hicom_colsum_fwd(const void* x_bf16, int64_t N, int32_t D, float* parts, int32_t nparts, void* stream);
+
 /* ---- backward of the windowed attention (training path; autograd through projector.py:550-553) ----------
  * For the reference's stage 3 (train.py:717-726: the SigLIP head and the guide encoder train too) the gradients
  * w.r.t. the key stream frames_embed and the query are needed.
