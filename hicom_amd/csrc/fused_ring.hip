@@ -105,6 +105,9 @@ __device__ __forceinline__ int fxg(int row, int kg) { return kg ^ (((row >> 3) &
 
 template <int NB>
 __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams p) {
+#ifdef HICOM_TRACE
+    const unsigned long long tr_entry = __builtin_readcyclecounter();
+#endif
     constexpr int E = NB * 128;
     constexpr int SLICE = E / kRingC;              // channels per compute wave
     constexpr int KS = SLICE / 16;                 // 16-column blocks of the P.x product per wave
@@ -147,6 +150,9 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
     // LOADER waves
     // =========================================================================================
     if (wave >= kRingC) {
+#ifdef HICOM_TRACE
+        if (lane == 0) g_fused_trace[(blockIdx.x * 3 + 2) * 256 + 240 + (wave - kRingC)] = __builtin_readcyclecounter();     // first instruction of loader l
+#endif
         const int l = wave - kRingC;
         const int row = 4 * l + (lane >> 4), cpos = lane & 15;          // token slot of this lane, 16-byte chunk in the row
         const int lane_off = 16 * (cpos ^ fswz(row));
@@ -184,17 +190,18 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
         const long o0 = src_off(0);
         issue(p.fe, o0, febuf);
         issue(p.ff, o0, ffbuf);
-        // Both images of tile 1 go out before [P] as well (token tiles need no table and all four ring slots are free at the
-        // start): 144 KB in flight per CU during the launch ramp instead of 72, while the compute waves fetch their operands
-        // (round 4: -0.9 us per launch, tools/gpu_ab.sh)
+        // Both images of tile 1 go out up front as well (token tiles need no table and all four ring slots are free at the start):
+        // 144 KB in flight per CU during the launch ramp instead of 72 (round 4: -0.9 us per launch, tools/gpu_ab.sh) -- but BEHIND
+        // [P]: issuing an image costs a loader ~2.5k clocks (18 pieces at 100-185 clocks), and the compute waves, ready with their
+        // tables at ~5k clocks, would wait at [P] for it (tools/fused_trace.py: loaders at [P] after 9.9k clocks with tile 1 in front)
         const bool pre1 = ntile > 1;
+        const long o1 = pre1 ? src_off(1) : 0;
+        HICOM_TR(2);   // prologue requests issued
+        __builtin_amdgcn_s_barrier();                                  // [P] (the compute waves' tables)
         if (pre1) {
-            const long o1 = src_off(1);
             issue(p.fe, o1, febuf + TILE_BYTES);
             issue(p.ff, o1, ffbuf + TILE_BYTES);
         }
-        HICOM_TR(2);   // prologue requests issued
-        __builtin_amdgcn_s_barrier();                                  // [P] (the compute waves' tables)
         if (p.pe_hi) {
             nsl = slot_row[64];
             ntot = ntile + ((nsl + 15) >> 4);
@@ -261,6 +268,26 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
     const int r16 = lane & 15, kg = lane >> 4;
     const int ctid = tid;                                              // compute threads are 0 .. 511
 
+    // ---- score-side pos table of this workgroup: its (cold) gathers go out FIRST, their latency runs under the operand loads and the
+    // table building below, and the values are parked in LDS at the end of the prologue (they were requested last and waited for at
+    // once: 4.5k of the prologue's 8.4k clocks, tools/fused_trace.py) ------------------------------------------------------------
+    const int t1_first = wb / per_t;
+    float apv[kPosPerThread];
+    if (p.pos_a) {
+        const int S = kMaxFramesPerWg + p.H + p.W, n_all = R * S;
+#pragma unroll
+        for (int u = 0; u < kPosPerThread; ++u) {
+            const int e = ctid + 64 * kRingC * u;
+            apv[u] = 0.f;
+            if (e < n_all) {
+                const int r = e / S, c = e - r * S;
+                const int t = t1_first * p.kt + c;
+                const int col = c < kMaxFramesPerWg ? p.t0i + t
+                                                    : (c < kMaxFramesPerWg + p.H ? p.y0i + (c - kMaxFramesPerWg) : p.x0i + (c - kMaxFramesPerWg - p.H));
+                if (c >= kMaxFramesPerWg || t < p.T) apv[u] = p.pos_a[(long)r * p.pos_stride + col];
+            }
+        }
+    }
     // ---- A operand (hi / lo) of this wave's channel slice: lane (query row r16, k group kg) -------
     // SLICE = K32 steps of 32 channels (v_mfma_f32_16x16x32_bf16, the full-rate instruction) + an optional
     // 16-channel tail (v_mfma_f32_16x16x16_bf16 runs at half the rate per flop).
@@ -280,8 +307,11 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
     }
     if (part == 0 && p.zero_ptr)                                     // (fixed-point accumulators of the merge + v_proj launch behind us)
         for (int i = ctid; i < p.zero_n; i += 64 * kRingC) p.zero_ptr[i] = 0ull;
+
+#ifdef HICOM_TRACE
+    if (lane == 0 && wave == 0) g_fused_trace[(blockIdx.x * 3 + 0) * 256 + 241] = __builtin_readcyclecounter();
+#endif
     // ---- per-workgroup tables ---------------------------------------------------------------------
-    const int t1_first = wb / per_t;
     if (ctid < p.WSZ) {
         const int t2 = ctid / ks2, r = ctid - t2 * ks2, h2 = r / p.ks, w2 = r - h2 * p.ks;
         win_txy[ctid] = (t2 << 16) | (h2 << 8) | w2;
@@ -291,6 +321,10 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
         const int t1 = w / per_t, r = w - t1 * per_t, h1 = r / p.nwx, w1 = r - h1 * p.nwx;
         wtxy[ctid] = (((t1 - t1_first) * p.kt) << 16) | ((h1 * p.ks) << 8) | (w1 * p.ks);
     }
+
+#ifdef HICOM_TRACE
+    if (lane == 0 && wave == 0) g_fused_trace[(blockIdx.x * 3 + 0) * 256 + 242] = __builtin_readcyclecounter();
+#endif
     if (p.pe_hi && wave == 0) {
         // Compact pos-emb slots of this workgroup: the 8 frames from its first frame group, then only the grid
         // rows and columns its windows touch (a few of the H + W): fewer pe rows to multiply after the stream.
@@ -315,21 +349,18 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
         if (xu) slot_row[cx] = p.x0i + lane;
         if (lane == 0) slot_row[64] = kMaxFramesPerWg + ny + __popcll(xm);
     }
+
+#ifdef HICOM_TRACE
+    if (lane == 0 && wave == 0) g_fused_trace[(blockIdx.x * 3 + 0) * 256 + 243] = __builtin_readcyclecounter();
+#endif
     if (p.pos_a) {
-        const int S = kMaxFramesPerWg + p.H + p.W, n_all = R * S;
+        const int n_all = R * (kMaxFramesPerWg + p.H + p.W);
 #pragma unroll
         for (int u = 0; u < kPosPerThread; ++u) {
             const int e = ctid + 64 * kRingC * u;
-            if (e < n_all) {
-                const int r = e / S, c = e - r * S;
-                const int t = t1_first * p.kt + c;
-                const int col = c < kMaxFramesPerWg ? p.t0i + t
-                                                    : (c < kMaxFramesPerWg + p.H ? p.y0i + (c - kMaxFramesPerWg) : p.x0i + (c - kMaxFramesPerWg - p.H));
-                a_pos[e] = (c >= kMaxFramesPerWg || t < p.T) ? p.pos_a[(long)r * p.pos_stride + col] : 0.f;
-            }
+            if (e < n_all) a_pos[e] = apv[u];
         }
     }
-
     f32x4 acc[KS];
 #pragma unroll
     for (int cb = 0; cb < KS; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -611,6 +642,7 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
         }
     }
     lds_barrier();                                                     // [E] every wave done with the ring
+    HICOM_TR(0); HICOM_TR(1);   // tail: value-side pos-emb done
     // ---- partial global state of this workgroup --------------------------------------------------
     const long prow = (long)part * 16;
     if (wave == 0 && kg == 0 && r16 < R) {
@@ -629,26 +661,33 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
             if (kg == 0) ascr[r16] = 1.0f / fmaxf(l_run, 1.0e-30f);
             linv = *reinterpret_cast<const f32x4*>(ascr + 4 * kg);
         }
+        if (p.part_ctx16) {
+            // straight from the accumulator layout: the 16 lanes of a DPP row hold 16 consecutive channels of one accumulator row, i.e.
+            // 32 contiguous bytes per 2-byte store instruction and row -- 20 KB per workgroup in all; the LDS regroup the fp32 form
+            // needs (36 scalar LDS writes + 5 strided read / store rounds per lane) was 4.3k clocks at the very end of the launch
+            _Float16* dst = p.part_ctx16 + prow * E + ch_base + r16;
 #pragma unroll
-        for (int cb = 0; cb < KS; ++cb)
+            for (int cb = 0; cb < KS; ++cb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (4 * kg + j < R) est[(4 * kg + j) * SLICE + 16 * cb + r16] = acc[cb][j] * linv[j];
-        const int n4 = R * (SLICE / 4);
-        for (int it = lane; it < n4; it += 64) {
-            const int row = it / (SLICE / 4), c4 = it - row * (SLICE / 4);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(est + 4 * it);
-            if (p.part_ctx16) {
-                typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-                half4_t hv;
+                for (int j = 0; j < 4; ++j)
+                    if (4 * kg + j < R) dst[(long)(4 * kg + j) * E + 16 * cb] = (_Float16)fminf(fmaxf(acc[cb][j] * linv[j], -65504.f), 65504.f);
+        } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) hv[u] = (_Float16)fminf(fmaxf(v[u], -65504.f), 65504.f);
-                *reinterpret_cast<half4_t*>(p.part_ctx16 + (prow + row) * E + ch_base + 4 * c4) = hv;
-            } else {
-                *reinterpret_cast<f32x4*>(p.part_acc + (prow + row) * E + ch_base + 4 * c4) = v;
+            for (int cb = 0; cb < KS; ++cb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * kg + j < R) est[(4 * kg + j) * SLICE + 16 * cb + r16] = acc[cb][j];
+            const int n4 = R * (SLICE / 4);
+            for (int it = lane; it < n4; it += 64) {
+                const int row = it / (SLICE / 4), c4 = it - row * (SLICE / 4);
+                *reinterpret_cast<f32x4*>(p.part_acc + (prow + row) * E + ch_base + 4 * c4) = *reinterpret_cast<const f32x4*>(est + 4 * it);
             }
         }
     }
+    HICOM_TR(0); HICOM_TR(1);   // tail: state written (stores issued)
+#ifdef HICOM_TRACE
+    if (lane == 0 && wave == 0 && tr_n < 256) g_fused_trace[(blockIdx.x * 3 + 0) * 256 + tr_n] = tr_entry;
+#endif
 }
 
 template <int N>
@@ -1204,23 +1243,26 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_logits_kernel(Ring
             if (kg == 0) ascr[r16] = 1.0f / fmaxf(l_run, 1.0e-30f);
             linv = *reinterpret_cast<const f32x4*>(ascr + 4 * kg);
         }
+        if (p.part_ctx16) {
+            // straight from the accumulator layout: the 16 lanes of a DPP row hold 16 consecutive channels of one accumulator row, i.e.
+            // 32 contiguous bytes per 2-byte store instruction and row -- 20 KB per workgroup in all; the LDS regroup the fp32 form
+            // needs (36 scalar LDS writes + 5 strided read / store rounds per lane) was 4.3k clocks at the very end of the launch
+            _Float16* dst = p.part_ctx16 + prow * E + ch_base + r16;
 #pragma unroll
-        for (int cb = 0; cb < KS; ++cb)
+            for (int cb = 0; cb < KS; ++cb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (4 * kg + j < R) est[(4 * kg + j) * SLICE + 16 * cb + r16] = acc[cb][j] * linv[j];
-        const int n4 = R * (SLICE / 4);
-        for (int it = lane; it < n4; it += 64) {
-            const int row = it / (SLICE / 4), c4 = it - row * (SLICE / 4);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(est + 4 * it);
-            if (p.part_ctx16) {
-                typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-                half4_t hv;
+                for (int j = 0; j < 4; ++j)
+                    if (4 * kg + j < R) dst[(long)(4 * kg + j) * E + 16 * cb] = (_Float16)fminf(fmaxf(acc[cb][j] * linv[j], -65504.f), 65504.f);
+        } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) hv[u] = (_Float16)fminf(fmaxf(v[u], -65504.f), 65504.f);
-                *reinterpret_cast<half4_t*>(p.part_ctx16 + (prow + row) * E + ch_base + 4 * c4) = hv;
-            } else {
-                *reinterpret_cast<f32x4*>(p.part_acc + (prow + row) * E + ch_base + 4 * c4) = v;
+            for (int cb = 0; cb < KS; ++cb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * kg + j < R) est[(4 * kg + j) * SLICE + 16 * cb + r16] = acc[cb][j];
+            const int n4 = R * (SLICE / 4);
+            for (int it = lane; it < n4; it += 64) {
+                const int row = it / (SLICE / 4), c4 = it - row * (SLICE / 4);
+                *reinterpret_cast<f32x4*>(p.part_acc + (prow + row) * E + ch_base + 4 * c4) = *reinterpret_cast<const f32x4*>(est + 4 * it);
             }
         }
     }

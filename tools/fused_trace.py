@@ -56,6 +56,19 @@ for who, label in ((0, "compute wave 0 (marginals)"), (1, "compute wave 2")):
         stat(n + " (all tiles)", np.concatenate(agg[n]))
     stat("tile 0: wait at [A] (first data)", c[:, 2] - c[:, 1])
     stat("loop total (first [A] arrive -> last P.x)", c[:, 1 + 5 * (ntile - 1) + 4] - c[:, 1])
+c0 = tr[:, 0, 0::2]
+e = 1 + 5 * ntile
+stat("PROLOGUE: kernel entry -> tables / operands done (wave 0, before [P])", c0[:, 0] - tr[:, 0, 2 * (e + 2)])
+stat("PROLOGUE: kernel entry -> loader 0 has issued its prologue requests", tr[:, 2, 0] - tr[:, 0, 2 * (e + 2)])
+for idx, what in ((241, "operand loads issued"), (242, "window tables written"), (243, "pos-emb slot tables built"), (244, "score-side pos table staged")):
+    stat("PROLOGUE: wave 0 entry -> " + what, tr[:, 0, idx] - tr[:, 0, 2 * (e + 2)])
+for l in range(4):
+    stat("PROLOGUE: wave 0 entry -> first instruction of loader %d (wave %d)" % (l, 8 + l), tr[:, 2, 240 + l] - tr[:, 0, 2 * (e + 2)])
+stat("PROLOGUE: kernel entry -> first [A] arrive (wave 0)", c0[:, 1] - tr[:, 0, 2 * (e + 2)])
+stat("PROLOGUE: kernel entry -> tile 0 data (past [A])", c0[:, 2] - tr[:, 0, 2 * (e + 2)])
+stat("TAIL: last P.x issued -> pos-emb tiles done", c0[:, e] - c0[:, e - 1])
+stat("TAIL: pos-emb done -> state stores issued", c0[:, e + 1] - c0[:, e])
+stat("WHOLE: entry -> state stores issued", c0[:, e + 1] - tr[:, 0, 2 * (e + 2)])
 c = tr[:, 2]
 print("---- loader 0: 1 + 6 stamps per tile")
 names = ["addr -> landed (vmcnt wait)", "wait at [A]", "issue ff(t+1)", "wait at [B]", "issue fe(t+2)", "next addr math"]
