@@ -740,8 +740,9 @@ extern "C" int hicom_dense16_tn_splits(int32_t M, int32_t N, int64_t Kt) {
     const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128), stages = (Kt + 63) / 64;
     long s = (768 + tiles - 1) / tiles;                  // ~3 workgroups per CU ...
     if (s > stages) s = stages;
-    if (s >= 6 && stages >= 8) {                         // ... in multiples of 8 where the token axis allows: one XCD per slice (see the kernel)
-        s = (s + 7) / 8 * 8;
+    if (stages >= 8) {                                   // ... in multiples of 8 where the token axis allows: one XCD per slice (see the kernel;
+        s = (s + 4) / 8 * 8;                             // 3 slices of a 306-tile product ran at half the rate of 8)
+        if (s < 8) s = 8;
         if (s > stages) s = stages / 8 * 8;
     }
     if (s > 64) s = 64;
