@@ -495,19 +495,20 @@ def neighbours_sweep(args, device):
         o.backward(cot)
         return o
 
+    # default: the backward of the plain recipes replays a captured hipGraph over static copies of the inputs (hicom_amd/autograd.py);
+    # graph_backward = False: every launch from Python (what rounds 2-3 reported as the eager step)
     for flag, key in ((False, "params_only_ms"), (True, "with_input_grads_ms")):
-        train_step(flag)
+        for _ in range(3):
+            train_step(flag)
         dt, _ = best(lambda: train_step(flag), n=5)
         out.setdefault("train_step", {"workload": f"{args.frames_per_gpu} frames, hidden {args.hidden}, use_guide=direct: forward() under autograd + backward (recompute-based, hicom_amd/autograd.py)"})[key] = dt * 1e3
-    # opt-in: the backward as a captured hipGraph (same input buffers step after step, as a training loop's allocator hands them out)
-    m.graph_backward = True
-    for _ in range(3):
-        train_step(False)
-    dt, _ = best(lambda: train_step(False), n=5)
-    out["train_step"]["params_only_graph_backward_ms"] = dt * 1e3
-    ent = next(iter(m.__dict__.get("_bwd_graphs", {}).values()), {})
-    out["train_step"]["graph_backward_captured"] = "graph" in ent
+    ents = list(m.__dict__.get("_bwd_graphs", {}).values())
+    out["train_step"]["graph_backward_captured"] = bool(ents) and all("graph" in e for e in ents)
     m.graph_backward = False
+    train_step(False)
+    dt, _ = best(lambda: train_step(False), n=5)
+    out["train_step"]["params_only_eager_backward_ms"] = dt * 1e3
+    m.graph_backward = None
     return out
 
 

@@ -244,7 +244,8 @@ class _CompressorFn(torch.autograd.Function):
         proj = ctx.proj
         want = tuple(bool(need[7 + k]) for k in range(len(ctx.names)))
         args = (proj, ff, fe, guide, ctx.modal, nl, ctx.names, want, bool(need[2]), bool(need[3]), bool(nl is not None and need[5]))
-        if getattr(proj, "graph_backward", False) and nl is None and _is_plain(proj):
+        gb = getattr(proj, "graph_backward", None)             # None: automatic; False: always eager
+        if (gb is None or gb) and nl is None:
             res = _graphed_backward(dout, *args)
         else:
             with torch.no_grad():
@@ -284,15 +285,17 @@ _MAX_BWD_GRAPHS = 4
 
 
 def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl):
-    """Opt-in (`proj.graph_backward = True`): the backward of a plain recipe as a captured hipGraph.  The backward is ~130 small
-    launches behind 1.4 ms of Python at the benchmark shape; its shapes are static, so the second backward with the same input
-    BUFFERS (a training loop's caching allocator hands the same blocks back step after step) is captured and later ones are one
-    graph launch.  Keyed by the addresses the captured kernels read (frames, guide, parameters) and by what is asked for; the
-    upstream gradient is copied into a static buffer, the results are cloned out of the graph's pool (gradient accumulation adds
-    into .grad in place: handing out the static buffers would alias them).  Falls back to the eager backward on any capture error."""
+    """The backward as a captured hipGraph (the default; `proj.graph_backward = False` turns it off).
+    The eager backward is ~130 small launches behind 1.4 ms of Python at the benchmark shape; its shapes are static, so the second
+    backward of a problem SHAPE is captured and later ones are one graph launch.  The captured kernels read STATIC copies of the inputs
+    (frames_feature, frames_embed, guide: one device copy each per step, ~0.1 ms at 64 frames) -- round 3 keyed the graph on the callers'
+    buffer addresses, which only held while the allocator handed the same blocks back.  The upstream gradient is copied into a static buffer
+    too, the results are cloned out of the graph's pool (gradient accumulation adds into .grad in place: handing out the static buffers would
+    alias them).  Keyed by shapes and by what is asked for; dropped when the parameters' storage or a cached device table moves
+    (`engine.plan_sig`).  Falls back to the eager backward on any capture error."""
     from . import engine
     cache = proj.__dict__.setdefault("_bwd_graphs", {})
-    key = (ff.data_ptr(), tuple(ff.shape), None if fe is None else fe.data_ptr(), None if guide is None else guide.data_ptr(), modal,
+    key = (tuple(ff.shape), None if fe is None else tuple(fe.shape), None if guide is None else tuple(guide.shape), modal,
            tuple(dout.shape), dout.dtype, want, want_fe, want_guide, torch.cuda.current_stream(ff.device).cuda_stream)
     # what else the captured kernels read by ADDRESS: every parameter's storage and the cached device tables (pe / kpe / planes:
     # `_cache_gen` moves when one is reallocated -- T above the cached cap, a cleared cache, a device move).  A graph whose
@@ -302,32 +305,39 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
     if ent is not None and ent["sig"] != sig:
         cache.pop(key)
         ent = None
-    if ent is None:                                                # first sight: eager (also the warm-up a capture needs)
-        if len(cache) >= _MAX_BWD_GRAPHS:
-            cache.pop(next(iter(cache)))
-        gc = proj.global_compressor
-        # the entry keeps the buffers the graph will read alive: inputs and the cached tables (a recycled address must not pass
-        # for the tensor the graph was captured over)
-        cache[key] = {"seen": 1, "sig": sig, "refs": (ff, fe, guide, None if gc is None else dict(gc._pe_cache))}
+
+    def eager():
         with torch.no_grad():
             return _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl)
+
+    if ent is None:                                                # first sight of the shape: eager (also the warm-up a capture needs)
+        if len(cache) >= _MAX_BWD_GRAPHS:
+            cache.pop(next(iter(cache)))
+        cache[key] = {"seen": 1, "sig": sig}
+        return eager()
     if "graph" not in ent:
         if ent.get("failed"):
-            with torch.no_grad():
-                return _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl)
+            return eager()
         try:
-            static_dout = dout.detach().clone()
+            gc = proj.global_compressor
+            st = {"ff": ff.detach().clone(), "fe": None if fe is None else fe.detach().clone(),
+                  "guide": None if guide is None else guide.detach().clone(), "dout": dout.detach().clone(),
+                  "tables": None if gc is None else dict(gc._pe_cache)}       # (the cached tables the kernels read stay alive with the entry)
             torch.cuda.current_stream(ff.device).synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(g):
-                outs = _backward_outputs(static_dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl)
-            if engine.plan_sig(proj) != sig:                       # (the eager pass inside the capture reallocated a table)
+                outs = _backward_outputs(st["dout"], proj, st["ff"], st["fe"], st["guide"], modal, nl, names, want, want_fe, want_guide, want_nl)
+            if engine.plan_sig(proj) != sig:                       # (the pass inside the capture reallocated a table)
                 raise RuntimeError("cached device tables moved during capture")
-            ent.update(graph=g, dout=static_dout, outs=outs)
+            ent.update(graph=g, outs=outs, **st)
         except Exception as e:  # noqa: BLE001
             ent["failed"] = repr(e)
-            with torch.no_grad():
-                return _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl)
+            return eager()
+    ent["ff"].copy_(ff)
+    if fe is not None:
+        ent["fe"].copy_(fe)
+    if guide is not None:
+        ent["guide"].copy_(guide)
     ent["dout"].copy_(dout)
     ent["graph"].replay()
     flats, d_fe, d_guide, d_nl = ent["outs"]

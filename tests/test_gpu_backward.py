@@ -230,8 +230,9 @@ def test_graph_backward_equals_eager():
         fe.grad = g.grad = None
         return got
 
+    m.graph_backward = False
     want = step()                                         # eager reference
-    m.graph_backward = True
+    m.graph_backward = None                               # automatic (the default)
     runs = [step() for _ in range(4)]                     # eager (first sight), capture, replay, replay
     ent = next(iter(m.__dict__["_bwd_graphs"].values()))
     assert "graph" in ent, ent.get("failed")
@@ -245,4 +246,22 @@ def test_graph_backward_equals_eager():
     for n, p in m.named_parameters():
         if n in want:
             assert torch.equal(p.grad, want[n] * 2), n
+    m.zero_grad(set_to_none=True)
+    fe.grad = g.grad = None
+    # the captured kernels read STATIC copies: inputs at other addresses (fresh tensors, other values) replay the same graph correctly
+    ff2 = (ff.float() * 0.5).to(ff.dtype)
+    fe2 = (fe.detach().float() * -0.75).to(fe.dtype).requires_grad_(True)
+    g2 = (g.detach().float() * 1.25).to(g.dtype).requires_grad_(True)
+    m(ff2, fe2, g2, case.modal, None).backward(R)
+    got2 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    got2["__fe__"], got2["__g__"] = fe2.grad.clone(), g2.grad.clone()
+    m.zero_grad(set_to_none=True)
+    assert len(m.__dict__["_bwd_graphs"]) == 1                     # (same entry: keyed by shape, not by buffer)
     m.graph_backward = False
+    fe2.grad = g2.grad = None
+    m(ff2, fe2, g2, case.modal, None).backward(R)
+    for n, p in m.named_parameters():
+        if n in got2:
+            assert torch.equal(p.grad, got2[n]), n
+    assert torch.equal(fe2.grad, got2["__fe__"]) and torch.equal(g2.grad, got2["__g__"])
+    m.graph_backward = None

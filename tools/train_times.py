@@ -32,4 +32,6 @@ for name in which:
         m(ff, fe_, g_, "video", None).backward(cot)
     tr = best(step, n=3)
     tri = best(lambda: step(True), n=3) if guide in ("direct", "coarse", "fine") else float("nan")
+    for e in m.__dict__.get("_bwd_graphs", {}).values():
+        print("   backward graph:", "captured" if "graph" in e else ("FAILED " + str(e.get("failed"))[:300]))
     print(f"{name}: forward {fwd * 1e3:.0f} us, train step {tr:.2f} ms, with input grads {tri:.2f} ms")
