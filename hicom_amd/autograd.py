@@ -486,7 +486,7 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         # (guide off, reference stage 1: IdentityMap injector, :586-587)
         q_in, n_rows = gc.injected_queries(guide)
         nq = q_in.shape[0]
-        ml, acc, scores = gc.partial_context(ff, q_in)                     # HIP: forward logits + softmax state, rows q*nh + h
+        ml, acc, scores = gc.partial_context(ff, q_in, need_scores=True)                     # HIP: forward logits + softmax state, rows q*nh + h
         R = ml.shape[0]
         ctxg = (acc / ml[:, 1:2]).view(nq, nh, E)                          # per-(query, head) contexts
         q32 = q_in.float()

@@ -36,6 +36,7 @@ struct WsLayout {
         ctx_g, o, qres, pre, hid_g, tok, po, o_fix, r0, total;
     int nw, R, rows_pad, nparts, P;
     long N, score_stride;
+    bool marg;      // generic global path: the stream kernel keeps the positional marginals itself (no logit tensor; `scores` holds them)
 };
 
 // The fused local+global stream kernel applies to the release recipe: shared bf16 local query
@@ -74,7 +75,8 @@ WsLayout make_layout(const hicom_compressor_args& a) {
     w.rows_pad = (w.R + 15) / 16 * 16;
     w.P = a.P;
     w.score_stride = (w.N + 15) / 16 * 16;
-    w.nparts = !a.has_global ? 0 : (can_fuse(a) ? hicom_fused_stream_nparts(w.nw) : hicom_global_stream_nparts(w.N, w.rows_pad));
+    const bool fuse = a.has_global && can_fuse(a);
+    w.nparts = !a.has_global ? 0 : (fuse ? hicom_fused_stream_nparts(w.nw) : hicom_global_stream_nparts(w.N, w.rows_pad));
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align256(off + bytes); return o; };
     // zero-initialised-once region first (padding rows that no kernel ever writes)
@@ -100,7 +102,14 @@ WsLayout make_layout(const hicom_compressor_args& a) {
     }
     if (a.has_global) {
         w.qp = take((size_t)a.nq * a.E * 4);
-        w.scores = take((size_t)w.rows_pad * w.score_stride * 4);
+        // (sized for the logit tensor also when the stream kernel keeps the positional marginals itself and writes its small
+        // part_marg here instead: the layout must not depend on the HICOM_GLOBAL_NARROW test switch, which a cached plan may outlive)
+        w.marg = !fuse && a.pe && hicom_global_stream_has_marg(w.N, a.E, w.rows_pad, a.H, a.W, w.nparts) == 1;
+        {
+            const size_t sb = (size_t)w.rows_pad * w.score_stride * 4;
+            const size_t mb = a.pe && a.H > 0 && a.W > 0 ? (size_t)w.nparts * w.rows_pad * hicom_global_stream_marg_width(a.H, a.W) * 4 : 0;
+            w.scores = take(sb > mb ? sb : mb);
+        }
         w.part_m = take((size_t)w.nparts * w.rows_pad * 4);
         w.part_l = take((size_t)w.nparts * w.rows_pad * 4);
         w.part_acc = take((size_t)w.nparts * w.rows_pad * a.E * 4);
@@ -245,6 +254,10 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                                           F(w.pos_a), a.P, with_local_rows ? a.lq : nullptr, w.R, 16 - w.R, st);
     };
     auto merge = [&](hipStream_t st) -> int {
+        if (w.marg)
+            return hicom_global_merge_marg_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), F(w.scores), w.nparts, w.R, w.rows_pad, a.E, w.N,
+                                               a.H, a.W, a.pe, a.t_index0, a.y_index0, a.x_index0, F(w.scratch), ml_out, acc_out,
+                                               solo ? 1 : 0, st);
         return hicom_global_merge_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E,
                                       F(w.scores), w.score_stride, w.N, a.H, a.W, a.pe, a.t_index0, a.y_index0,
                                       a.x_index0, F(w.scratch), ml_out, acc_out, solo ? 1 : 0, st);
@@ -416,9 +429,14 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         }
         if (a.has_global) {
             if (!a.reuse_queries) CHK(query_prep(sg, false));        // (guide off: weight-only, kept in the workspace across calls)
-            CHK(hicom_global_stream_fwd(a.ff, w.N, a.E, ws + w.qhi, ws + w.qlo, w.R, w.rows_pad,
-                                        a.pe ? F(w.pos_a) : nullptr, a.P, a.H, a.W, a.t_index0, a.y_index0, a.x_index0,
-                                        F(w.scores), w.score_stride, F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, sg));
+            if (w.marg)
+                CHK(hicom_global_stream_marg_fwd(a.ff, w.N, a.E, ws + w.qhi, ws + w.qlo, w.R, w.rows_pad, F(w.pos_a), a.P, a.H, a.W,
+                                                 a.t_index0, a.y_index0, a.x_index0, nullptr, 0, F(w.part_m), F(w.part_l), F(w.part_acc),
+                                                 F(w.scores), w.nparts, sg));
+            else
+                CHK(hicom_global_stream_fwd(a.ff, w.N, a.E, ws + w.qhi, ws + w.qlo, w.R, w.rows_pad,
+                                            a.pe ? F(w.pos_a) : nullptr, a.P, a.H, a.W, a.t_index0, a.y_index0, a.x_index0,
+                                            F(w.scores), w.score_stride, F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, sg));
             CHK(merge(sg));
         }
         if (a.has_local) CHK(local_readout(sm));

@@ -51,6 +51,11 @@ struct StreamParams {
     // clip-scale variant (forward): logit = (qt . x + pos + row_const[r]) * inv_norm[n]
     const float* inv_norm; // [N] or NULL
     const float* row_const;// [rows_pad] or NULL
+    // wide forward only: un-normalised positional marginals of the softmax weights of each token chunk, relative to the chunk's
+    // running max like part_acc: [nparts][rows_pad][marg_stride] = [kWideFrames frames from the chunk's first | pad to 16 |
+    // H grid rows | pad to 16 | W grid columns | pad to 16], or NULL (then `scores` must be given: the marginals are taken from it)
+    float* part_marg;
+    int marg_stride;
 };
 
 // bit rotation of the row index used as the 16-byte-chunk swizzle (bijective on 0..15)
@@ -299,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
 
 constexpr int kWideRG = 2;
 constexpr int kWideFrames = 8;      // frames a workgroup's token range may touch
+constexpr int kWideMargBlocks = 2;  // 16-column marginal blocks per wave (x 4 waves of a row group)
 
 // ---------------------------------------------------------------------------------------------
 // Wide form for many query rows (guide off / coarse / fine: 32 queries x 9 heads = 288 folded rows).  The narrow kernel above gives
@@ -378,6 +384,24 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
 #pragma unroll
     for (int cb = 0; cb < CBLK; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -1.0e30f, l_run = 0.f;
+
+    // positional marginals in the kernel (part_marg given): P[16 rows x 16 tokens] . onehot[16 tokens x 16 columns] on the matrix
+    // pipe, one MFMA per 16-column block of [frame | grid row | grid column]; the blocks are dealt to the 4 waves of the row group
+    // (wave w: blocks w, w + 4; <= 8 blocks: hicom_global_stream_has_marg).  The one-hot B operand is four compares on the token
+    // coordinates the lane already holds for the score-side lookups (same token <-> k-slot map as P).
+    constexpr int MBW = kWideMargBlocks;
+    const bool marg_on = p.part_marg != nullptr;
+    const int nby = (p.H + 15) >> 4, nbx = (p.W + 15) >> 4, nmb = marg_on ? 1 + nby + nbx : 0;
+    int mb_sh[MBW], mb_base[MBW];
+#pragma unroll
+    for (int u = 0; u < MBW; ++u) {
+        const int b = wave + 4 * u;
+        mb_sh[u] = b == 0 ? 16 : (b <= nby ? 8 : 0);
+        mb_base[u] = b == 0 ? 0 : (b <= nby ? 16 * (b - 1) : 16 * (b - 1 - nby));       // (wave-uniform: scalar registers)
+    }
+    f32x4 macc[MBW];
+#pragma unroll
+    for (int u = 0; u < MBW; ++u) macc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto stage = [&](int tile, int buf) {
         if (grp != 0) return;                            // waves 0-3 own the vector-memory requests
@@ -465,16 +489,17 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
         lg += *reinterpret_cast<const f32x4*>(rb + 256);
         lg += *reinterpret_cast<const f32x4*>(rb + 512);
         lg += *reinterpret_cast<const f32x4*>(rb + 768);
+        int tp[4] = {0, 0, 0, 0};
         if (p.pos_a) {
             int4 v;
             asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(tokpos_lds + 64 * h + 16 * sig(kg)) : "memory");
-            const int tp[4] = {v.x, v.y, v.z, v.w};
+            tp[0] = v.x; tp[1] = v.y; tp[2] = v.z; tp[3] = v.w;
             const float* pr_ = postab + (grp * 16 + r16) * S;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 lg[j] += pr_[tp[j] >> 16] + pr_[kWideFrames + ((tp[j] >> 8) & 255)] + pr_[kWideFrames + p.H + (tp[j] & 255)];
         }
-        if (wave == 0) *reinterpret_cast<f32x4*>(p.scores + row_glob * p.score_stride + n0) = lg;
+        if (wave == 0 && p.scores) *reinterpret_cast<f32x4*>(p.scores + row_glob * p.score_stride + n0) = lg;
 
         float tmax = -1.0e30f;
 #pragma unroll
@@ -504,6 +529,24 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
 #pragma unroll
             for (int cb = 0; cb < CBLK; ++cb) {
                 acc[cb][0] *= a0; acc[cb][1] *= a1; acc[cb][2] *= a2; acc[cb][3] *= a3;
+            }
+#pragma unroll
+            for (int u = 0; u < MBW; ++u) {
+                macc[u][0] *= a0; macc[u][1] *= a1; macc[u][2] *= a2; macc[u][3] *= a3;
+            }
+        }
+        // ---- positional marginals of this tile (this wave's column blocks) ----
+#pragma unroll
+        for (int u = 0; u < MBW; ++u) {
+            if (wave + 4 * u < nmb) {
+                bf16x8 oh;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const short one = (((tp[j] >> mb_sh[u]) & 255) - mb_base[u] == r16) ? (short)0x3F80 : (short)0;
+                    oh[j] = one;
+                    oh[4 + j] = one;
+                }
+                macc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pw, oh, macc[u], 0, 0, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -546,6 +589,15 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
         for (int j = 0; j < 4; ++j)
             if (rg * 16 + 4 * kg + j < p.rows) o[(long)j * E] = acc[cb][j];
     }
+#pragma unroll
+    for (int u = 0; u < MBW; ++u) {
+        if (wave + 4 * u < nmb) {
+            float* o = p.part_marg + (prow + 4 * kg) * p.marg_stride + 16 * (wave + 4 * u) + r16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (rg * 16 + 4 * kg + j < p.rows) o[(long)j * p.marg_stride] = macc[u][j];
+        }
+    }
 }
 
 static int g_num_cus = 0;
@@ -577,20 +629,44 @@ extern "C" int hicom_global_stream_nparts(int64_t N, int32_t rows_pad) {
     return (int)(want < cap ? want : cap);
 }
 
+extern "C" int hicom_global_stream_marg_width(int32_t H, int32_t W) {
+    if (H <= 0 || W <= 0) return HICOM_EINVAL;
+    return 16 * (1 + (H + 15) / 16 + (W + 15) / 16);
+}
+
+static bool wide_ok(int64_t N, int32_t E, int32_t rows_pad, int32_t H, int32_t W, int32_t nparts) {
+    const bool pos = H > 0 && W > 0;
+    const long ntiles = (N + 15) / 16, HW = pos ? (long)H * W : 1;
+    const long tiles_per_part = (ntiles + nparts - 1) / nparts + 1;
+    const bool span_ok = !pos || (tiles_per_part * 16 + HW - 1) / HW + 1 <= kWideFrames;
+    return E == 1152 && rows_pad > 16 && rows_pad % (16 * kWideRG) == 0 && (!pos || (H <= 64 && W <= 64)) && span_ok;
+}
+
+// 1 when hicom_global_stream_marg_fwd applies to this shape: the many-row form of the kernel (the only one with in-kernel
+// positional marginals) and a grid whose [frames | rows | columns] fit its 8 marginal blocks of 16 columns
+extern "C" int hicom_global_stream_has_marg(int64_t N, int32_t E, int32_t rows_pad, int32_t H, int32_t W, int32_t nparts) {
+    if (N <= 0 || nparts <= 0 || rows_pad <= 0 || H <= 0 || W <= 0) return HICOM_EINVAL;
+    const char* force_narrow = getenv("HICOM_GLOBAL_NARROW");      // dev / test switch: always take the one-row-group kernel
+    if (force_narrow && force_narrow[0] == '1') return 0;
+    const char* no_marg = getenv("HICOM_GLOBAL_NO_MARG");          // dev / A-B switch: logit tensor + marginal pass (the round-3 path)
+    if (no_marg && no_marg[0] == '1') return 0;
+    return (wide_ok(N, E, rows_pad, H, W, nparts) && 1 + (H + 15) / 16 + (W + 15) / 16 <= 4 * kWideMargBlocks) ? 1 : 0;
+}
+
 static int global_stream_launch(const void* x, int64_t N, int32_t E,
                                        const void* qt_hi, const void* qt_lo, int32_t rows, int32_t rows_pad,
                                        const float* pos_a, int32_t pos_stride,
                                        int32_t H, int32_t W, int32_t t_index0, int32_t y_index0, int32_t x_index0,
                                        float* scores, int64_t score_stride,
                                        float* part_m, float* part_l, float* part_acc, int32_t nparts,
-                                       const float* inv_norm, const float* row_const, void* stream) {
-    HICOM_REQUIRE(x && qt_hi && qt_lo && scores && part_m && part_l && part_acc, HICOM_EINVAL, "global_stream: NULL pointer");
+                                       const float* inv_norm, const float* row_const, float* part_marg, void* stream) {
+    HICOM_REQUIRE(x && qt_hi && qt_lo && (scores || part_marg) && part_m && part_l && part_acc, HICOM_EINVAL, "global_stream: NULL pointer");
     HICOM_REQUIRE(E == 1152 || E == 768, HICOM_EUNSUP, "global_stream: E=%d (only 1152 / 768)", E);
     HICOM_REQUIRE(N > 0 && N < (1L << 31), HICOM_EINVAL, "global_stream: N out of range");
     HICOM_REQUIRE(rows_pad > 0 && rows_pad % 16 == 0 && rows > 0 && rows <= rows_pad, HICOM_EINVAL,
                   "global_stream: rows_pad must be a multiple of 16 and 0 < rows <= rows_pad");
     HICOM_REQUIRE(nparts > 0, HICOM_EINVAL, "global_stream: nparts");
-    HICOM_REQUIRE(score_stride >= ((N + 15) / 16) * 16 && score_stride % 4 == 0, HICOM_EINVAL,
+    HICOM_REQUIRE(!scores || (score_stride >= ((N + 15) / 16) * 16 && score_stride % 4 == 0), HICOM_EINVAL,
                   "global_stream: score_stride must be >= roundup(N,16)");
     HICOM_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)qt_hi % 16 == 0) && ((uintptr_t)qt_lo % 16 == 0) &&
                       ((uintptr_t)scores % 16 == 0),
@@ -605,13 +681,17 @@ static int global_stream_launch(const void* x, int64_t N, int32_t E,
     p.ntiles = (int)((N + 15) / 16);
     p.s_in = nullptr; p.ml = nullptr; p.delta = nullptr;
     p.inv_norm = inv_norm; p.row_const = row_const;
+    p.part_marg = pos_a ? part_marg : nullptr;
+    p.marg_stride = pos_a ? hicom_global_stream_marg_width(H, W) : 0;
     dim3 grid((unsigned)nparts, (unsigned)(rows_pad / 16));
     hipStream_t s = (hipStream_t)stream;
     // many rows: the wide form (two row groups per workgroup, three-deep ring) when its limits hold
-    const long tiles_per_part = (p.ntiles + nparts - 1) / nparts + 1;
-    const bool span_ok = !pos_a || (tiles_per_part * 16 + p.HW - 1) / p.HW + 1 <= kWideFrames;
     const char* force_narrow = getenv("HICOM_GLOBAL_NARROW");      // dev / test switch: always take the one-row-group kernel
-    if (!inv_norm && !(force_narrow && force_narrow[0] == '1') && E == 1152 && rows_pad > 16 && rows_pad % (16 * kWideRG) == 0 && (!pos_a || (H <= 64 && W <= 64)) && span_ok) {
+    const bool wide = !inv_norm && !(force_narrow && force_narrow[0] == '1') && wide_ok(N, E, rows_pad, pos_a ? H : 0, pos_a ? W : 0, nparts);
+    HICOM_REQUIRE(!part_marg || (wide && hicom_global_stream_has_marg(N, E, rows_pad, H, W, nparts) == 1), HICOM_EUNSUP,
+                  "global_stream: no in-kernel marginals for this shape (hicom_global_stream_has_marg)");
+    HICOM_REQUIRE(scores || part_marg, HICOM_EINVAL, "global_stream: scores is NULL");
+    if (wide) {
         const int S = kWideFrames + (pos_a ? H + W : 0);
         const size_t smem = (size_t)3 * 9 * 4096 + 2 * (size_t)kWideRG * 4 * 1024 + 128 + (size_t)kWideRG * 16 * S * 4;
         static bool wide_attr = false;
@@ -647,7 +727,22 @@ extern "C" int hicom_global_stream_fwd(const void* x, int64_t N, int32_t E,
                                        float* part_m, float* part_l, float* part_acc, int32_t nparts,
                                        void* stream) {
     return global_stream_launch(x, N, E, qt_hi, qt_lo, rows, rows_pad, pos_a, pos_stride, H, W, t_index0, y_index0, x_index0, scores,
-                                score_stride, part_m, part_l, part_acc, nparts, nullptr, nullptr, stream);
+                                score_stride, part_m, part_l, part_acc, nparts, nullptr, nullptr, nullptr, stream);
+}
+
+// Same stream, positional marginals of the softmax weights accumulated IN the kernel (part_marg: f32 [nparts][rows_pad]
+// [hicom_global_stream_marg_width(H, W)], merged by hicom_global_merge_marg_fwd): `scores` may be NULL -- the [rows_pad, N] logit
+// tensor (54 MB at 288 rows x 64 frames) is then neither written nor read back.  Wide form only (hicom_global_stream_has_marg).
+extern "C" int hicom_global_stream_marg_fwd(const void* x, int64_t N, int32_t E,
+                                            const void* qt_hi, const void* qt_lo, int32_t rows, int32_t rows_pad,
+                                            const float* pos_a, int32_t pos_stride,
+                                            int32_t H, int32_t W, int32_t t_index0, int32_t y_index0, int32_t x_index0,
+                                            float* scores, int64_t score_stride,
+                                            float* part_m, float* part_l, float* part_acc, float* part_marg, int32_t nparts,
+                                            void* stream) {
+    HICOM_REQUIRE(pos_a && part_marg, HICOM_EINVAL, "global_stream_marg: pos_a and part_marg are required");
+    return global_stream_launch(x, N, E, qt_hi, qt_lo, rows, rows_pad, pos_a, pos_stride, H, W, t_index0, y_index0, x_index0, scores,
+                                score_stride, part_m, part_l, part_acc, nparts, nullptr, nullptr, part_marg, stream);
 }
 
 extern "C" int hicom_global_stream_clip_fwd(const void* x, int64_t N, int32_t E,
@@ -659,7 +754,7 @@ extern "C" int hicom_global_stream_clip_fwd(const void* x, int64_t N, int32_t E,
                                             float* part_m, float* part_l, float* part_acc, int32_t nparts, void* stream) {
     HICOM_REQUIRE(inv_norm && row_const, HICOM_EINVAL, "global_stream_clip: NULL pointer");
     return global_stream_launch(x, N, E, qt_hi, qt_lo, rows, rows_pad, pos_a, pos_stride, H, W, t_index0, y_index0, x_index0, scores,
-                                score_stride, part_m, part_l, part_acc, nparts, inv_norm, row_const, stream);
+                                score_stride, part_m, part_l, part_acc, nparts, inv_norm, row_const, nullptr, stream);
 }
 
 // ---- attention backward over the stream (training path) --------------------------------------------
@@ -687,7 +782,7 @@ extern "C" int hicom_global_stream_bwd(const void* x, int64_t N, int32_t E, cons
     p.scores = ds_out; p.score_stride = score_stride;
     p.part_m = nullptr; p.part_l = nullptr; p.part_acc = part_acc; p.rows_pad = rows_pad; p.rows = rows;
     p.ntiles = (int)((N + 15) / 16);
-    p.s_in = s_in; p.ml = ml; p.delta = delta; p.inv_norm = nullptr; p.row_const = nullptr;
+    p.s_in = s_in; p.ml = ml; p.delta = delta; p.inv_norm = nullptr; p.row_const = nullptr; p.part_marg = nullptr; p.marg_stride = 0;
     dim3 grid((unsigned)nparts, (unsigned)(rows_pad / 16));
     hipStream_t s = (hipStream_t)stream;
     if (E == 1152) {

@@ -322,6 +322,67 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
     }
 }
 
+// Row weights from the marginals the wide stream kernel accumulated itself (hicom_global_stream_marg_fwd): grid = rows.  Leaves
+// the record merge_ctx_kernel<2> applies -- [M, L | nparts partial weights | T + H + W positional weights] -- at the head of the
+// row's scratch region.  part_marg[i][r] holds chunk i's marginals relative to the chunk's own max m_i, like part_acc: the
+// weight e^(m_i - M) of the partial contexts applies to them too; its frame block starts at the chunk's first frame.
+__global__ __launch_bounds__(256) void merge_marg_weights_kernel(MergeCtxParams p, const float* part_marg, int MS, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int S = p.H + p.W + 2, HW2 = p.H + p.W;
+    float* red = wsm;
+    float* wp = red + 4;
+    int* ff = reinterpret_cast<int*>(wp + p.nparts);       // first frame of each chunk
+    float mx = -1.0e30f;
+    for (int i = tid; i < p.nparts; i += 256) mx = fmaxf(mx, p.part_m[(long)i * p.rows_pad + r]);
+    const float M = block_reduce_max(mx, red);
+    float l = 0.f;
+    for (int i = tid; i < p.nparts; i += 256) {
+        const float w = expf(p.part_m[(long)i * p.rows_pad + r] - M);
+        wp[i] = w;
+        l += w * p.part_l[(long)i * p.rows_pad + r];
+        const int tb = (int)(((long)ntiles * i) / p.nparts);
+        ff[i] = (int)((unsigned)(tb * 16) / (unsigned)(p.H * p.W));
+    }
+    const float L = block_reduce_sum(l, red);
+    __syncthreads();
+    float* wrow = const_cast<float*>(p.scratch) + (long)r * p.T * S;
+    const float* mg = part_marg + (long)r * MS;
+    const long mstride = (long)p.rows_pad * MS;
+    const int ybase = 16, xbase = 16 + 16 * ((p.H + 15) >> 4);
+    // two threads per output (even / odd chunks), loads of 8 chunks in flight together (the frame block only counts where the
+    // chunk covers the frame: clamped column, zero weight elsewhere -- no branch around the load)
+    for (int j2 = tid; j2 < 2 * (p.T + HW2); j2 += 256) {
+        const int j = j2 >> 1, par = j2 & 1;
+        const bool fr = j < p.T;
+        const int col = fr ? 0 : (j < p.T + p.H ? ybase + (j - p.T) : xbase + (j - p.T - p.H));
+        float a = 0.f;
+        for (int i0 = par; i0 < p.nparts; i0 += 16) {
+            float v[8], wgt[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 2 * u;
+                const int ic = i < p.nparts ? i : p.nparts - 1;
+                const int c = fr ? j - ff[ic] : col;
+                const bool ok = i < p.nparts && (!fr || (c >= 0 && c < 8));
+                v[u] = mg[ic * mstride + (ok ? c : 0)];
+                wgt[u] = ok ? wp[ic] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a = fmaf(wgt[u], v[u], a);
+        }
+        a += __shfl_xor(a, 1, 64);
+        if (par == 0) wrow[2 + p.nparts + j] = a;
+    }
+    for (int i = tid; i < p.nparts; i += 256) wrow[2 + i] = wp[i];
+    if (tid == 0) {
+        wrow[0] = M;
+        wrow[1] = L;
+        p.out_ml[2 * r] = M;
+        p.out_ml[2 * r + 1] = L;
+    }
+}
+
 __global__ __launch_bounds__(256) void combine_kernel(const float* ml, const float* acc, long ml_stride, long acc_stride,
                                                       int nsets, int rows, int E, float* ctx) {
     const int r = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
@@ -575,6 +636,29 @@ extern "C" int hicom_global_merge_fwd(const float* part_m, const float* part_l, 
         HICOM_LAUNCH(merge_ctx_kernel<0>, dim3((unsigned)rows, (unsigned)((E + 31) / 32)), dim3(256), smem2, s, p);
     }
     return hicom_host::check_launch("global_merge");
+}
+
+// Merge behind hicom_global_stream_marg_fwd: no logit tensor, no per-frame marginal pass.  scratch: f32, >= rows * T * (H + W + 2)
+// (the size hicom_global_merge_fwd asks for; only the head of each row's region is used).
+extern "C" int hicom_global_merge_marg_fwd(const float* part_m, const float* part_l, const float* part_acc, const float* part_marg,
+                                           int32_t nparts, int32_t rows, int32_t rows_pad, int32_t E, int64_t N,
+                                           int32_t H, int32_t W, const float* pe,
+                                           int32_t t_index0, int32_t y_index0, int32_t x_index0,
+                                           float* scratch, float* out_ml, float* out_acc, int32_t normalize, void* stream) {
+    HICOM_REQUIRE(part_m && part_l && part_acc && part_marg && pe && scratch && out_ml && out_acc, HICOM_EINVAL, "global_merge_marg: NULL pointer");
+    HICOM_REQUIRE(nparts > 0 && rows > 0 && rows <= rows_pad && E > 0 && E % 4 == 0 && H > 0 && W > 0 && H <= 64 && W <= 64 && N > 0 &&
+                      N % ((long)H * W) == 0, HICOM_EINVAL, "global_merge_marg: bad shape");
+    const int T = (int)(N / ((long)H * W));
+    HICOM_REQUIRE((long)2 + nparts + T + H + W <= (long)T * (H + W + 2), HICOM_EUNSUP, "global_merge_marg: weight record exceeds the row's scratch region");
+    hipStream_t s = (hipStream_t)stream;
+    MergeCtxParams p{part_m, part_l, part_acc, nparts, rows_pad, E, scratch, pe, T, H, W, t_index0, y_index0, x_index0, out_ml, out_acc, normalize};
+    const size_t smem1 = ((size_t)2 * nparts + 8) * 4;
+    const size_t smem2 = ((size_t)nparts + (size_t)2 * T + H + W + (size_t)kTC * (H + W + 2) + 16 * 64 + 4) * 4;
+    HICOM_REQUIRE(smem2 <= 60000, HICOM_EUNSUP, "global_merge_marg: too many partials/frames for one pass");
+    HICOM_LAUNCH(merge_marg_weights_kernel, dim3((unsigned)rows), dim3(256), smem1, s, p, part_marg, hicom_global_stream_marg_width(H, W),
+                 (int)((N + 15) / 16));
+    HICOM_LAUNCH(merge_ctx_kernel<2>, dim3((unsigned)rows, (unsigned)((E + 31) / 32)), dim3(256), smem2, s, p);
+    return hicom_host::check_launch("global_merge_marg");
 }
 
 extern "C" int hicom_global_combine_fwd(const float* ml, const float* acc, int32_t nsets, int32_t rows,

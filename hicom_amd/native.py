@@ -15,7 +15,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 # HICOM_NATIVE_LIB: dev override (instrumented builds from tools/); the product loads the in-tree library
 LIB_PATH = os.environ.get("HICOM_NATIVE_LIB") or os.path.join(HERE, "libhicom_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 DT_BF16, DT_F32, DT_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_GELU_TANH = 0, 1, 2
@@ -34,6 +34,7 @@ EXPORTS = (
     "hicom_query_prep_fwd", "hicom_query_prep_state_bytes", "hicom_partials_sum_fwd", "hicom_l2norm_stream_fwd", "hicom_local_attn_adapt_fwd",
     "hicom_small_mha_scaled_fwd", "hicom_merge_vproj_fixed_fwd", "hicom_dense16_tn_fwd", "hicom_dense16_tn_splits",
     "hicom_local_attn_adapt_bwd", "hicom_adapt_dy_fwd", "hicom_gelu_split_fwd", "hicom_gelu_bwd_fwd", "hicom_colsum_fwd",
+    "hicom_global_stream_marg_fwd", "hicom_global_stream_marg_width", "hicom_global_stream_has_marg", "hicom_global_merge_marg_fwd",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -124,6 +125,11 @@ def lib() -> C.CDLL:
     L.hicom_global_stream_fwd.argtypes = [vp, i64, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i64,
                                           vp, vp, vp, i32, vp]
     L.hicom_global_stream_nparts.argtypes = [i64, i32]
+    L.hicom_global_stream_marg_fwd.argtypes = [vp, i64, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i64,
+                                               vp, vp, vp, vp, i32, vp]
+    L.hicom_global_stream_marg_width.argtypes = [i32, i32]
+    L.hicom_global_stream_has_marg.argtypes = [i64, i32, i32, i32, i32, i32]
+    L.hicom_global_merge_marg_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, i32, vp, i32, i32, i32, vp, vp, vp, i32, vp]
     L.hicom_global_stream_bwd.argtypes = [vp, i64, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp, vp,
                                           vp, vp, i32, vp]
     L.hicom_global_merge_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, i64, i64, i32, i32, vp, i32, i32, i32,
@@ -323,6 +329,34 @@ def global_stream(x, N, qhi, qlo, pos_a, H, W, t0i, y0i, x0i, scores, part_m, pa
                                          pos_a.shape[1] if pos_a is not None else 0, H, W, t0i, y0i, x0i,
                                          _ptr(scores), scores.shape[1], _ptr(part_m), _ptr(part_l), _ptr(part_acc),
                                          nparts, _stream()), "hicom_global_stream_fwd")
+
+
+def global_stream_has_marg(N, E, rows_pad, H, W, nparts) -> bool:
+    """True when the stream kernel can accumulate the positional marginals itself for this shape (global_stream_marg)."""
+    return lib().hicom_global_stream_has_marg(N, E, rows_pad, H, W, nparts) == 1
+
+
+def global_stream_marg_width(H, W) -> int:
+    return lib().hicom_global_stream_marg_width(H, W)
+
+
+def global_stream_marg(x, N, qhi, qlo, pos_a, H, W, t0i, y0i, x0i, scores, part_m, part_l, part_acc, part_marg, rows=None):
+    """hicom_global_stream_marg_fwd: positional marginals in the kernel; scores may be None (no logit tensor)."""
+    E = x.shape[-1]
+    rows_pad = qhi.shape[0]
+    rows = rows_pad if rows is None else rows
+    _check(lib().hicom_global_stream_marg_fwd(_ptr(x), N, E, _ptr(qhi), _ptr(qlo), rows, rows_pad, _ptr(pos_a), pos_a.shape[1],
+                                              H, W, t0i, y0i, x0i, _ptr(scores), scores.shape[1] if scores is not None else 0,
+                                              _ptr(part_m), _ptr(part_l), _ptr(part_acc), _ptr(part_marg), part_m.shape[0],
+                                              _stream()), "hicom_global_stream_marg_fwd")
+
+
+def global_merge_marg(part_m, part_l, part_acc, part_marg, rows, N, H, W, pe, t0i, y0i, x0i, scratch, out_ml, out_acc,
+                      normalize=False):
+    nparts, rows_pad = part_m.shape
+    _check(lib().hicom_global_merge_marg_fwd(_ptr(part_m), _ptr(part_l), _ptr(part_acc), _ptr(part_marg), nparts, rows, rows_pad,
+                                             part_acc.shape[-1], N, H, W, _ptr(pe), t0i, y0i, x0i, _ptr(scratch), _ptr(out_ml),
+                                             _ptr(out_acc), int(normalize), _stream()), "hicom_global_merge_marg_fwd")
 
 
 def global_stream_bwd(x, N, dhi, dlo, pos_b, H, W, t0i, y0i, x0i, s_in, ml, delta, ds_out, part_acc, rows):

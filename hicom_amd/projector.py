@@ -183,7 +183,7 @@ def _linear_params(lin: nn.Linear):
     return lin.weight.detach(), (lin.bias.detach() if lin.bias is not None else None)
 
 
-def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i, clip=None, kpe_t=None, kpe=None):
+def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i, clip=None, kpe_t=None, kpe=None, need_scores=False):
     """Streams the tokens x2 [N, E] (bf16) once against the folded queries of q_in [nq, E]: returns the un-normalised
     online-softmax state (ml [R,2], acc [R,E]), R = nq * heads (ref :180-215 restated).
 
@@ -191,7 +191,10 @@ def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i, clip=None, kpe_t=N
     full projected width before the heads are split, so  logit_h(n) = e^ls (qhat_h . k_h(n)) / ||k(n)|| + logit_bias
     (the bias is a per-row shift: softmax cancels it).  k(n) = W_k (x_n + pos_n) + b_k never exists in memory: its norm
     comes from a dense MFMA GEMM with a row-sum-of-squares epilogue (hicom_dense16_gemm_fwd, the positional part as
-    three rows of kpe_t = PE . W_k^T per token), the numerator from the usual folded queries."""
+    three rows of kpe_t = PE . W_k^T per token), the numerator from the usual folded queries.
+
+    need_scores: also return the raw logits [rows_pad, N] (the backward pass reads them); without it the many-row form of the
+    kernel keeps the positional marginals itself and the logit tensor is never written (third result None)."""
     E, nh = att.embed_dim, att.num_heads
     _require_bf16_cuda("key / value tokens", x2)
     N, dev = x2.shape[0], x2.device
@@ -236,16 +239,22 @@ def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i, clip=None, kpe_t=N
         H, W = 1, N                                             # any factorisation of N: no positional terms
     nparts = nv.global_stream_nparts(N, rows_pad)
     stride = (N + 15) // 16 * 16
-    scores = _f32((rows_pad, stride), dev)
     part_m, part_l = _f32((nparts, rows_pad), dev), _f32((nparts, rows_pad), dev)
     part_acc = _f32((nparts, rows_pad, E), dev)
+    ml, acc = _f32((R, 2), dev), _f32((R, E), dev)
+    T = N // (H * W)
+    scratch = _f32((R * T * (H + W + 2),), dev) if pe is not None else None
+    in_kernel = inv is None and pe is not None and nv.global_stream_has_marg(N, E, rows_pad, H, W, nparts)
+    scores = _f32((rows_pad, stride), dev) if need_scores or not in_kernel else None
+    if in_kernel:
+        part_marg = _f32((nparts, rows_pad, nv.global_stream_marg_width(H, W)), dev)
+        nv.global_stream_marg(x2, N, qhi, qlo, pos_a, H, W, t0i, y0i, x0i, scores, part_m, part_l, part_acc, part_marg, rows=R)
+        nv.global_merge_marg(part_m, part_l, part_acc, part_marg, R, N, H, W, pe, t0i, y0i, x0i, scratch, ml, acc)
+        return ml, acc, scores
     if inv is not None:
         nv.global_stream_clip(x2, N, qhi, qlo, pos_a, H, W, t0i, y0i, x0i, inv, row_const, scores, part_m, part_l, part_acc, R)
     else:
         nv.global_stream(x2, N, qhi, qlo, pos_a, H, W, t0i, y0i, x0i, scores, part_m, part_l, part_acc, rows=R)
-    ml, acc = _f32((R, 2), dev), _f32((R, E), dev)
-    T = N // (H * W)
-    scratch = _f32((R * T * (H + W + 2),), dev) if pe is not None else None
     nv.global_merge(part_m, part_l, part_acc, R, scores, N, H, W, pe, t0i, y0i, x0i, scratch, ml, acc)
     return ml, acc, scores
 
@@ -587,9 +596,10 @@ class GlobalCompressor(nn.Module):
             self._pe_cache[key] = hit
         return hit[0]
 
-    def partial_context(self, frames_feature, q_in, t_offset: int = 0, logit_scale=None):
-        """Streams this call's frames once: returns (ml [R,2], acc [R,E], raw logits [rows_pad, N']) -- the un-normalised
-        online-softmax state for R = nq_eff * num_heads folded query rows (ref :180-215 restated)."""
+    def partial_context(self, frames_feature, q_in, t_offset: int = 0, logit_scale=None, need_scores: bool = False):
+        """Streams this call's frames once: returns (ml [R,2], acc [R,E], raw logits [rows_pad, N'] or None) -- the un-normalised
+        online-softmax state for R = nq_eff * num_heads folded query rows (ref :180-215 restated).  The logits are
+        only guaranteed with need_scores (the backward pass): the many-row kernel does not write them otherwise."""
         ff = frames_feature.contiguous()
         _require_bf16_cuda("frames_feature", ff)
         T, H, W, E = ff.shape
@@ -603,7 +613,7 @@ class GlobalCompressor(nn.Module):
         if logit_scale is not None:
             clip = float(logit_scale)
             kpe_t = self.pos_kpe_t(t_offset + T, H, W, ff.device) if self.use_pos_emb else None
-        return _stream_attention(self.attn_layer, ff.view(T * H * W, E), q_in, pe, H, W, t0i, y0i, x0i, clip, kpe_t, kpe)
+        return _stream_attention(self.attn_layer, ff.view(T * H * W, E), q_in, pe, H, W, t0i, y0i, x0i, clip, kpe_t, kpe, need_scores)
 
     def finish(self, ml_sets, acc_sets, q_in, out, row0: int, n_rows: int):
         """Combine shard states, apply v_proj per head, out_proj + residual, readout, and write

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HICOM_ABI_VERSION 9
+#define HICOM_ABI_VERSION 10
 
 #define HICOM_OK         0
 #define HICOM_EINVAL    -1   /* bad argument (shape, alignment, NULL)        */
@@ -222,6 +222,24 @@ int hicom_global_stream_clip_fwd(const void* x, int64_t N, int32_t E,
                                  float* scores, int64_t score_stride,
                                  float* part_m, float* part_l, float* part_acc, int32_t nparts, void* stream);
 
+/* The same pass with the positional marginals of the softmax weights accumulated IN the kernel (projector.py:176-179: the
+ * value-side pos-emb term sum_n p_n pos(n) collapses to the t / y / x marginals of p): `scores` may be NULL -- the
+ * [rows_pad, N] logit tensor (54 MB at 32 queries x 9 heads x 64 frames) is then neither written nor read back, and
+ * hicom_global_merge_marg_fwd needs no per-frame marginal pass.  Only the many-row form of the kernel has it (E = 1152, rows_pad
+ * a multiple of 32, grids up to 64 x 48): hicom_global_stream_has_marg(N, E, rows_pad, H, W, nparts) == 1, else HICOM_EUNSUP.
+ *   part_marg : f32 [nparts][rows_pad][hicom_global_stream_marg_width(H, W)], un-normalised, relative to the chunk's own max
+ *               like part_acc: [8 frames counted from the chunk's first | pad to 16 | H | pad to 16 | W | pad to 16]
+ *   pos_a     : required (without pos-emb there are no marginals: use hicom_global_stream_fwd) */
+int hicom_global_stream_marg_fwd(const void* x, int64_t N, int32_t E,
+                                 const void* qt_hi, const void* qt_lo, int32_t rows, int32_t rows_pad,
+                                 const float* pos_a, int32_t pos_stride,
+                                 int32_t H, int32_t W, int32_t t_index0, int32_t y_index0, int32_t x_index0,
+                                 float* scores, int64_t score_stride,
+                                 float* part_m, float* part_l, float* part_acc, float* part_marg, int32_t nparts,
+                                 void* stream);
+int hicom_global_stream_marg_width(int32_t H, int32_t W);
+int hicom_global_stream_has_marg(int64_t N, int32_t E, int32_t rows_pad, int32_t H, int32_t W, int32_t nparts);
+
 /* ---- backward of the global attention over the token stream (training) ------
  * Autograd through projector.py:197-215 in the folded form: with the forward's logits S (the `scores`
  * hicom_global_stream_fwd wrote), its softmax state ml [rows][2] = (M, L) and delta_r = dctx_r . ctx_r,
@@ -290,6 +308,14 @@ int hicom_global_merge_fwd(const float* part_m, const float* part_l, const float
                            int32_t H, int32_t W, const float* pe,
                            int32_t t_index0, int32_t y_index0, int32_t x_index0,
                            float* scratch, float* out_ml, float* out_acc, int32_t normalize, void* stream);
+
+/* Merge behind hicom_global_stream_marg_fwd (same outputs; pe required; scratch as above, only the head of each row's region is
+ * used for the row's weight record). */
+int hicom_global_merge_marg_fwd(const float* part_m, const float* part_l, const float* part_acc, const float* part_marg,
+                                int32_t nparts, int32_t rows, int32_t rows_pad, int32_t E, int64_t N,
+                                int32_t H, int32_t W, const float* pe,
+                                int32_t t_index0, int32_t y_index0, int32_t x_index0,
+                                float* scratch, float* out_ml, float* out_acc, int32_t normalize, void* stream);
 
 /* Combine `nsets` (M,L,ACC) triples (one per GPU after the all-gather, or one) and normalise:
  * ctx[r,:] = sum_k e^(M_k - M) ACC_k[r,:] / sum_k e^(M_k - M) L_k.

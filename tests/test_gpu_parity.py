@@ -502,6 +502,41 @@ def test_guide_off_wide_global_kernel_matches_narrow():
     assert float((wide[-32:].cpu() - want.reshape(32, 896)).abs().max()) <= TOL
 
 
+@pytest.mark.parametrize("T,t_offset", [(16, 0), (64, 0), (12, 40)])
+def test_global_stream_in_kernel_marginals_match_the_logit_tensor_path(T, t_offset, monkeypatch):
+    """Guide off (288 folded query rows, value-side pos-emb): the many-row stream kernel accumulates the t / y / x marginals of the
+    softmax weights itself (hicom_global_stream_marg_fwd + hicom_global_merge_marg_fwd, no [288, N] logit tensor) -- against the
+    path that writes the logits and takes per-frame marginals from them afterwards (hicom_global_stream_fwd +
+    hicom_global_merge_fwd), same (M, L), contexts to fp32 noise, with a frame offset (a shard of a longer clip), and with the
+    logits requested as well (the training forward): then they equal the other path's bit for bit."""
+    from types import SimpleNamespace
+    from hicom_amd import native as nv, synth
+    from oracle import hicom_oracle as orc
+    cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "mm_projector_type": "local43_global32", "use_guide": None,
+                             "hidden_size": 896, "max_num_frames": 64})
+    sd = synth.synth_state_dict(orc.param_shapes(cfg), tag="marg")
+    m = build_module(SimpleNamespace(cfg=cfg, sd=sd))
+    gc = m.global_compressor
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    ff = torch.randn(T, 27, 27, 1152, device="cuda", generator=gen).bfloat16()
+    with torch.no_grad():
+        q_in, _ = gc.injected_queries(None)
+        N = T * 729
+        assert nv.global_stream_has_marg(N, 1152, 288, 27, 27, nv.global_stream_nparts(N, 288))
+        ml, acc, none = gc.partial_context(ff, q_in, t_offset=t_offset)
+        ml2, acc2, sc2 = gc.partial_context(ff, q_in, t_offset=t_offset, need_scores=True)
+        assert none is None and sc2 is not None and torch.equal(ml, ml2) and torch.equal(acc, acc2)
+        monkeypatch.setattr(nv, "global_stream_has_marg", lambda *a: False)
+        ml3, acc3, sc3 = gc.partial_context(ff, q_in, t_offset=t_offset)
+        torch.cuda.synchronize()
+    assert torch.equal(ml, ml3) and torch.equal(sc2[:288, :N], sc3[:288, :N])
+    ctx, ctx3 = acc / ml[:, 1:2], acc3 / ml3[:, 1:2]
+    assert bool(torch.isfinite(ctx).all()) and float((ctx - ctx3).abs().max()) <= 2e-5
+    # the positional part is not negligible here: without it the contexts differ visibly
+    pe = gc.pos_and_kpe(t_offset + T, 27, 27, ff.device)[0]
+    assert float(pe.abs().max()) > 0.5
+
+
 @pytest.mark.parametrize("per,finish_rank", [(64, 5), (128, 6)])
 def test_c3_c5_eight_rank_emulation(per, finish_rank):
     """BASELINE configs[2] (512 frames over 8 GPUs, 64 per GPU) and configs[4] (1024 frames, 128 per GPU) on one GPU:

@@ -14,10 +14,16 @@ nparts = nv.global_stream_nparts(N, R)
 scores = torch.empty(R, (N + 15) // 16 * 16, device="cuda")
 pm, pl = torch.empty(nparts, R, device="cuda"), torch.empty(nparts, R, device="cuda")
 pacc = torch.empty(nparts, R, E, device="cuda")
-f = lambda: nv.global_stream(ff, N, qhi, qlo, pos_a, H, W, 0, 64, 64 + H, scores, pm, pl, pacc, rows=R)
-for _ in range(5): f()
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(20): f()
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+pmarg = torch.empty(nparts, R, nv.global_stream_marg_width(H, W), device="cuda")
+forms = {
+    "logits written (marginals taken from them afterwards)": lambda: nv.global_stream(ff, N, qhi, qlo, pos_a, H, W, 0, 64, 64 + H, scores, pm, pl, pacc, rows=R),
+    "marginals in the kernel + logits written": lambda: nv.global_stream_marg(ff, N, qhi, qlo, pos_a, H, W, 0, 64, 64 + H, scores, pm, pl, pacc, pmarg, rows=R),
+    "marginals in the kernel, no logit tensor": lambda: nv.global_stream_marg(ff, N, qhi, qlo, pos_a, H, W, 0, 64, 64 + H, None, pm, pl, pacc, pmarg, rows=R),
+}
 flops = 4.0 * R * N * E
-print(f"nparts {nparts}, {dt * 1e6:.1f} us, {flops / dt / 1e12:.0f} TFLOP/s useful (hi/lo MFMAs: x1.5), checksum {float(pacc.double().sum()):.6e} {float(scores[:, :N].double().sum()):.6e}")
+for name, f in forms.items():
+    for _ in range(5): f()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): f()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+    print(f"{name}: nparts {nparts}, {dt * 1e6:.1f} us, {flops / dt / 1e12:.0f} TFLOP/s useful (hi/lo MFMAs: x1.5), checksum {float(pacc.double().sum()):.6e}")
