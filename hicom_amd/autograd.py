@@ -77,21 +77,64 @@ def _ln_stats(x, eps):
     return (x - mu) * rstd, rstd
 
 
-def _adaptor_recompute(x2, mlp):
-    """Forward of one adaptor MLP over all tokens, recomputed with its intermediates on the forward's own kernels (gradient
-    checkpointing is on in the reference's scripts): h1 = W1 x + b1 (pre-activation, fp16), a = GELU(h1) as fp16 (operand of the second
-    GEMM, exactly the forward's hidden layer) and as bf16 (operand of dW2 = dy^T a), y = W2 a + b2 (fp16, the forward's y)."""
+def _adaptor_recompute(x2, mlp, out=None):
+    """Forward of one adaptor MLP over all tokens WITH what its backward needs, on the inference forward's own kernels and in its
+    arithmetic (the GELU fused into the first GEMM's epilogue, fp16 hidden layer): returns (h1, None, y) -- h1 = W1 x + b1 BEFORE
+    the activation (fp16, the epilogue's second output), y = W2 GELU(h1) + b2 (fp16, bit-identical to the inference forward's).
+    The bf16 copy of the hidden activation that dW2 = dy^T a needs is made by the backward itself (hicom_gelu_split_fwd on h1).
+    out = (h1, _, y) buffers to fill (the training forward's per-shape store), else fresh tensors."""
     from . import injector as inj
     N, D = x2.shape
     w1, b1 = mlp[0].weight.detach(), mlp[0].bias.detach()
-    h1 = torch.empty((N, w1.shape[0]), dtype=torch.float16, device=x2.device)
-    nv.dense16_gemm(x2, w1, b1, act=nv.ACT_NONE, out_f16=h1)
+    h1, _, y = out if out is not None else (torch.empty((N, w1.shape[0]), dtype=torch.float16, device=x2.device), None,
+                                            torch.empty((N, mlp[2].weight.shape[0]), dtype=torch.float16, device=x2.device))
     a16 = torch.empty_like(h1)
-    abf = torch.empty(h1.shape, dtype=torch.bfloat16, device=x2.device)
-    nv.gelu_split(h1, a16, abf)
-    y = torch.empty((N, mlp[2].weight.shape[0]), dtype=torch.float16, device=x2.device)
+    nv.dense16_gemm(x2, w1, b1, act=nv.ACT_GELU, out_f16=a16, pre_f16=h1)
     nv.dense16_gemm(a16, inj._f16_weight(mlp[2]), mlp[2].bias.detach(), out_f16=y)
-    return h1, abf, y
+    return h1, None, y
+
+
+class _AdaptorStore:
+    """The k / v adaptor MLPs' intermediates of the LAST training forward of one input shape (pre-activation hidden layer h1 and
+    output y per adapted stream, fp16: 2 x 107 MB each at 64 frames), in buffers that keep their addresses across steps -- the
+    captured backward reads them by address.  `serial` counts the forwards that filled them: a backward whose forward was not the
+    last one (two forwards before the first backward) refills them from its own inputs before it reads them."""
+
+    def __init__(self, lc, N, E, dev):
+        mk = lambda: torch.empty((N, E), dtype=torch.float16, device=dev)
+        self.k = (mk(), None, mk()) if lc.adapt_k else None
+        self.v = (mk(), None, mk()) if lc.adapt_v else None
+        self.serial = 0
+
+    def fill(self, lc, ff, fe):
+        E = ff.shape[-1]
+        key = fe if fe is not None else ff
+        if self.k is not None:
+            _adaptor_recompute(key.reshape(-1, E), lc.k_proj, self.k)
+        if self.v is not None:
+            _adaptor_recompute(ff.reshape(-1, E), lc.v_proj, self.v)
+        self.serial += 1
+        return self.serial
+
+    @property
+    def ys(self):
+        return (self.k[2] if self.k is not None else None, self.v[2] if self.v is not None else None)
+
+
+def _adaptor_store(proj, ff):
+    """The store of this input shape, or None when the recipe has no k / v adaptor (or the sharing is switched off:
+    `proj.share_adaptor_activations = False` recomputes the MLPs in the backward, as gradient checkpointing would)."""
+    lc = proj.local_compressor
+    if lc is None or not (lc.adapt_k or lc.adapt_v) or getattr(proj, "share_adaptor_activations", True) is False:
+        return None
+    stores = proj.__dict__.setdefault("_adaptor_stores", {})
+    key = (tuple(ff.shape), str(ff.device))
+    st = stores.get(key)
+    if st is None:
+        if len(stores) >= 2:
+            stores.pop(next(iter(stores)))
+        st = stores[key] = _AdaptorStore(lc, ff.shape[0] * ff.shape[1] * ff.shape[2], ff.shape[3], ff.device)
+    return st
 
 
 def _adaptor_mlp_backward(x2, mlp, norm, alpha, rec, coef, vec, vec_stride, axes, prefix, which, grads, want_x):
@@ -102,16 +145,21 @@ def _adaptor_mlp_backward(x2, mlp, norm, alpha, rec, coef, vec, vec_stride, axes
     h1, abf, y = rec
     N, D = x2.shape
     dev = x2.device
+    if abf is None:                                                                         # GELU(h1) as bf16: operand of dW2
+        abf = torch.empty(h1.shape, dtype=torch.bfloat16, device=dev)
+        nv.gelu_split(h1, None, abf)
     dy = torch.empty((N, y.shape[1]), dtype=torch.bfloat16, device=dev)
     r1 = torch.empty((N, D), dtype=torch.bfloat16, device=dev) if want_x else None
-    nv.adapt_dy(y, norm.weight.detach(), vec, vec_stride, coef, alpha.detach(), axes, dy, r1, eps=norm.eps)
+    # (the bias gradients -- column sums of dy and of d h1 -- come out of the launches that write those matrices)
+    grads[f"{prefix}{which}_proj.2.bias"] = nv.adapt_dy(y, norm.weight.detach(), vec, vec_stride, coef, alpha.detach(), axes, dy, r1, eps=norm.eps,
+                                                        colsum=True)
     grads[f"{prefix}{which}_proj.2.weight"] = nv.dense16_tn(dy, abf)                       # dW2[o, h] = sum_n dy[n, o] a[n, h]
-    grads[f"{prefix}{which}_proj.2.bias"] = nv.colsum(dy)
     da = torch.empty((N, h1.shape[1]), dtype=torch.bfloat16, device=dev)
     nv.dense16_gemm(dy, mlp[2].weight.detach().t().contiguous(), None, y=da)                # da[n, h] = sum_o dy[n, o] W2[o, h]
-    nv.gelu_bwd_(da, h1)                                                                    # dh1 = da * GELU'(h1), in place
+    can = da.shape[1] in (1152, 768)
+    db1 = nv.gelu_bwd_(da, h1, colsum=can)                                                  # dh1 = da * GELU'(h1), in place
     grads[f"{prefix}{which}_proj.0.weight"] = nv.dense16_tn(da, x2)                         # dW1[h, i] = sum_n dh1[n, h] x[n, i]
-    grads[f"{prefix}{which}_proj.0.bias"] = nv.colsum(da)
+    grads[f"{prefix}{which}_proj.0.bias"] = db1 if can else nv.colsum(da)
     if not want_x:
         return None
     dx = torch.empty((N, D), dtype=torch.bfloat16, device=dev)
@@ -225,9 +273,15 @@ class _CompressorFn(torch.autograd.Function):
     def forward(ctx, proj, ff, fe, guide, modal, nl, names, *params):
         from . import engine
         from .projector import _out_dtype
+        ctx.adapt_serial = None
         with torch.no_grad():
             if proj.use_executor and proj._executor_covers():          # (plain recipes and the k / v adaptors: one C call)
-                out = engine.run_dense(proj, ff, fe, guide, modal, nl, _out_dtype(proj))
+                store = _adaptor_store(proj, ff)
+                if store is not None:
+                    # the adaptor MLPs run here, with the intermediates their backward needs kept (as autograd keeps them in the
+                    # reference); the executor gets their outputs instead of running the four GEMMs itself
+                    ctx.adapt_serial = store.fill(proj.local_compressor, ff, fe)
+                out = engine.run_dense(proj, ff, fe, guide, modal, nl, _out_dtype(proj), adapt_y=store.ys if store is not None else None)
             else:                                                      # query-side adaptors / coarse / fine injection: operator by operator
                 out = proj.forward_stepwise(ff, fe, guide, modal, nl)
         ctx.proj, ctx.modal, ctx.names = proj, modal, names
@@ -244,12 +298,16 @@ class _CompressorFn(torch.autograd.Function):
         proj = ctx.proj
         want = tuple(bool(need[7 + k]) for k in range(len(ctx.names)))
         args = (proj, ff, fe, guide, ctx.modal, nl, ctx.names, want, bool(need[2]), bool(need[3]), bool(nl is not None and need[5]))
+        store = _adaptor_store(proj, ff) if ctx.adapt_serial is not None else None
+        if store is not None and store.serial != ctx.adapt_serial:
+            with torch.no_grad():
+                store.fill(proj.local_compressor, ff, fe)          # another forward of this shape ran in between: its intermediates are not ours
         gb = getattr(proj, "graph_backward", None)             # None: automatic; False: always eager
         if (gb is None or gb) and nl is None:
-            res = _graphed_backward(dout, *args)
+            res = _graphed_backward(dout, *args, store=store)
         else:
             with torch.no_grad():
-                res = _backward_outputs(dout, *args)
+                res = _backward_outputs(dout, *args, store=store)
         flats, d_fe, d_guide, d_nl = res
         plist = dict(proj.named_parameters())
         out = [None] * len(ctx.names)
@@ -262,12 +320,13 @@ class _CompressorFn(torch.autograd.Function):
         return (None, None, d_fe, d_guide, None, d_nl, None, *out)
 
 
-def _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl):
+def _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl, store=None):
     """({dtype: (flat gradient buffer, [(argument index, parameter name)])}, d frames_embed, d guide_embed, d image_newline) in
     the dtypes autograd hands on.  The parameter gradients leave as views of one buffer cast once (one concatenation + one cast
     instead of a cast per tensor)."""
     global LAST_FP32_GRADS
-    grads, d_nl, d_fe, d_guide = compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=want_fe, want_guide=want_guide)
+    grads, d_nl, d_fe, d_guide = compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=want_fe, want_guide=want_guide,
+                                                     adaptor_saved=(store.k, store.v) if store is not None else None)
     LAST_FP32_GRADS = dict(grads)
     if d_guide is not None:
         LAST_FP32_GRADS["__guide_embed__"] = d_guide
@@ -284,7 +343,7 @@ def _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
 _MAX_BWD_GRAPHS = 4
 
 
-def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl):
+def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl, store=None):
     """The backward as a captured hipGraph (the default; `proj.graph_backward = False` turns it off).
     The eager backward is ~130 small launches behind 1.4 ms of Python at the benchmark shape; its shapes are static, so the second
     backward of a problem SHAPE is captured and later ones are one graph launch.  The captured kernels read STATIC copies of the inputs
@@ -296,7 +355,8 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
     from . import engine
     cache = proj.__dict__.setdefault("_bwd_graphs", {})
     key = (tuple(ff.shape), None if fe is None else tuple(fe.shape), None if guide is None else tuple(guide.shape), modal,
-           tuple(dout.shape), dout.dtype, want, want_fe, want_guide, torch.cuda.current_stream(ff.device).cuda_stream)
+           tuple(dout.shape), dout.dtype, want, want_fe, want_guide, torch.cuda.current_stream(ff.device).cuda_stream,
+           None if store is None else id(store))          # (the captured kernels read the store's buffers by address)
     # what else the captured kernels read by ADDRESS: every parameter's storage and the cached device tables (pe / kpe / planes:
     # `_cache_gen` moves when one is reallocated -- T above the cached cap, a cleared cache, a device move).  A graph whose
     # signature moved is dropped, never replayed over freed or reused memory.
@@ -308,7 +368,7 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
 
     def eager():
         with torch.no_grad():
-            return _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl)
+            return _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl, store=store)
 
     if ent is None:                                                # first sight of the shape: eager (also the warm-up a capture needs)
         if len(cache) >= _MAX_BWD_GRAPHS:
@@ -326,7 +386,9 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
             torch.cuda.current_stream(ff.device).synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(g):
-                outs = _backward_outputs(st["dout"], proj, st["ff"], st["fe"], st["guide"], modal, nl, names, want, want_fe, want_guide, want_nl)
+                outs = _backward_outputs(st["dout"], proj, st["ff"], st["fe"], st["guide"], modal, nl, names, want, want_fe, want_guide, want_nl,
+                                         store=store)
+            st["store"] = store                                    # (keeps the buffers the graph reads alive with the entry)
             if engine.plan_sig(proj) != sig:                       # (the pass inside the capture reallocated a table)
                 raise RuntimeError("cached device tables moved during capture")
             ent.update(graph=g, outs=outs, **st)
@@ -345,7 +407,7 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
             None if d_guide is None else d_guide.clone(), None)
 
 
-def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, want_guide=False):
+def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, want_guide=False, adaptor_saved=None):
     """(fp32 gradients {parameter name: tensor} of sum(out * dout), d image_newline, d frames_embed (bf16) or None,
     d guide_embed (fp32) or None).  Restates autograd through reference projector.py:524-559 (local), :634-646 + :166-228
     (global) and mm_utils.py:92-140 (packing).  The input gradients exist for the direct recipe only."""
@@ -377,7 +439,18 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         dY = dout[rows]
         if lay.newline_rows:
             d_nl = dout[torch.tensor(lay.newline_rows, device=dev)].sum(0)
-        ctx_l, _ = lc.window_context(ff, fe, guide, modal, None, None)     # HIP: [Nw, E] fp32 window contexts
+        # k / v adaptors: ONE recomputation of the two MLPs over all tokens (with the intermediates their backward needs) serves the
+        # window contexts below as well
+        adapt = lc.adapt_k or lc.adapt_v
+        rec_k = rec_v = None
+        if adapt and adaptor_saved is not None:
+            rec_k, rec_v = adaptor_saved                                   # kept by the training forward (_AdaptorStore)
+        elif adapt:
+            key_ = fe if fe is not None else ff
+            rec_k = _adaptor_recompute(key_.reshape(-1, E), lc.k_proj) if lc.adapt_k else None
+            rec_v = _adaptor_recompute(ff.reshape(-1, E), lc.v_proj) if lc.adapt_v else None
+        ctx_l, _ = lc.window_context(ff, fe, guide, modal, None, None,     # HIP: [Nw, E] fp32 window contexts
+                                     adapt_y=(rec_k[2] if rec_k else None, rec_v[2] if rec_v else None) if adapt else None)
         W0, b0 = f32["local_compressor.readout.0.weight"], f32["local_compressor.readout.0.bias"]
         W2 = f32["local_compressor.readout.2.weight"]
         pre = torch.addmm(b0, ctx_l, W0.t())
@@ -388,7 +461,6 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         grads["local_compressor.readout.0.weight"] = dpre.t() @ ctx_l
         grads["local_compressor.readout.0.bias"] = dpre.sum(0)
         mode = lc.use_guide if lc.use_guide not in (None, "off") else None
-        adapt = lc.adapt_k or lc.adapt_v
         plain_q = not (lc.adapt_q or lc.adapt_guide)                       # plain direct / coarse / off: the hand-written paths below
         query_params = mode in ("coarse", "fine") or lc.adapt_q or lc.adapt_guide
         if want_fe or adapt or query_params or (want_guide and mode is not None):
@@ -420,8 +492,6 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
                 # the adaptor MLPs' backward per stream; everything token-stream sized runs on HIP kernels --------------------------
                 N = T * H * W
                 kx2, vx2 = key.reshape(N, E), ff.reshape(N, E)
-                rec_k = _adaptor_recompute(kx2, lc.k_proj) if lc.adapt_k else None
-                rec_v = _adaptor_recompute(vx2, lc.v_proj) if lc.adapt_v else None
                 ds = torch.empty((N,), dtype=torch.float32, device=dev)
                 pw = torch.empty_like(ds)
                 sxk, sxv = torch.empty((nw, E), dtype=torch.float32, device=dev), torch.empty((nw, E), dtype=torch.float32, device=dev)

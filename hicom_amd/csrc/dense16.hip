@@ -45,6 +45,8 @@ struct DenseParams {
     _Float16* o16;          // fp16 [M, ldo]; columns [N, n_store) are written as zeros (K padding of the next GEMM)
     long ldo;
     int n_store;
+    _Float16* pre16;        // fp16 [M, ldpre]: acc + b BEFORE the activation (what the activation's backward needs), or NULL; row epilogue only
+    long ldpre;
     void* y;                // bf16 | f32 [M, ldy]: value + residual
     int y_f32;
     long ldy;
@@ -152,7 +154,7 @@ __device__ __forceinline__ void dense_epilogue(const DenseParams& p, f32x4 (&acc
 // issue order: no barrier between the staging writes and reads.
 // bias_staged: the wave's bias slice (columns nw .. nw + 16 NJ, raw fp32 / bf16) already lies at the head of `stage` (the ring
 // kernel's loaders put it there by LDS-DMA a few K steps earlier): read before the first staging write, no global latency.
-template <int MI, int NJ>
+template <int MI, int NJ, bool PRE = false>
 __device__ __forceinline__ void dense_epilogue_rows(const DenseParams& p, f32x4 (&acc)[NJ][MI], int mw, int nw, int lane, float* stage,
                                                     bool bias_staged = false) {
     static_assert(NJ % 4 == 0, "64-column slices");
@@ -237,6 +239,15 @@ __device__ __forceinline__ void dense_epilogue_rows(const DenseParams& p, f32x4 
                     }
                 }
                 float rss = 0.f;
+                if constexpr (PRE) {
+                    // the value BEFORE the activation as a second fp16 output (own instantiation: the plain kernel keeps its 112 VGPRs)
+                    if (m < p.M && n_ok) {
+                        half8 hv;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) hv[e] = (_Float16)fminf(fmaxf(v[e] + bias[e], -65504.f), 65504.f);
+                        *reinterpret_cast<half8*>(p.pre16 + (long)m * p.ldpre + n) = hv;
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     v[e] = n_ok ? v[e] + bias[e] : 0.f;
@@ -294,7 +305,7 @@ __device__ __forceinline__ void dense_epilogue_rows(const DenseParams& p, f32x4 
 
 // 128 x 128 tile, 2 x 2 waves of 64 x 64, ONE 32-KB stage, two barriers per K step; the workgroups resident on a CU (four at
 // 112 VGPRs with the row epilogue) overlap each other's staging, MFMA and epilogue phases.
-template <bool BF16, bool ROWS>
+template <bool BF16, bool ROWS, bool PRE = false>
 __global__ __launch_bounds__(256, 3) void dense16_gemm_kernel(DenseParams p) {
     constexpr int NWAVE = 4, WC = 2, MI = 4, TM = 128, TN = 128;
     constexpr int PPW = (TM + TN) / 8 / NWAVE;                  // one-KiB DMA pieces (8 rows x 128 B) per wave and stage
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(256, 3) void dense16_gemm_kernel(DenseParams p) {
         dense_epilogue<MI, 4>(p, acc, m0 + 16 * MI * wr, n0 + 64 * wc, r16, kg);
     } else {
         lds_barrier();                                        // every wave is done reading the last stage: the buffer becomes staging space
-        dense_epilogue_rows<MI, 4>(p, acc, m0 + 16 * MI * wr, n0 + 64 * wc, lane, reinterpret_cast<float*>(lds) + wave * 1024);
+        dense_epilogue_rows<MI, 4, PRE>(p, acc, m0 + 16 * MI * wr, n0 + 64 * wc, lane, reinterpret_cast<float*>(lds) + wave * 1024);
     }
 }
 
@@ -669,7 +680,7 @@ using namespace hicom;
 
 extern "C" int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w, int64_t ldw, int32_t operand_dt,
                                       const void* b, int32_t b_dt, int32_t M, int32_t N, int32_t K, int32_t act,
-                                      void* out_f16, int64_t ldo, int32_t n_store,
+                                      void* out_f16, int64_t ldo, int32_t n_store, void* pre_f16, int64_t ldpre,
                                       void* y, int32_t y_dt, int64_t ldy, const void* res, int64_t ldr,
                                       float* ssq, const float* row_tab, int64_t row_tab_ld, int32_t tab_H, int32_t tab_W,
                                       int32_t tab_t0, int32_t tab_y0, int32_t tab_x0,
@@ -701,12 +712,18 @@ extern "C" int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w,
                           (!res || ((uintptr_t)res % 16 == 0 && ldr % 8 == 0)), HICOM_EINVAL,
                       "dense16_gemm: the row-dot output needs the row-contiguous epilogue (N %% 8, 16-byte aligned rows) and a bf16 | f32 vector");
     p.dotv = dot_vec; p.dotv_f32 = dot_vec_dt == HICOM_DT_F32; p.rdot = row_dot;
+    if (pre_f16)
+        HICOM_REQUIRE(rows && ldpre >= N && ldpre % 8 == 0 && (uintptr_t)pre_f16 % 16 == 0, HICOM_EINVAL,
+                      "dense16_gemm: the pre-activation output needs the row-contiguous epilogue (N %% 8) and 16-byte aligned rows");
+    p.pre16 = (_Float16*)pre_f16; p.ldpre = ldpre;
     hipStream_t st = (hipStream_t)stream;
     const bool bf = operand_dt == HICOM_DT_BF16;
     p.tiles_m = (M + 127) / 128; p.tiles_n = (N + 127) / 128;
     constexpr int smem = (128 + 128) * 128;
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
-    if (bf && rows) hipLaunchKernelGGL((dense16_gemm_kernel<true, true>), grid, dim3(256), smem, st, p);
+    if (pre_f16 && bf) hipLaunchKernelGGL((dense16_gemm_kernel<true, true, true>), grid, dim3(256), smem, st, p);
+    else if (pre_f16) hipLaunchKernelGGL((dense16_gemm_kernel<false, true, true>), grid, dim3(256), smem, st, p);
+    else if (bf && rows) hipLaunchKernelGGL((dense16_gemm_kernel<true, true>), grid, dim3(256), smem, st, p);
     else if (bf) hipLaunchKernelGGL((dense16_gemm_kernel<true, false>), grid, dim3(256), smem, st, p);
     else if (rows) hipLaunchKernelGGL((dense16_gemm_kernel<false, true>), grid, dim3(256), smem, st, p);
     else hipLaunchKernelGGL((dense16_gemm_kernel<false, false>), grid, dim3(256), smem, st, p);

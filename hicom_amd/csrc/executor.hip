@@ -410,16 +410,18 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                 const void* key_x = a.fe ? a.fe : a.ff;
                 auto mlp = [&](const hicom_compressor_args::hicom_adaptor& ad, const void* x, size_t y_off) -> int {
                     CHK(hicom_dense16_gemm_fwd(x, a.E, ad.w0, a.E, HICOM_DT_BF16, ad.b0, HICOM_DT_BF16, (int32_t)w.N, a.E, a.E, HICOM_ACT_GELU,
-                                               ws + w.ad_hid, a.E, a.E, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0, 0, nullptr, 0,
+                                               ws + w.ad_hid, a.E, a.E, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0, 0, nullptr, 0,
                                                nullptr, sm));
                     return hicom_dense16_gemm_fwd(ws + w.ad_hid, a.E, ad.w2_f16, a.E, HICOM_DT_F16, ad.b2, HICOM_DT_BF16, (int32_t)w.N, a.E, a.E,
-                                                  HICOM_ACT_NONE, ws + y_off, a.E, a.E, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0, 0,
+                                                  HICOM_ACT_NONE, ws + y_off, a.E, a.E, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0, 0,
                                                   nullptr, 0, nullptr, sm);
                 };
-                if (a.ak.w0) CHK(mlp(a.ak, key_x, w.ad_ky));
-                if (a.av.w0) CHK(mlp(a.av, a.ff, w.ad_vy));
-                CHK(hicom_local_attn_adapt_fwd(key_x, a.ak.w0 ? ws + w.ad_ky : nullptr, a.ak.gamma, a.ak.beta, a.ak.alpha,
-                                               a.ff, a.av.w0 ? ws + w.ad_vy : nullptr, a.av.gamma, a.av.beta, a.av.alpha,
+                if (a.ak.w0 && !a.ak.y) CHK(mlp(a.ak, key_x, w.ad_ky));
+                if (a.av.w0 && !a.av.y) CHK(mlp(a.av, a.ff, w.ad_vy));
+                const void* ky = !a.ak.w0 ? nullptr : (a.ak.y ? a.ak.y : (const void*)(ws + w.ad_ky));      // (.y: the caller's own MLP outputs)
+                const void* vy = !a.av.w0 ? nullptr : (a.av.y ? a.av.y : (const void*)(ws + w.ad_vy));
+                CHK(hicom_local_attn_adapt_fwd(key_x, ky, a.ak.gamma, a.ak.beta, a.ak.alpha,
+                                               a.ff, vy, a.av.gamma, a.av.beta, a.av.alpha,
                                                a.adapt_alpha_dt, a.adapt_eps, a.E, a.at, a.ay, a.ax, q, q_dt, q_stride, a.l_scale, a.l_bias,
                                                F(w.ctx_local), sm));
             } else {

@@ -762,14 +762,19 @@ struct AdaptDyParams {
     uint16_t* dy;           // bf16 [N, D]
     uint16_t* r1;           // bf16 [N, D] or NULL
     long N;
+    float* col_parts;       // f32 [gridDim.x][D] or NULL: this workgroup's column sums of dy (as stored: bf16-rounded) -- the bias gradient
 };
 
 template <int NV>
 __global__ __launch_bounds__(256) void adapt_dy_kernel(AdaptDyParams p) {
     constexpr int D = NV * 384;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long tok = (long)blockIdx.x * 4 + wave;
-    if (tok >= p.N) return;
+    float csum[NV][6];
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) csum[s][j] = 0.f;
+    for (long tok = (long)blockIdx.x * 4 + wave; tok < p.N; tok += (long)gridDim.x * 4) {
     const int H = p.ay.n, W = p.ax.n;
     const int t = (int)(tok / ((long)H * W)), rem = (int)(tok - (long)t * H * W), yy = rem / W, xx = rem - yy * W;
     const long win = ((long)(t / p.at.k) * p.ay.nwin + yy / p.ay.k) * p.ax.nwin + xx / p.ax.k;
@@ -817,6 +822,8 @@ __global__ __launch_bounds__(256) void adapt_dy_kernel(AdaptDyParams p) {
         w.b = f32_to_bf16(r[2]) | ((uint32_t)f32_to_bf16(r[3]) << 16);
         w.c = f32_to_bf16(r[4]) | ((uint32_t)f32_to_bf16(r[5]) << 16);
         *reinterpret_cast<Seg12*>(o + 384 * s + 6 * lane) = w;
+        csum[s][0] += bf16lo_to_f32(w.a); csum[s][1] += bf16hi_to_f32(w.a); csum[s][2] += bf16lo_to_f32(w.b);
+        csum[s][3] += bf16hi_to_f32(w.b); csum[s][4] += bf16lo_to_f32(w.c); csum[s][5] += bf16hi_to_f32(w.c);
     }
     if (p.r1) {
         const float k1 = (1.0f - alpha) * c;
@@ -829,6 +836,16 @@ __global__ __launch_bounds__(256) void adapt_dy_kernel(AdaptDyParams p) {
             w.c = f32_to_bf16(k1 * v[s][4]) | ((uint32_t)f32_to_bf16(k1 * v[s][5]) << 16);
             *reinterpret_cast<Seg12*>(o1 + 384 * s + 6 * lane) = w;
         }
+    }
+    }   // token loop
+    if (p.col_parts) {
+        __shared__ float red[4][D];
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) red[wave][384 * s + 6 * lane + j] = csum[s][j];
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += 256) p.col_parts[(long)blockIdx.x * D + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
     }
 }
 
@@ -860,7 +877,7 @@ __global__ __launch_bounds__(256) void gelu_split_kernel(const _Float16* h, _Flo
     for (int e = 0; e < 8; ++e) { f[e] = gelu_erf((float)hv[e]); av[e] = (_Float16)fminf(fmaxf(f[e], -65504.f), 65504.f); }
 #pragma unroll
     for (int e = 0; e < 4; ++e) bv[e] = f32_to_bf16(f[2 * e]) | ((uint32_t)f32_to_bf16(f[2 * e + 1]) << 16);
-    reinterpret_cast<half8*>(a16)[i] = av;
+    if (a16) reinterpret_cast<half8*>(a16)[i] = av;
     reinterpret_cast<u32x4*>(abf)[i] = bv;
 }
 
@@ -878,6 +895,44 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(uint16_t* da, const _Floa
         d[e] = f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
     }
     reinterpret_cast<u32x4*>(da)[i] = d;
+}
+
+// the same step with a wave per row and the rows strided over the grid, plus this workgroup's column sums of the result (as stored):
+// the bias gradient db1 = sum over the tokens of d h1 without another pass over the 107-MB matrix
+template <int NV>
+__global__ __launch_bounds__(256) void gelu_bwd_rows_kernel(uint16_t* da, const _Float16* h, long N, float* col_parts) {
+    constexpr int D = NV * 384;
+    __shared__ float red[4][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float csum[NV][6];
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) csum[s][j] = 0.f;
+    for (long r = (long)blockIdx.x * 4 + wave; r < N; r += (long)gridDim.x * 4) {
+        float d[NV][6], hv[NV][6];
+        load_row<NV>(da + r * D, lane, d);
+        load_row_f16<NV>(h + r * D, lane, hv);
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            float v[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v[j] = d[s][j] * gelu_erf_grad(hv[s][j]);
+            Seg12 w;
+            w.a = f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+            w.b = f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            w.c = f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+            *reinterpret_cast<Seg12*>(da + r * D + 384 * s + 6 * lane) = w;
+            csum[s][0] += bf16lo_to_f32(w.a); csum[s][1] += bf16hi_to_f32(w.a); csum[s][2] += bf16lo_to_f32(w.b);
+            csum[s][3] += bf16hi_to_f32(w.b); csum[s][4] += bf16lo_to_f32(w.c); csum[s][5] += bf16hi_to_f32(w.c);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) red[wave][384 * s + 6 * lane + j] = csum[s][j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) col_parts[(long)blockIdx.x * D + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 // column sums of a bf16 [N, D] matrix (bias gradients: db = sum over the tokens): partial [gridDim.x][D] f32, a wave per row, rows
@@ -1076,31 +1131,39 @@ extern "C" int hicom_local_attn_adapt_bwd(const void* key_x, const void* key_y, 
 
 extern "C" int hicom_adapt_dy_fwd(const void* y, const void* gamma, const void* vec, int32_t vec_dt, int64_t vec_stride, const float* coef,
                                   const void* alpha, int32_t alpha_dt, float eps, int32_t D, hicom_axis at, hicom_axis ay, hicom_axis ax,
-                                  void* dy, void* r1, void* stream) {
-    HICOM_REQUIRE(y && gamma && vec && coef && alpha && dy, HICOM_EINVAL, "adapt_dy: NULL pointer");
+                                  void* dy, void* r1, float* col_parts, int32_t nparts, void* stream) {
+    HICOM_REQUIRE(y && gamma && vec && coef && alpha && dy && (!col_parts || nparts > 0), HICOM_EINVAL, "adapt_dy: NULL pointer");
     HICOM_REQUIRE(D == 1152 || D == 768, HICOM_EUNSUP, "adapt_dy: D=%d (only 1152 / 768)", D);
     HICOM_REQUIRE((vec_dt == HICOM_DT_BF16 || vec_dt == HICOM_DT_F32) && (alpha_dt == HICOM_DT_BF16 || alpha_dt == HICOM_DT_F32), HICOM_EINVAL, "adapt_dy: dtypes");
     if (int rc = check_axes("adapt_dy", at, ay, ax, true)) return rc;
     const long N = (long)at.n * ay.n * ax.n;
     AdaptDyParams p{(const _Float16*)y, (const uint16_t*)gamma, vec, vec_dt == HICOM_DT_F32, (long)vec_stride, coef, alpha, alpha_dt == HICOM_DT_F32, eps,
-                    at, ay, ax, (uint16_t*)dy, (uint16_t*)r1, N};
+                    at, ay, ax, (uint16_t*)dy, (uint16_t*)r1, N, col_parts};
     hipStream_t s = (hipStream_t)stream;
-    if (D == 1152) hipLaunchKernelGGL(adapt_dy_kernel<3>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(adapt_dy_kernel<2>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, p);
+    // with column partials: `nparts` workgroups walk the tokens (each leaves one partial row); without: one token per wave
+    const unsigned grid = col_parts ? (unsigned)nparts : (unsigned)((N + 3) / 4);
+    if (D == 1152) hipLaunchKernelGGL(adapt_dy_kernel<3>, dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(adapt_dy_kernel<2>, dim3(grid), dim3(256), 0, s, p);
     return hicom_host::check_launch("adapt_dy");
 }
 
 extern "C" int hicom_gelu_split_fwd(const void* h_f16, void* a_f16, void* a_bf16, int64_t n, void* stream) {
-    HICOM_REQUIRE(h_f16 && a_f16 && a_bf16 && n > 0 && n % 8 == 0 && ((uintptr_t)h_f16 % 16 == 0) && ((uintptr_t)a_f16 % 16 == 0) && ((uintptr_t)a_bf16 % 16 == 0),
+    HICOM_REQUIRE(h_f16 && a_bf16 && n > 0 && n % 8 == 0 && ((uintptr_t)h_f16 % 16 == 0) && ((uintptr_t)a_f16 % 16 == 0) && ((uintptr_t)a_bf16 % 16 == 0),
                   HICOM_EINVAL, "gelu_split: bad arguments (n %% 8, 16-byte alignment)");
     hipLaunchKernelGGL(gelu_split_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)h_f16, (_Float16*)a_f16,
                        (uint16_t*)a_bf16, (long)(n / 8));
     return hicom_host::check_launch("gelu_split");
 }
 
-extern "C" int hicom_gelu_bwd_fwd(void* da_bf16, const void* h_f16, int64_t n, void* stream) {
+extern "C" int hicom_gelu_bwd_fwd(void* da_bf16, const void* h_f16, int64_t n, int32_t D, float* col_parts, int32_t nparts, void* stream) {
     HICOM_REQUIRE(da_bf16 && h_f16 && n > 0 && n % 8 == 0 && ((uintptr_t)da_bf16 % 16 == 0) && ((uintptr_t)h_f16 % 16 == 0), HICOM_EINVAL,
                   "gelu_bwd: bad arguments (n %% 8, 16-byte alignment)");
+    if (col_parts) {
+        HICOM_REQUIRE((D == 1152 || D == 768) && n % D == 0 && nparts > 0, HICOM_EINVAL, "gelu_bwd: column partials need rows of D = 1152 / 768 and nparts > 0");
+        if (D == 1152) hipLaunchKernelGGL(gelu_bwd_rows_kernel<3>, dim3((unsigned)nparts), dim3(256), 0, (hipStream_t)stream, (uint16_t*)da_bf16, (const _Float16*)h_f16, (long)(n / D), col_parts);
+        else hipLaunchKernelGGL(gelu_bwd_rows_kernel<2>, dim3((unsigned)nparts), dim3(256), 0, (hipStream_t)stream, (uint16_t*)da_bf16, (const _Float16*)h_f16, (long)(n / D), col_parts);
+        return hicom_host::check_launch("gelu_bwd");
+    }
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)da_bf16, (const _Float16*)h_f16,
                        (long)(n / 8));
     return hicom_host::check_launch("gelu_bwd");

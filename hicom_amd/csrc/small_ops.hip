@@ -412,13 +412,45 @@ __global__ __launch_bounds__(256) void partials_sum_kernel(const float* parts, i
     out[m] = s;
 }
 
+// Many partials of a short vector (column partials of the streaming backward kernels: 1024 x 1152): the loop above is one thread per
+// output walking all partials one load at a time.  Here a workgroup owns 16 outputs and 16 lanes share each output's partials
+// (k = g, g + 16, ...: 8 loads in flight per thread), combined in a fixed order through LDS: deterministic as well.
+__global__ __launch_bounds__(256) void partials_sum_tall_kernel(const float* parts, int nparts, long M, float* out) {
+    __shared__ float red[16][17];
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const long m = (long)blockIdx.x * 16 + c;
+    float s = 0.f;
+    if (m < M) {
+        int k = g;
+        for (; k + 16 * 7 < nparts; k += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = parts[(long)(k + 16 * u) * M + m];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < nparts; k += 16) s += parts[(long)k * M + m];
+    }
+    red[g][c] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && m < M) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x];
+        out[m] = t;
+    }
+}
+
 }  // namespace hicom
 
 using namespace hicom;
 
 extern "C" int hicom_partials_sum_fwd(const float* parts, int32_t nparts, int64_t M, float* out, void* stream) {
     HICOM_REQUIRE(parts && out && nparts > 0 && M > 0, HICOM_EINVAL, "partials_sum: bad arguments");
-    hipLaunchKernelGGL(partials_sum_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, parts, nparts, (long)M, out);
+    if (nparts >= 64 && M <= 65536)
+        hipLaunchKernelGGL(partials_sum_tall_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, parts, nparts, (long)M, out);
+    else
+        hipLaunchKernelGGL(partials_sum_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, parts, nparts, (long)M, out);
     return hicom_host::check_launch("partials_sum");
 }
 

@@ -271,8 +271,11 @@ def _evict_one(plans: dict):
         ws.record_stream(res.side)
 
 
-def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferred: bool = False, local_logits=None):
+def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferred: bool = False, local_logits=None, adapt_y=None):
     """HIComProjector.forward for a dense [T,H,W,E] input through hicom_compressor_fwd.
+
+    adapt_y = (y_k, y_v): fp16 [T*H*W, E] outputs of the k / v adaptor MLPs the caller computed itself (the training forward keeps
+    their intermediates for the backward): the executor then skips those GEMMs (hicom_adaptor.y).
 
     With `proj.graph_replay = True` the launch sequence of a plan is captured into a hipGraph on its second use and
     replayed afterwards (one graph launch + one device copy of the result); graph plans are additionally keyed by the
@@ -295,7 +298,8 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
     key = (tuple(ff.shape), None if fe is None else tuple(fe.shape), None if guide is None else tuple(guide.shape), modal,
            None if nl is None else tuple(nl.shape), out_dtype,
            torch.cuda.current_stream(dev).cuda_stream,
-           (ff.data_ptr(), _p(fe), _p(guide), _p(nl), _p(ll)) if graph else None, ll is not None)
+           (ff.data_ptr(), _p(fe), _p(guide), _p(nl), _p(ll), None if adapt_y is None else tuple(_p(t) for t in adapt_y)) if graph else None,
+           ll is not None)
     plans = proj.__dict__.setdefault("_engine_plans", {})
     plan = plans.get(key)
     sig = plan_sig(proj)
@@ -359,6 +363,8 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
         a.fe = fe.data_ptr()
     if ll is not None:
         a.local_logits = ll.data_ptr()
+    a.ak.y = adapt_y[0].data_ptr() if adapt_y is not None and adapt_y[0] is not None else None
+    a.av.y = adapt_y[1].data_ptr() if adapt_y is not None and adapt_y[1] is not None else None
     if guide is not None:
         gp = guide.data_ptr()
         for f in plan.guide_fields:

@@ -60,7 +60,7 @@ class AuxGemv(C.Structure):
 class Adaptor(C.Structure):
     """hicom_compressor_args.ak / .av: one k / v adaptor of the local stage (include/hicom_hip.h)."""
     _fields_ = [("w0", C.c_void_p), ("b0", C.c_void_p), ("w2_f16", C.c_void_p), ("b2", C.c_void_p), ("gamma", C.c_void_p),
-                ("beta", C.c_void_p), ("alpha", C.c_void_p)]
+                ("beta", C.c_void_p), ("alpha", C.c_void_p), ("y", C.c_void_p)]
 
 
 class CompressorArgs(C.Structure):
@@ -142,7 +142,7 @@ def lib() -> C.CDLL:
     L.hicom_splice_rows_fwd.argtypes = [vp, i64, i32, vp, vp]
     L.hicom_splice_labels_fwd.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i64, vp, vp, vp]
     L.hicom_to_f16_padded_fwd.argtypes = [vp, i32, i64, i64, vp, i64, vp]
-    L.hicom_dense16_gemm_fwd.argtypes = [vp, i64, vp, i64, i32, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, i32, i64, vp, i64, vp,
+    L.hicom_dense16_gemm_fwd.argtypes = [vp, i64, vp, i64, i32, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, i64, vp, i32, i64, vp, i64, vp,
                                          vp, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp]
     L.hicom_partials_sum_fwd.argtypes = [vp, i32, i64, vp, vp]
     L.hicom_dense16_tn_splits.argtypes = [i32, i32, i64]
@@ -151,9 +151,9 @@ def lib() -> C.CDLL:
     L.hicom_local_attn_adapt_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32, vp, vp]
     L.hicom_local_attn_adapt_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32,
                                              vp, vp, vp, vp, vp, vp, vp, vp]
-    L.hicom_adapt_dy_fwd.argtypes = [vp, vp, vp, i32, i64, vp, vp, i32, f32, i32, Axis, Axis, Axis, vp, vp, vp]
+    L.hicom_adapt_dy_fwd.argtypes = [vp, vp, vp, i32, i64, vp, vp, i32, f32, i32, Axis, Axis, Axis, vp, vp, vp, i32, vp]
     L.hicom_gelu_split_fwd.argtypes = [vp, vp, vp, i64, vp]
-    L.hicom_gelu_bwd_fwd.argtypes = [vp, vp, i64, vp]
+    L.hicom_gelu_bwd_fwd.argtypes = [vp, vp, i64, i32, vp, i32, vp]
     L.hicom_colsum_fwd.argtypes = [vp, i64, i32, vp, i32, vp]
     L.hicom_clip_query_prep_fwd.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp]
     L.hicom_inv_norm_fwd.argtypes = [vp, i32, i64, vp, vp]
@@ -255,18 +255,43 @@ def local_attn_adapt_bwd(key_x, key_y, k_norm, k_alpha, value_x, value_y, v_norm
            "hicom_local_attn_adapt_bwd")
 
 
-def adapt_dy(y, gamma, vec, vec_stride, coef, alpha, axes, dy, r1=None, eps=1e-6):
+_COL_PARTS = 1024        # workgroups (= partial rows) of the streaming kernels that leave column sums beside their output
+
+
+def _col_parts(rows, D, dev):
+    n = max(1, min(_COL_PARTS, (rows + 3) // 4))
+    return torch.empty((n, D), dtype=torch.float32, device=dev)
+
+
+def adapt_dy(y, gamma, vec, vec_stride, coef, alpha, axes, dy, r1=None, eps=1e-6, colsum=False):
+    """colsum=True: also returns the column sums of dy (f32 [D], the bias gradient) from partials the same launch leaves."""
     D = y.shape[-1]
+    parts = _col_parts(dy.shape[0], D, dy.device) if colsum else None
     _check(lib().hicom_adapt_dy_fwd(_ptr(y), _ptr(gamma), _ptr(vec), _dt(vec), vec_stride, _ptr(coef), _ptr(alpha), _dt(alpha), eps, D,
-                                    axes[0], axes[1], axes[2], _ptr(dy), _ptr(r1), _stream()), "hicom_adapt_dy_fwd")
+                                    axes[0], axes[1], axes[2], _ptr(dy), _ptr(r1), _ptr(parts), parts.shape[0] if colsum else 0, _stream()),
+           "hicom_adapt_dy_fwd")
+    if not colsum:
+        return None
+    out = torch.empty((D,), dtype=torch.float32, device=dy.device)
+    partials_sum(parts, out)
+    return out
 
 
 def gelu_split(h16, a16, abf):
     _check(lib().hicom_gelu_split_fwd(_ptr(h16), _ptr(a16), _ptr(abf), h16.numel(), _stream()), "hicom_gelu_split_fwd")
 
 
-def gelu_bwd_(da_bf16, h16):
-    _check(lib().hicom_gelu_bwd_fwd(_ptr(da_bf16), _ptr(h16), da_bf16.numel(), _stream()), "hicom_gelu_bwd_fwd")
+def gelu_bwd_(da_bf16, h16, colsum=False):
+    """da *= GELU'(h) in place; colsum=True (rows of 1152 / 768): also returns the column sums of the result (f32 [D])."""
+    D = da_bf16.shape[-1]
+    parts = _col_parts(da_bf16.shape[0], D, da_bf16.device) if colsum else None
+    _check(lib().hicom_gelu_bwd_fwd(_ptr(da_bf16), _ptr(h16), da_bf16.numel(), D, _ptr(parts), parts.shape[0] if colsum else 0, _stream()),
+           "hicom_gelu_bwd_fwd")
+    if not colsum:
+        return None
+    out = torch.empty((D,), dtype=torch.float32, device=da_bf16.device)
+    partials_sum(parts, out)
+    return out
 
 
 def colsum(x_bf16, nparts=128):
@@ -557,9 +582,10 @@ def to_f16_padded(src, ld, dst=None):
 
 
 def dense16_gemm(a, w, b, N=None, K=None, act=ACT_NONE, out_f16=None, n_store=None, y=None, res=None, ssq=None, row_tab=None,
-                 row_dot=None):
+                 row_dot=None, pre_f16=None):
     """C = epi(A . W^T + b) on matrix cores; a [M, lda], w [N, ldw] both fp16 or both bf16 (see include/hicom_hip.h).
-    row_dot = (vec [N] bf16 | f32, parts f32 [ceil(N/64), M]): per-slice partials of vec . (value + res) per row."""
+    row_dot = (vec [N] bf16 | f32, parts f32 [ceil(N/64), M]): per-slice partials of vec . (value + res) per row.
+    pre_f16: fp16 [M, >= N] that receives acc + b before the activation."""
     if a.dtype != w.dtype or a.dtype not in (torch.float16, torch.bfloat16):
         raise HicomNativeError("dense16_gemm: operands are both fp16 or both bf16")
     M = a.shape[0]
@@ -568,6 +594,7 @@ def dense16_gemm(a, w, b, N=None, K=None, act=ACT_NONE, out_f16=None, n_store=No
     _check(lib().hicom_dense16_gemm_fwd(_ptr(a), a.shape[1], _ptr(w), w.shape[1], _dt(a), _ptr(b), _dt(b) if b is not None else 0,
                                         M, N, K, act, _ptr(out_f16), out_f16.shape[1] if out_f16 is not None else 0,
                                         (out_f16.shape[1] if n_store is None else n_store) if out_f16 is not None else 0,
+                                        _ptr(pre_f16), pre_f16.shape[1] if pre_f16 is not None else 0,
                                         _ptr(y), _dt(y) if y is not None else 0, y.shape[1] if y is not None else 0,
                                         _ptr(res), res.shape[1] if res is not None else 0, _ptr(ssq),
                                         _ptr(row_tab[0]) if row_tab else None, row_tab[0].shape[1] if row_tab else 0,

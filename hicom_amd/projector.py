@@ -323,8 +323,10 @@ class LocalCompressor(nn.Module):
             raise NotImplementedError(f"LocalCompressor: use_guide={self.use_guide!r}")
 
     # -- attention context: [Nw, D] fp32 -----------------------------------------------------
-    def window_context(self, frames_feature, frames_embed, guide_embed, modal, logit_scale, logit_bias):
-        """Operator-by-operator form of ref :524-558 (everything before the readout), all variants."""
+    def window_context(self, frames_feature, frames_embed, guide_embed, modal, logit_scale, logit_bias, adapt_y=None):
+        """Operator-by-operator form of ref :524-558 (everything before the readout), all variants.
+        adapt_y = (y_k, y_v): the adaptor MLPs' outputs over all tokens (fp16 [N, D] or None each) when the caller already has them
+        (the backward pass computes them with their intermediates): the four dense GEMMs are then not run again."""
         from . import injector as inj
         self._check_native()
         _require_bf16_cuda("frames_feature", frames_feature)
@@ -371,13 +373,18 @@ class LocalCompressor(nn.Module):
         # blend fused into the window kernel's row loads (the blended streams are never written)
         fuse_blend = (self.adapt_k or self.adapt_v) and l2norm == 0
         ky = vy = None
+        have_y = adapt_y is not None and fuse_blend
         if self.adapt_k:                                               # ref :533
-            if fuse_blend:
+            if have_y:
+                ky = adapt_y[0]
+            elif fuse_blend:
                 ky = inj.adapt_stream_y(key, self.k_proj)
             else:
                 key = inj.adapt_stream(key, self.k_proj, self.k_norm, self.k_alpha)
         if self.adapt_v:                                               # ref :534
-            if fuse_blend:
+            if have_y:
+                vy = adapt_y[1]
+            elif fuse_blend:
                 vy = inj.adapt_stream_y(ff, self.v_proj)
             else:
                 value = inj.adapt_stream(ff, self.v_proj, self.v_norm, self.v_alpha)

@@ -93,7 +93,9 @@ int hicom_local_attn_adapt_fwd(const void* key_x, const void* key_y, const void*
  * hicom_adapt_dy_fwd continues into the adaptor MLP: dy[tok] = d/dy of alpha LN(y) gamma for the upstream gradient coef[tok] * vec[w(tok)]
  * (K: coef = ds, vec = q; V: coef = pw, vec = dctx), written as bf16 [N, D]; r1 (may be NULL) = (1 - alpha) coef[tok] vec[w] as bf16, the
  * x-branch of d frames_embed.  hicom_gelu_split_fwd / hicom_gelu_bwd_fwd / hicom_colsum_fwd: the elementwise steps of the adaptor-MLP backward
- * (a = GELU(h) as fp16 and bf16; da *= GELU'(h) in place; partial column sums [nparts][D] for the bias gradients). */
+ * (a = GELU(h) as fp16 and bf16; da *= GELU'(h) in place; partial column sums [nparts][D] for the bias gradients).
+ * hicom_adapt_dy_fwd and hicom_gelu_bwd_fwd leave the column partials of what they write themselves when col_parts (f32 [nparts][D],
+ * summed by hicom_partials_sum_fwd) is given: `nparts` workgroups then walk the rows -- no separate pass for the bias gradients. */
 int hicom_local_attn_adapt_bwd(const void* key_x, const void* key_y, const void* k_gamma, const void* k_beta, const void* k_alpha,
                                const void* value_x, const void* value_y, const void* v_gamma, const void* v_beta, const void* v_alpha,
                                int32_t alpha_dt, float eps, int32_t D, hicom_axis at, hicom_axis ay, hicom_axis ax,
@@ -101,9 +103,9 @@ int hicom_local_attn_adapt_bwd(const void* key_x, const void* key_y, const void*
                                const float* dctx, float* ds, float* pw, float* sxk, float* syk, float* sxv, float* syv, void* stream);
 int hicom_adapt_dy_fwd(const void* y, const void* gamma, const void* vec, int32_t vec_dt, int64_t vec_stride, const float* coef,
                        const void* alpha, int32_t alpha_dt, float eps, int32_t D, hicom_axis at, hicom_axis ay, hicom_axis ax,
-                       void* dy, void* r1, void* stream);
-int hicom_gelu_split_fwd(const void* h_f16, void* a_f16, void* a_bf16, int64_t n, void* stream);
-int hicom_gelu_bwd_fwd(void* da_bf16, const void* h_f16, int64_t n, void* stream);
+                       void* dy, void* r1, float* col_parts, int32_t nparts, void* stream);
+int hicom_gelu_split_fwd(const void* h_f16, void* a_f16 /* may be NULL */, void* a_bf16, int64_t n, void* stream);
+int hicom_gelu_bwd_fwd(void* da_bf16, const void* h_f16, int64_t n, int32_t D, float* col_parts, int32_t nparts, void* stream);
 int hicom_colsum_fwd(const void* x_bf16, int64_t N, int32_t D, float* parts, int32_t nparts, void* stream);
 
 /* ---- backward of the windowed attention (training path; autograd through projector.py:550-553) ----------
@@ -402,6 +404,8 @@ int hicom_merge_vproj_fixed_fwd(const float* part_m, const float* part_l, const 
  * K % 64 == 0 (pad with zero columns), fp32 accumulation; act NONE | GELU (erf) | GELU_TANH.  Outputs, any subset:
  *   out_f16 [M, ldo] fp16 (saturating): the activated value; columns [N, n_store) are written as zeros (the K padding
  *           of a following GEMM);
+ *   pre_f16 [M, ldpre] fp16 (saturating; may be NULL): acc + b BEFORE the activation -- what the activation's backward needs, kept by
+ *           the training forward of the adaptor MLPs (needs N % 8 == 0, ldpre % 8 == 0, 16-byte aligned rows);
  *   y [M, ldy] bf16 | f32: value + res[m, n] (res bf16 [M, ldr] or NULL);
  *   ssq f32 [ceil(N/64)][M]: partial row sums of squares of (acc + b) per 64-column slice, summed by the consumer (key norms of the
  *           clip-scale global stage, projector.py:184-186).
@@ -416,7 +420,7 @@ int hicom_merge_vproj_fixed_fwd(const float* part_m, const float* part_l, const 
  * (encoder.py:284-286), the k / v adaptor MLPs (projector.py:533-534). */
 int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w, int64_t ldw, int32_t operand_dt,
                            const void* b, int32_t b_dt, int32_t M, int32_t N, int32_t K, int32_t act,
-                           void* out_f16, int64_t ldo, int32_t n_store,
+                           void* out_f16, int64_t ldo, int32_t n_store, void* pre_f16, int64_t ldpre,
                            void* y, int32_t y_dt, int64_t ldy, const void* res, int64_t ldr,
                            float* ssq, const float* row_tab, int64_t row_tab_ld, int32_t tab_H, int32_t tab_W,
                            int32_t tab_t0, int32_t tab_y0, int32_t tab_x0,
@@ -615,6 +619,8 @@ typedef struct hicom_compressor_args {
         const void *w2_f16, *b2;   /* Linear(E, E): fp16 copy of the weight (cached by the caller per weight state), bf16 bias */
         const void *gamma, *beta;  /* LayerNorm: bf16 [E] */
         const void* alpha;         /* device scalar, dtype adapt_alpha_dt */
+        const void* y;             /* optional: fp16 [T*H*W, E] = MLP(x) of this stream, already computed by the caller (the training
+                                    * forward keeps the MLP's intermediates for its backward): the adaptor's two GEMMs are skipped */
     } ak, av;
     int32_t adapt_alpha_dt;
     float adapt_eps;

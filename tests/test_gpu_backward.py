@@ -207,6 +207,51 @@ def test_adaptor_gradients_at_27x27_by_finite_differences():
         assert abs(got - fd) <= 0.05 * abs(fd) + 1e-3, (which, got, fd)
 
 
+def test_adaptor_intermediates_of_the_training_forward_are_shared_with_the_backward():
+    """adaptkv: the training forward runs the k / v adaptor MLPs itself and keeps (h1, GELU(h1), y) in a per-shape store for the
+    backward (no recomputation); the executor gets y (hicom_adaptor.y).  Gradients equal the recomputing backward's
+    (`share_adaptor_activations = False`) bit for bit -- same kernels on the same data -- in the eager, the capturing and the replayed
+    step, and a backward whose forward was NOT the last one of its shape (two forwards, then two backwards) refills the store from
+    its own inputs instead of reading the other forward's intermediates."""
+    from types import SimpleNamespace
+    from hicom_amd import synth
+    from oracle import hicom_oracle as orc
+    T = 8
+    cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "hidden_size": 896, "max_num_frames": T, "mm_projector_type": "local43_adaptkv_global32"})
+    sd = synth.synth_state_dict(orc.param_shapes(cfg), tag="adaptshare")
+    m = build_module(SimpleNamespace(cfg=cfg, sd=sd)).train()
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    mk = lambda: (torch.randn(T, 27, 27, 1152, device="cuda", generator=gen).bfloat16(), torch.randn(T, 27, 27, 1152, device="cuda", generator=gen).bfloat16(),
+                  torch.randn(1152, device="cuda", generator=gen).bfloat16())
+    a, b = mk(), mk()
+    cot = torch.randn(T // 4 * 81 + 32, 896, device="cuda", generator=gen)
+
+    def grads_of(inp, share):
+        m.share_adaptor_activations = share
+        m.zero_grad(set_to_none=True)
+        (m(*inp, "video", None).float() * cot).sum().backward()
+        return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    ref_a, ref_b = grads_of(a, False), grads_of(b, False)
+    ref_a2 = grads_of(a, False)                                     # (second and third sight of the shape: capture, replay)
+    assert all(torch.equal(ref_a[n], ref_a2[n]) for n in ref_a)
+    for _ in range(3):                                              # eager, capture, replay with the store
+        got = grads_of(a, True)
+        assert set(got) == set(ref_a) and all(torch.equal(got[n], ref_a[n]) for n in ref_a)
+    assert any("k_proj.0.weight" in n for n in ref_a) and float(ref_a["local_compressor.k_proj.0.weight"].abs().max()) > 0
+    # two forwards, then the backwards in the order a, b: a's backward finds b's intermediates in the store
+    m.share_adaptor_activations = True
+    m.zero_grad(set_to_none=True)
+    oa, ob = m(*a, "video", None), m(*b, "video", None)
+    (oa.float() * cot).sum().backward()
+    ga = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad(set_to_none=True)
+    (ob.float() * cot).sum().backward()
+    gb = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    assert all(torch.equal(ga[n], ref_a[n]) for n in ref_a) and all(torch.equal(gb[n], ref_b[n]) for n in ref_b)
+    assert not torch.equal(ref_a["local_compressor.k_proj.0.weight"], ref_b["local_compressor.k_proj.0.weight"])
+
+
 def test_graph_backward_equals_eager():
     """`proj.graph_backward = True` (opt-in): the backward of a plain recipe captured into a hipGraph on its second use with the same
     input buffers and replayed afterwards.  Same kernels, same order: the gradients of the eager, the capturing and the replayed step

@@ -96,6 +96,26 @@ def test_dense16_gemm_matches_torch(M, N, K, dt):
     assert float((ssq.sum(0).double() - (ref ** 2).sum(1)).abs().max()) <= 1e-4 * float((ref ** 2).sum(1).max())
 
 
+def test_dense16_pre_activation_output():
+    """pre_f16: acc + b BEFORE the activation as a second fp16 output of the same launch (the training forward of the adaptor MLPs
+    keeps it for GELU'): equals the activation-free launch bit for bit, and the activated output is unchanged by asking for it."""
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 1300, 1152, 192
+    a = (torch.randn(M, K, generator=g) * 0.5).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+    b = (torch.randn(N, generator=g) * 0.1).bfloat16().cuda()
+    act0, act1, pre, plain = (torch.empty(M, N, dtype=torch.float16, device="cuda") for _ in range(4))
+    nv.dense16_gemm(a, w, b, act=nv.ACT_GELU, out_f16=act0)
+    nv.dense16_gemm(a, w, b, act=nv.ACT_GELU, out_f16=act1, pre_f16=pre)
+    nv.dense16_gemm(a, w, b, act=nv.ACT_NONE, out_f16=plain)
+    torch.cuda.synchronize()
+    assert torch.equal(act0, act1) and torch.equal(pre, plain)
+    ref = a.double() @ w.double().t() + b.double()
+    assert float((pre.double() - ref).abs().max()) <= 2 ** -10 * max(1.0, float(ref.abs().max()))
+    with pytest.raises(nv.HicomNativeError):                      # N % 8 != 0: no row epilogue
+        nv.dense16_gemm(a, w[:132], b[:132], act=nv.ACT_GELU, out_f16=act1[:, :136], n_store=136, pre_f16=pre[:, :136])
+
+
 @pytest.mark.parametrize("vec_dt", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("M,N,K,with_y", [(200, 136, 128, True), (1000, 1152, 192, False), (4099, 1152, 128, True)])
 def test_dense16_row_dot_epilogue(M, N, K, with_y, vec_dt):

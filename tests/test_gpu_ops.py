@@ -761,6 +761,43 @@ def test_readout16_aux_gemv_f32_weights_and_row_output():
     assert maxabs(o16, a16.double() @ w16.double().t()) <= 2 ** -10 * float((a16.double() @ w16.double().t()).abs().max())
 
 
+def test_streaming_backward_kernels_leave_their_column_sums():
+    """hicom_gelu_bwd_fwd / hicom_adapt_dy_fwd with col_parts: the bias gradients (column sums of what the launch writes, as stored)
+    come out of the same launch -- equal to summing the written matrix, and the matrix itself equals the launch without them;
+    hicom_partials_sum_fwd in its many-partials form against torch."""
+    g = torch.Generator(device="cuda").manual_seed(2)
+    N, Dm = 16 * 6 * 6, 1152
+    h = (torch.randn(N, Dm, device="cuda", generator=g) * 1.5).half()
+    da0 = torch.randn(N, Dm, device="cuda", generator=g).bfloat16()
+    a, b = da0.clone(), da0.clone()
+    assert nv.gelu_bwd_(a, h) is None
+    cs = nv.gelu_bwd_(b, h, colsum=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    hf = h.float()
+    want = da0.float() * (0.5 * (1 + torch.erf(hf / math.sqrt(2))) + hf * torch.exp(-hf * hf / 2) / math.sqrt(2 * math.pi))
+    assert maxabs(a.float(), want) <= 2 ** -7 * float(want.abs().max())
+    assert maxabs(cs, b.float().sum(0)) <= 1e-4 * max(1.0, float(b.float().sum(0).abs().max()))
+    # adapt_dy on a 16 x 6 x 6 grid with 4 x 3 x 3 windows
+    axes = tuple(nv.Axis(ax.n, ax.k, ax.nwin, ax.nfull) for ax in (geo.axis_tiling(16, 4), geo.axis_tiling(6, 3), geo.axis_tiling(6, 3)))
+    y = torch.randn(N, Dm, device="cuda", generator=g).half()
+    gamma = (1 + 0.1 * torch.randn(Dm, device="cuda", generator=g)).bfloat16()
+    vec = torch.randn(16, Dm, device="cuda", generator=g)
+    coef = torch.randn(N, device="cuda", generator=g)
+    alpha = torch.full((1,), 0.5, device="cuda").bfloat16()
+    d0, d1 = torch.empty(N, Dm, device="cuda", dtype=torch.bfloat16), torch.empty(N, Dm, device="cuda", dtype=torch.bfloat16)
+    nv.adapt_dy(y, gamma, vec, Dm, coef, alpha, axes, d0)
+    cs = nv.adapt_dy(y, gamma, vec, Dm, coef, alpha, axes, d1, colsum=True)
+    torch.cuda.synchronize()
+    assert torch.equal(d0, d1) and float(d0.float().abs().max()) > 0
+    assert maxabs(cs, d1.float().sum(0)) <= 1e-4 * max(1.0, float(d1.float().sum(0).abs().max()))
+    for nparts, M in ((1024, 1152), (100, 70), (64, 16)):
+        parts = torch.randn(nparts, M, device="cuda", generator=g)
+        out = torch.empty(M, device="cuda")
+        nv.partials_sum(parts, out)
+        assert maxabs(out, parts.double().sum(0).float()) <= 1e-4
+
+
 @pytest.mark.parametrize("which", ["both", "key", "value"])
 @pytest.mark.parametrize("T,H,W,kt,ks,shared_query", [(4, 6, 6, 4, 3, True), (7, 6, 9, 4, 3, False), (1, 4, 4, 1, 2, False)])
 def test_local_attn_adapt_matches_torch(T, H, W, kt, ks, shared_query, which):
