@@ -864,6 +864,60 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
+// tanh form (HF gelu_pytorch_tanh, the SigLIP head's activation) and its derivative:  g(x) = x s(2u),  u = c0 (x + c1 x^3),
+// s = logistic;  g'(x) = s + x s (1 - s) 2 c0 (1 + 3 c1 x^2)
+__device__ __forceinline__ float gelu_tanh_val(float x) {
+    const float t = x * x;
+    const float arg = x * fmaf(t, -0.10294324f, -2.3022082f);                             // -2u log2(e)
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(arg));
+}
+__device__ __forceinline__ float gelu_tanh_grad(float x) {
+    const float t = x * x;
+    const float arg = x * fmaf(t, -0.10294324f, -2.3022082f);
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(arg));
+    const float du2 = 1.5957691216f * fmaf(0.134145f, t, 1.0f);                            // d(2u)/dx = 2 c0 (1 + 3 c1 x^2)
+    return fmaf(x * sg * (1.0f - sg), du2, sg);
+}
+
+// Pitched forms for the head projection's hidden layer ([M, 4304] inside rows of 4544 fp16 elements):
+//   act_rows:      a_bf16[r, c] = act(h[r, c])                  (operand of dW2 = dY^T a; dense [rows, cols])
+//   act_bwd_rows:  da[r, c]    *= act'(h[r, c])  in place       (dense [rows, cols] bf16)
+// cols % 8 == 0; one 16-byte vector per thread.  TANH: gelu_pytorch_tanh, else erf.
+template <bool TANH>
+__global__ __launch_bounds__(256) void act_rows_kernel(const _Float16* h, long ldh, long rows, int c8, uint16_t* abf) {
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * c8) return;
+    const long r = i / c8;
+    const int c = (int)(i - r * c8);
+    const half8 hv = *reinterpret_cast<const half8*>(h + r * ldh + 8 * c);
+    u32x4 bv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float lo = TANH ? gelu_tanh_val((float)hv[2 * e]) : gelu_erf((float)hv[2 * e]);
+        const float hi = TANH ? gelu_tanh_val((float)hv[2 * e + 1]) : gelu_erf((float)hv[2 * e + 1]);
+        bv[e] = f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    }
+    reinterpret_cast<u32x4*>(abf)[i] = bv;
+}
+template <bool TANH>
+__global__ __launch_bounds__(256) void act_bwd_rows_kernel(uint16_t* da, const _Float16* h, long ldh, long rows, int c8) {
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * c8) return;
+    const long r = i / c8;
+    const int c = (int)(i - r * c8);
+    const half8 hv = *reinterpret_cast<const half8*>(h + r * ldh + 8 * c);
+    u32x4 d = reinterpret_cast<const u32x4*>(da)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float g0 = TANH ? gelu_tanh_grad((float)hv[2 * e]) : gelu_erf_grad((float)hv[2 * e]);
+        const float g1 = TANH ? gelu_tanh_grad((float)hv[2 * e + 1]) : gelu_erf_grad((float)hv[2 * e + 1]);
+        d[e] = f32_to_bf16(bf16lo_to_f32(d[e]) * g0) | ((uint32_t)f32_to_bf16(bf16hi_to_f32(d[e]) * g1) << 16);
+    }
+    reinterpret_cast<u32x4*>(da)[i] = d;
+}
+
 // a16 = GELU(h) as fp16 (operand of the recomputed second GEMM) and abf = GELU(h) as bf16 (operand of dW2 = dy^T a): n elements, n % 8 == 0
 __global__ __launch_bounds__(256) void gelu_split_kernel(const _Float16* h, _Float16* a16, uint16_t* abf, long n8) {
     typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -1167,6 +1221,26 @@ extern "C" int hicom_gelu_bwd_fwd(void* da_bf16, const void* h_f16, int64_t n, i
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)da_bf16, (const _Float16*)h_f16,
                        (long)(n / 8));
     return hicom_host::check_launch("gelu_bwd");
+}
+
+extern "C" int hicom_act_rows_fwd(const void* h_f16, int64_t ldh, int64_t rows, int32_t cols, int32_t act, void* a_bf16, void* stream) {
+    HICOM_REQUIRE(h_f16 && a_bf16 && rows > 0 && cols > 0 && cols % 8 == 0 && ldh >= cols && ldh % 8 == 0 && ((uintptr_t)h_f16 % 16 == 0) &&
+                      ((uintptr_t)a_bf16 % 16 == 0) && (act == HICOM_ACT_GELU || act == 2), HICOM_EINVAL,
+                  "act_rows: bad arguments (cols, ldh %% 8; 16-byte alignment; act GELU | GELU_TANH)");
+    const long n = rows * (cols / 8);
+    if (act == 2) hipLaunchKernelGGL(act_rows_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)h_f16, (long)ldh, (long)rows, cols / 8, (uint16_t*)a_bf16);
+    else hipLaunchKernelGGL(act_rows_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)h_f16, (long)ldh, (long)rows, cols / 8, (uint16_t*)a_bf16);
+    return hicom_host::check_launch("act_rows");
+}
+
+extern "C" int hicom_act_bwd_rows_fwd(void* da_bf16, const void* h_f16, int64_t ldh, int64_t rows, int32_t cols, int32_t act, void* stream) {
+    HICOM_REQUIRE(h_f16 && da_bf16 && rows > 0 && cols > 0 && cols % 8 == 0 && ldh >= cols && ldh % 8 == 0 && ((uintptr_t)h_f16 % 16 == 0) &&
+                      ((uintptr_t)da_bf16 % 16 == 0) && (act == HICOM_ACT_GELU || act == 2), HICOM_EINVAL,
+                  "act_bwd_rows: bad arguments (cols, ldh %% 8; 16-byte alignment; act GELU | GELU_TANH)");
+    const long n = rows * (cols / 8);
+    if (act == 2) hipLaunchKernelGGL(act_bwd_rows_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)da_bf16, (const _Float16*)h_f16, (long)ldh, (long)rows, cols / 8);
+    else hipLaunchKernelGGL(act_bwd_rows_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)da_bf16, (const _Float16*)h_f16, (long)ldh, (long)rows, cols / 8);
+    return hicom_host::check_launch("act_bwd_rows");
 }
 
 extern "C" int hicom_colsum_fwd(const void* x_bf16, int64_t N, int32_t D, float* parts, int32_t nparts, void* stream) {

@@ -78,15 +78,21 @@ class _HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, head, hidden_act, *params):
         with torch.no_grad():
-            out = _head_chain(x, head, hidden_act, None, None, True)[0]
+            keep = {} if getattr(head, "keep_hidden_for_backward", True) else None
+            out = _head_chain(x, head, hidden_act, None, None, True, keep=keep)[0]
         ctx.head, ctx.hidden_act = head, hidden_act
-        ctx.save_for_backward(x)
+        # the pre-activation hidden layer (second output of fc1's epilogue: 0.4 GB fp16 at 64 frames) stays for the backward, as autograd
+        # keeps it in the reference; `head.keep_hidden_for_backward = False` recomputes it instead (gradient checkpointing)
+        if keep is not None and "h1" in keep:
+            ctx.save_for_backward(x, keep["h1"])
+        else:
+            ctx.save_for_backward(x)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         global LAST_FP32_GRADS
-        (x,) = ctx.saved_tensors
+        x, h1 = ctx.saved_tensors if len(ctx.saved_tensors) == 2 else (ctx.saved_tensors[0], None)
         if ctx.needs_input_grad[0]:
             raise NotImplementedError("siglip_head_embed backward: the gradient w.r.t. the tower's hidden states is not built (the "
                                       "tower body is frozen in every stage of the reference's script, train.py:703); detach them")
@@ -100,17 +106,23 @@ class _HeadFn(torch.autograd.Function):
             w1, w2, kpad, ld = _head_cache(head, store=False)
             inter = fc1.weight.shape[0]
             dY = d_out.contiguous().view(M, D)
-            # ---- recompute (HIP): normalised tokens, pre-activation hidden layer ------------------------------------------
-            n16 = torch.empty((M, D), dtype=torch.float16, device=x.device)
-            nv.ln_stream(x2, ln.weight.detach(), ln.bias.detach(), n16, eps=ln.eps)
-            h1 = torch.empty((M, ld), dtype=torch.float16, device=x.device)
-            nv.dense16_gemm(n16, w1, fc1.bias.detach(), act=nv.ACT_NONE, out_f16=h1, n_store=kpad)
+            # ---- the pre-activation hidden layer: kept by the forward, else recomputed (HIP) ------------------------------------
+            if h1 is None:
+                n16 = torch.empty((M, D), dtype=torch.float16, device=x.device)
+                nv.ln_stream(x2, ln.weight.detach(), ln.bias.detach(), n16, eps=ln.eps)
+                h1 = torch.empty((M, ld), dtype=torch.float16, device=x.device)
+                nv.dense16_gemm(n16, w1, fc1.bias.detach(), act=nv.ACT_NONE, out_f16=h1, n_store=kpad)
+                del n16
             # the [M, inter] tensors (0.4 GB each in bf16 at 64 frames) are touched as few times as possible: one cast of the
             # pre-activation, one fused GELU, one fused GELU-backward (fp32 math inside, bf16 in / out), fp32 only in the reductions
             approx = "tanh" if hidden_act == "gelu_pytorch_tanh" else "none"
-            h1b = h1[:, :inter].to(torch.bfloat16)
-            del h1
-            a_b = torch.nn.functional.gelu(h1b, approximate=approx)
+            hip_act = inter % 8 == 0 and hidden_act in _ACTS and _ACTS[hidden_act] in (nv.ACT_GELU, nv.ACT_GELU_TANH)
+            if hip_act:
+                a_b = nv.act_rows(h1, inter, _ACTS[hidden_act])             # HIP: GELU of the pitched fp16 rows -> dense bf16
+                h1b = None
+            else:
+                h1b = h1[:, :inter].to(torch.bfloat16)
+                a_b = torch.nn.functional.gelu(h1b, approximate=approx)
             # ---- fc2: dW2 = dY^T a, db2, d a = dY W2 --------------------------------------------------------------------------
             dYb = dY.to(torch.bfloat16)
             grads = {}
@@ -123,20 +135,25 @@ class _HeadFn(torch.autograd.Function):
                 nv.dense16_gemm(dYb, w2t, None, y=da)                        # HIP: bf16 x bf16, fp32 accumulate
             else:
                 da = torch.mm(dYb, fc2.weight.detach())
-            # ---- activation, fc1: dW1 = dh1^T n, db1, d n = dh1 W1 ---------------------------------------------------------------
-            dh1b = torch.ops.aten.gelu_backward(da, h1b, approximate=approx)
-            del da, h1b
-            nb = n16.to(torch.bfloat16)
-            grads["mlp.fc1.weight"] = _tn_f32(dh1b, nb)
-            grads["mlp.fc1.bias"] = dh1b.sum(0, dtype=torch.float32)
-            dn = _mm_f32(dh1b, fc1.weight.detach())                         # [M, D]
-            del dh1b
-            # ---- LayerNorm affine: n = nhat gamma + beta ---------------------------------------------------------------------------
-            xf = x2.float()
-            mu = xf.mean(-1, keepdim=True)
-            nhat = (xf - mu) * torch.rsqrt(xf.var(-1, unbiased=False, keepdim=True) + ln.eps)
-            grads["layernorm.weight"] = (dn * nhat).sum(0)
-            grads["layernorm.bias"] = dn.sum(0)
+            # ---- activation, fc1 and the LayerNorm affine from ONE token contraction -------------------------------------------
+            # With n = nhat gamma + beta and G = dh1^T nhat ([inter, D], the TN GEMM against the NORMALISED tokens):
+            #   dW1 = G gamma + db1 (x) beta,   d gamma = sum_j W1[j, :] G[j, :],   d beta = W1^T db1
+            # -- the gradients of the LayerNorm affine need neither d n = dh1 W1 (a 0.46-TFLOP GEMM for 2 x 1152 numbers) nor an
+            # fp32 recomputation of nhat over all tokens.
+            dh1b = nv.act_bwd_rows_(da, h1, _ACTS[hidden_act]) if hip_act else torch.ops.aten.gelu_backward(da, h1b, approximate=approx)
+            del da, h1b, h1
+            ones, zeros = torch.ones(D, dtype=torch.bfloat16, device=x.device), torch.zeros(D, dtype=torch.bfloat16, device=x.device)
+            nhat = torch.empty((M, D), dtype=torch.bfloat16, device=x.device)
+            nv.ln_stream(x2, ones, zeros, nhat, eps=ln.eps)                  # HIP: normalised tokens, no affine
+            G = _tn_f32(dh1b, nhat)
+            db1 = dh1b.sum(0, dtype=torch.float32)
+            del dh1b, nhat
+            gamma, beta = ln.weight.detach().float(), ln.bias.detach().float()
+            w1f = fc1.weight.detach().float()
+            grads["mlp.fc1.weight"] = G * gamma[None, :] + db1[:, None] * beta[None, :]
+            grads["mlp.fc1.bias"] = db1
+            grads["layernorm.weight"] = (w1f * G).sum(0)
+            grads["layernorm.bias"] = (w1f * db1[:, None]).sum(0)
         LAST_FP32_GRADS = grads
         names = ("layernorm.weight", "layernorm.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
         plist = _head_params(head)
@@ -175,7 +192,7 @@ def siglip_head_scores(last_hidden_state: torch.Tensor, head, guide_embed: torch
     return (logits, out) if return_embed else logits
 
 
-def _head_chain(last_hidden_state, head, hidden_act, out_dtype, guide, want_embed):
+def _head_chain(last_hidden_state, head, hidden_act, out_dtype, guide, want_embed, keep=None):
     from .projector import _require_bf16_cuda
     x = last_hidden_state
     _require_bf16_cuda("last_hidden_state", x)
@@ -196,7 +213,10 @@ def _head_chain(last_hidden_state, head, hidden_act, out_dtype, guide, want_embe
     a16 = torch.empty((M, D), dtype=torch.float16, device=x.device)
     nv.ln_stream(x2, ln.weight.detach(), ln.bias.detach(), a16, eps=ln.eps)
     hid = torch.empty((M, ld), dtype=torch.float16, device=x.device)
-    nv.dense16_gemm(a16, w1, fc1.bias.detach(), act=_ACTS[hidden_act], out_f16=hid, n_store=kpad)
+    pre = None
+    if keep is not None and fc1.weight.shape[0] % 8 == 0:              # training forward: fc1's value before the activation as well
+        pre = keep["h1"] = torch.empty((M, ld), dtype=torch.float16, device=x.device)
+    nv.dense16_gemm(a16, w1, fc1.bias.detach(), act=_ACTS[hidden_act], out_f16=hid, n_store=kpad, pre_f16=pre)
     out = torch.empty((M, D), dtype=out_dtype or x.dtype, device=x.device) if want_embed else None
     parts = torch.empty(((D + 63) // 64, M), dtype=torch.float32, device=x.device) if guide is not None else None
     nv.dense16_gemm(hid, w2, fc2.bias.detach(), N=D, K=kpad, y=out, res=x2, row_dot=(guide, parts) if guide is not None else None)

@@ -35,6 +35,7 @@ EXPORTS = (
     "hicom_small_mha_scaled_fwd", "hicom_merge_vproj_fixed_fwd", "hicom_dense16_tn_fwd", "hicom_dense16_tn_splits",
     "hicom_local_attn_adapt_bwd", "hicom_adapt_dy_fwd", "hicom_gelu_split_fwd", "hicom_gelu_bwd_fwd", "hicom_colsum_fwd",
     "hicom_global_stream_marg_fwd", "hicom_global_stream_marg_width", "hicom_global_stream_has_marg", "hicom_global_merge_marg_fwd",
+    "hicom_act_rows_fwd", "hicom_act_bwd_rows_fwd",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -154,6 +155,8 @@ def lib() -> C.CDLL:
     L.hicom_adapt_dy_fwd.argtypes = [vp, vp, vp, i32, i64, vp, vp, i32, f32, i32, Axis, Axis, Axis, vp, vp, vp, i32, vp]
     L.hicom_gelu_split_fwd.argtypes = [vp, vp, vp, i64, vp]
     L.hicom_gelu_bwd_fwd.argtypes = [vp, vp, i64, i32, vp, i32, vp]
+    L.hicom_act_rows_fwd.argtypes = [vp, i64, i64, i32, i32, vp, vp]
+    L.hicom_act_bwd_rows_fwd.argtypes = [vp, vp, i64, i64, i32, i32, vp]
     L.hicom_colsum_fwd.argtypes = [vp, i64, i32, vp, i32, vp]
     L.hicom_clip_query_prep_fwd.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp]
     L.hicom_inv_norm_fwd.argtypes = [vp, i32, i64, vp, vp]
@@ -292,6 +295,22 @@ def gelu_bwd_(da_bf16, h16, colsum=False):
     out = torch.empty((D,), dtype=torch.float32, device=da_bf16.device)
     partials_sum(parts, out)
     return out
+
+
+def act_rows(h16, cols, act, out=None):
+    """bf16 [rows, cols] = act(h16[:, :cols]) for a pitched fp16 matrix (act: ACT_GELU | ACT_GELU_TANH)."""
+    rows = h16.shape[0]
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.bfloat16, device=h16.device)
+    _check(lib().hicom_act_rows_fwd(_ptr(h16), h16.shape[1], rows, cols, act, _ptr(out), _stream()), "hicom_act_rows_fwd")
+    return out
+
+
+def act_bwd_rows_(da_bf16, h16, act):
+    """da_bf16 [rows, cols] *= act'(h16[:, :cols]) in place."""
+    rows, cols = da_bf16.shape
+    _check(lib().hicom_act_bwd_rows_fwd(_ptr(da_bf16), _ptr(h16), h16.shape[1], rows, cols, act, _stream()), "hicom_act_bwd_rows_fwd")
+    return da_bf16
 
 
 def colsum(x_bf16, nparts=128):

@@ -105,6 +105,11 @@ int hicom_adapt_dy_fwd(const void* y, const void* gamma, const void* vec, int32_
                        const void* alpha, int32_t alpha_dt, float eps, int32_t D, hicom_axis at, hicom_axis ay, hicom_axis ax,
                        void* dy, void* r1, float* col_parts, int32_t nparts, void* stream);
 int hicom_gelu_split_fwd(const void* h_f16, void* a_f16 /* may be NULL */, void* a_bf16, int64_t n, void* stream);
+/* The same two steps for a hidden layer that lies inside pitched rows (the SigLIP head's [M, 4304] inside rows of 4544 fp16 elements,
+ * encoder.py:284-286) and for either activation (act = HICOM_ACT_GELU | 2 = gelu_pytorch_tanh): a_bf16 [rows, cols] = act(h[r, c]);
+ * da_bf16 [rows, cols] *= act'(h[r, c]) in place.  cols, ldh multiples of 8. */
+int hicom_act_rows_fwd(const void* h_f16, int64_t ldh, int64_t rows, int32_t cols, int32_t act, void* a_bf16, void* stream);
+int hicom_act_bwd_rows_fwd(void* da_bf16, const void* h_f16, int64_t ldh, int64_t rows, int32_t cols, int32_t act, void* stream);
 int hicom_gelu_bwd_fwd(void* da_bf16, const void* h_f16, int64_t n, int32_t D, float* col_parts, int32_t nparts, void* stream);
 int hicom_colsum_fwd(const void* x_bf16, int64_t N, int32_t D, float* parts, int32_t nparts, void* stream);
 

@@ -96,6 +96,24 @@ def test_dense16_gemm_matches_torch(M, N, K, dt):
     assert float((ssq.sum(0).double() - (ref ** 2).sum(1)).abs().max()) <= 1e-4 * float((ref ** 2).sum(1).max())
 
 
+@pytest.mark.parametrize("act,approx", [(nv.ACT_GELU_TANH, "tanh"), (nv.ACT_GELU, "none")])
+def test_pitched_activation_forward_and_backward(act, approx):
+    """hicom_act_rows_fwd / hicom_act_bwd_rows_fwd (the head backward's elementwise steps on the [M, 4304] hidden layer inside rows of
+    4544 fp16 elements) against torch's gelu / gelu_backward in fp32."""
+    g = torch.Generator(device="cuda").manual_seed(4)
+    rows, cols, ld = 777, 4304, 4544
+    h = (torch.randn(rows, ld, device="cuda", generator=g) * 2).half()
+    da = torch.randn(rows, cols, device="cuda", generator=g).bfloat16()
+    a = nv.act_rows(h, cols, act)
+    hf = h[:, :cols].float()
+    want_a = torch.nn.functional.gelu(hf, approximate=approx)
+    assert a.shape == (rows, cols) and float((a.float() - want_a).abs().max()) <= 2 ** -8 * float(want_a.abs().max()) + 2e-3
+    d = da.clone()
+    nv.act_bwd_rows_(d, h, act)
+    want_d = torch.ops.aten.gelu_backward(da.float(), hf, approximate=approx)
+    assert float((d.float() - want_d).abs().max()) <= 2 ** -7 * float(want_d.abs().max()) + 2e-3
+
+
 def test_dense16_pre_activation_output():
     """pre_f16: acc + b BEFORE the activation as a second fp16 output of the same launch (the training forward of the adaptor MLPs
     keeps it for GELU'): equals the activation-free launch bit for bit, and the activated output is unchanged by asking for it."""
