@@ -326,6 +326,15 @@ constexpr int kWideMargBlocks = 2;  // 16-column marginal blocks per wave (x 4 w
 // latency chain of a tile's softmax inside a wave (LDS exchange -> positional lookups -> max / exp / sum -> hi/lo split -> transposed
 // reads -> P.x) with two waves per SIMD to hide it.
 // ---------------------------------------------------------------------------------------------
+// Round 4: the softmax is DE-DUPLICATED.  Until then every one of the four channel-slice waves of a row group redid the whole tile's
+// softmax (logit exchange, positional lookups, max / exp / sum, hi / lo split: ~200 VALU instructions per wave and tile, four times
+// over) because each needs P as its MFMA operand.  Now a wave owns a QUARTER of the tile's rows: lane (row, token) holds one logit,
+// row max / sum are DPP row reductions, and P (bf16 hi | lo, already in A-operand order) and the rescale factors go through 2 KB
+// of LDS to all four waves -- a second barrier per tile again, a quarter of the VALU work: 248 -> 233 us alone at C2 (tools/wide_bench.py).
+// Same arithmetic per element (same fp32 logits, same exp, same split).  What is left is the tile's latency chain
+// (LDS exchange -> lookups -> DPP reductions -> exp -> LDS hand-over -> transposed reads -> MFMAs, ~5k clocks per 16 tokens, both
+// waves of a SIMD in the same phase): two tiles per barrier interval would overlap two such chains, and 160 KB of LDS hold four
+// 36-KB tiles, not the six that needs.
 template <int NB>
 __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams p) {
     constexpr int NBUF = 3, NRED = 2;
@@ -342,7 +351,9 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
     char* tilebuf = smem;                                                    // [NBUF][TILE_BYTES]
     float* red = reinterpret_cast<float*>(smem + NBUF * TILE_BYTES);        // [NRED][RG][4 waves][16 rows][16 tokens]
     int* tokpos = reinterpret_cast<int*>(red + NRED * RG * 4 * 256);        // [2][16] packed (frame - f_first) << 16 | y << 8 | x
-    float* postab = reinterpret_cast<float*>(tokpos + 32);                   // [RG * 16][kWideFrames + H + W]
+    uint16_t* pbuf = reinterpret_cast<uint16_t*>(tokpos + 32);              // [RG][16 rows][4 k groups][8] P of the current tile, A-operand order (hi x 4 | lo x 4)
+    float* alpha_s = reinterpret_cast<float*>(pbuf + RG * 16 * 4 * 8);       // [RG][16] rescale factors of the current tile
+    float* postab = alpha_s + RG * 16;                                       // [RG * 16][kWideFrames + H + W]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -383,7 +394,10 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
     f32x4 acc[CBLK];
 #pragma unroll
     for (int cb = 0; cb < CBLK; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // online-softmax state of row 4 * wave + (lane >> 4) of this wave's row group (replicated over the 16 token lanes of a DPP row):
+    // each of the four waves of a row group owns a QUARTER of the tile's rows
     float m_run = -1.0e30f, l_run = 0.f;
+    const int rl = lane >> 4, tok = lane & 15, srow = 4 * wave + rl;
 
     // positional marginals in the kernel (part_marg given): P[16 rows x 16 tokens] . onehot[16 tokens x 16 columns] on the matrix
     // pipe, one MFMA per 16-column block of [frame | grid row | grid column]; the blocks are dealt to the 4 waves of the row group
@@ -482,60 +496,53 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
         if (more) sn = scores_of(tilebuf + ((k + 1) % NBUF) * TILE_BYTES);
         __builtin_amdgcn_sched_barrier(0);
 
-        // ---- exchange / positional terms / online softmax of THIS tile (VALU + LDS, under the MFMAs above) ----
-        const long n0 = (long)tile * 16 + 4 * sig(kg);
-        const float* rb = red + (h * RG * 4 + grp * 4) * 256 + r16 * 16 + 4 * sig(kg);
-        f32x4 lg = *reinterpret_cast<const f32x4*>(rb);
-        lg += *reinterpret_cast<const f32x4*>(rb + 256);
-        lg += *reinterpret_cast<const f32x4*>(rb + 512);
-        lg += *reinterpret_cast<const f32x4*>(rb + 768);
+        // ---- softmax of THIS tile, a quarter of the rows per wave: lane (row srow, token tok) holds ONE logit ----
+        {
+            const float* rb = red + (h * RG * 4 + grp * 4) * 256 + srow * 16 + tok;
+            float lg = (rb[0] + rb[256]) + (rb[512] + rb[768]);
+            if (p.pos_a) {
+                const int tp = tokpos[16 * h + tok];
+                const float* pr_ = postab + (grp * 16 + srow) * S;
+                lg += pr_[tp >> 16] + pr_[kWideFrames + ((tp >> 8) & 255)] + pr_[kWideFrames + p.H + (tp & 255)];
+            }
+            const long n = (long)tile * 16 + tok;
+            if (p.scores) p.scores[((long)rg * 16 + srow) * p.score_stride + n] = lg;
+            const bool ok = n < p.N;
+            const float m_new = fmaxf(m_run, row16_max(ok ? lg : -1.0e30f));
+            const float alpha = fast_exp(m_run - m_new);
+            const float pr = ok ? fast_exp(lg - m_new) : 0.f;
+            l_run = l_run * alpha + row16_sum(pr);
+            m_run = m_new;
+            uint16_t hh, ll;
+            split_bf16(pr, hh, ll);
+            uint16_t* pb = pbuf + ((grp * 16 + srow) * 4 + sig(tok >> 2)) * 8 + (tok & 3);   // k slot 8 kg + j <-> token 4 sig(kg) + j
+            pb[0] = hh;
+            pb[4] = ll;
+            if (tok == 0) alpha_s[grp * 16 + srow] = alpha;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // P and the rescale factors of this tile are complete
+        asm volatile("" ::: "memory");
+
+        // ---- this wave's channel slice: rescale, marginals, P.x ----
+        const bf16x8 pw = *reinterpret_cast<const bf16x8*>(pbuf + ((grp * 16 + r16) * 4 + kg) * 8);
+        const f32x4 al = *reinterpret_cast<const f32x4*>(alpha_s + grp * 16 + 4 * kg);
         int tp[4] = {0, 0, 0, 0};
-        if (p.pos_a) {
+        if (marg_on) {
             int4 v;
             asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(tokpos_lds + 64 * h + 16 * sig(kg)) : "memory");
             tp[0] = v.x; tp[1] = v.y; tp[2] = v.z; tp[3] = v.w;
-            const float* pr_ = postab + (grp * 16 + r16) * S;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                lg[j] += pr_[tp[j] >> 16] + pr_[kWideFrames + ((tp[j] >> 8) & 255)] + pr_[kWideFrames + p.H + (tp[j] & 255)];
         }
-        if (wave == 0 && p.scores) *reinterpret_cast<f32x4*>(p.scores + row_glob * p.score_stride + n0) = lg;
-
-        float tmax = -1.0e30f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) tmax = (n0 + j < p.N) ? fmaxf(tmax, lg[j]) : tmax;
-        tmax = xrow4_max(tmax);
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = fast_exp(m_run - m_new);
-        float pr[4], lsum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            pr[j] = (n0 + j < p.N) ? fast_exp(lg[j] - m_new) : 0.f;
-            lsum += pr[j];
-        }
-        l_run = l_run * alpha + xrow4_sum(lsum);
-        m_run = m_new;
-        bf16x8 pw;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint16_t hh, ll;
-            split_bf16(pr[j], hh, ll);
-            pw[j] = (short)hh;
-            pw[4 + j] = (short)ll;
-        }
-        if (__any(alpha != 1.0f)) {
-            const float a0 = __shfl(alpha, 4 * kg + 0, 64), a1 = __shfl(alpha, 4 * kg + 1, 64);
-            const float a2 = __shfl(alpha, 4 * kg + 2, 64), a3 = __shfl(alpha, 4 * kg + 3, 64);
+        if (__any(al[0] != 1.0f || al[1] != 1.0f || al[2] != 1.0f || al[3] != 1.0f)) {
 #pragma unroll
             for (int cb = 0; cb < CBLK; ++cb) {
-                acc[cb][0] *= a0; acc[cb][1] *= a1; acc[cb][2] *= a2; acc[cb][3] *= a3;
+                acc[cb][0] *= al[0]; acc[cb][1] *= al[1]; acc[cb][2] *= al[2]; acc[cb][3] *= al[3];
             }
 #pragma unroll
             for (int u = 0; u < MBW; ++u) {
-                macc[u][0] *= a0; macc[u][1] *= a1; macc[u][2] *= a2; macc[u][3] *= a3;
+                macc[u][0] *= al[0]; macc[u][1] *= al[1]; macc[u][2] *= al[2]; macc[u][3] *= al[3];
             }
         }
-        // ---- positional marginals of this tile (this wave's column blocks) ----
 #pragma unroll
         for (int u = 0; u < MBW; ++u) {
             if (wave + 4 * u < nmb) {
@@ -550,7 +557,6 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        // ---- P.x of this tile ----
         const unsigned img_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(img);
         constexpr int PGW = (CBLK % 6 == 0) ? 6 : CBLK;      // transposed fragments in flight together
 #pragma unroll
@@ -578,9 +584,9 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
     }
 
     const long prow = (long)part * p.rows_pad + rg * 16;
-    if (wave == 0 && kg == 0 && rg * 16 + r16 < p.rows) {
-        p.part_m[prow + r16] = m_run;
-        p.part_l[prow + r16] = l_run;
+    if (tok == 0 && rg * 16 + srow < p.rows) {
+        p.part_m[prow + srow] = m_run;
+        p.part_l[prow + srow] = l_run;
     }
 #pragma unroll
     for (int cb = 0; cb < CBLK; ++cb) {
@@ -693,7 +699,7 @@ static int global_stream_launch(const void* x, int64_t N, int32_t E,
     HICOM_REQUIRE(scores || part_marg, HICOM_EINVAL, "global_stream: scores is NULL");
     if (wide) {
         const int S = kWideFrames + (pos_a ? H + W : 0);
-        const size_t smem = (size_t)3 * 9 * 4096 + 2 * (size_t)kWideRG * 4 * 1024 + 128 + (size_t)kWideRG * 16 * S * 4;
+        const size_t smem = (size_t)3 * 9 * 4096 + 2 * (size_t)kWideRG * 4 * 1024 + 128 + (size_t)kWideRG * (1024 + 64) + (size_t)kWideRG * 16 * S * 4;
         static bool wide_attr = false;
         if (!wide_attr) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(global_stream_wide_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);

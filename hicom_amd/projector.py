@@ -89,24 +89,31 @@ class MultiheadAttention(nn.Module):
             raise NotImplementedError("MultiheadAttention: attention_mask has no HIP path (never passed by the reference)")
         if not torch.is_grad_enabled():
             nv.begin_inference()
-        B, q_len, _ = query.shape
+        B, q_len, E = query.shape
         kv_len = key.shape[1]
+        if kv_len <= 64:
+            # the four projections and the clip normalisation are row-wise: ONE launch each over all batch entries; only the 64-key
+            # attention itself is per entry
+            dev = query.device
+            qp = inj.linear_rows(query.reshape(B * q_len, E).contiguous(), self.q_proj)
+            kp = inj.linear_rows(key.reshape(B * kv_len, E).contiguous(), self.k_proj)
+            vp = inj.linear_rows(value.reshape(B * kv_len, E).contiguous(), self.v_proj)
+            sc = None
+            if logit_scale is not None:
+                # clip form (ref :184-191): projected queries and keys L2-normalised over the FULL width before the heads are
+                # split, logits * exp(logit_scale) (+ logit_bias: a per-row shift, softmax cancels it)
+                nv.clip_query_prep(qp, None, 1, 1.0, _f32((B * q_len,), dev))
+                nv.clip_query_prep(kp, None, 1, 1.0, _f32((B * kv_len,), dev))
+                sc = math.exp(float(logit_scale))
+            ao = _f32((B * q_len, self.embed_dim), dev)
+            for b in range(B):
+                nv.small_mha(qp[b * q_len:(b + 1) * q_len], kp[b * kv_len:(b + 1) * kv_len], vp[b * kv_len:(b + 1) * kv_len], self.num_heads,
+                             ao[b * q_len:(b + 1) * q_len], scale=sc)
+            out = inj.linear_rows(ao, self.out_proj).view(B, q_len, -1)
+            return (out if getattr(self, "return_fp32", False) else out.to(query.dtype)), None
         outs = []
-        for b in range(B):
-            q2, k2, v2 = query[b].contiguous(), key[b].contiguous(), value[b].contiguous()
-            if kv_len <= 64:
-                qp, kp, vp = inj.linear_rows(q2, self.q_proj), inj.linear_rows(k2, self.k_proj), inj.linear_rows(v2, self.v_proj)
-                ao = _f32((q_len, self.embed_dim), q2.device)
-                sc = None
-                if logit_scale is not None:
-                    # clip form (ref :184-191): projected queries and keys L2-normalised over the FULL width before the heads are
-                    # split, logits * exp(logit_scale) (+ logit_bias: a per-row shift, softmax cancels it)
-                    nv.clip_query_prep(qp, None, 1, 1.0, _f32((q_len,), q2.device))
-                    nv.clip_query_prep(kp, None, 1, 1.0, _f32((kv_len,), q2.device))
-                    sc = math.exp(float(logit_scale))
-                nv.small_mha(qp, kp, vp, self.num_heads, ao, scale=sc)
-                outs.append(inj.linear_rows(ao, self.out_proj))
-                continue
+        for b in range(B):                      # long key streams: one pass over each entry's tokens
+            q2, k2 = query[b].contiguous(), key[b].contiguous()
             if key[b].data_ptr() != value[b].data_ptr() or key.shape != value.shape:
                 raise NotImplementedError("MultiheadAttention: long key streams take key is value (k_proj / v_proj folded)")
             # clip-scale (ref :184-191): queries and PROJECTED keys L2-normalised over the full width, logits * exp(logit_scale)
