@@ -600,15 +600,27 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
             t0i, y0i, x0i = 0, cap, cap + H
             pos_b = torch.zeros((rows_pad, pe.shape[0]), dtype=torch.float32, device=dev)
             nv.linear(dctx, pe, None, pos_b, M=R)
-        ds = torch.empty_like(scores)
-        nparts = nv.global_stream_nparts(N, 16)
+        nparts = nv.global_stream_nparts(N, rows_pad)
         part = torch.empty((nparts, rows_pad, E), dtype=torch.float32, device=dev)
-        nv.global_stream_bwd(ff.view(N, E), N, dhi, dlo, pos_b, H if pe is not None else 1, W if pe is not None else N,
-                             t0i, y0i, x0i, scores, ml, delta, ds, part, R)
+        in_kernel = pe is not None and nv.global_stream_has_marg(N, E, rows_pad, H, W, nparts)
+        if in_kernel:
+            # many rows: the stream kernel leaves the t / y / x marginals of dS per token chunk -- the [rows, N] dS tensor is never written
+            pm = torch.empty((nparts, rows_pad, nv.global_stream_marg_width(H, W)), dtype=torch.float32, device=dev)
+            nv.global_stream_bwd(ff.view(N, E), N, dhi, dlo, pos_b, H, W, t0i, y0i, x0i, scores, ml, delta, None, part, R, part_marg=pm)
+            ybase, xbase = 16, 16 + 16 * ((H + 15) // 16)
+            mT = torch.zeros((R, T), dtype=torch.float32, device=dev)
+            mT.index_add_(1, nv.marg_frame_index(N, H, W, nparts, dev).reshape(-1), pm[:, :R, :8].permute(1, 0, 2).reshape(R, -1))
+            mY, mX = pm[:, :R, ybase:ybase + H].sum(0), pm[:, :R, xbase:xbase + W].sum(0)
+        else:
+            ds = torch.empty_like(scores)
+            nv.global_stream_bwd(ff.view(N, E), N, dhi, dlo, pos_b, H if pe is not None else 1, W if pe is not None else N,
+                                 t0i, y0i, x0i, scores, ml, delta, ds, part, R)
+            if pe is not None:
+                dS = ds[:R, :N].view(R, T, H, W)
+                mT, mY, mX = dS.sum((2, 3)), dS.sum((1, 3)), dS.sum((1, 2))
         dqt = part.sum(0)[:R]                                              # sum_n dS[r, n] x_n
         if pe is not None:
-            dS = ds[:R, :N].view(R, T, H, W)
-            dqt = dqt + dS.sum((2, 3)) @ pe[t0i:t0i + T] + dS.sum((1, 3)) @ pe[y0i:y0i + H] + dS.sum((1, 2)) @ pe[x0i:x0i + W]
+            dqt = dqt + mT @ pe[t0i:t0i + T] + mY @ pe[y0i:y0i + H] + mX @ pe[x0i:x0i + W]
         dqt = dqt.view(nq, nh, E)
         # ---- through the fold: qt[q,h] = scale W_k,h^T (W_q q + b_q)[q, h-slice]  (ref :180-181,:193-197) ---------
         scale = att.scale

@@ -335,7 +335,12 @@ constexpr int kWideMargBlocks = 2;  // 16-column marginal blocks per wave (x 4 w
 // (LDS exchange -> lookups -> DPP reductions -> exp -> LDS hand-over -> transposed reads -> MFMAs, ~5k clocks per 16 tokens, both
 // waves of a SIMD in the same phase): two tiles per barrier interval would overlap two such chains, and 160 KB of LDS hold four
 // 36-KB tiles, not the six that needs.
-template <int NB>
+// BWD = true: the attention backward over the same stream (see global_stream_kernel<NB, true>): the "queries" are the upstream
+// gradients dctx_r, the score tile is dP, the quarter-of-the-rows step forms dS = exp(S - M) / L (dP - delta) from the forward's logits
+// (fetched one tile ahead by an asm load the end-of-iteration wait covers: the loading waves' counted LDS-DMA and compiler-counted
+// loads do not mix), dS goes through the same P hand-over into the dS . x MFMAs, no running max, no rescale.  The positional
+// marginals of dS (part_marg) are what the positional part of d q~ needs: with them the [rows, N] dS tensor need not be written.
+template <int NB, bool BWD = false>
 __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams p) {
     constexpr int NBUF = 3, NRED = 2;
     constexpr int E = NB * 128;
@@ -398,6 +403,21 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
     // each of the four waves of a row group owns a QUARTER of the tile's rows
     float m_run = -1.0e30f, l_run = 0.f;
     const int rl = lane >> 4, tok = lane & 15, srow = 4 * wave + rl;
+    // backward: softmax state and delta of this lane's row, the forward's logit of (row, token) one tile ahead
+    float bw_m = 0.f, bw_linv = 0.f, bw_delta = 0.f, s_nx = 0.f;
+    const long srow_g = (long)rg * 16 + srow;
+    if constexpr (BWD) {
+        if (srow_g < p.rows) {
+            bw_m = p.ml[2 * srow_g];
+            bw_linv = 1.0f / p.ml[2 * srow_g + 1];
+            bw_delta = p.delta[srow_g];
+        }
+        asm volatile("" : "+v"(bw_m), "+v"(bw_linv), "+v"(bw_delta));      // landed before any DMA is issued
+    }
+    auto fetch_s = [&](int tile) {                                         // (waited for by the fence at the end of the iteration)
+        const float* src = p.s_in + srow_g * p.score_stride + (long)tile * 16 + tok;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(s_nx) : "v"(src) : "memory");
+    };
 
     // positional marginals in the kernel (part_marg given): P[16 rows x 16 tokens] . onehot[16 tokens x 16 columns] on the matrix
     // pipe, one MFMA per 16-column block of [frame | grid row | grid column]; the blocks are dealt to the 4 waves of the row group
@@ -476,6 +496,9 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
         asm volatile("" ::: "memory");
     };
 
+    if constexpr (BWD) {
+        if (tb < te) fetch_s(tb);
+    }
     if (tb < te) stage(tb, 0);
     if (tb + 1 < te) stage(tb + 1, 1);
     __syncthreads();                                   // positional tables
@@ -489,6 +512,12 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
     for (int tile = tb; tile < te; ++tile) {
         const int k = tile - tb, cur = k % NBUF, h = k & 1;
         const bool more = tile + 1 < te;
+        float s_cur = 0.f;
+        if constexpr (BWD) {
+            s_cur = s_nx;                                                 // (landed: the fence of the previous iteration waited for it)
+            asm volatile("" : "+v"(s_cur));
+            if (more) fetch_s(tile + 1);
+        }
         if (tile + NBUF - 1 < te) stage(tile + NBUF - 1, (k + NBUF - 1) % NBUF);     // into the buffer of tile - 1 (retired by the barrier just passed)
         const char* img = tilebuf + cur * TILE_BYTES;
         // ---- scores of tile + 1: issued now, needed at the end of the iteration ----
@@ -506,19 +535,26 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
                 lg += pr_[tp >> 16] + pr_[kWideFrames + ((tp >> 8) & 255)] + pr_[kWideFrames + p.H + (tp & 255)];
             }
             const long n = (long)tile * 16 + tok;
-            if (p.scores) p.scores[((long)rg * 16 + srow) * p.score_stride + n] = lg;
             const bool ok = n < p.N;
-            const float m_new = fmaxf(m_run, row16_max(ok ? lg : -1.0e30f));
-            const float alpha = fast_exp(m_run - m_new);
-            const float pr = ok ? fast_exp(lg - m_new) : 0.f;
-            l_run = l_run * alpha + row16_sum(pr);
-            m_run = m_new;
+            float pr, alpha = 1.0f;
+            if constexpr (BWD) {
+                // dS = softmax weight x (dP - delta); padded rows (state 0, 0, 0) and tail tokens contribute nothing
+                pr = (ok && srow_g < p.rows) ? expf(s_cur - bw_m) * bw_linv * (lg - bw_delta) : 0.f;
+                if (p.scores) p.scores[srow_g * p.score_stride + n] = pr;
+            } else {
+                if (p.scores) p.scores[srow_g * p.score_stride + n] = lg;
+                const float m_new = fmaxf(m_run, row16_max(ok ? lg : -1.0e30f));
+                alpha = fast_exp(m_run - m_new);
+                pr = ok ? fast_exp(lg - m_new) : 0.f;
+                l_run = l_run * alpha + row16_sum(pr);
+                m_run = m_new;
+            }
             uint16_t hh, ll;
             split_bf16(pr, hh, ll);
             uint16_t* pb = pbuf + ((grp * 16 + srow) * 4 + sig(tok >> 2)) * 8 + (tok & 3);   // k slot 8 kg + j <-> token 4 sig(kg) + j
             pb[0] = hh;
             pb[4] = ll;
-            if (tok == 0) alpha_s[grp * 16 + srow] = alpha;
+            if (!BWD && tok == 0) alpha_s[grp * 16 + srow] = alpha;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // P and the rescale factors of this tile are complete
@@ -526,14 +562,15 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
 
         // ---- this wave's channel slice: rescale, marginals, P.x ----
         const bf16x8 pw = *reinterpret_cast<const bf16x8*>(pbuf + ((grp * 16 + r16) * 4 + kg) * 8);
-        const f32x4 al = *reinterpret_cast<const f32x4*>(alpha_s + grp * 16 + 4 * kg);
+        f32x4 al = f32x4{1.f, 1.f, 1.f, 1.f};
+        if constexpr (!BWD) al = *reinterpret_cast<const f32x4*>(alpha_s + grp * 16 + 4 * kg);
         int tp[4] = {0, 0, 0, 0};
         if (marg_on) {
             int4 v;
             asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(tokpos_lds + 64 * h + 16 * sig(kg)) : "memory");
             tp[0] = v.x; tp[1] = v.y; tp[2] = v.z; tp[3] = v.w;
         }
-        if (__any(al[0] != 1.0f || al[1] != 1.0f || al[2] != 1.0f || al[3] != 1.0f)) {
+        if (!BWD && __any(al[0] != 1.0f || al[1] != 1.0f || al[2] != 1.0f || al[3] != 1.0f)) {
 #pragma unroll
             for (int cb = 0; cb < CBLK; ++cb) {
                 acc[cb][0] *= al[0]; acc[cb][1] *= al[1]; acc[cb][2] *= al[2]; acc[cb][3] *= al[3];
@@ -584,7 +621,7 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
     }
 
     const long prow = (long)part * p.rows_pad + rg * 16;
-    if (tok == 0 && rg * 16 + srow < p.rows) {
+    if (!BWD && tok == 0 && rg * 16 + srow < p.rows) {
         p.part_m[prow + srow] = m_run;
         p.part_l[prow + srow] = l_run;
     }
@@ -772,14 +809,15 @@ extern "C" int hicom_global_stream_bwd(const void* x, int64_t N, int32_t E, cons
                                        int32_t rows, int32_t rows_pad, const float* pos_b, int32_t pos_stride,
                                        int32_t H, int32_t W, int32_t t_index0, int32_t y_index0, int32_t x_index0,
                                        const float* s_in, int64_t score_stride, const float* ml, const float* delta,
-                                       float* ds_out, float* part_acc, int32_t nparts, void* stream) {
-    HICOM_REQUIRE(x && dctx_hi && dctx_lo && s_in && ml && delta && ds_out && part_acc, HICOM_EINVAL, "global_stream_bwd: NULL pointer");
+                                       float* ds_out, float* part_acc, float* part_marg, int32_t nparts, void* stream) {
+    HICOM_REQUIRE(x && dctx_hi && dctx_lo && s_in && ml && delta && (ds_out || part_marg || !pos_b) && part_acc, HICOM_EINVAL, "global_stream_bwd: NULL pointer");
     HICOM_REQUIRE(E == 1152 || E == 768, HICOM_EUNSUP, "global_stream_bwd: E=%d (only 1152 / 768)", E);
     HICOM_REQUIRE(N > 0 && N < (1L << 31) && rows_pad > 0 && rows_pad % 16 == 0 && rows > 0 && rows <= rows_pad && nparts > 0,
                   HICOM_EINVAL, "global_stream_bwd: bad shape");
     HICOM_REQUIRE(score_stride >= ((N + 15) / 16) * 16 && score_stride % 4 == 0, HICOM_EINVAL, "global_stream_bwd: score_stride");
     HICOM_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)dctx_hi % 16 == 0) && ((uintptr_t)dctx_lo % 16 == 0) &&
                       ((uintptr_t)s_in % 16 == 0) && ((uintptr_t)ds_out % 16 == 0), HICOM_EINVAL, "global_stream_bwd: alignment");
+    HICOM_REQUIRE(rows_pad % 16 == 0, HICOM_EINVAL, "global_stream_bwd: rows_pad");
     if (pos_b) HICOM_REQUIRE(H > 0 && W > 0 && pos_stride > 0, HICOM_EINVAL, "global_stream_bwd: pos geometry");
     StreamParams p;
     p.x = (const uint16_t*)x; p.N = N; p.qhi = (const uint16_t*)dctx_hi; p.qlo = (const uint16_t*)dctx_lo;
@@ -791,6 +829,27 @@ extern "C" int hicom_global_stream_bwd(const void* x, int64_t N, int32_t E, cons
     p.s_in = s_in; p.ml = ml; p.delta = delta; p.inv_norm = nullptr; p.row_const = nullptr; p.part_marg = nullptr; p.marg_stride = 0;
     dim3 grid((unsigned)nparts, (unsigned)(rows_pad / 16));
     hipStream_t s = (hipStream_t)stream;
+    // many rows: the wide form (two row groups per workgroup, half the passes over the tokens; with part_marg the positional marginals
+    // of dS come out of the kernel and ds_out may be NULL)
+    const char* force_narrow = getenv("HICOM_GLOBAL_NARROW");
+    const bool wide = !(force_narrow && force_narrow[0] == '1') && wide_ok(N, E, rows_pad, pos_b ? H : 0, pos_b ? W : 0, nparts);
+    HICOM_REQUIRE(!part_marg || (wide && pos_b && hicom_global_stream_has_marg(N, E, rows_pad, H, W, nparts) == 1), HICOM_EUNSUP,
+                  "global_stream_bwd: no in-kernel marginals for this shape (hicom_global_stream_has_marg)");
+    HICOM_REQUIRE(wide || ds_out, HICOM_EINVAL, "global_stream_bwd: ds_out is NULL");
+    if (wide) {
+        const int S = kWideFrames + (pos_b ? H + W : 0);
+        const size_t smem = (size_t)3 * 9 * 4096 + 2 * (size_t)kWideRG * 4 * 1024 + 128 + (size_t)kWideRG * (1024 + 64) + (size_t)kWideRG * 16 * S * 4;
+        static bool wide_attr = false;
+        if (!wide_attr) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(global_stream_wide_kernel<9, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+            wide_attr = true;
+        }
+        p.part_marg = part_marg;
+        p.marg_stride = part_marg ? hicom_global_stream_marg_width(H, W) : 0;
+        if (!pos_b) { p.H = 1; p.W = 1; p.HW = 1; }
+        hipLaunchKernelGGL((global_stream_wide_kernel<9, true>), dim3((unsigned)nparts, (unsigned)(rows_pad / (16 * kWideRG))), dim3(512), smem, s, p);
+        return hicom_host::check_launch("global_stream_bwd");
+    }
     if (E == 1152) {
         constexpr int smem = 2 * 9 * 4096 + 4096;
         static bool attr_set = false;

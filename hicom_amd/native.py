@@ -132,7 +132,7 @@ def lib() -> C.CDLL:
     L.hicom_global_stream_has_marg.argtypes = [i64, i32, i32, i32, i32, i32]
     L.hicom_global_merge_marg_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, i32, vp, i32, i32, i32, vp, vp, vp, i32, vp]
     L.hicom_global_stream_bwd.argtypes = [vp, i64, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp, vp,
-                                          vp, vp, i32, vp]
+                                          vp, vp, vp, i32, vp]
     L.hicom_global_merge_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, i64, i64, i32, i32, vp, i32, i32, i32,
                                          vp, vp, vp, i32, vp]
     L.hicom_linear_to_rows_fwd.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i64, i64, i32, vp]
@@ -403,12 +403,34 @@ def global_merge_marg(part_m, part_l, part_acc, part_marg, rows, N, H, W, pe, t0
                                              _ptr(out_acc), int(normalize), _stream()), "hicom_global_merge_marg_fwd")
 
 
-def global_stream_bwd(x, N, dhi, dlo, pos_b, H, W, t0i, y0i, x0i, s_in, ml, delta, ds_out, part_acc, rows):
+def global_stream_bwd(x, N, dhi, dlo, pos_b, H, W, t0i, y0i, x0i, s_in, ml, delta, ds_out, part_acc, rows, part_marg=None):
+    """part_marg (shapes with global_stream_has_marg): the positional marginals of dS per token chunk; ds_out may then be None."""
     E = x.shape[-1]
     _check(lib().hicom_global_stream_bwd(_ptr(x), N, E, _ptr(dhi), _ptr(dlo), rows, dhi.shape[0], _ptr(pos_b),
                                          pos_b.shape[1] if pos_b is not None else 0, H, W, t0i, y0i, x0i, _ptr(s_in),
-                                         s_in.shape[1], _ptr(ml), _ptr(delta), _ptr(ds_out), _ptr(part_acc),
+                                         s_in.shape[1], _ptr(ml), _ptr(delta), _ptr(ds_out), _ptr(part_acc), _ptr(part_marg),
                                          part_acc.shape[0], _stream()), "hicom_global_stream_bwd")
+
+
+_MARG_IDX = {}
+
+
+def marg_frame_index(N, H, W, nparts, device):
+    """Frame of column c of chunk i's frame block in a part_marg tensor (hicom_global_stream_marg_fwd / _bwd): [nparts, 8] int64,
+    entries past the clip's last frame clamped to it (their marginals are zero).  Cached per shape: the upload must not happen inside
+    a graph capture."""
+    key = (N, H, W, nparts, str(device))
+    hit = _MARG_IDX.get(key)
+    if hit is not None:
+        return hit
+    if len(_MARG_IDX) >= 16:
+        _MARG_IDX.clear()
+    ntiles = (N + 15) // 16
+    T = N // (H * W)
+    first = torch.tensor([((ntiles * i) // nparts * 16) // (H * W) for i in range(nparts)], dtype=torch.int64)
+    idx = (first[:, None] + torch.arange(8)[None, :]).clamp_(max=T - 1)
+    hit = _MARG_IDX[key] = idx.to(device)
+    return hit
 
 
 def global_merge(part_m, part_l, part_acc, rows, scores, N, H, W, pe, t0i, y0i, x0i, scratch, out_ml, out_acc,

@@ -254,12 +254,15 @@ int hicom_global_stream_has_marg(int64_t N, int32_t E, int32_t rows_pad, int32_t
  *   part_acc[p, r, :] = sum over chunk p of dS[r,n] x_n          (sum over p = the x part of d qt_r)
  * dctx_hi / dctx_lo: bf16 [rows_pad, E] planes of the upstream context gradients (padding rows zero);
  * pos_b: f32 [rows_pad, pos_stride] = dctx . PE^T (or NULL); ds_out: f32 [rows_pad, score_stride] (its t / y / x
- * marginals times PE give the positional part of d qt).  One pass over x, same tiling as the forward. */
+ * marginals times PE give the positional part of d qt).  One pass over x, same tiling as the forward.  part_marg (may be NULL; f32
+ * [nparts][rows_pad][hicom_global_stream_marg_width(H, W)], shapes with hicom_global_stream_has_marg == 1): the t / y / x marginals of dS
+ * per token chunk, laid out as in hicom_global_stream_marg_fwd (no rescaling: plain sums) -- ds_out may then be NULL and the
+ * [rows, N] dS tensor is never written. */
 int hicom_global_stream_bwd(const void* x, int64_t N, int32_t E, const void* dctx_hi, const void* dctx_lo,
                             int32_t rows, int32_t rows_pad, const float* pos_b, int32_t pos_stride,
                             int32_t H, int32_t W, int32_t t_index0, int32_t y_index0, int32_t x_index0,
                             const float* s_in, int64_t score_stride, const float* ml, const float* delta,
-                            float* ds_out, float* part_acc, int32_t nparts, void* stream);
+                            float* ds_out, float* part_acc, float* part_marg, int32_t nparts, void* stream);
 
 /* Suggested nparts for N tokens (fills the chip: 2 workgroups per CU). */
 int hicom_global_stream_nparts(int64_t N, int32_t rows_pad);

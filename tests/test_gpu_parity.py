@@ -537,6 +537,53 @@ def test_global_stream_in_kernel_marginals_match_the_logit_tensor_path(T, t_offs
     assert float(pe.abs().max()) > 0.5
 
 
+def test_global_stream_backward_many_row_form_matches_the_one_row_group_kernel(monkeypatch):
+    """Attention backward over the token stream at 288 rows (guide off / coarse / fine): the many-row kernel (two row groups per
+    workgroup, dS handed over through LDS, positional marginals of dS taken in the kernel -- no [rows, N] dS tensor) against the
+    one-row-group kernel that writes dS: same sum dS . x per row, same t / y / x marginals."""
+    import os
+    from hicom_amd import native as nv
+    g = torch.Generator(device="cuda").manual_seed(8)
+    T, H, W, E, R = 12, 27, 27, 1152, 288
+    N = T * H * W
+    x = torch.randn(N, E, device="cuda", generator=g).bfloat16()
+    dctx = torch.randn(R, E, device="cuda", generator=g) * 0.05
+    dhi, dlo = torch.empty(R, E, device="cuda", dtype=torch.bfloat16), torch.empty(R, E, device="cuda", dtype=torch.bfloat16)
+    nv.split_bf16(dctx, R, dhi, dlo)
+    P = T + H + W
+    pos_b = torch.randn(R, P, device="cuda", generator=g) * 0.1
+    stride = (N + 15) // 16 * 16
+    s_in = torch.randn(R, stride, device="cuda", generator=g)
+    ml = torch.stack([s_in[:, :N].max(1).values, torch.exp(s_in[:, :N] - s_in[:, :N].max(1, keepdim=True).values).sum(1)], 1).contiguous()
+    delta = torch.randn(R, device="cuda", generator=g) * 0.1
+    nparts = nv.global_stream_nparts(N, R)
+    assert nv.global_stream_has_marg(N, E, R, H, W, nparts)
+    part = torch.empty(nparts, R, E, device="cuda")
+    pm = torch.empty(nparts, R, nv.global_stream_marg_width(H, W), device="cuda")
+    nv.global_stream_bwd(x, N, dhi, dlo, pos_b, H, W, 0, T, T + H, s_in, ml, delta, None, part, R, part_marg=pm)
+    mT = torch.zeros(R, T, device="cuda")
+    mT.index_add_(1, nv.marg_frame_index(N, H, W, nparts, x.device).reshape(-1), pm[:, :, :8].permute(1, 0, 2).reshape(R, -1))
+    mY, mX = pm[:, :, 16:16 + H].sum(0), pm[:, :, 48:48 + W].sum(0)
+    # with dS written as well: same partial sums bit for bit
+    part2, ds2 = torch.empty_like(part), torch.empty(R, stride, device="cuda")
+    nv.global_stream_bwd(x, N, dhi, dlo, pos_b, H, W, 0, T, T + H, s_in, ml, delta, ds2, part2, R, part_marg=torch.empty_like(pm))
+    assert torch.equal(part, part2)
+    os.environ["HICOM_GLOBAL_NARROW"] = "1"
+    try:
+        part1, ds1 = torch.empty_like(part), torch.empty(R, stride, device="cuda")
+        nv.global_stream_bwd(x, N, dhi, dlo, pos_b, H, W, 0, T, T + H, s_in, ml, delta, ds1, part1, R)
+    finally:
+        del os.environ["HICOM_GLOBAL_NARROW"]
+    torch.cuda.synchronize()
+    scale = float(ds1[:, :N].abs().max())
+    assert float((ds2[:, :N] - ds1[:, :N]).abs().max()) <= 1e-5 * scale
+    a, b = part.sum(0), part1.sum(0)
+    assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    dS = ds1[:, :N].view(R, T, H, W)
+    for got, want in ((mT, dS.sum((2, 3))), (mY, dS.sum((1, 3))), (mX, dS.sum((1, 2)))):
+        assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-6
+
+
 @pytest.mark.parametrize("per,finish_rank", [(64, 5), (128, 6)])
 def test_c3_c5_eight_rank_emulation(per, finish_rank):
     """BASELINE configs[2] (512 frames over 8 GPUs, 64 per GPU) and configs[4] (1024 frames, 128 per GPU) on one GPU:
