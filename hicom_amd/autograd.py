@@ -121,6 +121,37 @@ class _AdaptorStore:
         return (self.k[2] if self.k is not None else None, self.v[2] if self.v is not None else None)
 
 
+class _GlobalStore:
+    """Softmax state (M, L), un-normalised contexts and raw logits of the global stage of the LAST training forward of one input
+    shape, in buffers with stable addresses (the captured backward reads them by address instead of streaming the tokens once more);
+    `serial` as in _AdaptorStore."""
+
+    def __init__(self):
+        self.bufs = None
+        self.serial = 0
+
+    def buffers(self, R, rows_pad, stride, E, dev):
+        if self.bufs is None or self.bufs[0].shape[0] != R or self.bufs[2].shape != (rows_pad, stride) or self.bufs[0].device != dev:
+            f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+            self.bufs = (f(R, 2), f(R, E), f(rows_pad, stride))
+        return self.bufs
+
+
+def _global_store(proj, ff):
+    """The global stage's store of this input shape, or None (no global stage; `proj.share_global_state = False`: the backward
+    streams the tokens again, as gradient checkpointing would)."""
+    if proj.global_compressor is None or getattr(proj, "share_global_state", True) is False:
+        return None
+    stores = proj.__dict__.setdefault("_global_stores", {})
+    key = (tuple(ff.shape), str(ff.device))
+    st = stores.get(key)
+    if st is None:
+        if len(stores) >= 2:
+            stores.pop(next(iter(stores)))
+        st = stores[key] = _GlobalStore()
+    return st
+
+
 def _adaptor_store(proj, ff):
     """The store of this input shape, or None when the recipe has no k / v adaptor (or the sharing is switched off:
     `proj.share_adaptor_activations = False` recomputes the MLPs in the backward, as gradient checkpointing would)."""
@@ -273,7 +304,7 @@ class _CompressorFn(torch.autograd.Function):
     def forward(ctx, proj, ff, fe, guide, modal, nl, names, *params):
         from . import engine
         from .projector import _out_dtype
-        ctx.adapt_serial = None
+        ctx.adapt_serial = ctx.global_serial = None
         with torch.no_grad():
             if proj.use_executor and proj._executor_covers():          # (plain recipes and the k / v adaptors: one C call)
                 store = _adaptor_store(proj, ff)
@@ -283,7 +314,17 @@ class _CompressorFn(torch.autograd.Function):
                     ctx.adapt_serial = store.fill(proj.local_compressor, ff, fe)
                 out = engine.run_dense(proj, ff, fe, guide, modal, nl, _out_dtype(proj), adapt_y=store.ys if store is not None else None)
             else:                                                      # query-side adaptors / coarse / fine injection: operator by operator
-                out = proj.forward_stepwise(ff, fe, guide, modal, nl)
+                gstore = _global_store(proj, ff)
+                gc = proj.global_compressor
+                if gstore is not None:
+                    gc.__dict__["_train_store"] = gstore               # partial_context fills it (and asks the kernel for the logits)
+                try:
+                    out = proj.forward_stepwise(ff, fe, guide, modal, nl)
+                finally:
+                    if gstore is not None:
+                        gc.__dict__.pop("_train_store", None)
+                if gstore is not None and gstore.bufs is not None:
+                    ctx.global_serial = gstore.serial
         ctx.proj, ctx.modal, ctx.names = proj, modal, names
         ctx.save_for_backward(ff, fe, guide, nl)
         return out
@@ -302,12 +343,21 @@ class _CompressorFn(torch.autograd.Function):
         if store is not None and store.serial != ctx.adapt_serial:
             with torch.no_grad():
                 store.fill(proj.local_compressor, ff, fe)          # another forward of this shape ran in between: its intermediates are not ours
+        gstore = _global_store(proj, ff) if ctx.global_serial is not None else None
+        if gstore is not None and (gstore.bufs is None or gstore.serial != ctx.global_serial):
+            with torch.no_grad():                                  # another forward of this shape ran in between: stream again, into the store
+                gc = proj.global_compressor
+                gc.__dict__["_train_store"] = gstore
+                try:
+                    gc.partial_context(ff, gc.injected_queries(guide)[0])
+                finally:
+                    gc.__dict__.pop("_train_store", None)
         gb = getattr(proj, "graph_backward", None)             # None: automatic; False: always eager
         if (gb is None or gb) and nl is None:
-            res = _graphed_backward(dout, *args, store=store)
+            res = _graphed_backward(dout, *args, store=store, gstore=gstore)
         else:
             with torch.no_grad():
-                res = _backward_outputs(dout, *args, store=store)
+                res = _backward_outputs(dout, *args, store=store, gstore=gstore)
         flats, d_fe, d_guide, d_nl = res
         plist = dict(proj.named_parameters())
         out = [None] * len(ctx.names)
@@ -320,13 +370,14 @@ class _CompressorFn(torch.autograd.Function):
         return (None, None, d_fe, d_guide, None, d_nl, None, *out)
 
 
-def _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl, store=None):
+def _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl, store=None, gstore=None):
     """({dtype: (flat gradient buffer, [(argument index, parameter name)])}, d frames_embed, d guide_embed, d image_newline) in
     the dtypes autograd hands on.  The parameter gradients leave as views of one buffer cast once (one concatenation + one cast
     instead of a cast per tensor)."""
     global LAST_FP32_GRADS
     grads, d_nl, d_fe, d_guide = compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=want_fe, want_guide=want_guide,
-                                                     adaptor_saved=(store.k, store.v) if store is not None else None)
+                                                     adaptor_saved=(store.k, store.v) if store is not None else None,
+                                                     global_saved=gstore.bufs if gstore is not None else None)
     LAST_FP32_GRADS = dict(grads)
     if d_guide is not None:
         LAST_FP32_GRADS["__guide_embed__"] = d_guide
@@ -343,7 +394,7 @@ def _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
 _MAX_BWD_GRAPHS = 4
 
 
-def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl, store=None):
+def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl, store=None, gstore=None):
     """The backward as a captured hipGraph (the default; `proj.graph_backward = False` turns it off).
     The eager backward is ~130 small launches behind 1.4 ms of Python at the benchmark shape; its shapes are static, so the second
     backward of a problem SHAPE is captured and later ones are one graph launch.  The captured kernels read STATIC copies of the inputs
@@ -356,7 +407,8 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
     cache = proj.__dict__.setdefault("_bwd_graphs", {})
     key = (tuple(ff.shape), None if fe is None else tuple(fe.shape), None if guide is None else tuple(guide.shape), modal,
            tuple(dout.shape), dout.dtype, want, want_fe, want_guide, torch.cuda.current_stream(ff.device).cuda_stream,
-           None if store is None else id(store))          # (the captured kernels read the store's buffers by address)
+           None if store is None else id(store),          # (the captured kernels read the stores' buffers by address)
+           None if gstore is None else tuple(b.data_ptr() for b in gstore.bufs))
     # what else the captured kernels read by ADDRESS: every parameter's storage and the cached device tables (pe / kpe / planes:
     # `_cache_gen` moves when one is reallocated -- T above the cached cap, a cleared cache, a device move).  A graph whose
     # signature moved is dropped, never replayed over freed or reused memory.
@@ -368,7 +420,7 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
 
     def eager():
         with torch.no_grad():
-            return _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl, store=store)
+            return _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl, store=store, gstore=gstore)
 
     if ent is None:                                                # first sight of the shape: eager (also the warm-up a capture needs)
         if len(cache) >= _MAX_BWD_GRAPHS:
@@ -387,8 +439,8 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
             g = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(g):
                 outs = _backward_outputs(st["dout"], proj, st["ff"], st["fe"], st["guide"], modal, nl, names, want, want_fe, want_guide, want_nl,
-                                         store=store)
-            st["store"] = store                                    # (keeps the buffers the graph reads alive with the entry)
+                                         store=store, gstore=gstore)
+            st["store"] = (store, gstore, None if gstore is None else gstore.bufs)   # (keeps the buffers the graph reads alive with the entry)
             if engine.plan_sig(proj) != sig:                       # (the pass inside the capture reallocated a table)
                 raise RuntimeError("cached device tables moved during capture")
             ent.update(graph=g, outs=outs, **st)
@@ -407,7 +459,7 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
             None if d_guide is None else d_guide.clone(), None)
 
 
-def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, want_guide=False, adaptor_saved=None):
+def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, want_guide=False, adaptor_saved=None, global_saved=None):
     """(fp32 gradients {parameter name: tensor} of sum(out * dout), d image_newline, d frames_embed (bf16) or None,
     d guide_embed (fp32) or None).  Restates autograd through reference projector.py:524-559 (local), :634-646 + :166-228
     (global) and mm_utils.py:92-140 (packing).  The input gradients exist for the direct recipe only."""
@@ -556,7 +608,10 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         # (guide off, reference stage 1: IdentityMap injector, :586-587)
         q_in, n_rows = gc.injected_queries(guide)
         nq = q_in.shape[0]
-        ml, acc, scores = gc.partial_context(ff, q_in, need_scores=True)                     # HIP: forward logits + softmax state, rows q*nh + h
+        if global_saved is not None:
+            ml, acc, scores = global_saved                                 # kept by the training forward (_GlobalStore)
+        else:
+            ml, acc, scores = gc.partial_context(ff, q_in, need_scores=True)   # HIP: forward logits + softmax state, rows q*nh + h
         R = ml.shape[0]
         ctxg = (acc / ml[:, 1:2]).view(nq, nh, E)                          # per-(query, head) contexts
         q32 = q_in.float()

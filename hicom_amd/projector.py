@@ -190,7 +190,7 @@ def _linear_params(lin: nn.Linear):
     return lin.weight.detach(), (lin.bias.detach() if lin.bias is not None else None)
 
 
-def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i, clip=None, kpe_t=None, kpe=None, need_scores=False):
+def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i, clip=None, kpe_t=None, kpe=None, need_scores=False, out=None):
     """Streams the tokens x2 [N, E] (bf16) once against the folded queries of q_in [nq, E]: returns the un-normalised
     online-softmax state (ml [R,2], acc [R,E]), R = nq * heads (ref :180-215 restated).
 
@@ -201,7 +201,9 @@ def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i, clip=None, kpe_t=N
     three rows of kpe_t = PE . W_k^T per token), the numerator from the usual folded queries.
 
     need_scores: also return the raw logits [rows_pad, N] (the backward pass reads them); without it the many-row form of the
-    kernel keeps the positional marginals itself and the logit tensor is never written (third result None)."""
+    kernel keeps the positional marginals itself and the logit tensor is never written (third result None).
+    out: callable (R, rows_pad, stride, E) -> (ml, acc, scores) buffers to fill instead of fresh tensors (the training forward's
+    store, whose addresses the captured backward reads)."""
     E, nh = att.embed_dim, att.num_heads
     _require_bf16_cuda("key / value tokens", x2)
     N, dev = x2.shape[0], x2.device
@@ -248,11 +250,14 @@ def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i, clip=None, kpe_t=N
     stride = (N + 15) // 16 * 16
     part_m, part_l = _f32((nparts, rows_pad), dev), _f32((nparts, rows_pad), dev)
     part_acc = _f32((nparts, rows_pad, E), dev)
-    ml, acc = _f32((R, 2), dev), _f32((R, E), dev)
     T = N // (H * W)
     scratch = _f32((R * T * (H + W + 2),), dev) if pe is not None else None
     in_kernel = inv is None and pe is not None and nv.global_stream_has_marg(N, E, rows_pad, H, W, nparts)
-    scores = _f32((rows_pad, stride), dev) if need_scores or not in_kernel else None
+    if out is not None:
+        ml, acc, scores = out(R, rows_pad, stride, E)
+    else:
+        ml, acc = _f32((R, 2), dev), _f32((R, E), dev)
+        scores = _f32((rows_pad, stride), dev) if need_scores or not in_kernel else None
     if in_kernel:
         part_marg = _f32((nparts, rows_pad, nv.global_stream_marg_width(H, W)), dev)
         nv.global_stream_marg(x2, N, qhi, qlo, pos_a, H, W, t0i, y0i, x0i, scores, part_m, part_l, part_acc, part_marg, rows=R)
@@ -627,6 +632,13 @@ class GlobalCompressor(nn.Module):
         if logit_scale is not None:
             clip = float(logit_scale)
             kpe_t = self.pos_kpe_t(t_offset + T, H, W, ff.device) if self.use_pos_emb else None
+        # training forward (autograd._CompressorFn): softmax state and logits go into the per-shape store the backward reads
+        store = getattr(self, "_train_store", None) if (t_offset == 0 and logit_scale is None) else None
+        if store is not None:
+            res = _stream_attention(self.attn_layer, ff.view(T * H * W, E), q_in, pe, H, W, t0i, y0i, x0i, clip, kpe_t, kpe, True,
+                                    out=lambda R, rows_pad, stride, E_: store.buffers(R, rows_pad, stride, E_, ff.device))
+            store.serial += 1
+            return res
         return _stream_attention(self.attn_layer, ff.view(T * H * W, E), q_in, pe, H, W, t0i, y0i, x0i, clip, kpe_t, kpe, need_scores)
 
     def finish(self, ml_sets, acc_sets, q_in, out, row0: int, n_rows: int):

@@ -252,6 +252,47 @@ def test_adaptor_intermediates_of_the_training_forward_are_shared_with_the_backw
     assert not torch.equal(ref_a["local_compressor.k_proj.0.weight"], ref_b["local_compressor.k_proj.0.weight"])
 
 
+@pytest.mark.parametrize("name", ["G6_coarse", "G7_fine"])
+def test_global_state_of_the_training_forward_is_shared_with_the_backward(name):
+    """coarse / fine (operator-by-operator training forward): the global stage's softmax state, contexts and logits stay in a per-shape
+    store for the backward, which then does not stream the tokens a second time.  Gradients equal the re-streaming backward's
+    (`share_global_state = False`) bit for bit in the eager, the capturing and the replayed step, and after two forwards in front of
+    two backwards (the first backward finds the other forward's state in the store and streams again)."""
+    case = cases.build_case(name)
+    m = build_module(case).train()
+    ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    ff2 = (ff.float() + 0.5 * torch.randn(ff.shape, device="cuda", generator=gen)).bfloat16()
+    a, b = (ff, fe, g), (ff2, fe, g)
+    with torch.no_grad():
+        shape = m(ff, fe, g, case.modal, None).shape
+    cot = torch.randn(shape, device="cuda", generator=gen)
+
+    def grads_of(inp, share):
+        m.share_global_state = share
+        m.zero_grad(set_to_none=True)
+        (m(*inp, case.modal, None).float() * cot).sum().backward()
+        return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    ref_a, ref_b = grads_of(a, False), grads_of(b, False)
+    for _ in range(2):
+        assert all(torch.equal(v, ref_a[n]) for n, v in grads_of(a, False).items())
+    for _ in range(3):
+        got = grads_of(a, True)
+        assert set(got) == set(ref_a) and all(torch.equal(got[n], ref_a[n]) for n in ref_a)
+    assert "_global_stores" in m.__dict__ and next(iter(m.__dict__["_global_stores"].values())).bufs is not None
+    m.share_global_state = True
+    m.zero_grad(set_to_none=True)
+    oa, ob = m(*a, case.modal, None), m(*b, case.modal, None)
+    (oa.float() * cot).sum().backward()
+    ga = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad(set_to_none=True)
+    (ob.float() * cot).sum().backward()
+    gb = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    assert all(torch.equal(ga[n], ref_a[n]) for n in ref_a) and all(torch.equal(gb[n], ref_b[n]) for n in ref_b)
+    assert any(not torch.equal(ref_a[n], ref_b[n]) for n in ref_a)
+
+
 def test_graph_backward_equals_eager():
     """`proj.graph_backward = True` (opt-in): the backward of a plain recipe captured into a hipGraph on its second use with the same
     input buffers and replayed afterwards.  Same kernels, same order: the gradients of the eager, the capturing and the replayed step
