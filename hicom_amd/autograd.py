@@ -306,7 +306,11 @@ class _CompressorFn(torch.autograd.Function):
         from .projector import _out_dtype
         ctx.adapt_serial = ctx.global_serial = None
         with torch.no_grad():
-            if proj.use_executor and proj._executor_covers():          # (plain recipes and the k / v adaptors: one C call)
+            gc_ = proj.global_compressor
+            # guide off (32 learnable queries x 9 heads): operator by operator, so that the global stage's state and logits stay for the
+            # backward (_GlobalStore) -- the executor keeps them in its workspace only
+            many_rows = gc_ is not None and gc_.use_guide in (None, "off") and _global_store(proj, ff) is not None
+            if proj.use_executor and proj._executor_covers() and not many_rows:          # (plain recipes and the k / v adaptors: one C call)
                 store = _adaptor_store(proj, ff)
                 if store is not None:
                     # the adaptor MLPs run here, with the intermediates their backward needs kept (as autograd keeps them in the
