@@ -391,6 +391,32 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                                        0, a.nl_count, sm));
     } else if (do_stream) {
         if (both) CHK(fork());
+        auto global_stream_part = [&]() -> int {
+            if (!a.reuse_queries) CHK(query_prep(sg, false));        // (guide off: weight-only, kept in the workspace across calls)
+            if (w.marg)
+                CHK(hicom_global_stream_marg_fwd(a.ff, w.N, a.E, ws + w.qhi, ws + w.qlo, w.R, w.rows_pad, F(w.pos_a), a.P, a.H, a.W,
+                                                 a.t_index0, a.y_index0, a.x_index0, nullptr, 0, F(w.part_m), F(w.part_l), F(w.part_acc),
+                                                 F(w.scores), w.nparts, sg));
+            else
+                CHK(hicom_global_stream_fwd(a.ff, w.N, a.E, ws + w.qhi, ws + w.qlo, w.R, w.rows_pad,
+                                            a.pe ? F(w.pos_a) : nullptr, a.P, a.H, a.W, a.t_index0, a.y_index0, a.x_index0,
+                                            F(w.scores), w.score_stride, F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, sg));
+            return HICOM_OK;
+        };
+        // Many query rows (guide off: 288): the stream kernel fills the chip for ~230 us and IS the critical path; run beside it, the
+        // local window kernel takes CU time from it (276 against 233 us) while the latency-bound tail behind it (merge + four 32-row
+        // linears, ~80 us) leaves the chip idle.  So: stream kernel first and alone, then the local chain beside the global tail.
+        static int sf_env = -1;
+        if (sf_env < 0) {
+            const char* e = getenv("HICOM_STREAM_FIRST");            // dev / A-B switch: 0 = local and global chains side by side from the start
+            sf_env = (e && e[0] == '0') ? 0 : 1;
+        }
+        const bool stream_first = sf_env && both && w.rows_pad > 16 && !(a.ak.w0 || a.av.w0) && a.ev_merge && sg == ss;
+        if (stream_first) {
+            CHK(global_stream_part());
+            HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_merge, ss) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
+            HICOM_REQUIRE(hipStreamWaitEvent(sm, (hipEvent_t)a.ev_merge, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
+        }
         // Host enqueue order matters (each launch costs a few us of host time): the long local
         // attention kernel goes first so that the side chain is enqueued while it runs.
         if (a.has_local) {
@@ -430,15 +456,7 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
             }
         }
         if (a.has_global) {
-            if (!a.reuse_queries) CHK(query_prep(sg, false));        // (guide off: weight-only, kept in the workspace across calls)
-            if (w.marg)
-                CHK(hicom_global_stream_marg_fwd(a.ff, w.N, a.E, ws + w.qhi, ws + w.qlo, w.R, w.rows_pad, F(w.pos_a), a.P, a.H, a.W,
-                                                 a.t_index0, a.y_index0, a.x_index0, nullptr, 0, F(w.part_m), F(w.part_l), F(w.part_acc),
-                                                 F(w.scores), w.nparts, sg));
-            else
-                CHK(hicom_global_stream_fwd(a.ff, w.N, a.E, ws + w.qhi, ws + w.qlo, w.R, w.rows_pad,
-                                            a.pe ? F(w.pos_a) : nullptr, a.P, a.H, a.W, a.t_index0, a.y_index0, a.x_index0,
-                                            F(w.scores), w.score_stride, F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, sg));
+            if (!stream_first) CHK(global_stream_part());
             CHK(merge(sg));
         }
         if (a.has_local) CHK(local_readout(sm));
