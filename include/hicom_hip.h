@@ -591,7 +591,9 @@ typedef struct hicom_compressor_args {
      * global chain at the end of the call -- the 32 global rows of `out` are complete when ev_join (recorded on the
      * side stream) has fired, so the chain of one video overlaps the streaming of the next.  ev_merge (may be NULL
      * when defer_join == 0) is recorded after the merge kernel and waited on before the next stream kernel, which
-     * overwrites the partial states the merge reads. */
+     * overwrites the partial states the merge reads.  Generic path with many query rows (guide off: 288): when given, the side
+     * stream launches the stream kernel first and records ev_merge behind it, the main stream waits for it before the local
+     * chain -- the stream kernel runs alone, the local chain beside the global tail. */
     void* ev_merge;
     int32_t defer_join, reserved_;
     /* Frame-sharded serving (hicom_amd/dist.py): what follows a phase on its own stream, so that one C call enqueues
