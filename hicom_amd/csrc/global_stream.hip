@@ -302,6 +302,15 @@ __global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
     }
 }
 
+// Dev-only phase sums of the many-row kernel (tools/wide_trace.py builds a second library with -DHICOM_WTRACE): lane 0 of every wave
+// adds up the cycles between ten points of its tile iteration; [block][wave][phase].
+#ifdef HICOM_WTRACE
+__device__ unsigned long long g_wide_trace[512 * 8 * 12];
+#define HICOM_WT(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); wt_sum[i] += now_ - wt_last; wt_last = now_; } while (0)
+#else
+#define HICOM_WT(i) do {} while (0)
+#endif
+
 constexpr int kWideRG = 2;
 constexpr int kWideFrames = 8;      // frames a workgroup's token range may touch
 constexpr int kWideMargBlocks = 2;  // 16-column marginal blocks per wave (x 4 waves of a row group)
@@ -490,10 +499,15 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
     };
     // the loading waves' pieces of the youngest staged tile have landed (nothing may stay in flight across the barrier: the next
     // iteration's scores read that tile), then the workgroup barrier
+#ifdef HICOM_WTRACE
+    unsigned long long wt_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, wt_last = 0;
+#endif
     auto fence = [&]() {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        HICOM_WT(8);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        HICOM_WT(9);
     };
 
     if constexpr (BWD) {
@@ -518,12 +532,17 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
             asm volatile("" : "+v"(s_cur));
             if (more) fetch_s(tile + 1);
         }
+#ifdef HICOM_WTRACE
+        if (k == 0) { wt_last = __builtin_readcyclecounter(); for (int i_ = 0; i_ < 12; ++i_) wt_sum[i_] = 0; }
+#endif
         if (tile + NBUF - 1 < te) stage(tile + NBUF - 1, (k + NBUF - 1) % NBUF);     // into the buffer of tile - 1 (retired by the barrier just passed)
+        HICOM_WT(1);
         const char* img = tilebuf + cur * TILE_BYTES;
         // ---- scores of tile + 1: issued now, needed at the end of the iteration ----
         f32x4 sn = f32x4{0.f, 0.f, 0.f, 0.f};
         if (more) sn = scores_of(tilebuf + ((k + 1) % NBUF) * TILE_BYTES);
         __builtin_amdgcn_sched_barrier(0);
+        HICOM_WT(2);
 
         // ---- softmax of THIS tile, a quarter of the rows per wave: lane (row srow, token tok) holds ONE logit ----
         {
@@ -556,9 +575,12 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
             pb[4] = ll;
             if (!BWD && tok == 0) alpha_s[grp * 16 + srow] = alpha;
         }
+        HICOM_WT(3);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        HICOM_WT(4);
         __builtin_amdgcn_s_barrier();                    // P and the rescale factors of this tile are complete
         asm volatile("" ::: "memory");
+        HICOM_WT(5);
 
         // ---- this wave's channel slice: rescale, marginals, P.x ----
         const bf16x8 pw = *reinterpret_cast<const bf16x8*>(pbuf + ((grp * 16 + r16) * 4 + kg) * 8);
@@ -615,10 +637,18 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        HICOM_WT(6);
         // ---- hand the next tile's partials over ----
         if (more) publish(sn, tile + 1, h ^ 1);
+        HICOM_WT(7);
         fence();                                         // (tile + 2, staged in this iteration, has landed: the next scores read it)
     }
+#ifdef HICOM_WTRACE
+    if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 512) {
+        wt_sum[0] = (unsigned long long)(te - tb);
+        for (int i_ = 0; i_ < 12; ++i_) g_wide_trace[(blockIdx.x * 8 + wave8) * 12 + i_] = wt_sum[i_];
+    }
+#endif
 
     const long prow = (long)part * p.rows_pad + rg * 16;
     if (!BWD && tok == 0 && rg * 16 + srow < p.rows) {
@@ -642,6 +672,14 @@ __global__ __launch_bounds__(512, 1) void global_stream_wide_kernel(StreamParams
         }
     }
 }
+
+#ifdef HICOM_WTRACE
+}  // namespace hicom
+extern "C" int hicom_debug_wide_trace(void* dst, int64_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(hicom::g_wide_trace), (size_t)bytes) == hipSuccess ? HICOM_OK : HICOM_ELAUNCH;
+}
+namespace hicom {
+#endif
 
 static int g_num_cus = 0;
 static int num_cus() {
