@@ -262,11 +262,13 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                                       F(w.scores), w.score_stride, w.N, a.H, a.W, a.pe, a.t_index0, a.y_index0,
                                       a.x_index0, F(w.scratch), ml_out, acc_out, solo ? 1 : 0, st);
     };
+    const bool readout16 = a.lw0_f16 && a.lw2_f16 && a.E % 64 == 0 && a.hidden % 64 == 0;
+    bool ctx16_ready = false;      // the window kernel wrote the fp16 plane itself
     auto local_readout = [&](hipStream_t st) -> int {
-        if (a.lw0_f16 && a.lw2_f16 && a.E % 64 == 0 && a.hidden % 64 == 0) {
+        if (readout16) {
             // the hot path's GEMM (one fp16 plane per activation, cached fp16 weights): 12 us per layer at 1296 rows against 26 for the
             // fp32-input form
-            CHK(hicom_to_f16_fwd(F(w.ctx_local), HICOM_DT_F32, ws + w.ctx16, (int64_t)w.nw * a.E, st));
+            if (!ctx16_ready) CHK(hicom_to_f16_fwd(F(w.ctx_local), HICOM_DT_F32, ws + w.ctx16, (int64_t)w.nw * a.E, st));
             CHK(hicom_readout16_gemm_fwd(ws + w.ctx16, a.lw0_f16, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E, HICOM_ACT_GELU, ws + w.hid16, nullptr, 0, 0, 0,
                                          0, nullptr, st));
             CHK(hicom_readout16_gemm_fwd(ws + w.hid16, a.lw2_f16, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden, HICOM_ACT_NONE, nullptr,
@@ -412,9 +414,12 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
             sf_env = (e && e[0] == '0') ? 0 : 1;
         }
         const bool stream_first = sf_env && both && w.rows_pad > 16 && !(a.ak.w0 || a.av.w0) && a.ev_merge && sg == ss;
+        const bool pool_q = a.has_local && !a.lq;                    // guide off: per-window pooled query
         if (stream_first) {
             CHK(global_stream_part());
             HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_merge, ss) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
+            // (the 8-us pooling kernel in front of the wait: it runs under the stream kernel's start)
+            if (pool_q) CHK(hicom_trilinear_pool_fwd(a.ff, a.T, a.H, a.W, a.E, a.at.nwin, a.ay.nwin, a.ax.nwin, F(w.pooled_q), sm));
             HICOM_REQUIRE(hipStreamWaitEvent(sm, (hipEvent_t)a.ev_merge, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
         }
         // Host enqueue order matters (each launch costs a few us of host time): the long local
@@ -424,7 +429,7 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
             int q_dt = a.lq_dt;
             int64_t q_stride = a.lq_stride;
             if (!q) {   // guide off: per-window pooled query
-                CHK(hicom_trilinear_pool_fwd(a.ff, a.T, a.H, a.W, a.E, a.at.nwin, a.ay.nwin, a.ax.nwin, F(w.pooled_q), sm));
+                if (!stream_first) CHK(hicom_trilinear_pool_fwd(a.ff, a.T, a.H, a.W, a.E, a.at.nwin, a.ay.nwin, a.ax.nwin, F(w.pooled_q), sm));
                 q = F(w.pooled_q);
                 q_dt = HICOM_DT_F32;
                 q_stride = a.E;
@@ -451,8 +456,10 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                                                a.adapt_alpha_dt, a.adapt_eps, a.E, a.at, a.ay, a.ax, q, q_dt, q_stride, a.l_scale, a.l_bias,
                                                F(w.ctx_local), sm));
             } else {
+                // (fp16 readout: the contexts leave the window kernel as the fp16 plane the GEMM reads -- no conversion launch)
+                ctx16_ready = readout16;
                 CHK(hicom_local_attn_fwd(a.fe ? a.fe : a.ff, HICOM_DT_BF16, a.ff, HICOM_DT_BF16, a.E, a.at, a.ay, a.ax, q, q_dt, q_stride, a.l_scale,
-                                         a.l_bias, a.l2norm, F(w.ctx_local), sm));
+                                         a.l_bias, a.l2norm, readout16 ? nullptr : F(w.ctx_local), readout16 ? ws + w.ctx16 : nullptr, sm));
             }
         }
         if (a.has_global) {

@@ -30,6 +30,7 @@ struct LocalParams {
     float scale, bias;
     int l2norm;
     float* ctx;
+    _Float16* ctx16;             // fp16 [Nw, D] (saturating) instead of / beside ctx: the operand of hicom_readout16_gemm_fwd, or NULL
 };
 
 template <int NV>
@@ -186,8 +187,11 @@ __global__ __launch_bounds__(256) void local_attn_kernel(LocalParams p) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) part[wave * D + 384 * s + 6 * lane + j] = acc[s][j];
     __syncthreads();
-    float* out = p.ctx + (long)win * D;
-    for (int c = tid; c < D; c += 256) out[c] = (part[c] + part[D + c]) + (part[2 * D + c] + part[3 * D + c]);
+    for (int c = tid; c < D; c += 256) {
+        const float v = (part[c] + part[D + c]) + (part[2 * D + c] + part[3 * D + c]);
+        if (p.ctx) p.ctx[(long)win * D + c] = v;
+        if (p.ctx16) p.ctx16[(long)win * D + c] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+    }
 }
 
 // ---- windowed attention with the adaptor blend fused into the row loads ("fused into the K/V tile load") -------
@@ -1066,8 +1070,8 @@ extern "C" int hicom_local_attn_fwd(const void* key, int32_t key_dt, const void*
                                     hicom_axis at, hicom_axis ay, hicom_axis ax,
                                     const void* query, int32_t query_dt, int64_t query_stride,
                                     float scale, float bias, int32_t l2norm,
-                                    float* ctx, void* stream) {
-    HICOM_REQUIRE(key && value && query && ctx, HICOM_EINVAL, "local_attn: NULL pointer");
+                                    float* ctx, void* ctx_f16, void* stream) {
+    HICOM_REQUIRE(key && value && query && (ctx || ctx_f16), HICOM_EINVAL, "local_attn: NULL pointer");
     HICOM_REQUIRE(D == 1152 || D == 768, HICOM_EUNSUP, "local_attn: D=%d (only 1152 / 768)", D);
     HICOM_REQUIRE(query_dt == HICOM_DT_BF16 || query_dt == HICOM_DT_F32, HICOM_EINVAL, "local_attn: query dtype");
     HICOM_REQUIRE(key_dt >= 0 && key_dt <= 2 && value_dt >= 0 && value_dt <= 2, HICOM_EINVAL, "local_attn: stream dtype");
@@ -1082,7 +1086,7 @@ extern "C" int hicom_local_attn_fwd(const void* key, int32_t key_dt, const void*
     const long nwin = (long)at.nwin * ay.nwin * ax.nwin;
     HICOM_REQUIRE(nwin < (1L << 31), HICOM_EINVAL, "local_attn: too many windows");
     LocalParams p{key, value, key_dt, value_dt, query, query_dt == HICOM_DT_F32,
-                  (long)query_stride, at, ay, ax, scale, bias, l2norm, ctx};
+                  (long)query_stride, at, ay, ax, scale, bias, l2norm, ctx, (_Float16*)ctx_f16};
     const size_t smem = (((size_t)win + 3) & ~(size_t)3) * 4 + 4 * (size_t)D * 4;
     hipStream_t s = (hipStream_t)stream;
     if (D == 1152) hipLaunchKernelGGL(local_attn_kernel<3>, dim3((unsigned)nwin), dim3(256), smem, s, p);

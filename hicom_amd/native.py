@@ -117,7 +117,7 @@ def lib() -> C.CDLL:
     if L.hicom_abi_version() != ABI_VERSION:
         raise HicomNativeError(f"ABI mismatch: library {L.hicom_abi_version()} vs binding {ABI_VERSION}; rebuild")
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
-    L.hicom_local_attn_fwd.argtypes = [vp, i32, vp, i32, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32, i32, vp, vp]
+    L.hicom_local_attn_fwd.argtypes = [vp, i32, vp, i32, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32, i32, vp, vp, vp]
     L.hicom_local_attn_bwd.argtypes = [vp, vp, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32, vp, vp, vp, vp]
     L.hicom_trilinear_pool_fwd.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.hicom_linear_fwd.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
@@ -226,10 +226,10 @@ def _stream():
 # ------------------------------------------------------------------------------------------
 # thin typed wrappers (one per entry point)
 # ------------------------------------------------------------------------------------------
-def local_attn(key, value, axes, query, query_stride, scale, bias, l2norm, ctx):
+def local_attn(key, value, axes, query, query_stride, scale, bias, l2norm, ctx, ctx_f16=None):
     D = value.shape[-1]
     _check(lib().hicom_local_attn_fwd(_ptr(key), _dt(key), _ptr(value), _dt(value), D, axes[0], axes[1], axes[2], _ptr(query), _dt(query),
-                                      query_stride, scale, bias, l2norm, _ptr(ctx), _stream()), "hicom_local_attn_fwd")
+                                      query_stride, scale, bias, l2norm, _ptr(ctx), _ptr(ctx_f16), _stream()), "hicom_local_attn_fwd")
 
 
 def local_attn_adapt(key_x, key_y, k_norm, k_alpha, value_x, value_y, v_norm, v_alpha, axes, query, query_stride, scale, bias, ctx, eps=1e-6):

@@ -62,7 +62,8 @@ typedef struct hicom_axis {
  *                projector.py:352-368) or [Nw, D] with row stride query_stride elements;
  *                dtype query_dt
  *   logits     : (q.k) * scale + bias        (scale = 1/sqrt(D) or exp(logit_scale))
- *   ctx        : f32 [Nw, D], window order (t1,h1,w1) row-major, Nw = at.nwin*ay.nwin*ax.nwin
+ *   ctx        : f32 [Nw, D], window order (t1,h1,w1) row-major, Nw = at.nwin*ay.nwin*ax.nwin; and / or
+ *   ctx_f16    : the same contexts as one fp16 plane (saturating): the operand of hicom_readout16_gemm_fwd (either may be NULL)
  *   l2norm     : bit 0 = L2-normalise every key row, bit 1 = L2-normalise the query
  *                (clip-scale variant, projector.py:527-529)
  * D must be 1152 or 768 (projector.py:407-414). */
@@ -70,7 +71,7 @@ int hicom_local_attn_fwd(const void* key, int32_t key_dt, const void* value, int
                          hicom_axis at, hicom_axis ay, hicom_axis ax,
                          const void* query, int32_t query_dt, int64_t query_stride,
                          float scale, float bias, int32_t l2norm,
-                         float* ctx, void* stream);
+                         float* ctx, void* ctx_f16, void* stream);
 
 /* ---- windowed attention with the k / v adaptor blend fused into its row loads (projector.py:533-534 in front of :544-553) ----
  *   key_n = (1 - a_k) key_x_n + a_k (LayerNorm_eps(key_y_n) k_gamma + k_beta),  key_y = k_proj(key_x) (the two dense GEMMs of the

@@ -45,13 +45,13 @@ int main() {
     CK(hipMemcpy(dq, q.data(), q.size() * 2, hipMemcpyHostToDevice));
     hicom_axis at{T, kt, T / kt, T / kt}, ay{H, ks, H / ks, H / ks}, ax{W, ks, W / ks, W / ks};
     const float scale = 1.0f / sqrtf((float)D);
-    int rc = hicom_local_attn_fwd(dk, HICOM_DT_BF16, dv, HICOM_DT_BF16, D, at, ay, ax, dq, HICOM_DT_BF16, 0, scale, 0.0f, 0, dctx, nullptr);
+    int rc = hicom_local_attn_fwd(dk, HICOM_DT_BF16, dv, HICOM_DT_BF16, D, at, ay, ax, dq, HICOM_DT_BF16, 0, scale, 0.0f, 0, dctx, nullptr, nullptr);
     if (rc != HICOM_OK) { printf("hicom_local_attn_fwd failed: %d %s\n", rc, hicom_last_error()); return 4; }
     CK(hipDeviceSynchronize());
     std::vector<float> ctx((size_t)nw * D);
     CK(hipMemcpy(ctx.data(), dctx, ctx.size() * 4, hipMemcpyDeviceToHost));
     // an argument error comes back as a status + message, never as an exception or a crash
-    rc = hicom_local_attn_fwd(dk, HICOM_DT_BF16, dv, HICOM_DT_BF16, 1000, at, ay, ax, dq, HICOM_DT_BF16, 0, scale, 0.0f, 0, dctx, nullptr);
+    rc = hicom_local_attn_fwd(dk, HICOM_DT_BF16, dv, HICOM_DT_BF16, 1000, at, ay, ax, dq, HICOM_DT_BF16, 0, scale, 0.0f, 0, dctx, nullptr, nullptr);
     if (rc == HICOM_OK || !hicom_last_error()[0]) { printf("bad D was accepted\n"); return 5; }
     double worst = 0;
     for (int w = 0; w < nw; ++w) {
