@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void local_attn_kernel(LocalParams p) {
         for (int s = 0; s < NV; ++s)
 #pragma unroll
             for (int j = 0; j < 6; ++j) qq += q[s][j] * q[s][j];
-        const float inv = 1.0f / sqrtf(wave_sum(qq));
+        const float inv = 1.0f / sqrtf(wave_sum_fast(qq));
 #pragma unroll
         for (int s = 0; s < NV; ++s)
 #pragma unroll
@@ -141,8 +141,8 @@ __global__ __launch_bounds__(256) void local_attn_kernel(LocalParams p) {
                         dot = fmaf(q[s][j], k[u][s][j], dot);
                         kk = fmaf(k[u][s][j], k[u][s][j], kk);
                     }
-                dot = wave_sum(dot);
-                if (p.l2norm & 1) dot /= sqrtf(wave_sum(kk));   // frames_embed / ||.||  (:528)
+                dot = wave_sum_fast(dot);
+                if (p.l2norm & 1) dot /= sqrtf(wave_sum_fast(kk));   // frames_embed / ||.||  (:528)
                 if (lane == 0) sc[i] = dot * p.scale + p.bias;
             }
         }
@@ -152,10 +152,10 @@ __global__ __launch_bounds__(256) void local_attn_kernel(LocalParams p) {
     // ---- softmax statistics (every wave redundantly; WIN is tiny) -------------------------
     float mx = -3.0e38f;
     for (int i = lane; i < WIN; i += 64) mx = fmaxf(mx, sc[i]);
-    mx = wave_max(mx);
+    mx = wave_max_fast(mx);
     float sum = 0.f;
     for (int i = lane; i < WIN; i += 64) sum += expf(sc[i] - mx);
-    const float inv_sum = 1.0f / wave_sum(sum);
+    const float inv_sum = 1.0f / wave_sum_fast(sum);
 
     // ---- phase 2: context = sum_i p_i * value_i ---------------------------------------------
     float acc[NV][6];
@@ -261,8 +261,8 @@ __global__ __launch_bounds__(256) void local_attn_adapt_kernel(LocalAdaptParams 
                 cg += qg[s][j];
                 cb = fmaf(q[s][j], b[s][j], cb);
             }
-        cg = wave_sum(cg);
-        cb = wave_sum(cb);
+        cg = wave_sum_fast(cg);
+        cb = wave_sum_fast(cb);
     }
     auto token_of = [&](int i) -> long {
         const int t2 = i / ks2, r = i - t2 * ks2;
@@ -297,16 +297,16 @@ __global__ __launch_bounds__(256) void local_attn_adapt_kernel(LocalAdaptParams 
                             s1 += ky[u][s][j];
                         }
                     }
-                dx = wave_sum(dx);
+                dx = wave_sum_fast(dx);
                 float logit = dx;
                 if (p.ky) {
-                    dy = wave_sum(dy);
-                    const float mu = wave_sum(s1) * (1.0f / D);
+                    dy = wave_sum_fast(dy);
+                    const float mu = wave_sum_fast(s1) * (1.0f / D);
 #pragma unroll
                     for (int s = 0; s < NV; ++s)
 #pragma unroll
                         for (int j = 0; j < 6; ++j) { const float d = ky[u][s][j] - mu; s2 = fmaf(d, d, s2); }
-                    const float rstd = 1.0f / sqrtf(wave_sum(s2) * (1.0f / D) + p.eps);
+                    const float rstd = 1.0f / sqrtf(wave_sum_fast(s2) * (1.0f / D) + p.eps);
                     logit = (1.0f - ak) * dx + ak * (rstd * (dy - mu * cg) + cb);
                 }
                 if (lane == 0) sc[i] = logit * p.scale + p.bias;
@@ -316,10 +316,10 @@ __global__ __launch_bounds__(256) void local_attn_adapt_kernel(LocalAdaptParams 
     __syncthreads();
     float mx = -3.0e38f;
     for (int i = lane; i < WIN; i += 64) mx = fmaxf(mx, sc[i]);
-    mx = wave_max(mx);
+    mx = wave_max_fast(mx);
     float sum = 0.f;
     for (int i = lane; i < WIN; i += 64) sum += expf(sc[i] - mx);
-    const float inv_sum = 1.0f / wave_sum(sum);
+    const float inv_sum = 1.0f / wave_sum_fast(sum);
 
     // ---- phase 2: context ----------------------------------------------------------------
     float accx[NV][6], accy[NV][6];
@@ -351,12 +351,12 @@ __global__ __launch_bounds__(256) void local_attn_adapt_kernel(LocalAdaptParams 
                     for (int s = 0; s < NV; ++s)
 #pragma unroll
                         for (int j = 0; j < 6; ++j) s1 += vy[u][s][j];
-                    const float mu = wave_sum(s1) * (1.0f / D);
+                    const float mu = wave_sum_fast(s1) * (1.0f / D);
 #pragma unroll
                     for (int s = 0; s < NV; ++s)
 #pragma unroll
                         for (int j = 0; j < 6; ++j) { const float d = vy[u][s][j] - mu; s2 = fmaf(d, d, s2); }
-                    const float rstd = 1.0f / sqrtf(wave_sum(s2) * (1.0f / D) + p.eps);
+                    const float rstd = 1.0f / sqrtf(wave_sum_fast(s2) * (1.0f / D) + p.eps);
                     w = pi * rstd;
                     smu = fmaf(w, mu, smu);
                 }
@@ -478,8 +478,8 @@ __global__ __launch_bounds__(256) void local_attn_bwd_kernel(LocalBwdParams p) {
                         dot = fmaf(q[s][j], k[u][s][j], dot);
                         dd = fmaf(g[s][j], v[u][s][j], dd);
                     }
-                dot = wave_sum(dot);
-                dd = wave_sum(dd);
+                dot = wave_sum_fast(dot);
+                dd = wave_sum_fast(dd);
                 if (lane == 0) { sc[i] = dot * p.scale + p.bias; dp[i] = dd; }
             }
         }
@@ -489,15 +489,15 @@ __global__ __launch_bounds__(256) void local_attn_bwd_kernel(LocalBwdParams p) {
     // ---- softmax statistics and delta (every wave redundantly; WIN is tiny) ----------------------------
     float mx = -3.0e38f;
     for (int i = lane; i < WIN; i += 64) mx = fmaxf(mx, sc[i]);
-    mx = wave_max(mx);
+    mx = wave_max_fast(mx);
     float sum = 0.f, pd = 0.f;
     for (int i = lane; i < WIN; i += 64) {
         const float e = expf(sc[i] - mx);
         sum += e;
         pd = fmaf(e, dp[i], pd);
     }
-    const float inv_sum = 1.0f / wave_sum(sum);
-    const float delta = wave_sum(pd) * inv_sum;
+    const float inv_sum = 1.0f / wave_sum_fast(sum);
+    const float delta = wave_sum_fast(pd) * inv_sum;
     __syncthreads();                               // every wave has read sc / dp as scores
     if (wave == 0)
         for (int i = lane; i < WIN; i += 64) sc[i] = expf(sc[i] - mx) * inv_sum * (dp[i] - delta);     // dS
@@ -620,8 +620,8 @@ __global__ __launch_bounds__(256) void local_attn_adapt_bwd_kernel(LocalAdaptBwd
         for (int s = 0; s < NV; ++s)
 #pragma unroll
             for (int j = 0; j < 6; ++j) { qg[s][j] = q[s][j] * ga[s][j]; cgk += qg[s][j]; cbk = fmaf(q[s][j], be[s][j], cbk); }
-        cgk = wave_sum(cgk);
-        cbk = wave_sum(cbk);
+        cgk = wave_sum_fast(cgk);
+        cbk = wave_sum_fast(cbk);
     }
     if (p.vy) {
         float ga[NV][6], be[NV][6];
@@ -631,8 +631,8 @@ __global__ __launch_bounds__(256) void local_attn_adapt_bwd_kernel(LocalAdaptBwd
         for (int s = 0; s < NV; ++s)
 #pragma unroll
             for (int j = 0; j < 6; ++j) { gg[s][j] = g[s][j] * ga[s][j]; cgv += gg[s][j]; cbv = fmaf(g[s][j], be[s][j], cbv); }
-        cgv = wave_sum(cgv);
-        cbv = wave_sum(cbv);
+        cgv = wave_sum_fast(cgv);
+        cbv = wave_sum_fast(cbv);
     }
     auto token_of = [&](int i) -> long {
         const int t2 = i / ks2, r = i - t2 * ks2;
@@ -650,16 +650,16 @@ __global__ __launch_bounds__(256) void local_attn_adapt_bwd_kernel(LocalAdaptBwd
                 dx = fmaf(v[s][j], x[s][j], dx);
                 if (has_y) { dy = fmaf(vgm[s][j], y[s][j], dy); s1 += y[s][j]; }
             }
-        dx = wave_sum(dx);
+        dx = wave_sum_fast(dx);
         if (!has_y) return dx;
-        dy = wave_sum(dy);
-        const float mu = wave_sum(s1) * (1.0f / D);
+        dy = wave_sum_fast(dy);
+        const float mu = wave_sum_fast(s1) * (1.0f / D);
         float s2 = 0.f;
 #pragma unroll
         for (int s = 0; s < NV; ++s)
 #pragma unroll
             for (int j = 0; j < 6; ++j) { const float d = y[s][j] - mu; s2 = fmaf(d, d, s2); }
-        const float rstd = 1.0f / sqrtf(wave_sum(s2) * (1.0f / D) + p.eps);
+        const float rstd = 1.0f / sqrtf(wave_sum_fast(s2) * (1.0f / D) + p.eps);
         mu_o = mu; rstd_o = rstd;
         return (1.0f - a) * dx + a * (rstd * (dy - mu * cg) + cb);
     };
@@ -686,15 +686,15 @@ __global__ __launch_bounds__(256) void local_attn_adapt_bwd_kernel(LocalAdaptBwd
     // ---- softmax statistics and delta (every wave redundantly; WIN is tiny) ----------------------------------------------------
     float mx = -3.0e38f;
     for (int i = lane; i < WIN; i += 64) mx = fmaxf(mx, sc[i]);
-    mx = wave_max(mx);
+    mx = wave_max_fast(mx);
     float sum = 0.f, pd = 0.f;
     for (int i = lane; i < WIN; i += 64) {
         const float e = expf(sc[i] - mx);
         sum += e;
         pd = fmaf(e, dp[i], pd);
     }
-    const float inv_sum = 1.0f / wave_sum(sum);
-    const float delta = wave_sum(pd) * inv_sum;
+    const float inv_sum = 1.0f / wave_sum_fast(sum);
+    const float delta = wave_sum_fast(pd) * inv_sum;
     __syncthreads();                               // every wave has read sc / dp as scores / dP
     if (wave == 0)
         for (int i = lane; i < WIN; i += 64) {
@@ -794,13 +794,13 @@ __global__ __launch_bounds__(256) void adapt_dy_kernel(AdaptDyParams p) {
     for (int s = 0; s < NV; ++s)
 #pragma unroll
         for (int j = 0; j < 6; ++j) s1 += y[s][j];
-    const float mu = wave_sum(s1) * (1.0f / D);
+    const float mu = wave_sum_fast(s1) * (1.0f / D);
     float s2 = 0.f;
 #pragma unroll
     for (int s = 0; s < NV; ++s)
 #pragma unroll
         for (int j = 0; j < 6; ++j) { y[s][j] -= mu; s2 = fmaf(y[s][j], y[s][j], s2); }
-    const float rstd = 1.0f / sqrtf(wave_sum(s2) * (1.0f / D) + p.eps);
+    const float rstd = 1.0f / sqrtf(wave_sum_fast(s2) * (1.0f / D) + p.eps);
     float m1 = 0.f, m2 = 0.f;
 #pragma unroll
     for (int s = 0; s < NV; ++s)
@@ -812,8 +812,8 @@ __global__ __launch_bounds__(256) void adapt_dy_kernel(AdaptDyParams p) {
             m2 = fmaf(gv, y[s][j], m2);
             ga[s][j] = gv;                           // (vec gamma)
         }
-    m1 = wave_sum(m1) * (1.0f / D);
-    m2 = wave_sum(m2) * (1.0f / D);
+    m1 = wave_sum_fast(m1) * (1.0f / D);
+    m2 = wave_sum_fast(m2) * (1.0f / D);
     const float k = alpha * c * rstd;
     uint16_t* o = p.dy + tok * D;
 #pragma unroll
