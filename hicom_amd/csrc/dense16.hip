@@ -604,14 +604,14 @@ __global__ __launch_bounds__(256) void ln_stream_kernel(LnStreamParams p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) sum += v[c][i];
     }
-    const float mean = wave_sum(sum) / (float)p.E;
+    const float mean = wave_sum_fast(sum) / (float)p.E;
     float var = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
         if (lane + 64 * c < nch)
 #pragma unroll
             for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mean; var = fmaf(d, d, var); }
-    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)p.E + p.eps);
+    const float rstd = 1.0f / sqrtf(wave_sum_fast(var) / (float)p.E + p.eps);
     float alpha = 1.0f;
     if (p.alpha) alpha = p.alpha_dt == HICOM_DT_F32 ? *reinterpret_cast<const float*>(p.alpha) : bf16_to_f32(*reinterpret_cast<const uint16_t*>(p.alpha));
 #pragma unroll
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void l2norm_stream_kernel(const uint16_t* x, u
 #pragma unroll
         for (int i = 0; i < 8; ++i) ss = fmaf(v[c][i], v[c][i], ss);
     }
-    const float inv = 1.0f / sqrtf(wave_sum(ss));
+    const float inv = 1.0f / sqrtf(wave_sum_fast(ss));
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int ch = lane + 64 * c;

@@ -242,8 +242,7 @@ __global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
         float tmax = -1.0e30f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) tmax = (n0 + j < p.N) ? fmaxf(tmax, lg[j]) : tmax;
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = xrow4_max(tmax);                          // (the row's four lanes r16 + 16 kg: gfx950 row swaps, no LDS round trip)
         const float m_new = fmaxf(m_run, tmax);
         const float alpha = expf(m_run - m_new);
         float lsum = 0.f;
@@ -252,8 +251,7 @@ __global__ __launch_bounds__(256, 2) void global_stream_kernel(StreamParams p) {
             pr[j] = (n0 + j < p.N) ? expf(lg[j] - m_new) : 0.f;
             lsum += pr[j];
         }
-        lsum += __shfl_xor(lsum, 16, 64);
-        lsum += __shfl_xor(lsum, 32, 64);
+        lsum = xrow4_sum(lsum);
         l_run = l_run * alpha + lsum;
         m_run = m_new;
         // rescale the running context when any row's max moved (wave-uniform branch)

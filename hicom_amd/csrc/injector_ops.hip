@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void row_ln_kernel(RowLnParams p) {
         v[i] = t;
         sum += t;
     }
-    const float mean = wave_sum(sum) / (float)p.E;
+    const float mean = wave_sum_fast(sum) / (float)p.E;
     float var = 0.f;
 #pragma unroll
     for (int i = 0; i < n; ++i) {
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void row_ln_kernel(RowLnParams p) {
         const float d = c < p.E ? v[i] - mean : 0.f;
         var += d * d;
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)p.E + p.eps);
+    const float rstd = 1.0f / sqrtf(wave_sum_fast(var) / (float)p.E + p.eps);
     const float alpha = p.alpha_ptr ? ld(p.alpha_ptr, p.alpha_dt, 0) : 1.0f;
 #pragma unroll
     for (int i = 0; i < n; ++i) {
@@ -114,14 +114,14 @@ __global__ __launch_bounds__(256) void row_ln8_kernel(RowLnParams p) {
             sum += v[c][i];
         }
     }
-    const float mean = wave_sum(sum) / (float)p.E;
+    const float mean = wave_sum_fast(sum) / (float)p.E;
     float var = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
         if (lane + 64 * c < nch)
 #pragma unroll
             for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mean; var = fmaf(d, d, var); }
-    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)p.E + p.eps);
+    const float rstd = 1.0f / sqrtf(wave_sum_fast(var) / (float)p.E + p.eps);
     const float alpha = p.alpha_ptr ? ld(p.alpha_ptr, p.alpha_dt, 0) : 1.0f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -168,9 +168,9 @@ __global__ __launch_bounds__(256) void small_mha_kernel(const float* q, const fl
         for (int c = 0; c < hd; ++c) d = fmaf(qh[c], kh[c], d);
         s = d * scale;
     }
-    const float mx = wave_max(s);
+    const float mx = wave_max_fast(s);
     const float e = lane < L ? expf(s - mx) : 0.f;
-    const float pr = e / wave_sum(e);
+    const float pr = e / wave_sum_fast(e);
     for (int c0 = 0; c0 < hd; c0 += 64) {
         const int c = c0 + lane;
         float a = 0.f;

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void frame_marginals_kernel(const float* score
     } else {
         for (int i = threadIdx.x; i < HW; i += 256) mx = fmaxf(mx, s[i]);
     }
-    mx = wave_max(mx);
+    mx = wave_max_fast(mx);
     if (lane == 0) wred[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
@@ -134,14 +134,14 @@ struct MergeCtxParams {
 };
 
 __device__ __forceinline__ float block_reduce_max(float v, float* red) {
-    v = wave_max(v);
+    v = wave_max_fast(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
-    v = wave_sum(v);
+    v = wave_sum_fast(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(LinearParams p) {
     }
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
-        const float s = wave_sum(acc[r]);
+        const float s = wave_sum_fast(acc[r]);
         const int m = m0 + r;
         if (lane == 0 && m < p.M) {
             float v = s;
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void clip_query_prep_kernel(float* qp, const u
     const int q = blockIdx.x, tid = threadIdx.x, hd = E / nh;
     float ss = 0.f;
     for (int i = tid; i < E; i += 256) { const float v = qp[(long)q * E + i]; ss = fmaf(v, v, ss); }
-    ss = wave_sum(ss);
+    ss = wave_sum_fast(ss);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
     const float inv = 1.0f / sqrtf((red[0] + red[1]) + (red[2] + red[3]));
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void clip_query_prep_kernel(float* qp, const u
         float d = 0.f;
         if (bk)
             for (int j = lane; j < hd; j += 64) d = fmaf(qp[(long)q * E + h * hd + j], bf16_to_f32(bk[h * hd + j]), d);
-        d = wave_sum(d);
+        d = wave_sum_fast(d);
         if (lane == 0) c[q * nh + h] = scale * d;
     }
 }
