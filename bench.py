@@ -248,13 +248,12 @@ def main():
     with torch.no_grad():
         # a step is ~0.1 ms: a fresh process needs a few hundred of them before clocks, caches of lazily loaded code
         # objects and the allocator have settled (a cold 50-step run measured 151 us/step, the next one 88)
+        gc.collect()                       # the collector pass takes tens of ms: BEFORE the warm-up, so that the GPU does not sit idle
+        gc.disable()                       # (and drop its clocks) between the warm-up and the timed region; no collector pause inside it
         for _ in range(PRE_WARMUP_STEPS):
             step()
-        fence()
-        gc.collect()
-        gc.disable()                       # no collector pause inside the timed region (a step is ~0.1 ms)
-        for _ in range(args.warmup):       # the W warm-up steps run right in front of the timed region (the collector pass above
-            out = step()                   # idles the GPU for tens of ms, long enough for its clocks to drop)
+        for _ in range(args.warmup):       # the W warm-up steps run right in front of the timed region
+            out = step()
         assert out.shape == (n_out, args.hidden)
         # N = 1: the drop-in call, joined.  N > 1: there is no reference call to be a drop-in for (the reference never
         # shards a video); the metric is a throughput, so the timed loop is the steady-state serving loop of the frame-
