@@ -450,6 +450,9 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
             ent.update(graph=g, outs=outs, **st)
         except Exception as e:  # noqa: BLE001
             ent["failed"] = repr(e)
+            import warnings
+            warnings.warn(f"hicom_amd: capturing the backward of shape {tuple(ff.shape)} into a hipGraph failed ({e!r}); this shape keeps "
+                          "the eager backward (~2x slower per training step)", RuntimeWarning, stacklevel=2)
             return eager()
     ent["ff"].copy_(ff)
     if fe is not None:

@@ -1,7 +1,9 @@
 """Compiles the HIP sources into hicom_amd/libhicom_hip.so (gfx950 only, in-tree).
 
-One object per source under hicom_amd/build/ (compiled in parallel, recompiled only when the source, a shared header or the
-flags changed), then one link: an edit of one kernel file costs one compile, not thirteen."""
+One object per source under hicom_amd/build/ (compiled in parallel, recompiled only when the source, a shared header, the flag
+list or the compiler changed: the object names carry a hash of the last two), then one link: an edit of one kernel file costs
+one compile, not thirteen.  Objects and the library are written to private temporaries and renamed into place, so concurrent
+builders of one tree cannot tear each other's files."""
 from __future__ import annotations
 
 import glob
@@ -45,6 +47,19 @@ def _obj_of(src: str, tag: str) -> str:
     return os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + tag + ".o")
 
 
+_CC_ID = {}
+
+
+def _toolchain_id(cc: str) -> str:
+    """`hipcc --version` (cached per process): part of the object tag, so objects of another compiler are never linked."""
+    if cc not in _CC_ID:
+        try:
+            _CC_ID[cc] = subprocess.run([cc, "--version"], capture_output=True, text=True, timeout=60).stdout
+        except Exception:
+            _CC_ID[cc] = cc
+    return _CC_ID[cc]
+
+
 def build(force: bool = False, verbose: bool = True, extra_flags=(), lib_path: str = None) -> str:
     """extra_flags / lib_path: instrumented dev builds (tools/) go to their own library and their own objects."""
     # HICOM_FORCE_BUILD=1: compile even when an up-to-date library is present (the driver's "does it build" check)
@@ -54,7 +69,8 @@ def build(force: bool = False, verbose: bool = True, extra_flags=(), lib_path: s
         return LIB
     cc = hipcc()
     flags = FLAGS + list(extra_flags)
-    tag = "" if not extra_flags else "." + hashlib.sha1(" ".join(extra_flags).encode()).hexdigest()[:8]
+    # the object tag covers the FULL flag list and the compiler's identity: a change of either recompiles everything
+    tag = "." + hashlib.sha1((" ".join(flags) + "\n" + _toolchain_id(cc)).encode()).hexdigest()[:10]
     os.makedirs(OBJ_DIR, exist_ok=True)
     hdr_t = max(os.path.getmtime(h) for h in headers())
     todo = []
@@ -64,19 +80,33 @@ def build(force: bool = False, verbose: bool = True, extra_flags=(), lib_path: s
             todo.append((s, o))
 
     def compile_one(so):
+        # to a private temporary, then an atomic rename: several processes building the same tree (ranks of `bench.py --gpus N` on a
+        # stale checkout) never see -- or link -- a half-written object
         s, o = so
-        cmd = [cc, *flags, "-c", s, "-o", o]
+        tmp = f"{o}.tmp.{os.getpid()}"
+        cmd = [cc, *flags, "-c", s, "-o", tmp]
         if verbose:
-            print("[hicom_amd] " + " ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+            print("[hicom_amd] " + " ".join(cmd[:-1] + [o]), file=sys.stderr)
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, o)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
 
     workers = max(1, min(len(todo), (os.cpu_count() or 2) - 1, 8))
     with ThreadPoolExecutor(max_workers=workers) as ex:
         list(ex.map(compile_one, todo))
-    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *[_obj_of(s, tag) for s in sources()]]
+    tmp_out = f"{out}.tmp.{os.getpid()}"
+    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_out, *[_obj_of(s, tag) for s in sources()]]
     if verbose:
         print("[hicom_amd] " + " ".join(link), file=sys.stderr)
-    subprocess.check_call(link)
+    try:
+        subprocess.check_call(link)
+        os.replace(tmp_out, out)
+    finally:
+        if os.path.exists(tmp_out):
+            os.remove(tmp_out)
     return out
 
 

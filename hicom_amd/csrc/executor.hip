@@ -32,7 +32,7 @@ namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct WsLayout {
-    size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, ctx16, hid16, ad_hid, ad_ky, ad_vy, qp, qhi, qlo, pos_a, prep_state, scores, part_m, part_l, part_acc, scratch, ml, acc,
+    size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, ctx16, hid16, ad_hid, ad_ky, ad_vy, qp, qhi, qlo, pos_a, prep_state, tail_state, scores, part_m, part_l, part_acc, scratch, ml, acc,
         ctx_g, o, qres, pre, hid_g, tok, po, o_fix, r0, total;
     int nw, R, rows_pad, nparts, P;
     long N, score_stride;
@@ -84,6 +84,7 @@ WsLayout make_layout(const hicom_compressor_args& a) {
     w.qlo = take((size_t)w.rows_pad * a.E * 2);
     w.pos_a = take((size_t)w.rows_pad * (a.P > 0 ? a.P : 1) * 4);
     w.prep_state = take(a.has_global ? (size_t)hicom_query_prep_state_bytes(a.E) : 0);   // (epoch word + granules: zero once)
+    w.tail_state = take(a.has_global ? (size_t)hicom_r16_chain_state_bytes(a.hidden) : 0);  // (the GEMV chain inside readout GEMM 2's launch: zero once)
     if (a.has_local) {
         w.ctx_local = take((size_t)w.nw * a.E * 4);          // fp32 form (two-kernel path) ...
         w.hid_local = take((size_t)w.nw * a.hidden * 4);
@@ -320,7 +321,38 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                                    a.x_index0, F(w.part_m), F(w.part_l), F(w.part_acc),
                                    w.nparts, nullptr, f16 ? nullptr : ws + w.ctx_hi, f16 ? nullptr : ws + w.ctx_lo, f16 ? ws + w.ctx_hi : nullptr,
                                    single ? ws + w.o_fix : nullptr, single ? (int64_t)a.E * 8 : 0, single ? ws + w.part_acc : nullptr, sm));
-        if (single) {
+        // Round 5: FOUR launches.  The merge of the partial states is independent of the local readout, and the global tail behind it
+        // is two dependent single-row layers: the merge rides as a ROLE on the CUs readout GEMM 1's tile grid leaves idle, the two layers
+        // as a chain role (in-launch granule hand-off) under GEMM 2 -- the merge launch (5.2 us) is gone from the step.
+        // HICOM_TAIL_LAUNCHES=5 keeps round 4's five-launch form (A/B switch).
+        static int tail_env = -1;
+        if (tail_env < 0) {
+            const char* e = getenv("HICOM_TAIL_LAUNCHES");
+            tail_env = (e && e[0] == '5') ? 5 : 4;
+        }
+        const bool tail4 = single && tail5 && ro2_aux && tail_env == 4;
+        if (single && tail4) {
+            const int64_t* ofx = (const int64_t*)(ws + w.o_fix);
+            hicom_r16_role r1;
+            memset(&r1, 0, sizeof(r1));
+            r1.kind = HICOM_ROLE_MERGE_VPROJ;
+            r1.part_m = F(w.part_m); r1.part_l = F(w.part_l); r1.part_acc = ws + w.part_acc; r1.part_dt = HICOM_DT_F16;
+            r1.nparts = w.nparts; r1.rows = w.R; r1.rows_pad = w.rows_pad; r1.E = a.E; r1.w_v = a.wv; r1.o_fix = (int64_t*)(ws + w.o_fix);
+            r1.out_ml = F(w.ml); r1.out_ctx = F(w.ctx_g);
+            CHK(hicom_readout16_gemm_role_fwd(ws + w.ctx_hi, a.lw0_f16, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E, HICOM_ACT_GELU,
+                                              ws + w.hid_hi, nullptr, 0, 0, 0, 0, &r1, sm));
+            hicom_r16_role r2;
+            memset(&r2, 0, sizeof(r2));
+            r2.kind = HICOM_ROLE_GEMV_CHAIN;
+            r2.gemv = hicom_aux_gemv{nullptr, 0, 0, a.bv, a.gc0, F(w.r0), nullptr, a.hidden, a.E, HICOM_ACT_GELU, F(w.hid_g),
+                                     HICOM_DT_F32, HICOM_DT_F32, nullptr, 0, 0, 0, 0, ofx};
+            r2.gemv2 = hicom_aux_gemv{nullptr, 0, 0, nullptr, a.gw2, a.gb2, nullptr, a.hidden, a.hidden, HICOM_ACT_NONE, nullptr,
+                                      HICOM_DT_BF16, HICOM_DT_BF16, a.out, a.out_dt, a.n_global_rows, a.ldo, a.global_row0, nullptr};
+            r2.chain_state = ws + w.tail_state;
+            CHK(hicom_readout16_gemm_role_fwd(ws + w.hid_hi, a.lw2_f16, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden, HICOM_ACT_NONE,
+                                              nullptr, a.local_out ? a.local_out : a.out, a.out_dt, a.local_out ? a.hidden : a.ldo,
+                                              a.local_out ? 0 : a.local_row0, a.local_out ? 0 : a.nl_group, &r2, sm));
+        } else if (single) {
             // merge + v_proj with the slab sums taken inside the launch (fixed-point accumulators, cleared by the stream kernel):
             // GEMM 1's aux role reads ONE 9-KB vector instead of E/64 partial vectors (83 KB per workgroup)
             // (the partial states travel as normalised fp16 contexts in the bytes of the fp32 accumulators: half of them)
@@ -346,6 +378,8 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
             CHK(hicom_readout16_gemm_fwd(ws + w.hid_hi, a.lw2_f16, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden, HICOM_ACT_NONE,
                                          nullptr, a.local_out ? a.local_out : a.out, a.out_dt, a.local_out ? a.hidden : a.ldo,
                                          a.local_out ? 0 : a.local_row0, a.local_out ? 0 : a.nl_group, (tail5 && !ro2_aux) ? nullptr : &ax2, sm));
+        }
+        if (single) {
             if (a.nl_count > 0 && !a.local_out)
                 CHK(hicom_scatter_rows_fwd(a.newline, a.newline_dt, 1, a.hidden, a.out, a.out_dt, a.ldo, a.nl_first, a.nl_step,
                                            0, a.nl_count, sm));

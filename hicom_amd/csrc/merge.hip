@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "merge_item.hpp"
 
 namespace hicom {
 
@@ -499,101 +500,10 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(MergeVprojParams p) {
 // to launch).  o_fix must be zero on entry: hicom_fused_stream_fwd zeroes it (same stream, one launch earlier).
 // Narrower slabs (32 channels, 36 x 9 = 324 workgroups, two or more per CU): the 9 MB of partial states spread evenly over
 // the chip instead of 71 KB on each of 162 CUs.
-constexpr float kMvFixScale = 68719476736.f;          // 2^36: |o| < 2^26 representable, 1.5e-11 resolution
-
-struct MergeVprojFixParams {
-    const float* part_m;
-    const float* part_l;
-    const void* part_acc;   // fp32 un-normalised accumulators, or (F16) fp16 normalised contexts
-    int nparts, rows_pad, E, hd;
-    const uint16_t* wv;     // bf16 [E, E]
-    long long* o_fix;       // [E] fixed-point accumulators (zero on entry)
-    float* out_ml;          // [R][2] or NULL
-    float* out_ctx;         // [R][E] normalised, or NULL
-};
-
-template <int kMvSlab, bool F16>      // channels per workgroup (32 or 64); partials as normalised fp16 contexts
+template <int kMvSlab, bool F16>
 __global__ __launch_bounds__(256) void merge_vproj_fixed_kernel(MergeVprojFixParams p) {
-    constexpr int NC4 = kMvSlab / 4;             // 4-channel columns of the slab
-    constexpr int NG = 256 / NC4;                // partial groups
-    constexpr int NU = (256 + NG - 1) / NG;      // partials per thread
-    constexpr int WQ = kMvSlab / 16;             // 16-byte weight chunks per thread (the slab halved between a row's two threads)
-    __shared__ float wp[256];
-    __shared__ float red[4];
-    __shared__ __attribute__((aligned(16))) float cpart[NG][kMvSlab];
-    __shared__ __attribute__((aligned(16))) float cx[kMvSlab];
-    const int slab = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
-    // v_proj weights of this (head, slab) first: independent of everything else here
-    const int j = tid >> 1, half = tid & 1;
-    u32x4 wreg[WQ];
-#pragma unroll
-    for (int q = 0; q < WQ; ++q)
-        wreg[q] = (j < p.hd) ? *reinterpret_cast<const u32x4*>(p.wv + (long)(h * p.hd + j) * p.E + slab * kMvSlab + (kMvSlab / 2) * half + 8 * q) : u32x4{0, 0, 0, 0};
-    // raw partial rows: thread = (float4 column c4 of the slab, partial group pg of NG); all of a thread's <= NU loads in flight
-    const int c4 = tid % NC4, pg = tid / NC4;
-    const long eoff = (long)h * p.E + slab * kMvSlab + 4 * c4;
-    const long pstride = (long)p.rows_pad * p.E;
-    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-    float4 v[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int i = pg + NG * u;
-        if constexpr (F16) {
-            half4_t hv = half4_t{0, 0, 0, 0};
-            if (i < p.nparts) hv = *reinterpret_cast<const half4_t*>(reinterpret_cast<const _Float16*>(p.part_acc) + eoff + (long)i * pstride);
-            v[u] = make_float4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
-        } else {
-            v[u] = (i < p.nparts) ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.part_acc) + eoff + (long)i * pstride)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    const float pm = tid < p.nparts ? p.part_m[(long)tid * p.rows_pad + h] : -1.0e30f;       // nparts <= 256 (host-checked)
-    const float pl = tid < p.nparts ? p.part_l[(long)tid * p.rows_pad + h] : 0.f;
-    const float M = block_reduce_max(pm, red);
-    const float w = tid < p.nparts ? expf(pm - M) : 0.f;
-    wp[tid] = F16 ? w * pl : w;                          // (normalised contexts are weighed with l e^(m - M))
-    const float L = block_reduce_sum(w * pl, red);       // (barriers inside: wp[] is visible afterwards)
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int i = pg + NG * u;
-        const float wu = i < 256 ? wp[i] : 0.f;
-        a.x = fmaf(wu, v[u].x, a.x); a.y = fmaf(wu, v[u].y, a.y); a.z = fmaf(wu, v[u].z, a.z); a.w = fmaf(wu, v[u].w, a.w);
-    }
-    *reinterpret_cast<float4*>(&cpart[pg][4 * c4]) = a;
-    __syncthreads();
-    if (tid < kMvSlab) {
-        float sum = 0.f;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) sum += cpart[g][tid];
-        const float val = sum / L;
-        cx[tid] = val;
-        if (p.out_ctx) p.out_ctx[(long)h * p.E + slab * kMvSlab + tid] = val;
-    }
-    if (tid == 0 && slab == 0 && p.out_ml) {
-        p.out_ml[2 * h] = M;
-        p.out_ml[2 * h + 1] = L;
-    }
-    __syncthreads();
-    // partial v_proj: thread (j, half) dots its half of the slab with weight row h*hd + j
-    float dot = 0.f;
-    if (j < p.hd) {
-#pragma unroll
-        for (int q = 0; q < WQ; ++q) {
-            const u32x4 g = wreg[q];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                dot = fmaf(bf16lo_to_f32(g[i]), cx[(kMvSlab / 2) * half + 8 * q + 2 * i], dot);
-                dot = fmaf(bf16hi_to_f32(g[i]), cx[(kMvSlab / 2) * half + 8 * q + 2 * i + 1], dot);
-            }
-        }
-    }
-    dot += __shfl_xor(dot, 1, 64);
-    if (half == 0 && j < p.hd) {
-        const long long q = (long long)rintf(dot * kMvFixScale);
-        __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned long long*)(p.o_fix + h * p.hd + j), (unsigned long long)q,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // result unused: no-return atomic
-    }
+    __shared__ __attribute__((aligned(16))) char lds[mv_item_lds_bytes<kMvSlab>()];
+    merge_vproj_fixed_item<kMvSlab, F16>(p, blockIdx.x, blockIdx.y, lds);
 }
 
 }  // namespace hicom

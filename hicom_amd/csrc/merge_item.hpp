@@ -1,0 +1,152 @@
+// merge + v_proj of the ring kernel's partial global states, one (head, 64-channel slab) ITEM at a time -- shared by the
+// standalone launch (merge.hip: hicom_merge_vproj_fixed_fwd) and by the merge ROLE inside readout GEMM 1's launch
+// (readout16.hip, round 5: the merge is independent of the local readout, so it rides on the CUs the tile grid leaves idle
+// and its launch disappears from the step).
+#pragma once
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace hicom {
+
+__device__ __forceinline__ float mv_block_max(float v, float* red) {
+    v = wave_max_fast(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ float mv_block_sum(float v, float* red) {
+    v = wave_sum_fast(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+constexpr float kMvFixScale = 68719476736.f;          // 2^36: |o| < 2^26 representable, 1.5e-11 resolution
+
+struct MergeVprojFixParams {
+    const float* part_m;
+    const float* part_l;
+    const void* part_acc;   // fp32 un-normalised accumulators, or (F16) fp16 normalised contexts
+    int nparts, rows_pad, E, hd;
+    const uint16_t* wv;     // bf16 [E, E]
+    long long* o_fix;       // [E] fixed-point accumulators (zero on entry)
+    float* out_ml;          // [R][2] or NULL
+    float* out_ctx;         // [R][E] normalised, or NULL
+};
+
+template <int kMvSlab>
+constexpr int mv_item_lds_bytes() { return (256 + 4 + (256 / (kMvSlab / 4)) * kMvSlab + kMvSlab) * 4; }
+
+// One item: head h, channels [slab * kMvSlab, + kMvSlab).  256 threads; `lds` >= mv_item_lds_bytes<kMvSlab>() bytes, 16-byte aligned.
+// Split into a LOAD half (every global read of the item, into registers) and a COMPUTE half, so that a workgroup that owns several
+// items (the merge role inside readout GEMM 1's launch) requests all of them before it touches the first: its items then cost ONE
+// memory round trip instead of one each (beside ~200 streaming tile workgroups a round trip is 3-5 us).
+template <int kMvSlab, bool F16>
+struct MvItemRegs {
+    static constexpr int NC4 = kMvSlab / 4, NG = 256 / NC4, NU = (256 + NG - 1) / NG, WQ = kMvSlab / 16;
+    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+    u32x4 wreg[WQ];                               // v_proj weights of this thread's (row j, half of the slab)
+    typename std::conditional<F16, half4_t, float4>::type v[NU];   // raw partial rows
+    float pm, pl;
+};
+
+template <int kMvSlab, bool F16>      // channels per item (32 or 64); partials as normalised fp16 contexts
+__device__ __forceinline__ void merge_vproj_fixed_load(const MergeVprojFixParams& p, int slab, int h, MvItemRegs<kMvSlab, F16>& r) {
+    using R = MvItemRegs<kMvSlab, F16>;
+    const int tid = threadIdx.x;
+    // v_proj weights of this (head, slab) first: independent of everything else here
+    const int j = tid >> 1, half = tid & 1;
+#pragma unroll
+    for (int q = 0; q < R::WQ; ++q)
+        r.wreg[q] = (j < p.hd) ? *reinterpret_cast<const u32x4*>(p.wv + (long)(h * p.hd + j) * p.E + slab * kMvSlab + (kMvSlab / 2) * half + 8 * q) : u32x4{0, 0, 0, 0};
+    // raw partial rows: thread = (float4 column c4 of the slab, partial group pg of NG); all of a thread's <= NU loads in flight
+    const int c4 = tid % R::NC4, pg = tid / R::NC4;
+    const long eoff = (long)h * p.E + slab * kMvSlab + 4 * c4;
+    const long pstride = (long)p.rows_pad * p.E;
+#pragma unroll
+    for (int u = 0; u < R::NU; ++u) {
+        const int i = pg + R::NG * u;
+        if constexpr (F16) {
+            r.v[u] = typename R::half4_t{0, 0, 0, 0};
+            if (i < p.nparts) r.v[u] = *reinterpret_cast<const typename R::half4_t*>(reinterpret_cast<const _Float16*>(p.part_acc) + eoff + (long)i * pstride);
+        } else {
+            r.v[u] = (i < p.nparts) ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.part_acc) + eoff + (long)i * pstride)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    r.pm = tid < p.nparts ? p.part_m[(long)tid * p.rows_pad + h] : -1.0e30f;       // nparts <= 256 (host-checked)
+    r.pl = tid < p.nparts ? p.part_l[(long)tid * p.rows_pad + h] : 0.f;
+}
+
+template <int kMvSlab, bool F16>
+__device__ __forceinline__ void merge_vproj_fixed_compute(const MergeVprojFixParams& p, int slab, int h, const MvItemRegs<kMvSlab, F16>& r, char* lds) {
+    using R = MvItemRegs<kMvSlab, F16>;
+    float* cpart = reinterpret_cast<float*>(lds);            // [NG][kMvSlab]
+    float* cx = cpart + R::NG * kMvSlab;                      // [kMvSlab]
+    float* wp = cx + kMvSlab;                                 // [256]
+    float* red = wp + 256;                                    // [4]
+    const int tid = threadIdx.x;
+    const int j = tid >> 1, half = tid & 1;
+    const int c4 = tid % R::NC4, pg = tid / R::NC4;
+    const float pm = r.pm, pl = r.pl;
+    const float M = mv_block_max(pm, red);
+    const float w = tid < p.nparts ? expf(pm - M) : 0.f;
+    wp[tid] = F16 ? w * pl : w;                          // (normalised contexts are weighed with l e^(m - M))
+    const float L = mv_block_sum(w * pl, red);           // (barriers inside: wp[] is visible afterwards)
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < R::NU; ++u) {
+        const int i = pg + R::NG * u;
+        const float wu = i < 256 ? wp[i] : 0.f;
+        float4 vv;
+        if constexpr (F16) vv = make_float4((float)r.v[u][0], (float)r.v[u][1], (float)r.v[u][2], (float)r.v[u][3]);
+        else vv = r.v[u];
+        a.x = fmaf(wu, vv.x, a.x); a.y = fmaf(wu, vv.y, a.y); a.z = fmaf(wu, vv.z, a.z); a.w = fmaf(wu, vv.w, a.w);
+    }
+    *reinterpret_cast<float4*>(&cpart[pg * kMvSlab + 4 * c4]) = a;
+    __syncthreads();
+    if (tid < kMvSlab) {
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < R::NG; ++g) sum += cpart[g * kMvSlab + tid];
+        const float val = sum / L;
+        cx[tid] = val;
+        if (p.out_ctx) p.out_ctx[(long)h * p.E + slab * kMvSlab + tid] = val;
+    }
+    if (tid == 0 && slab == 0 && p.out_ml) {
+        p.out_ml[2 * h] = M;
+        p.out_ml[2 * h + 1] = L;
+    }
+    __syncthreads();
+    // partial v_proj: thread (j, half) dots its half of the slab with weight row h*hd + j
+    float dot = 0.f;
+    if (j < p.hd) {
+#pragma unroll
+        for (int q = 0; q < R::WQ; ++q) {
+            const u32x4 g = r.wreg[q];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dot = fmaf(bf16lo_to_f32(g[i]), cx[(kMvSlab / 2) * half + 8 * q + 2 * i], dot);
+                dot = fmaf(bf16hi_to_f32(g[i]), cx[(kMvSlab / 2) * half + 8 * q + 2 * i + 1], dot);
+            }
+        }
+    }
+    dot += __shfl_xor(dot, 1, 64);
+    if (half == 0 && j < p.hd) {
+        const long long q = (long long)rintf(dot * kMvFixScale);
+        __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned long long*)(p.o_fix + h * p.hd + j), (unsigned long long)q,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // result unused: no-return atomic
+    }
+}
+
+template <int kMvSlab, bool F16>
+__device__ __forceinline__ void merge_vproj_fixed_item(const MergeVprojFixParams& p, int slab, int h, char* lds) {
+    MvItemRegs<kMvSlab, F16> r;
+    merge_vproj_fixed_load<kMvSlab, F16>(p, slab, h, r);
+    merge_vproj_fixed_compute<kMvSlab, F16>(p, slab, h, r, lds);
+}
+
+}  // namespace hicom

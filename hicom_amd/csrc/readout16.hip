@@ -19,9 +19,11 @@
 // global compressor's tail (out_proj / readout of the 32 global rows, projector.py:226,646) on the CUs the tiles
 // leave idle: two dependent small launches of the step disappear under the two GEMMs.
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 #include "common.hpp"
+#include "merge_item.hpp"
 
 namespace hicom {
 
@@ -60,14 +62,29 @@ struct R16Params {
     long ldy, row0;
     int nl_group;
     int vec, bvec;
-    int n_gemm;             // workgroups of the tile grid; blocks >= n_gemm run the aux role
-    AuxGemv aux;
+    int n_gemm;             // workgroups of the tile grid; blocks >= n_gemm run the role
+    int role;               // HICOM_ROLE_*: what the workgroups behind the tile grid do
+    AuxGemv aux;            // GEMV; first layer of GEMV_CHAIN
+    AuxGemv aux2;           // GEMV_CHAIN: second layer (x = the first layer's result, handed over inside the launch)
+    unsigned* chain_state;  // GEMV_CHAIN: [0..1] 64-bit arrival counter, [2] failed hand-offs, [3] role workgroups of the first launch; granules from byte 64
+    MergeVprojFixParams mv; // MERGE_VPROJ
+    int cg_cpw1, cg_cpw2, cg_r1, cg_r2;   // GEMV_CHAIN: chain_geom() of this launch, computed by the host
 };
+
+// Dev-only timeline (tools/tail_trace.py builds a second library with -DHICOM_TRACE): s_memrealtime (100 MHz, chip-wide) stamps of
+// every workgroup of the LAST launch: [0] entry, [1..6] role phases / tile phases, [7] exit.  Compiled out of the product.
+#ifdef HICOM_TRACE
+__device__ unsigned long long g_r16_trace[512 * 16];
+#define R16_TR(k) do { if (threadIdx.x == 0) g_r16_trace[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define R16_TR(k) do {} while (0)
+#endif
 
 constexpr int kRM = 96, kRN = 64;
 constexpr int kRImgA = kRM * 128;                   // 12 KB: 96 rows x 64 fp16
 constexpr int kRStage = kRImgA + kRN * 128;         // 20 KB
 constexpr int kRRingMax = 8;                        // ring depth is a template parameter (6 or 8 stages: 120 / 160 KB of LDS)
+constexpr int kMvRoleItems = 3;                      // merge items a role workgroup keeps in flight together
 constexpr int kRPW = 5;                             // DMA pieces (1 KiB = 8 rows x 128 B) per wave and stage: 12 A + 8 W
 
 __device__ __forceinline__ _Float16 to_f16_sat(float v) {
@@ -209,6 +226,290 @@ __device__ __forceinline__ void aux_gemv_role(const AuxGemv& g, int aux_idx, int
     }
 }
 
+
+// ---- GEMV_CHAIN role (round 5): TWO dependent single-row layers in one launch,
+//   h[n]  = act1(sum_k w1[n,k] x[k] + b1[n]),   x from the fixed-point accumulators of the merge (+ xb)
+//   y2[m] = act2(sum_n w2[m,n] h[n] + b2[m])    -> the replicated rows of the output
+// i.e. GELU(C o + r0) and the last global readout layer (reference projector.py:226, :646, :307-312 after folding): the whole
+// global tail behind the merge rides under readout GEMM 2, and the merge itself under GEMM 1 -- its launch is gone from the step.
+// The N1 <= 1536 intermediate values travel as 8-byte {epoch, f32} granules (cdna_hip_programming.md Guideline 16, form R2; the
+// scheme of query_prep.hip): every role workgroup first produces its columns of h, then sweeps ALL granules.  The second layer's
+// weight rows are requested before anything else, so their cold-memory latency runs under the first layer.
+// Residency: the role workgroups have the highest block indices; the tile workgroups never wait, so every role workgroup is
+// dispatched at the latest when the tiles have finished -- a spinning role workgroup cannot starve its producers as long as the
+// role fits the chip (n_role <= CUs; host-checked).  Every spin is bounded; a failed hand-off poisons the result with NaN.
+typedef __attribute__((address_space(1))) unsigned long long r16_gu64;
+typedef __attribute__((address_space(1))) unsigned int r16_gu32;
+
+// Layout of the role's LDS (the launch's 160 KB, unused by a role workgroup otherwise): weight rows of both layers land by LDS-DMA --
+// a role CU that loads into REGISTERS keeps ~64 KB in flight (26 GB/s beside the streaming tiles: tools/tail_trace.py saw the last
+// of 111 KB requested 4.6 us after entry), the DMA path keeps everything it is given in flight (the tiles' own 140 KB per CU).
+constexpr int kChainLds = 160 * 1024, kChainVec = 1536 * 4, kChainBias = 2 * 256 * 4, kChainOut = 256 * 4;
+constexpr int kChainW2Max = 40 * 1024;             // second-layer rows resident per batch (all of a workgroup's at the release shape: 16 x 1792 B)
+
+struct ChainGeom { int cpw1, cpw2, r1, r2; long row1, row2; };
+__host__ __device__ inline long chain_pad1k(long b) { return (b + 1023) & ~1023L; }
+__host__ __device__ inline ChainGeom chain_geom(int N1, int K1, bool w1f32, int N2, int an) {
+    ChainGeom g;
+    g.cpw1 = (N1 + an - 1) / an;
+    g.cpw2 = (N2 + an - 1) / an;
+    g.row1 = (long)K1 * (w1f32 ? 4 : 2);
+    g.row2 = (long)N1 * 2;
+    g.r2 = (int)(kChainW2Max / g.row2) < g.cpw2 ? (int)(kChainW2Max / g.row2) : g.cpw2;
+    // (a batch lands in whole 1-KB pieces: each region is rounded up to the piece size, so a tail piece never reaches the next region)
+    const long left = kChainLds - kChainVec - kChainBias - kChainOut - chain_pad1k((long)g.r2 * g.row2) - 1024;
+    g.r1 = (int)(left / g.row1) < g.cpw1 ? (int)(left / g.row1) : g.cpw1;
+    return g;
+}
+
+template <bool W1F32>
+__device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int an, char* lds) {
+    const AuxGemv& g1 = p.aux;
+    const AuxGemv& g2 = p.aux2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    R16_TR(6);   // role entered (kernel arguments read)
+    ChainGeom cg;                                                     // (host-computed: four integer divisions off the role's critical path)
+    cg.cpw1 = p.cg_cpw1; cg.cpw2 = p.cg_cpw2; cg.r1 = p.cg_r1; cg.r2 = p.cg_r2;
+    cg.row1 = (long)g1.K * (W1F32 ? 4 : 2); cg.row2 = (long)g1.N * 2;
+    float* xl = reinterpret_cast<float*>(lds);                       // [1536] x, later h
+    float* bl1 = xl + 1536;                                          // [256] first-layer biases of this workgroup's columns
+    float* bl2 = bl1 + 256;                                          // [256] second-layer biases
+    float* yl = bl2 + 256;                                           // [256] second-layer results of this workgroup
+    char* w2l = lds + kChainVec + kChainBias + kChainOut;            // [r2][row2]
+    char* w1l = w2l + chain_pad1k((long)cg.r2 * cg.row2);            // [r1][row1]
+    r16_gu64* cnt = (r16_gu64*)p.chain_state;
+    r16_gu64* gran = (r16_gu64*)((char*)p.chain_state + 64);
+    const int n_lo = ai * cg.cpw1, n_hi = min(g1.N, n_lo + cg.cpw1);  // first-layer columns of this workgroup
+    const int m_lo = ai * cg.cpw2, m_hi = min(g2.N, m_lo + cg.cpw2);  // second-layer columns
+    // One word of every memory region this workgroup is about to read, requested by a DIFFERENT wave each: the regions (state block,
+    // accumulators, two weight matrices, biases) lie on different pages, a CU's first touch of a page is an address-translation miss,
+    // and a wave's requests wait in order behind it (tools/tail_trace.py: 0.5-1.5 us per region, 3.5 us in series).  Four waves
+    // miss in parallel.
+    int touch = 0;
+    if (n_lo < g1.N && m_lo < g2.N) {
+        const char* tp = wave == 0 ? reinterpret_cast<const char*>(g1.x_fixed)
+                       : wave == 1 ? reinterpret_cast<const char*>(g1.w) + (long)n_lo * cg.row1
+                       : wave == 2 ? reinterpret_cast<const char*>(g2.w) + (long)m_lo * cg.row2
+                                   : reinterpret_cast<const char*>(g2.b ? g2.b : g2.w);
+        touch = *reinterpret_cast<const int*>(tp);
+    }
+    // (the counter is requested first and CONSUMED behind the first barrier: a returned atomic takes 2-4 us beside the tiles)
+    unsigned long long c0 = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    R16_TR(8);
+    // Every request of the prologue goes out BEFORE anything is computed from a returned value: straight-line, unconditional loads
+    // (clamped indices instead of predicates, raw bias bits instead of a per-type branch), pinned by a scheduling barrier.  hipcc had
+    // placed the int64 -> float conversion of x -- and its wait -- in front of the bias and weight requests, and the bf16 bias branch
+    // carried a vmcnt(0) of its own (tools/tail_trace.py: last request 4.5 us after entry).
+    long long xf[6];                                                  // x from the fixed-point accumulators (K1 <= 1536 = 6 per thread)
+#pragma unroll
+    for (int u = 0; u < 6; ++u) xf[u] = g1.x_fixed[min(tid + 256 * u, g1.K - 1)];
+    R16_TR(9);
+    auto bias_raw = [&](const AuxGemv& g, int n) -> unsigned {
+        n = n < g.N ? n : g.N - 1;
+        const char* bp = reinterpret_cast<const char*>(g.b ? g.b : g.w) + (long)n * (g.b_f32 ? 4 : 2);
+        return g.b_f32 ? *reinterpret_cast<const unsigned*>(bp) : (unsigned)*reinterpret_cast<const uint16_t*>(bp);
+    };
+    const unsigned b1raw = bias_raw(g1, n_lo + tid), b2raw = bias_raw(g2, m_lo + tid);
+    // DMA of rows [r_lo, r_hi) of a row-major matrix (a CONTIGUOUS byte range) into `dst`, 1-KB pieces dealt over the four waves;
+    // a piece's tail beyond the range re-reads the matrix's last 16 bytes (lands in unread LDS)
+    auto dma_rows = [&](const void* w, long rowbytes, long total_rows, int r_lo, int r_hi, char* dst) -> int {
+        if (r_hi <= r_lo) return 0;
+        const long lo = (long)r_lo * rowbytes, bytes = (long)(r_hi - r_lo) * rowbytes, last = total_rows * rowbytes - 16;
+        const int npieces = (int)((bytes + 1023) >> 10);
+        int mine = 0;
+        for (int pi = wave; pi < npieces; pi += 4, ++mine) {
+            long off = lo + (long)pi * 1024 + lane * 16;
+            off = off < last ? off : last;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(w) + off),
+                                             (__attribute__((address_space(3))) void*)(dst + (long)pi * 1024), 16, 0, 0);
+        }
+        return mine;
+    };
+    R16_TR(10);
+    dma_rows(g1.w, cg.row1, g1.N, n_lo, min(n_hi, n_lo + cg.r1), w1l);
+    R16_TR(11);
+    dma_rows(g2.w, cg.row2, g2.N, m_lo, min(m_hi, m_lo + cg.r2), w2l);
+    __builtin_amdgcn_sched_barrier(0);
+    R16_TR(1);   // every load requested
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int k = tid + 256 * u;
+        if (k < g1.K) xl[k] = (float)xf[u] * (1.0f / HICOM_FIXED_SCALE) + (g1.xb ? bf16_to_f32(g1.xb[k]) : 0.f);
+    }
+    bl1[tid] = g1.b ? __uint_as_float(g1.b_f32 ? b1raw : b1raw << 16) : 0.f;
+    bl2[tid] = g2.b ? __uint_as_float(g2.b_f32 ? b2raw : b2raw << 16) : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's DMA pieces (both layers') have landed
+    __syncthreads();
+    R16_TR(2);   // x and the weights landed
+    asm volatile("" : "+v"(c0));                                      // nothing computed from the counter is scheduled above this point
+    const unsigned epoch = (unsigned)(c0 / (unsigned)an) + 1u;
+    // dot products of up to FOUR LDS-resident weight rows (this wave's: rows r, r + 4, r + 8, r + 12 of the batch) with the vector in
+    // xl, their chains interleaved: lane owns elements 4 lane + 256 c (f32 rows) or 8 lane + 512 c (bf16 rows)
+    auto dots_f32 = [&](const char* row0, long stride, int nrows, int K, float (&out)[4]) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int k = 4 * lane + 256 * c;
+            if (k < K) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xl + k);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < nrows) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(row0 + j * stride + (long)k * 4);
+                        acc[j] = fmaf(wv[0], xv[0], acc[j]); acc[j] = fmaf(wv[1], xv[1], acc[j]);
+                        acc[j] = fmaf(wv[2], xv[2], acc[j]); acc[j] = fmaf(wv[3], xv[3], acc[j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = wave_sum_fast(acc[j]);
+    };
+    auto dots_bf16 = [&](const char* row0, long stride, int nrows, int K, float (&out)[4]) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int k = 8 * lane + 512 * c;
+            if (k < K) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xl + k), x1 = *reinterpret_cast<const f32x4*>(xl + k + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < nrows) {
+                        const u32x4 wv = *reinterpret_cast<const u32x4*>(row0 + j * stride + (long)k * 2);
+                        acc[j] = fmaf(bf16lo_to_f32(wv[0]), x0[0], acc[j]); acc[j] = fmaf(bf16hi_to_f32(wv[0]), x0[1], acc[j]);
+                        acc[j] = fmaf(bf16lo_to_f32(wv[1]), x0[2], acc[j]); acc[j] = fmaf(bf16hi_to_f32(wv[1]), x0[3], acc[j]);
+                        acc[j] = fmaf(bf16lo_to_f32(wv[2]), x1[0], acc[j]); acc[j] = fmaf(bf16hi_to_f32(wv[2]), x1[1], acc[j]);
+                        acc[j] = fmaf(bf16lo_to_f32(wv[3]), x1[2], acc[j]); acc[j] = fmaf(bf16hi_to_f32(wv[3]), x1[3], acc[j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = wave_sum_fast(acc[j]);
+    };
+    // ---- first layer: rows of the resident batch dealt over the four waves; further batches (shapes whose rows do not fit at once) ----
+    for (int b0 = n_lo; b0 < n_hi; b0 += cg.r1) {
+        const int b1 = min(n_hi, b0 + cg.r1);
+        if (b0 != n_lo) {
+            __syncthreads();                                          // the previous batch has been consumed
+            dma_rows(g1.w, cg.row1, g1.N, b0, b1, w1l);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        for (int n = b0 + wave; n < b1; n += 16) {                     // rows n, n + 4, n + 8, n + 12 of this wave, together
+            const int nrows = min(4, (b1 - n + 3) >> 2);
+            float d[4];
+            if (W1F32) dots_f32(w1l + (long)(n - b0) * cg.row1, 4 * cg.row1, nrows, g1.K, d);
+            else dots_bf16(w1l + (long)(n - b0) * cg.row1, 4 * cg.row1, nrows, g1.K, d);
+            float v = lane == 0 ? d[0] : lane == 1 ? d[1] : lane == 2 ? d[2] : d[3];          // lane j < nrows finishes row n + 4 j
+            const int nn = n + 4 * lane;
+            if (lane < nrows) {
+                v += bl1[nn - n_lo];
+                if (g1.act == HICOM_ACT_GELU) v = gelu_erf(v);
+                if (g1.res) v += bf16_to_f32(g1.res[nn]);
+                __hip_atomic_store(gran + nn, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                if (g1.y) g1.y[nn] = v;
+            }
+        }
+    }
+    __syncthreads();                                  // every wave is done with x in xl
+    R16_TR(3);   // first layer done, granules stored
+    // ---- sweep: wave w collects granules [w * q, (w + 1) * q) of h until every tag carries this launch's epoch ----
+    {
+        constexpr int GPL = 6;                        // granules per lane and wave: N1 <= 4 * 64 * 6 = 1536
+        const int q = (g1.N + 3) >> 2, lo = wave * q, hi = min(g1.N, lo + q);
+        unsigned long long gv[GPL];
+        unsigned spins = 0;
+        const unsigned grid0 = __hip_atomic_load((r16_gu32*)p.chain_state + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool failed = grid0 != 0u && grid0 != (unsigned)an;       // (the epoch arithmetic needs the same role size on every launch)
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < GPL; ++u) {
+                const int n = lo + lane + 64 * u;
+                gv[u] = (n < hi) ? __hip_atomic_load(gran + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)epoch << 32);
+                ok &= (unsigned)(gv[u] >> 32) == epoch;
+            }
+            if (__all(ok)) break;
+            if (failed || ++spins > (1u << 22)) {
+                failed = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (failed && lane == 0) atomicAdd(p.chain_state + 2, 1u);
+#pragma unroll
+        for (int u = 0; u < GPL; ++u) {
+            const int n = lo + lane + 64 * u;
+            if (n < hi) xl[n] = failed ? __uint_as_float(0x7FC00000u) : __uint_as_float((unsigned)gv[u]);
+        }
+    }
+    __syncthreads();
+    R16_TR(4);   // hand-off complete
+    // ---- second layer (bf16 rows, K2 = N1) ----
+    for (int b0 = m_lo; b0 < m_hi; b0 += cg.r2) {
+        const int b1 = min(m_hi, b0 + cg.r2);
+        if (b0 != m_lo) {
+            __syncthreads();
+            dma_rows(g2.w, cg.row2, g2.N, b0, b1, w2l);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        for (int m = b0 + wave; m < b1; m += 16) {
+            const int nrows = min(4, (b1 - m + 3) >> 2);
+            float d[4];
+            dots_bf16(w2l + (long)(m - b0) * cg.row2, 4 * cg.row2, nrows, g2.K, d);
+            float v = lane == 0 ? d[0] : lane == 1 ? d[1] : lane == 2 ? d[2] : d[3];
+            const int mm = m + 4 * lane;
+            if (lane < nrows) {
+                v += bl2[mm - m_lo];
+                if (g2.act == HICOM_ACT_GELU) v = gelu_erf(v);
+                if (g2.res) v += bf16_to_f32(g2.res[mm]);
+                yl[mm - m_lo] = v;
+                if (g2.y) g2.y[mm] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (g2.dst) {
+        // the workgroup's columns of every replica row: consecutive threads write consecutive columns
+        const int ncol = m_hi - m_lo;
+        for (int idx = tid; idx < g2.reps * ncol; idx += 256) {
+            const int rr = idx / ncol, c = idx - rr * ncol;
+            const long o = (g2.row0 + rr) * g2.ldd + m_lo + c;
+            if (g2.dst_f32) reinterpret_cast<float*>(g2.dst)[o] = yl[c];
+            else reinterpret_cast<uint16_t*>(g2.dst)[o] = f32_to_bf16(yl[c]);
+        }
+    }
+    // the arrival: after every wave of the workgroup has read the counter (all did before the first barrier)
+    R16_TR(5);   // second layer done, rows stored
+    if (tid == 0 && ai == 0 && __hip_atomic_load((r16_gu32*)p.chain_state + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+        __hip_atomic_store((r16_gu32*)p.chain_state + 3, (unsigned)an, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(touch));                    // (the touch loads' only consumer: they are never waited for on their own)
+}
+
+// ---- MERGE_VPROJ role: the (head, 64-channel slab) items of hicom_merge_vproj_fixed_fwd dealt over the role workgroups ----
+__device__ __forceinline__ void merge_vproj_role(const R16Params& p, int ai, int an, char* lds) {
+    const int nslab = p.mv.E / 64, rows = p.mv.E / p.mv.hd, items = nslab * rows;
+    // up to kMvRoleItems items per workgroup with ALL their loads requested before the first is reduced (host: items <= kMvRoleItems * an)
+    MvItemRegs<64, true> regs[kMvRoleItems];
+#pragma unroll
+    for (int u = 0; u < kMvRoleItems; ++u) {
+        const int it = ai + u * an;
+        if (it < items) merge_vproj_fixed_load<64, true>(p.mv, it % nslab, it / nslab, regs[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kMvRoleItems; ++u) {
+        const int it = ai + u * an;
+        if (it < items) merge_vproj_fixed_compute<64, true>(p.mv, it % nslab, it / nslab, regs[u], lds);
+    }
+    for (int it = ai + kMvRoleItems * an; it < items; it += an)        // (never at the shapes the host admits; kept for safety)
+        merge_vproj_fixed_item<64, true>(p.mv, it % nslab, it / nslab, lds);
+}
+
 template <int N>
 __device__ __forceinline__ void r16_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -217,8 +518,21 @@ __device__ __forceinline__ void r16_wait_vm() {
 template <int kRRing>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void readout16_gemm_kernel(R16Params p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [kRRing][kRStage]
+    R16_TR(0);
+    warm_kernarg<sizeof(R16Params)>();
     if ((int)blockIdx.x >= p.n_gemm) {
         const int ai = (int)blockIdx.x - p.n_gemm, an = (int)gridDim.x - p.n_gemm;
+        if (p.role == HICOM_ROLE_MERGE_VPROJ) {
+            merge_vproj_role(p, ai, an, lds);
+            R16_TR(7);
+            return;
+        }
+        if (p.role == HICOM_ROLE_GEMV_CHAIN) {
+            if (p.aux.w_f32) gemv_chain_role<true>(p, ai, an, lds);
+            else gemv_chain_role<false>(p, ai, an, lds);
+            R16_TR(7);
+            return;
+        }
         if (p.aux.x_fixed) {
             if (p.aux.w_f32) aux_gemv_role<true, true>(p.aux, ai, an, lds);
             else aux_gemv_role<false, true>(p.aux, ai, an, lds);
@@ -242,7 +556,22 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const int t_lo = (tiles * xcd) >> 3, t_hi = (tiles * (xcd + 1)) >> 3;
     if (slot >= t_hi - t_lo) return;
     const int tile = t_lo + slot;
-    const int by = tile / nbx, bx = tile - by * nbx;
+    // ... in a BLOCKED order: the left half of the tile columns row by row, then the right half -- an XCD's run of ~tiles/8 tiles is a
+    // ~(3.5 rows x 7 columns) patch, so both its A row blocks and its W column blocks are shared by several of its CUs and cross
+    // its L2 once (row-major runs shared the A rows 14 ways and the W columns hardly at all: every CU pulled its W panel from
+    // beyond L2, profiles/r04_d: 24.5 MB of fabric traffic for 7.3 MB of operands)
+    int by, bx;
+    {
+        const int hx = nbx >= 4 ? (nbx + 1) >> 1 : nbx, nleft = nby * hx;
+        if (tile < nleft) {
+            by = tile / hx;
+            bx = tile - by * hx;
+        } else {
+            const int t2 = tile - nleft, wx = nbx - hx;
+            by = t2 / wx;
+            bx = hx + t2 - by * wx;
+        }
+    }
     const int m0 = by * kRM, n0 = bx * kRN;
     const int ns = p.K >> 6;
 
@@ -346,6 +675,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     else wait_stages(npro - 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    R16_TR(1);   // tile: first stage landed
     Frags f0, f1;
     read(0, f0);
     land(f0);
@@ -391,6 +721,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     }
     // MFMA results -> VALU reads (CDNA4 ISA §4.1 "XDL write VGPR -> VALU read": do not rely on hipcc's padding, see fused_ring.hip)
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+    R16_TR(2);   // tile: main loop done
 
     // epilogue.  Transposed product: lane holds columns n .. n+3 (4 * kg + q) of row m = r16 of each block.
 #pragma unroll
@@ -451,6 +782,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             }
         }
     }
+    R16_TR(7);
 }
 
 // bf16 -> fp16 (weights, once per weight version) and f32 -> fp16 (saturating) conversions
@@ -492,10 +824,10 @@ extern "C" int hicom_to_f16_fwd(const void* src, int32_t src_dt, void* dst, int6
     return hicom_host::check_launch("to_f16");
 }
 
-extern "C" int hicom_readout16_gemm_fwd(const void* a, const void* w, const void* b, int32_t b_dt,
-                                        int32_t M, int32_t N, int32_t K, int32_t act, void* out_f16,
-                                        void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group,
-                                        const hicom_aux_gemv* aux, void* stream) {
+static int readout16_launch(const void* a, const void* w, const void* b, int32_t b_dt,
+                            int32_t M, int32_t N, int32_t K, int32_t act, void* out_f16,
+                            void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group,
+                            const hicom_r16_role* role, void* stream) {
     HICOM_REQUIRE(a && w, HICOM_EINVAL, "readout16_gemm: NULL pointer");
     HICOM_REQUIRE(out_f16 || y, HICOM_EINVAL, "readout16_gemm: no output");
     HICOM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, HICOM_EINVAL, "readout16_gemm: bad shape M=%d N=%d K=%d (K %% 64)", M, N, K);
@@ -509,24 +841,80 @@ extern "C" int hicom_readout16_gemm_fwd(const void* a, const void* w, const void
     const int nbx = (N + kRN - 1) / kRN, nby = (M + kRM - 1) / kRM;
     p.n_gemm = 8 * ((nbx * nby + 7) / 8);
     int n_aux = 0;
-    p.aux = AuxGemv{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, 0, 0, 0, nullptr};
-    if (aux && aux->N > 0) {
-        HICOM_REQUIRE(aux->w && (aux->y || aux->rows_dst) && aux->K > 0 && aux->K % 8 == 0 && aux->K <= 1536 && ((uintptr_t)aux->w % 16 == 0), HICOM_EINVAL,
+    const AuxGemv none{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, 0, 0, 0, nullptr};
+    p.aux = none;
+    p.aux2 = none;
+    p.role = HICOM_ROLE_NONE;
+    p.chain_state = nullptr;
+    p.mv = MergeVprojFixParams{nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+    p.cg_cpw1 = p.cg_cpw2 = p.cg_r1 = p.cg_r2 = 0;
+    auto conv = [](const hicom_aux_gemv* aux) {
+        return AuxGemv{aux->xs, aux->x_parts, (long)aux->x_stride, (const uint16_t*)aux->xb, aux->w,
+                       aux->b, (const uint16_t*)aux->res, aux->N, aux->K, aux->act, aux->y, aux->w_dt == HICOM_DT_F32, aux->b_dt == HICOM_DT_F32,
+                       aux->rows_dst, aux->rows_dt == HICOM_DT_F32, aux->rows_dst ? aux->rows_reps : 0, (long)aux->rows_ld, (long)aux->rows_row0,
+                       (const long long*)aux->x_fixed};
+    };
+    auto check_gemv = [](const hicom_aux_gemv* aux, bool needs_x) -> int {
+        HICOM_REQUIRE(aux->w && (aux->y || aux->rows_dst) && aux->N > 0 && aux->K > 0 && aux->K % 8 == 0 && aux->K <= 1536 && ((uintptr_t)aux->w % 16 == 0), HICOM_EINVAL,
                       "readout16_gemm: aux GEMV arguments");
         if (aux->x_fixed) HICOM_REQUIRE((uintptr_t)aux->x_fixed % 8 == 0, HICOM_EINVAL, "readout16_gemm: aux x_fixed alignment");
-        else HICOM_REQUIRE(aux->xs && aux->x_parts > 0 && aux->x_stride % 4 == 0 && ((uintptr_t)aux->xs % 16 == 0) && (long)aux->x_parts * aux->K <= 28 * 1024 &&
-                               (1536 + (long)aux->x_parts * aux->K) * 4 <= 6 * kRStage, HICOM_EINVAL, "readout16_gemm: aux GEMV partial vectors");
+        else if (needs_x) HICOM_REQUIRE(aux->xs && aux->x_parts > 0 && aux->x_stride % 4 == 0 && ((uintptr_t)aux->xs % 16 == 0) && (long)aux->x_parts * aux->K <= 28 * 1024 &&
+                                            (1536 + (long)aux->x_parts * aux->K) * 4 <= 6 * kRStage, HICOM_EINVAL, "readout16_gemm: aux GEMV partial vectors");
         HICOM_REQUIRE(!aux->rows_dst || (aux->rows_reps > 0 && aux->rows_ld >= aux->N && aux->rows_row0 >= 0), HICOM_EINVAL, "readout16_gemm: aux row destination");
-        p.aux = AuxGemv{aux->xs, aux->x_parts, (long)aux->x_stride, (const uint16_t*)aux->xb, aux->w,
-                        aux->b, (const uint16_t*)aux->res, aux->N, aux->K, aux->act, aux->y, aux->w_dt == HICOM_DT_F32, aux->b_dt == HICOM_DT_F32,
-                        aux->rows_dst, aux->rows_dt == HICOM_DT_F32, aux->rows_dst ? aux->rows_reps : 0, (long)aux->rows_ld, (long)aux->rows_row0,
-                        (const long long*)aux->x_fixed};
-        // the CUs the tile grid leaves idle (one workgroup per CU: the ring takes 120 KB of LDS), at least 16
+        return HICOM_OK;
+    };
+    const int kind = role ? role->kind : HICOM_ROLE_NONE;
+    if (kind == HICOM_ROLE_GEMV && role->gemv.N > 0) {
+        if (int rc = check_gemv(&role->gemv, true)) return rc;
+        p.aux = conv(&role->gemv);
+        p.role = HICOM_ROLE_GEMV;
+    } else if (kind == HICOM_ROLE_GEMV_CHAIN) {
+        if (int rc = check_gemv(&role->gemv, true)) return rc;
+        if (int rc = check_gemv(&role->gemv2, false)) return rc;
+        HICOM_REQUIRE(role->gemv.x_fixed && role->gemv2.K == role->gemv.N && role->gemv2.w_dt == HICOM_DT_BF16 && role->chain_state &&
+                          (uintptr_t)role->chain_state % 16 == 0, HICOM_EINVAL,
+                      "readout16_gemm: GEMV chain (first layer from x_fixed, second layer bf16 with K = the first layer's N, state block)");
+        HICOM_REQUIRE(role->gemv.K % 8 == 0 && role->gemv.N % 8 == 0 && ((uintptr_t)role->gemv2.w % 16 == 0), HICOM_EINVAL,
+                      "readout16_gemm: GEMV chain: K and N of the first layer must be multiples of 8 (16-byte weight rows)");
+        p.aux = conv(&role->gemv);
+        p.aux2 = conv(&role->gemv2);
+        p.chain_state = (unsigned*)role->chain_state;
+        p.role = HICOM_ROLE_GEMV_CHAIN;
+    } else if (kind == HICOM_ROLE_MERGE_VPROJ) {
+        HICOM_REQUIRE(role->part_m && role->part_l && role->part_acc && role->w_v && role->o_fix, HICOM_EINVAL, "readout16_gemm: merge role: NULL pointer");
+        HICOM_REQUIRE(role->part_dt == HICOM_DT_F16 && role->nparts > 0 && role->nparts <= 256 && role->rows > 0 && role->rows <= role->rows_pad &&
+                          role->E > 0 && role->E % 64 == 0 && role->E % role->rows == 0 && role->E / role->rows <= 128 &&
+                          ((uintptr_t)role->o_fix % 8 == 0) && ((uintptr_t)role->w_v % 16 == 0) && ((uintptr_t)role->part_acc % 16 == 0),
+                      HICOM_EINVAL, "readout16_gemm: merge role: fp16 partial contexts, nparts <= 256, head dim <= 128, E %% 64, alignment");
+        p.mv = MergeVprojFixParams{role->part_m, role->part_l, role->part_acc, role->nparts, role->rows_pad, role->E, role->E / role->rows,
+                                   (const uint16_t*)role->w_v, (long long*)role->o_fix, role->out_ml, role->out_ctx};
+        p.role = HICOM_ROLE_MERGE_VPROJ;
+    } else {
+        HICOM_REQUIRE(kind == HICOM_ROLE_NONE || kind == HICOM_ROLE_GEMV, HICOM_EINVAL, "readout16_gemm: role kind %d", kind);
+    }
+    if (p.role != HICOM_ROLE_NONE) {
+        // the CUs the tile grid leaves idle (one workgroup per CU: the ring takes 160 KB of LDS), at least 16
         // the same number on every XCD, and ONE CU per XCD left free: with every CU of an XCD spoken for (25 tiles + 7 aux
         // = 32) an aux workgroup was seen queueing behind a 12-us tile (GEMM 1 in situ: 16.6 us with aux, 12.2 without)
         n_aux = ((256 - p.n_gemm) / 8 - 1) * 8;
         if (n_aux < 16) n_aux = 16;
         if (n_aux > 72) n_aux = 72;
+        // the two-layer chain is bound by the bytes a role CU pulls (4.1 + 1.6 MB of weights beside the streaming tiles): every CU the
+        // tile grid leaves free takes a share (the four tile slots beyond the 196 tiles exit at once)
+        if (p.role == HICOM_ROLE_GEMV_CHAIN && 256 - p.n_gemm >= 16) n_aux = 256 - p.n_gemm < 72 ? 256 - p.n_gemm : 72;
+        if (p.role == HICOM_ROLE_MERGE_VPROJ) {
+            // every item of a role workgroup in flight at once: ceil(items / kMvRoleItems) workgroups (162 items -> 54), never more than
+            // the CUs the tile grid leaves free (one workgroup per CU: the launch asks for 160 KB of LDS)
+            const int items = (p.mv.E / 64) * (p.mv.E / p.mv.hd);
+            const int want = (items + kMvRoleItems - 1) / kMvRoleItems;
+            if (want > n_aux && want <= 256 - p.n_gemm - 2) n_aux = want;
+        }
+    }
+    if (p.role == HICOM_ROLE_GEMV_CHAIN) {
+        const ChainGeom cg = chain_geom(p.aux.N, p.aux.K, p.aux.w_f32 != 0, p.aux2.N, n_aux);
+        HICOM_REQUIRE(cg.r1 >= 1 && cg.r2 >= 1 && cg.cpw1 <= 256 && cg.cpw2 <= 256, HICOM_EUNSUP,
+                      "readout16_gemm: GEMV chain: layers of %d and %d columns over %d role workgroups do not fit", p.aux.N, p.aux2.N, n_aux);
+        p.cg_cpw1 = cg.cpw1; p.cg_cpw2 = cg.cpw2; p.cg_r1 = cg.r1; p.cg_r2 = cg.r2;
     }
     // 8 ring stages (160 KB: one workgroup per CU); 6 stages measured 0.5 us slower per GEMM (tools/gpu_round_c.sh, round 2)
     static bool attr_set = false;
@@ -534,7 +922,34 @@ extern "C" int hicom_readout16_gemm_fwd(const void* a, const void* w, const void
         hipFuncSetAttribute(reinterpret_cast<const void*>(readout16_gemm_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kRStage);
         attr_set = true;
     }
-    // aux workgroups first in dispatch order would delay tiles on their CUs; they go last and land on the free CUs
+    // role workgroups first in dispatch order would delay tiles on their CUs; they go last and land on the free CUs
     HICOM_LAUNCH(readout16_gemm_kernel<8>, dim3((unsigned)(p.n_gemm + n_aux)), dim3(256), 8 * kRStage, (hipStream_t)stream, p);
     return hicom_host::check_launch("readout16_gemm");
 }
+
+extern "C" int hicom_readout16_gemm_fwd(const void* a, const void* w, const void* b, int32_t b_dt,
+                                        int32_t M, int32_t N, int32_t K, int32_t act, void* out_f16,
+                                        void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group,
+                                        const hicom_aux_gemv* aux, void* stream) {
+    if (!aux || aux->N <= 0) return readout16_launch(a, w, b, b_dt, M, N, K, act, out_f16, y, y_dt, ldy, row0, nl_group, nullptr, stream);
+    hicom_r16_role role;
+    memset(&role, 0, sizeof(role));
+    role.kind = HICOM_ROLE_GEMV;
+    role.gemv = *aux;
+    return readout16_launch(a, w, b, b_dt, M, N, K, act, out_f16, y, y_dt, ldy, row0, nl_group, &role, stream);
+}
+
+extern "C" int hicom_readout16_gemm_role_fwd(const void* a, const void* w, const void* b, int32_t b_dt,
+                                             int32_t M, int32_t N, int32_t K, int32_t act, void* out_f16,
+                                             void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group,
+                                             const hicom_r16_role* role, void* stream) {
+    return readout16_launch(a, w, b, b_dt, M, N, K, act, out_f16, y, y_dt, ldy, row0, nl_group, role, stream);
+}
+
+#ifdef HICOM_TRACE
+extern "C" int hicom_debug_r16_trace(void* dst, int64_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(hicom::g_r16_trace), (size_t)bytes) == hipSuccess ? HICOM_OK : HICOM_ELAUNCH;
+}
+#endif
+
+extern "C" int64_t hicom_r16_chain_state_bytes(int32_t n_mid) { return n_mid > 0 ? (int64_t)n_mid * 8 + 64 : HICOM_EINVAL; }

@@ -221,6 +221,7 @@ def _param_list(proj):
     gen = d.get("_engine_params_gen", 0)
     cached = d.get("_engine_params")
     if cached is None or cached[0] != gen:
+        nv.track_parameters(proj)           # (`.data` accesses bump the weights epoch: native.TrackedParameter)
         cached = (gen, [p for p in proj.parameters()])
         d["_engine_params"] = cached
     return cached

@@ -15,7 +15,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 # HICOM_NATIVE_LIB: dev override (instrumented builds from tools/); the product loads the in-tree library
 LIB_PATH = os.environ.get("HICOM_NATIVE_LIB") or os.path.join(HERE, "libhicom_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 DT_BF16, DT_F32, DT_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_GELU_TANH = 0, 1, 2
@@ -35,7 +35,7 @@ EXPORTS = (
     "hicom_small_mha_scaled_fwd", "hicom_merge_vproj_fixed_fwd", "hicom_dense16_tn_fwd", "hicom_dense16_tn_splits",
     "hicom_local_attn_adapt_bwd", "hicom_adapt_dy_fwd", "hicom_gelu_split_fwd", "hicom_gelu_bwd_fwd", "hicom_colsum_fwd",
     "hicom_global_stream_marg_fwd", "hicom_global_stream_marg_width", "hicom_global_stream_has_marg", "hicom_global_merge_marg_fwd",
-    "hicom_act_rows_fwd", "hicom_act_bwd_rows_fwd",
+    "hicom_act_rows_fwd", "hicom_act_bwd_rows_fwd", "hicom_readout16_gemm_role_fwd", "hicom_r16_chain_state_bytes",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -56,6 +56,17 @@ class AuxGemv(C.Structure):
                 ("b", C.c_void_p), ("res", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32), ("act", C.c_int32), ("y", C.c_void_p),
                 ("w_dt", C.c_int32), ("b_dt", C.c_int32), ("rows_dst", C.c_void_p), ("rows_dt", C.c_int32), ("rows_reps", C.c_int32),
                 ("rows_ld", C.c_int64), ("rows_row0", C.c_int64), ("x_fixed", C.c_void_p)]
+
+
+class R16Role(C.Structure):
+    """hicom_r16_role (include/hicom_hip.h): what the workgroups behind a readout GEMM's tile grid do."""
+    _fields_ = [("kind", C.c_int32), ("gemv", AuxGemv), ("gemv2", AuxGemv), ("chain_state", C.c_void_p),
+                ("part_m", C.c_void_p), ("part_l", C.c_void_p), ("part_acc", C.c_void_p), ("part_dt", C.c_int32), ("nparts", C.c_int32),
+                ("rows", C.c_int32), ("rows_pad", C.c_int32), ("E", C.c_int32), ("w_v", C.c_void_p), ("o_fix", C.c_void_p),
+                ("out_ml", C.c_void_p), ("out_ctx", C.c_void_p)]
+
+
+ROLE_NONE, ROLE_GEMV, ROLE_MERGE_VPROJ, ROLE_GEMV_CHAIN = 0, 1, 2, 3
 
 
 class Adaptor(C.Structure):
@@ -139,6 +150,9 @@ def lib() -> C.CDLL:
     L.hicom_fused_stream_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, f32, vp, i32, vp, vp, i32, i32, i32,
                                          vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, vp, vp]
     L.hicom_readout16_gemm_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i64, i64, i32, C.POINTER(AuxGemv), vp]
+    L.hicom_readout16_gemm_role_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i64, i64, i32, C.POINTER(R16Role), vp]
+    L.hicom_r16_chain_state_bytes.argtypes = [i32]
+    L.hicom_r16_chain_state_bytes.restype = i64
     L.hicom_to_f16_fwd.argtypes = [vp, i32, vp, i64, vp]
     L.hicom_splice_rows_fwd.argtypes = [vp, i64, i32, vp, vp]
     L.hicom_splice_labels_fwd.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i64, vp, vp, vp]
@@ -587,6 +601,37 @@ def weight_stamp(*weights):
     return (_WEIGHTS_EPOCH[0],) + tuple(v for w in weights for v in (w.data_ptr(), w._version))
 
 
+class TrackedParameter(torch.nn.Parameter):
+    """nn.Parameter whose `.data` attribute reports its use (round 5: closes the stale-weights footgun of eval-mode `p.data.copy_`).
+
+    `p.data` hands out an alias of the storage with a FRESH version counter: `p.data.copy_(w)`, `p.data.mul_(s)`, `p.data = w` change the
+    weights without any trace on `p._version`, and at inference nothing else (no training forward) bumps the weights epoch, so the
+    weight-derived tables (fp16 readout copies, kpe, folded products, executor plans) would be served stale -- round 4 documented
+    "call hicom_amd.invalidate_weight_caches()".  Here every ACCESS of `.data` on a projector parameter bumps the epoch (a read is
+    indistinguishable from the write that may follow it; the cost of a false alarm is one re-run of the table producers, ~0.1 ms).
+    Forward / backward, optimizers, state_dict(), load_state_dict() and this package's own code never touch `.data`.
+    Not covered: writes through an alias taken earlier (DeepSpeed's flat bf16 buffer) -- the training-forward epoch and its dirty
+    mark (above) handle those; `invalidate_weight_caches()` stays as the explicit form."""
+
+    @property
+    def data(self):
+        _WEIGHTS_EPOCH[0] += 1
+        return torch.Tensor.data.__get__(self)
+
+    @data.setter
+    def data(self, value):
+        _WEIGHTS_EPOCH[0] += 1
+        torch.Tensor.data.__set__(self, value)
+
+
+def track_parameters(module) -> None:
+    """Every nn.Parameter of `module` becomes a TrackedParameter IN PLACE (same object: optimizers and state dicts keep their
+    references; `copy.deepcopy` keeps the class, pickling falls back to nn.Parameter and is re-tracked on the next plan build)."""
+    for p in module.parameters():
+        if type(p) is torch.nn.Parameter:
+            p.__class__ = TrackedParameter
+
+
 _F16_MAX = 65504.0
 _RANGE_CHECKED = set()
 
@@ -701,33 +746,58 @@ def ln_stream(x, gamma, beta, out, src=None, alpha=None, eps=1e-6):
            "hicom_ln_stream_fwd")
 
 
-def readout16_gemm(a16, w16, b, act=ACT_NONE, out_f16=None, y=None, row0=0, nl_group=0, aux=None):
-    """aux: dict(xs f32 [parts, K], xb bf16 [K] | None, w bf16 | f32 [N, K], b bf16 | f32 [N] | None, res bf16 [N] | None, act,
-    y f32 [N] | None, rows=(dst [*, ld], row0, reps) | None)"""
+def _aux_gemv(aux) -> AuxGemv:
+    ag = AuxGemv()
+    if aux.get("x_fixed") is not None:                    # int64 [K] fixed-point accumulators (merge_vproj_fixed)
+        ag.x_fixed = aux["x_fixed"].data_ptr()
+    elif aux.get("xs") is not None:
+        xs = aux["xs"].reshape(-1, aux["w"].shape[1])
+        ag.xs, ag.x_parts, ag.x_stride = xs.data_ptr(), xs.shape[0], xs.shape[1]
+    ag.xb = None if aux.get("xb") is None else aux["xb"].data_ptr()
+    ag.w, ag.N, ag.K = aux["w"].data_ptr(), aux["w"].shape[0], aux["w"].shape[1]
+    ag.b = None if aux.get("b") is None else aux["b"].data_ptr()
+    ag.res = None if aux.get("res") is None else aux["res"].data_ptr()
+    ag.act, ag.y = aux.get("act", ACT_NONE), (None if aux.get("y") is None else aux["y"].data_ptr())
+    ag.w_dt = _dt(aux["w"])
+    ag.b_dt = 0 if aux.get("b") is None else _dt(aux["b"])
+    if aux.get("rows") is not None:
+        dst, row0_, reps = aux["rows"]
+        ag.rows_dst, ag.rows_dt, ag.rows_reps, ag.rows_ld, ag.rows_row0 = dst.data_ptr(), _dt(dst), reps, dst.shape[-1], row0_
+    return ag
+
+
+def readout16_gemm(a16, w16, b, act=ACT_NONE, out_f16=None, y=None, row0=0, nl_group=0, aux=None, merge=None, chain=None):
+    """aux: dict(xs f32 [parts, K] | x_fixed int64 [K], xb bf16 [K] | None, w bf16 | f32 [N, K], b bf16 | f32 [N] | None, res bf16 [N] | None,
+    act, y f32 [N] | None, rows=(dst [*, ld], row0, reps) | None): one GEMV in the launch (HICOM_ROLE_GEMV).
+    merge: dict(part_m, part_l f32 [nparts, rows_pad], part_ctx16 fp16 [nparts, rows_pad, E], rows, w_v bf16 [E, E], o_fix int64 [E] (zero),
+    out_ml | None, out_ctx | None): the merge + v_proj items in the launch (HICOM_ROLE_MERGE_VPROJ).
+    chain: (aux1, aux2, state): two dependent GEMVs in the launch (HICOM_ROLE_GEMV_CHAIN), aux1 from x_fixed; state = r16_chain_state()."""
     N, K = w16.shape
     M = a16.shape[0]
-    ag = None
-    if aux is not None:
-        ag = AuxGemv()
-        if aux.get("x_fixed") is not None:                    # int64 [K] fixed-point accumulators (merge_vproj_fixed)
-            ag.x_fixed = aux["x_fixed"].data_ptr()
-        else:
-            xs = aux["xs"].reshape(-1, aux["w"].shape[1])
-            ag.xs, ag.x_parts, ag.x_stride = xs.data_ptr(), xs.shape[0], xs.shape[1]
-        ag.xb = None if aux.get("xb") is None else aux["xb"].data_ptr()
-        ag.w, ag.N, ag.K = aux["w"].data_ptr(), aux["w"].shape[0], aux["w"].shape[1]
-        ag.b = None if aux.get("b") is None else aux["b"].data_ptr()
-        ag.res = None if aux.get("res") is None else aux["res"].data_ptr()
-        ag.act, ag.y = aux.get("act", ACT_NONE), (None if aux.get("y") is None else aux["y"].data_ptr())
-        ag.w_dt = _dt(aux["w"])
-        ag.b_dt = 0 if aux.get("b") is None else _dt(aux["b"])
-        if aux.get("rows") is not None:
-            dst, row0_, reps = aux["rows"]
-            ag.rows_dst, ag.rows_dt, ag.rows_reps, ag.rows_ld, ag.rows_row0 = dst.data_ptr(), _dt(dst), reps, dst.shape[-1], row0_
-    _check(lib().hicom_readout16_gemm_fwd(_ptr(a16), _ptr(w16), _ptr(b), _dt(b) if b is not None else 0, M, N, K, act,
-                                          _ptr(out_f16), _ptr(y), _dt(y) if y is not None else 0, y.shape[-1] if y is not None else 0,
-                                          row0, nl_group, C.byref(ag) if ag is not None else None, _stream()),
-           "hicom_readout16_gemm_fwd")
+    args = (_ptr(a16), _ptr(w16), _ptr(b), _dt(b) if b is not None else 0, M, N, K, act,
+            _ptr(out_f16), _ptr(y), _dt(y) if y is not None else 0, y.shape[-1] if y is not None else 0, row0, nl_group)
+    if merge is None and chain is None:
+        ag = _aux_gemv(aux) if aux is not None else None
+        _check(lib().hicom_readout16_gemm_fwd(*args, C.byref(ag) if ag is not None else None, _stream()), "hicom_readout16_gemm_fwd")
+        return
+    role = R16Role()
+    if merge is not None:
+        role.kind = ROLE_MERGE_VPROJ
+        pc = merge["part_ctx16"]
+        role.part_m, role.part_l, role.part_acc, role.part_dt = merge["part_m"].data_ptr(), merge["part_l"].data_ptr(), pc.data_ptr(), DT_F16
+        role.nparts, role.rows_pad, role.E, role.rows = pc.shape[0], pc.shape[1], pc.shape[2], merge["rows"]
+        role.w_v, role.o_fix = merge["w_v"].data_ptr(), merge["o_fix"].data_ptr()
+        role.out_ml, role.out_ctx = _ptr(merge.get("out_ml")), _ptr(merge.get("out_ctx"))
+    else:
+        a1, a2, state = chain
+        role.kind = ROLE_GEMV_CHAIN
+        role.gemv, role.gemv2, role.chain_state = _aux_gemv(a1), _aux_gemv(a2), state.data_ptr()
+    _check(lib().hicom_readout16_gemm_role_fwd(*args, C.byref(role), _stream()), "hicom_readout16_gemm_role_fwd")
+
+
+def r16_chain_state(n_mid, device):
+    """Zeroed state block of the GEMV chain role (arrival counter + granules), owned by ONE sequence of launches of one shape."""
+    return torch.zeros(int(lib().hicom_r16_chain_state_bytes(n_mid)), dtype=torch.uint8, device=device)
 
 
 def query_prep_state(E, device):

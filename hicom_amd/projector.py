@@ -53,6 +53,17 @@ def build_mlp(depth: int, hidden_size: int, output_hidden_size: int) -> nn.Seque
     return nn.Sequential(*layers)
 
 
+class _TrackedWeights:
+    """Mixin of the modules that own weight-derived device caches: their parameters report `.data` accesses
+    (native.TrackedParameter: an eval-mode `p.data.copy_(...)` then refreshes the caches by itself).  Re-applied after every
+    _apply (.to() / .cuda() may hand out fresh nn.Parameter objects)."""
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        nv.track_parameters(self)
+        return out
+
+
 class IdentityMap(nn.Module):
     def forward(self, x, *args, **kwargs):
         return x
@@ -271,7 +282,7 @@ def _stream_attention(att, x2, q_in, pe, H, W, t0i, y0i, x0i, clip=None, kpe_t=N
     return ml, acc, scores
 
 
-class LocalCompressor(nn.Module):
+class LocalCompressor(_TrackedWeights, nn.Module):
     """Windowed (t x s x s) single-head cross-attention + 2-layer readout (ref :399-559)."""
 
     def __init__(self, config, temporal_kernel_size=4, spatial_kernel_size=2,
@@ -310,6 +321,7 @@ class LocalCompressor(nn.Module):
             self.v_proj, self.v_norm, self.v_alpha = nn.Identity(), nn.Identity(), 0
         self.readout = build_mlp(mlp_depth, enc, out)
         self.apply(_init_like_reference)
+        nv.track_parameters(self)
 
     # -- geometry -------------------------------------------------------------------------
     def tilings(self, T: int, H: int, W: int, modal: str):
@@ -477,7 +489,7 @@ def _out_dtype(module: nn.Module) -> torch.dtype:
     return torch.float32 if getattr(module, "return_fp32", False) else torch.bfloat16
 
 
-class GlobalCompressor(nn.Module):
+class GlobalCompressor(_TrackedWeights, nn.Module):
     """num_queries x 9-head cross-attention over all T*h*w tokens + readout (ref :562-646)."""
 
     def __init__(self, config, num_queries, use_pos_emb=True, adapt_guide=False,
@@ -498,6 +510,7 @@ class GlobalCompressor(nn.Module):
         self.attn_layer = MultiheadAttention(embed_dim, embed_dim // 128)
         self.readout = build_mlp(mlp_depth, embed_dim, config.hidden_size)
         self.apply(_init_like_reference)
+        nv.track_parameters(self)
         self._pe_cache: Dict[Tuple, torch.Tensor] = {}
         self._cache_gen = 0          # bumped whenever a cached device table is (re)built: invalidates engine plans
 
@@ -711,7 +724,9 @@ class HIComProjector(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):           # .to() / .cuda() / .bfloat16() ...
         self._invalidate_plans()
-        return super()._apply(fn, *args, **kwargs)
+        out = super()._apply(fn, *args, **kwargs)
+        nv.track_parameters(self)
+        return out
 
     def load_state_dict(self, *args, **kwargs):
         self._invalidate_plans()

@@ -20,6 +20,8 @@ from __future__ import annotations
 
 from typing import List, Optional
 
+import threading
+
 import numpy as np
 import torch
 
@@ -27,6 +29,7 @@ from . import native as nv
 
 _PLAN_CACHE: dict = {}       # content hash of (ids, feature rows, embedding table) -> layout plan + pointer table (see below)
 _MAX_PLANS = 8
+_PLAN_LOCK = threading.Lock()   # guards the dict itself; entries are immutable apart from ONE reference store (`upload`)
 
 IGNORE_INDEX = -100                                                   # reference hicom/constants.py:7
 MODAL_INDEX_MAP = {"<image>": -200, "<video>": -201, "<audio>": -202}  # reference hicom/constants.py:30-34
@@ -179,9 +182,11 @@ def prepare_inputs_labels_for_multimodal(embed_tokens, input_ids, attention_mask
     # A serving loop splices the SAME prompt template around every video: the layout plan and the text half of the pointer table
     # depend on (ids, feature row counts, the embedding table) only and are kept per content hash; a call whose feature tensors
     # sit at the addresses of the cached call (the caching allocator hands the same blocks back) re-uses the uploaded table too.
-    ckey = (hash(ids.tobytes()), ids.shape, feat_rows, weight.data_ptr(), weight.shape[0], row_bytes, need_maps)
-    hit = _PLAN_CACHE.get(ckey)
-    if hit is not None and not np.array_equal(hit["ids"], ids):        # (hash collision)
+    # (the key names the embedding table by identity AND address: a freed table's address can be handed to a new one of the same shape)
+    ckey = (hash(ids.tobytes()), ids.shape, feat_rows, id(weight), weight.data_ptr(), weight.shape[0], row_bytes, need_maps)
+    with _PLAN_LOCK:
+        hit = _PLAN_CACHE.get(ckey)
+    if hit is not None and (not np.array_equal(hit["ids"], ids) or hit["weight"]() is not weight):   # (hash collision / recycled id)
         hit = None
     if hit is None:
         plan = plan_layout(ids, list(feat_rows))
@@ -198,8 +203,9 @@ def prepare_inputs_labels_for_multimodal(embed_tokens, input_ids, attention_mask
     # device-pointer table of the output rows + label map + lengths: ONE packed upload, filled segment by segment
     n = B * Lmax
     packed_d = None
-    if hit is not None and hit["feat_ptrs"] == feat_ptrs and hit["packed_d"] is not None and hit["packed_d"].device == dev:
-        packed_d = hit["packed_d"]
+    cached_upload = None if hit is None else hit["upload"]            # ONE read: (feature pointers, device table) published together
+    if cached_upload is not None and cached_upload[0] == feat_ptrs and cached_upload[1].device == dev:
+        packed_d = cached_upload[1]
     else:
         if hit is None:
             packed = np.zeros(n * 8 + (n * 4 + (B * 4 + 15) // 16 * 16 if need_maps else 0), dtype=np.uint8)
@@ -214,17 +220,21 @@ def prepare_inputs_labels_for_multimodal(embed_tokens, input_ids, attention_mask
             if need_maps:
                 packed[n * 8:n * 12].view(np.int32)[:] = plan.src_kind.ravel()
                 packed[n * 12:n * 12 + B * 4].view(np.int32)[:] = new_len
-            hit = {"ids": ids.copy(), "plan": plan, "packed": packed, "feat_ptrs": None, "packed_d": None}
-            if len(_PLAN_CACHE) >= _MAX_PLANS:
-                _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
-            _PLAN_CACHE[ckey] = hit
-        packed = hit["packed"]                                            # (text half final; the visual rows are re-pointed per call)
+            import weakref
+            hit = {"ids": ids.copy(), "plan": plan, "packed": packed, "upload": None, "weight": weakref.ref(weight)}
+            with _PLAN_LOCK:
+                if len(_PLAN_CACHE) >= _MAX_PLANS:
+                    _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+                _PLAN_CACHE[ckey] = hit
+        # the cached host table is a TEMPLATE (text half final) and is never written again: the visual rows are re-pointed in a
+        # private copy, so two threads that splice the same prompt concurrently (serving workers) cannot mix their feature pointers
+        packed = hit["packed"].copy()
         table = packed[:n * 8].view(np.int64).reshape(B, Lmax)
         for b, o, p0, nt, k, nrows in plan.segments:
             if nrows:
                 table[b, o + nt:o + nt + nrows] = feat_ptrs[k] + np.arange(nrows, dtype=np.int64) * row_bytes
         packed_d = torch.from_numpy(packed).to(dev)                       # (a fresh device buffer: an earlier call's table may be in flight)
-        hit["feat_ptrs"], hit["packed_d"] = feat_ptrs, packed_d
+        hit["upload"] = (feat_ptrs, packed_d)                             # (one reference store: readers see the pair or the old pair)
     table_d = packed_d[:n * 8].view(torch.int64).view(B, Lmax)
     needs_grad = torch.is_grad_enabled() and (weight.requires_grad or any(f.requires_grad for f in feats))
     if needs_grad:

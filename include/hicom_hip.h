@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HICOM_ABI_VERSION 10
+#define HICOM_ABI_VERSION 11
 
 #define HICOM_OK         0
 #define HICOM_EINVAL    -1   /* bad argument (shape, alignment, NULL)        */
@@ -387,6 +387,41 @@ int hicom_readout16_gemm_fwd(const void* a, const void* w, const void* b, int32_
                              int32_t M, int32_t N, int32_t K, int32_t act, void* out_f16,
                              void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group,
                              const hicom_aux_gemv* aux, void* stream);
+/* The same launch with a ROLE for the workgroups behind the tile grid (round 5: four launches per step of the release recipe):
+ *   HICOM_ROLE_GEMV         `gemv`, as hicom_readout16_gemm_fwd's aux;
+ *   HICOM_ROLE_MERGE_VPROJ  the (head, 64-channel slab) items of hicom_merge_vproj_fixed_fwd (fp16 partial contexts only): the merge
+ *                           of the ring kernel's partial states (projector.py:193-215 after folding) is independent of the local
+ *                           readout (projector.py:559), so it rides under readout GEMM 1 and its launch disappears;
+ *   HICOM_ROLE_GEMV_CHAIN   two dependent single-row layers in one launch: h = act(gemv.w . x + gemv.b) with x from gemv.x_fixed,
+ *                           then gemv2 with x = h (gemv2.K == gemv.N <= 1536, gemv2.w bf16): GELU(C o + r0) and the last global
+ *                           readout layer (projector.py:226, :646, :307-312) under readout GEMM 2.  h travels between the role's
+ *                           workgroups as {epoch, value} granules in `chain_state` (hicom_r16_chain_state_bytes(gemv.N) bytes,
+ *                           zeroed ONCE by the caller, owned by one plan: every launch on it must have the same tile grid); a
+ *                           failed hand-off (bounded spin) writes NaN rows and counts in word 2 of the state block. */
+#define HICOM_ROLE_NONE 0
+#define HICOM_ROLE_GEMV 1
+#define HICOM_ROLE_MERGE_VPROJ 2
+#define HICOM_ROLE_GEMV_CHAIN 3
+typedef struct hicom_r16_role {
+    int32_t kind;
+    hicom_aux_gemv gemv;
+    hicom_aux_gemv gemv2;
+    void* chain_state;
+    /* MERGE_VPROJ: the arguments of hicom_merge_vproj_fixed_fwd */
+    const float* part_m;
+    const float* part_l;
+    const void* part_acc;
+    int32_t part_dt, nparts, rows, rows_pad, E;
+    const void* w_v;
+    int64_t* o_fix;
+    float* out_ml;
+    float* out_ctx;
+} hicom_r16_role;
+int hicom_readout16_gemm_role_fwd(const void* a, const void* w, const void* b, int32_t b_dt,
+                                  int32_t M, int32_t N, int32_t K, int32_t act, void* out_f16,
+                                  void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group,
+                                  const hicom_r16_role* role, void* stream);
+int64_t hicom_r16_chain_state_bytes(int32_t n_mid);
 /* dst fp16 [rows, ld_dst] = saturating cast of src (bf16 or f32) [rows, cols]; columns [cols, ld_dst) are zero-filled */
 int hicom_to_f16_fwd(const void* src, int32_t src_dt, void* dst, int64_t n, void* stream);
 int hicom_to_f16_padded_fwd(const void* src, int32_t src_dt, int64_t rows, int64_t cols, void* dst, int64_t ld_dst, void* stream);

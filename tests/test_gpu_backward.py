@@ -351,3 +351,47 @@ def test_graph_backward_equals_eager():
             assert torch.equal(p.grad, got2[n]), n
     assert torch.equal(fe2.grad, got2["__fe__"]) and torch.equal(g2.grad, got2["__g__"])
     m.graph_backward = None
+
+
+@pytest.mark.parametrize("name", ["G1_direct_T8", "G5_adaptkv", "G6_coarse", "G7_fine"])
+@pytest.mark.parametrize("how", ["add_", "data_copy_"])
+def test_graph_backward_follows_weight_updates_between_steps(name, how):
+    """the captured backward is keyed by shape and by parameter ADDRESSES; between two training steps an optimizer changes
+    the CONTENT of every weight in place -- through the version counter (`p.add_`) or past it (`p.data.copy_`, DeepSpeed's flat bf16
+    alias).  Every weight-derived table the captured kernels read (kpe, fp16 weight copies, injector tables) must then have been
+    rebuilt in place by that step's training forward.  Two identical modules take the same sequence of steps and updates, one with
+    the hipGraph backward (eager, capture, replay, replay), one eager throughout: gradients bit for bit equal at every step."""
+    case = cases.build_case(name)
+    ma, mb = build_module(case).train(), build_module(case).train()
+    mb.graph_backward = False
+    ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    R = None
+    for stepno in range(5):
+        outs = []
+        for m in (ma, mb):
+            m.zero_grad(set_to_none=True)
+            out = m(ff, fe, g, case.modal, None)
+            if R is None:
+                R = torch.randn(out.shape, device="cuda", generator=gen).to(out.dtype)
+            out.backward(R)
+            outs.append(out.detach().clone())
+        assert torch.equal(outs[0], outs[1]), f"forward differs at step {stepno}"
+        ga = {n: p.grad for n, p in ma.named_parameters() if p.grad is not None}
+        gb = {n: p.grad for n, p in mb.named_parameters() if p.grad is not None}
+        assert ga.keys() == gb.keys() and len(ga) > 0
+        for n in ga:
+            assert torch.equal(ga[n], gb[n]), f"{n} differs at step {stepno} ({how})"
+        # the "optimizer": the same in-place change of every weight in both modules
+        with torch.no_grad():
+            for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+                delta = (torch.randn(pa.shape, device="cuda", generator=gen) * 0.01).to(pa.dtype)
+                if how == "add_":
+                    pa.add_(delta)
+                    pb.add_(delta)
+                else:
+                    new = (pa.detach().float() + delta.float()).to(pa.dtype)
+                    pa.data.copy_(new)
+                    pb.data.copy_(new)
+    ents = list(ma.__dict__.get("_bwd_graphs", {}).values())
+    assert ents and all("graph" in e for e in ents), [e.get("failed") for e in ents]

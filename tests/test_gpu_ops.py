@@ -580,6 +580,77 @@ def test_merge_vproj_fixed_point_accumulators(nparts):
     assert maxabs(y3, want) <= 2e-5
 
 
+@pytest.mark.parametrize("nparts", [216, 7])
+def test_merge_role_inside_the_readout_gemm_launch_equals_the_merge_launch(nparts):
+    """Round 5: HICOM_ROLE_MERGE_VPROJ -- the (head, slab) items of the merge + v_proj dealt over the workgroups behind readout
+    GEMM 1's tile grid.  Same device function as the standalone launch: bit-identical fixed-point sums, (M, L) and contexts; the
+    GEMM's own result is untouched."""
+    g = torch.Generator().manual_seed(150 + nparts)
+    E, nh = 1152, 9
+    pm = torch.randn(nparts, 16, generator=g).cuda() * 3
+    pl = (torch.rand(nparts, 16, generator=g) + 0.5).cuda()
+    p16 = torch.randn(nparts, 16, E, generator=g).cuda().to(torch.float16)
+    wv = bf(torch.randn(E, E, generator=g) * 0.02)
+    ofx_ref = torch.zeros(E, dtype=torch.int64, device="cuda")
+    ml_ref, ctx_ref = torch.empty(nh, 2, device="cuda"), torch.empty(nh, E, device="cuda")
+    nv.merge_vproj_fixed(pm, pl, p16, nh, wv, ofx_ref, ml_ref, ctx_ref)
+    M, N, K = 1296, 896, 1152
+    a16 = nv.to_f16(torch.randn(M, K, generator=g).cuda())
+    w16 = nv.to_f16(torch.randn(N, K, generator=g).cuda() * 0.02)
+    b = bf(torch.randn(N, generator=g) * 0.02)
+    o_ref = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    nv.readout16_gemm(a16, w16, b, act=nv.ACT_GELU, out_f16=o_ref)
+    for _ in range(2):
+        ofx = torch.zeros(E, dtype=torch.int64, device="cuda")
+        ml, ctx = torch.empty(nh, 2, device="cuda"), torch.empty(nh, E, device="cuda")
+        o16 = torch.empty(M, N, dtype=torch.float16, device="cuda")
+        nv.readout16_gemm(a16, w16, b, act=nv.ACT_GELU, out_f16=o16,
+                          merge=dict(part_m=pm, part_l=pl, part_ctx16=p16, rows=nh, w_v=wv, o_fix=ofx, out_ml=ml, out_ctx=ctx))
+        torch.cuda.synchronize()
+        assert torch.equal(ofx, ofx_ref) and torch.equal(ml, ml_ref) and torch.equal(ctx, ctx_ref)
+        assert torch.equal(o16, o_ref)
+
+
+@pytest.mark.parametrize("n_mid,n_out,tile_rows", [(896, 896, 1296), (896, 896, 200), (3584 // 4, 512, 648), (1536, 1000, 96)])
+def test_gemv_chain_role_hands_the_hidden_layer_over_inside_the_launch(n_mid, n_out, tile_rows):
+    """Round 5: HICOM_ROLE_GEMV_CHAIN -- h = GELU(C (o + b_v) + r0) and y = W2 h + b2 -> replicated output rows in ONE launch, h handed
+    over between the role's workgroups as {epoch, value} granules.  Against float64 torch; repeated launches on one state block (the
+    epoch advances by itself), results bit-identical from launch to launch; the hand-off failure counter stays 0."""
+    g = torch.Generator().manual_seed(7 + n_mid + n_out)
+    E = 1152
+    o = torch.randn(E, generator=g).double() * 2
+    ofx = torch.round(o * 2.0 ** 36).to(torch.int64).cuda()
+    bv = bf(torch.randn(E, generator=g) * 0.02)
+    c = (torch.randn(n_mid, E, generator=g) * 0.03).cuda()                     # f32 weights (a cached product of weight matrices)
+    r0 = torch.randn(n_mid, generator=g).cuda() * 0.1
+    w2 = bf(torch.randn(n_out, n_mid, generator=g) * 0.03)
+    b2 = bf(torch.randn(n_out, generator=g) * 0.02)
+    M, N, K = tile_rows, 128, 128
+    a16 = nv.to_f16(torch.randn(M, K, generator=g).cuda())
+    w16 = nv.to_f16(torch.randn(N, K, generator=g).cuda())
+    state = nv.r16_chain_state(n_mid, "cuda")
+    h_want = torch.nn.functional.gelu((ofx.cpu().double() / 2.0 ** 36 + bv.cpu().double()) @ c.cpu().double().t() + r0.cpu().double())
+    y_want = h_want @ w2.cpu().double().t() + b2.cpu().double()
+    outs = []
+    for rep in range(4):
+        dst = torch.full((40, n_out + 8), 7.0, device="cuda")
+        hbuf = torch.empty(n_mid, device="cuda")
+        o16 = torch.empty(M, N, dtype=torch.float16, device="cuda")
+        nv.readout16_gemm(a16, w16, None, out_f16=o16,
+                          chain=(dict(x_fixed=ofx, xb=bv, w=c, b=r0, act=nv.ACT_GELU, y=hbuf),
+                                 dict(w=w2, b=b2, act=nv.ACT_NONE, rows=(dst, 3, 32)), state))
+        torch.cuda.synchronize()
+        assert maxabs(hbuf, h_want) <= 2e-5
+        assert maxabs(dst[3:35, :n_out], y_want.expand(32, n_out)) <= 5e-5 * max(1.0, float(y_want.abs().max()))
+        assert bool((dst[:3] == 7).all()) and bool((dst[35:] == 7).all()) and bool((dst[:, n_out:] == 7).all())
+        assert maxabs(o16.float(), a16.float() @ w16.float().t()) <= 0.05 * K ** 0.5
+        outs.append(dst.clone())
+    assert all(torch.equal(outs[0], x) for x in outs[1:])
+    words = state[:16].view(torch.int32)
+    assert int(words[2]) == 0                                                  # no failed hand-off
+    assert int(state[:8].view(torch.int64)[0]) == 4 * int(words[3])            # four launches' worth of role arrivals
+
+
 def test_fused_stream_clears_the_scratch_it_is_given():
     """hicom_fused_stream_fwd's zero_ptr: workgroup 0 clears the accumulators of the merge + v_proj launch behind it."""
     T, H, W, kt, ks, R = 8, 6, 6, 4, 3, 9

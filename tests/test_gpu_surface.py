@@ -17,6 +17,8 @@ import torch
 
 import cases
 from gpu_util import build_module, dev_bf16
+from hicom_amd import native as nv
+from hicom_amd import synth
 from oracle import hicom_oracle as orc
 from oracle import splice_oracle as so
 
@@ -187,7 +189,7 @@ def test_plan_key_includes_frames_embed_shape():
 def test_weight_writes_that_bypass_the_version_counter():
     """DeepSpeed's bf16 optimizer updates parameters with `p.data.copy_(...)` / through a flat alias, which
     bumps no version counter.  Training-mode forwards rebuild every weight-derived cache (fp16 readout copies, kpe, plans)
-    from the live weights; at inference `hicom_amd.invalidate_weight_caches()` does."""
+    from the live weights; at inference the parameters' `.data` hook does (round 5), or `hicom_amd.invalidate_weight_caches()`."""
     import hicom_amd
     m, _, case = _module_and_sd("G1_direct_T8")
     ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
@@ -206,11 +208,19 @@ def test_weight_writes_that_bypass_the_version_counter():
     with torch.no_grad():
         # the first inference forward after training rebuilds once and agrees with the training forward
         assert float((m(ff, fe, g, "video", None) - trained).abs().max()) <= 2e-4
+        # round 5 (verdict r4 #9): an eval-mode `p.data.copy_` is seen WITHOUT a call to hicom_amd.invalidate_weight_caches() --
+        # the projector's parameters report `.data` accesses (native.TrackedParameter) and the next forward refreshes the tables
         w.data.copy_(w.data / 1.5)
         wk.data.copy_(wk.data * -1.0)
-        stale = m(ff, fe, g, "video", None).clone()                        # documented: inference caches cannot see this write
-        assert float((stale[:-32] - trained[:-32]).abs().max()) <= 2e-4        # (the cached fp16 readout copies; kernels that read the
-        #                                                                       bf16 weights directly -- q_proj, the fold -- do see it)
+        assert float((m(ff, fe, g, "video", None) - base).abs().max()) <= 2e-4
+        # `p.data = new tensor` and an in-place op on the alias likewise; the explicit call stays available (writes through an alias
+        # of the storage taken earlier, which no parameter object sees)
+        w.data = (w.detach().float() * 2).to(w.dtype)
+        doubled = m(ff, fe, g, "video", None).clone()
+        assert float((doubled[:-32] - base[:-32]).abs().max()) > 1e-3
+        alias = w.detach()
+        alias.copy_((alias.float() / 2).to(alias.dtype))                     # bumps the shared version counter: seen as well
+        assert float((m(ff, fe, g, "video", None) - base).abs().max()) <= 2e-4
         hicom_amd.invalidate_weight_caches()
         assert float((m(ff, fe, g, "video", None) - base).abs().max()) <= 2e-4
 
@@ -365,3 +375,32 @@ def test_bench_distributed_branch_world1_prints_one_json_line():
     assert "frame-shard" in d["config"]["parallelism"] and "RCCL" in d["config"]["parallelism"]
     assert d["ms_per_step_joined"]["median"] > 0 and d["ms_per_step"] > 0
     assert d["roofline"]["frac"] > 0
+
+
+def test_integration_md_ctypes_example_runs_as_published():
+    """the ctypes stub in INTEGRATION.md section 2 had fallen one ABI version behind (a 16-argument hicom_local_attn_fwd
+    against the library's 17: the stream handle landed in ctx_f16).  The published block is executed verbatim here and checked
+    against the oracle's window attention, so the document cannot drift from include/hicom_hip.h again."""
+    import math
+    import os
+    import re
+    from oracle import hicom_oracle as orc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = text[text.index("## 2. C-ABI seam"):]
+    block = re.search(r"```python\n(.*?)```", sec, re.S).group(1)
+    assert "hicom_abi_version() == %d" % nv.ABI_VERSION in block
+    block = block.replace('"hicom_amd/libhicom_hip.so"', repr(nv.LIB_PATH))
+    ns = {}
+    exec(compile(block, "INTEGRATION.md", "exec"), ns)
+    x = synth.synth_inputs(8, 6, 6, 1152, tag="doc")
+    ff = torch.from_numpy(x["ff"]).to(torch.bfloat16).cuda()
+    fe = torch.from_numpy(x["fe"]).to(torch.bfloat16).cuda()
+    g = torch.from_numpy(x["g"]).to(torch.bfloat16).cuda()
+    ctx = ns["local_windows"](fe, ff, g)
+    torch.cuda.synchronize()
+    idx = orc.window_token_index(8, 6, 6, 4, 3)
+    k, v = fe.float().cpu().reshape(-1, 1152)[idx], ff.float().cpu().reshape(-1, 1152)[idx]
+    s = torch.einsum("d,wnd->wn", g.float().cpu(), k) / math.sqrt(1152)
+    want = torch.einsum("wn,wnd->wd", torch.softmax(s, 1), v)
+    assert float((ctx.cpu() - want).abs().max()) <= 2e-5
