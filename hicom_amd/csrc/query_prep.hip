@@ -55,6 +55,13 @@ struct PrepParams {
 
 // (round 4: 2 / 4 rows per wave -- 299 workgroups, 18 / 36 KB of cold weights each -- measured 10.9 us against 9.3 us: more than
 // one workgroup per CU puts consumers beside producers, as round 3 found)
+#ifdef HICOM_TRACE
+__device__ unsigned long long g_prep_trace[512 * 8];      // dev-only (tools/prep_trace.py): s_memrealtime stamps per workgroup of the last launch
+#define PREP_TR(k) do { if (threadIdx.x == 0) g_prep_trace[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PREP_TR(k) do {} while (0)
+#endif
+
 constexpr int kQRows = 4;                // q_proj outputs per wave (72 workgroups at E = 1152: the whole grid stays <= 256 workgroups)
 constexpr int kRRows = 8;                // r0 outputs per wave
 constexpr int kPrepCh = 3;               // 16-byte chunks per lane and row: K <= 1536
@@ -133,6 +140,7 @@ __global__ __launch_bounds__(256) void query_prep_kernel(PrepParams p) {
     const int b = blockIdx.x;
     gu64* cnt = (gu64*)p.state;
     gu64* gran = (gu64*)p.gran;
+    PREP_TR(0);
 
     if (b < p.nq_wg) {
         // ---- q_proj: wave -> kQRows consecutive outputs (few rows per wave, many workgroups: the stage is one cold-memory
@@ -146,8 +154,10 @@ __global__ __launch_bounds__(256) void query_prep_kernel(PrepParams p) {
         const unsigned epoch = read_epoch(cnt);
         const int nb = n0 + (lane < kQRows ? lane : 0);
         const float bias = (p.bq && nb < p.E) ? bf16_to_f32(p.bq[nb]) : 0.f;
+        PREP_TR(1);   // q_proj: loads requested
         float out[kQRows];
         prep_dot<kQRows>(wv, x, out);
+        PREP_TR(2);   // q_proj: dots done
         float v = out[0];
 #pragma unroll
         for (int r = 1; r < kQRows; ++r) v = lane == r ? out[r] : v;
@@ -157,6 +167,7 @@ __global__ __launch_bounds__(256) void query_prep_kernel(PrepParams p) {
             __hip_atomic_store(gran + n, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
+        PREP_TR(3);   // q_proj: granules stored
     } else if (b < p.nq_wg + p.nr_wg) {
         // ---- r0 = G0 (b_o + g) + g_b0: independent of everything else in this launch --------------------------------------
         u32x4 wv[kRRows][kPrepCh];
@@ -201,6 +212,7 @@ __global__ __launch_bounds__(256) void query_prep_kernel(PrepParams p) {
                 kp[r] = (j < hd && pc < p.P) ? p.kpe[(long)(h * hd + j) * p.P + pc] : 0.f;
             }
         }
+        PREP_TR(1);   // fold: weights requested
         if (wave == 0) {
             // one wave sweeps the head's granules (<= 128: two per lane) until every tag carries this launch's epoch
             const unsigned epoch = read_epoch(cnt);
@@ -230,6 +242,7 @@ __global__ __launch_bounds__(256) void query_prep_kernel(PrepParams p) {
             if (j1 < hd) qs[j1] = failed ? poison : __uint_as_float((unsigned)c);
         }
         __syncthreads();
+        PREP_TR(2);   // fold: granules swept
         if (is_w) {
             const int jg = tid >> 4, cl = tid & 15;
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -278,6 +291,7 @@ __global__ __launch_bounds__(256) void query_prep_kernel(PrepParams p) {
     }
     // the arrival: after every wave of the workgroup has read the counter (they all did before their first barrier / store)
     __syncthreads();
+    PREP_TR(7);
     if (tid == 0 && b == 0 && __hip_atomic_load((gu32*)p.state + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
         __hip_atomic_store((gu32*)p.state + 3, gridDim.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // result unused: no-return atomic
@@ -287,7 +301,17 @@ __global__ __launch_bounds__(256) void query_prep_kernel(PrepParams p) {
 
 using namespace hicom;
 
-extern "C" int64_t hicom_query_prep_state_bytes(int32_t E) { return (int64_t)E * 8 + 64; }
+#ifdef HICOM_TRACE
+extern "C" int hicom_debug_prep_trace(void* dst, int64_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(hicom::g_prep_trace), (size_t)bytes) == hipSuccess ? HICOM_OK : HICOM_ELAUNCH;
+}
+#endif
+
+// [state words: one 256-byte block of its own | granules].  The arrival counter takes an atomic add from every workgroup of every launch and
+// an epoch read from most: round 4 had the granules start 64 bytes behind it, i.e. the first eight granules of head 0 on the counter's
+// 128-byte line, and head 0's fold workgroups saw their granules 1.5-2 us after everybody else's (tools/prep_trace.py).
+constexpr int kPrepStateHead = 256;
+extern "C" int64_t hicom_query_prep_state_bytes(int32_t E) { return (int64_t)E * 8 + kPrepStateHead; }
 
 extern "C" int hicom_query_prep_fwd(const void* guide, const void* local_q, const void* w_q, const void* b_q, const void* w_k, const float* kpe,
                                     int32_t nh, int32_t E, int32_t P, float scale, void* qt_hi, void* qt_lo, float* pos_a,
@@ -305,7 +329,7 @@ extern "C" int hicom_query_prep_fwd(const void* guide, const void* local_q, cons
     p.E = E; p.nh = nh; p.hd = E / nh; p.P = kpe ? P : 0; p.scale = scale;
     p.qhi = (uint16_t*)qt_hi; p.qlo = (uint16_t*)qt_lo; p.pos_a = pos_a; p.pos_stride = pos_stride; p.R = rows;
     p.gw0 = (const uint16_t*)g_w0; p.gb0 = (const uint16_t*)g_b0; p.bo = (const uint16_t*)b_o; p.hidden = g_w0 ? hidden : 0; p.r0 = r0;
-    p.gran = (unsigned long long*)((char*)state + 64); p.state = (unsigned*)state;
+    p.gran = (unsigned long long*)((char*)state + kPrepStateHead); p.state = (unsigned*)state;
     p.nq_wg = (E + 4 * kQRows - 1) / (4 * kQRows);
     p.nr_wg = p.hidden ? (p.hidden + 4 * kRRows - 1) / (4 * kRRows) : 0;
     p.nf_wg = nh * (E / 128);

@@ -66,7 +66,7 @@ struct R16Params {
     int role;               // HICOM_ROLE_*: what the workgroups behind the tile grid do
     AuxGemv aux;            // GEMV; first layer of GEMV_CHAIN
     AuxGemv aux2;           // GEMV_CHAIN: second layer (x = the first layer's result, handed over inside the launch)
-    unsigned* chain_state;  // GEMV_CHAIN: [0..1] 64-bit arrival counter, [2] failed hand-offs, [3] role workgroups of the first launch; granules from byte 64
+    unsigned* chain_state;  // GEMV_CHAIN: [0..1] 64-bit arrival counter, [2] failed hand-offs, [3] role workgroups of the first launch; granules from byte 256
     MergeVprojFixParams mv; // MERGE_VPROJ
     int cg_cpw1, cg_cpw2, cg_r1, cg_r2;   // GEMV_CHAIN: chain_geom() of this launch, computed by the host
 };
@@ -244,6 +244,7 @@ typedef __attribute__((address_space(1))) unsigned int r16_gu32;
 // Layout of the role's LDS (the launch's 160 KB, unused by a role workgroup otherwise): weight rows of both layers land by LDS-DMA --
 // a role CU that loads into REGISTERS keeps ~64 KB in flight (26 GB/s beside the streaming tiles: tools/tail_trace.py saw the last
 // of 111 KB requested 4.6 us after entry), the DMA path keeps everything it is given in flight (the tiles' own 140 KB per CU).
+constexpr int kChainStateHead = 256;              // state words (arrival counter: an atomic per role workgroup) on lines of their own, granules behind
 constexpr int kChainLds = 160 * 1024, kChainVec = 1536 * 4, kChainBias = 2 * 256 * 4, kChainOut = 256 * 4;
 constexpr int kChainW2Max = 40 * 1024;             // second-layer rows resident per batch (all of a workgroup's at the release shape: 16 x 1792 B)
 
@@ -279,7 +280,7 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
     char* w2l = lds + kChainVec + kChainBias + kChainOut;            // [r2][row2]
     char* w1l = w2l + chain_pad1k((long)cg.r2 * cg.row2);            // [r1][row1]
     r16_gu64* cnt = (r16_gu64*)p.chain_state;
-    r16_gu64* gran = (r16_gu64*)((char*)p.chain_state + 64);
+    r16_gu64* gran = (r16_gu64*)((char*)p.chain_state + kChainStateHead);
     const int n_lo = ai * cg.cpw1, n_hi = min(g1.N, n_lo + cg.cpw1);  // first-layer columns of this workgroup
     const int m_lo = ai * cg.cpw2, m_hi = min(g2.N, m_lo + cg.cpw2);  // second-layer columns
     // One word of every memory region this workgroup is about to read, requested by a DIFFERENT wave each: the regions (state block,
@@ -952,4 +953,4 @@ extern "C" int hicom_debug_r16_trace(void* dst, int64_t bytes) {
 }
 #endif
 
-extern "C" int64_t hicom_r16_chain_state_bytes(int32_t n_mid) { return n_mid > 0 ? (int64_t)n_mid * 8 + 64 : HICOM_EINVAL; }
+extern "C" int64_t hicom_r16_chain_state_bytes(int32_t n_mid) { return n_mid > 0 ? (int64_t)n_mid * 8 + kChainStateHead : HICOM_EINVAL; }

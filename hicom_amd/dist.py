@@ -273,18 +273,22 @@ def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: in
     lc, gc = projector.local_compressor, projector.global_compressor
     if lc is None or gc is None:
         raise NotImplementedError("sharded_forward expects both compressors")
-    if not projector._executor_covers():
-        # coarse / fine / query-side adaptor recipes compute their injected queries per call from the guide; the shard plans patch
-        # only the fields that alias the guide tensor itself (direct) -- refuse instead of running a stale query.  The k / v adaptors
-        # act on the tokens (shard-local, like the windows): the second released recipe `local43_adaptkv_global32` shards.
-        raise NotImplementedError("sharded_forward: use_guide in (None, 'off', 'direct'), optionally with k / v adaptors (the recipes "
-                                  "of the one-call executor); other recipes run unsharded through HIComProjector.forward")
     projector._check_clip_logits()
     if projector.global_logit is not None:
         raise NotImplementedError("sharded_forward: no clip-scale global stage (use forward_stepwise, unsharded)")
     if torch.is_grad_enabled() and projector._needs_grad(ff_shard, fe_shard, guide_embed, image_newline):
         raise RuntimeError("sharded_forward is an inference path: call it under torch.no_grad() / inference_mode()")
     nv.begin_inference()
+    if not projector._executor_covers():
+        # coarse / fine / query-side adaptor recipes (reference projector.py:369-397, :431-441): their injected queries are computed
+        # per call from the guide -- redundantly on every rank for the 32 global rows, from the shard's own frames for the pooled
+        # window queries (window-local: projector.py:539-542) -- so they shard operator by operator (round 5)
+        out = sharded_forward_stepwise(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group)
+        if deferred:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(ff_shard.device))
+            return out, ev
+        return out
     if not all(t is None or t.is_contiguous() for t in (ff_shard, fe_shard, guide_embed, image_newline)):
         raise ValueError("sharded_forward: contiguous inputs only")
     dev = ff_shard.device
@@ -334,3 +338,67 @@ def _comm_step(plan, st, out, image_newline, group, restore=None):
         fenced = False                             # the newline rows were written behind the C call's record
     if not fenced:
         st.ev_tok.record(comm)                     # ev_tok always covers the LAST write of the step into `out`
+
+
+# ---- operator-by-operator sharded path: every recipe (coarse / fine injection, query-side adaptors, clip-scale on the local stage) ----
+
+def stepwise_shard_send(projector, ff_shard, fe_shard, guide_embed, total_frames: int, rank: int, world: int):
+    """STREAM half of a shard, one C-ABI call per operator: the shard's window contexts -> readout -> token rows, and the shard's
+    online-softmax state of the global stage with ABSOLUTE frame indices for the positional terms; both packed into ONE send buffer.
+    Returns (PackLayout, send buffer uint8 [total], (q_in, n_rows, nw, grid)).  The injected queries are computed here from the guide:
+    the 32 global rows' redundantly on every rank (reference projector.py:642), the per-window ones from the shard's own frames
+    (pooled queries are window-local, :539-542)."""
+    from .projector import _out_dtype
+    lc, gc = projector.local_compressor, projector.global_compressor
+    shard = FrameShardPlan(total_frames, world, lc.temporal_kernel_size)
+    t0, t1 = shard.frame_range(rank)
+    if ff_shard.shape[0] != t1 - t0:
+        raise ValueError(f"rank {rank} must hold frames [{t0},{t1})")
+    dev, odt = ff_shard.device, _out_dtype(projector)
+    hidden = lc.readout[2].out_features
+    ctx, grid = lc.window_context(ff_shard, fe_shard, guide_embed, "video", projector.local_logit_scale, projector.local_logit_bias)
+    nw = grid[0] * grid[1] * grid[2]
+    q_in, n_rows = gc.injected_queries(guide_embed)
+    ml, acc, _ = gc.partial_context(ff_shard, q_in, t_offset=t0)
+    R, E = acc.shape
+    lay = PackLayout(2 * R + R * E, nw, hidden, torch.empty((), dtype=odt).element_size())
+    mine = lay.new_buffer(dev)
+    state = lay.state_view(mine)
+    state[:2 * R].copy_(ml.reshape(-1))
+    state[2 * R:].copy_(acc.reshape(-1))
+    lc.readout_into(ctx, lay.tokens_view(mine, odt), 0, 0)            # plain rows: the packing (newline groups) happens at placement
+    return lay, mine, (q_in, n_rows, nw, grid)
+
+
+def stepwise_shard_finish(projector, lay: PackLayout, everyone: torch.Tensor, meta, world: int, image_newline=None) -> torch.Tensor:
+    """FINISH half on the gathered buffers [world, total]: every rank's token block into the packed output (reference row order
+    `[local (t h w) (+ newline rows) ; global]`, projector.py:707, mm_utils.py:92-140), the states combined, the global chain."""
+    from . import native as nv
+    from .projector import _out_dtype
+    lc, gc = projector.local_compressor, projector.global_compressor
+    q_in, n_rows, nw, grid = meta
+    dev, odt = everyone.device, _out_dtype(projector)
+    hidden = lc.readout[2].out_features
+    playout = projector._layout((grid[0] * world, grid[1], grid[2]), "video", image_newline is not None, False)
+    out = torch.empty((playout.n_rows + n_rows, hidden), dtype=odt, device=dev)
+    nv.place_blocks(everyone.data_ptr() + lay.tok_off, nw, world, lay.total, hidden * out.element_size(), out, 0, playout.nl_group)
+    if playout.newline_rows:
+        first = playout.newline_rows[0]
+        step = playout.newline_rows[1] - first if len(playout.newline_rows) > 1 else 1
+        nv.scatter_rows(image_newline.contiguous().view(1, -1), out, first, len(playout.newline_rows), row_step=step)
+    states = lay.state_view(everyone)                                    # [world, 2R + R E] f32
+    R = q_in.shape[0] * gc.attn_layer.num_heads
+    E = gc.embed_dim
+    ml_sets = states[:, :2 * R].reshape(world, R, 2).contiguous()
+    acc_sets = states[:, 2 * R:].reshape(world, R, E).contiguous()
+    gc.finish(ml_sets, acc_sets, q_in, out, playout.n_rows, n_rows)
+    return out
+
+
+def sharded_forward_stepwise(projector, ff_shard, fe_shard, guide_embed, total_frames: int, image_newline=None, group=None):
+    """sharded_forward for the recipes outside the one-call executor: send half, ONE all-gather (RCCL), finish half, all on the
+    caller's stream.  Same exchange format (`PackLayout`, `gather_packed`) as the release path."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lay, mine, meta = stepwise_shard_send(projector, ff_shard, fe_shard, guide_embed, total_frames, rank, world)
+    everyone = gather_packed(mine, lay.new_buffer(mine.device, world), group)
+    return stepwise_shard_finish(projector, lay, everyone, meta, world, image_newline)

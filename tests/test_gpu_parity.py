@@ -732,3 +732,53 @@ def test_large_video_local_tokens_are_frame_group_local(c2):
     assert float((big[:1296].float() - small[:1296].float()).abs().max()) <= 2e-4
     assert all(torch.equal(big[-32], big[-32 + k]) for k in range(1, 32))
     assert not torch.equal(big[-32:], small[-32:])
+
+
+@pytest.mark.parametrize("recipe,world,newline", [("coarse", 2, None), ("coarse", 4, "grid"), ("fine", 2, "frame"), ("fine", 4, None),
+                                                  ("adaptqg_coarse", 2, None), ("clip_local_coarse", 4, None)])
+def test_sharded_stepwise_recipes_emulated_on_one_gpu(recipe, world, newline):
+    """Round 5 (verdict r4 #6): coarse / fine injection and the query-side adaptors shard over frames, operator by operator
+    (`dist.stepwise_shard_send` / `stepwise_shard_finish`, the two halves of `sharded_forward_stepwise` around its one all-gather).
+    2- and 4-rank worlds on one GPU at the 27 x 27 grid -- the all-gather replaced by stacking the ranks' send buffers -- against the
+    ORACLE (reference projector.py:369-397 injectors, :539-542 pooled window queries, absolute frame indices in the positional terms)
+    and against the unsharded HIP forward; with and without newline rows in the packed output."""
+    from types import SimpleNamespace
+    from hicom_amd import dist as hd, synth
+    from oracle import hicom_oracle as orc
+    T, H, W = 16, 27, 27
+    over = {"hidden_size": 128, "max_num_frames": 32}
+    if recipe in ("coarse", "fine"):
+        over.update(mm_projector_type="local43_global32", use_guide=recipe)
+    elif recipe == "adaptqg_coarse":
+        over.update(mm_projector_type="local43_adaptqg_global32_adaptg", use_guide="coarse")
+    else:
+        over.update(mm_projector_type="local43_global32", use_guide="coarse", use_clip_scale="local")
+    if newline:
+        over.update(mm_patch_merge_type="spatial_unpad", mm_newline_position=newline)
+    cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, **over})
+    sd = synth.synth_state_dict(orc.param_shapes(cfg), tag="shard_" + recipe)
+    m = build_module(SimpleNamespace(cfg=cfg, sd=sd))
+    x = synth.synth_inputs(T, H, W, 1152, tag="shard_" + recipe, guide_len=64 if recipe == "fine" else 0)
+    ff, fe, g = dev_bf16(x["ff"]), dev_bf16(x["fe"]), dev_bf16(x["g"])
+    nl = dev_bf16(synth.normal_like((128,), 991)) if newline else None
+    logit = None
+    if recipe == "clip_local_coarse":
+        logit = (2.0, -3.0)
+        m.set_clip_logits(local=logit)
+    per = T // world
+    with torch.no_grad():
+        want = m(ff, fe, g, "video", nl)
+        sends = []
+        for r in range(world):
+            lay, mine, meta = hd.stepwise_shard_send(m, ff[r * per:(r + 1) * per], fe[r * per:(r + 1) * per], g, T, r, world)
+            sends.append(mine)
+        everyone = torch.stack(sends)
+        got = hd.stepwise_shard_finish(m, lay, everyone, meta, world, nl)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape
+    assert float((got.float() - want.float()).abs().max()) <= PATH_TOL
+    if logit is None:
+        sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+        ref = orc.projector_forward(cfg, sdt, ff.float().cpu(), fe.float().cpu(), g.float().cpu(), "video",
+                                    None if nl is None else nl.float().cpu())
+        assert float((got.float().cpu() - ref).abs().max()) <= TOL
