@@ -62,6 +62,7 @@ struct R16Params {
     long ldy, row0;
     int nl_group;
     int vec, bvec;
+    int line16;             // exactly one 16-bit output whose tile rows are whole 16-byte aligned 128-byte lines: the row-line epilogue
     int n_gemm;             // workgroups of the tile grid; blocks >= n_gemm run the role
     int role;               // HICOM_ROLE_*: what the workgroups behind the tile grid do
     AuxGemv aux;            // GEMV; first layer of GEMV_CHAIN
@@ -724,6 +725,65 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
     R16_TR(2);   // tile: main loop done
 
+    // Row-line epilogue (one 16-bit output, whole 64-column tiles): the results go through the (idle) ring as a [96][64] 16-bit image
+    // and leave as 16-byte stores, eight consecutive lanes writing one 128-byte line of an output row.  The straight form -- every lane
+    // storing its four columns of six accumulator blocks, 8 bytes at a time, 16 partial lines per instruction -- is store-ISSUE bound
+    // (cdna_hip_programming.md T21; tools/tail_trace.py: 1.8 us for 12 KB per workgroup, the same on a second pass with warm caches).
+    if (p.line16 && n0 + kRN <= p.N) {
+        constexpr int TP = kRN + 8;                                // row pitch in 16-bit elements: 16-byte aligned rows, shifted banks
+        uint16_t* tl = reinterpret_cast<uint16_t*>(lds);
+        __syncthreads();                                           // every wave has read its last fragments out of the ring
+        const bool to_f16 = p.o16 != nullptr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float bias[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bpre[j]) {
+                if (p.b_f32) {
+                    bias[0] = brawf[j].x; bias[1] = brawf[j].y; bias[2] = brawf[j].z; bias[3] = brawf[j].w;
+                } else {
+                    bias[0] = bf16lo_to_f32(braw[j].x); bias[1] = bf16hi_to_f32(braw[j].x);
+                    bias[2] = bf16lo_to_f32(braw[j].y); bias[3] = bf16hi_to_f32(braw[j].y);
+                }
+            } else if (p.b) {
+                const int n = n0 + 32 * wc + 16 * j + 4 * kg;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    bias[q] = p.b_f32 ? reinterpret_cast<const float*>(p.b)[n + q] : bf16_to_f32(reinterpret_cast<const uint16_t*>(p.b)[n + q]);
+            }
+#pragma unroll
+            for (int im = 0; im < 3; ++im) {
+                uint16_t h[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = acc[j][im][q] + bias[q];
+                    if (p.act == HICOM_ACT_GELU) v = gelu_erf(v);
+                    if (to_f16) {
+                        const _Float16 hv = to_f16_sat(v);
+                        h[q] = __builtin_bit_cast(uint16_t, hv);
+                    } else {
+                        h[q] = f32_to_bf16(v);
+                    }
+                }
+                *reinterpret_cast<uint2*>(tl + (48 * wr + 16 * im + r16) * TP + 32 * wc + 16 * j + 4 * kg) =
+                    make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+            }
+        }
+        __syncthreads();
+        for (int it = tid; it < kRM * (kRN / 8); it += 256) {
+            const int row = it >> 3, c8 = it & 7, m = m0 + row;
+            if (m < p.M) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(tl + row * TP + 8 * c8);
+                if (to_f16) {
+                    *reinterpret_cast<u32x4*>(p.o16 + (long)m * p.N + n0 + 8 * c8) = v;
+                } else {
+                    const long orow = p.row0 + m + (p.nl_group > 0 ? m / p.nl_group : 0);
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.y) + orow * p.ldy + n0 + 8 * c8) = v;
+                }
+            }
+        }
+        R16_TR(5);   // tile: stores issued
+        return;
+    }
     // epilogue.  Transposed product: lane holds columns n .. n+3 (4 * kg + q) of row m = r16 of each block.
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -783,7 +843,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             }
         }
     }
-    R16_TR(7);
+    R16_TR(5);   // tile: stores issued
 }
 
 // bf16 -> fp16 (weights, once per weight version) and f32 -> fp16 (saturating) conversions
@@ -839,6 +899,10 @@ static int readout16_launch(const void* a, const void* w, const void* b, int32_t
     p.a = (const _Float16*)a; p.w = (const _Float16*)w; p.b = b; p.b_f32 = b_dt == HICOM_DT_F32;
     p.M = M; p.N = N; p.K = K; p.act = act; p.o16 = (_Float16*)out_f16; p.y = y; p.y_f32 = y_dt == HICOM_DT_F32;
     p.ldy = (long)ldy; p.row0 = (long)row0; p.nl_group = nl_group; p.vec = vec ? 1 : 0; p.bvec = (b && (uintptr_t)b % 16 == 0) ? 1 : 0;
+    {
+        const bool y16 = y && y_dt != HICOM_DT_F32;
+        p.line16 = (N % 8 == 0 && ((out_f16 && !y && (uintptr_t)out_f16 % 16 == 0) || (!out_f16 && y16 && (uintptr_t)y % 16 == 0 && ldy % 8 == 0))) ? 1 : 0;
+    }
     const int nbx = (N + kRN - 1) / kRN, nby = (M + kRM - 1) / kRM;
     p.n_gemm = 8 * ((nbx * nby + 7) / 8);
     int n_aux = 0;

@@ -262,15 +262,40 @@ def test_f16_weight_copy_range_check():
     assert float((c.float() - ok.float()).abs().max()) <= 2.0 ** -25
 
 
-def test_sharded_forward_refuses_recipes_it_cannot_patch():
-    """coarse / fine / adaptor recipes derive their queries from the guide per call; the shard plans only
-    patch guide ALIASES, so those recipes must raise instead of reusing a freed / stale query."""
+def test_sharded_forward_takes_the_recipes_outside_the_executor_operator_by_operator():
+    """Round 2 (ADVICE, medium) made coarse / fine / query-side-adaptor recipes RAISE in sharded_forward: the shard plans only patch guide
+    aliases, and those recipes derive their queries from the guide per call.  Round 5 (verdict r4 #6): they shard operator by
+    operator (`dist.sharded_forward_stepwise`: queries recomputed on every call, nothing cached that could go stale) -- through a
+    1-rank RCCL group the result equals the unsharded forward, also when the guide changes between two calls; a clip-scale GLOBAL
+    stage and unset clip logits still refuse."""
+    import socket
+    import torch.distributed as dist
     from hicom_amd.dist import sharded_forward
-    for name in ("G6_coarse", "G5b_adaptqkvg_off"):        # (query-side adaptors / injected queries; the k / v adaptors alone DO shard)
-        m, _, case = _module_and_sd(name)
-        ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for name in ("G6_coarse", "G7_fine", "G5b_adaptqkvg_off"):
+            m, _, case = _module_and_sd(name)
+            ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+            with torch.no_grad():
+                for gg in (g, (g.float() * -0.5).to(g.dtype)):                 # a second call with another guide: no stale query
+                    want = m(ff, fe, gg, "video", None)
+                    got = sharded_forward(m, ff, fe, gg, ff.shape[0])
+                    torch.cuda.synchronize()
+                    assert got.shape == want.shape and float((got.float() - want.float()).abs().max()) <= 2e-4, name
+                out, ev = sharded_forward(m, ff, fe, g, ff.shape[0], deferred=True)
+                ev.synchronize()
+                assert float((out.float() - m(ff, fe, g, "video", None).float()).abs().max()) <= 2e-4
+        m, _, case = _module_and_sd("G1_direct_T8")
+        m.global_use_clip_scale = True
+        m.set_clip_logits(glob=(1.5, -2.0))
         with torch.no_grad(), pytest.raises(NotImplementedError):
-            sharded_forward(m, ff, fe, g, ff.shape[0])
+            sharded_forward(m, dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g), 8)
+    finally:
+        dist.destroy_process_group()
     m, _, case = _module_and_sd("G1_direct_T8")
     m.config.use_clip_scale = "local"
     m.local_use_clip_scale = True

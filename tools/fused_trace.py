@@ -92,3 +92,19 @@ for t in range(ntile - 3, ntile + 3):
         break
     seg = [c[:, b0 + 1] - c[:, b0], c[:, b0 + 2] - c[:, b0 + 1], c[:, b0 + 3] - c[:, b0 + 2], c[:, b0 + 4] - c[:, b0 + 3], c[:, b0 + 5] - c[:, b0 + 4]]
     print("tile %2d: " % t + "  ".join("%6.0f" % np.median(x) for x in seg) + ("   next-addr %6.0f" % np.median(c[:, b0 + 6] - c[:, b0 + 5]) if (c[:, b0 + 6] > 0).all() else ""))
+
+# wall-clock view (s_memrealtime, 100 MHz, chip-wide): when does each workgroup start and finish?
+rt0, rt1, xcc = tr[:, 0, 250], tr[:, 0, 251], tr[:, 0, 252]
+base = rt0.min()
+st, en = (rt0 - base) / 100.0, (rt1 - base) / 100.0
+print("---- wall clock (us from the first workgroup's entry)")
+print("entry : p50 %.2f  p90 %.2f  max %.2f" % (np.percentile(st, 50), np.percentile(st, 90), st.max()))
+print("exit  : min %.2f  p10 %.2f  p50 %.2f  p90 %.2f  max %.2f   (kernel ends with the LAST: max - p50 = %.2f us)" % (en.min(), np.percentile(en, 10), np.percentile(en, 50), np.percentile(en, 90), en.max(), en.max() - np.percentile(en, 50)))
+dur = en - st
+print("duration per workgroup: p10 %.2f  p50 %.2f  p90 %.2f  max %.2f" % (np.percentile(dur, 10), np.percentile(dur, 50), np.percentile(dur, 90), dur.max()))
+for x in range(8):
+    sel = xcc == x
+    if sel.any():
+        print("  XCC %d: %3d workgroups, exit p50 %.2f max %.2f" % (x, sel.sum(), np.percentile(en[sel], 50), en[sel].max()))
+late = np.argsort(en)[-8:]
+print("latest workgroups:", [(int(i), round(float(en[i]), 2), int(xcc[i])) for i in late])

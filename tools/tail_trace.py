@@ -43,7 +43,7 @@ tiles = slice(0, n_gemm)
 live = tr[:, :n_gemm, 2] > tr[:, :n_gemm, 0]
 print("tile workgroups (us from the launch's first entry):")
 show("entry", rel(0, tiles))
-for k, nm in ((1, "first stage landed"), (2, "main loop done"), (7, "exit")):
+for k, nm in ((1, "first stage landed"), (2, "main loop done"), (5, "stores issued (exit)")):
     x = ((tr[:, :n_gemm, k] - t0) / 100.0)[live]
     show(nm, x)
 roles = slice(n_gemm, n_gemm + 80)
