@@ -77,7 +77,7 @@ def _ln_stats(x, eps):
     return (x - mu) * rstd, rstd
 
 
-def _adaptor_recompute(x2, mlp, out=None):
+def _adaptor_recompute(x2, mlp, out=None, a16=None):
     """Forward of one adaptor MLP over all tokens WITH what its backward needs, on the inference forward's own kernels and in its
     arithmetic (the GELU fused into the first GEMM's epilogue, fp16 hidden layer): returns (h1, None, y) -- h1 = W1 x + b1 BEFORE
     the activation (fp16, the epilogue's second output), y = W2 GELU(h1) + b2 (fp16, bit-identical to the inference forward's).
@@ -88,7 +88,7 @@ def _adaptor_recompute(x2, mlp, out=None):
     w1, b1 = mlp[0].weight.detach(), mlp[0].bias.detach()
     h1, _, y = out if out is not None else (torch.empty((N, w1.shape[0]), dtype=torch.float16, device=x2.device), None,
                                             torch.empty((N, mlp[2].weight.shape[0]), dtype=torch.float16, device=x2.device))
-    a16 = torch.empty_like(h1)
+    a16 = torch.empty_like(h1) if a16 is None else a16
     nv.dense16_gemm(x2, w1, b1, act=nv.ACT_GELU, out_f16=a16, pre_f16=h1)
     nv.dense16_gemm(a16, inj._f16_weight(mlp[2]), mlp[2].bias.detach(), out_f16=y)
     return h1, None, y
@@ -104,15 +104,29 @@ class _AdaptorStore:
         mk = lambda: torch.empty((N, E), dtype=torch.float16, device=dev)
         self.k = (mk(), None, mk()) if lc.adapt_k else None
         self.v = (mk(), None, mk()) if lc.adapt_v else None
+        # the activated hidden layer(s) between the two GEMMs of a fill: scratch kept with the store (a fresh 107-MB temporary
+        # per fill before); two of them when both streams are adapted -- their layers run as paired launches
+        self.a16 = tuple(mk() for _ in range(2 if (lc.adapt_k and lc.adapt_v) else 1))
         self.serial = 0
 
     def fill(self, lc, ff, fe):
+        from . import injector as inj
         E = ff.shape[-1]
         key = fe if fe is not None else ff
-        if self.k is not None:
-            _adaptor_recompute(key.reshape(-1, E), lc.k_proj, self.k)
-        if self.v is not None:
-            _adaptor_recompute(ff.reshape(-1, E), lc.v_proj, self.v)
+        if self.k is not None and self.v is not None:
+            # both adaptors: each layer of the two MLPs as ONE launch of two problems (hicom_dense16_gemm_pair_fwd), in the inference
+            # forward's arithmetic (GELU fused into the first layer's epilogue whose second output is the value before the activation)
+            kp, vp = lc.k_proj, lc.v_proj
+            nv.dense16_gemm_pair(key.reshape(-1, E), kp[0].weight.detach(), kp[0].bias.detach(), self.a16[0],
+                                 ff.reshape(-1, E), vp[0].weight.detach(), vp[0].bias.detach(), self.a16[1],
+                                 act=nv.ACT_GELU, pre_k=self.k[0], pre_v=self.v[0])
+            nv.dense16_gemm_pair(self.a16[0], inj._f16_weight(kp[2]), kp[2].bias.detach(), self.k[2],
+                                 self.a16[1], inj._f16_weight(vp[2]), vp[2].bias.detach(), self.v[2])
+        else:
+            if self.k is not None:
+                _adaptor_recompute(key.reshape(-1, E), lc.k_proj, self.k, a16=self.a16[0])
+            if self.v is not None:
+                _adaptor_recompute(ff.reshape(-1, E), lc.v_proj, self.v, a16=self.a16[0])
         self.serial += 1
         return self.serial
 

@@ -63,6 +63,13 @@ struct DenseParams {
     const float* tab;
     long tab_ld;
     int H, W, t0, y0, x0;
+    // optional SECOND problem of the same shape in the same launch (hicom_dense16_gemm_pair_fwd): blocks >= tiles_m * tiles_n run it.
+    // Its operands, bias and fp16 output replace a / w / b / o16 / pre16; every other field is shared.
+    const uint16_t* a2;
+    const uint16_t* w2;
+    const void* b2;
+    _Float16* o16_2;
+    _Float16* pre16_2;
 };
 
 __device__ __forceinline__ float gelu_tanh(float x) {
@@ -316,7 +323,12 @@ __global__ __launch_bounds__(256, 3) void dense16_gemm_kernel(DenseParams p) {
     const int wr = wave / WC, wc = wave - wr * WC;
     const int r16 = lane & 15, kg = lane >> 4;
     // XCD-aware bijective remap (cdna_hip_programming.md §5 "XCD swizzle must be bijective")
-    const int nwg = p.tiles_m * p.tiles_n, orig = blockIdx.x;
+    const int nwg = p.tiles_m * p.tiles_n;
+    int orig = blockIdx.x;
+    if (orig >= nwg) {                      // second problem of a paired launch (uniform per workgroup: scalar moves)
+        orig -= nwg;
+        p.a = p.a2; p.w = p.w2; p.b = p.b2; p.o16 = p.o16_2; p.pre16 = p.pre16_2;
+    }
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     // super-tile order inside the run: blocks of RM row tiles, column-major inside a block, so that the tiles an XCD has in
@@ -678,7 +690,8 @@ __global__ __launch_bounds__(256) void l2norm_stream_kernel(const uint16_t* x, u
 
 using namespace hicom;
 
-extern "C" int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w, int64_t ldw, int32_t operand_dt,
+static int dense16_launch(const void* a2, const void* w2, const void* b2, void* out2_f16, void* pre2_f16,
+                          const void* a, int64_t lda, const void* w, int64_t ldw, int32_t operand_dt,
                                       const void* b, int32_t b_dt, int32_t M, int32_t N, int32_t K, int32_t act,
                                       void* out_f16, int64_t ldo, int32_t n_store, void* pre_f16, int64_t ldpre,
                                       void* y, int32_t y_dt, int64_t ldy, const void* res, int64_t ldr,
@@ -720,7 +733,15 @@ extern "C" int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w,
     const bool bf = operand_dt == HICOM_DT_BF16;
     p.tiles_m = (M + 127) / 128; p.tiles_n = (N + 127) / 128;
     constexpr int smem = (128 + 128) * 128;
-    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+    p.a2 = (const uint16_t*)a2; p.w2 = (const uint16_t*)w2; p.b2 = b2; p.o16_2 = (_Float16*)out2_f16; p.pre16_2 = (_Float16*)pre2_f16;
+    if (a2) {
+        HICOM_REQUIRE(w2 && out_f16 && out2_f16 && !y && !ssq && !row_dot && !row_tab && (!b == !b2) && (!pre_f16 == !pre2_f16), HICOM_EINVAL,
+                      "dense16_gemm_pair: two problems of one shape with fp16 outputs (bias / pre-activation output for both or neither)");
+        HICOM_REQUIRE(((uintptr_t)a2 % 16 == 0) && ((uintptr_t)w2 % 16 == 0) && ((uintptr_t)out2_f16 % 16 == 0) && (!b2 || (uintptr_t)b2 % 16 == 0) &&
+                          (!pre2_f16 || (uintptr_t)pre2_f16 % 16 == 0) && (uintptr_t)out_f16 % 16 == 0 && (!b || (uintptr_t)b % 16 == 0), HICOM_EINVAL,
+                      "dense16_gemm_pair: 16-byte alignment");
+    }
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * (a2 ? 2 : 1)));
     if (pre_f16 && bf) hipLaunchKernelGGL((dense16_gemm_kernel<true, true, true>), grid, dim3(256), smem, st, p);
     else if (pre_f16) hipLaunchKernelGGL((dense16_gemm_kernel<false, true, true>), grid, dim3(256), smem, st, p);
     else if (bf && rows) hipLaunchKernelGGL((dense16_gemm_kernel<true, true>), grid, dim3(256), smem, st, p);
@@ -728,6 +749,29 @@ extern "C" int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w,
     else if (rows) hipLaunchKernelGGL((dense16_gemm_kernel<false, true>), grid, dim3(256), smem, st, p);
     else hipLaunchKernelGGL((dense16_gemm_kernel<false, false>), grid, dim3(256), smem, st, p);
     return hicom_host::check_launch("dense16_gemm");
+}
+
+extern "C" int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w, int64_t ldw, int32_t operand_dt,
+                                      const void* b, int32_t b_dt, int32_t M, int32_t N, int32_t K, int32_t act,
+                                      void* out_f16, int64_t ldo, int32_t n_store, void* pre_f16, int64_t ldpre,
+                                      void* y, int32_t y_dt, int64_t ldy, const void* res, int64_t ldr,
+                                      float* ssq, const float* row_tab, int64_t row_tab_ld, int32_t tab_H, int32_t tab_W,
+                                      int32_t tab_t0, int32_t tab_y0, int32_t tab_x0,
+                                      const void* dot_vec, int32_t dot_vec_dt, float* row_dot, void* stream) {
+    return dense16_launch(nullptr, nullptr, nullptr, nullptr, nullptr, a, lda, w, ldw, operand_dt, b, b_dt, M, N, K, act, out_f16, ldo, n_store, pre_f16, ldpre,
+                          y, y_dt, ldy, res, ldr, ssq, row_tab, row_tab_ld, tab_H, tab_W, tab_t0, tab_y0, tab_x0, dot_vec, dot_vec_dt, row_dot, stream);
+}
+
+// TWO problems of one shape in ONE launch: out_k = act(a_k . w_k^T + b_k), out_v = act(a_v . w_v^T + b_v) -- the same layer of the k and
+// of the v adaptor MLP (reference projector.py:533-534: two independent MLPs over all tokens).  3 285 tiles fill the chip's ~1 000
+// resident workgroup slots 3.2 times, i.e. a fifth of the last round is idle; 6 570 tiles share that tail between both problems.
+extern "C" int hicom_dense16_gemm_pair_fwd(const void* a_k, const void* w_k, const void* b_k, void* out_k, void* pre_k,
+                                           const void* a_v, const void* w_v, const void* b_v, void* out_v, void* pre_v,
+                                           int64_t lda, int64_t ldw, int32_t operand_dt, int32_t b_dt, int32_t M, int32_t N, int32_t K, int32_t act,
+                                           int64_t ldo, int32_t n_store, int64_t ldpre, void* stream) {
+    HICOM_REQUIRE(a_v && w_v && out_v, HICOM_EINVAL, "dense16_gemm_pair: NULL pointer");
+    return dense16_launch(a_v, w_v, b_v, out_v, pre_v, a_k, lda, w_k, ldw, operand_dt, b_k, b_dt, M, N, K, act, out_k, ldo, n_store, pre_k, ldpre,
+                          nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0, 0, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int hicom_ln_stream_fwd(const void* x, int32_t x_dt, int64_t ldx, const void* gamma, const void* beta,

@@ -32,7 +32,7 @@ namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct WsLayout {
-    size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, ctx16, hid16, ad_hid, ad_ky, ad_vy, qp, qhi, qlo, pos_a, prep_state, tail_state, scores, part_m, part_l, part_acc, scratch, ml, acc,
+    size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, ctx16, hid16, ad_hid, ad_hid2, ad_ky, ad_vy, qp, qhi, qlo, pos_a, prep_state, tail_state, scores, part_m, part_l, part_acc, scratch, ml, acc,
         ctx_g, o, qres, pre, hid_g, tok, po, o_fix, r0, total;
     int nw, R, rows_pad, nparts, P;
     long N, score_stride;
@@ -97,9 +97,13 @@ WsLayout make_layout(const hicom_compressor_args& a) {
         w.hid16 = take((size_t)w.nw * a.hidden * 2);
         // adaptor streams: the hidden layer of the MLP (shared by the two streams, which run one after the other) and y = MLP(x)
         // per adapted stream, fp16 [N, E]
-        if (a.ak.w0 || a.av.w0) w.ad_hid = take((size_t)w.N * a.E * 2);
-        if (a.ak.w0) w.ad_ky = take((size_t)w.N * a.E * 2);
-        if (a.av.w0) w.ad_vy = take((size_t)w.N * a.E * 2);
+        // (an adaptor whose y the CALLER supplies -- hicom_adaptor.y, the training forward -- needs none of this: 107 MB per region at 64
+        // frames.  Whether y is supplied is part of what a plan is built for: the layout is the same on every call of one plan.)
+        const bool mk = a.ak.w0 && !a.ak.y, mv = a.av.w0 && !a.av.y;
+        if (mk || mv) w.ad_hid = take((size_t)w.N * a.E * 2);
+        if (mk && mv) w.ad_hid2 = take((size_t)w.N * a.E * 2);      // (both adaptors: the two hidden layers live side by side, paired launches)
+        if (mk) w.ad_ky = take((size_t)w.N * a.E * 2);
+        if (mv) w.ad_vy = take((size_t)w.N * a.E * 2);
     }
     if (a.has_global) {
         w.qp = take((size_t)a.nq * a.E * 4);
@@ -481,8 +485,19 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                                                   HICOM_ACT_NONE, ws + y_off, a.E, a.E, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0, 0,
                                                   nullptr, 0, nullptr, sm);
                 };
-                if (a.ak.w0 && !a.ak.y) CHK(mlp(a.ak, key_x, w.ad_ky));
-                if (a.av.w0 && !a.av.y) CHK(mlp(a.av, a.ff, w.ad_vy));
+                // both adaptors from scratch: each layer of the two MLPs as ONE paired launch (two problems of one shape: their tiles share the
+                // last, partly filled round of workgroup slots -- 6 570 tiles = 6.4 rounds instead of 2 x 3.2)
+                static const bool pair_env = !(getenv("HICOM_ADAPT_PAIR") && getenv("HICOM_ADAPT_PAIR")[0] == '0');
+                if (a.ak.w0 && a.av.w0 && !a.ak.y && !a.av.y && pair_env && a.ak.b0 && a.av.b0 && a.ak.b2 && a.av.b2) {
+                    CHK(hicom_dense16_gemm_pair_fwd(key_x, a.ak.w0, a.ak.b0, ws + w.ad_hid, nullptr, a.ff, a.av.w0, a.av.b0, ws + w.ad_hid2, nullptr,
+                                                    a.E, a.E, HICOM_DT_BF16, HICOM_DT_BF16, (int32_t)w.N, a.E, a.E, HICOM_ACT_GELU, a.E, a.E, 0, sm));
+                    CHK(hicom_dense16_gemm_pair_fwd(ws + w.ad_hid, a.ak.w2_f16, a.ak.b2, ws + w.ad_ky, nullptr, ws + w.ad_hid2, a.av.w2_f16, a.av.b2,
+                                                    ws + w.ad_vy, nullptr, a.E, a.E, HICOM_DT_F16, HICOM_DT_BF16, (int32_t)w.N, a.E, a.E, HICOM_ACT_NONE,
+                                                    a.E, a.E, 0, sm));
+                } else {
+                    if (a.ak.w0 && !a.ak.y) CHK(mlp(a.ak, key_x, w.ad_ky));
+                    if (a.av.w0 && !a.av.y) CHK(mlp(a.av, a.ff, w.ad_vy));
+                }
                 const void* ky = !a.ak.w0 ? nullptr : (a.ak.y ? a.ak.y : (const void*)(ws + w.ad_ky));      // (.y: the caller's own MLP outputs)
                 const void* vy = !a.av.w0 ? nullptr : (a.av.y ? a.av.y : (const void*)(ws + w.ad_vy));
                 CHK(hicom_local_attn_adapt_fwd(key_x, ky, a.ak.gamma, a.ak.beta, a.ak.alpha,

@@ -300,7 +300,8 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
            None if nl is None else tuple(nl.shape), out_dtype,
            torch.cuda.current_stream(dev).cuda_stream,
            (ff.data_ptr(), _p(fe), _p(guide), _p(nl), _p(ll), None if adapt_y is None else tuple(_p(t) for t in adapt_y)) if graph else None,
-           ll is not None)
+           ll is not None,
+           None if adapt_y is None else tuple(t is not None for t in adapt_y))     # (supplied adaptor outputs: the workspace has no regions for them)
     plans = proj.__dict__.setdefault("_engine_plans", {})
     plan = plans.get(key)
     sig = plan_sig(proj)
@@ -328,6 +329,9 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
         hidden = (lc or gc).readout[2].out_features
         probe = torch.empty((n_local + n_global, hidden), dtype=out_dtype, device=dev)
         a = build_args(proj, ff, fe, guide, modal, nl, probe, layout, global_row0=n_local)
+        if adapt_y is not None:             # (before the workspace is sized: make_layout skips the regions of supplied outputs)
+            a.ak.y = _p(adapt_y[0])
+            a.av.y = _p(adapt_y[1])
         if ll is not None:
             a.local_logits = ll.data_ptr()
             if not nv.compressor_is_fused(a):

@@ -35,7 +35,7 @@ EXPORTS = (
     "hicom_small_mha_scaled_fwd", "hicom_merge_vproj_fixed_fwd", "hicom_dense16_tn_fwd", "hicom_dense16_tn_splits",
     "hicom_local_attn_adapt_bwd", "hicom_adapt_dy_fwd", "hicom_gelu_split_fwd", "hicom_gelu_bwd_fwd", "hicom_colsum_fwd",
     "hicom_global_stream_marg_fwd", "hicom_global_stream_marg_width", "hicom_global_stream_has_marg", "hicom_global_merge_marg_fwd",
-    "hicom_act_rows_fwd", "hicom_act_bwd_rows_fwd", "hicom_readout16_gemm_role_fwd", "hicom_r16_chain_state_bytes",
+    "hicom_act_rows_fwd", "hicom_act_bwd_rows_fwd", "hicom_readout16_gemm_role_fwd", "hicom_r16_chain_state_bytes", "hicom_dense16_gemm_pair_fwd",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -159,6 +159,7 @@ def lib() -> C.CDLL:
     L.hicom_to_f16_padded_fwd.argtypes = [vp, i32, i64, i64, vp, i64, vp]
     L.hicom_dense16_gemm_fwd.argtypes = [vp, i64, vp, i64, i32, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, i64, vp, i32, i64, vp, i64, vp,
                                          vp, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp]
+    L.hicom_dense16_gemm_pair_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i64, i32, i64, vp]
     L.hicom_partials_sum_fwd.argtypes = [vp, i32, i64, vp, vp]
     L.hicom_dense16_tn_splits.argtypes = [i32, i32, i64]
     L.hicom_dense16_tn_fwd.argtypes = [vp, i64, vp, i64, i32, i64, i32, i32, vp, i64, i32, vp]
@@ -688,6 +689,17 @@ def dense16_gemm(a, w, b, N=None, K=None, act=ACT_NONE, out_f16=None, n_store=No
                                         _ptr(row_dot[0]) if row_dot else None, _dt(row_dot[0]) if row_dot else 0,
                                         _ptr(row_dot[1]) if row_dot else None, _stream()),
            "hicom_dense16_gemm_fwd")
+
+
+def dense16_gemm_pair(a_k, w_k, b_k, out_k, a_v, w_v, b_v, out_v, act=ACT_NONE, pre_k=None, pre_v=None):
+    """Two GEMMs of ONE shape in one launch (the same layer of the k and of the v adaptor MLP): out_x = act(a_x . w_x^T + b_x), fp16 outputs."""
+    if a_k.dtype != w_k.dtype or a_v.dtype != a_k.dtype or w_v.dtype != a_k.dtype or a_k.shape != a_v.shape or w_k.shape != w_v.shape:
+        raise HicomNativeError("dense16_gemm_pair: two problems of one shape and one operand dtype")
+    M, (N, K) = a_k.shape[0], w_k.shape
+    _check(lib().hicom_dense16_gemm_pair_fwd(_ptr(a_k), _ptr(w_k), _ptr(b_k), _ptr(out_k), _ptr(pre_k), _ptr(a_v), _ptr(w_v), _ptr(b_v), _ptr(out_v),
+                                             _ptr(pre_v), a_k.shape[1], w_k.shape[1], _dt(a_k), _dt(b_k) if b_k is not None else 0, M, N, K, act,
+                                             out_k.shape[1], out_k.shape[1], pre_k.shape[1] if pre_k is not None else 0, _stream()),
+           "hicom_dense16_gemm_pair_fwd")
 
 
 def dense16_tn(a, b, M=None, N=None, out=None, splits=None):

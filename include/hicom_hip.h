@@ -469,6 +469,12 @@ int hicom_dense16_gemm_fwd(const void* a, int64_t lda, const void* w, int64_t ld
                            float* ssq, const float* row_tab, int64_t row_tab_ld, int32_t tab_H, int32_t tab_W,
                            int32_t tab_t0, int32_t tab_y0, int32_t tab_x0,
                            const void* dot_vec, int32_t dot_vec_dt, float* row_dot, void* stream);
+/* The same for TWO problems of one shape in ONE launch (fp16 outputs only): the same layer of the k and of the v adaptor MLP
+ * (projector.py:533-534).  The tiles of both problems share the last, partly filled round of workgroup slots. */
+int hicom_dense16_gemm_pair_fwd(const void* a_k, const void* w_k, const void* b_k, void* out_k, void* pre_k,
+                                const void* a_v, const void* w_v, const void* b_v, void* out_v, void* pre_v,
+                                int64_t lda, int64_t ldw, int32_t operand_dt, int32_t b_dt, int32_t M, int32_t N, int32_t K, int32_t act,
+                                int64_t ldo, int32_t n_store, int64_t ldpre, void* stream);
 /* TN form: c_parts[s][m][n] = sum over the s-th slice of the Kt rows of a[k][m] * b[k][n] -- the weight gradients dW = dY^T X of the
  * token-stream layers (a = dY [Kt, lda], b = X [Kt, ldb], both token-major, both fp16 or both bf16; fp32 accumulation).  The
  * contraction axis is split into `splits` slices (hicom_dense16_tn_splits proposes a count), each writing its own f32 partial

@@ -916,3 +916,25 @@ def test_local_attn_adapt_matches_torch(T, H, W, kt, ks, shared_query, which):
         p = torch.softmax(kw @ qq * scale, 0)
         want[w] = p @ vw
     assert float((ctx.double().cpu() - want).abs().max()) <= 2e-4
+
+
+@pytest.mark.parametrize("M,dt,act", [(729 * 4, torch.bfloat16, nv.ACT_GELU), (1000, torch.float16, nv.ACT_NONE)])
+def test_dense16_pair_launch_equals_two_launches(M, dt, act):
+    """Round 5: hicom_dense16_gemm_pair_fwd -- the same layer of the k and of the v adaptor MLP (reference projector.py:533-534) as ONE
+    launch of two problems; every output bit-identical to the single-problem launch (same tiles, same arithmetic), ragged M included."""
+    g = torch.Generator().manual_seed(M)
+    E = 1152
+    a_k, a_v = (torch.randn(M, E, generator=g).cuda().to(dt) for _ in range(2))
+    w_k, w_v = ((torch.randn(E, E, generator=g) * 0.03).cuda().to(dt) for _ in range(2))
+    b_k, b_v = (bf(torch.randn(E, generator=g) * 0.05) for _ in range(2))
+    ref_k, ref_v = (torch.empty(M, E, dtype=torch.float16, device="cuda") for _ in range(2))
+    nv.dense16_gemm(a_k, w_k, b_k, act=act, out_f16=ref_k)
+    nv.dense16_gemm(a_v, w_v, b_v, act=act, out_f16=ref_v)
+    out_k, out_v = (torch.full((M, E), float("nan"), dtype=torch.float16, device="cuda") for _ in range(2))
+    nv.dense16_gemm_pair(a_k, w_k, b_k, out_k, a_v, w_v, b_v, out_v, act=act)
+    torch.cuda.synchronize()
+    assert torch.equal(out_k, ref_k) and torch.equal(out_v, ref_v)
+    want = a_k.float() @ w_k.float().t() + b_k.float()
+    if act == nv.ACT_GELU:
+        want = torch.nn.functional.gelu(want)
+    assert maxabs(out_k, want) <= 2e-2 * max(1.0, float(want.abs().max()))

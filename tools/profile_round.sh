@@ -16,6 +16,11 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFM
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma/off -- python3 tools/modes_one.py off > $O/mfma2.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma/head -- python3 -m pytest tests/test_gpu_head.py -q -k benchmark > $O/mfma3.log 2>&1
 python3 tools/pmc_mfma.py $O/mfma $R/gpurun_out/${TAG}_mfma_util.json
+# BASELINE configs[3]'s compressor shape (32 frames, hidden 3584): kernel table + whole-step fraction
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4 -- python3 tools/c4_step.py 500 > $O/c4.log 2>&1
+cp $(ls $O/c4/*/*kernel_stats.csv | head -1) $R/gpurun_out/${TAG}_c4_kernel_stats.csv
+python3 tools/c4_step.py 2000 2>/dev/null | tail -1 > $R/gpurun_out/${TAG}_c4_step.txt; cat $R/gpurun_out/${TAG}_c4_step.txt
+python3 tools/step_trace.py $O/stats > $R/gpurun_out/${TAG}_step_trace.txt; cat $R/gpurun_out/${TAG}_step_trace.txt
 timeout 900 python3 bench.py 2> $O/bench.err | grep '^{' > $R/gpurun_out/${TAG}_bench.json
 cut -c1-600 $R/gpurun_out/${TAG}_bench.json
 head -8 $R/gpurun_out/${TAG}_kernel_stats.csv | cut -c1-150
