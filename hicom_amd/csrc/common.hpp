@@ -124,19 +124,6 @@ __device__ __forceinline__ void lds_add_f32(float* lds_ptr, float v) {
     asm volatile("ds_add_f32 %0, %1" : : "v"(addr), "v"(v) : "memory");
 }
 
-// Kernel-argument block -> scalar cache in ONE memory round trip.  A kernel whose argument struct spans several 64-byte lines reads
-// it lazily: every first touch of a line is a cold scalar load (0.5-1 us beside a streaming chip), and pointer -> data chains put
-// them in series -- tools/tail_trace.py saw a role workgroup request its first data 2.8 us after entry.  Here one word of every
-// line of the block is requested back to back behind a single wait; the compiler's own argument loads then hit the scalar cache.
-template <int BYTES>
-__device__ __forceinline__ void warm_kernarg() {
-    const __attribute__((address_space(4))) char* ka = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
-    int acc = 0;
-#pragma unroll
-    for (int o = 0; o < BYTES; o += 64) acc ^= *reinterpret_cast<const __attribute__((address_space(4))) int*>(ka + o);
-    asm volatile("" ::"s"(acc));
-}
-
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

@@ -284,18 +284,6 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
     r16_gu64* gran = (r16_gu64*)((char*)p.chain_state + kChainStateHead);
     const int n_lo = ai * cg.cpw1, n_hi = min(g1.N, n_lo + cg.cpw1);  // first-layer columns of this workgroup
     const int m_lo = ai * cg.cpw2, m_hi = min(g2.N, m_lo + cg.cpw2);  // second-layer columns
-    // One word of every memory region this workgroup is about to read, requested by a DIFFERENT wave each: the regions (state block,
-    // accumulators, two weight matrices, biases) lie on different pages, a CU's first touch of a page is an address-translation miss,
-    // and a wave's requests wait in order behind it (tools/tail_trace.py: 0.5-1.5 us per region, 3.5 us in series).  Four waves
-    // miss in parallel.
-    int touch = 0;
-    if (n_lo < g1.N && m_lo < g2.N) {
-        const char* tp = wave == 0 ? reinterpret_cast<const char*>(g1.x_fixed)
-                       : wave == 1 ? reinterpret_cast<const char*>(g1.w) + (long)n_lo * cg.row1
-                       : wave == 2 ? reinterpret_cast<const char*>(g2.w) + (long)m_lo * cg.row2
-                                   : reinterpret_cast<const char*>(g2.b ? g2.b : g2.w);
-        touch = *reinterpret_cast<const int*>(tp);
-    }
     // (the counter is requested first and CONSUMED behind the first barrier: a returned atomic takes 2-4 us beside the tiles)
     unsigned long long c0 = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     R16_TR(8);
@@ -490,7 +478,6 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
     if (tid == 0 && ai == 0 && __hip_atomic_load((r16_gu32*)p.chain_state + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
         __hip_atomic_store((r16_gu32*)p.chain_state + 3, (unsigned)an, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("" ::"v"(touch));                    // (the touch loads' only consumer: they are never waited for on their own)
 }
 
 // ---- MERGE_VPROJ role: the (head, 64-channel slab) items of hicom_merge_vproj_fixed_fwd dealt over the role workgroups ----
@@ -521,7 +508,6 @@ template <int kRRing>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void readout16_gemm_kernel(R16Params p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [kRRing][kRStage]
     R16_TR(0);
-    warm_kernarg<sizeof(R16Params)>();
     if ((int)blockIdx.x >= p.n_gemm) {
         const int ai = (int)blockIdx.x - p.n_gemm, an = (int)gridDim.x - p.n_gemm;
         if (p.role == HICOM_ROLE_MERGE_VPROJ) {
