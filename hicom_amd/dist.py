@@ -356,7 +356,7 @@ def stepwise_shard_send(projector, ff_shard, fe_shard, guide_embed, total_frames
         raise ValueError(f"rank {rank} must hold frames [{t0},{t1})")
     dev, odt = ff_shard.device, _out_dtype(projector)
     hidden = lc.readout[2].out_features
-    ctx, grid = lc.window_context(ff_shard, fe_shard, guide_embed, "video", projector.local_logit_scale, projector.local_logit_bias)
+    ctx, grid = lc.window_context(ff_shard, fe_shard, guide_embed, "video", *projector._logit_args("local"))
     nw = grid[0] * grid[1] * grid[2]
     q_in, n_rows = gc.injected_queries(guide_embed)
     ml, acc, _ = gc.partial_context(ff_shard, q_in, t_offset=t0)

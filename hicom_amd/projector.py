@@ -703,11 +703,17 @@ class HIComProjector(nn.Module):
         use_clip_scale = (getattr(config, "use_clip_scale", "") or "").split(",")
         self.local_use_clip_scale = "local" in use_clip_scale
         self.global_use_clip_scale = "global" in use_clip_scale
-        # The reference copies SigLIP's logit_scale / logit_bias out of the hub checkpoint at construction
-        # (ref :660-670); this build has no hub access and takes them from set_clip_logits() -- a projector configured
-        # with use_clip_scale constructs fine and refuses to run until they have been set.
+        # The reference copies SigLIP's logit_scale / logit_bias out of the hub checkpoint at construction (ref :660-670) and keeps them as
+        # PARAMETERS of the projector (`local_logit_scale`, ... [1]: part of its state dict, trainable under `attn_scale`,
+        # train.py:730-734).  This build has no hub access: the parameters are registered here with NaN ("not given yet") and filled by
+        # load_state_dict() -- a checkpoint saved by the reference carries them -- or by set_clip_logits(); a projector whose logits are
+        # still NaN refuses to run.  The Python floats the plans bake in (`local_logit` / `global_logit`) follow the parameters'
+        # content (_sync_clip_logits: one host read per change, none per call).
         self.local_logit_scale = self.local_logit_bias = None
         self.global_logit_scale = self.global_logit_bias = None
+        for stage, on in (("local", self.local_use_clip_scale), ("global", self.global_use_clip_scale)):
+            if on:
+                self._register_clip_params(stage)
         self.local_logit = self.global_logit = None          # (log scale, bias) as Python floats: what the plans bake in
         self.local_compressor = local_compressor
         self.global_compressor = global_compressor
@@ -732,21 +738,65 @@ class HIComProjector(nn.Module):
         self._invalidate_plans()
         return super().load_state_dict(*args, **kwargs)
 
+    def _register_clip_params(self, stage: str):
+        ref = next(self.parameters(), None)
+        kw = {} if ref is None else dict(device=ref.device, dtype=ref.dtype)
+        for what in ("scale", "bias"):
+            name = f"{stage}_logit_{what}"
+            if not isinstance(getattr(self, name, None), nn.Parameter):
+                if name in self.__dict__:
+                    del self.__dict__[name]                      # (the plain `None` attribute set before registration)
+                self.register_parameter(name, nn.Parameter(torch.full((1,), float("nan"), **kw), requires_grad=False))
+
     def set_clip_logits(self, local=None, glob=None):
-        """(logit_scale, logit_bias) of the SigLIP checkpoint for the stages named in config.use_clip_scale
-        (ref :660-670 reads them from AutoModel.from_pretrained).  Tensors or numbers; read once."""
-        if local is not None:
-            self.local_logit_scale, self.local_logit_bias = local
-            self.local_logit = (float(local[0]), float(local[1]))
-        if glob is not None:
-            self.global_logit_scale, self.global_logit_bias = glob
-            self.global_logit = (float(glob[0]), float(glob[1]))
-        self._invalidate_plans()
+        """(logit_scale, logit_bias) of the SigLIP checkpoint for the stages named in config.use_clip_scale (ref :660-670 reads them
+        from AutoModel.from_pretrained), written into the projector's `*_logit_scale` / `*_logit_bias` parameters.  Tensors or numbers."""
+        for stage, val in (("local", local), ("global", glob)):
+            if val is None:
+                continue
+            self._register_clip_params(stage)
+            with torch.no_grad():
+                getattr(self, f"{stage}_logit_scale").fill_(float(val[0]))
+                getattr(self, f"{stage}_logit_bias").fill_(float(val[1]))
+        self._sync_clip_logits(force=True)
+
+    def _clip_params(self):
+        return [p for p in (self.local_logit_scale, self.local_logit_bias, self.global_logit_scale, self.global_logit_bias)
+                if isinstance(p, nn.Parameter)]
+
+    def _sync_clip_logits(self, force: bool = False):
+        """`local_logit` / `global_logit` (Python floats) from the parameters, re-read only when their content may have changed
+        (storage, in-place version, weights epoch: load_state_dict, .to(), an optimizer step, `p.data.copy_`)."""
+        ps = self._clip_params()
+        if not ps:
+            return
+        stamp = nv.weight_stamp(*ps)
+        if not force and stamp == self.__dict__.get("_clip_stamp"):
+            return
+
+        def read(scale, bias):
+            if not isinstance(scale, nn.Parameter) or not isinstance(bias, nn.Parameter):
+                return None
+            v = (float(scale.detach().float().cpu()), float(bias.detach().float().cpu()))
+            return None if any(math.isnan(x) for x in v) else v
+
+        new = (read(self.local_logit_scale, self.local_logit_bias), read(self.global_logit_scale, self.global_logit_bias))
+        if new != (self.local_logit, self.global_logit):
+            self.local_logit, self.global_logit = new
+            self._invalidate_plans()
+        self.__dict__["_clip_stamp"] = nv.weight_stamp(*ps)
+
+    def _logit_args(self, stage: str):
+        """(log scale, bias) as the stage modules' forward takes them (reference :524, :634), from the cached floats."""
+        v = self.local_logit if stage == "local" else self.global_logit
+        return (None, None) if v is None else v
 
     def _check_clip_logits(self):
+        self._sync_clip_logits()
         if (self.local_use_clip_scale and self.local_logit is None) or (self.global_use_clip_scale and self.global_logit is None):
             raise RuntimeError("config.use_clip_scale names a stage whose SigLIP logit_scale / logit_bias have not been "
-                               "given: call set_clip_logits(local=(scale, bias), glob=(scale, bias)) first")
+                               "given: load a checkpoint that carries `*_logit_scale` / `*_logit_bias` or call "
+                               "set_clip_logits(local=(scale, bias), glob=(scale, bias)) first")
 
     def _layout(self, grid, modal, has_newline, is_anyres):
         return geo.pack_layout(getattr(self.config, "mm_patch_merge_type", "flat"),
@@ -846,15 +896,15 @@ class HIComProjector(nn.Module):
                 if frames_feature["base"] is not None:
                     fe = frames_embed["base"].unsqueeze(0) if frames_embed is not None else None
                     ctx, grid = lc.window_context(frames_feature["base"].unsqueeze(0), fe, guide_embed, modal,
-                                                  self.local_logit_scale, self.local_logit_bias)
+                                                  *self._logit_args("local"))
                     segments.append((ctx, self._layout(grid, modal, image_newline is not None, False)))
                 fe = frames_embed["patch"].unsqueeze(0) if frames_embed is not None else None
                 ctx, grid = lc.window_context(frames_feature["patch"].unsqueeze(0), fe, guide_embed, modal,
-                                              self.local_logit_scale, self.local_logit_bias)
+                                              *self._logit_args("local"))
                 segments.append((ctx, self._layout(grid, modal, image_newline is not None, True)))
             else:
                 ctx, grid = lc.window_context(frames_feature, frames_embed, guide_embed, modal,
-                                              self.local_logit_scale, self.local_logit_bias)
+                                              *self._logit_args("local"))
                 segments.append((ctx, self._layout(grid, modal, image_newline is not None, False)))
         n_local = sum(lay.n_rows for _, lay in segments)
         n_global = gc.num_queries if gc is not None else 0
@@ -873,7 +923,7 @@ class HIComProjector(nn.Module):
             row += lay.n_rows
         if gc is not None:
             gff = frames_feature["patch"].unsqueeze(0) if isinstance(frames_feature, dict) else frames_feature
-            gc.forward_into(gff, guide_embed, self.global_logit_scale, out, row, self.global_logit_bias)
+            gc.forward_into(gff, guide_embed, self._logit_args("global")[0], out, row, self._logit_args("global")[1])
         return out
 
 
@@ -897,7 +947,7 @@ def _two_stream_forward(self, frames_feature, frames_embed, guide_embed, modal, 
     res.ev_fork.record(main)
     res.side.wait_event(res.ev_fork)
     with torch.cuda.stream(res.side):
-        ctx, _ = lc.window_context(ff, frames_embed, guide_embed, modal, self.local_logit_scale, self.local_logit_bias)
+        ctx, _ = lc.window_context(ff, frames_embed, guide_embed, modal, *self._logit_args("local"))
         lc.readout_into(ctx, out, 0, lay.nl_group)
         if lay.newline_rows:
             nl = image_newline.contiguous()
@@ -909,7 +959,7 @@ def _two_stream_forward(self, frames_feature, frames_embed, guide_embed, modal, 
     for t in (ff, frames_embed, guide_embed, image_newline, out):
         if isinstance(t, torch.Tensor):
             t.record_stream(res.side)
-    gc.forward_into(ff, guide_embed, self.global_logit_scale, out, lay.n_rows, self.global_logit_bias)
+    gc.forward_into(ff, guide_embed, self._logit_args("global")[0], out, lay.n_rows, self._logit_args("global")[1])
     main.wait_event(res.ev_join)
     return out
 

@@ -11,7 +11,10 @@ def dev_bf16(a):
 
 def build_module(case, fp32_out=True):
     m = hicom_amd.build_vision_projector(case.cfg)
-    missing, unexpected = m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd.items()}, strict=True)
+    missing, unexpected = m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd.items()}, strict=False)
+    # (a clip-scale projector also owns `*_logit_scale` / `*_logit_bias`, reference projector.py:655-670: the synthetic state dicts do
+    # not carry them, the tests give them through set_clip_logits())
+    assert not unexpected and all("_logit_" in k for k in missing), (missing, unexpected)
     m = m.to(torch.bfloat16).cuda().eval()
     m.return_fp32 = fp32_out
     for sub in (m.local_compressor, m.global_compressor):

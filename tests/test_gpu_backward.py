@@ -93,7 +93,7 @@ def test_unsupported_recipes_and_input_grads_refuse():
     case = cases.build_case("G8_clip_scale")
     case.cfg.use_clip_scale = "local,global"
     m = hicom_amd.build_vision_projector(case.cfg)
-    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd.items()}, strict=True)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd.items()}, strict=False)     # (the four logit parameters: set below)
     m = m.to(torch.bfloat16).cuda().train()
     m.set_clip_logits(local=case.logit["local"], glob=case.logit["glob"])
     with pytest.raises(NotImplementedError):

@@ -76,25 +76,43 @@ def test_clip_scale_global_matches_golden(golden, name):
 
 def test_use_clip_scale_config_constructs_and_runs(golden):
     """A projector configured with use_clip_scale='local,global' constructs (the reference reads the logits from the SigLIP
-    checkpoint there), refuses to run before set_clip_logits(), and then reproduces G8's local and global vectors through
-    HIComProjector.forward."""
+    checkpoint there and keeps them as PARAMETERS `local_logit_scale` ... of the projector, reference projector.py:655-670), refuses to
+    run while they are unset, and reproduces G8's local and global vectors through HIComProjector.forward -- with the logits given by
+    set_clip_logits() and with the logits arriving through load_state_dict() of a checkpoint that carries them (round 5: the
+    state-dict schema of a clip-scale projector equals the reference's)."""
     import hicom_amd
     case = cases.build_case("G8_clip_scale")
     case.cfg.use_clip_scale = "local,global"
+    sd = {k: torch.from_numpy(v.copy()) for k, v in case.sd.items()}
     m = hicom_amd.build_vision_projector(case.cfg)
-    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd.items()}, strict=True)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert sorted(missing) == ["global_logit_bias", "global_logit_scale", "local_logit_bias", "local_logit_scale"] and not unexpected
     m = m.to(torch.bfloat16).cuda().eval()
     m.return_fp32 = True
     ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+    loc, glo = golden["G8_clip_scale/local"], golden["G8_clip_scale/global"]
+    nl = loc.reshape(-1, loc.shape[-1]).shape[0]
     with torch.no_grad():
         with pytest.raises(RuntimeError):
             m(ff, fe, g, case.modal, None)
         m.set_clip_logits(local=case.logit["local"], glob=case.logit["glob"])
         out = m(ff, fe, g, case.modal, None).float().cpu().numpy()
-    loc, glo = golden["G8_clip_scale/local"], golden["G8_clip_scale/global"]
-    nl = loc.reshape(-1, loc.shape[-1]).shape[0]
     assert out.shape[0] == nl + glo.shape[0]
     assert np.abs(out[:nl] - loc.reshape(nl, -1)).max() <= TOL and np.abs(out[nl:] - glo).max() <= TOL
+    # the reference's checkpoint format: the four logits are entries of the state dict
+    full = {k: v.float().cpu() for k, v in m.state_dict().items()}
+    assert float(full["local_logit_scale"]) == case.logit["local"][0] and float(full["global_logit_bias"]) == case.logit["glob"][1]
+    m2 = hicom_amd.build_vision_projector(case.cfg)
+    m2.load_state_dict(full, strict=True)
+    m2 = m2.to(torch.bfloat16).cuda().eval()
+    m2.return_fp32 = True
+    with torch.no_grad():
+        out2 = m2(ff, fe, g, case.modal, None).float().cpu().numpy()
+        assert np.array_equal(out2, out)
+        # an in-place change of a logit parameter is seen by the next forward (the plans bake the floats in)
+        m2.local_logit_scale.fill_(0.5)
+        out3 = m2(ff, fe, g, case.modal, None).float().cpu().numpy()
+    assert np.abs(out3[:nl] - out[:nl]).max() > 1e-3 and np.array_equal(out3[nl:], out[nl:])
 
 
 @pytest.mark.parametrize("name", ["G3b_direct_T5_raises", "G4c_image_T2_raises"])
