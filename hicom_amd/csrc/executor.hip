@@ -171,6 +171,16 @@ struct HtDump {
     } while (0)
 #endif
 
+// HICOM_SHARD_TAIL=0: the frame-sharded step in round 4's form (merge on the comm stream, five small launches in FINISH): A/B switch
+bool shard_tail_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("HICOM_SHARD_TAIL");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 int check_args(const hicom_compressor_args& a) {
     HICOM_REQUIRE(a.has_local || a.has_global, HICOM_EINVAL, "compressor: nothing to do");
     HICOM_REQUIRE(a.ff && a.out && a.ws, HICOM_EINVAL, "compressor: NULL pointer");
@@ -315,16 +325,45 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         const bool prep1 = a.nq == 1 && a.E % 128 == 0 && a.E <= 1536 && a.E / a.nh <= 128;
         const bool tail5 = single && prep1 && a.gc0;       // the global tail folded over out_proj (gc0): one dependent stage fewer
         const bool ro2_aux = tail5 && a.hidden <= 1536;    // ... and its last layer inside GEMM 2's launch (aux GEMV: K <= 1536)
+        // Frame-sharded release step in the four-launch form (round 5): the shard's state (M, L, ACC) comes out of the merge ROLE of
+        // GEMM 1's launch (no merge launch on the comm stream, no v_proj here), r0 travels to the FINISH phase through r0_buf.
+        const bool shard4 = f16 && merge_on_next && !do_finish && !solo && prep1 && a.gc0 && a.hidden <= 1536 && a.r0_buf && a.local_out &&
+                            w.nparts <= 256 && a.E / a.nh <= 128 && shard_tail_enabled();
         if (prep1)
             CHK(hicom_query_prep_fwd(a.gq, a.lq, a.wq, a.bq, a.wk, a.kpe, a.nh, a.E, a.P, qscale, ws + w.qhi, ws + w.qlo, F(w.pos_a), a.P,
-                                     w.R, tail5 ? a.gw0 : nullptr, a.gb0, a.bo, a.hidden, F(w.r0), ws + w.prep_state, sm));
+                                     w.R, (tail5 || shard4) ? a.gw0 : nullptr, a.gb0, a.bo, a.hidden, shard4 ? a.r0_buf : F(w.r0), ws + w.prep_state, sm));
         else CHK(query_prep(sm, true));
         if (fold_ev && !merge_on_next && !single) hicom_host::set_stop_event(a.ev_fork);      // "record ev_fork" rides on the launch
         CHK(hicom_fused_stream_fwd(a.ff, a.fe ? a.fe : a.ff, a.local_logits, a.T, a.H, a.W, a.E, a.at.k, a.ay.k, ws + w.qhi, ws + w.qlo,
                                    w.R, a.l_scale, a.l_bias, a.pe ? F(w.pos_a) : nullptr, a.P, a.pe ? a.pe_hi : nullptr, a.pe ? a.pe_lo : nullptr, a.t_index0, a.y_index0,
                                    a.x_index0, F(w.part_m), F(w.part_l), F(w.part_acc),
                                    w.nparts, nullptr, f16 ? nullptr : ws + w.ctx_hi, f16 ? nullptr : ws + w.ctx_lo, f16 ? ws + w.ctx_hi : nullptr,
-                                   single ? ws + w.o_fix : nullptr, single ? (int64_t)a.E * 8 : 0, single ? ws + w.part_acc : nullptr, sm));
+                                   single ? ws + w.o_fix : nullptr, single ? (int64_t)a.E * 8 : 0, (single || shard4) ? ws + w.part_acc : nullptr, sm));
+        if (shard4) {
+            hicom_r16_role r1;
+            memset(&r1, 0, sizeof(r1));
+            r1.kind = HICOM_ROLE_MERGE_VPROJ;
+            r1.part_m = F(w.part_m); r1.part_l = F(w.part_l); r1.part_acc = ws + w.part_acc; r1.part_dt = HICOM_DT_F16;
+            r1.nparts = w.nparts; r1.rows = w.R; r1.rows_pad = w.rows_pad; r1.E = a.E;
+            r1.out_ml = ml_out; r1.out_ctx = acc_out; r1.ctx_unnorm = 1;                 // the shard STATE, straight into the send buffer
+            CHK(hicom_readout16_gemm_role_fwd(ws + w.ctx_hi, a.lw0_f16, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E, HICOM_ACT_GELU,
+                                              ws + w.hid_hi, nullptr, 0, 0, 0, 0, &r1, sm));
+            if (fold_ev && a.ev_done && !(a.nl_count > 0)) {
+                hicom_host::set_stop_event(a.ev_done);        // last main-stream launch of the STREAM-only call
+                done_folded = true;
+            }
+            CHK(hicom_readout16_gemm_fwd(ws + w.hid_hi, a.lw2_f16, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden, HICOM_ACT_NONE,
+                                         nullptr, a.local_out, a.out_dt, a.hidden, 0, 0, nullptr, sm));
+            if (a.ev_done && done_folded) {
+                if (a.stream_next)
+                    HICOM_REQUIRE(hipStreamWaitEvent((hipStream_t)a.stream_next, (hipEvent_t)a.ev_done, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
+            } else if (a.ev_done) {
+                HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_done, sm) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
+                if (a.stream_next)
+                    HICOM_REQUIRE(hipStreamWaitEvent((hipStream_t)a.stream_next, (hipEvent_t)a.ev_done, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
+            }
+            return HICOM_OK;
+        }
         // Round 5: FOUR launches.  The merge of the partial states is independent of the local readout, and the global tail behind it
         // is two dependent single-row layers: the merge rides as a ROLE on the CUs readout GEMM 1's tile grid leaves idle, the two layers
         // as a chain role (in-launch granule hand-off) under GEMM 2 -- the merge launch (5.2 us) is gone from the step.
@@ -519,7 +558,25 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
     }
 
     // ------------------------------------------------------------------ global chain, part 2
-    if (a.has_global && do_finish) {
+    const bool finish4 = a.has_global && do_finish && !do_stream && a.state_sets && a.nsets > 0 && a.nsets <= 256 && a.r0_buf && a.gc0 && a.nq == 1 &&
+                         a.hidden <= 1536 && a.hidden % 8 == 0 && a.E % 64 == 0 && a.E / a.nh <= 128 && a.E <= 1536 && a.lw0_f16 && shard_tail_enabled();
+    if (finish4) {
+        // FINISH of the four-launch sharded step: [clear the accumulators | merge of the gathered shard states + v_proj | chain launch:
+        // GELU(C o + r0) -> granule hand-off -> last readout layer -> the 32 global rows] -- three launches where the generic form
+        // below has five (combine, v_proj, out_proj, two readout layers)
+        HICOM_REQUIRE(a.state_set_stride >= (int64_t)(2 * w.R + (long)w.R * a.E), HICOM_EINVAL, "compressor: state set layout");
+        HICOM_REQUIRE(hipMemsetAsync(ws + w.o_fix, 0, (size_t)a.E * 8, sg) == hipSuccess, HICOM_ELAUNCH, "compressor: memset");
+        CHK(hicom_merge_vproj_sets_fwd((const float*)a.state_sets, a.state_set_stride, a.nsets, w.R, a.E, a.wv, (int64_t*)(ws + w.o_fix), nullptr, nullptr, sg));
+        hicom_r16_role r2;
+        memset(&r2, 0, sizeof(r2));
+        r2.kind = HICOM_ROLE_GEMV_CHAIN;
+        r2.gemv = hicom_aux_gemv{nullptr, 0, 0, a.bv, a.gc0, a.r0_buf, nullptr, a.hidden, a.E, HICOM_ACT_GELU, nullptr,
+                                 HICOM_DT_F32, HICOM_DT_F32, nullptr, 0, 0, 0, 0, (const int64_t*)(ws + w.o_fix)};
+        r2.gemv2 = hicom_aux_gemv{nullptr, 0, 0, nullptr, a.gw2, a.gb2, nullptr, a.hidden, a.hidden, HICOM_ACT_NONE, nullptr,
+                                  HICOM_DT_BF16, HICOM_DT_BF16, a.out, a.out_dt, a.n_global_rows, a.ldo, a.global_row0, nullptr};
+        r2.chain_state = ws + w.tail_state;
+        CHK(hicom_gemv_chain_fwd(&r2, sg));
+    } else if (a.has_global && do_finish) {
         const float* ctx = F(w.ctx_g);
         if (a.state_sets) {   // gathered (M, L, ACC) states of all shards: [nsets][2R + R*E]
             HICOM_REQUIRE(a.nsets > 0 && a.state_set_stride >= (int64_t)(2 * w.R + (long)w.R * a.E), HICOM_EINVAL,

@@ -604,6 +604,18 @@ extern "C" int hicom_merge_vproj_fixed_fwd(const float* part_m, const float* par
     return hicom_host::check_launch("merge_vproj_fixed");
 }
 
+extern "C" int hicom_merge_vproj_sets_fwd(const float* sets, int64_t set_stride, int32_t nsets, int32_t rows, int32_t E, const void* w_v, int64_t* o_fix,
+                                          float* out_ml, float* out_ctx, void* stream) {
+    HICOM_REQUIRE(sets && w_v && o_fix, HICOM_EINVAL, "merge_vproj_sets: NULL pointer");
+    HICOM_REQUIRE(nsets > 0 && nsets <= 256 && rows > 0 && E > 0 && E % 64 == 0 && E % rows == 0 && E / rows <= 128 && set_stride >= 2 * rows + (int64_t)rows * E &&
+                      set_stride % 2 == 0 && ((uintptr_t)sets % 8 == 0) && ((uintptr_t)o_fix % 8 == 0) && ((uintptr_t)w_v % 16 == 0),
+                  HICOM_EINVAL, "merge_vproj_sets: bad shape (nsets <= 256, head dim <= 128, E %% 64, 8-byte aligned sets)");
+    MergeVprojFixParams p{sets, sets + 1, sets + 2 * rows, nsets, rows, E, E / rows, (const uint16_t*)w_v, (long long*)o_fix, out_ml, out_ctx};
+    p.ml_part = set_stride; p.ml_row = 2; p.acc_part = set_stride; p.acc_row = E;
+    HICOM_LAUNCH((merge_vproj_fixed_kernel<64, false>), dim3((unsigned)(E / 64), (unsigned)rows), dim3(256), 0, (hipStream_t)stream, p);
+    return hicom_host::check_launch("merge_vproj_sets");
+}
+
 extern "C" int hicom_merge_vproj_fwd(const float* part_m, const float* part_l, const float* part_acc, int32_t nparts,
                                      int32_t rows, int32_t rows_pad, int32_t E, const void* w_v, float* po,
                                      float* out_ml, float* out_ctx, void* stream) {

@@ -34,7 +34,11 @@ struct MergeVprojFixParams {
     const uint16_t* wv;     // bf16 [E, E]
     long long* o_fix;       // [E] fixed-point accumulators (zero on entry)
     float* out_ml;          // [R][2] or NULL
-    float* out_ctx;         // [R][E] normalised, or NULL
+    float* out_ctx;         // [R][E] normalised (or, ctx_unnorm: the un-normalised accumulator relative to M), or NULL
+    // layout of the partials (elements): m / l of (part i, row h) at part_m[i * ml_part + h * ml_row]; accumulator row at
+    // part_acc[i * acc_part + h * acc_row].  Defaults (0): ml_part = rows_pad, ml_row = 1, acc_part = rows_pad * E, acc_row = E.
+    long ml_part, ml_row, acc_part, acc_row;
+    int ctx_unnorm;         // out_ctx receives sum_i w_i ACC_i (the shard STATE of the frame-sharded path) instead of the normalised context
 };
 
 template <int kMvSlab>
@@ -57,15 +61,16 @@ template <int kMvSlab, bool F16>      // channels per item (32 or 64); partials 
 __device__ __forceinline__ void merge_vproj_fixed_load(const MergeVprojFixParams& p, int slab, int h, MvItemRegs<kMvSlab, F16>& r) {
     using R = MvItemRegs<kMvSlab, F16>;
     const int tid = threadIdx.x;
-    // v_proj weights of this (head, slab) first: independent of everything else here
+    // v_proj weights of this (head, slab) first: independent of everything else here (wv NULL: merge only, no v_proj)
     const int j = tid >> 1, half = tid & 1;
 #pragma unroll
     for (int q = 0; q < R::WQ; ++q)
-        r.wreg[q] = (j < p.hd) ? *reinterpret_cast<const u32x4*>(p.wv + (long)(h * p.hd + j) * p.E + slab * kMvSlab + (kMvSlab / 2) * half + 8 * q) : u32x4{0, 0, 0, 0};
+        r.wreg[q] = (p.wv && j < p.hd) ? *reinterpret_cast<const u32x4*>(p.wv + (long)(h * p.hd + j) * p.E + slab * kMvSlab + (kMvSlab / 2) * half + 8 * q) : u32x4{0, 0, 0, 0};
     // raw partial rows: thread = (float4 column c4 of the slab, partial group pg of NG); all of a thread's <= NU loads in flight
     const int c4 = tid % R::NC4, pg = tid / R::NC4;
-    const long eoff = (long)h * p.E + slab * kMvSlab + 4 * c4;
-    const long pstride = (long)p.rows_pad * p.E;
+    const long eoff = (long)h * (p.acc_row ? p.acc_row : p.E) + slab * kMvSlab + 4 * c4;
+    const long pstride = p.acc_part ? p.acc_part : (long)p.rows_pad * p.E;
+    const long mlp = p.ml_part ? p.ml_part : p.rows_pad, mlr = p.ml_row ? p.ml_row : 1;
 #pragma unroll
     for (int u = 0; u < R::NU; ++u) {
         const int i = pg + R::NG * u;
@@ -73,12 +78,19 @@ __device__ __forceinline__ void merge_vproj_fixed_load(const MergeVprojFixParams
             r.v[u] = typename R::half4_t{0, 0, 0, 0};
             if (i < p.nparts) r.v[u] = *reinterpret_cast<const typename R::half4_t*>(reinterpret_cast<const _Float16*>(p.part_acc) + eoff + (long)i * pstride);
         } else {
-            r.v[u] = (i < p.nparts) ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.part_acc) + eoff + (long)i * pstride)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* src = reinterpret_cast<const float*>(p.part_acc) + eoff + (long)i * pstride;
+            if (i >= p.nparts) {
+                r.v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if (p.acc_row) {                        // shard states: the accumulators start 2 * rows floats into a set (8-byte aligned)
+                const float2 lo = *reinterpret_cast<const float2*>(src), hi = *reinterpret_cast<const float2*>(src + 2);
+                r.v[u] = make_float4(lo.x, lo.y, hi.x, hi.y);
+            } else {
+                r.v[u] = *reinterpret_cast<const float4*>(src);
+            }
         }
     }
-    r.pm = tid < p.nparts ? p.part_m[(long)tid * p.rows_pad + h] : -1.0e30f;       // nparts <= 256 (host-checked)
-    r.pl = tid < p.nparts ? p.part_l[(long)tid * p.rows_pad + h] : 0.f;
+    r.pm = tid < p.nparts ? p.part_m[(long)tid * mlp + h * mlr] : -1.0e30f;       // nparts <= 256 (host-checked)
+    r.pl = tid < p.nparts ? p.part_l[(long)tid * mlp + h * mlr] : 0.f;
 }
 
 template <int kMvSlab, bool F16>
@@ -114,13 +126,14 @@ __device__ __forceinline__ void merge_vproj_fixed_compute(const MergeVprojFixPar
         for (int g = 0; g < R::NG; ++g) sum += cpart[g * kMvSlab + tid];
         const float val = sum / L;
         cx[tid] = val;
-        if (p.out_ctx) p.out_ctx[(long)h * p.E + slab * kMvSlab + tid] = val;
+        if (p.out_ctx) p.out_ctx[(long)h * p.E + slab * kMvSlab + tid] = p.ctx_unnorm ? sum : val;
     }
     if (tid == 0 && slab == 0 && p.out_ml) {
         p.out_ml[2 * h] = M;
         p.out_ml[2 * h + 1] = L;
     }
     __syncthreads();
+    if (!p.wv) return;                                  // (merge only: the shard state of the frame-sharded path)
     // partial v_proj: thread (j, half) dots its half of the slab with weight row h*hd + j
     float dot = 0.f;
     if (j < p.hd) {

@@ -875,9 +875,12 @@ static int readout16_launch(const void* a, const void* w, const void* b, int32_t
                             int32_t M, int32_t N, int32_t K, int32_t act, void* out_f16,
                             void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group,
                             const hicom_r16_role* role, void* stream) {
-    HICOM_REQUIRE(a && w, HICOM_EINVAL, "readout16_gemm: NULL pointer");
-    HICOM_REQUIRE(out_f16 || y, HICOM_EINVAL, "readout16_gemm: no output");
-    HICOM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, HICOM_EINVAL, "readout16_gemm: bad shape M=%d N=%d K=%d (K %% 64)", M, N, K);
+    const bool role_only = !a && !w && M == 0;                    // (hicom_gemv_chain_fwd: no tile grid, every workgroup runs the role)
+    if (!role_only) {
+        HICOM_REQUIRE(a && w, HICOM_EINVAL, "readout16_gemm: NULL pointer");
+        HICOM_REQUIRE(out_f16 || y, HICOM_EINVAL, "readout16_gemm: no output");
+        HICOM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, HICOM_EINVAL, "readout16_gemm: bad shape M=%d N=%d K=%d (K %% 64)", M, N, K);
+    }
     HICOM_REQUIRE(!y || (ldy >= N && row0 >= 0 && nl_group >= 0), HICOM_EINVAL, "readout16_gemm: bad output layout");
     HICOM_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)w % 16 == 0) && M < (1 << 30), HICOM_EINVAL, "readout16_gemm: alignment");
     const bool vec = N % 4 == 0 && (!out_f16 || ((uintptr_t)out_f16 % 8 == 0)) && (!y || (ldy % 4 == 0 && (uintptr_t)y % 16 == 0));
@@ -890,7 +893,7 @@ static int readout16_launch(const void* a, const void* w, const void* b, int32_t
         p.line16 = (N % 8 == 0 && ((out_f16 && !y && (uintptr_t)out_f16 % 16 == 0) || (!out_f16 && y16 && (uintptr_t)y % 16 == 0 && ldy % 8 == 0))) ? 1 : 0;
     }
     const int nbx = (N + kRN - 1) / kRN, nby = (M + kRM - 1) / kRM;
-    p.n_gemm = 8 * ((nbx * nby + 7) / 8);
+    p.n_gemm = role_only ? 0 : 8 * ((nbx * nby + 7) / 8);
     int n_aux = 0;
     const AuxGemv none{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, 0, 0, 0, nullptr};
     p.aux = none;
@@ -905,8 +908,8 @@ static int readout16_launch(const void* a, const void* w, const void* b, int32_t
                        aux->rows_dst, aux->rows_dt == HICOM_DT_F32, aux->rows_dst ? aux->rows_reps : 0, (long)aux->rows_ld, (long)aux->rows_row0,
                        (const long long*)aux->x_fixed};
     };
-    auto check_gemv = [](const hicom_aux_gemv* aux, bool needs_x) -> int {
-        HICOM_REQUIRE(aux->w && (aux->y || aux->rows_dst) && aux->N > 0 && aux->K > 0 && aux->K % 8 == 0 && aux->K <= 1536 && ((uintptr_t)aux->w % 16 == 0), HICOM_EINVAL,
+    auto check_gemv = [](const hicom_aux_gemv* aux, bool needs_x, bool needs_out = true) -> int {
+        HICOM_REQUIRE(aux->w && (!needs_out || aux->y || aux->rows_dst) && aux->N > 0 && aux->K > 0 && aux->K % 8 == 0 && aux->K <= 1536 && ((uintptr_t)aux->w % 16 == 0), HICOM_EINVAL,
                       "readout16_gemm: aux GEMV arguments");
         if (aux->x_fixed) HICOM_REQUIRE((uintptr_t)aux->x_fixed % 8 == 0, HICOM_EINVAL, "readout16_gemm: aux x_fixed alignment");
         else if (needs_x) HICOM_REQUIRE(aux->xs && aux->x_parts > 0 && aux->x_stride % 4 == 0 && ((uintptr_t)aux->xs % 16 == 0) && (long)aux->x_parts * aux->K <= 28 * 1024 &&
@@ -920,7 +923,7 @@ static int readout16_launch(const void* a, const void* w, const void* b, int32_t
         p.aux = conv(&role->gemv);
         p.role = HICOM_ROLE_GEMV;
     } else if (kind == HICOM_ROLE_GEMV_CHAIN) {
-        if (int rc = check_gemv(&role->gemv, true)) return rc;
+        if (int rc = check_gemv(&role->gemv, true, false)) return rc;          // (the first layer's result travels as granules: y optional)
         if (int rc = check_gemv(&role->gemv2, false)) return rc;
         HICOM_REQUIRE(role->gemv.x_fixed && role->gemv2.K == role->gemv.N && role->gemv2.w_dt == HICOM_DT_BF16 && role->chain_state &&
                           (uintptr_t)role->chain_state % 16 == 0, HICOM_EINVAL,
@@ -932,13 +935,15 @@ static int readout16_launch(const void* a, const void* w, const void* b, int32_t
         p.chain_state = (unsigned*)role->chain_state;
         p.role = HICOM_ROLE_GEMV_CHAIN;
     } else if (kind == HICOM_ROLE_MERGE_VPROJ) {
-        HICOM_REQUIRE(role->part_m && role->part_l && role->part_acc && role->w_v && role->o_fix, HICOM_EINVAL, "readout16_gemm: merge role: NULL pointer");
+        HICOM_REQUIRE(role->part_m && role->part_l && role->part_acc && (!role->w_v == !role->o_fix) && (role->w_v || (role->out_ml && role->out_ctx)), HICOM_EINVAL,
+                      "readout16_gemm: merge role: NULL pointer (w_v and o_fix go together; without them out_ml and out_ctx are the result)");
         HICOM_REQUIRE(role->part_dt == HICOM_DT_F16 && role->nparts > 0 && role->nparts <= 256 && role->rows > 0 && role->rows <= role->rows_pad &&
                           role->E > 0 && role->E % 64 == 0 && role->E % role->rows == 0 && role->E / role->rows <= 128 &&
                           ((uintptr_t)role->o_fix % 8 == 0) && ((uintptr_t)role->w_v % 16 == 0) && ((uintptr_t)role->part_acc % 16 == 0),
                       HICOM_EINVAL, "readout16_gemm: merge role: fp16 partial contexts, nparts <= 256, head dim <= 128, E %% 64, alignment");
         p.mv = MergeVprojFixParams{role->part_m, role->part_l, role->part_acc, role->nparts, role->rows_pad, role->E, role->E / role->rows,
                                    (const uint16_t*)role->w_v, (long long*)role->o_fix, role->out_ml, role->out_ctx};
+        p.mv.ctx_unnorm = role->ctx_unnorm ? 1 : 0;
         p.role = HICOM_ROLE_MERGE_VPROJ;
     } else {
         HICOM_REQUIRE(kind == HICOM_ROLE_NONE || kind == HICOM_ROLE_GEMV, HICOM_EINVAL, "readout16_gemm: role kind %d", kind);
@@ -953,6 +958,7 @@ static int readout16_launch(const void* a, const void* w, const void* b, int32_t
         // the two-layer chain is bound by the bytes a role CU pulls (4.1 + 1.6 MB of weights beside the streaming tiles): every CU the
         // tile grid leaves free takes a share (the four tile slots beyond the 196 tiles exit at once)
         if (p.role == HICOM_ROLE_GEMV_CHAIN && 256 - p.n_gemm >= 16) n_aux = 256 - p.n_gemm < 72 ? 256 - p.n_gemm : 72;
+        if (role_only) n_aux = 64;             // (alone on the chip: one workgroup per four CUs' worth of weights is plenty; a fixed count per state block)
         if (p.role == HICOM_ROLE_MERGE_VPROJ) {
             // every item of a role workgroup in flight at once: ceil(items / kMvRoleItems) workgroups (162 items -> 54), never more than
             // the CUs the tile grid leaves free (one workgroup per CU: the launch asks for 160 KB of LDS)
@@ -1002,5 +1008,10 @@ extern "C" int hicom_debug_r16_trace(void* dst, int64_t bytes) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(hicom::g_r16_trace), (size_t)bytes) == hipSuccess ? HICOM_OK : HICOM_ELAUNCH;
 }
 #endif
+
+extern "C" int hicom_gemv_chain_fwd(const hicom_r16_role* role, void* stream) {
+    HICOM_REQUIRE(role && role->kind == HICOM_ROLE_GEMV_CHAIN, HICOM_EINVAL, "gemv_chain: a HICOM_ROLE_GEMV_CHAIN role");
+    return readout16_launch(nullptr, nullptr, nullptr, 0, 0, 64, 64, HICOM_ACT_NONE, nullptr, nullptr, 0, 0, 0, 0, role, stream);
+}
 
 extern "C" int64_t hicom_r16_chain_state_bytes(int32_t n_mid) { return n_mid > 0 ? (int64_t)n_mid * 8 + kChainStateHead : HICOM_EINVAL; }

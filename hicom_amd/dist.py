@@ -135,7 +135,7 @@ def exchange(state: torch.Tensor, local_tokens: torch.Tensor, group=None):
 class _ShardSet:
     """One set of exchange buffers + argument blocks + workspaces (two sets alternate so that the all-gather of step i
     can still be reading its send buffer while step i+1 streams into the other one)."""
-    __slots__ = ("mine", "everyone", "a_stream", "a_finish", "ws_stream", "ws_finish", "ev_stream", "ev_tok", "out", "fused")
+    __slots__ = ("mine", "everyone", "a_stream", "a_finish", "ws_stream", "ws_finish", "ev_stream", "ev_tok", "out", "fused", "r0")
 
 
 class _ShardPlan:
@@ -233,6 +233,12 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
         # token block into the packed output, record ev_tok
         st.a_stream.ev_done, st.a_stream.stream_next = st.ev_stream.cuda_event, plan.comm.cuda_stream
         st.fused = nv.compressor_is_fused(st.a_stream)
+        st.r0 = None
+        if st.fused:
+            # four-launch form of the sharded step (executor.hip: shard4 / finish4): r0 travels from the STREAM phase's query prep to the
+            # FINISH phase's chain launch through this buffer (their workspaces are separate)
+            st.r0 = torch.empty(hidden, dtype=torch.float32, device=dev)
+            st.a_stream.r0_buf = st.a_finish.r0_buf = st.r0.data_ptr()
         if st.fused:
             # release recipe: no side stream -- the merge of the partials runs on the comm stream, in front of the
             # all-gather (the fork / join / ev_merge event traffic was ~17 us of host time on a host-bound step)

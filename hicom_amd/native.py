@@ -35,7 +35,8 @@ EXPORTS = (
     "hicom_small_mha_scaled_fwd", "hicom_merge_vproj_fixed_fwd", "hicom_dense16_tn_fwd", "hicom_dense16_tn_splits",
     "hicom_local_attn_adapt_bwd", "hicom_adapt_dy_fwd", "hicom_gelu_split_fwd", "hicom_gelu_bwd_fwd", "hicom_colsum_fwd",
     "hicom_global_stream_marg_fwd", "hicom_global_stream_marg_width", "hicom_global_stream_has_marg", "hicom_global_merge_marg_fwd",
-    "hicom_act_rows_fwd", "hicom_act_bwd_rows_fwd", "hicom_readout16_gemm_role_fwd", "hicom_r16_chain_state_bytes", "hicom_dense16_gemm_pair_fwd",
+    "hicom_act_rows_fwd", "hicom_act_bwd_rows_fwd", "hicom_readout16_gemm_role_fwd", "hicom_r16_chain_state_bytes", "hicom_dense16_gemm_pair_fwd", "hicom_gemv_chain_fwd",
+    "hicom_merge_vproj_sets_fwd",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -63,7 +64,7 @@ class R16Role(C.Structure):
     _fields_ = [("kind", C.c_int32), ("gemv", AuxGemv), ("gemv2", AuxGemv), ("chain_state", C.c_void_p),
                 ("part_m", C.c_void_p), ("part_l", C.c_void_p), ("part_acc", C.c_void_p), ("part_dt", C.c_int32), ("nparts", C.c_int32),
                 ("rows", C.c_int32), ("rows_pad", C.c_int32), ("E", C.c_int32), ("w_v", C.c_void_p), ("o_fix", C.c_void_p),
-                ("out_ml", C.c_void_p), ("out_ctx", C.c_void_p)]
+                ("out_ml", C.c_void_p), ("out_ctx", C.c_void_p), ("ctx_unnorm", C.c_int32)]
 
 
 ROLE_NONE, ROLE_GEMV, ROLE_MERGE_VPROJ, ROLE_GEMV_CHAIN = 0, 1, 2, 3
@@ -105,6 +106,7 @@ class CompressorArgs(C.Structure):
         ("ev_done", C.c_void_p), ("stream_next", C.c_void_p),
         ("gc0", C.c_void_p), ("local_logits", C.c_void_p), ("reuse_queries", C.c_int32),
         ("ak", Adaptor), ("av", Adaptor), ("adapt_alpha_dt", C.c_int32), ("adapt_eps", C.c_float),
+        ("r0_buf", C.c_void_p),
     ]
 
 
@@ -152,6 +154,8 @@ def lib() -> C.CDLL:
     L.hicom_readout16_gemm_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i64, i64, i32, C.POINTER(AuxGemv), vp]
     L.hicom_readout16_gemm_role_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i64, i64, i32, C.POINTER(R16Role), vp]
     L.hicom_r16_chain_state_bytes.argtypes = [i32]
+    L.hicom_gemv_chain_fwd.argtypes = [C.POINTER(R16Role), vp]
+    L.hicom_merge_vproj_sets_fwd.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp]
     L.hicom_r16_chain_state_bytes.restype = i64
     L.hicom_to_f16_fwd.argtypes = [vp, i32, vp, i64, vp]
     L.hicom_splice_rows_fwd.argtypes = [vp, i64, i32, vp, vp]
@@ -798,13 +802,28 @@ def readout16_gemm(a16, w16, b, act=ACT_NONE, out_f16=None, y=None, row0=0, nl_g
         pc = merge["part_ctx16"]
         role.part_m, role.part_l, role.part_acc, role.part_dt = merge["part_m"].data_ptr(), merge["part_l"].data_ptr(), pc.data_ptr(), DT_F16
         role.nparts, role.rows_pad, role.E, role.rows = pc.shape[0], pc.shape[1], pc.shape[2], merge["rows"]
-        role.w_v, role.o_fix = merge["w_v"].data_ptr(), merge["o_fix"].data_ptr()
+        role.w_v, role.o_fix = _ptr(merge.get("w_v")), _ptr(merge.get("o_fix"))
         role.out_ml, role.out_ctx = _ptr(merge.get("out_ml")), _ptr(merge.get("out_ctx"))
+        role.ctx_unnorm = int(bool(merge.get("unnorm", False)))
     else:
         a1, a2, state = chain
         role.kind = ROLE_GEMV_CHAIN
         role.gemv, role.gemv2, role.chain_state = _aux_gemv(a1), _aux_gemv(a2), state.data_ptr()
     _check(lib().hicom_readout16_gemm_role_fwd(*args, C.byref(role), _stream()), "hicom_readout16_gemm_role_fwd")
+
+
+def gemv_chain(a1, a2, state):
+    """The two-layer GEMV chain as a launch of its own (hicom_gemv_chain_fwd): see readout16_gemm(chain=)."""
+    role = R16Role()
+    role.kind = ROLE_GEMV_CHAIN
+    role.gemv, role.gemv2, role.chain_state = _aux_gemv(a1), _aux_gemv(a2), state.data_ptr()
+    _check(lib().hicom_gemv_chain_fwd(C.byref(role), _stream()), "hicom_gemv_chain_fwd")
+
+
+def merge_vproj_sets(sets, rows, E, w_v, o_fix, out_ml=None, out_ctx=None):
+    """merge + v_proj over gathered shard states `sets` f32 [nsets, stride >= 2 rows + rows * E] (hicom_merge_vproj_sets_fwd)."""
+    _check(lib().hicom_merge_vproj_sets_fwd(_ptr(sets), sets.shape[1], sets.shape[0], rows, E, _ptr(w_v), _ptr(o_fix), _ptr(out_ml), _ptr(out_ctx),
+                                            _stream()), "hicom_merge_vproj_sets_fwd")
 
 
 def r16_chain_state(n_mid, device):

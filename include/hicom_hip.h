@@ -412,16 +412,24 @@ typedef struct hicom_r16_role {
     const float* part_l;
     const void* part_acc;
     int32_t part_dt, nparts, rows, rows_pad, E;
-    const void* w_v;
+    const void* w_v;           /* NULL (with o_fix NULL): merge only, no v_proj -- the shard state of the frame-sharded path */
     int64_t* o_fix;
     float* out_ml;
     float* out_ctx;
+    int32_t ctx_unnorm;        /* out_ctx receives the un-normalised accumulator sum_i e^(m_i - M) ACC_i (with out_ml = (M, L): a shard STATE) */
 } hicom_r16_role;
 int hicom_readout16_gemm_role_fwd(const void* a, const void* w, const void* b, int32_t b_dt,
                                   int32_t M, int32_t N, int32_t K, int32_t act, void* out_f16,
                                   void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group,
                                   const hicom_r16_role* role, void* stream);
 int64_t hicom_r16_chain_state_bytes(int32_t n_mid);
+/* The GEMV chain as a launch of its own (no tile grid): role.kind must be HICOM_ROLE_GEMV_CHAIN.  The FINISH phase of the frame-sharded
+ * step: GELU(C o + r0) and the last global readout layer behind the merge of the gathered shard states. */
+int hicom_gemv_chain_fwd(const hicom_r16_role* role, void* stream);
+/* hicom_merge_vproj_fixed_fwd over shard STATES as hicom_compressor_fwd's STREAM phase leaves them: `nsets` sets, `set_stride` floats apart,
+ * each [(M, L) x rows | ACC rows x E] with un-normalised f32 accumulators.  o_fix as above (zero on entry). */
+int hicom_merge_vproj_sets_fwd(const float* sets, int64_t set_stride, int32_t nsets, int32_t rows, int32_t E, const void* w_v, int64_t* o_fix,
+                               float* out_ml, float* out_ctx, void* stream);
 /* dst fp16 [rows, ld_dst] = saturating cast of src (bf16 or f32) [rows, cols]; columns [cols, ld_dst) are zero-filled */
 int hicom_to_f16_fwd(const void* src, int32_t src_dt, void* dst, int64_t n, void* stream);
 int hicom_to_f16_padded_fwd(const void* src, int32_t src_dt, int64_t rows, int64_t cols, void* dst, int64_t ld_dst, void* stream);
@@ -676,6 +684,12 @@ typedef struct hicom_compressor_args {
     } ak, av;
     int32_t adapt_alpha_dt;
     float adapt_eps;
+    /* r0_buf (frame-sharded release recipe, may be NULL): f32 [hidden] in CALLER memory that carries r0 = G0 (b_o + g) + g_b0 from the
+     * STREAM phase (query prep writes it there) to the FINISH phase (the chain launch reads it), whose workspaces are separate.  With it
+     * (and gc0, one query row per head, hidden <= 1536) the sharded step takes the four-launch form: the shard's state (M, L, ACC)
+     * comes out of the merge ROLE of readout GEMM 1's launch, and FINISH is [memset | merge of the gathered states + v_proj |
+     * chain launch -> 32 rows | token placement]. */
+    float* r0_buf;
 } hicom_compressor_args;
 
 /* 1 when hicom_compressor_fwd takes the release-recipe (single streaming kernel) path for these arguments. */

@@ -108,3 +108,13 @@ for x in range(8):
         print("  XCC %d: %3d workgroups, exit p50 %.2f max %.2f" % (x, sel.sum(), np.percentile(en[sel], 50), en[sel].max()))
 late = np.argsort(en)[-8:]
 print("latest workgroups:", [(int(i), round(float(en[i]), 2), int(xcc[i])) for i in late])
+
+# is the per-XCC pattern stable from launch to launch?  five more launches (rotating nothing: the same inputs), per-XCC median exit time
+for rep in range(5):
+    run(); torch.cuda.synchronize()
+    assert L.hicom_debug_fused_trace(buf.ctypes.data, buf.nbytes) == 0
+    t2 = buf.reshape(1024, 3, 256)[:nparts].astype(np.int64)
+    r0, r1, xc = t2[:, 0, 250], t2[:, 0, 251], t2[:, 0, 252]
+    e2 = (r1 - r0.min()) / 100.0
+    print("launch %d: per-XCC median exit" % rep, " ".join("%d:%.1f" % (x, np.percentile(e2[xc == x], 50)) for x in range(8) if (xc == x).any()), " last %.1f" % e2.max(),
+          " blocks->xcc of blocks 0..7:", [int(xc[i]) for i in range(8)])
