@@ -938,3 +938,46 @@ def test_dense16_pair_launch_equals_two_launches(M, dt, act):
     if act == nv.ACT_GELU:
         want = torch.nn.functional.gelu(want)
     assert maxabs(out_k, want) <= 2e-2 * max(1.0, float(want.abs().max()))
+
+
+def test_merge_over_shard_states_and_chain_launch_alone():
+    """Round 5, FINISH phase of the frame-sharded step: hicom_merge_vproj_sets_fwd (the merge item over `world` gathered shard states
+    [(M, L) pairs | un-normalised ACC], strided) against the combine + per-head v_proj of float64 torch, and hicom_gemv_chain_fwd (the
+    two-layer chain as a launch of its own) fed from its fixed-point result."""
+    g = torch.Generator().manual_seed(77)
+    E, nh, world, hid = 1152, 9, 8, 896
+    hd = E // nh
+    stride = 2 * nh + nh * E + 6                      # (a packed send buffer is longer than the state: tokens follow)
+    stride += stride % 2
+    sets = torch.zeros(world, stride)
+    M = torch.randn(world, nh, generator=g) * 3
+    L = torch.rand(world, nh, generator=g) + 0.5
+    ACC = torch.randn(world, nh, E, generator=g) * L[:, :, None]
+    sets[:, 0:2 * nh:2], sets[:, 1:2 * nh:2] = M, L
+    sets[:, 2 * nh:2 * nh + nh * E] = ACC.reshape(world, -1)
+    wv = bf(torch.randn(E, E, generator=g) * 0.02)
+    bv = bf(torch.randn(E, generator=g) * 0.02)
+    Mx = M.max(0).values
+    w = torch.exp(M - Mx)                                                         # [world, nh]
+    ctx = (w[:, :, None] * ACC).sum(0).double() / (w * L).sum(0).double()[:, None]    # [nh, E]
+    o_want = torch.cat([ctx[h] @ wv.cpu().double()[h * hd:(h + 1) * hd].t() for h in range(nh)])
+    ofx = torch.zeros(E, dtype=torch.int64, device="cuda")
+    ml, cx = torch.empty(nh, 2, device="cuda"), torch.empty(nh, E, device="cuda")
+    nv.merge_vproj_sets(sets.cuda(), nh, E, wv, ofx, ml, cx)
+    torch.cuda.synchronize()
+    assert maxabs(cx, ctx) <= 1e-5 and maxabs(ml[:, 0], Mx) == 0
+    assert maxabs(ofx.double() / 2.0 ** 36, o_want) <= 1e-5
+    c = (torch.randn(hid, E, generator=g) * 0.03).cuda()
+    r0 = torch.randn(hid, generator=g).cuda() * 0.1
+    w2 = bf(torch.randn(hid, hid, generator=g) * 0.03)
+    b2 = bf(torch.randn(hid, generator=g) * 0.02)
+    state = nv.r16_chain_state(hid, "cuda")
+    h_want = torch.nn.functional.gelu((ofx.cpu().double() / 2.0 ** 36 + bv.cpu().double()) @ c.cpu().double().t() + r0.cpu().double())
+    y_want = h_want @ w2.cpu().double().t() + b2.cpu().double()
+    for _ in range(3):
+        dst = torch.full((40, hid), 7.0, device="cuda")
+        nv.gemv_chain(dict(x_fixed=ofx, xb=bv, w=c, b=r0, act=nv.ACT_GELU), dict(w=w2, b=b2, act=nv.ACT_NONE, rows=(dst, 5, 32)), state)
+        torch.cuda.synchronize()
+        assert maxabs(dst[5:37], y_want.expand(32, hid)) <= 5e-5 * max(1.0, float(y_want.abs().max()))
+        assert bool((dst[:5] == 7).all()) and bool((dst[37:] == 7).all())
+    assert int(state[:16].view(torch.int32)[2]) == 0
