@@ -63,7 +63,7 @@ __device__ unsigned long long g_prep_trace[512 * 8];      // dev-only (tools/pre
 #endif
 
 constexpr int kQRows = 4;                // q_proj outputs per wave (72 workgroups at E = 1152: the whole grid stays <= 256 workgroups)
-constexpr int kRRows = 8;                // r0 outputs per wave
+constexpr int kRRows = 4;                // r0 outputs per wave (round 5: 8 made the 28 r0 workgroups -- 73 KB of cold weights each -- the LAST to leave the launch, tools/prep_trace.py)
 constexpr int kPrepCh = 3;               // 16-byte chunks per lane and row: K <= 1536
 
 __device__ __forceinline__ void prep_load_x(const uint16_t* g, const uint16_t* add, int K, int lane, float (&x)[kPrepCh][8]) {

@@ -30,7 +30,7 @@ with torch.no_grad():
         assert L.hicom_debug_prep_trace(buf.ctypes.data, buf.nbytes) == 0
         agg.append(buf.reshape(512, 8).astype(np.int64))
 tr = np.stack(agg)
-nq, nr, nf, npos = 72, 28, 81, 18
+nq, nr, nf, npos = 72, 56, 81, 18
 t0 = np.where(tr[:, :, 0] > 0, tr[:, :, 0], np.iinfo(np.int64).max).min(axis=1)[:, None]
 def show(name, x):
     print("  %-40s p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f us" % (name, *np.percentile(x, [10, 50, 90]), x.max()))
