@@ -32,7 +32,7 @@ namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct WsLayout {
-    size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, ctx16, hid16, ad_hid, ad_hid2, ad_ky, ad_vy, qp, qhi, qlo, pos_a, prep_state, tail_state, scores, part_m, part_l, part_acc, scratch, ml, acc,
+    size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, ctx16, hid16, ad_hid, ad_hid2, ad_ky, ad_vy, qp, qhi, qlo, pos_a, prep_state, tail_state, tail_sync, scores, part_m, part_l, part_acc, scratch, ml, acc,
         ctx_g, o, qres, pre, hid_g, tok, po, o_fix, r0, total;
     int nw, R, rows_pad, nparts, P;
     long N, score_stride;
@@ -85,6 +85,7 @@ WsLayout make_layout(const hicom_compressor_args& a) {
     w.pos_a = take((size_t)w.rows_pad * (a.P > 0 ? a.P : 1) * 4);
     w.prep_state = take(a.has_global ? (size_t)hicom_query_prep_state_bytes(a.E) : 0);   // (epoch word + granules: zero once)
     w.tail_state = take(a.has_global ? (size_t)hicom_r16_chain_state_bytes(a.hidden) : 0);  // (the GEMV chain inside readout GEMM 2's launch: zero once)
+    w.tail_sync = take(a.has_global && a.has_local ? (size_t)hicom_readout_tail_state_bytes() : 0);   // (counters of the fused tail launch: zero once)
     if (a.has_local) {
         w.ctx_local = take((size_t)w.nw * a.E * 4);          // fp32 form (two-kernel path) ...
         w.hid_local = take((size_t)w.nw * a.hidden * 4);
@@ -213,7 +214,7 @@ extern "C" int64_t hicom_compressor_workspace_bytes(const hicom_compressor_args*
 extern "C" int64_t hicom_compressor_zero_prefix_bytes(const hicom_compressor_args* a) {
     if (!a) return HICOM_EINVAL;
     const WsLayout w = make_layout(*a);
-    return (int64_t)(a->has_local ? w.ctx_local : w.qp);      // qhi | qlo | pos_a | prep_state
+    return (int64_t)(a->has_local ? w.ctx_local : w.qp);      // qhi | qlo | pos_a | prep_state | tail_state | tail_sync
 }
 
 extern "C" int hicom_compressor_is_fused(const hicom_compressor_args* a) {
@@ -371,9 +372,9 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         static int tail_env = -1;
         if (tail_env < 0) {
             const char* e = getenv("HICOM_TAIL_LAUNCHES");
-            tail_env = (e && e[0] == '5') ? 5 : 4;
+            tail_env = (e && e[0] == '5') ? 5 : (e && e[0] == '3') ? 3 : 4;
         }
-        const bool tail4 = single && tail5 && ro2_aux && tail_env == 4;
+        const bool tail4 = single && tail5 && ro2_aux && tail_env <= 4;
         if (single && tail4) {
             const int64_t* ofx = (const int64_t*)(ws + w.o_fix);
             hicom_r16_role r1;
@@ -382,8 +383,6 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
             r1.part_m = F(w.part_m); r1.part_l = F(w.part_l); r1.part_acc = ws + w.part_acc; r1.part_dt = HICOM_DT_F16;
             r1.nparts = w.nparts; r1.rows = w.R; r1.rows_pad = w.rows_pad; r1.E = a.E; r1.w_v = a.wv; r1.o_fix = (int64_t*)(ws + w.o_fix);
             r1.out_ml = F(w.ml); r1.out_ctx = F(w.ctx_g);
-            CHK(hicom_readout16_gemm_role_fwd(ws + w.ctx_hi, a.lw0_f16, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E, HICOM_ACT_GELU,
-                                              ws + w.hid_hi, nullptr, 0, 0, 0, 0, &r1, sm));
             hicom_r16_role r2;
             memset(&r2, 0, sizeof(r2));
             r2.kind = HICOM_ROLE_GEMV_CHAIN;
@@ -392,9 +391,21 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
             r2.gemv2 = hicom_aux_gemv{nullptr, 0, 0, nullptr, a.gw2, a.gb2, nullptr, a.hidden, a.hidden, HICOM_ACT_NONE, nullptr,
                                       HICOM_DT_BF16, HICOM_DT_BF16, a.out, a.out_dt, a.n_global_rows, a.ldo, a.global_row0, nullptr};
             r2.chain_state = ws + w.tail_state;
-            CHK(hicom_readout16_gemm_role_fwd(ws + w.hid_hi, a.lw2_f16, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden, HICOM_ACT_NONE,
-                                              nullptr, a.local_out ? a.local_out : a.out, a.out_dt, a.local_out ? a.hidden : a.ldo,
-                                              a.local_out ? 0 : a.local_row0, a.local_out ? 0 : a.nl_group, &r2, sm));
+            // HICOM_TAIL_LAUNCHES=3 (opt-in, measured SLOWER: 24.5 us against 12.0 + 11.6 and the gap between them): both GEMMs
+            // and both roles in one grid, the hidden plane handed over inside the launch row block by row block (readout16.hip:
+            // readout_tail_kernel).  The seam between the GEMMs costs what the kernel boundary cost, and the merge -> chain role, now one
+            // uninterrupted run of dependent round trips, ends last.
+            const hicom_r16_gemm g1{ws + w.ctx_hi, a.lw0_f16, a.lb0, HICOM_DT_BF16, (int32_t)w.nw, a.hidden, a.E, HICOM_ACT_GELU, ws + w.hid_hi, nullptr, 0, 0, 0, 0};
+            const hicom_r16_gemm g2{ws + w.hid_hi, a.lw2_f16, a.lb2, HICOM_DT_BF16, (int32_t)w.nw, a.hidden, a.hidden, HICOM_ACT_NONE, nullptr,
+                                    a.local_out ? a.local_out : a.out, a.out_dt, a.local_out ? (int64_t)a.hidden : a.ldo,
+                                    a.local_out ? 0 : a.local_row0, a.local_out ? 0 : a.nl_group};
+            int rc3 = tail_env == 3 ? hicom_readout_tail_fwd(&g1, &g2, &r1, &r2, ws + w.tail_sync, sm) : HICOM_EUNSUP;
+            if (rc3 == HICOM_EUNSUP) {
+                CHK(hicom_readout16_gemm_role_fwd(g1.a, g1.w, g1.b, g1.b_dt, g1.M, g1.N, g1.K, g1.act, g1.out_f16, nullptr, 0, 0, 0, 0, &r1, sm));
+                CHK(hicom_readout16_gemm_role_fwd(g2.a, g2.w, g2.b, g2.b_dt, g2.M, g2.N, g2.K, g2.act, nullptr, g2.y, g2.y_dt, g2.ldy, g2.row0, g2.nl_group, &r2, sm));
+            } else {
+                CHK(rc3);
+            }
         } else if (single) {
             // merge + v_proj with the slab sums taken inside the launch (fixed-point accumulators, cleared by the stream kernel):
             // GEMM 1's aux role reads ONE 9-KB vector instead of E/64 partial vectors (83 KB per workgroup)

@@ -264,8 +264,22 @@ __host__ __device__ inline ChainGeom chain_geom(int N1, int K1, bool w1f32, int 
     return g;
 }
 
-template <bool W1F32>
-__device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int an, char* lds) {
+// `mid`: work in front of the role's first use of x (the fused tail launch: the merge items that PRODUCE x and the wait for every role
+// workgroup's; it may use the first kChainVec + kChainBias + kChainOut bytes of `lds`).  With a gated mid the order is: mid's requests,
+// mid's work and arrival at the gate, THEN the weight rows (waves 1..3: wave 0 polls the gate, and a wave's requests return in order),
+// the gate, x with agent-scope loads.  A round trip beside ~200 streaming tile workgroups is 2-4 us, so the role is priced in dependent
+// round trips: the weight rows first made the merge -- the head of the chain -- wait for ~100 KB per CU that nothing needs before the
+// gate has passed (tools/tail3_trace.py: merge done at 12.7 us instead of 10.5).  Tried and dropped: accumulators that carry their own
+// completion count, polled by every role workgroup in place of the gate -- 62 k polling loads per round on the 72 lines the atomic
+// adds are working on: x complete at 24 us instead of 14.6.
+struct ChainNoMid {
+    __device__ __forceinline__ void pre() {}                                   // (the mid work's requests)
+    __device__ __forceinline__ void reduce() {}                                // (the mid work itself, up to this workgroup's arrival at the gate)
+    __device__ __forceinline__ bool wait() { return false; }                   // (the gate; returns whether x must be treated as lost)
+};
+template <bool W1F32, class Mid>
+__device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int an, char* lds, Mid& mid) {
+    constexpr bool kGated = !std::is_same<Mid, ChainNoMid>::value;
     const AuxGemv& g1 = p.aux;
     const AuxGemv& g2 = p.aux2;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -292,8 +306,10 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
     // placed the int64 -> float conversion of x -- and its wait -- in front of the bias and weight requests, and the bf16 bias branch
     // carried a vmcnt(0) of its own (tools/tail_trace.py: last request 4.5 us after entry).
     long long xf[6];                                                  // x from the fixed-point accumulators (K1 <= 1536 = 6 per thread)
+    if constexpr (!kGated) {
 #pragma unroll
-    for (int u = 0; u < 6; ++u) xf[u] = g1.x_fixed[min(tid + 256 * u, g1.K - 1)];
+        for (int u = 0; u < 6; ++u) xf[u] = g1.x_fixed[min(tid + 256 * u, g1.K - 1)];
+    }
     R16_TR(9);
     auto bias_raw = [&](const AuxGemv& g, int n) -> unsigned {
         n = n < g.N ? n : g.N - 1;
@@ -308,7 +324,8 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
         const long lo = (long)r_lo * rowbytes, bytes = (long)(r_hi - r_lo) * rowbytes, last = total_rows * rowbytes - 16;
         const int npieces = (int)((bytes + 1023) >> 10);
         int mine = 0;
-        for (int pi = wave; pi < npieces; pi += 4, ++mine) {
+        for (int pi = kGated ? wave - 1 : wave; pi < npieces; pi += kGated ? 3 : 4, ++mine) {
+            if (kGated && wave == 0) break;
             long off = lo + (long)pi * 1024 + lane * 16;
             off = off < last ? off : last;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(w) + off),
@@ -317,15 +334,26 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
         return mine;
     };
     R16_TR(10);
+    if constexpr (kGated) {
+        mid.pre();
+        mid.reduce();
+    }
     dma_rows(g1.w, cg.row1, g1.N, n_lo, min(n_hi, n_lo + cg.r1), w1l);
     R16_TR(11);
     dma_rows(g2.w, cg.row2, g2.N, m_lo, min(m_hi, m_lo + cg.r2), w2l);
     __builtin_amdgcn_sched_barrier(0);
     R16_TR(1);   // every load requested
+    bool xlost = false;
+    if constexpr (kGated) {
+        xlost = mid.wait();
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            xf[u] = (long long)__hip_atomic_load((r16_gu64*)(g1.x_fixed + min(tid + 256 * u, g1.K - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
         const int k = tid + 256 * u;
-        if (k < g1.K) xl[k] = (float)xf[u] * (1.0f / HICOM_FIXED_SCALE) + (g1.xb ? bf16_to_f32(g1.xb[k]) : 0.f);
+        if (k < g1.K) xl[k] = xlost ? __uint_as_float(0x7FC00000u) : (float)xf[u] * (1.0f / HICOM_FIXED_SCALE) + (g1.xb ? bf16_to_f32(g1.xb[k]) : 0.f);
     }
     bl1[tid] = g1.b ? __uint_as_float(g1.b_f32 ? b1raw : b1raw << 16) : 0.f;
     bl2[tid] = g2.b ? __uint_as_float(g2.b_f32 ? b2raw : b2raw << 16) : 0.f;
@@ -404,7 +432,12 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
             }
         }
     }
-    __syncthreads();                                  // every wave is done with x in xl
+    // every wave is done with x in xl: an LDS-only meeting.  __syncthreads() also drains vmcnt, i.e. waits for the acknowledgement of the
+    // granule stores just issued -- a round trip (2-4 us beside the tiles) that nothing here needs: the sweep's polls go out at once and
+    // return behind those acknowledgements anyway (a wave's requests complete in order)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     R16_TR(3);   // first layer done, granules stored
     // ---- sweep: wave w collects granules [w * q, (w + 1) * q) of h until every tag carries this launch's epoch ----
     {
@@ -480,6 +513,12 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
     if (tid == 0) __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template <bool W1F32>
+__device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int an, char* lds) {
+    ChainNoMid none;
+    gemv_chain_role<W1F32, ChainNoMid>(p, ai, an, lds, none);
+}
+
 // ---- MERGE_VPROJ role: the (head, 64-channel slab) items of hicom_merge_vproj_fixed_fwd dealt over the role workgroups ----
 __device__ __forceinline__ void merge_vproj_role(const R16Params& p, int ai, int an, char* lds) {
     const int nslab = p.mv.E / 64, rows = p.mv.E / p.mv.hd, items = nslab * rows;
@@ -504,46 +543,47 @@ __device__ __forceinline__ void r16_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int kRRing>
-__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void readout16_gemm_kernel(R16Params p) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];   // [kRRing][kRStage]
-    R16_TR(0);
-    if ((int)blockIdx.x >= p.n_gemm) {
-        const int ai = (int)blockIdx.x - p.n_gemm, an = (int)gridDim.x - p.n_gemm;
-        if (p.role == HICOM_ROLE_MERGE_VPROJ) {
-            merge_vproj_role(p, ai, an, lds);
-            R16_TR(7);
-            return;
-        }
-        if (p.role == HICOM_ROLE_GEMV_CHAIN) {
-            if (p.aux.w_f32) gemv_chain_role<true>(p, ai, an, lds);
-            else gemv_chain_role<false>(p, ai, an, lds);
-            R16_TR(7);
-            return;
-        }
-        if (p.aux.x_fixed) {
-            if (p.aux.w_f32) aux_gemv_role<true, true>(p.aux, ai, an, lds);
-            else aux_gemv_role<false, true>(p.aux, ai, an, lds);
-        } else {
-            if (p.aux.w_f32) aux_gemv_role<true, false>(p.aux, ai, an, lds);
-            else aux_gemv_role<false, false>(p.aux, ai, an, lds);
-        }
-        return;
-    }
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int r16 = lane & 15, kg = lane >> 4;
+
+enum { R16_PLAIN = 0, R16_PUBLISH = 1, R16_CONSUME = 2 };
+typedef __attribute__((address_space(1))) unsigned long long r16_sync64;
+// Counters of the fused tail launch (hicom_readout_tail_fwd), each on a 128-byte line of its own; all cumulative over launches:
+// a launch's epoch = arrivals / gridDim.x + 1 (every workgroup adds one arrival when it is done).
+struct TileSync {
+    unsigned long long* arrivals;     // [0] arrivals, [1] failed waits
+    unsigned long long* gate;         // the merge role's fan-in (one add per role workgroup)
+    unsigned long long* rowblk;       // [nby][16]: tiles of row block `by` published (one add per tile, `per_epoch` per launch)
+    unsigned long long* flags;        // [tiles]: (epoch << 1 | abandoned) once GEMM 2's tile has an owner or has been given up by it
+    int per_epoch;
+};
+
+// the workgroup -> tile map of the tile grid: ordinal of the tile in the blocked order below, or -1 (the grid is rounded up to 8 x slots)
+__device__ __forceinline__ int r16_tile_of_block(const R16Params& p, int vblock) {
     const int nbx = (p.N + kRN - 1) / kRN, nby = (p.M + kRM - 1) / kRM;
     // XCD-balanced order (speed only): workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md "Workgroup dispatch"); every
     // XCD gets a contiguous run of ~tiles/8 tiles in row-major tile order, i.e. ~2 row tiles whose A rows stay in ITS L2,
     // and -- the point -- the same number of busy CUs, so that the aux workgroups (dealt round-robin too) find a free CU
     // on their XCD at once instead of queueing behind a 10-us tile (measured: +6 us per launch with whole row tiles per XCD)
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = vblock & 7, slot = vblock >> 3;
     const int tiles = nbx * nby;
     const int t_lo = (tiles * xcd) >> 3, t_hi = (tiles * (xcd + 1)) >> 3;
-    if (slot >= t_hi - t_lo) return;
-    const int tile = t_lo + slot;
+    return slot >= t_hi - t_lo ? -1 : t_lo + slot;
+}
+
+// One 96 x 64 output tile of y = act(a . w^T + b) by one 256-thread workgroup (`tile` = r16_tile_of_block()).
+// MODE: R16_PLAIN; R16_PUBLISH = the fp16 plane leaves as write-through stores and the tile's row block counts it (the fused tail
+// launch: the plane is the next GEMM's A operand, read inside the same launch); R16_CONSUME = the A rows are such a plane: the W
+// stages of the prologue go out at entry, the A stages behind the row block's counter (`epoch` = this launch's).  A consumer that
+// `may_abandon` waits a BOUNDED time: if the row block is not complete by then it marks the tile abandoned and returns false (it
+// must not hold its CU: a publisher may still be waiting for one); otherwise it marks the tile owned.  Returns true when the tile is done.
+template <int kRRing, int MODE>
+__device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds, const TileSync sy, unsigned long long epoch = 0, bool may_abandon = false) {
+    constexpr int kTrOff = MODE == R16_CONSUME ? 8 : 0;      // (dev timeline: a consumer's stamps go to slots of their own)
+    (void)kTrOff;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int nbx = (p.N + kRN - 1) / kRN, nby = (p.M + kRM - 1) / kRM;
     // ... in a BLOCKED order: the left half of the tile columns row by row, then the right half -- an XCD's run of ~tiles/8 tiles is a
     // ~(3.5 rows x 7 columns) patch, so both its A row blocks and its W column blocks are shared by several of its CUs and cross
     // its L2 once (row-major runs shared the A rows 14 ways and the W columns hardly at all: every CU pulled its W panel from
@@ -583,12 +623,27 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         }
         dst_off[i] = pi * 1024;
     }
-    auto issue = [&](int s, int ring_slot) {
+    // (this wave's pieces 0..2 are A rows, 3..4 W rows: wave + 4 i < 12 <=> i < 3.)  A published plane (R16_CONSUME) is read with sc1
+    // loads: they bypass this CU's L1, the one cache a write-through store of another CU does not reach (MI355X_MICROARCH.md
+    // "inter-workgroup visibility": every store of the bytes sc1 and drained, every load of them sc1 -- no acquire needed)
+    constexpr int kAuxA = MODE == R16_CONSUME ? 16 : 0;
+    auto issue_a = [&](int s, int ring_slot) {
         char* base = lds + ring_slot * kRStage;
 #pragma unroll
-        for (int i = 0; i < kRPW; ++i)
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + 64 * s),
+                                             (__attribute__((address_space(3))) void*)(base + dst_off[i]), 16, 0, kAuxA);
+    };
+    auto issue_w = [&](int s, int ring_slot) {
+        char* base = lds + ring_slot * kRStage;
+#pragma unroll
+        for (int i = 3; i < kRPW; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + 64 * s),
                                              (__attribute__((address_space(3))) void*)(base + dst_off[i]), 16, 0, 0);
+    };
+    auto issue = [&](int s, int ring_slot) {
+        issue_a(s, ring_slot);
+        issue_w(s, ring_slot);
     };
     auto wait_stages = [&](int k) {      // at most k of this wave's stages still in flight
         if (k >= 6) r16_wait_vm<6 * kRPW>();
@@ -645,7 +700,46 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 
     // prologue: stages 0 .. kRRing-2 in flight, stage 0 landed, its fragments on the way
     const int npro = ns < kRRing - 1 ? ns : kRRing - 1;
-    for (int s = 0; s < npro; ++s) issue(s, s);
+    bool poisoned = false;
+    if constexpr (MODE == R16_CONSUME) {
+        // (host: ns >= kRRing + 6, so the prologue is full and the first six steps are steady ones)
+        r16_sync64* cnt = (r16_sync64*)(sy.rowblk + 16 * by);
+        const unsigned long long target = epoch * (unsigned long long)sy.per_epoch;
+        unsigned long long seen = 0;
+        if (tid == 0) seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (requested in FRONT of the W pieces: returns first)
+        for (int s = 0; s < kRRing - 1; ++s) issue_w(s, s);
+        unsigned* flag = reinterpret_cast<unsigned*>(lds + (kRRing - 1) * kRStage);   // (the ring's last slot: first written by step 0)
+        if (tid == 0) {
+            // an owner that may abandon waits ~100 us at most (every publisher of a healthy launch is done within ~2); a sweeper
+            // (every publisher has finished by the time it runs) waits like every other hand-off of the step
+            const unsigned limit = may_abandon ? 256u : (1u << 22);
+            unsigned spins = 0, failed = 0;
+            while (seen < target) {
+                if (++spins > limit) {
+                    failed = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (may_abandon)
+                __hip_atomic_store((r16_sync64*)(sy.flags + tile), (epoch << 1) | failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (failed)
+                __hip_atomic_fetch_add((r16_sync64*)sy.arrivals + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = failed;
+        }
+        __syncthreads();
+        poisoned = *flag != 0u;
+        R16_TR(6 + kTrOff);   // consumer: row block published
+        if (poisoned && may_abandon) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the W pieces land in LDS this workgroup is about to give back)
+            __syncthreads();
+            return false;
+        }
+        for (int s = 0; s < kRRing - 1; ++s) issue_a(s, s);
+    } else {
+        for (int s = 0; s < npro; ++s) issue(s, s);
+    }
     // the bias of this wave's columns, fetched now (one vector load per column block)
     uint2 braw[2] = {make_uint2(0, 0), make_uint2(0, 0)};
     float4 brawf[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
@@ -659,11 +753,12 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             else braw[j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.b) + nb);
         }
     }
-    if (npro == kRRing - 1) r16_wait_vm<(kRRing - 2) * kRPW>();
+    if constexpr (MODE == R16_CONSUME) r16_wait_vm<(kRRing - 2) * 3>();          // A pieces of stage 0 landed (every W piece is older)
+    else if (npro == kRRing - 1) r16_wait_vm<(kRRing - 2) * kRPW>();
     else wait_stages(npro - 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    R16_TR(1);   // tile: first stage landed
+    R16_TR(1 + kTrOff);   // tile: first stage landed
     Frags f0, f1;
     read(0, f0);
     land(f0);
@@ -693,6 +788,31 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     using Yes = std::integral_constant<bool, true>;
     using No = std::integral_constant<bool, false>;
     int s = 0;
+    if constexpr (MODE == R16_CONSUME) {
+        // the first kRRing - 3 steps wait on a prologue whose A pieces were issued LAST: behind stage s + 1's A pieces are the A pieces
+        // of prologue stages s + 2 .. kRRing - 2 (3 each) and the whole stages issued by steps 0 .. s - 1 (kRPW each)
+        auto early = [&](auto allow, int s_, const Frags& cur, Frags& nxt) {
+            r16_wait_vm<decltype(allow)::value>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue(s_ + kRRing - 1, slot_issue);
+            read(slot_next, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            land(nxt);
+            slot_next = slot_next + 1 == kRRing ? 0 : slot_next + 1;
+            slot_issue = slot_issue + 1 == kRRing ? 0 : slot_issue + 1;
+        };
+        static_assert(kRRing == 8, "the early-step waits are written out for an 8-stage ring");
+        early(std::integral_constant<int, 3 * 5 + kRPW * 0>{}, 0, f0, f1);
+        early(std::integral_constant<int, 3 * 4 + kRPW * 1>{}, 1, f1, f0);
+        early(std::integral_constant<int, 3 * 3 + kRPW * 2>{}, 2, f0, f1);
+        early(std::integral_constant<int, 3 * 2 + kRPW * 3>{}, 3, f1, f0);
+        early(std::integral_constant<int, 3 * 1 + kRPW * 4>{}, 4, f0, f1);
+        step(Yes{}, 5, f1, f0);
+        s = 6;
+    }
     for (; s + kRRing < ns; s += 2) {
         step(Yes{}, s, f0, f1);
         step(Yes{}, s + 1, f1, f0);
@@ -709,7 +829,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     }
     // MFMA results -> VALU reads (CDNA4 ISA §4.1 "XDL write VGPR -> VALU read": do not rely on hipcc's padding, see fused_ring.hip)
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-    R16_TR(2);   // tile: main loop done
+    R16_TR(2 + kTrOff);   // tile: main loop done
 
     // Row-line epilogue (one 16-bit output, whole 64-column tiles): the results go through the (idle) ring as a [96][64] 16-bit image
     // and leave as 16-byte stores, eight consecutive lanes writing one 128-byte line of an output row.  The straight form -- every lane
@@ -743,6 +863,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 for (int q = 0; q < 4; ++q) {
                     float v = acc[j][im][q] + bias[q];
                     if (p.act == HICOM_ACT_GELU) v = gelu_erf(v);
+                    if (MODE == R16_CONSUME && poisoned) v = __uint_as_float(0x7FC00000u);     // the row block never arrived: fail loudly
                     if (to_f16) {
                         const _Float16 hv = to_f16_sat(v);
                         h[q] = __builtin_bit_cast(uint16_t, hv);
@@ -760,16 +881,26 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             if (m < p.M) {
                 const u32x4 v = *reinterpret_cast<const u32x4*>(tl + row * TP + 8 * c8);
                 if (to_f16) {
-                    *reinterpret_cast<u32x4*>(p.o16 + (long)m * p.N + n0 + 8 * c8) = v;
+                    if constexpr (MODE == R16_PUBLISH)        // write-through: the bytes are at the memory side when the store is acknowledged
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p.o16 + (long)m * p.N + n0 + 8 * c8), "v"(v) : "memory");
+                    else
+                        *reinterpret_cast<u32x4*>(p.o16 + (long)m * p.N + n0 + 8 * c8) = v;
                 } else {
                     const long orow = p.row0 + m + (p.nl_group > 0 ? m / p.nl_group : 0);
                     *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.y) + orow * p.ldy + n0 + 8 * c8) = v;
                 }
             }
         }
-        R16_TR(5);   // tile: stores issued
-        return;
+        R16_TR(5 + kTrOff);   // tile: stores issued
+        if constexpr (MODE == R16_PUBLISH) {
+            // every storing wave drains its stores, the workgroup meets, ONE lane counts the tile in
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add((r16_sync64*)(sy.rowblk + 16 * by), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return true;
     }
+    if constexpr (MODE != R16_PLAIN) return true;          // (host: the fused tail launch admits row-line shapes only)
     // epilogue.  Transposed product: lane holds columns n .. n+3 (4 * kg + q) of row m = r16 of each block.
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -829,7 +960,172 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             }
         }
     }
-    R16_TR(5);   // tile: stores issued
+    R16_TR(5 + kTrOff);   // tile: stores issued
+    return true;
+}
+
+template <int kRRing>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void readout16_gemm_kernel(R16Params p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // [kRRing][kRStage]
+    R16_TR(0);
+    if ((int)blockIdx.x >= p.n_gemm) {
+        const int ai = (int)blockIdx.x - p.n_gemm, an = (int)gridDim.x - p.n_gemm;
+        if (p.role == HICOM_ROLE_MERGE_VPROJ) {
+            merge_vproj_role(p, ai, an, lds);
+            R16_TR(7);
+            return;
+        }
+        if (p.role == HICOM_ROLE_GEMV_CHAIN) {
+            if (p.aux.w_f32) gemv_chain_role<true>(p, ai, an, lds);
+            else gemv_chain_role<false>(p, ai, an, lds);
+            R16_TR(7);
+            return;
+        }
+        if (p.aux.x_fixed) {
+            if (p.aux.w_f32) aux_gemv_role<true, true>(p.aux, ai, an, lds);
+            else aux_gemv_role<false, true>(p.aux, ai, an, lds);
+        } else {
+            if (p.aux.w_f32) aux_gemv_role<true, false>(p.aux, ai, an, lds);
+            else aux_gemv_role<false, false>(p.aux, ai, an, lds);
+        }
+        return;
+    }
+    const int tile = r16_tile_of_block(p, (int)blockIdx.x);
+    if (tile >= 0) r16_tile<kRRing, R16_PLAIN>(p, tile, lds, TileSync{nullptr, nullptr, nullptr, nullptr, 0});
+}
+
+// ---- the fused tail launch: both readout GEMMs and the merge -> two-layer chain role in ONE grid ----
+// Workgroups [0, n1) are tile workgroups: each computes its tile of GEMM 1 (hidden = GELU(ctx . W1^T + b1)), PUBLISHES it (write-through
+// stores, a per-row-block counter), requests the W2 rows of the SAME tile of GEMM 2 (y = hidden . W2^T + b2), waits for the 14 tiles
+// of its row block and computes it: no second cold start, no kernel boundary between the two GEMMs.  Workgroups [n1, n1 + n_role)
+// run the merge items, meet at a counter, and run the global tail's two single-row layers.
+//
+// Progress without any assumption about how many workgroups are resident: a tile workgroup's wait for its row block is BOUNDED -- if
+// the block is not complete in time (publishers still queueing for a CU: fewer CUs than workgroups, a co-tenant kernel) it marks its
+// GEMM-2 tile abandoned and EXITS, so publishers never starve.  The role workgroups (highest block ids: dispatched last) finish by
+// waiting until every GEMM-2 tile is owned or abandoned -- every tile workgroup gets there in bounded time -- and computing the
+// abandoned ones (none in a healthy launch: one look at the flags, off the critical path).
+struct TailParams {
+    R16Params g1;           // GEMM 1 (+ mv: the merge items)
+    R16Params g2;           // GEMM 2 (+ aux, aux2, chain_state, cg_*: the chain)
+    TileSync sy;
+    int n1, n_role, tiles;
+};
+
+template <int kRRing>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void readout_tail_kernel(TailParams q) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    R16_TR(0);
+    const int b = (int)blockIdx.x, tid = threadIdx.x;
+    // this launch's epoch, from the arrival counter (every workgroup adds one when it is done: gridDim.x per launch).  Requested by
+    // every thread's first instruction, consumed behind the first phase.
+    unsigned long long c0 = __hip_atomic_load((r16_sync64*)q.sy.arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool tile_wg = b < q.n1;
+    int t2 = -1, t2_step = q.tiles;                // GEMM-2 tiles of this workgroup: t2, t2 + t2_step, ... (a role workgroup: the abandoned ones among them)
+    if (tile_wg) {
+        const int tile = r16_tile_of_block(q.g1, b);
+        if (tile >= 0) {
+            r16_tile<kRRing, R16_PUBLISH>(q.g1, tile, lds, q.sy);
+            t2 = tile;
+        }
+    } else {
+        const int ai = b - q.n1, an = q.n_role;
+        // the merge items' loads go out FIRST (a CU's requests return in order: behind the chain's ~100 KB of weight rows they came back
+        // 6 us later, tools/tail3_trace.py), the chain's weight rows right behind them, then the items are reduced
+        struct Hooks {
+            const TailParams& q;
+            char* lds;
+            int ai, an;
+            const unsigned long long& epoch_src;        // (a reference: the value is consumed behind the merge items, not here)
+            MvItemRegs<64, true> regs[kMvRoleItems];
+            __device__ __forceinline__ void pre() {
+                const int nslab = q.g1.mv.E / 64, items = nslab * (q.g1.mv.E / q.g1.mv.hd);
+#pragma unroll
+                for (int u = 0; u < kMvRoleItems; ++u) {
+                    const int it = ai + u * an;
+                    if (it < items) merge_vproj_fixed_load<64, true>(q.g1.mv, it % nslab, it / nslab, regs[u]);
+                }
+            }
+            __device__ __forceinline__ void reduce() {
+                const int nslab = q.g1.mv.E / 64, items = nslab * (q.g1.mv.E / q.g1.mv.hd);
+#pragma unroll
+                for (int u = 0; u < kMvRoleItems; ++u) {
+                    const int it = ai + u * an;
+                    if (it < items) merge_vproj_fixed_compute<64, true>(q.g1.mv, it % nslab, it / nslab, regs[u], lds);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's atomic adds are at the memory side
+                __syncthreads();
+                R16_TR(12);   // role: merge items done
+                if (threadIdx.x == 0) __hip_atomic_fetch_add((r16_sync64*)q.sy.gate, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __device__ __forceinline__ bool wait() {
+                unsigned* lost = reinterpret_cast<unsigned*>(lds + kChainVec + kChainBias);      // (the chain's result area: unused until its second layer)
+                if (threadIdx.x == 0) {
+                    r16_sync64* gate = (r16_sync64*)q.sy.gate;
+                    const unsigned long long target = (epoch_src / gridDim.x + 1ull) * (unsigned long long)an;
+                    unsigned spins = 0, failed = 0;
+                    while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                        if (++spins > (1u << 22)) {
+                            // (counted; the chain runs on NaNs so that its own hand-off still completes and the result says so)
+                            __hip_atomic_fetch_add((r16_sync64*)q.sy.arrivals + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            failed = 1;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    *lost = failed;
+                }
+                __syncthreads();
+                R16_TR(13);   // role: every merge item of the launch done
+                return *lost != 0u;
+            }
+        };
+        Hooks mid{q, lds, ai, an, c0, {}};
+        if (q.g2.aux.w_f32) gemv_chain_role<true>(q.g2, ai, an, lds, mid);
+        else gemv_chain_role<false>(q.g2, ai, an, lds, mid);
+        // ---- sweep: every GEMM-2 tile owned or abandoned?  (thread t looks at tiles t, t + 256, ...) ----
+        const unsigned long long epoch = c0 / gridDim.x + 1ull;
+        unsigned* cnt_l = reinterpret_cast<unsigned*>(lds);         // [0] abandoned tiles, [1] timed out
+        __syncthreads();                                             // (the chain is done with its LDS)
+        if (tid < 2) cnt_l[tid] = 0u;
+        __syncthreads();
+        unsigned spins = 0;
+        for (int t = tid; t < q.tiles; t += 256) {
+            unsigned long long f;
+            while (((f = __hip_atomic_load((r16_sync64*)(q.sy.flags + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != epoch) {
+                if (++spins > (1u << 22)) {
+                    atomicAdd(&cnt_l[1], 1u);
+                    f = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (f & 1ull) atomicAdd(&cnt_l[0], 1u);
+        }
+        __syncthreads();
+        if (cnt_l[1] != 0u && tid == 0) __hip_atomic_fetch_add((r16_sync64*)q.sy.arrivals + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cnt_l[0] != 0u) {                                        // (rare: abandoned tile t belongs to role workgroup t % an)
+            t2 = ai;
+            t2_step = an;
+        }
+        __syncthreads();
+    }
+    // ---- GEMM 2: a tile workgroup's own tile (bounded wait, may abandon); a role workgroup's share of the abandoned tiles ----
+    {
+        asm volatile("" : "+v"(c0));
+        const unsigned long long epoch = c0 / gridDim.x + 1ull;
+        for (; t2 >= 0 && t2 < q.tiles; t2 += t2_step) {
+            if (!tile_wg) {
+                const unsigned long long f = __hip_atomic_load((r16_sync64*)(q.sy.flags + t2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!((f >> 1) == epoch && (f & 1ull))) continue;
+                __syncthreads();
+            }
+            r16_tile<kRRing, R16_CONSUME>(q.g2, t2, lds, q.sy, epoch, tile_wg);
+            if (!tile_wg) __syncthreads();
+        }
+    }
+    R16_TR(7);
+    if (tid == 0) __hip_atomic_fetch_add((r16_sync64*)q.sy.arrivals, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // bf16 -> fp16 (weights, once per weight version) and f32 -> fp16 (saturating) conversions
@@ -871,10 +1167,11 @@ extern "C" int hicom_to_f16_fwd(const void* src, int32_t src_dt, void* dst, int6
     return hicom_host::check_launch("to_f16");
 }
 
-static int readout16_launch(const void* a, const void* w, const void* b, int32_t b_dt,
-                            int32_t M, int32_t N, int32_t K, int32_t act, void* out_f16,
-                            void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group,
-                            const hicom_r16_role* role, void* stream) {
+// Checks one problem (+ role) and fills the kernel's parameter block.  `force_aux` > 0: the role runs on exactly that many workgroups.
+static int r16_build(const void* a, const void* w, const void* b, int32_t b_dt,
+                     int32_t M, int32_t N, int32_t K, int32_t act, void* out_f16,
+                     void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group,
+                     const hicom_r16_role* role, int force_aux, R16Params& p, int& n_aux) {
     const bool role_only = !a && !w && M == 0;                    // (hicom_gemv_chain_fwd: no tile grid, every workgroup runs the role)
     if (!role_only) {
         HICOM_REQUIRE(a && w, HICOM_EINVAL, "readout16_gemm: NULL pointer");
@@ -884,7 +1181,6 @@ static int readout16_launch(const void* a, const void* w, const void* b, int32_t
     HICOM_REQUIRE(!y || (ldy >= N && row0 >= 0 && nl_group >= 0), HICOM_EINVAL, "readout16_gemm: bad output layout");
     HICOM_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)w % 16 == 0) && M < (1 << 30), HICOM_EINVAL, "readout16_gemm: alignment");
     const bool vec = N % 4 == 0 && (!out_f16 || ((uintptr_t)out_f16 % 8 == 0)) && (!y || (ldy % 4 == 0 && (uintptr_t)y % 16 == 0));
-    R16Params p;
     p.a = (const _Float16*)a; p.w = (const _Float16*)w; p.b = b; p.b_f32 = b_dt == HICOM_DT_F32;
     p.M = M; p.N = N; p.K = K; p.act = act; p.o16 = (_Float16*)out_f16; p.y = y; p.y_f32 = y_dt == HICOM_DT_F32;
     p.ldy = (long)ldy; p.row0 = (long)row0; p.nl_group = nl_group; p.vec = vec ? 1 : 0; p.bvec = (b && (uintptr_t)b % 16 == 0) ? 1 : 0;
@@ -894,7 +1190,7 @@ static int readout16_launch(const void* a, const void* w, const void* b, int32_t
     }
     const int nbx = (N + kRN - 1) / kRN, nby = (M + kRM - 1) / kRM;
     p.n_gemm = role_only ? 0 : 8 * ((nbx * nby + 7) / 8);
-    int n_aux = 0;
+    n_aux = 0;
     const AuxGemv none{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, 0, 0, 0, nullptr};
     p.aux = none;
     p.aux2 = none;
@@ -966,6 +1262,7 @@ static int readout16_launch(const void* a, const void* w, const void* b, int32_t
             const int want = (items + kMvRoleItems - 1) / kMvRoleItems;
             if (want > n_aux && want <= 256 - p.n_gemm - 2) n_aux = want;
         }
+        if (force_aux > 0) n_aux = force_aux;
     }
     if (p.role == HICOM_ROLE_GEMV_CHAIN) {
         const ChainGeom cg = chain_geom(p.aux.N, p.aux.K, p.aux.w_f32 != 0, p.aux2.N, n_aux);
@@ -973,6 +1270,16 @@ static int readout16_launch(const void* a, const void* w, const void* b, int32_t
                       "readout16_gemm: GEMV chain: layers of %d and %d columns over %d role workgroups do not fit", p.aux.N, p.aux2.N, n_aux);
         p.cg_cpw1 = cg.cpw1; p.cg_cpw2 = cg.cpw2; p.cg_r1 = cg.r1; p.cg_r2 = cg.r2;
     }
+    return HICOM_OK;
+}
+
+static int readout16_launch(const void* a, const void* w, const void* b, int32_t b_dt,
+                            int32_t M, int32_t N, int32_t K, int32_t act, void* out_f16,
+                            void* y, int32_t y_dt, int64_t ldy, int64_t row0, int32_t nl_group,
+                            const hicom_r16_role* role, void* stream) {
+    R16Params p;
+    int n_aux = 0;
+    if (int rc = r16_build(a, w, b, b_dt, M, N, K, act, out_f16, y, y_dt, ldy, row0, nl_group, role, 0, p, n_aux)) return rc;
     // 8 ring stages (160 KB: one workgroup per CU); 6 stages measured 0.5 us slower per GEMM (tools/gpu_round_c.sh, round 2)
     static bool attr_set = false;
     if (!attr_set) {
@@ -1012,6 +1319,46 @@ extern "C" int hicom_debug_r16_trace(void* dst, int64_t bytes) {
 extern "C" int hicom_gemv_chain_fwd(const hicom_r16_role* role, void* stream) {
     HICOM_REQUIRE(role && role->kind == HICOM_ROLE_GEMV_CHAIN, HICOM_EINVAL, "gemv_chain: a HICOM_ROLE_GEMV_CHAIN role");
     return readout16_launch(nullptr, nullptr, nullptr, 0, 0, 64, 64, HICOM_ACT_NONE, nullptr, nullptr, 0, 0, 0, 0, role, stream);
+}
+
+// ---- fused tail launch (see readout_tail_kernel) ----
+constexpr int kTailRole = 54;                 // role workgroups: ceil(162 merge items / 3) at the release shape; 200 + 54 = 254 of 256 CUs
+constexpr int kTailSyncLines = 2 + 64;        // arrivals, gate, up to 64 row blocks
+constexpr int kTailFlags = 256;               // one ownership flag per GEMM-2 tile
+
+extern "C" int64_t hicom_readout_tail_state_bytes(void) { return (int64_t)kTailSyncLines * 128 + kTailFlags * 8; }
+
+extern "C" int hicom_readout_tail_fwd(const hicom_r16_gemm* g1, const hicom_r16_gemm* g2, const hicom_r16_role* merge,
+                                      const hicom_r16_role* chain, void* state, void* stream) {
+    HICOM_REQUIRE(g1 && g2 && merge && chain && state && (uintptr_t)state % 128 == 0, HICOM_EINVAL, "readout_tail: NULL pointer / state alignment");
+    HICOM_REQUIRE(merge->kind == HICOM_ROLE_MERGE_VPROJ && chain->kind == HICOM_ROLE_GEMV_CHAIN, HICOM_EINVAL, "readout_tail: a merge role and a chain role");
+    HICOM_REQUIRE(g1->out_f16 && !g1->y && g2->a == g1->out_f16 && g2->M == g1->M && g2->K == g1->N && !g2->out_f16 && g2->y, HICOM_EINVAL,
+                  "readout_tail: GEMM 2 reads GEMM 1's fp16 plane");
+    TailParams q;
+    int na1 = 0, na2 = 0;
+    if (int rc = r16_build(g1->a, g1->w, g1->b, g1->b_dt, g1->M, g1->N, g1->K, g1->act, g1->out_f16, nullptr, 0, 0, 0, 0, merge, kTailRole, q.g1, na1)) return rc;
+    if (int rc = r16_build(g2->a, g2->w, g2->b, g2->b_dt, g2->M, g2->N, g2->K, g2->act, nullptr, g2->y, g2->y_dt, g2->ldy, g2->row0, g2->nl_group, chain,
+                           kTailRole, q.g2, na2)) return rc;
+    const int nby = (g1->M + kRM - 1) / kRM, nbx = g1->N / kRN, items = (q.g1.mv.E / 64) * (q.g1.mv.E / q.g1.mv.hd);
+    HICOM_REQUIRE(q.g1.line16 && q.g2.line16 && g1->N % kRN == 0 && g2->N == g1->N && g2->K / 64 >= 8 + 6 && nby + 2 <= kTailSyncLines &&
+                      nbx * nby <= kTailFlags && q.g1.n_gemm + kTailRole <= 256 && items <= kMvRoleItems * kTailRole && q.g1.mv.wv,
+                  HICOM_EUNSUP, "readout_tail: shape outside the fused form (two layers of the same width in whole 64-column tiles, K2 >= 896, "
+                                "<= 202 tiles, <= 162 merge items)");
+    q.sy.arrivals = (unsigned long long*)state;
+    q.sy.gate = (unsigned long long*)state + 16;
+    q.sy.rowblk = (unsigned long long*)state + 32;
+    q.sy.flags = (unsigned long long*)state + 16 * kTailSyncLines;
+    q.sy.per_epoch = nbx;
+    q.n1 = q.g1.n_gemm;
+    q.n_role = kTailRole;
+    q.tiles = nbx * nby;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(readout_tail_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kRStage);
+        attr_set = true;
+    }
+    HICOM_LAUNCH(readout_tail_kernel<8>, dim3((unsigned)(q.n1 + q.n_role)), dim3(256), 8 * kRStage, (hipStream_t)stream, q);
+    return hicom_host::check_launch("readout_tail");
 }
 
 extern "C" int64_t hicom_r16_chain_state_bytes(int32_t n_mid) { return n_mid > 0 ? (int64_t)n_mid * 8 + kChainStateHead : HICOM_EINVAL; }

@@ -15,7 +15,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 # HICOM_NATIVE_LIB: dev override (instrumented builds from tools/); the product loads the in-tree library
 LIB_PATH = os.environ.get("HICOM_NATIVE_LIB") or os.path.join(HERE, "libhicom_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 DT_BF16, DT_F32, DT_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_GELU_TANH = 0, 1, 2
@@ -36,7 +36,7 @@ EXPORTS = (
     "hicom_local_attn_adapt_bwd", "hicom_adapt_dy_fwd", "hicom_gelu_split_fwd", "hicom_gelu_bwd_fwd", "hicom_colsum_fwd",
     "hicom_global_stream_marg_fwd", "hicom_global_stream_marg_width", "hicom_global_stream_has_marg", "hicom_global_merge_marg_fwd",
     "hicom_act_rows_fwd", "hicom_act_bwd_rows_fwd", "hicom_readout16_gemm_role_fwd", "hicom_r16_chain_state_bytes", "hicom_dense16_gemm_pair_fwd", "hicom_gemv_chain_fwd",
-    "hicom_merge_vproj_sets_fwd",
+    "hicom_merge_vproj_sets_fwd", "hicom_readout_tail_fwd", "hicom_readout_tail_state_bytes",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -65,6 +65,13 @@ class R16Role(C.Structure):
                 ("part_m", C.c_void_p), ("part_l", C.c_void_p), ("part_acc", C.c_void_p), ("part_dt", C.c_int32), ("nparts", C.c_int32),
                 ("rows", C.c_int32), ("rows_pad", C.c_int32), ("E", C.c_int32), ("w_v", C.c_void_p), ("o_fix", C.c_void_p),
                 ("out_ml", C.c_void_p), ("out_ctx", C.c_void_p), ("ctx_unnorm", C.c_int32)]
+
+
+class R16Gemm(C.Structure):
+    """hicom_r16_gemm (include/hicom_hip.h)."""
+    _fields_ = [("a", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p), ("b_dt", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
+                ("K", C.c_int32), ("act", C.c_int32), ("out_f16", C.c_void_p), ("y", C.c_void_p), ("y_dt", C.c_int32),
+                ("ldy", C.c_int64), ("row0", C.c_int64), ("nl_group", C.c_int32)]
 
 
 ROLE_NONE, ROLE_GEMV, ROLE_MERGE_VPROJ, ROLE_GEMV_CHAIN = 0, 1, 2, 3
@@ -157,6 +164,9 @@ def lib() -> C.CDLL:
     L.hicom_gemv_chain_fwd.argtypes = [C.POINTER(R16Role), vp]
     L.hicom_merge_vproj_sets_fwd.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp]
     L.hicom_r16_chain_state_bytes.restype = i64
+    L.hicom_readout_tail_fwd.argtypes = [C.POINTER(R16Gemm), C.POINTER(R16Gemm), C.POINTER(R16Role), C.POINTER(R16Role), vp, vp]
+    L.hicom_readout_tail_state_bytes.argtypes = []
+    L.hicom_readout_tail_state_bytes.restype = i64
     L.hicom_to_f16_fwd.argtypes = [vp, i32, vp, i64, vp]
     L.hicom_splice_rows_fwd.argtypes = [vp, i64, i32, vp, vp]
     L.hicom_splice_labels_fwd.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i64, vp, vp, vp]
@@ -782,6 +792,43 @@ def _aux_gemv(aux) -> AuxGemv:
     return ag
 
 
+def _merge_role(merge):
+    role = R16Role()
+    role.kind = ROLE_MERGE_VPROJ
+    pc = merge["part_ctx16"]
+    role.part_m, role.part_l, role.part_acc, role.part_dt = merge["part_m"].data_ptr(), merge["part_l"].data_ptr(), pc.data_ptr(), DT_F16
+    role.nparts, role.rows_pad, role.E, role.rows = pc.shape[0], pc.shape[1], pc.shape[2], merge["rows"]
+    role.w_v, role.o_fix = _ptr(merge.get("w_v")), _ptr(merge.get("o_fix"))
+    role.out_ml, role.out_ctx = _ptr(merge.get("out_ml")), _ptr(merge.get("out_ctx"))
+    role.ctx_unnorm = int(bool(merge.get("unnorm", False)))
+    return role
+
+
+def _chain_role(chain):
+    a1, a2, state = chain
+    role = R16Role()
+    role.kind = ROLE_GEMV_CHAIN
+    role.gemv, role.gemv2, role.chain_state = _aux_gemv(a1), _aux_gemv(a2), state.data_ptr()
+    return role
+
+
+def readout_tail_state(device):
+    """Zeroed counter block of hicom_readout_tail_fwd, owned by ONE stream of launches."""
+    return torch.zeros(int(lib().hicom_readout_tail_state_bytes()), dtype=torch.uint8, device=device)
+
+
+def readout_tail(a16, w1_16, b1, hid16, w2_16, b2, y, merge, chain, state, row0=0, nl_group=0):
+    """GELU(a . w1^T + b1) -> hid16 -> hid16 . w2^T + b2 -> y rows, with the merge role and the chain role, ONE launch
+    (hicom_readout_tail_fwd).  Raises HicomNativeError(HICOM_EUNSUP) for shapes outside the fused form."""
+    M, K1 = a16.shape
+    N1, N2 = w1_16.shape[0], w2_16.shape[0]
+    g1 = R16Gemm(_ptr(a16), _ptr(w1_16), _ptr(b1), _dt(b1) if b1 is not None else 0, M, N1, K1, ACT_GELU, _ptr(hid16), None, 0, 0, 0, 0)
+    g2 = R16Gemm(_ptr(hid16), _ptr(w2_16), _ptr(b2), _dt(b2) if b2 is not None else 0, M, N2, N1, ACT_NONE, None, _ptr(y), _dt(y), y.shape[-1],
+                 row0, nl_group)
+    r1, r2 = _merge_role(merge), _chain_role(chain)
+    _check(lib().hicom_readout_tail_fwd(C.byref(g1), C.byref(g2), C.byref(r1), C.byref(r2), _ptr(state), _stream()), "hicom_readout_tail_fwd")
+
+
 def readout16_gemm(a16, w16, b, act=ACT_NONE, out_f16=None, y=None, row0=0, nl_group=0, aux=None, merge=None, chain=None):
     """aux: dict(xs f32 [parts, K] | x_fixed int64 [K], xb bf16 [K] | None, w bf16 | f32 [N, K], b bf16 | f32 [N] | None, res bf16 [N] | None,
     act, y f32 [N] | None, rows=(dst [*, ld], row0, reps) | None): one GEMV in the launch (HICOM_ROLE_GEMV).
@@ -796,19 +843,7 @@ def readout16_gemm(a16, w16, b, act=ACT_NONE, out_f16=None, y=None, row0=0, nl_g
         ag = _aux_gemv(aux) if aux is not None else None
         _check(lib().hicom_readout16_gemm_fwd(*args, C.byref(ag) if ag is not None else None, _stream()), "hicom_readout16_gemm_fwd")
         return
-    role = R16Role()
-    if merge is not None:
-        role.kind = ROLE_MERGE_VPROJ
-        pc = merge["part_ctx16"]
-        role.part_m, role.part_l, role.part_acc, role.part_dt = merge["part_m"].data_ptr(), merge["part_l"].data_ptr(), pc.data_ptr(), DT_F16
-        role.nparts, role.rows_pad, role.E, role.rows = pc.shape[0], pc.shape[1], pc.shape[2], merge["rows"]
-        role.w_v, role.o_fix = _ptr(merge.get("w_v")), _ptr(merge.get("o_fix"))
-        role.out_ml, role.out_ctx = _ptr(merge.get("out_ml")), _ptr(merge.get("out_ctx"))
-        role.ctx_unnorm = int(bool(merge.get("unnorm", False)))
-    else:
-        a1, a2, state = chain
-        role.kind = ROLE_GEMV_CHAIN
-        role.gemv, role.gemv2, role.chain_state = _aux_gemv(a1), _aux_gemv(a2), state.data_ptr()
+    role = _merge_role(merge) if merge is not None else _chain_role(chain)
     _check(lib().hicom_readout16_gemm_role_fwd(*args, C.byref(role), _stream()), "hicom_readout16_gemm_role_fwd")
 
 

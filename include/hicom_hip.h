@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HICOM_ABI_VERSION 11
+#define HICOM_ABI_VERSION 12
 
 #define HICOM_OK         0
 #define HICOM_EINVAL    -1   /* bad argument (shape, alignment, NULL)        */
@@ -426,6 +426,26 @@ int64_t hicom_r16_chain_state_bytes(int32_t n_mid);
 /* The GEMV chain as a launch of its own (no tile grid): role.kind must be HICOM_ROLE_GEMV_CHAIN.  The FINISH phase of the frame-sharded
  * step: GELU(C o + r0) and the last global readout layer behind the merge of the gathered shard states. */
 int hicom_gemv_chain_fwd(const hicom_r16_role* role, void* stream);
+/* The readout tail as ONE launch (replaces nn.Linear / GELU / nn.Linear of the local readout, projector.py:307-312,559, with the merge of
+ * the global partial states, v_proj, out_proj and the global readout, projector.py:226,640-646, riding beside them): GEMM 1's tiles
+ * publish the fp16 hidden plane inside the launch, the role workgroups run `merge` then `chain`, GEMM 2's tiles consume the plane row
+ * block by row block.  g2->a must be g1->out_f16.  `state`: hicom_readout_tail_state_bytes() bytes, 128-byte aligned, zeroed ONCE
+ * (the counters are cumulative); one state block per stream of launches.  HICOM_EUNSUP for shapes outside the fused form (the
+ * caller then issues the two hicom_readout16_gemm_role_fwd launches). */
+typedef struct hicom_r16_gemm {
+    const void* a;             /* fp16 [M, K] */
+    const void* w;             /* fp16 [N, K] */
+    const void* b;             /* bias [N] (b_dt) or NULL */
+    int32_t b_dt, M, N, K, act;
+    void* out_f16;             /* fp16 [M, N] plane, or NULL */
+    void* y;                   /* packed rows (y_dt), or NULL */
+    int32_t y_dt;
+    int64_t ldy, row0;
+    int32_t nl_group;
+} hicom_r16_gemm;
+int64_t hicom_readout_tail_state_bytes(void);
+int hicom_readout_tail_fwd(const hicom_r16_gemm* g1, const hicom_r16_gemm* g2, const hicom_r16_role* merge, const hicom_r16_role* chain,
+                           void* state, void* stream);
 /* hicom_merge_vproj_fixed_fwd over shard STATES as hicom_compressor_fwd's STREAM phase leaves them: `nsets` sets, `set_stride` floats apart,
  * each [(M, L) x rows | ACC rows x E] with un-normalised f32 accumulators.  o_fix as above (zero on entry). */
 int hicom_merge_vproj_sets_fwd(const float* sets, int64_t set_stride, int32_t nsets, int32_t rows, int32_t E, const void* w_v, int64_t* o_fix,

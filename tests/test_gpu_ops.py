@@ -981,3 +981,73 @@ def test_merge_over_shard_states_and_chain_launch_alone():
         assert maxabs(dst[5:37], y_want.expand(32, hid)) <= 5e-5 * max(1.0, float(y_want.abs().max()))
         assert bool((dst[:5] == 7).all()) and bool((dst[37:] == 7).all())
     assert int(state[:16].view(torch.int32)[2]) == 0
+
+
+@pytest.mark.parametrize("M", [1296, 96, 700])
+def test_fused_tail_launch_equals_the_two_role_launches(M):
+    """Round 5: hicom_readout_tail_fwd -- tile workgroups that compute a tile of GEMM 1 (publishing the fp16 hidden plane) and then the
+    same tile of GEMM 2 (consuming the plane behind its row block's counter), beside the merge -> chain role, in ONE grid.  Same tile and role device functions as the two launches: every output
+    bit-identical, on every one of a run of launches whose inputs CHANGE from launch to launch (a consumer that read a stale or an
+    unpublished line of the plane, or a chain that read x before the last merge item, would differ); counters: no failed wait."""
+    g = torch.Generator().manual_seed(31 + M)
+    E, nh, H, nparts = 1152, 9, 896, 216
+    wv = bf(torch.randn(E, E, generator=g) * 0.02)
+    bv = bf(torch.randn(E, generator=g) * 0.02)
+    w1 = nv.to_f16(torch.randn(H, E, generator=g).cuda() * 0.03)
+    b1 = bf(torch.randn(H, generator=g) * 0.02)
+    w2 = nv.to_f16(torch.randn(H, H, generator=g).cuda() * 0.03)
+    b2 = bf(torch.randn(H, generator=g) * 0.02)
+    c = (torch.randn(H, E, generator=g) * 0.03).cuda()
+    r0 = torch.randn(H, generator=g).cuda() * 0.1
+    gw2 = bf(torch.randn(H, H, generator=g) * 0.03)
+    gb2 = bf(torch.randn(H, generator=g) * 0.02)
+    st_ref, st_tail, sync = nv.r16_chain_state(H, "cuda"), nv.r16_chain_state(H, "cuda"), nv.readout_tail_state("cuda")
+    hid_ref = torch.empty(M, H, dtype=torch.float16, device="cuda")
+    hid = torch.empty(M, H, dtype=torch.float16, device="cuda")                # ONE plane, re-used by every launch (as the workspace is)
+    nrep = 12
+    for rep in range(nrep):
+        pm = torch.randn(nparts, 16, generator=g).cuda() * 3
+        pl = (torch.rand(nparts, 16, generator=g) + 0.5).cuda()
+        p16 = torch.randn(nparts, 16, E, generator=g).cuda().to(torch.float16)
+        a16 = nv.to_f16(torch.randn(M, E, generator=g).cuda())
+
+        def run(fused, hidbuf, state):
+            ofx = torch.zeros(E, dtype=torch.int64, device="cuda")
+            ml, ctx = torch.empty(nh, 2, device="cuda"), torch.empty(nh, E, device="cuda")
+            hg = torch.empty(H, device="cuda")
+            y = torch.full((M + 40, H), 7.0, device="cuda", dtype=torch.bfloat16)
+            merge = dict(part_m=pm, part_l=pl, part_ctx16=p16, rows=nh, w_v=wv, o_fix=ofx, out_ml=ml, out_ctx=ctx)
+            chain = (dict(x_fixed=ofx, xb=bv, w=c, b=r0, act=nv.ACT_GELU, y=hg), dict(w=gw2, b=gb2, act=nv.ACT_NONE, rows=(y, M + 2, 32)), state)
+            if fused:
+                nv.readout_tail(a16, w1, b1, hidbuf, w2, b2, y, merge, chain, sync)
+            else:
+                nv.readout16_gemm(a16, w1, b1, act=nv.ACT_GELU, out_f16=hidbuf, merge=merge)
+                nv.readout16_gemm(hidbuf, w2, b2, y=y, chain=chain)
+            torch.cuda.synchronize()
+            return ofx, ml, ctx, hg, y, hidbuf.clone()
+
+        want = run(False, hid_ref, st_ref)
+        got = run(True, hid, st_tail)
+        for k, (a, b) in enumerate(zip(want, got)):
+            assert torch.equal(a, b), (rep, k)
+        assert bool((got[4][M:M + 2] == 7).all()) and bool((got[4][M + 34:] == 7).all())
+    words = sync.view(torch.int64)
+    assert int(words[1]) == 0 and int(st_tail[:16].view(torch.int32)[2]) == 0                  # no failed wait, no failed hand-off
+    nby, grid = (M + 95) // 96, 8 * ((14 * ((M + 95) // 96) + 7) // 8) + 54
+    assert int(words[0]) == nrep * grid and int(words[16]) == nrep * 54
+    assert all(int(words[32 + 16 * r]) == nrep * 14 for r in range(nby))
+    flags = words[16 * 66:16 * 66 + 14 * nby]
+    assert bool((flags == 2 * nrep).all())                                                      # every GEMM-2 tile owned (none abandoned) in the last launch
+
+
+def test_fused_tail_launch_refuses_shapes_outside_its_form():
+    """fp32 output rows (no row-line epilogue) are outside the fused form: HICOM_EUNSUP, nothing launched -- the executor then issues
+    the two role launches."""
+    E, nh, H, M = 1152, 9, 896, 96
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device="cuda")
+    merge = dict(part_m=z(8, 16), part_l=z(8, 16) + 1, part_ctx16=z(8, 16, E, dt=torch.float16), rows=nh, w_v=z(E, E, dt=torch.bfloat16), o_fix=z(E, dt=torch.int64))
+    chain = (dict(x_fixed=merge["o_fix"], w=z(H, E), act=nv.ACT_GELU), dict(w=z(H, H, dt=torch.bfloat16), act=nv.ACT_NONE, rows=(z(40, H), 0, 32)),
+             nv.r16_chain_state(H, "cuda"))
+    with pytest.raises(nv.HicomNativeError):
+        nv.readout_tail(z(M, E, dt=torch.float16), z(H, E, dt=torch.float16), None, z(M, H, dt=torch.float16), z(H, H, dt=torch.float16), None,
+                        z(M, H), merge, chain, nv.readout_tail_state("cuda"))

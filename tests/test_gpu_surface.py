@@ -429,3 +429,40 @@ def test_integration_md_ctypes_example_runs_as_published():
     s = torch.einsum("d,wnd->wn", g.float().cpu(), k) / math.sqrt(1152)
     want = torch.einsum("wn,wnd->wd", torch.softmax(s, 1), v)
     assert float((ctx.cpu() - want).abs().max()) <= 2e-5
+
+
+def test_release_step_is_bit_identical_in_its_three_and_four_launch_forms():
+    """The executor's A/B switch HICOM_TAIL_LAUNCHES (read once per process): 4 (default) = merge role + chain role in the two GEMM
+    launches, 3 (opt-in) = the fused tail launch (hicom_readout_tail_fwd).  Same device functions, same arithmetic order: the packed bf16
+    output of a run of release-recipe forwards on changing inputs hashes the same.  (5 = round 4's merge launch + GEMV roles sums its
+    single-row layers in another order: it runs here too, finite, not compared bit for bit.)"""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = (
+        "import hashlib, sys, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import bench\n"
+        "dev = torch.device('cuda', 0)\n"
+        "torch.manual_seed(5)\n"
+        "m = bench.make_projector(bench.release_config(896, 16), dev)\n"
+        "h = hashlib.sha256()\n"
+        "with torch.no_grad():\n"
+        "    for i in range(6):\n"
+        "        g = torch.Generator(device='cuda').manual_seed(100 + i)\n"
+        "        a = torch.randn(16, 27, 27, 1152, device=dev, generator=g).bfloat16()\n"
+        "        b = torch.randn(16, 27, 27, 1152, device=dev, generator=g).bfloat16()\n"
+        "        q = torch.randn(1152, device=dev, generator=g).bfloat16()\n"
+        "        out = m(a, b, q, 'video', None)\n"
+        "        assert bool(torch.isfinite(out.float()).all())\n"
+        "        h.update(out.view(torch.int16).cpu().numpy().tobytes())\n"
+        "print('HASH', h.hexdigest())\n")
+    got = {}
+    for form in ("3", "4", "5"):
+        env = dict(os.environ, HICOM_TAIL_LAUNCHES=form)
+        r = subprocess.run([sys.executable, "-c", prog], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+        got[form] = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("HASH")][0]
+    assert got["3"] == got["4"] and len(got["5"]) == len(got["4"]), got
