@@ -323,7 +323,9 @@ class _CompressorFn(torch.autograd.Function):
             gc_ = proj.global_compressor
             # guide off (32 learnable queries x 9 heads): operator by operator, so that the global stage's state and logits stay for the
             # backward (_GlobalStore) -- the executor keeps them in its workspace only
-            many_rows = gc_ is not None and gc_.use_guide in (None, "off") and _global_store(proj, ff) is not None
+            # (the same for coarse / fine: 32 injected rows; in inference those recipes take the executor with their query rows made in
+            # front of the call, engine.run_dense)
+            many_rows = gc_ is not None and (gc_.use_guide in (None, "off") or not gc_.queries_native) and _global_store(proj, ff) is not None
             if proj.use_executor and proj._executor_covers() and not many_rows:          # (plain recipes and the k / v adaptors: one C call)
                 store = _adaptor_store(proj, ff)
                 if store is not None:

@@ -32,7 +32,7 @@ namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct WsLayout {
-    size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, ctx16, hid16, ad_hid, ad_hid2, ad_ky, ad_vy, qp, qhi, qlo, pos_a, prep_state, tail_state, tail_sync, scores, part_m, part_l, part_acc, scratch, ml, acc,
+    size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, ctx16, hid16, ad_hid, ad_hid2, ad_ky, ad_vy, qp, qhi, qlo, pos_a, prep_state, tail_state, tail_sync, lq_inj, gq_inj, inj_l_s, inj_g_s, scores, part_m, part_l, part_acc, scratch, ml, acc,
         ctx_g, o, qres, pre, hid_g, tok, po, o_fix, r0, total;
     int nw, R, rows_pad, nparts, P;
     long N, score_stride;
@@ -42,7 +42,8 @@ struct WsLayout {
 // The fused local+global stream kernel applies to the release recipe: shared bf16 local query
 // ("direct"), plain 1/sqrt(d) logits, windows that partition the grid, <= 14 folded global rows.
 bool can_fuse(const hicom_compressor_args& a) {
-    if (!(a.has_local && a.has_global) || !a.lq || a.lq_stride != 0 || a.lq_dt != HICOM_DT_BF16 || a.l2norm != 0) return false;
+    if (!(a.has_local && a.has_global) || !a.lq || a.lq_stride != 0 || a.lq_dt != HICOM_DT_BF16 || a.l2norm != 0 || a.gq_dt != HICOM_DT_BF16 ||
+        a.inj_l.mode || a.inj_g.mode) return false;
     if (a.ak.w0 || a.av.w0) return false;         // adapted local streams: the two stages no longer share their tokens
     if (a.E != 1152 || a.nq * a.nh > 12) return false;
     for (const hicom_axis* x : {&a.at, &a.ay, &a.ax})
@@ -105,6 +106,21 @@ WsLayout make_layout(const hicom_compressor_args& a) {
         if (mk && mv) w.ad_hid2 = take((size_t)w.N * a.E * 2);      // (both adaptors: the two hidden layers live side by side, paired launches)
         if (mk) w.ad_ky = take((size_t)w.N * a.E * 2);
         if (mv) w.ad_vy = take((size_t)w.N * a.E * 2);
+    }
+    // in-call guide injection (hicom_injector): the injected rows and the injector's intermediates (coarse: two [1, <= 2E] rows; fine: the
+    // projected queries, the attention output and out_proj's result [M, E] each, the projected text tokens [<= 64, E] twice)
+    auto inj_scratch = [&](const hicom_compressor_args::hicom_injector& j, long M) -> size_t {
+        if (j.mode == 1) return (size_t)(j.c_hidden + 2 * a.E) * 4 + 512;
+        if (j.mode == 2) return ((size_t)3 * M + 2 * 64) * a.E * 4 + 5 * 256;
+        return 0;
+    };
+    if (a.has_local && a.inj_l.mode) {
+        w.lq_inj = take((size_t)w.nw * a.E * 4);
+        w.inj_l_s = take(inj_scratch(a.inj_l, w.nw));
+    }
+    if (a.has_global && a.inj_g.mode) {
+        w.gq_inj = take((size_t)a.nq * a.E * 4);
+        w.inj_g_s = take(inj_scratch(a.inj_g, a.nq));
     }
     if (a.has_global) {
         w.qp = take((size_t)a.nq * a.E * 4);
@@ -194,14 +210,56 @@ int check_args(const hicom_compressor_args& a) {
             HICOM_REQUIRE(a.l2norm == 0 && a.E % 64 == 0, HICOM_EUNSUP, "compressor: adaptors with clip-scale / E %% 64 != 0 run operator by operator");
         }
     if (a.has_global) {
-        HICOM_REQUIRE(a.gq && a.nq > 0 && a.nh > 0 && a.wq && a.wk && a.wv && a.wo && a.gw0 && a.gw2, HICOM_EINVAL,
+        HICOM_REQUIRE((a.gq || a.inj_g.mode) && a.nq > 0 && a.nh > 0 && a.wq && a.wk && a.wv && a.wo && a.gw0 && a.gw2, HICOM_EINVAL,
                       "compressor: global weights");
+        HICOM_REQUIRE(!a.inj_g.mode || a.inj_g.visual, HICOM_EINVAL, "compressor: the global injector needs the rows it injects into");
         HICOM_REQUIRE(a.n_global_rows >= a.nq && a.n_global_rows % a.nq == 0, HICOM_EINVAL, "compressor: global row count");
+        HICOM_REQUIRE(a.gq_dt == HICOM_DT_BF16 || a.gq_dt == HICOM_DT_F32, HICOM_EINVAL, "compressor: gq_dt");
         HICOM_REQUIRE((a.pe == nullptr) == (a.kpe == nullptr), HICOM_EINVAL, "compressor: pe and kpe go together");
+    }
+    if ((a.has_local && a.inj_l.mode) || (a.has_global && a.inj_g.mode)) {
+        HICOM_REQUIRE((a.phases & (HICOM_PHASE_STREAM | HICOM_PHASE_FINISH)) == (HICOM_PHASE_STREAM | HICOM_PHASE_FINISH) && !a.state_sets && !a.state_out,
+                      HICOM_EUNSUP, "compressor: in-call guide injection runs STREAM and FINISH in one call (the injected rows live in its workspace)");
+        HICOM_REQUIRE(!(a.has_local && a.inj_l.mode) || (!a.lq && a.l2norm == 0), HICOM_EINVAL, "compressor: the local injector takes the pooled queries (lq NULL, no clip-scale)");
+        HICOM_REQUIRE((a.inj_l.mode >= 0 && a.inj_l.mode <= 2) && (a.inj_g.mode >= 0 && a.inj_g.mode <= 2), HICOM_EINVAL, "compressor: injector mode");
     }
     if (a.has_local && a.has_global && (a.phases & HICOM_PHASE_STREAM))
         HICOM_REQUIRE(a.stream_side && a.ev_fork && a.ev_join, HICOM_EINVAL, "compressor: side stream and events required");
     return HICOM_OK;
+}
+
+// GuideInjector.forward with a plain injector (reference projector.py:369-397) for M visual rows x (x_dt, [M, E]) -> out f32 [M, E]; the
+// operator sequence of hicom_amd/injector.py: inject(), launch for launch (same kernels, same results).
+int run_injector(const hicom_compressor_args::hicom_injector& j, const void* x, int x_dt, int M, int E, float* out, char* scratch, hipStream_t st) {
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    if (j.mode == 1) {
+        HICOM_REQUIRE(j.guide && j.guide_rows == 1 && j.c_w0 && j.c_w2 && j.ln_w && j.ln_b && j.c_hidden > 0, HICOM_EINVAL, "compressor: coarse injector arguments");
+        float* h = reinterpret_cast<float*>(scratch);
+        float* cs = reinterpret_cast<float*>(scratch + al((size_t)j.c_hidden * 4));
+        CHK(hicom_linear_fwd(j.guide, HICOM_DT_BF16, j.c_w0, HICOM_DT_BF16, j.c_b0, HICOM_DT_BF16, nullptr, 0, 1, j.c_hidden, E, 0, 0, HICOM_ACT_GELU, h, st));
+        CHK(hicom_linear_fwd(h, HICOM_DT_F32, j.c_w2, HICOM_DT_BF16, j.c_b2, HICOM_DT_BF16, nullptr, 0, 1, 2 * E, j.c_hidden, 0, 0, HICOM_ACT_NONE, cs, st));
+        return hicom_row_ln_fwd(x, x_dt, E, cs, 0, cs + E, 0, j.ln_w, j.ln_b, HICOM_DT_BF16, nullptr, 0, E, nullptr, 0, j.eps, out, HICOM_DT_F32, E, M, E, st);
+    }
+    HICOM_REQUIRE(j.mode == 2 && j.guide && j.guide_rows > 0 && j.guide_rows <= 64 && j.wq && j.wk && j.wv && j.wo && j.ln_w && j.ln_b && j.nheads > 0 &&
+                      E % j.nheads == 0, HICOM_EINVAL, "compressor: fine injector arguments (<= 64 text tokens)");
+    const int L = j.guide_rows;
+    const size_t me = al((size_t)M * E * 4), le = al((size_t)64 * E * 4);
+    float* qp = reinterpret_cast<float*>(scratch);
+    float* ao = reinterpret_cast<float*>(scratch + me);
+    float* o = reinterpret_cast<float*>(scratch + 2 * me);
+    float* kp = reinterpret_cast<float*>(scratch + 3 * me);
+    float* vp = reinterpret_cast<float*>(scratch + 3 * me + le);
+    auto rows = [&](const void* xx, int dt, const void* wgt, const void* bias, float* y) -> int {    // injector.py: linear_rows()
+        if (M <= 64 || dt != HICOM_DT_F32 || E % 64)
+            return hicom_linear_fwd(xx, dt, wgt, HICOM_DT_BF16, bias, HICOM_DT_BF16, nullptr, 0, M, E, E, 0, 0, HICOM_ACT_NONE, y, st);
+        return hicom_readout_gemm_fwd(reinterpret_cast<const float*>(xx), wgt, bias, HICOM_DT_BF16, M, E, E, HICOM_ACT_NONE, y, HICOM_DT_F32, E, 0, 0, st);
+    };
+    CHK(rows(x, x_dt, j.wq, j.bq, qp));
+    CHK(hicom_linear_fwd(j.guide, HICOM_DT_BF16, j.wk, HICOM_DT_BF16, j.bk, HICOM_DT_BF16, nullptr, 0, L, E, E, 0, 0, HICOM_ACT_NONE, kp, st));
+    CHK(hicom_linear_fwd(j.guide, HICOM_DT_BF16, j.wv, HICOM_DT_BF16, j.bv, HICOM_DT_BF16, nullptr, 0, L, E, E, 0, 0, HICOM_ACT_NONE, vp, st));
+    CHK(hicom_small_mha_fwd(qp, kp, vp, M, L, j.nheads, E / j.nheads, ao, st));
+    CHK(rows(ao, HICOM_DT_F32, j.wo, j.bo, o));
+    return hicom_row_ln_fwd(x, x_dt, E, nullptr, 0, o, E, j.ln_w, j.ln_b, HICOM_DT_BF16, nullptr, 0, E, nullptr, 0, j.eps, out, HICOM_DT_F32, E, M, E, st);
 }
 
 }  // namespace
@@ -263,8 +321,15 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         HICOM_REQUIRE(hipStreamWaitEvent(ss, (hipEvent_t)a.ev_fork, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
         return HICOM_OK;
     };
+    // the global stage's injected queries: the caller's rows, or -- in-call injection -- rows this call makes (f32, in the workspace)
+    const void* gq = a.gq;
+    int gq_dt = a.gq_dt;
+    if (a.has_global && a.inj_g.mode) {
+        gq = ws + w.gq_inj;
+        gq_dt = HICOM_DT_F32;
+    }
     auto query_prep = [&](hipStream_t st, bool with_local_rows) -> int {
-        CHK(hicom_linear_fwd(a.gq, HICOM_DT_BF16, a.wq, HICOM_DT_BF16, a.bq, HICOM_DT_BF16, nullptr, 0, a.nq, a.E, a.E,
+        CHK(hicom_linear_fwd(gq, gq_dt, a.wq, HICOM_DT_BF16, a.bq, HICOM_DT_BF16, nullptr, 0, a.nq, a.E, a.E,
                              0, 0, HICOM_ACT_NONE, F(w.qp), st));
         return hicom_fold_query_split_fwd(F(w.qp), a.wk, a.kpe, a.nq, a.nh, a.E, a.P, qscale, ws + w.qhi, ws + w.qlo,
                                           F(w.pos_a), a.P, with_local_rows ? a.lq : nullptr, w.R, 16 - w.R, st);
@@ -481,8 +546,13 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                                        0, a.nl_count, sm));
     } else if (do_stream) {
         if (both) CHK(fork());
-        auto global_stream_part = [&]() -> int {
-            if (!a.reuse_queries) CHK(query_prep(sg, false));        // (guide off: weight-only, kept in the workspace across calls)
+        auto global_prep = [&]() -> int {
+            if (a.inj_g.mode)      // coarse / fine: the guide into the learnable queries (projector.py:642 with :369-397), 3 / 6 small launches
+                CHK(run_injector(a.inj_g, a.inj_g.visual, HICOM_DT_BF16, a.nq, a.E, F(w.gq_inj), ws + w.inj_g_s, sg));
+            if (!a.reuse_queries || a.inj_g.mode) CHK(query_prep(sg, false));        // (guide off: weight-only, kept in the workspace across calls)
+            return HICOM_OK;
+        };
+        auto global_stream = [&]() -> int {
             if (w.marg)
                 CHK(hicom_global_stream_marg_fwd(a.ff, w.N, a.E, ws + w.qhi, ws + w.qlo, w.R, w.rows_pad, F(w.pos_a), a.P, a.H, a.W,
                                                  a.t_index0, a.y_index0, a.x_index0, nullptr, 0, F(w.part_m), F(w.part_l), F(w.part_acc),
@@ -492,6 +562,10 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                                             a.pe ? F(w.pos_a) : nullptr, a.P, a.H, a.W, a.t_index0, a.y_index0, a.x_index0,
                                             F(w.scores), w.score_stride, F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, sg));
             return HICOM_OK;
+        };
+        auto global_stream_part = [&]() -> int {
+            CHK(global_prep());
+            return global_stream();
         };
         // Many query rows (guide off: 288): the stream kernel fills the chip for ~230 us and IS the critical path; run beside it, the
         // local window kernel takes CU time from it (276 against 233 us) while the latency-bound tail behind it (merge + four 32-row
@@ -508,10 +582,16 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
             HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_merge, ss) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
             // (the 8-us pooling kernel in front of the wait: it runs under the stream kernel's start)
             if (pool_q) CHK(hicom_trilinear_pool_fwd(a.ff, a.T, a.H, a.W, a.E, a.at.nwin, a.ay.nwin, a.ax.nwin, F(w.pooled_q), sm));
+            // (... and the local stage's guide injection is enqueued here too: 3 / 6 launches.  Beside the stream kernel, which holds every
+            // CU, they mostly run when it ends -- tools/recipe_trace.py -- but ordering the stream kernel BEHIND them was measured no faster:
+            // "fine" 0.474 against 0.463 ms)
+            if (pool_q && a.inj_l.mode) CHK(run_injector(a.inj_l, F(w.pooled_q), HICOM_DT_F32, (int)w.nw, a.E, F(w.lq_inj), ws + w.inj_l_s, sm));
             HICOM_REQUIRE(hipStreamWaitEvent(sm, (hipEvent_t)a.ev_merge, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
         }
         // Host enqueue order matters (each launch costs a few us of host time): the long local
         // attention kernel goes first so that the side chain is enqueued while it runs.
+        if (a.has_local && a.ev_queries)      // (lq made by the caller on a stream of its own, beside the global stream kernel)
+            HICOM_REQUIRE(hipStreamWaitEvent(sm, (hipEvent_t)a.ev_queries, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
         if (a.has_local) {
             const void* q = a.lq;
             int q_dt = a.lq_dt;
@@ -521,6 +601,10 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                 q = F(w.pooled_q);
                 q_dt = HICOM_DT_F32;
                 q_stride = a.E;
+                if (a.inj_l.mode) {     // coarse / fine injection into the pooled queries (projector.py:542)
+                    if (!stream_first) CHK(run_injector(a.inj_l, F(w.pooled_q), HICOM_DT_F32, (int)w.nw, a.E, F(w.lq_inj), ws + w.inj_l_s, sm));
+                    q = F(w.lq_inj);
+                }
             }
             if (a.ak.w0 || a.av.w0) {
                 // k / v adaptors (projector.py:533-534): y = MLP(x) over all tokens on the dense MFMA GEMM (raw bf16 tokens x bf16
@@ -597,8 +681,8 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         }
         CHK(hicom_linear_fwd(ctx, HICOM_DT_F32, a.wv, HICOM_DT_BF16, a.bv, HICOM_DT_BF16, nullptr, 0, a.nq, a.E, a.E,
                              a.nh, a.E / a.nh, HICOM_ACT_NONE, F(w.o), sg));
-        // residual with the injected query (projector.py:646), read as bf16 directly
-        CHK(hicom_linear_fwd(F(w.o), HICOM_DT_F32, a.wo, HICOM_DT_BF16, a.bo, HICOM_DT_BF16, a.gq, 2, a.nq, a.E, a.E,
+        // residual with the injected query (projector.py:646), read in its own dtype
+        CHK(hicom_linear_fwd(F(w.o), HICOM_DT_F32, a.wo, HICOM_DT_BF16, a.bo, HICOM_DT_BF16, gq, gq_dt == HICOM_DT_F32 ? 0 : 2, a.nq, a.E, a.E,
                              0, 0, HICOM_ACT_NONE, F(w.pre), sg));
         CHK(hicom_linear_fwd(F(w.pre), HICOM_DT_F32, a.gw0, HICOM_DT_BF16, a.gb0, HICOM_DT_BF16, nullptr, 0, a.nq, a.hidden,
                              a.E, 0, 0, HICOM_ACT_GELU, F(w.hid_g), sg));

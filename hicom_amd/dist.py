@@ -285,7 +285,7 @@ def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: in
     if torch.is_grad_enabled() and projector._needs_grad(ff_shard, fe_shard, guide_embed, image_newline):
         raise RuntimeError("sharded_forward is an inference path: call it under torch.no_grad() / inference_mode()")
     nv.begin_inference()
-    if not projector._executor_covers():
+    if not projector._executor_covers() or not projector._queries_native():
         # coarse / fine / query-side adaptor recipes (reference projector.py:369-397, :431-441): their injected queries are computed
         # per call from the guide -- redundantly on every rank for the 32 global rows, from the shard's own frames for the pooled
         # window queries (window-local: projector.py:539-542) -- so they shard operator by operator (round 5)

@@ -32,6 +32,10 @@ class _DeviceResources:
         self.ev_fork.record(cur)
         self.ev_join.record(cur)
         self.ev_merge.record(cur)
+        # injected local queries (coarse / fine / adapt_q recipes) are made on a stream of their own, beside the global stage's stream kernel
+        self.inj = torch.cuda.Stream(device=device, priority=-1)
+        self.ev_lq = torch.cuda.Event()
+        self.ev_lq.record(cur)
         self.done = [torch.cuda.Event() for _ in range(16)]     # per-call completion events of deferred forwards
         for ev in self.done:
             ev.record(cur)                                      # (created: the executor records them from C)
@@ -63,6 +67,39 @@ def _w(lin) -> Tuple[int, Optional[int]]:
     return w.data_ptr(), (lin.bias.data_ptr() if lin.bias is not None else None)
 
 
+def _fill_injector(j, inj, mode, guide, visual, keep):
+    """hicom_injector for a plain GuideInjector (reference projector.py:369-397); the weights' addresses are plan state (plan_sig)."""
+    from .projector import _require_bf16_cuda
+    _require_bf16_cuda("guide_embed", guide)
+    E = guide.shape[-1]
+    if mode == "coarse":
+        if guide.ndim != 1:
+            raise ValueError("coarse guide injection takes a [D] guide embedding")
+        j.mode, j.guide_rows = 1, 1
+        j.c_w0, j.c_b0 = _w(inj.coarse_proj[0])
+        j.c_w2, j.c_b2 = _w(inj.coarse_proj[2])
+        j.c_hidden = inj.coarse_proj[0].out_features
+        norm = inj.coarse_norm
+    else:
+        if guide.ndim != 2:
+            raise ValueError("fine guide injection takes an [L, D] guide embedding")
+        if guide.shape[0] > 64:
+            raise NotImplementedError("fine guide injection: at most 64 text tokens (hicom_small_mha_fwd)")
+        att = inj.fine_proj
+        j.mode, j.guide_rows = 2, guide.shape[0]
+        j.wq, j.bq = _w(att.q_proj)
+        j.wk, j.bk = _w(att.k_proj)
+        j.wv, j.bv = _w(att.v_proj)
+        j.wo, j.bo = _w(att.out_proj)
+        j.nheads = att.num_heads
+        norm = inj.fine_norm
+    _require_bf16_cuda("injector norm", norm.weight)
+    j.ln_w, j.ln_b, j.eps = norm.weight.data_ptr(), norm.bias.data_ptr(), 1e-6      # (the eps injector.inject() runs the row LayerNorm with)
+    j.guide = guide.data_ptr()
+    j.visual = None if visual is None else visual.data_ptr()
+    keep.append(guide)
+
+
 def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, t_offset=0,
                phases=nv.PHASE_STREAM | nv.PHASE_FINISH, local_out=None, state_out=None,
                state_sets=None, state_set_stride=0, nsets=0, global_row0=None) -> nv.CompressorArgs:
@@ -78,6 +115,7 @@ def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, 
     a.hidden = (lc or gc).readout[2].out_features
     keep = [ff]
     a._guide_ptr_fields = ()            # argument fields that alias the caller's guide tensor (patched per call)
+    ext_l = ext_g = None
     gptr = None if guide_embed is None else guide_embed.data_ptr()
     if lc is not None:
         lc._check_native()
@@ -97,7 +135,24 @@ def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, 
                 a.l2norm = 1 | (2 if lc.use_guide == "direct" else 0)
         else:
             a.l_scale, a.l_bias = 1.0 / math.sqrt(lc.qk_dim), 0.0      # ref :551
-        if lc.use_guide == "direct":
+        if lc.inject_in_call:
+            # coarse / fine injection into the pooled queries, run by the executor itself (hicom_compressor_args.inj_l)
+            if ls is not None:
+                raise NotImplementedError("the one-call executor takes injected local queries without clip-scale")
+            a.lq = None
+            _fill_injector(a.inj_l, lc.guide_injector, lc.use_guide, guide_embed, None, keep)
+            a._guide_ptr_fields += ("inj_l.guide",)
+        elif lc.external_queries:
+            # coarse / fine injection, adapt_q, an adapted guide (ref :539-542): pooling + adaptor + injector run in front of every call
+            # (`_queries` below) and leave f32 rows in buffers this plan owns
+            if ls is not None:
+                raise NotImplementedError("the one-call executor takes injected / adapted local queries without clip-scale")
+            nw = at.nwin * ay.nwin * ax.nwin
+            rows = 1 if lc.use_guide == "direct" else nw
+            ext_l = (torch.empty((rows, E), dtype=torch.float32, device=ff.device),
+                     torch.empty((at.nwin, ay.nwin, ax.nwin, E), dtype=torch.float32, device=ff.device))
+            a.lq, a.lq_dt, a.lq_stride = ext_l[0].data_ptr(), nv.DT_F32, 0 if rows == 1 else E
+        elif lc.use_guide == "direct":
             g = guide_embed
             _require_bf16_cuda("guide_embed", g)
             if g.ndim != 1 or g.shape[0] != E:
@@ -114,8 +169,8 @@ def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, 
         keep += [w0_16, w2_16]
         if lc.adapt_k or lc.adapt_v:                                  # k / v adaptors (ref :431-457, :533-534)
             from . import injector as inj
-            if lc.adapt_q or lc.adapt_guide or ls is not None:
-                raise NotImplementedError("the one-call executor takes k / v adaptors without query-side adaptors and without clip-scale")
+            if ls is not None:
+                raise NotImplementedError("the one-call executor takes k / v adaptors without clip-scale")
             for on, dst, mlp, norm, alpha in ((lc.adapt_k, a.ak, lc.k_proj, lc.k_norm, lc.k_alpha), (lc.adapt_v, a.av, lc.v_proj, lc.v_norm, lc.v_alpha)):
                 if not on:
                     continue
@@ -130,8 +185,23 @@ def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, 
         gc._check_native(None)
         if proj.global_logit is not None:
             raise NotImplementedError("the one-call executor has no clip-scale global stage (use forward_stepwise)")
-        q_in, n_rows = gc.injected_queries(guide_embed)
-        keep.append(q_in)
+        if gc.inject_in_call:
+            q_in, n_rows = gc.query.detach(), gc.num_queries                # injected by the executor itself (hicom_compressor_args.inj_g)
+            _require_bf16_cuda("global_compressor.query", q_in)
+            _fill_injector(a.inj_g, gc.guide_injector, gc.use_guide, guide_embed, q_in, keep)
+            a._guide_ptr_fields += ("inj_g.guide",)
+            a.gq_dt = nv.DT_BF16
+            keep.append(q_in)
+        elif gc.external_queries:
+            # injected through coarse / fine / an adapted guide (ref :642 with :369-397): f32 rows in a buffer this plan owns, refilled per call
+            q_in, n_rows = gc.injected_queries(guide_embed)
+            ext_g = torch.empty((q_in.shape[0], E), dtype=torch.float32, device=ff.device)
+            q_in = ext_g
+            a.gq_dt = nv.DT_F32
+        else:
+            q_in, n_rows = gc.injected_queries(guide_embed)
+            a.gq_dt = nv.DT_BF16
+            keep.append(q_in)
         att = gc.attn_layer
         a.gq, a.nq, a.nh, a.n_global_rows = q_in.data_ptr(), q_in.shape[0], att.num_heads, n_rows
         if gptr is not None and q_in.data_ptr() == gptr:
@@ -172,6 +242,32 @@ def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, 
     a.local_out, a.state_out = _p(local_out), _p(state_out)
     a.state_sets, a.state_set_stride, a.nsets = _p(state_sets), state_set_stride, nsets
     a._keep = keep                      # keeps borrowed tensors alive until the call is enqueued
+    a._queries = None
+    if ext_l is not None or ext_g is not None:
+        grid = (a.at.nwin, a.ay.nwin, a.ax.nwin) if lc is not None else None
+
+        def queries(ff, guide, res=None, lc=lc, gc=gc, ext_l=ext_l, ext_g=ext_g, grid=grid, a=a):
+            """Fills the plan's query rows for this call.  The global rows on the current stream (the stream kernel needs them first);
+            the local rows -- pooling, adaptor, injector: up to ~10 launches, two of them GEMMs over all windows -- on `res.inj` beside
+            the global stage's stream kernel, the executor waiting for `res.ev_lq` in front of the window kernel.  res=None (graph
+            capture): everything on the current stream."""
+            if ext_g is not None:
+                gc.make_queries(guide, ext_g)
+            a.ev_queries = None
+            if ext_l is not None:
+                if res is None or gc is None:
+                    lc.make_queries(ff, guide, grid, ext_l[1], ext_l[0])
+                else:
+                    main = torch.cuda.current_stream(ff.device)
+                    res.inj.wait_stream(main)          # (inputs ready; the previous call's readers of the rows are done)
+                    with torch.cuda.stream(res.inj):
+                        lc.make_queries(ff, guide, grid, ext_l[1], ext_l[0])
+                        res.ev_lq.record(res.inj)
+                    ff.record_stream(res.inj)
+                    if guide is not None:
+                        guide.record_stream(res.inj)
+                    a.ev_queries = res.ev_lq.cuda_event
+        a._queries = queries            # (the closure owns the buffers a.lq / a.gq point into)
     return a
 
 
@@ -198,7 +294,8 @@ def attach_execution(a: nv.CompressorArgs, device, main_stream=None, res=None) -
 class _Plan:
     """A filled argument block for one (projector state, problem shape) combination and the workspace it owns, plus --
     in graph mode -- the captured hipGraph of its launch sequence and the static buffer it writes."""
-    __slots__ = ("args", "ws", "rows", "hidden", "graph", "static_out", "hits", "fused", "sig", "guide_fields", "res", "fresh", "refresh")
+    __slots__ = ("args", "ws", "rows", "hidden", "graph", "static_out", "hits", "fused", "sig", "guide_fields", "res", "fresh", "refresh",
+                 "queries")
 
     def __init__(self, args, ws, rows, hidden, sig, res):
         self.args, self.ws, self.rows, self.hidden, self.sig, self.res = args, ws, rows, hidden, sig, res
@@ -209,6 +306,7 @@ class _Plan:
         self.hits = 0
         self.fresh = None          # weight CONTENT state (versions, epoch) the derived device caches were last built from
         self.refresh = None        # callable that rebuilds them in place
+        self.queries = getattr(args, "_queries", None)     # producer of per-call query rows (coarse / fine injection, query adaptors), or None
 
 
 _MAX_PLANS = 16      # per projector; plans live ON the module (they point into its cached device tables)
@@ -373,20 +471,27 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
     if guide is not None:
         gp = guide.data_ptr()
         for f in plan.guide_fields:
-            setattr(a, f, gp)
+            obj, _, leaf = f.rpartition(".")
+            setattr(getattr(a, obj) if obj else a, leaf, gp)
     if nl is not None and a.nl_count > 0:
         a.newline = nl.data_ptr()
+    if plan.queries is not None and deferred:
+        raise NotImplementedError("forward_deferred: recipes whose queries are injected per call (coarse / fine, query adaptors) run joined")
     if graph:
         a.ev_join, a.defer_join = res.ev_join.cuda_event, 0
         if plan.graph is None:
             plan.static_out = torch.empty((plan.rows, plan.hidden), dtype=out_dtype, device=dev)
             a.out = plan.static_out.data_ptr()
+            if plan.queries is not None:
+                plan.queries(ff, guide)
             nv.compressor_fwd(a)                       # warm (lazy module loads must not happen in capture)
             torch.cuda.current_stream(dev).synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=torch.cuda.Stream(device=dev)):
                 # inside capture torch's current stream is the capture stream: re-point the plan at it
                 a.stream_main = torch.cuda.current_stream(dev).cuda_stream
+                if plan.queries is not None:
+                    plan.queries(ff, guide)
                 nv.compressor_fwd(a)
             plan.graph = g
         plan.graph.replay()
@@ -400,8 +505,10 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
         a.ev_join = ev.cuda_event
     else:
         a.ev_join = res.ev_join.cuda_event
+    if plan.queries is not None:
+        plan.queries(ff, guide, res)                   # pooling / adaptor / injector launches -> the plan's query rows
     nv.compressor_fwd(a)
-    if gc is not None and gc.use_guide in (None, "off") and not plan.fused:
+    if gc is not None and gc.use_guide in (None, "off") and gc.queries_native and not plan.fused:
         a.reuse_queries = 1                            # q_proj + fold of the learnable queries: weight-only, they stay in the plan's workspace
     if deferred:
         # the side stream is still busy with the 32 global rows: it writes `out` and reads the guide (the residual of

@@ -54,10 +54,11 @@ def adapted_guide(inj, guide):
     return out.reshape(guide.shape)
 
 
-def inject(inj, mode, visual, guide):
+def inject(inj, mode, visual, guide, out=None):
     """GuideInjector.forward for `visual` [M, D] (the pooled / learnable queries).
 
-    Returns (query, shared): shared=True means one row that every position uses ("direct")."""
+    Returns (query, shared): shared=True means one row that every position uses ("direct").  `out` (f32 [M, D]): where the coarse /
+    fine result is written (the engine's plan-owned query rows); other modes ignore it."""
     if mode in (None, "off"):
         return visual, False
     if mode == "direct":
@@ -66,7 +67,8 @@ def inject(inj, mode, visual, guide):
         return adapted_guide(inj, guide).reshape(1, -1), True
     D = visual.shape[-1]
     vis = visual.reshape(-1, D).contiguous()
-    out = _f32(vis.shape, vis.device)
+    if out is None or tuple(out.shape) != tuple(vis.shape) or out.dtype != torch.float32:
+        out = _f32(vis.shape, vis.device)
     if mode == "coarse":
         if guide.ndim != 1:
             raise ValueError("coarse guide injection takes a [D] guide embedding")

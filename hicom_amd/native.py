@@ -15,7 +15,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 # HICOM_NATIVE_LIB: dev override (instrumented builds from tools/); the product loads the in-tree library
 LIB_PATH = os.environ.get("HICOM_NATIVE_LIB") or os.path.join(HERE, "libhicom_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 DT_BF16, DT_F32, DT_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_GELU_TANH = 0, 1, 2
@@ -83,6 +83,15 @@ class Adaptor(C.Structure):
                 ("beta", C.c_void_p), ("alpha", C.c_void_p), ("y", C.c_void_p)]
 
 
+class Injector(C.Structure):
+    """hicom_compressor_args::hicom_injector (include/hicom_hip.h)."""
+    _fields_ = [("mode", C.c_int32), ("guide", C.c_void_p), ("guide_rows", C.c_int32),
+                ("c_w0", C.c_void_p), ("c_b0", C.c_void_p), ("c_w2", C.c_void_p), ("c_b2", C.c_void_p), ("c_hidden", C.c_int32),
+                ("wq", C.c_void_p), ("bq", C.c_void_p), ("wk", C.c_void_p), ("bk", C.c_void_p), ("wv", C.c_void_p), ("bv", C.c_void_p),
+                ("wo", C.c_void_p), ("bo", C.c_void_p), ("nheads", C.c_int32), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p), ("eps", C.c_float),
+                ("visual", C.c_void_p)]
+
+
 class CompressorArgs(C.Structure):
     """hicom_compressor_args (include/hicom_hip.h) -- field order and types must match the header."""
     _fields_ = [
@@ -114,6 +123,9 @@ class CompressorArgs(C.Structure):
         ("gc0", C.c_void_p), ("local_logits", C.c_void_p), ("reuse_queries", C.c_int32),
         ("ak", Adaptor), ("av", Adaptor), ("adapt_alpha_dt", C.c_int32), ("adapt_eps", C.c_float),
         ("r0_buf", C.c_void_p),
+        ("gq_dt", C.c_int32),
+        ("ev_queries", C.c_void_p),
+        ("inj_l", Injector), ("inj_g", Injector),
     ]
 
 

@@ -337,10 +337,47 @@ class LocalCompressor(_TrackedWeights, nn.Module):
 
     @property
     def executor_ok(self) -> bool:
-        """The one-call executor also covers the k / v adaptors (the second released recipe `local43_adaptkv_global32`): guide
-        direct / off, plain injector, no query-side adaptor.  (Clip-scale on the local stage with adaptors: operator by operator.)"""
-        return (self.use_guide in _NATIVE_GUIDE_MODES and _plain_injector(self.guide_injector)
-                and not (self.adapt_q or self.adapt_guide) and self.qk_dim % 64 == 0)
+        """The one-call executor also covers the k / v adaptors (the second released recipe `local43_adaptkv_global32`) and -- with the
+        per-window queries made in front of the call (`external_queries`) -- coarse / fine injection and the query-side adaptors.
+        (Clip-scale on the local stage with adaptors or injected queries: operator by operator.)"""
+        return self.use_guide in (None, "off", "direct", "coarse", "fine") and self.qk_dim % 64 == 0
+
+    @property
+    def queries_native(self) -> bool:
+        """The per-window queries are something hicom_compressor_fwd has without help: the pooled queries of guide off, the guide row
+        of plain direct injection."""
+        return self.use_guide in _NATIVE_GUIDE_MODES and _plain_injector(self.guide_injector) and not (self.adapt_q or self.adapt_guide)
+
+    @property
+    def inject_in_call(self) -> bool:
+        """coarse / fine injection with a plain injector into the plain pooled queries (ref :369-397, :542): hicom_compressor_fwd runs
+        the injector itself (hicom_compressor_args.inj_l)."""
+        return (self.use_guide in ("coarse", "fine") and _plain_injector(self.guide_injector) and not (self.adapt_q or self.adapt_guide))
+
+    @property
+    def external_queries(self) -> bool:
+        """Everything else -- adapt_q (:541), an adapted or re-projected guide (:364-365), alone or in front of an injector: the engine
+        runs pooling + adaptor + injector in front of the call and hands the rows in (f32 [windows, E])."""
+        return not (self.queries_native or self.inject_in_call)
+
+    def make_queries(self, ff, guide_embed, grid, pooled, out):
+        """The per-window queries of ref :539-542 into `out` (f32 [windows | 1, E]); `pooled` f32 [*grid, E] is scratch."""
+        from . import injector as inj
+        E = ff.shape[-1]
+        mode = self.use_guide if self.use_guide not in (None, "off") else None
+        if mode == "direct":
+            q, _ = inj.inject(self.guide_injector, "direct", None, guide_embed.contiguous())
+            q = q.reshape(1, E)
+        else:
+            nv.trilinear_pool(ff, pooled)                                  # ref :539-540
+            q = pooled.view(-1, E)
+            if self.adapt_q:
+                q = inj.adapt_query(q, self.q_proj, self.q_norm, self.q_alpha)                      # ref :541
+            if mode in ("coarse", "fine"):
+                q, _ = inj.inject(self.guide_injector, mode, q, guide_embed.contiguous(), out=out)  # ref :369-397
+        if q.data_ptr() != out.data_ptr():
+            nv.scatter_rows(q.reshape(out.shape).contiguous(), out, 0, out.shape[0])
+        return out
 
     def _check_native(self):
         if self.use_guide not in (None, "off", "direct", "coarse", "fine"):
@@ -588,7 +625,29 @@ class GlobalCompressor(_TrackedWeights, nn.Module):
     def is_plain(self) -> bool:
         return self.use_guide in _NATIVE_GUIDE_MODES and _plain_injector(self.guide_injector) and not self.adapt_guide
 
-    executor_ok = is_plain
+    @property
+    def executor_ok(self) -> bool:
+        return self.use_guide in (None, "off", "direct", "coarse", "fine")
+
+    queries_native = is_plain
+
+    @property
+    def inject_in_call(self) -> bool:
+        """coarse / fine injection of the guide into the learnable queries through a plain injector (ref :642 with :369-397):
+        hicom_compressor_fwd runs the injector itself (hicom_compressor_args.inj_g)."""
+        return self.use_guide in ("coarse", "fine") and _plain_injector(self.guide_injector) and not self.adapt_guide
+
+    @property
+    def external_queries(self) -> bool:
+        """An adapted or re-projected guide in front of the injection: made in front of hicom_compressor_fwd, handed in as f32 rows."""
+        return not (self.is_plain or self.inject_in_call)
+
+    def make_queries(self, guide_embed, out):
+        """The injected global queries (ref :642) into `out` (f32 [rows, E])."""
+        q, _ = self.injected_queries(guide_embed, out=out)
+        if q.data_ptr() != out.data_ptr():
+            nv.scatter_rows(q.reshape(out.shape).contiguous(), out, 0, out.shape[0])
+        return out
 
     def _check_native(self, logit_scale):
         if self.use_guide not in (None, "off", "direct", "coarse", "fine"):
@@ -596,7 +655,7 @@ class GlobalCompressor(_TrackedWeights, nn.Module):
         # (clip-scale, logit_scale given: the operator-by-operator path -- _stream_attention(clip=...) -- has it; the
         # one-call executor does not, HIComProjector.forward routes such projectors to forward_stepwise)
 
-    def injected_queries(self, guide_embed) -> Tuple[torch.Tensor, int]:
+    def injected_queries(self, guide_embed, out=None) -> Tuple[torch.Tensor, int]:
         """[nq_eff, E] distinct injected query rows (bf16 or f32) and how many output rows they stand for.
         direct: the 32 queries are 32 copies of the (adapted) guide (ref :352-368, :642) -> one row."""
         from . import injector as inj
@@ -610,7 +669,7 @@ class GlobalCompressor(_TrackedWeights, nn.Module):
             if guide_embed.ndim != 1 or guide_embed.shape[0] != self.embed_dim:
                 raise ValueError("direct guide injection takes a [D] guide embedding")
         _require_bf16_cuda("global_compressor.query", self.query)
-        q, shared = inj.inject(self.guide_injector, self.use_guide, self.query.detach(), guide_embed)
+        q, shared = inj.inject(self.guide_injector, self.use_guide, self.query.detach(), guide_embed, out=out)
         return q.reshape(-1, self.embed_dim).contiguous(), self.num_queries
 
     def pos_kpe_t(self, t_cap: int, H: int, W: int, device):
@@ -840,12 +899,22 @@ class HIComProjector(nn.Module):
         return self.forward_stepwise(frames_feature, frames_embed, guide_embed, modal, image_newline)
 
     def _executor_covers(self) -> bool:
-        """Recipes hicom_compressor_fwd runs in one call: guide direct / off with a plain injector, optionally with k / v adaptors
-        on the local stage; no clip-scale on the global stage, none on an adapted local stage."""
+        """Recipes whose token-stream work hicom_compressor_fwd runs in one call: every injection mode (coarse / fine / the query-side
+        adaptors: a handful of small launches in front of the call make the query rows), optionally with k / v adaptors on the local
+        stage; no clip-scale on the global stage, none on an adapted or injected local stage."""
         lc, gc = self.local_compressor, self.global_compressor
         if not all(c is None or c.executor_ok for c in (lc, gc)) or self.global_logit is not None:
             return False
-        return not (lc is not None and (lc.adapt_k or lc.adapt_v) and self.local_logit is not None)
+        return not (lc is not None and (lc.adapt_k or lc.adapt_v or not lc.queries_native) and self.local_logit is not None)
+
+    def _external_queries(self) -> bool:
+        """Some stage's queries are made in front of the executor call (engine.run_dense does; forward_deferred refuses such recipes)."""
+        return any(c is not None and c.external_queries for c in (self.local_compressor, self.global_compressor))
+
+    def _queries_native(self) -> bool:
+        """No stage injects through an injector module or adapts its queries: what the frame-sharded executor phases can run (the
+        others shard operator by operator, dist.sharded_forward_stepwise)."""
+        return all(c is None or c.queries_native for c in (self.local_compressor, self.global_compressor))
 
     def _forward_with_logits(self, frames_feature, frames_embed, guide_embed, modal, image_newline, local_logits):
         lc = self.local_compressor
@@ -877,8 +946,10 @@ class HIComProjector(nn.Module):
             raise RuntimeError("forward_deferred is an inference API: call it under torch.no_grad() / inference_mode(), "
                                "or use forward() for training")
         nv.begin_inference()
-        if not self._executor_covers() or isinstance(frames_feature, dict):
-            raise NotImplementedError("forward_deferred: dense inputs of the recipes the one-call executor covers")
+        if not self._executor_covers() or self._external_queries() or isinstance(frames_feature, dict):
+            raise NotImplementedError("forward_deferred: dense inputs of the recipes the one-call executor covers on its own")
+        # (injected queries: their buffers belong to the plan, and a deferred call's side stream may still read them when the next
+        # call refills them -- such recipes run joined)
         from . import engine
         return engine.run_dense(self, frames_feature, frames_embed, guide_embed, modal, image_newline, _out_dtype(self),
                                 deferred=True)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HICOM_ABI_VERSION 12
+#define HICOM_ABI_VERSION 13
 
 #define HICOM_OK         0
 #define HICOM_EINVAL    -1   /* bad argument (shape, alignment, NULL)        */
@@ -710,6 +710,29 @@ typedef struct hicom_compressor_args {
      * comes out of the merge ROLE of readout GEMM 1's launch, and FINISH is [memset | merge of the gathered states + v_proj |
      * chain launch -> 32 rows | token placement]. */
     float* r0_buf;
+    /* dtype of gq (HICOM_DT_BF16 = 0, the learnable queries / the guide, or HICOM_DT_F32: queries a guide injector produced on the
+     * caller's side -- coarse / fine injection, projector.py:369-397 -- handed in as f32 rows; with lq f32 [windows, E] the same way).
+     * The release-recipe paths (query_prep kernel, fused stream kernel) take bf16 queries only. */
+    int32_t gq_dt;
+    /* optional hipEvent_t: the main stream waits for it in front of the local stage's first launch -- the caller produces lq (injected
+     * per-window queries) on a stream of its own, beside the global stage's stream kernel, and records this event behind it */
+    void* ev_queries;
+    /* GuideInjector.forward inside the call (projector.py:369-397), plain injectors (no text2qk projection, no adapt_guide): the local
+     * stage injects the guide into its pooled per-window queries (lq must be NULL), the global stage into `visual` = its learnable
+     * queries (gq is ignored).  STREAM | FINISH in one call only (the injected rows live in this call's workspace). */
+    struct hicom_injector {
+        int32_t mode;              /* 0: none; 1: coarse = LN(v (1 + scale) + shift), (scale | shift) = MLP(guide) (:370-372);
+                                    * 2: fine = LN(v + MHA(v, guide tokens)) (:391-392) */
+        const void* guide;         /* bf16 [guide_rows, E]: one row (coarse) or <= 64 text tokens (fine) */
+        int32_t guide_rows;
+        const void *c_w0, *c_b0, *c_w2, *c_b2;       /* coarse_proj: Linear(E, c_hidden) GELU Linear(c_hidden, 2E), bf16 */
+        int32_t c_hidden;
+        const void *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo;   /* fine_proj (MultiheadAttention, :166-228), bf16 [E, E] / [E] */
+        int32_t nheads;
+        const void *ln_w, *ln_b;   /* coarse_norm / fine_norm, bf16 [E] */
+        float eps;
+        const void* visual;        /* global stage: bf16 [nq, E]; local stage: NULL */
+    } inj_l, inj_g;
 } hicom_compressor_args;
 
 /* 1 when hicom_compressor_fwd takes the release-recipe (single streaming kernel) path for these arguments. */

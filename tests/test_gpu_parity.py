@@ -257,16 +257,27 @@ def test_c2_uniform_attention_known_answer(c2):
 
 
 @pytest.mark.parametrize("name", ["G1_direct_T8", "G2_off_T8", "G9_grid", "G9_one_token", "G3_direct_T7", "G9_local_only",
-                                  "G9_global_only", "G10b_peaky_off"])
+                                  "G9_global_only", "G10b_peaky_off",
+                                  # round 5: injected / adapted queries made in front of the call, handed in as f32 rows (external_queries)
+                                  "G6_coarse", "G7_fine", "G7b_guide_override", "G5b_adaptqkvg_off"])
 def test_executor_equals_stepwise(name):
     """The one-call native executor (two streams, fused fold) and the operator-by-operator path agree."""
     case = cases.build_case(name)
     m = build_module(case)
+    assert m._executor_covers()
     ff, fe, g, nl = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g), dev_bf16(case.newline)
     with torch.no_grad():
         a = m(ff, fe, g, case.modal, nl)
         b = m.forward_stepwise(ff, fe, g, case.modal, nl)
         a2 = m(ff, fe, g, case.modal, nl)                  # workspace reuse: same bits on the second call
+        assert len(m.__dict__.get("_engine_plans", {})) == 1 and next(iter(m._engine_plans.values())).hits == 2
+        if g is not None and m._external_queries():
+            # the plan's query rows follow the guide of EACH call: another guide, then the first one again
+            g2 = (g.float() * -0.5 + 0.25).to(g.dtype)
+            c = m(ff, fe, g2, case.modal, nl)
+            c_step = m.forward_stepwise(ff, fe, g2, case.modal, nl)
+            assert float((c - c_step).abs().max()) <= PATH_TOL and float((c - a).abs().max()) > 1e-3
+            assert torch.equal(m(ff, fe, g, case.modal, nl), a)
     assert a.shape == b.shape and float((a - b).abs().max()) <= PATH_TOL
     assert torch.equal(a, a2)
 
