@@ -490,13 +490,14 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
     dev = ff.device
     d_fe = d_guide = None
     if want_fe or want_guide:
-        if not any(c is not None and c.use_guide in ("direct", "coarse", "fine") for c in (lc, gc)):
-            raise NotImplementedError("hicom_amd backward: gradients w.r.t. frames_embed / guide_embed need a recipe that uses them "
-                                      "(use_guide = direct / coarse / fine; stage 3 of the reference's script)")
+        if want_guide and not any(c is not None and c.use_guide in ("direct", "coarse", "fine") for c in (lc, gc)):
+            want_guide = False         # guide off: guide_embed does not enter the forward: no gradient (None), as in the reference
         if want_guide:
             d_guide = torch.zeros(guide.shape, dtype=torch.float32, device=dev)
         if want_fe and lc is None:
             want_fe = False            # without a local stage frames_embed does not enter the forward: no gradient (None), as in the reference
+        # (guide off with a local stage: frames_embed are the window keys, reference :544-551 -- d frames_embed[n] = dS_n q_w with the
+        # pooled query of the token's window, the same kernel as the direct recipe's with one query row per window)
     dout = dout.float()
     f32 = _f32_params(proj)
     T, H, W, E = ff.shape

@@ -1,4 +1,4 @@
-"""Generates tests/golden/golden_grad_v1.npz: parameter (and, for the direct recipe, guide_embed / frames_embed) gradients of the REFERENCE (imported in place from
+"""Generates tests/golden/golden_grad_v1.npz (+ golden_grad_v2.npz: d frames_embed of the guide-off recipes): parameter (and, for the direct recipe, guide_embed / frames_embed) gradients of the REFERENCE (imported in place from
 /root/reference through oracle/ref_shim.py, float32 autograd) for loss = sum(out * R), R a fixed synthetic cotangent.
 
 Run in the build container only:  python tests/golden/make_golden_grad.py
@@ -41,6 +41,7 @@ def sample_positions(n, count=512):
 def main():
     proj, _ = ref_shim.load()
     blobs = {}
+    blobs2 = {}     # golden_grad_v2.npz: d frames_embed of the recipes that do NOT inject the guide (guide off: frames_embed are the window keys)
     for name in GRAD_CASES:
         case = cases.build_case(name)
         torch.manual_seed(0)
@@ -55,6 +56,8 @@ def main():
             g = g.clone().requires_grad_(True)
             if fe is not None:
                 fe = fe.clone().requires_grad_(True)
+        elif fe is not None:
+            fe = fe.clone().requires_grad_(True)
         nl = None
         if case.newline is not None:
             nl = torch.nn.Parameter(t(case.newline))
@@ -68,19 +71,23 @@ def main():
             items.append(("__guide_embed__", g.grad))
             if fe is not None:
                 items.append(("__frames_embed__", fe.grad))
+        elif fe is not None:
+            items.append(("__frames_embed__", fe.grad))
         for k, gr in items:
+            dst = blobs2 if (k == "__frames_embed__" and not direct) else blobs
             if gr is None:
-                blobs[f"{name}/{k}/none"] = np.zeros(1, dtype=np.uint8)
+                dst[f"{name}/{k}/none"] = np.zeros(1, dtype=np.uint8)
                 continue
             v = gr.detach().numpy().astype(np.float32).reshape(-1)
             pos = sample_positions(v.size)
-            blobs[f"{name}/{k}/samples"] = v[pos]
-            blobs[f"{name}/{k}/sums"] = np.array([v.astype(np.float64).sum(), np.abs(v.astype(np.float64)).sum(),
-                                                  np.abs(v).max()], dtype=np.float64)
+            dst[f"{name}/{k}/samples"] = v[pos]
+            dst[f"{name}/{k}/sums"] = np.array([v.astype(np.float64).sum(), np.abs(v.astype(np.float64)).sum(),
+                                                np.abs(v).max()], dtype=np.float64)
         print(name, "params with grad:", sum(1 for _, gr in items if gr is not None), "/", len(items))
-    path = os.path.join(HERE, "golden_grad_v1.npz")
-    np.savez_compressed(path, **blobs)
-    print("wrote", path, os.path.getsize(path), "bytes")
+    for fname, data in (("golden_grad_v1.npz", blobs), ("golden_grad_v2.npz", blobs2)):
+        path = os.path.join(HERE, fname)
+        np.savez_compressed(path, **data)
+        print("wrote", path, os.path.getsize(path), "bytes", len(data), "arrays")
 
 
 if __name__ == "__main__":
