@@ -482,11 +482,15 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
             None if d_guide is None else d_guide.clone(), None)
 
 
-def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, want_guide=False, adaptor_saved=None, global_saved=None):
+def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, want_guide=False, adaptor_saved=None, global_saved=None,
+                        stages=("local", "global"), is_anyres=False):
     """(fp32 gradients {parameter name: tensor} of sum(out * dout), d image_newline, d frames_embed (bf16) or None,
     d guide_embed (fp32) or None).  Restates autograd through reference projector.py:524-559 (local), :634-646 + :166-228
-    (global) and mm_utils.py:92-140 (packing).  The input gradients exist for the direct recipe only."""
-    lc, gc = proj.local_compressor, proj.global_compressor
+    (global) and mm_utils.py:92-140 (packing).  The input gradients exist for the direct recipe only.
+    `stages` / `is_anyres`: one SEGMENT of an anyres dict input (reference :679-689: the base image goes through the local stage
+    only, the patch grid through both, packed with the anyres layout); `dout` holds that segment's rows."""
+    lc = proj.local_compressor if "local" in stages else None
+    gc = proj.global_compressor if "global" in stages else None
     dev = ff.device
     d_fe = d_guide = None
     if want_fe or want_guide:
@@ -507,7 +511,7 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
     if lc is not None:
         at, ay, ax = lc.tilings(T, H, W, modal)
         grid = (at.nwin, ay.nwin, ax.nwin)
-        lay = proj._layout(grid, modal, nl is not None, False)
+        lay = proj._layout(grid, modal, nl is not None, is_anyres)
         nw = grid[0] * grid[1] * grid[2]
         n_local = lay.n_rows
         idx = torch.arange(nw, device=dev)
@@ -731,15 +735,71 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
     return grads, d_nl, d_fe, d_guide
 
 
+class _AnyresFn(torch.autograd.Function):
+    """The anyres dict input of an image (reference projector.py:679-689): base image -> local stage; patch grid -> local stage with the
+    anyres packing and the global stage.  Forward operator by operator (HIComProjector.forward_stepwise), backward = compressor_backward
+    per segment on that segment's rows of the cotangent, parameter gradients summed.  Parameters and image_newline only: the
+    inputs' gradients (stage 3 trains on videos) are not built for dict inputs."""
+
+    @staticmethod
+    def forward(ctx, proj, ff_base, ff_patch, fe_base, fe_patch, guide, modal, nl, names, *params):
+        with torch.no_grad():
+            fdict = {"base": ff_base, "patch": ff_patch}
+            edict = None if fe_patch is None else {"base": fe_base, "patch": fe_patch}
+            out = proj.forward_stepwise(fdict, edict, guide, modal, nl)
+        ctx.proj, ctx.modal, ctx.names = proj, modal, names
+        ctx.save_for_backward(ff_base, ff_patch, fe_base, fe_patch, guide, nl)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        global LAST_FP32_GRADS
+        ff_base, ff_patch, fe_base, fe_patch, guide, nl = ctx.saved_tensors
+        need = ctx.needs_input_grad            # (proj, ff_base, ff_patch, fe_base, fe_patch, guide, modal, nl, names, *params)
+        if any(need[1:6]):
+            raise NotImplementedError("hicom_amd backward: input gradients (frames_feature / frames_embed / guide_embed) are not built "
+                                      "for anyres dict inputs; detach them")
+        proj = ctx.proj
+        lc = proj.local_compressor
+        with torch.no_grad():
+            dout = dout.float()
+            total, d_nl, row = {}, None, 0
+            segs = []
+            if lc is not None and ff_base is not None:
+                T, H, W = 1, ff_base.shape[0], ff_base.shape[1]
+                at, ay, ax = lc.tilings(T, H, W, ctx.modal)
+                n = proj._layout((at.nwin, ay.nwin, ax.nwin), ctx.modal, nl is not None, False).n_rows
+                segs.append((ff_base, fe_base, ("local",), False, row, row + n))
+                row += n
+            segs.append((ff_patch, fe_patch, ("local", "global"), True, row, dout.shape[0]))
+            for ff, fe, stages, anyres, r0, r1 in segs:
+                g, dn, _, _ = compressor_backward(proj, ff.unsqueeze(0).contiguous(), None if fe is None else fe.unsqueeze(0).contiguous(), guide,
+                                                  ctx.modal, nl, dout[r0:r1], stages=stages, is_anyres=anyres)
+                for k, v in g.items():
+                    total[k] = v if k not in total else total[k] + v
+                if dn is not None:
+                    d_nl = dn if d_nl is None else d_nl + dn
+        LAST_FP32_GRADS = dict(total)
+        plist = dict(proj.named_parameters())
+        out = [total[name].to(plist[name].dtype).view(plist[name].shape) if (need[9 + k] and total.get(name) is not None) else None
+               for k, name in enumerate(ctx.names)]
+        return (None, None, None, None, None, None, None, (d_nl.to(nl.dtype) if (nl is not None and need[7] and d_nl is not None) else None), None, *out)
+
+
 def forward_with_grad(proj, frames_feature, frames_embed, guide_embed, modal, image_newline):
     from .projector import _require_bf16_cuda
     some = frames_feature["patch"] if isinstance(frames_feature, dict) else frames_feature
     _require_bf16_cuda("frames_feature", some)
-    if isinstance(frames_feature, dict) or not _supported(proj):
-        raise NotImplementedError("hicom_amd: the backward pass covers every injection mode and adaptor on dense inputs, without "
-                                  "clip-scale and without a text2qk projection; run other configurations under torch.no_grad() / "
-                                  "inference_mode() -- forward() never returns a silently detached tensor")
+    if not _supported(proj):
+        raise NotImplementedError("hicom_amd: the backward pass covers every injection mode and adaptor, without clip-scale and without "
+                                  "a text2qk projection; run other configurations under torch.no_grad() / inference_mode() -- forward() "
+                                  "never returns a silently detached tensor")
     names, params = zip(*[(n, p) for n, p in proj.named_parameters()])
+    if isinstance(frames_feature, dict):
+        c = lambda t: None if t is None else t.contiguous()
+        fe = frames_embed if frames_embed is not None else {"base": None, "patch": None}
+        return _AnyresFn.apply(proj, c(frames_feature["base"]), c(frames_feature["patch"]), c(fe["base"]), c(fe["patch"]), c(guide_embed), modal,
+                               c(image_newline), names, *params)
     ff = frames_feature.contiguous()
     fe = frames_embed.contiguous() if frames_embed is not None else None
     return _CompressorFn.apply(proj, ff, fe, guide_embed.contiguous() if guide_embed is not None else None, modal,

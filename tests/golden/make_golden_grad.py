@@ -38,10 +38,49 @@ def sample_positions(n, count=512):
     return (k * 2654435761 + 12345) % n
 
 
+ANYRES_CASES = ["G9_anyres", "G9_anyres_nobase"]        # dict inputs of an anyres image (reference projector.py:679-689), into v2
+
+
+def store(dst, name, items):
+    for k, gr in items:
+        if gr is None:
+            dst[f"{name}/{k}/none"] = np.zeros(1, dtype=np.uint8)
+            continue
+        v = gr.detach().numpy().astype(np.float32).reshape(-1)
+        pos = sample_positions(v.size)
+        dst[f"{name}/{k}/samples"] = v[pos]
+        dst[f"{name}/{k}/sums"] = np.array([v.astype(np.float64).sum(), np.abs(v.astype(np.float64)).sum(),
+                                            np.abs(v).max()], dtype=np.float64)
+
+
+def anyres_grads(proj, blobs2):
+    for name in ANYRES_CASES:
+        case = cases.build_case(name)
+        torch.manual_seed(0)
+        module = proj.build_vision_projector(case.cfg).float().train()
+        module.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd.items()}, strict=True)
+        t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))
+        a = case.anyres
+        fdict = {"base": None if a["no_base"] else t(case.ff)[0], "patch": t(a["patch_ff"])}
+        edict = {"base": None if a["no_base"] else t(case.fe)[0], "patch": t(a["patch_fe"])}
+        nl = torch.nn.Parameter(t(case.newline)) if case.newline is not None else None
+        out = module(fdict, edict, t(case.g), case.modal, nl)
+        R = torch.from_numpy(cotangent(name, out.shape))
+        (out * R).sum().backward()
+        items = [(k, p.grad) for k, p in module.named_parameters()]
+        if nl is not None:
+            items.append(("image_newline", nl.grad))
+        store(blobs2, name, items)
+        blobs2[f"{name}/out_shape"] = np.array(out.shape, dtype=np.int64)
+        print(name, "(anyres) params with grad:", sum(1 for _, gr in items if gr is not None), "/", len(items))
+
+
 def main():
     proj, _ = ref_shim.load()
     blobs = {}
-    blobs2 = {}     # golden_grad_v2.npz: d frames_embed of the recipes that do NOT inject the guide (guide off: frames_embed are the window keys)
+    blobs2 = {}     # golden_grad_v2.npz: d frames_embed of the recipes that do NOT inject the guide (guide off: frames_embed are the window
+    #                 keys), and the parameter gradients of anyres dict inputs
+    anyres_grads(proj, blobs2)
     for name in GRAD_CASES:
         case = cases.build_case(name)
         torch.manual_seed(0)

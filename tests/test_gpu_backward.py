@@ -70,6 +70,11 @@ def test_parameter_gradients_match_reference_autograd(name, golden_grad):
     if nl is not None:
         items.append(("image_newline", nl))
     items += inputs
+    assert _check_against_fixture(name, items, fp32, golden_grad) >= 4 + len(inputs)
+
+
+def _check_against_fixture(name, items, fp32, golden_grad):
+    import make_golden_grad as mg
     checked = 0
     mx_case = max(float(golden_grad[f][2]) for f in golden_grad if f.startswith(name + "/") and f.endswith("/sums"))
     for k, p in items:
@@ -88,7 +93,34 @@ def test_parameter_gradients_match_reference_autograd(name, golden_grad):
             assert abs(float(fp32[k].double().sum()) - s) <= 2e-3 * sabs + tol * p.numel() ** 0.5, k
         assert np.abs(got16 - want).max() <= 2 ** -7 * mx + tol, k              # the bf16 cast of it
         checked += 1
-    assert checked >= 4 + len(inputs)
+    return checked
+
+
+@pytest.mark.parametrize("name", ["G9_anyres", "G9_anyres_nobase"])
+def test_anyres_dict_parameter_gradients_match_reference_autograd(name, golden_grad):
+    """Round 5: the anyres dict input of an image (reference projector.py:679-689: base image -> local stage; patch grid -> local stage
+    with the anyres packing + global stage) under autograd.  Forward = the inference path's bits; parameter and image_newline gradients
+    against the reference's own autograd on the same dict (golden_grad_v2); input gradients refuse."""
+    import make_golden_grad as mg
+    from hicom_amd import autograd as hag
+    case = cases.build_case(name)
+    m = build_module(case).train()
+    a = case.anyres
+    ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+    fdict = {"base": None if a["no_base"] else ff[0], "patch": dev_bf16(a["patch_ff"])}
+    edict = {"base": None if a["no_base"] else fe[0], "patch": dev_bf16(a["patch_fe"])}
+    nl = torch.nn.Parameter(dev_bf16(case.newline))
+    with torch.no_grad():
+        want_out = m(fdict, edict, g, case.modal, nl).clone()
+    out = m(fdict, edict, g, case.modal, nl)
+    assert out.requires_grad and torch.equal(out.detach(), want_out) and tuple(out.shape) == tuple(golden_grad[f"{name}/out_shape"])
+    R = torch.from_numpy(mg.cotangent(name, out.shape)).cuda()
+    (out * R).sum().backward()
+    items = [(k, p) for k, p in m.named_parameters()] + [("image_newline", nl)]
+    assert _check_against_fixture(name, items, dict(hag.LAST_FP32_GRADS), golden_grad) >= 8
+    g2 = g.clone().requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        m(fdict, edict, g2, case.modal, nl).sum().backward()
 
 
 def test_unsupported_recipes_and_input_grads_refuse():
