@@ -63,6 +63,7 @@ struct R16Params {
     int nl_group;
     int vec, bvec;
     int line16;             // exactly one 16-bit output whose tile rows are whole 16-byte aligned 128-byte lines: the row-line epilogue
+    int tn;                 // tile width the host chose (64 | 128): selects the kernel instantiation
     int n_gemm;             // workgroups of the tile grid; blocks >= n_gemm run the role
     int role;               // HICOM_ROLE_*: what the workgroups behind the tile grid do
     AuxGemv aux;            // GEMV; first layer of GEMV_CHAIN
@@ -557,8 +558,9 @@ struct TileSync {
 };
 
 // the workgroup -> tile map of the tile grid: ordinal of the tile in the blocked order below, or -1 (the grid is rounded up to 8 x slots)
+template <int TN = kRN>
 __device__ __forceinline__ int r16_tile_of_block(const R16Params& p, int vblock) {
-    const int nbx = (p.N + kRN - 1) / kRN, nby = (p.M + kRM - 1) / kRM;
+    const int nbx = (p.N + TN - 1) / TN, nby = (p.M + kRM - 1) / kRM;
     // XCD-balanced order (speed only): workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md "Workgroup dispatch"); every
     // XCD gets a contiguous run of ~tiles/8 tiles in row-major tile order, i.e. ~2 row tiles whose A rows stay in ITS L2,
     // and -- the point -- the same number of busy CUs, so that the aux workgroups (dealt round-robin too) find a free CU
@@ -569,21 +571,29 @@ __device__ __forceinline__ int r16_tile_of_block(const R16Params& p, int vblock)
     return slot >= t_hi - t_lo ? -1 : t_lo + slot;
 }
 
-// One 96 x 64 output tile of y = act(a . w^T + b) by one 256-thread workgroup (`tile` = r16_tile_of_block()).
+// One 96 x TN output tile of y = act(a . w^T + b) by one 256-thread workgroup (`tile` = r16_tile_of_block<TN>()).
+// TN = 64: the hot path's tile (20 KB per BK = 64 stage, 8-stage ring).  TN = 128 (round 5): for wide layers -- hidden 3584, the 7B
+// model's width -- where the 64-column grid is several rounds of workgroups: half the tiles, A staged half as often (28 KB per
+// stage, 5-stage ring); a wave owns 48 x 64 outputs.
 // MODE: R16_PLAIN; R16_PUBLISH = the fp16 plane leaves as write-through stores and the tile's row block counts it (the fused tail
 // launch: the plane is the next GEMM's A operand, read inside the same launch); R16_CONSUME = the A rows are such a plane: the W
 // stages of the prologue go out at entry, the A stages behind the row block's counter (`epoch` = this launch's).  A consumer that
 // `may_abandon` waits a BOUNDED time: if the row block is not complete by then it marks the tile abandoned and returns false (it
 // must not hold its CU: a publisher may still be waiting for one); otherwise it marks the tile owned.  Returns true when the tile is done.
-template <int kRRing, int MODE>
+template <int kRRing, int MODE, int TN = kRN>
 __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds, const TileSync sy, unsigned long long epoch = 0, bool may_abandon = false) {
+    static_assert(TN == 64 || TN == 128, "tile width");
+    constexpr int NJ = TN / 32;                              // 16-column blocks per wave (a wave owns TN / 2 columns)
+    constexpr int PW = 3 + TN / 32;                          // DMA pieces (1 KiB = 8 rows x 128 B) per wave and stage: 12 A + TN / 8 W over four waves
+    constexpr int STAGE = kRImgA + TN * 128;                 // bytes of a ring stage
+    static_assert(kRRing * STAGE <= 160 * 1024, "ring exceeds the LDS");
     constexpr int kTrOff = MODE == R16_CONSUME ? 8 : 0;      // (dev timeline: a consumer's stamps go to slots of their own)
     (void)kTrOff;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int r16 = lane & 15, kg = lane >> 4;
-    const int nbx = (p.N + kRN - 1) / kRN, nby = (p.M + kRM - 1) / kRM;
+    const int nbx = (p.N + TN - 1) / TN, nby = (p.M + kRM - 1) / kRM;
     // ... in a BLOCKED order: the left half of the tile columns row by row, then the right half -- an XCD's run of ~tiles/8 tiles is a
     // ~(3.5 rows x 7 columns) patch, so both its A row blocks and its W column blocks are shared by several of its CUs and cross
     // its L2 once (row-major runs shared the A rows 14 ways and the W columns hardly at all: every CU pulled its W panel from
@@ -600,15 +610,15 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
             bx = hx + t2 - by * wx;
         }
     }
-    const int m0 = by * kRM, n0 = bx * kRN;
+    const int m0 = by * kRM, n0 = bx * TN;
     const int ns = p.K >> 6;
 
-    // DMA assignment: a stage is 20 one-KiB pieces (8 rows x 128 B): 12 of A, 8 of W; wave w issues pieces w, w+4, ...
+    // DMA assignment: a stage is 12 + TN / 8 one-KiB pieces (8 rows x 128 B): 12 of A, then W; wave w issues pieces w, w+4, ...
     const int prow = lane >> 3, cpos = lane & 7;
-    const _Float16* src[kRPW];
-    int dst_off[kRPW];
+    const _Float16* src[PW];
+    int dst_off[PW];
 #pragma unroll
-    for (int i = 0; i < kRPW; ++i) {
+    for (int i = 0; i < PW; ++i) {
         const int pi = wave + 4 * i;
         if (pi < 12) {
             const int row = 8 * pi + prow;
@@ -623,21 +633,21 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
         }
         dst_off[i] = pi * 1024;
     }
-    // (this wave's pieces 0..2 are A rows, 3..4 W rows: wave + 4 i < 12 <=> i < 3.)  A published plane (R16_CONSUME) is read with sc1
+    // (this wave's pieces 0..2 are A rows, the others W rows: wave + 4 i < 12 <=> i < 3.)  A published plane (R16_CONSUME) is read with sc1
     // loads: they bypass this CU's L1, the one cache a write-through store of another CU does not reach (MI355X_MICROARCH.md
     // "inter-workgroup visibility": every store of the bytes sc1 and drained, every load of them sc1 -- no acquire needed)
     constexpr int kAuxA = MODE == R16_CONSUME ? 16 : 0;
     auto issue_a = [&](int s, int ring_slot) {
-        char* base = lds + ring_slot * kRStage;
+        char* base = lds + ring_slot * STAGE;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + 64 * s),
                                              (__attribute__((address_space(3))) void*)(base + dst_off[i]), 16, 0, kAuxA);
     };
     auto issue_w = [&](int s, int ring_slot) {
-        char* base = lds + ring_slot * kRStage;
+        char* base = lds + ring_slot * STAGE;
 #pragma unroll
-        for (int i = 3; i < kRPW; ++i)
+        for (int i = 3; i < PW; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + 64 * s),
                                              (__attribute__((address_space(3))) void*)(base + dst_off[i]), 16, 0, 0);
     };
@@ -646,54 +656,68 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
         issue_w(s, ring_slot);
     };
     auto wait_stages = [&](int k) {      // at most k of this wave's stages still in flight
-        if (k >= 6) r16_wait_vm<6 * kRPW>();
-        else if (k == 5) r16_wait_vm<5 * kRPW>();
-        else if (k == 4) r16_wait_vm<4 * kRPW>();
-        else if (k == 3) r16_wait_vm<3 * kRPW>();
-        else if (k == 2) r16_wait_vm<2 * kRPW>();
-        else if (k == 1) r16_wait_vm<kRPW>();
+        if (k >= 6) r16_wait_vm<6 * PW>();
+        else if (k == 5) r16_wait_vm<5 * PW>();
+        else if (k == 4) r16_wait_vm<4 * PW>();
+        else if (k == 3) r16_wait_vm<3 * PW>();
+        else if (k == 2) r16_wait_vm<2 * PW>();
+        else if (k == 1) r16_wait_vm<PW>();
         else r16_wait_vm<0>();
     };
 
-    // fragments of one BK = 64 stage: two K = 32 steps x (2 W blocks of this wave's 32 columns, 3 A blocks of its 48 rows)
+    // fragments of one BK = 64 stage: two K = 32 steps x (NJ W blocks of this wave's TN / 2 columns, 3 A blocks of its 48 rows)
     struct Frags {
-        half8 w[2][2], a[2][3];
+        half8 w[2][NJ], a[2][3];
     };
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(lds);
     const int swz = (r16 >> 1) & 7;
     const int f0off = r16 * 128 + 16 * (kg ^ swz), f1off = r16 * 128 + 16 * ((4 + kg) ^ swz);
-    const int a_base = 48 * wr * 128, w_base = kRImgA + 32 * wc * 128;
+    const int a_base = 48 * wr * 128, w_base = kRImgA + (TN / 2) * wc * 128;
 #define HICOM_LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
     auto read = [&](int ring_slot, Frags& f) {
-        const unsigned st = lds0 + ring_slot * kRStage;
+        const unsigned st = lds0 + ring_slot * STAGE;
         const unsigned a0 = st + a_base + f0off, a1 = st + a_base + f1off, w0 = st + w_base + f0off, w1 = st + w_base + f1off;
         HICOM_LDS_RD(f.w[0][0], w0, 0);
         HICOM_LDS_RD(f.w[0][1], w0, 2048);
+        if constexpr (NJ == 4) {
+            HICOM_LDS_RD(f.w[0][NJ - 2], w0, 4096);
+            HICOM_LDS_RD(f.w[0][NJ - 1], w0, 6144);
+        }
         HICOM_LDS_RD(f.a[0][0], a0, 0);
         HICOM_LDS_RD(f.a[0][1], a0, 2048);
         HICOM_LDS_RD(f.a[0][2], a0, 4096);
         HICOM_LDS_RD(f.w[1][0], w1, 0);
         HICOM_LDS_RD(f.w[1][1], w1, 2048);
+        if constexpr (NJ == 4) {
+            HICOM_LDS_RD(f.w[1][NJ - 2], w1, 4096);
+            HICOM_LDS_RD(f.w[1][NJ - 1], w1, 6144);
+        }
         HICOM_LDS_RD(f.a[1][0], a1, 0);
         HICOM_LDS_RD(f.a[1][1], a1, 2048);
         HICOM_LDS_RD(f.a[1][2], a1, 4096);
     };
 #undef HICOM_LDS_RD
     auto land = [&](Frags& f) {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(f.w[0][0]), "+v"(f.w[0][1]), "+v"(f.w[1][0]), "+v"(f.w[1][1]), "+v"(f.a[0][0]), "+v"(f.a[0][1]),
-                       "+v"(f.a[0][2]), "+v"(f.a[1][0]), "+v"(f.a[1][1]), "+v"(f.a[1][2])::"memory");
+        if constexpr (NJ == 4)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(f.w[0][0]), "+v"(f.w[0][1]), "+v"(f.w[0][NJ - 2]), "+v"(f.w[0][NJ - 1]), "+v"(f.w[1][0]), "+v"(f.w[1][1]),
+                           "+v"(f.w[1][NJ - 2]), "+v"(f.w[1][NJ - 1]), "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[0][2]), "+v"(f.a[1][0]),
+                           "+v"(f.a[1][1]), "+v"(f.a[1][2])::"memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(f.w[0][0]), "+v"(f.w[0][1]), "+v"(f.w[1][0]), "+v"(f.w[1][1]), "+v"(f.a[0][0]), "+v"(f.a[0][1]),
+                           "+v"(f.a[0][2]), "+v"(f.a[1][0]), "+v"(f.a[1][1]), "+v"(f.a[1][2])::"memory");
     };
-    f32x4 acc[2][3];
+    f32x4 acc[NJ][3];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int i = 0; i < 3; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto compute = [&](const Frags& f) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int i = 0; i < 3; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[ks][j], f.a[ks][i], acc[j][i], 0, 0, 0);
     };
@@ -708,7 +732,7 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
         unsigned long long seen = 0;
         if (tid == 0) seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (requested in FRONT of the W pieces: returns first)
         for (int s = 0; s < kRRing - 1; ++s) issue_w(s, s);
-        unsigned* flag = reinterpret_cast<unsigned*>(lds + (kRRing - 1) * kRStage);   // (the ring's last slot: first written by step 0)
+        unsigned* flag = reinterpret_cast<unsigned*>(lds + (kRRing - 1) * STAGE);   // (the ring's last slot: first written by step 0)
         if (tid == 0) {
             // an owner that may abandon waits ~100 us at most (every publisher of a healthy launch is done within ~2); a sweeper
             // (every publisher has finished by the time it runs) waits like every other hand-off of the step
@@ -741,12 +765,14 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
         for (int s = 0; s < npro; ++s) issue(s, s);
     }
     // the bias of this wave's columns, fetched now (one vector load per column block)
-    uint2 braw[2] = {make_uint2(0, 0), make_uint2(0, 0)};
-    float4 brawf[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-    bool bpre[2];
+    uint2 braw[NJ];
+    float4 brawf[NJ];
+    bool bpre[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int nb = n0 + 32 * wc + 16 * j + 4 * kg;
+    for (int j = 0; j < NJ; ++j) {
+        braw[j] = make_uint2(0, 0);
+        brawf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int nb = n0 + (TN / 2) * wc + 16 * j + 4 * kg;
         bpre[j] = p.b && p.bvec && nb + 3 < p.N;
         if (bpre[j]) {
             if (p.b_f32) brawf[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.b) + nb);
@@ -754,7 +780,7 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
         }
     }
     if constexpr (MODE == R16_CONSUME) r16_wait_vm<(kRRing - 2) * 3>();          // A pieces of stage 0 landed (every W piece is older)
-    else if (npro == kRRing - 1) r16_wait_vm<(kRRing - 2) * kRPW>();
+    else if (npro == kRRing - 1) r16_wait_vm<(kRRing - 2) * PW>();
     else wait_stages(npro - 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -766,7 +792,7 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
     int slot_issue = kRRing - 1;       // ring slot of stage s+kRRing-1 (= the slot of stage s-1)
     auto step = [&](auto steady, int s, const Frags& cur, Frags& nxt) {
         if constexpr (decltype(steady)::value) {
-            r16_wait_vm<(kRRing - 3) * kRPW>();         // stage s+1 landed (this wave's pieces); s+2 .. s+kRRing-2 may fly
+            r16_wait_vm<(kRRing - 3) * PW>();         // stage s+1 landed (this wave's pieces); s+2 .. s+kRRing-2 may fly
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             issue(s + kRRing - 1, slot_issue);
@@ -790,7 +816,7 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
     int s = 0;
     if constexpr (MODE == R16_CONSUME) {
         // the first kRRing - 3 steps wait on a prologue whose A pieces were issued LAST: behind stage s + 1's A pieces are the A pieces
-        // of prologue stages s + 2 .. kRRing - 2 (3 each) and the whole stages issued by steps 0 .. s - 1 (kRPW each)
+        // of prologue stages s + 2 .. kRRing - 2 (3 each) and the whole stages issued by steps 0 .. s - 1 (PW each)
         auto early = [&](auto allow, int s_, const Frags& cur, Frags& nxt) {
             r16_wait_vm<decltype(allow)::value>();
             __builtin_amdgcn_s_barrier();
@@ -804,12 +830,12 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
             slot_next = slot_next + 1 == kRRing ? 0 : slot_next + 1;
             slot_issue = slot_issue + 1 == kRRing ? 0 : slot_issue + 1;
         };
-        static_assert(kRRing == 8, "the early-step waits are written out for an 8-stage ring");
-        early(std::integral_constant<int, 3 * 5 + kRPW * 0>{}, 0, f0, f1);
-        early(std::integral_constant<int, 3 * 4 + kRPW * 1>{}, 1, f1, f0);
-        early(std::integral_constant<int, 3 * 3 + kRPW * 2>{}, 2, f0, f1);
-        early(std::integral_constant<int, 3 * 2 + kRPW * 3>{}, 3, f1, f0);
-        early(std::integral_constant<int, 3 * 1 + kRPW * 4>{}, 4, f0, f1);
+        static_assert(kRRing == 8 && TN == 64, "the early-step waits are written out for an 8-stage ring of 64-column tiles");
+        early(std::integral_constant<int, 3 * 5 + PW * 0>{}, 0, f0, f1);
+        early(std::integral_constant<int, 3 * 4 + PW * 1>{}, 1, f1, f0);
+        early(std::integral_constant<int, 3 * 3 + PW * 2>{}, 2, f0, f1);
+        early(std::integral_constant<int, 3 * 2 + PW * 3>{}, 3, f1, f0);
+        early(std::integral_constant<int, 3 * 1 + PW * 4>{}, 4, f0, f1);
         step(Yes{}, 5, f1, f0);
         s = 6;
     }
@@ -835,13 +861,13 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
     // and leave as 16-byte stores, eight consecutive lanes writing one 128-byte line of an output row.  The straight form -- every lane
     // storing its four columns of six accumulator blocks, 8 bytes at a time, 16 partial lines per instruction -- is store-ISSUE bound
     // (cdna_hip_programming.md T21; tools/tail_trace.py: 1.8 us for 12 KB per workgroup, the same on a second pass with warm caches).
-    if (p.line16 && n0 + kRN <= p.N) {
-        constexpr int TP = kRN + 8;                                // row pitch in 16-bit elements: 16-byte aligned rows, shifted banks
+    if (p.line16 && n0 + TN <= p.N) {
+        constexpr int TP = TN + 8;                                 // row pitch in 16-bit elements: 16-byte aligned rows, shifted banks
         uint16_t* tl = reinterpret_cast<uint16_t*>(lds);
         __syncthreads();                                           // every wave has read its last fragments out of the ring
         const bool to_f16 = p.o16 != nullptr;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             float bias[4] = {0.f, 0.f, 0.f, 0.f};
             if (bpre[j]) {
                 if (p.b_f32) {
@@ -851,7 +877,7 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
                     bias[2] = bf16lo_to_f32(braw[j].y); bias[3] = bf16hi_to_f32(braw[j].y);
                 }
             } else if (p.b) {
-                const int n = n0 + 32 * wc + 16 * j + 4 * kg;
+                const int n = n0 + (TN / 2) * wc + 16 * j + 4 * kg;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     bias[q] = p.b_f32 ? reinterpret_cast<const float*>(p.b)[n + q] : bf16_to_f32(reinterpret_cast<const uint16_t*>(p.b)[n + q]);
@@ -871,13 +897,13 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
                         h[q] = f32_to_bf16(v);
                     }
                 }
-                *reinterpret_cast<uint2*>(tl + (48 * wr + 16 * im + r16) * TP + 32 * wc + 16 * j + 4 * kg) =
+                *reinterpret_cast<uint2*>(tl + (48 * wr + 16 * im + r16) * TP + (TN / 2) * wc + 16 * j + 4 * kg) =
                     make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
             }
         }
         __syncthreads();
-        for (int it = tid; it < kRM * (kRN / 8); it += 256) {
-            const int row = it >> 3, c8 = it & 7, m = m0 + row;
+        for (int it = tid; it < kRM * (TN / 8); it += 256) {
+            const int row = it / (TN / 8), c8 = it % (TN / 8), m = m0 + row;
             if (m < p.M) {
                 const u32x4 v = *reinterpret_cast<const u32x4*>(tl + row * TP + 8 * c8);
                 if (to_f16) {
@@ -903,8 +929,8 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
     if constexpr (MODE != R16_PLAIN) return true;          // (host: the fused tail launch admits row-line shapes only)
     // epilogue.  Transposed product: lane holds columns n .. n+3 (4 * kg + q) of row m = r16 of each block.
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + 32 * wc + 16 * j + 4 * kg;
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + (TN / 2) * wc + 16 * j + 4 * kg;
         if (n >= p.N) continue;
         float bias[4] = {0.f, 0.f, 0.f, 0.f};
         if (bpre[j]) {
@@ -964,9 +990,9 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
     return true;
 }
 
-template <int kRRing>
+template <int kRRing, int TN = kRN>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void readout16_gemm_kernel(R16Params p) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];   // [kRRing][kRStage]
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // [kRRing][stage]; the roles take the whole 160 KB
     R16_TR(0);
     if ((int)blockIdx.x >= p.n_gemm) {
         const int ai = (int)blockIdx.x - p.n_gemm, an = (int)gridDim.x - p.n_gemm;
@@ -990,8 +1016,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         }
         return;
     }
-    const int tile = r16_tile_of_block(p, (int)blockIdx.x);
-    if (tile >= 0) r16_tile<kRRing, R16_PLAIN>(p, tile, lds, TileSync{nullptr, nullptr, nullptr, nullptr, 0});
+    const int tile = r16_tile_of_block<TN>(p, (int)blockIdx.x);
+    if (tile >= 0) r16_tile<kRRing, R16_PLAIN, TN>(p, tile, lds, TileSync{nullptr, nullptr, nullptr, nullptr, 0});
 }
 
 // ---- the fused tail launch: both readout GEMMs and the merge -> two-layer chain role in ONE grid ----
@@ -1188,7 +1214,21 @@ static int r16_build(const void* a, const void* w, const void* b, int32_t b_dt,
         const bool y16 = y && y_dt != HICOM_DT_F32;
         p.line16 = (N % 8 == 0 && ((out_f16 && !y && (uintptr_t)out_f16 % 16 == 0) || (!out_f16 && y16 && (uintptr_t)y % 16 == 0 && ldy % 8 == 0))) ? 1 : 0;
     }
-    const int nbx = (N + kRN - 1) / kRN, nby = (M + kRM - 1) / kRM;
+    // tile width: 64 columns, or -- wide layers whose 64-column grid is more ROUNDS of one-per-CU workgroups than the 128-column grid --
+    // 128 (HICOM_R16_TN = 64 | 128 forces one: A/B switch)
+    const int nby = (M + kRM - 1) / kRM;
+    int tn = kRN;
+    if (!role_only && N % 128 == 0) {
+        static int tn_env = -1;
+        if (tn_env < 0) {
+            const char* e = getenv("HICOM_R16_TN");
+            tn_env = (e && !strcmp(e, "128")) ? 128 : (e && !strcmp(e, "64")) ? 64 : 0;
+        }
+        const int t64 = nby * (N / 64), t128 = nby * (N / 128);
+        if (tn_env == 128 || (tn_env == 0 && (t128 + 255) / 256 < (t64 + 255) / 256)) tn = 128;
+    }
+    p.tn = tn;
+    const int nbx = (N + tn - 1) / tn;
     p.n_gemm = role_only ? 0 : 8 * ((nbx * nby + 7) / 8);
     n_aux = 0;
     const AuxGemv none{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, 0, 0, 0, nullptr};
@@ -1283,11 +1323,14 @@ static int readout16_launch(const void* a, const void* w, const void* b, int32_t
     // 8 ring stages (160 KB: one workgroup per CU); 6 stages measured 0.5 us slower per GEMM (tools/gpu_round_c.sh, round 2)
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(readout16_gemm_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kRStage);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(readout16_gemm_kernel<8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kRStage);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(readout16_gemm_kernel<5, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kRStage);
         attr_set = true;
     }
     // role workgroups first in dispatch order would delay tiles on their CUs; they go last and land on the free CUs
-    HICOM_LAUNCH(readout16_gemm_kernel<8>, dim3((unsigned)(p.n_gemm + n_aux)), dim3(256), 8 * kRStage, (hipStream_t)stream, p);
+    // (both forms ask for the whole 160 KB: one workgroup per CU, and the roles use it)
+    if (p.tn == 128) HICOM_LAUNCH((readout16_gemm_kernel<5, 128>), dim3((unsigned)(p.n_gemm + n_aux)), dim3(256), 8 * kRStage, (hipStream_t)stream, p);
+    else HICOM_LAUNCH((readout16_gemm_kernel<8, 64>), dim3((unsigned)(p.n_gemm + n_aux)), dim3(256), 8 * kRStage, (hipStream_t)stream, p);
     return hicom_host::check_launch("readout16_gemm");
 }
 
@@ -1340,7 +1383,7 @@ extern "C" int hicom_readout_tail_fwd(const hicom_r16_gemm* g1, const hicom_r16_
     if (int rc = r16_build(g2->a, g2->w, g2->b, g2->b_dt, g2->M, g2->N, g2->K, g2->act, nullptr, g2->y, g2->y_dt, g2->ldy, g2->row0, g2->nl_group, chain,
                            kTailRole, q.g2, na2)) return rc;
     const int nby = (g1->M + kRM - 1) / kRM, nbx = g1->N / kRN, items = (q.g1.mv.E / 64) * (q.g1.mv.E / q.g1.mv.hd);
-    HICOM_REQUIRE(q.g1.line16 && q.g2.line16 && g1->N % kRN == 0 && g2->N == g1->N && g2->K / 64 >= 8 + 6 && nby + 2 <= kTailSyncLines &&
+    HICOM_REQUIRE(q.g1.line16 && q.g2.line16 && q.g1.tn == kRN && q.g2.tn == kRN && g1->N % kRN == 0 && g2->N == g1->N && g2->K / 64 >= 8 + 6 && nby + 2 <= kTailSyncLines &&
                       nbx * nby <= kTailFlags && q.g1.n_gemm + kTailRole <= 256 && items <= kMvRoleItems * kTailRole && q.g1.mv.wv,
                   HICOM_EUNSUP, "readout_tail: shape outside the fused form (two layers of the same width in whole 64-column tiles, K2 >= 896, "
                                 "<= 202 tiles, <= 162 merge items)");

@@ -463,7 +463,9 @@ def test_local_attn_fp32_streams():
 
 # ---- round 2: fp16 readout GEMM (+ co-scheduled GEMV), fused merge + v_proj -------------------------------------------
 @pytest.mark.parametrize("M,N,K,act", [(8, 64, 1152, 1), (81, 896, 1152, 1), (130, 64, 64, 0), (1296, 896, 896, 0), (1296, 896, 1152, 1),
-                                       (648, 3584, 1152, 1), (97, 200, 128, 0)])
+                                       (648, 3584, 1152, 1), (97, 200, 128, 0),
+                                       # round 5: 128-column tiles (chosen when they take fewer rounds of one-per-CU workgroups)
+                                       (648, 3584, 3584, 0), (1296, 3584, 3584, 1), (1300, 2176, 192, 0)])
 def test_readout16_gemm_matches_torch(M, N, K, act):
     """fp16-plane GEMM against fp64 torch on the SAME fp16-rounded operands (the kernel's arithmetic: exact products,
     fp32 accumulation), both output forms (fp16 plane, packed rows with a newline gap)."""
@@ -489,6 +491,27 @@ def test_readout16_gemm_matches_torch(M, N, K, act):
     untouched = torch.ones(y.shape[0], dtype=torch.bool, device="cuda")
     untouched[rows] = False
     assert bool(torch.isnan(y[untouched]).all())
+
+
+@pytest.mark.parametrize("M,N,K", [(648, 3584, 1152), (1296, 3584, 3584), (1296, 896, 1152)])
+def test_readout16_row_line_epilogue_equals_the_general_one(M, N, K):
+    """One 16-bit output (the fp16 plane alone, or packed bf16 rows alone) leaves through the row-line epilogue (LDS image, 16-byte
+    stores); both outputs at once through the general one.  Same values: the plane bit for bit, the bf16 rows = the rounded f32 rows.
+    (N = 3584: 128-column tiles; N = 896: 64-column tiles.)"""
+    g = torch.Generator().manual_seed(M + N + K)
+    a16 = nv.to_f16((torch.randn(M, K, generator=g) * 0.7).cuda())
+    w16 = nv.to_f16(bf(torch.randn(N, K, generator=g) * 0.02))
+    b = bf(torch.randn(N, generator=g) * 0.02)
+    o_ref = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    y_ref = torch.zeros(M + M // 9 + 3, N, device="cuda")
+    nv.readout16_gemm(a16, w16, b, act=nv.ACT_GELU, out_f16=o_ref, y=y_ref, row0=2, nl_group=9)
+    o16 = torch.empty_like(o_ref)
+    nv.readout16_gemm(a16, w16, b, act=nv.ACT_GELU, out_f16=o16)
+    y16 = torch.zeros(M + M // 9 + 3, N, device="cuda", dtype=torch.bfloat16)
+    nv.readout16_gemm(a16, w16, b, act=nv.ACT_GELU, y=y16, row0=2, nl_group=9)
+    torch.cuda.synchronize()
+    assert torch.equal(o16, o_ref)
+    assert torch.equal(y16, y_ref.to(torch.bfloat16))
 
 
 def test_readout16_aux_gemv_and_merge_vproj():
