@@ -309,7 +309,11 @@ def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: in
     else:
         out = torch.empty((plan.n_rows_total, plan.hidden), dtype=plan.odt, device=dev)
         out.record_stream(comm)
-    main.wait_event(st.ev_tok)                     # this buffer set's previous exchange (two steps ago) has drained
+    # this buffer set's previous exchange (two steps ago) has drained.  In the steady state it has long done so: ask the event on the
+    # host first -- a wait that is not needed still costs the main stream a barrier packet (a 4-5 us bubble in its launch pipeline,
+    # DESIGN.md §3.1 "speculative query prep")
+    if not st.ev_tok.query():
+        main.wait_event(st.ev_tok)
     plan.set_inputs(st, ff_shard, fe_shard, guide_embed, out)
     # main: prep, stream kernel, readout GEMMs, ev_stream; the comm stream waits for it and merges the partials -> state
     nv.compressor_fwd(st.a_stream)
