@@ -729,6 +729,11 @@ extern "C" int hicom_global_stream_has_marg(int64_t N, int32_t E, int32_t rows_p
     if (force_narrow && force_narrow[0] == '1') return 0;
     const char* no_marg = getenv("HICOM_GLOBAL_NO_MARG");          // dev / A-B switch: logit tensor + marginal pass (the round-3 path)
     if (no_marg && no_marg[0] == '1') return 0;
+    // (the merge behind it keeps its weight record -- 2 + nparts + T + H + W floats per row -- in the head of the row's scratch region of
+    // T (H + W + 2) floats, hicom_global_merge_marg_fwd: a single image, T = 1, has no room for it and takes the logit-tensor form)
+    if (N % ((long)H * W) != 0) return 0;
+    const long T = N / ((long)H * W);
+    if (2 + (long)nparts + T + H + W > T * (H + W + 2)) return 0;
     return (wide_ok(N, E, rows_pad, H, W, nparts) && 1 + (H + 15) / 16 + (W + 15) / 16 <= 4 * kWideMargBlocks) ? 1 : 0;
 }
 

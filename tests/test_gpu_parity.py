@@ -811,3 +811,86 @@ def test_sharded_stepwise_recipes_emulated_on_one_gpu(recipe, world, newline):
         ref = orc.projector_forward(cfg, sdt, ff.float().cpu(), fe.float().cpu(), g.float().cpu(), "video",
                                     None if nl is None else nl.float().cpu())
         assert float((got.float().cpu() - ref).abs().max()) <= TOL
+
+
+@pytest.mark.parametrize("ptype,mode,guide_len,T,h,w,modal,newline", [
+    ("local43", "coarse", 0, 4, 6, 6, "video", False),            # local stage alone: the call's local chain injects
+    ("local43", "fine", 17, 8, 9, 6, "video", False),             # fewer than 64 text tokens
+    ("global32", "fine", 64, 4, 6, 6, "video", False),            # global stage alone
+    ("global16", "coarse", 0, 3, 5, 7, "video", False),
+    ("local43_global32", "coarse", 0, 1, 6, 9, "image", True),    # image modal with the newline token (T = 1: the logit-tensor form of the merge)
+    ("local43_global32", None, 0, 1, 9, 6, "image", False),       # guide off on a single image (found broken by the case above: round 5 fix)
+    ("local43_global32", None, 0, 2, 27, 27, "video", False),
+    ("local22_global8", "fine", 40, 6, 8, 8, "video", False)])
+def test_in_call_injection_shapes_against_the_oracle(ptype, mode, guide_len, T, h, w, modal, newline):
+    """Round 5: coarse / fine injection run by hicom_compressor_fwd itself (`inj_l` / `inj_g`) on configurations the golden set does not
+    hold: one stage alone, short guides, image inputs with the newline token, other window / query geometries -- against the pinned
+    oracle (tolerance of the golden cases) and against the operator-by-operator path."""
+    from types import SimpleNamespace
+    from hicom_amd import synth
+    from oracle import hicom_oracle as orc
+    tag = f"inj:{ptype}:{mode}:{T}:{h}:{w}"
+    cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "mm_projector_type": ptype, "use_guide": mode,
+                             "mm_newline_position": "grid" if newline else cases.DEFAULT_CFG.get("mm_newline_position", "no_token")})
+    sd = synth.synth_state_dict(orc.param_shapes(cfg), tag=tag)
+    x = synth.synth_inputs(T, h, w, cases.D, tag=tag, guide_len=guide_len)
+    nl_np = synth.normal_like((cfg.hidden_size,), synth.seed_of(tag + ":newline")) if newline else None
+    case = SimpleNamespace(cfg=cfg, sd=sd, ff=x["ff"], fe=x["fe"], g=x["g"], modal=modal, newline=nl_np, anyres=None, logit=None)
+    m = build_module(case)
+    assert m._executor_covers() and not m._external_queries()
+    ff, fe, g, nl = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g), dev_bf16(case.newline)
+    with torch.no_grad():
+        got = m(ff, fe, g, modal, nl)
+        step = m.forward_stepwise(ff, fe, g, modal, nl)
+    want = run_oracle(case)["out"].numpy()
+    assert got.shape == step.shape == tuple(want.shape)
+    assert float((got - step).abs().max()) <= PATH_TOL
+    assert np.abs(got.float().cpu().numpy() - want).max() <= TOL
+
+
+@pytest.mark.parametrize("seed,large,count,need", [(20251004, False, 28, 18), (7, False, 28, 16), (99, True, 10, 6)])
+def test_random_configuration_sweep_against_the_oracle(seed, large, count, need):
+    """Seeded sweep over (geometry, projector type, injection mode, modal, newline position): the drop-in forward against the pinned
+    oracle on configurations nobody wrote down -- single images, tiny grids, odd frame counts, one stage alone.  Where the oracle
+    (= the reference's behaviour) raises, the HIP path must raise too; everywhere else: same shape, max-abs <= 1e-3."""
+    import random
+    from types import SimpleNamespace
+    from hicom_amd import synth
+    from oracle import hicom_oracle as orc
+    rng = random.Random(seed)
+    ptypes = ["local43_global32", "local43_global32", "local22_global8", "local41_global16", "local43", "global32", "local23_global4"]
+    ran = raised = 0
+    for k in range(count):
+        ptype = rng.choice(ptypes)
+        mode = rng.choice(["direct", None, "coarse", "fine", "direct"])
+        modal = rng.choice(["video", "video", "image"])
+        T = 1 if modal == "image" else rng.choice([1, 4, 8, 16] if large else [1, 2, 3, 4, 5, 8, 12])
+        h, w = (rng.choice([9, 14, 27]), rng.choice([9, 18, 27])) if large else (rng.choice([2, 3, 4, 6, 7, 9, 12]), rng.choice([2, 3, 5, 6, 8, 9]))
+        nlpos = rng.choice(["no_token", "grid", "frame", "one_token"])
+        merge = rng.choice(["spatial_unpad", "flat"])
+        glen = rng.choice([5, 33, 64]) if mode == "fine" else 0
+        tag = f"sweep{seed}:{k}" if seed != 20251004 else f"sweep{k}"
+        cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "mm_projector_type": ptype, "use_guide": mode, "mm_newline_position": nlpos,
+                                 "mm_patch_merge_type": merge})
+        sd = synth.synth_state_dict(orc.param_shapes(cfg), tag=tag)
+        x = synth.synth_inputs(T, h, w, cases.D, tag=tag, guide_len=glen)
+        nl_np = synth.normal_like((cfg.hidden_size,), synth.seed_of(tag + ":newline"))
+        case = SimpleNamespace(cfg=cfg, sd=sd, ff=x["ff"], fe=x["fe"], g=x["g"], modal=modal, newline=nl_np, anyres=None, logit=None)
+        what = (k, ptype, mode, modal, T, h, w, nlpos, merge, glen)
+        try:
+            want = run_oracle(case)["out"].numpy()
+        except Exception as e:                                        # the reference refuses this geometry (e.g. 5 frames under a 4-frame kernel)
+            m = build_module(case)
+            with pytest.raises(Exception):
+                with torch.no_grad():
+                    m(dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g), modal, dev_bf16(case.newline))
+            raised += 1
+            continue
+        m = build_module(case)
+        with torch.no_grad():
+            got = m(dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g), modal, dev_bf16(case.newline))
+        assert tuple(got.shape) == tuple(want.shape), what
+        err = float(np.abs(got.float().cpu().numpy() - want).max())
+        assert err <= TOL, (what, err)
+        ran += 1
+    assert ran >= need, (ran, raised)
