@@ -438,3 +438,89 @@ def test_graph_backward_follows_weight_updates_between_steps(name, how):
                     pb.data.copy_(new)
     ents = list(ma.__dict__.get("_bwd_graphs", {}).values())
     assert ents and all("graph" in e for e in ents), [e.get("failed") for e in ents]
+
+
+@pytest.mark.parametrize("seed,count", [(11, 14), (23, 14)])
+def test_random_backward_sweep_against_the_oracle_autograd(seed, count):
+    """Seeded sweep of the backward over configurations no fixture holds -- geometry, projector type, injection mode, modal, newline,
+    dense and anyres dict inputs -- against torch autograd THROUGH the oracle (pinned to the reference's autograd by
+    tests/test_oracle_golden.py::test_oracle_autograd_reproduces_the_reference_gradients).  Every parameter gradient: max-abs <=
+    2e-3 of the parameter's largest entry (or 1e-5 of the case's largest), as in the fixture test; input gradients where built."""
+    import random
+    from types import SimpleNamespace
+    from hicom_amd import autograd as hag
+    from hicom_amd import synth
+    from oracle import hicom_oracle as orc
+    from oracle_util import oracle_grads
+    rng = random.Random(seed)
+    ran = 0
+    for k in range(count):
+        ptype = rng.choice(["local43_global32", "local43_global32", "local22_global8", "local43", "global32", "local43_adaptkv_global32",
+                            "local23_global4"])
+        mode = rng.choice(["direct", None, "coarse", "fine", "direct"])
+        modal = rng.choice(["video", "video", "image"])
+        T = 1 if modal == "image" else rng.choice([1, 4, 8, 12])
+        h, w = rng.choice([3, 6, 9, 12]), rng.choice([3, 6, 9])
+        anyres = modal == "image" and rng.random() < 0.5 and "local" in ptype
+        nlpos = rng.choice(["no_token", "grid", "one_token"])
+        glen = rng.choice([9, 64]) if mode == "fine" else 0
+        tag = f"bwd{seed}:{k}"
+        cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "mm_projector_type": ptype, "use_guide": mode, "mm_newline_position": nlpos})
+        sd = synth.synth_state_dict(orc.param_shapes(cfg), tag=tag)
+        x = synth.synth_inputs(T, h, w, cases.D, tag=tag, guide_len=glen)
+        nl_np = synth.normal_like((cfg.hidden_size,), synth.seed_of(tag + ":newline")) if (nlpos != "no_token" or anyres) else None
+        ar = None
+        if anyres:
+            pz = synth.synth_inputs(1, rng.choice([6, 9]), rng.choice([6, 12]), cases.D, tag=tag + ":patch")
+            ar = dict(patch_ff=pz["ff"][0], patch_fe=pz["fe"][0], no_base=rng.random() < 0.3)
+        case = SimpleNamespace(cfg=cfg, sd=sd, ff=x["ff"], fe=x["fe"], g=x["g"], modal=modal, newline=nl_np, anyres=ar, logit=None)
+        what = (seed, k, ptype, mode, modal, T, h, w, anyres, nlpos)
+        try:
+            shape = tuple(orc.projector_forward(cfg, {n: torch.from_numpy(v) for n, v in sd.items()},
+                                                *(({"base": None if ar["no_base"] else torch.from_numpy(x["ff"])[0], "patch": torch.from_numpy(ar["patch_ff"])},
+                                                   {"base": None if ar["no_base"] else torch.from_numpy(x["fe"])[0], "patch": torch.from_numpy(ar["patch_fe"])})
+                                                  if ar else (torch.from_numpy(x["ff"]), torch.from_numpy(x["fe"]))),
+                                                None if x["g"] is None else torch.from_numpy(x["g"]), modal,
+                                                None if nl_np is None else torch.from_numpy(nl_np)).shape)
+        except Exception:
+            continue                                                  # a geometry the reference refuses
+        cot = synth.normal_like(shape, synth.seed_of(tag + ":cot"))
+        m = build_module(case).train()
+        lc = m.local_compressor
+        exact = lc is None or all(a.nwin * a.k == a.n for a in lc.tilings(T, h, w, modal))
+        uses_guide = mode in ("direct", "coarse", "fine")
+        inputs = []
+        ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+        nl = torch.nn.Parameter(dev_bf16(nl_np)) if nl_np is not None else None
+        if not anyres:
+            if uses_guide:
+                g.requires_grad_(True)
+                inputs.append(("__guide_embed__", g))
+            if exact and lc is not None and not (lc.adapt_k or lc.adapt_v) or (exact and lc is not None and uses_guide):
+                fe.requires_grad_(True)
+                inputs.append(("__frames_embed__", fe))
+        if anyres:
+            f_in = {"base": None if ar["no_base"] else ff[0], "patch": dev_bf16(ar["patch_ff"])}
+            e_in = {"base": None if ar["no_base"] else fe[0], "patch": dev_bf16(ar["patch_fe"])}
+        else:
+            f_in, e_in = ff, fe
+        out = m(f_in, e_in, g, modal, nl)
+        assert tuple(out.shape) == shape, what
+        (out * torch.from_numpy(cot).cuda()).sum().backward()
+        fp32 = dict(hag.LAST_FP32_GRADS)
+        _, want = oracle_grads(case, cot, tuple(n for n, _ in inputs))
+        assert float(np.abs(out.detach().float().cpu().numpy() - _.numpy()).max()) <= 1e-3, what
+        mx_case = max(float(v.abs().max()) for v in want.values() if v is not None)
+        items = [(n, p) for n, p in m.named_parameters()] + ([("image_newline", nl)] if nl is not None else []) + inputs
+        for n, p in items:
+            w_ = want.get(n)
+            if w_ is None or float(w_.abs().max()) == 0.0:
+                assert p.grad is None or float(p.grad.float().abs().max()) <= 1e-6 * max(mx_case, 1.0), (what, n)
+                continue
+            assert p.grad is not None, (what, n)
+            got = (fp32[n] if n in fp32 else p.grad).float().cpu().reshape(w_.shape)
+            mx = float(w_.abs().max())
+            tol = max(2e-3 * mx, 1e-5 * mx_case) + 1e-6 + (2.0 ** -7 * mx if n not in fp32 else 0.0)
+            assert float((got - w_).abs().max()) <= tol, (what, n, float((got - w_).abs().max()), tol)
+        ran += 1
+    assert ran >= 9, ran

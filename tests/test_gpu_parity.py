@@ -894,3 +894,66 @@ def test_random_configuration_sweep_against_the_oracle(seed, large, count, need)
         assert err <= TOL, (what, err)
         ran += 1
     assert ran >= need, (ran, raised)
+
+
+@pytest.mark.parametrize("hidden,T,mode,fp32_out", [(64, 4, "direct", True), (128, 8, None, False), (1024, 4, "direct", True), (1536, 8, "direct", False),
+                                                     (2048, 16, "direct", False), (2048, 32, None, True), (3584, 32, "direct", False), (3584, 8, "coarse", False),
+                                                     (3584, 64, "direct", True), (4096, 32, "direct", False)])
+def test_hidden_width_sweep_against_the_oracle(hidden, T, mode, fp32_out):
+    """LLM widths other than the benchmark's 896 on the real 27 x 27 grid: every readout form (fp16 planes with 64- and 128-column
+    tiles, the chain role up to 1536, the GEMV role above), bf16 and fp32 rows.  (Widths that are no multiple of 64 are refused by
+    the one-call executor with a message -- no LLM has one.)"""
+    from types import SimpleNamespace
+    from hicom_amd import synth
+    from oracle import hicom_oracle as orc
+    tag = f"width:{hidden}:{T}:{mode}"
+    cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "hidden_size": hidden, "use_guide": mode, "max_num_frames": max(T, 32)})
+    sd = synth.synth_state_dict(orc.param_shapes(cfg), tag=tag)
+    x = synth.synth_inputs(T, 27, 27, cases.D, tag=tag)
+    case = SimpleNamespace(cfg=cfg, sd=sd, ff=x["ff"], fe=x["fe"], g=x["g"], modal="video", newline=None, anyres=None, logit=None)
+    m = build_module(case, fp32_out=fp32_out)
+    with torch.no_grad():
+        got = m(dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g), "video", None)
+        again = m(dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g), "video", None)
+    want = run_oracle(case)["out"].numpy()
+    assert tuple(got.shape) == tuple(want.shape) and got.dtype == (torch.float32 if fp32_out else torch.bfloat16)
+    assert torch.equal(got, again)
+    tol = TOL if fp32_out else TOL + 2.0 ** -8 * float(np.abs(want).max())          # (+ the bf16 rounding of the rows)
+    assert float(np.abs(got.float().cpu().numpy() - want).max()) <= tol
+
+
+def test_random_anyres_sweep_against_the_oracle():
+    """Seeded sweep over anyres dict inputs (reference projector.py:679-689): base image (or none) + patch grid of another size, every
+    injection mode, both merge types -- the operator-by-operator path against the pinned oracle."""
+    import random
+    from types import SimpleNamespace
+    from hicom_amd import synth
+    from oracle import hicom_oracle as orc
+    rng = random.Random(4242)
+    ran = 0
+    for k in range(14):
+        ptype = rng.choice(["local43_global32", "local22_global8", "local43", "local43_global32"])
+        mode = rng.choice(["direct", None, "coarse", "fine"])
+        h, w = rng.choice([3, 6, 9]), rng.choice([3, 6, 9])
+        ph, pw = rng.choice([3, 6, 9, 12]), rng.choice([6, 9, 12, 18])
+        no_base = rng.random() < 0.3
+        glen = rng.choice([7, 64]) if mode == "fine" else 0
+        merge = rng.choice(["spatial_unpad", "flat"])
+        tag = f"anyres{k}"
+        cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "mm_projector_type": ptype, "use_guide": mode, "mm_patch_merge_type": merge})
+        sd = synth.synth_state_dict(orc.param_shapes(cfg), tag=tag)
+        x = synth.synth_inputs(1, h, w, cases.D, tag=tag, guide_len=glen)
+        pz = synth.synth_inputs(1, ph, pw, cases.D, tag=tag + ":patch")
+        nl_np = synth.normal_like((cfg.hidden_size,), synth.seed_of(tag + ":newline"))
+        case = SimpleNamespace(cfg=cfg, sd=sd, ff=x["ff"], fe=x["fe"], g=x["g"], modal="image", newline=nl_np, logit=None,
+                               anyres=dict(patch_ff=pz["ff"][0], patch_fe=pz["fe"][0], no_base=no_base))
+        what = (k, ptype, mode, h, w, ph, pw, no_base, merge)
+        try:
+            want = run_oracle(case)["out"].numpy()
+        except Exception:
+            continue
+        got = run_native(case)["out"].float().cpu().numpy()
+        assert got.shape == want.shape, what
+        assert float(np.abs(got - want).max()) <= TOL, what
+        ran += 1
+    assert ran >= 9, ran
