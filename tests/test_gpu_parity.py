@@ -957,3 +957,26 @@ def test_random_anyres_sweep_against_the_oracle():
         assert float(np.abs(got - want).max()) <= TOL, what
         ran += 1
     assert ran >= 9, ran
+
+
+@pytest.mark.parametrize("name", ["G2_off_T8", "G6_coarse", "G7_fine", "G5b_adaptqkvg_off", "G5_adaptkv"])
+def test_graph_replay_of_the_other_recipes_equals_eager(name):
+    """hipGraph capture / replay of the plans of the non-release recipes: guide off (folded queries kept across calls), coarse / fine
+    (injector chains inside the C call), query adaptors (their producers are captured in front of the call), k / v adaptors -- the
+    replayed result follows the inputs of each call and equals the eager one bit for bit."""
+    case = cases.build_case(name)
+    m = build_module(case)
+    ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+    ff2 = (ff.float() * 0.5 + 0.1).to(ff.dtype)
+    with torch.no_grad():
+        want, want2 = m(ff, fe, g, case.modal, None).clone(), m(ff2, fe, g, case.modal, None).clone()
+        m.graph_replay = True
+        try:
+            a, b, c = m(ff, fe, g, case.modal, None), m(ff2, fe, g, case.modal, None), m(ff, fe, g, case.modal, None)
+            a2 = m(ff, fe, g, case.modal, None)
+            torch.cuda.synchronize()
+        finally:
+            m.graph_replay = False
+            m._invalidate_plans()
+    assert torch.equal(a, want) and torch.equal(c, want) and torch.equal(a2, want) and torch.equal(b, want2)
+    assert not torch.equal(want, want2)
