@@ -980,3 +980,37 @@ def test_graph_replay_of_the_other_recipes_equals_eager(name):
             m._invalidate_plans()
     assert torch.equal(a, want) and torch.equal(c, want) and torch.equal(a2, want) and torch.equal(b, want2)
     assert not torch.equal(want, want2)
+
+
+def test_random_shard_emulation_sweep():
+    """Seeded sweep of the frame-sharded device path (see _emulate_ranks) over world sizes, frames per rank, grids, hidden widths and the
+    guide-off / direct / k-v-adaptor recipes the executor's STREAM / FINISH phases run: every emulated world against the dense forward
+    of all frames."""
+    import random
+    from types import SimpleNamespace
+    from hicom_amd import synth
+    from oracle import hicom_oracle as orc
+    rng = random.Random(77)
+    for k in range(10):
+        world = rng.choice([2, 3, 4, 8])
+        per = 4 * rng.choice([1, 2, 4])
+        h, w = rng.choice([(27, 27), (9, 9), (6, 12), (27, 27)])
+        ptype, mode = rng.choice([("local43_global32", "direct"), ("local43_global32", None), ("local43_adaptkv_global32", "direct"),
+                                  ("local43_global32", "direct")])
+        hidden = rng.choice([64, 896, 3584]) if (h, w) == (27, 27) else 64
+        T = world * per
+        tag = f"shard{k}"
+        cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "mm_projector_type": ptype, "use_guide": mode, "hidden_size": hidden,
+                                 "max_num_frames": max(T, 32)})
+        sd = synth.synth_state_dict(orc.param_shapes(cfg), tag=tag)
+        m = build_module(SimpleNamespace(cfg=cfg, sd=sd))
+        gen = torch.Generator(device="cuda").manual_seed(500 + k)
+        ff = torch.randn(T, h, w, 1152, device="cuda", generator=gen).bfloat16()
+        fe = torch.randn(T, h, w, 1152, device="cuda", generator=gen).bfloat16()
+        g = torch.randn(1152, device="cuda", generator=gen).bfloat16()
+        with torch.no_grad():
+            want = m(ff, fe, g, "video", None)
+            got = _emulate_ranks(m, ff, fe, g, world, rng.randrange(world))
+        what = (k, world, per, h, w, ptype, mode, hidden)
+        assert got.shape == want.shape and bool(torch.isfinite(got).all()), what
+        assert float((got - want).abs().max()) <= PATH_TOL * max(1.0, float(want.abs().max())), (what, float((got - want).abs().max()))
