@@ -1014,3 +1014,49 @@ def test_random_shard_emulation_sweep():
         what = (k, world, per, h, w, ptype, mode, hidden)
         assert got.shape == want.shape and bool(torch.isfinite(got).all()), what
         assert float((got - want).abs().max()) <= PATH_TOL * max(1.0, float(want.abs().max())), (what, float((got - want).abs().max()))
+
+
+def test_random_clip_scale_sweep_against_the_oracle():
+    """Seeded sweep of the clip-scale variants (reference projector.py:184-191, :527-529, :549) through HIComProjector.forward: which
+    stages use the SigLIP logits, their values, injection mode, adaptors, geometry -- against the oracle's projector forward."""
+    import random
+    import hicom_amd
+    from types import SimpleNamespace
+    from hicom_amd import synth
+    from oracle import hicom_oracle as orc
+    from oracle_util import to_t
+    rng = random.Random(909)
+    ran = 0
+    for k in range(16):
+        ptype = rng.choice(["local43_global32", "local43_global32", "local22_global8", "local43_adaptkv_global32", "local43", "global32"])
+        mode = rng.choice(["direct", None, "coarse", "fine", "direct"])
+        which = rng.choice(["local", "global", "local,global"])
+        T, h, w = rng.choice([1, 4, 8]), rng.choice([3, 6, 9]), rng.choice([3, 6, 9])
+        glen = rng.choice([5, 64]) if mode == "fine" else 0
+        q16 = lambda lo, hi: round(rng.uniform(lo, hi) * 16) / 16            # (bf16-representable: the module keeps its logit parameters in bf16)
+        logit = {"local": (q16(0.5, 2.5), q16(-4, 1)), "global": (q16(0.5, 2.5), q16(-4, 1))}
+        tag = f"clip{k}"
+        cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, "mm_projector_type": ptype, "use_guide": mode, "use_clip_scale": which})
+        sd = synth.synth_state_dict(orc.param_shapes(cfg), tag=tag)
+        x = synth.synth_inputs(T, h, w, cases.D, tag=tag, guide_len=glen)
+        what = (k, ptype, mode, which, T, h, w)
+        used = {s: tuple(torch.tensor(v) for v in logit[s]) for s in ("local", "global") if s in which.split(",")}
+        try:
+            want = orc.projector_forward(cfg, {n: to_t(v) for n, v in sd.items()}, to_t(x["ff"]), to_t(x["fe"]), to_t(x["g"]), "video", None,
+                                         logit=used).numpy()
+        except Exception:
+            continue
+        m = hicom_amd.build_vision_projector(cfg)
+        m.load_state_dict({n: torch.from_numpy(v.copy()) for n, v in sd.items()}, strict=False)
+        m = m.to(torch.bfloat16).cuda().eval()
+        m.return_fp32 = True
+        for sub in (m.local_compressor, m.global_compressor):
+            if sub is not None:
+                sub.return_fp32 = True
+        m.set_clip_logits(local=logit["local"] if "local" in which else None, glob=logit["global"] if "global" in which else None)
+        with torch.no_grad():
+            got = m(dev_bf16(x["ff"]), dev_bf16(x["fe"]), dev_bf16(x["g"]), "video", None).float().cpu().numpy()
+        assert got.shape == want.shape, what
+        assert float(np.abs(got - want).max()) <= TOL, (what, float(np.abs(got - want).max()))
+        ran += 1
+    assert ran >= 10, ran
