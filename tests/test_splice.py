@@ -195,3 +195,59 @@ def test_hip_splice_input_validation():
     mask = torch.ones(1, S, dtype=torch.long).cuda()
     with pytest.raises(RuntimeError, match="negative dimension"):
         prepare_inputs_labels_for_multimodal(emb, ids, mask, None, ids.clamp(min=0), [torch.zeros(0, H, dtype=torch.bfloat16).cuda()])
+
+
+@pytest.mark.gpu
+def test_hip_splice_random_sweep_against_the_oracle():
+    """Seeded sweep of `prepare_inputs_labels_for_multimodal` (hicom_arch.py:283-372): batch sizes, prompt lengths, 0..3 placeholders per
+    sample of all three modal tokens (also adjacent, first and last position), feature row counts incl. zero rows, text-only samples
+    between multimodal ones, with / without labels and mask -- bit-exact embeddings, labels and mask against the splice oracle."""
+    import random
+    from hicom_amd.splice import prepare_inputs_labels_for_multimodal
+    rng = random.Random(31337)
+    V, H = 300, 64
+    gw = torch.Generator().manual_seed(2)
+    weight = torch.randn(V, H, generator=gw).to(torch.bfloat16)
+    emb = torch.nn.Embedding(V, H).to(torch.bfloat16).cuda()
+    emb.weight.data.copy_(weight)
+    emb.weight.requires_grad_(False)
+    ran = 0
+    for k in range(40):
+        B, S = rng.choice([1, 2, 3, 5]), rng.choice([4, 9, 33, 128])
+        ids = torch.randint(0, V, (B, S), generator=gw)
+        feats = []
+        for b in range(B):
+            nph = rng.choice([0, 1, 1, 2, 3])
+            if nph == 0:
+                feats.append(torch.randn(rng.choice([0, 3]), H, generator=gw).to(torch.bfloat16))       # a text-only sample still consumes one entry (:290-299)
+                continue
+            pos = sorted(rng.sample(range(S), min(nph, S)))
+            if rng.random() < 0.3:
+                pos[0] = 0
+            if rng.random() < 0.3:
+                pos[-1] = S - 1
+            for p_ in sorted(set(pos)):
+                ids[b, p_] = rng.choice([-200, -201, -202])
+                feats.append(torch.randn(rng.choice([0, 1, 7, 40]), H, generator=gw).to(torch.bfloat16))
+        with_labels = rng.random() < 0.7
+        with_mask = with_labels and rng.random() < 0.7            # (a mask without labels on a ragged batch is the reference's UnboundLocalError)
+        labels = torch.where(ids >= 0, ids, torch.full_like(ids, -100)) if with_labels else None
+        mask = None
+        if with_mask:
+            mask = torch.ones(B, S, dtype=torch.long)
+            for b in range(B):
+                mask[b, S - rng.randrange(0, min(S, 4)):] = 0
+        try:
+            wm, we, wl = so.splice(weight.float(), ids, mask, labels, [f.float() for f in feats])
+        except RuntimeError:
+            continue          # (the reference cannot build the mask of a sample that SHRANK -- a placeholder with zero feature rows, :354-363)
+        ran += 1
+        d = lambda t: None if t is None else t.cuda()
+        with torch.no_grad():
+            _, m, _, e, l = prepare_inputs_labels_for_multimodal(emb, d(ids), d(mask), None, d(labels), [f.cuda() for f in feats])
+        torch.cuda.synchronize()
+        what = (k, B, S, with_labels, with_mask)
+        assert tuple(e.shape) == tuple(we.shape) and torch.equal(e.float().cpu(), we), what
+        assert (l is None) == (wl is None) and (l is None or torch.equal(l.cpu(), wl)), what
+        assert (m is None) == (wm is None) and (m is None or torch.equal(m.cpu().to(wm.dtype), wm)), what
+    assert ran >= 30, ran
