@@ -63,7 +63,7 @@ struct R16Params {
     int nl_group;
     int vec, bvec;
     int line16;             // exactly one 16-bit output whose tile rows are whole 16-byte aligned 128-byte lines: the row-line epilogue
-    int tn;                 // tile width the host chose (64 | 128): selects the kernel instantiation
+    int tn, tm;             // tile shape the host chose (96 x 64 | 96 x 128 | 192 x 128): selects the kernel instantiation
     int n_gemm;             // workgroups of the tile grid; blocks >= n_gemm run the role
     int role;               // HICOM_ROLE_*: what the workgroups behind the tile grid do
     AuxGemv aux;            // GEMV; first layer of GEMV_CHAIN
@@ -558,9 +558,9 @@ struct TileSync {
 };
 
 // the workgroup -> tile map of the tile grid: ordinal of the tile in the blocked order below, or -1 (the grid is rounded up to 8 x slots)
-template <int TN = kRN>
+template <int TN = kRN, int TM = kRM>
 __device__ __forceinline__ int r16_tile_of_block(const R16Params& p, int vblock) {
-    const int nbx = (p.N + TN - 1) / TN, nby = (p.M + kRM - 1) / kRM;
+    const int nbx = (p.N + TN - 1) / TN, nby = (p.M + TM - 1) / TM;
     // XCD-balanced order (speed only): workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md "Workgroup dispatch"); every
     // XCD gets a contiguous run of ~tiles/8 tiles in row-major tile order, i.e. ~2 row tiles whose A rows stay in ITS L2,
     // and -- the point -- the same number of busy CUs, so that the aux workgroups (dealt round-robin too) find a free CU
@@ -571,21 +571,25 @@ __device__ __forceinline__ int r16_tile_of_block(const R16Params& p, int vblock)
     return slot >= t_hi - t_lo ? -1 : t_lo + slot;
 }
 
-// One 96 x TN output tile of y = act(a . w^T + b) by one 256-thread workgroup (`tile` = r16_tile_of_block<TN>()).
+// One TM x TN output tile of y = act(a . w^T + b) by one 256-thread workgroup (`tile` = r16_tile_of_block<TN, TM>()).
 // TN = 64: the hot path's tile (20 KB per BK = 64 stage, 8-stage ring).  TN = 128 (round 5): for wide layers -- hidden 3584, the 7B
 // model's width -- where the 64-column grid is several rounds of workgroups: half the tiles, A staged half as often (28 KB per
-// stage, 5-stage ring); a wave owns 48 x 64 outputs.
+// stage, 5-stage ring); a wave owns 48 x 64 outputs.  TM = 192 (with TN = 128: 40-KB stages, 4-stage ring, a wave owns 96 x 64 outputs): when
+// even the 96 x 128 grid is more than one round (1296 rows at hidden 3584: 392 tiles -> 196).
 // MODE: R16_PLAIN; R16_PUBLISH = the fp16 plane leaves as write-through stores and the tile's row block counts it (the fused tail
 // launch: the plane is the next GEMM's A operand, read inside the same launch); R16_CONSUME = the A rows are such a plane: the W
 // stages of the prologue go out at entry, the A stages behind the row block's counter (`epoch` = this launch's).  A consumer that
 // `may_abandon` waits a BOUNDED time: if the row block is not complete by then it marks the tile abandoned and returns false (it
 // must not hold its CU: a publisher may still be waiting for one); otherwise it marks the tile owned.  Returns true when the tile is done.
-template <int kRRing, int MODE, int TN = kRN>
+template <int kRRing, int MODE, int TN = kRN, int TM = kRM>
 __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds, const TileSync sy, unsigned long long epoch = 0, bool may_abandon = false) {
-    static_assert(TN == 64 || TN == 128, "tile width");
+    static_assert((TN == 64 || TN == 128) && (TM == 96 || (TM == 192 && TN == 128)), "tile shape");
     constexpr int NJ = TN / 32;                              // 16-column blocks per wave (a wave owns TN / 2 columns)
-    constexpr int PW = 3 + TN / 32;                          // DMA pieces (1 KiB = 8 rows x 128 B) per wave and stage: 12 A + TN / 8 W over four waves
-    constexpr int STAGE = kRImgA + TN * 128;                 // bytes of a ring stage
+    constexpr int MI = TM / 32;                              // 16-row blocks per wave (a wave owns TM / 2 rows)
+    constexpr int AW = TM / 32;                              // A pieces per wave and stage (TM / 8 one-KiB pieces over four waves)
+    constexpr int PW = AW + TN / 32;                         // DMA pieces (1 KiB = 8 rows x 128 B) per wave and stage: TM / 8 A + TN / 8 W over four waves
+    constexpr int IMG_A = TM * 128;                          // bytes of a stage's A image
+    constexpr int STAGE = IMG_A + TN * 128;                  // bytes of a ring stage
     static_assert(kRRing * STAGE <= 160 * 1024, "ring exceeds the LDS");
     constexpr int kTrOff = MODE == R16_CONSUME ? 8 : 0;      // (dev timeline: a consumer's stamps go to slots of their own)
     (void)kTrOff;
@@ -593,7 +597,7 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int r16 = lane & 15, kg = lane >> 4;
-    const int nbx = (p.N + TN - 1) / TN, nby = (p.M + kRM - 1) / kRM;
+    const int nbx = (p.N + TN - 1) / TN, nby = (p.M + TM - 1) / TM;
     // ... in a BLOCKED order: the left half of the tile columns row by row, then the right half -- an XCD's run of ~tiles/8 tiles is a
     // ~(3.5 rows x 7 columns) patch, so both its A row blocks and its W column blocks are shared by several of its CUs and cross
     // its L2 once (row-major runs shared the A rows 14 ways and the W columns hardly at all: every CU pulled its W panel from
@@ -610,44 +614,44 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
             bx = hx + t2 - by * wx;
         }
     }
-    const int m0 = by * kRM, n0 = bx * TN;
+    const int m0 = by * TM, n0 = bx * TN;
     const int ns = p.K >> 6;
 
-    // DMA assignment: a stage is 12 + TN / 8 one-KiB pieces (8 rows x 128 B): 12 of A, then W; wave w issues pieces w, w+4, ...
+    // DMA assignment: a stage is TM / 8 + TN / 8 one-KiB pieces (8 rows x 128 B): A first, then W; wave w issues pieces w, w+4, ...
     const int prow = lane >> 3, cpos = lane & 7;
     const _Float16* src[PW];
     int dst_off[PW];
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
         const int pi = wave + 4 * i;
-        if (pi < 12) {
+        if (pi < TM / 8) {
             const int row = 8 * pi + prow;
             int m = m0 + row;
             m = m < p.M ? m : p.M - 1;
             src[i] = p.a + (long)m * p.K + 8 * (cpos ^ ((row >> 1) & 7));
         } else {
-            const int row = 8 * (pi - 12) + prow;
+            const int row = 8 * (pi - TM / 8) + prow;
             int n = n0 + row;
             n = n < p.N ? n : p.N - 1;
             src[i] = p.w + (long)n * p.K + 8 * (cpos ^ ((row >> 1) & 7));
         }
         dst_off[i] = pi * 1024;
     }
-    // (this wave's pieces 0..2 are A rows, the others W rows: wave + 4 i < 12 <=> i < 3.)  A published plane (R16_CONSUME) is read with sc1
+    // (this wave's first AW pieces are A rows, the others W rows: wave + 4 i < TM / 8 <=> i < AW.)  A published plane (R16_CONSUME) is read with sc1
     // loads: they bypass this CU's L1, the one cache a write-through store of another CU does not reach (MI355X_MICROARCH.md
     // "inter-workgroup visibility": every store of the bytes sc1 and drained, every load of them sc1 -- no acquire needed)
     constexpr int kAuxA = MODE == R16_CONSUME ? 16 : 0;
     auto issue_a = [&](int s, int ring_slot) {
         char* base = lds + ring_slot * STAGE;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < AW; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + 64 * s),
                                              (__attribute__((address_space(3))) void*)(base + dst_off[i]), 16, 0, kAuxA);
     };
     auto issue_w = [&](int s, int ring_slot) {
         char* base = lds + ring_slot * STAGE;
 #pragma unroll
-        for (int i = 3; i < PW; ++i)
+        for (int i = AW; i < PW; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + 64 * s),
                                              (__attribute__((address_space(3))) void*)(base + dst_off[i]), 16, 0, 0);
     };
@@ -665,14 +669,14 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
         else r16_wait_vm<0>();
     };
 
-    // fragments of one BK = 64 stage: two K = 32 steps x (NJ W blocks of this wave's TN / 2 columns, 3 A blocks of its 48 rows)
+    // fragments of one BK = 64 stage: two K = 32 steps x (NJ W blocks of this wave's TN / 2 columns, MI A blocks of its TM / 2 rows)
     struct Frags {
-        half8 w[2][NJ], a[2][3];
+        half8 w[2][NJ], a[2][MI];
     };
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(lds);
     const int swz = (r16 >> 1) & 7;
     const int f0off = r16 * 128 + 16 * (kg ^ swz), f1off = r16 * 128 + 16 * ((4 + kg) ^ swz);
-    const int a_base = 48 * wr * 128, w_base = kRImgA + (TN / 2) * wc * 128;
+    const int a_base = (TM / 2) * wr * 128, w_base = IMG_A + (TN / 2) * wc * 128;
 #define HICOM_LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
     auto read = [&](int ring_slot, Frags& f) {
         const unsigned st = lds0 + ring_slot * STAGE;
@@ -686,6 +690,11 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
         HICOM_LDS_RD(f.a[0][0], a0, 0);
         HICOM_LDS_RD(f.a[0][1], a0, 2048);
         HICOM_LDS_RD(f.a[0][2], a0, 4096);
+        if constexpr (MI == 6) {
+            HICOM_LDS_RD(f.a[0][MI - 3], a0, 6144);
+            HICOM_LDS_RD(f.a[0][MI - 2], a0, 8192);
+            HICOM_LDS_RD(f.a[0][MI - 1], a0, 10240);
+        }
         HICOM_LDS_RD(f.w[1][0], w1, 0);
         HICOM_LDS_RD(f.w[1][1], w1, 2048);
         if constexpr (NJ == 4) {
@@ -695,10 +704,21 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
         HICOM_LDS_RD(f.a[1][0], a1, 0);
         HICOM_LDS_RD(f.a[1][1], a1, 2048);
         HICOM_LDS_RD(f.a[1][2], a1, 4096);
+        if constexpr (MI == 6) {
+            HICOM_LDS_RD(f.a[1][MI - 3], a1, 6144);
+            HICOM_LDS_RD(f.a[1][MI - 2], a1, 8192);
+            HICOM_LDS_RD(f.a[1][MI - 1], a1, 10240);
+        }
     };
 #undef HICOM_LDS_RD
     auto land = [&](Frags& f) {
-        if constexpr (NJ == 4)
+        if constexpr (MI == 6)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(f.w[0][0]), "+v"(f.w[0][1]), "+v"(f.w[0][NJ - 2]), "+v"(f.w[0][NJ - 1]), "+v"(f.w[1][0]), "+v"(f.w[1][1]),
+                           "+v"(f.w[1][NJ - 2]), "+v"(f.w[1][NJ - 1]), "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[0][2]), "+v"(f.a[0][MI - 3]),
+                           "+v"(f.a[0][MI - 2]), "+v"(f.a[0][MI - 1]), "+v"(f.a[1][0]), "+v"(f.a[1][1]), "+v"(f.a[1][2]), "+v"(f.a[1][MI - 3]),
+                           "+v"(f.a[1][MI - 2]), "+v"(f.a[1][MI - 1])::"memory");
+        else if constexpr (NJ == 4)
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(f.w[0][0]), "+v"(f.w[0][1]), "+v"(f.w[0][NJ - 2]), "+v"(f.w[0][NJ - 1]), "+v"(f.w[1][0]), "+v"(f.w[1][1]),
                            "+v"(f.w[1][NJ - 2]), "+v"(f.w[1][NJ - 1]), "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[0][2]), "+v"(f.a[1][0]),
@@ -708,18 +728,18 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
                          : "+v"(f.w[0][0]), "+v"(f.w[0][1]), "+v"(f.w[1][0]), "+v"(f.w[1][1]), "+v"(f.a[0][0]), "+v"(f.a[0][1]),
                            "+v"(f.a[0][2]), "+v"(f.a[1][0]), "+v"(f.a[1][1]), "+v"(f.a[1][2])::"memory");
     };
-    f32x4 acc[NJ][3];
+    f32x4 acc[NJ][MI];
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto compute = [&](const Frags& f) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int i = 0; i < 3; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[ks][j], f.a[ks][i], acc[j][i], 0, 0, 0);
+                for (int i = 0; i < MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[ks][j], f.a[ks][i], acc[j][i], 0, 0, 0);
     };
 
     // prologue: stages 0 .. kRRing-2 in flight, stage 0 landed, its fragments on the way
@@ -830,7 +850,7 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
             slot_next = slot_next + 1 == kRRing ? 0 : slot_next + 1;
             slot_issue = slot_issue + 1 == kRRing ? 0 : slot_issue + 1;
         };
-        static_assert(kRRing == 8 && TN == 64, "the early-step waits are written out for an 8-stage ring of 64-column tiles");
+        static_assert(kRRing == 8 && TN == 64 && TM == 96, "the early-step waits are written out for an 8-stage ring of 96 x 64 tiles");
         early(std::integral_constant<int, 3 * 5 + PW * 0>{}, 0, f0, f1);
         early(std::integral_constant<int, 3 * 4 + PW * 1>{}, 1, f1, f0);
         early(std::integral_constant<int, 3 * 3 + PW * 2>{}, 2, f0, f1);
@@ -883,7 +903,7 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
                     bias[q] = p.b_f32 ? reinterpret_cast<const float*>(p.b)[n + q] : bf16_to_f32(reinterpret_cast<const uint16_t*>(p.b)[n + q]);
             }
 #pragma unroll
-            for (int im = 0; im < 3; ++im) {
+            for (int im = 0; im < MI; ++im) {
                 uint16_t h[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -897,12 +917,12 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
                         h[q] = f32_to_bf16(v);
                     }
                 }
-                *reinterpret_cast<uint2*>(tl + (48 * wr + 16 * im + r16) * TP + (TN / 2) * wc + 16 * j + 4 * kg) =
+                *reinterpret_cast<uint2*>(tl + ((TM / 2) * wr + 16 * im + r16) * TP + (TN / 2) * wc + 16 * j + 4 * kg) =
                     make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
             }
         }
         __syncthreads();
-        for (int it = tid; it < kRM * (TN / 8); it += 256) {
+        for (int it = tid; it < TM * (TN / 8); it += 256) {
             const int row = it / (TN / 8), c8 = it % (TN / 8), m = m0 + row;
             if (m < p.M) {
                 const u32x4 v = *reinterpret_cast<const u32x4*>(tl + row * TP + 8 * c8);
@@ -949,8 +969,8 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
         }
         const bool vec = p.vec && n + 3 < p.N;
 #pragma unroll
-        for (int im = 0; im < 3; ++im) {
-            const int m = m0 + 48 * wr + 16 * im + r16;
+        for (int im = 0; im < MI; ++im) {
+            const int m = m0 + (TM / 2) * wr + 16 * im + r16;
             if (m >= p.M) continue;
             float v[4];
 #pragma unroll
@@ -990,7 +1010,7 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
     return true;
 }
 
-template <int kRRing, int TN = kRN>
+template <int kRRing, int TN = kRN, int TM = kRM>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void readout16_gemm_kernel(R16Params p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [kRRing][stage]; the roles take the whole 160 KB
     R16_TR(0);
@@ -1016,8 +1036,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         }
         return;
     }
-    const int tile = r16_tile_of_block<TN>(p, (int)blockIdx.x);
-    if (tile >= 0) r16_tile<kRRing, R16_PLAIN, TN>(p, tile, lds, TileSync{nullptr, nullptr, nullptr, nullptr, 0});
+    const int tile = r16_tile_of_block<TN, TM>(p, (int)blockIdx.x);
+    if (tile >= 0) r16_tile<kRRing, R16_PLAIN, TN, TM>(p, tile, lds, TileSync{nullptr, nullptr, nullptr, nullptr, 0});
 }
 
 // ---- the fused tail launch: both readout GEMMs and the merge -> two-layer chain role in ONE grid ----
@@ -1214,20 +1234,26 @@ static int r16_build(const void* a, const void* w, const void* b, int32_t b_dt,
         const bool y16 = y && y_dt != HICOM_DT_F32;
         p.line16 = (N % 8 == 0 && ((out_f16 && !y && (uintptr_t)out_f16 % 16 == 0) || (!out_f16 && y16 && (uintptr_t)y % 16 == 0 && ldy % 8 == 0))) ? 1 : 0;
     }
-    // tile width: 64 columns, or -- wide layers whose 64-column grid is more ROUNDS of one-per-CU workgroups than the 128-column grid --
-    // 128 (HICOM_R16_TN = 64 | 128 forces one: A/B switch)
-    const int nby = (M + kRM - 1) / kRM;
-    int tn = kRN;
+    // tile shape: 96 x 64, or -- wide layers whose grid is more ROUNDS of one-per-CU workgroups than a larger tile's -- 96 x 128, or 192 x 128
+    // (HICOM_R16_TN = 64 | 128 | 192x128 forces one: A/B switch).  The smallest tile among those with the fewest rounds.
+    int tn = kRN, tm = kRM;
     if (!role_only && N % 128 == 0) {
         static int tn_env = -1;
         if (tn_env < 0) {
             const char* e = getenv("HICOM_R16_TN");
-            tn_env = (e && !strcmp(e, "128")) ? 128 : (e && !strcmp(e, "64")) ? 64 : 0;
+            tn_env = (e && !strcmp(e, "128")) ? 128 : (e && !strcmp(e, "64")) ? 64 : (e && !strcmp(e, "192x128")) ? 192 : 0;
         }
-        const int t64 = nby * (N / 64), t128 = nby * (N / 128);
-        if (tn_env == 128 || (tn_env == 0 && (t128 + 255) / 256 < (t64 + 255) / 256)) tn = 128;
+        auto rounds = [&](int tm_, int tn_) { return (((M + tm_ - 1) / tm_) * (N / tn_) + 255) / 256; };
+        const int r64 = rounds(96, 64), r128 = rounds(96, 128), r192 = rounds(192, 128);
+        if (tn_env == 128 || (tn_env == 0 && r128 < r64)) tn = 128;
+        if (tn_env == 192 || (tn_env == 0 && r192 < r128 && r192 < r64)) {
+            tn = 128;
+            tm = 192;
+        }
     }
     p.tn = tn;
+    p.tm = tm;
+    const int nby = (M + tm - 1) / tm;
     const int nbx = (N + tn - 1) / tn;
     p.n_gemm = role_only ? 0 : 8 * ((nbx * nby + 7) / 8);
     n_aux = 0;
@@ -1325,11 +1351,13 @@ static int readout16_launch(const void* a, const void* w, const void* b, int32_t
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(readout16_gemm_kernel<8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kRStage);
         hipFuncSetAttribute(reinterpret_cast<const void*>(readout16_gemm_kernel<5, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kRStage);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(readout16_gemm_kernel<4, 128, 192>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kRStage);
         attr_set = true;
     }
     // role workgroups first in dispatch order would delay tiles on their CUs; they go last and land on the free CUs
     // (both forms ask for the whole 160 KB: one workgroup per CU, and the roles use it)
-    if (p.tn == 128) HICOM_LAUNCH((readout16_gemm_kernel<5, 128>), dim3((unsigned)(p.n_gemm + n_aux)), dim3(256), 8 * kRStage, (hipStream_t)stream, p);
+    if (p.tm == 192) HICOM_LAUNCH((readout16_gemm_kernel<4, 128, 192>), dim3((unsigned)(p.n_gemm + n_aux)), dim3(256), 8 * kRStage, (hipStream_t)stream, p);
+    else if (p.tn == 128) HICOM_LAUNCH((readout16_gemm_kernel<5, 128>), dim3((unsigned)(p.n_gemm + n_aux)), dim3(256), 8 * kRStage, (hipStream_t)stream, p);
     else HICOM_LAUNCH((readout16_gemm_kernel<8, 64>), dim3((unsigned)(p.n_gemm + n_aux)), dim3(256), 8 * kRStage, (hipStream_t)stream, p);
     return hicom_host::check_launch("readout16_gemm");
 }
@@ -1383,7 +1411,7 @@ extern "C" int hicom_readout_tail_fwd(const hicom_r16_gemm* g1, const hicom_r16_
     if (int rc = r16_build(g2->a, g2->w, g2->b, g2->b_dt, g2->M, g2->N, g2->K, g2->act, nullptr, g2->y, g2->y_dt, g2->ldy, g2->row0, g2->nl_group, chain,
                            kTailRole, q.g2, na2)) return rc;
     const int nby = (g1->M + kRM - 1) / kRM, nbx = g1->N / kRN, items = (q.g1.mv.E / 64) * (q.g1.mv.E / q.g1.mv.hd);
-    HICOM_REQUIRE(q.g1.line16 && q.g2.line16 && q.g1.tn == kRN && q.g2.tn == kRN && g1->N % kRN == 0 && g2->N == g1->N && g2->K / 64 >= 8 + 6 && nby + 2 <= kTailSyncLines &&
+    HICOM_REQUIRE(q.g1.line16 && q.g2.line16 && q.g1.tn == kRN && q.g2.tn == kRN && q.g1.tm == kRM && q.g2.tm == kRM && g1->N % kRN == 0 && g2->N == g1->N && g2->K / 64 >= 8 + 6 && nby + 2 <= kTailSyncLines &&
                       nbx * nby <= kTailFlags && q.g1.n_gemm + kTailRole <= 256 && items <= kMvRoleItems * kTailRole && q.g1.mv.wv,
                   HICOM_EUNSUP, "readout_tail: shape outside the fused form (two layers of the same width in whole 64-column tiles, K2 >= 896, "
                                 "<= 202 tiles, <= 162 merge items)");

@@ -465,7 +465,9 @@ def test_local_attn_fp32_streams():
 @pytest.mark.parametrize("M,N,K,act", [(8, 64, 1152, 1), (81, 896, 1152, 1), (130, 64, 64, 0), (1296, 896, 896, 0), (1296, 896, 1152, 1),
                                        (648, 3584, 1152, 1), (97, 200, 128, 0),
                                        # round 5: 128-column tiles (chosen when they take fewer rounds of one-per-CU workgroups)
-                                       (648, 3584, 3584, 0), (1296, 3584, 3584, 1), (1300, 2176, 192, 0)])
+                                       (648, 3584, 3584, 0), (1296, 3584, 3584, 1), (1300, 2176, 192, 0),
+                                       # ... and 192 x 128 tiles where even those take two rounds (1296 rows at 3584; a ragged last row block)
+                                       (1000, 3584, 1152, 1), (2592, 2048, 896, 0)])
 def test_readout16_gemm_matches_torch(M, N, K, act):
     """fp16-plane GEMM against fp64 torch on the SAME fp16-rounded operands (the kernel's arithmetic: exact products,
     fp32 accumulation), both output forms (fp16 plane, packed rows with a newline gap)."""
@@ -493,11 +495,11 @@ def test_readout16_gemm_matches_torch(M, N, K, act):
     assert bool(torch.isnan(y[untouched]).all())
 
 
-@pytest.mark.parametrize("M,N,K", [(648, 3584, 1152), (1296, 3584, 3584), (1296, 896, 1152)])
+@pytest.mark.parametrize("M,N,K", [(648, 3584, 1152), (1296, 3584, 3584), (1296, 896, 1152), (1000, 3584, 1152)])
 def test_readout16_row_line_epilogue_equals_the_general_one(M, N, K):
     """One 16-bit output (the fp16 plane alone, or packed bf16 rows alone) leaves through the row-line epilogue (LDS image, 16-byte
     stores); both outputs at once through the general one.  Same values: the plane bit for bit, the bf16 rows = the rounded f32 rows.
-    (N = 3584: 128-column tiles; N = 896: 64-column tiles.)"""
+    (648 x 3584: 96 x 128 tiles; 1296 / 1000 x 3584: 192 x 128; N = 896: 96 x 64.)"""
     g = torch.Generator().manual_seed(M + N + K)
     a16 = nv.to_f16((torch.randn(M, K, generator=g) * 0.7).cuda())
     w16 = nv.to_f16(bf(torch.randn(N, K, generator=g) * 0.02))
