@@ -15,9 +15,15 @@
 // counted vmcnt, raw s_barrier), XOR-swizzled [rows][128 B] images, fragment reads of stage s+1 under the MFMAs of
 // stage s, product computed transposed (W fragment as the A operand) so that a lane stores 4 consecutive columns.
 //
-// Horizontal fusion: the launch may carry `n_aux` extra workgroups that run a single-row linear layer (GEMV) of the
-// global compressor's tail (out_proj / readout of the 32 global rows, projector.py:226,646) on the CUs the tiles
-// leave idle: two dependent small launches of the step disappear under the two GEMMs.
+// Round 5: the tile shape is a template parameter (r16_tile<ring, MODE, TN, TM>): 96 x 64 (8-stage ring, the hot path), 96 x 128
+// (5 stages) and 192 x 128 (4 stages) for wide layers whose 64-column grid would be several rounds of one-per-CU workgroups
+// (hidden 3584); the host takes the smallest tile among those with the fewest rounds.
+//
+// Horizontal fusion: the launch may carry `n_aux` extra workgroups that run a ROLE on the CUs the tiles leave idle: a single-row
+// linear layer (GEMV) of the global compressor's tail (out_proj / readout of the 32 global rows, projector.py:226,646), the merge
+// of the ring kernel's partial global states + v_proj (HICOM_ROLE_MERGE_VPROJ), or the tail's two dependent single-row layers with
+// an in-launch hand-off (HICOM_ROLE_GEMV_CHAIN): the dependent small launches of the step disappear under the two GEMMs
+// (DESIGN.md §3.1).  hicom_readout_tail_fwd (opt-in) runs both GEMMs and both roles in ONE grid.
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -85,9 +91,7 @@ __device__ unsigned long long g_r16_trace[512 * 16];
 constexpr int kRM = 96, kRN = 64;
 constexpr int kRImgA = kRM * 128;                   // 12 KB: 96 rows x 64 fp16
 constexpr int kRStage = kRImgA + kRN * 128;         // 20 KB
-constexpr int kRRingMax = 8;                        // ring depth is a template parameter (6 or 8 stages: 120 / 160 KB of LDS)
 constexpr int kMvRoleItems = 3;                      // merge items a role workgroup keeps in flight together
-constexpr int kRPW = 5;                             // DMA pieces (1 KiB = 8 rows x 128 B) per wave and stage: 12 A + 8 W
 
 __device__ __forceinline__ _Float16 to_f16_sat(float v) {
     v = fminf(fmaxf(v, -65504.f), 65504.f);
