@@ -10,7 +10,6 @@ hicom_arch.py:162-164) therefore pays one ctypes call per forward, not a plan bu
 """
 from __future__ import annotations
 
-import ctypes as C
 import math
 from typing import Dict, Optional, Tuple
 

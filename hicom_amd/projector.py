@@ -21,9 +21,8 @@ from __future__ import annotations
 import math
 import re
 from functools import partial
-from typing import Dict, Optional, Tuple
+from typing import Dict, Tuple
 
-import numpy as np
 import torch
 import torch.nn as nn
 from torch.nn.init import trunc_normal_
