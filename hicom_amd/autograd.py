@@ -737,7 +737,7 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
 
 class _AnyresFn(torch.autograd.Function):
     """The anyres dict input of an image (reference projector.py:679-689): base image -> local stage; patch grid -> local stage with the
-    anyres packing and the global stage.  Forward operator by operator (HIComProjector.forward_stepwise), backward = compressor_backward
+    anyres packing and the global stage.  Forward = the inference path (engine.run_anyres: one C call per segment), backward = compressor_backward
     per segment on that segment's rows of the cotangent, parameter gradients summed.  Parameters and image_newline only: the
     inputs' gradients (stage 3 trains on videos) are not built for dict inputs."""
 
@@ -746,7 +746,12 @@ class _AnyresFn(torch.autograd.Function):
         with torch.no_grad():
             fdict = {"base": ff_base, "patch": ff_patch}
             edict = None if fe_patch is None else {"base": fe_base, "patch": fe_patch}
-            out = proj.forward_stepwise(fdict, edict, guide, modal, nl)
+            if proj.use_executor and proj._executor_covers():         # (the inference path's calls: same kernels, same bits)
+                from . import engine
+                from .projector import _out_dtype
+                out = engine.run_anyres(proj, fdict, edict, guide, modal, nl, _out_dtype(proj))
+            else:
+                out = proj.forward_stepwise(fdict, edict, guide, modal, nl)
         ctx.proj, ctx.modal, ctx.names = proj, modal, names
         ctx.save_for_backward(ff_base, ff_patch, fe_base, fe_patch, guide, nl)
         return out

@@ -891,8 +891,10 @@ class HIComProjector(nn.Module):
             from . import autograd
             return autograd.forward_with_grad(self, frames_feature, frames_embed, guide_embed, modal, image_newline)
         nv.begin_inference()           # (the first inference forward after training rebuilds the weight-derived tables)
-        if self.use_executor and self._executor_covers() and not isinstance(frames_feature, dict):
+        if self.use_executor and self._executor_covers():
             from . import engine
+            if isinstance(frames_feature, dict):             # anyres image (ref :679-700): one call per segment
+                return engine.run_anyres(self, frames_feature, frames_embed, guide_embed, modal, image_newline, _out_dtype(self))
             return engine.run_dense(self, frames_feature, frames_embed, guide_embed, modal, image_newline,
                                     _out_dtype(self))
         return self.forward_stepwise(frames_feature, frames_embed, guide_embed, modal, image_newline)

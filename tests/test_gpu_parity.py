@@ -1060,3 +1060,28 @@ def test_random_clip_scale_sweep_against_the_oracle():
         assert float(np.abs(got - want).max()) <= TOL, (what, float(np.abs(got - want).max()))
         ran += 1
     assert ran >= 10, ran
+
+
+@pytest.mark.parametrize("name", ["G9_anyres", "G9_anyres_nobase"])
+def test_anyres_dict_through_the_executor_equals_stepwise(name):
+    """Round 5: the anyres dict input takes hicom_compressor_fwd once per segment (base image: local stage; patch grid: local stage with
+    the anyres packing + global stage, rows behind the base image's) instead of one C call per operator: same rows (<= PATH_TOL; the
+    one-call form carries its activations as fp16 planes), same bits from call to call, and a second image of another size on the
+    same module."""
+    case = cases.build_case(name)
+    m = build_module(case)
+    a = case.anyres
+    ff, fe, g, nl = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g), dev_bf16(case.newline)
+    fd = {"base": None if a["no_base"] else ff[0], "patch": dev_bf16(a["patch_ff"])}
+    ed = {"base": None if a["no_base"] else fe[0], "patch": dev_bf16(a["patch_fe"])}
+    with torch.no_grad():
+        got = m(fd, ed, g, case.modal, nl)
+        step = m.forward_stepwise(fd, ed, g, case.modal, nl)
+        again = m(fd, ed, g, case.modal, nl)
+        fd2 = {"base": fd["base"], "patch": fd["patch"][:6, :3].contiguous()}
+        ed2 = {"base": ed["base"], "patch": ed["patch"][:6, :3].contiguous()}
+        other = m(fd2, ed2, g, case.modal, nl)
+        other_step = m.forward_stepwise(fd2, ed2, g, case.modal, nl)
+    assert len(m.__dict__.get("_engine_plans", {})) >= 2
+    assert got.shape == step.shape and float((got - step).abs().max()) <= PATH_TOL and torch.equal(got, again)
+    assert other.shape == other_step.shape and float((other - other_step).abs().max()) <= PATH_TOL
