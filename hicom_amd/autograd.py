@@ -373,7 +373,7 @@ class _CompressorFn(torch.autograd.Function):
                 finally:
                     gc.__dict__.pop("_train_store", None)
         gb = getattr(proj, "graph_backward", None)             # None: automatic; False: always eager
-        if (gb is None or gb) and nl is None:
+        if gb is None or gb:
             res = _graphed_backward(dout, *args, store=store, gstore=gstore)
         else:
             with torch.no_grad():
@@ -426,7 +426,8 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
     from . import engine
     cache = proj.__dict__.setdefault("_bwd_graphs", {})
     key = (tuple(ff.shape), None if fe is None else tuple(fe.shape), None if guide is None else tuple(guide.shape), modal,
-           tuple(dout.shape), dout.dtype, want, want_fe, want_guide, torch.cuda.current_stream(ff.device).cuda_stream,
+           tuple(dout.shape), dout.dtype, want, want_fe, want_guide, None if nl is None else (tuple(nl.shape), nl.dtype, want_nl),
+           torch.cuda.current_stream(ff.device).cuda_stream,
            None if store is None else id(store),          # (the captured kernels read the stores' buffers by address)
            None if gstore is None else tuple(b.data_ptr() for b in gstore.bufs))
     # what else the captured kernels read by ADDRESS: every parameter's storage and the cached device tables (pe / kpe / planes:
@@ -478,8 +479,25 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
     ent["dout"].copy_(dout)
     ent["graph"].replay()
     flats, d_fe, d_guide, d_nl = ent["outs"]
+    # (image_newline -- the reference's scripts always pass it, hicom_arch.py:212, also where mm_newline_position = "no_token" leaves it
+    # unused -- enters the backward by shape and dtype only: d image_newline is a sum of cotangent rows)
     return ({dt: (flat.clone(), group) for dt, (flat, group) in flats.items()}, None if d_fe is None else d_fe.clone(),
-            None if d_guide is None else d_guide.clone(), None)
+            None if d_guide is None else d_guide.clone(), None if d_nl is None else d_nl.clone())
+
+
+_ROW_INDEX = {}
+
+
+def _row_index(rows, dev):
+    """Device index tensor of a packing's newline rows, kept per (rows, device): the captured backward must not make it (a host-to-device
+    copy inside a stream capture); the eager pass that precedes every capture does."""
+    key = (tuple(rows), str(dev))
+    t = _ROW_INDEX.get(key)
+    if t is None:
+        if len(_ROW_INDEX) >= 64:
+            _ROW_INDEX.pop(next(iter(_ROW_INDEX)))
+        t = _ROW_INDEX[key] = torch.tensor(list(rows), device=dev)
+    return t
 
 
 def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, want_guide=False, adaptor_saved=None, global_saved=None,
@@ -518,7 +536,7 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         rows = idx + (idx // lay.nl_group if lay.nl_group else 0)          # packing row map of the readout store
         dY = dout[rows]
         if lay.newline_rows:
-            d_nl = dout[torch.tensor(lay.newline_rows, device=dev)].sum(0)
+            d_nl = dout[_row_index(lay.newline_rows, dev)].sum(0)
         # k / v adaptors: ONE recomputation of the two MLPs over all tokens (with the intermediates their backward needs) serves the
         # window contexts below as well
         adapt = lc.adapt_k or lc.adapt_v
