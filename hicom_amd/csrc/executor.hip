@@ -467,6 +467,12 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
             int rc3 = tail_env == 3 ? hicom_readout_tail_fwd(&g1, &g2, &r1, &r2, ws + w.tail_sync, sm) : HICOM_EUNSUP;
             if (rc3 == HICOM_EUNSUP) {
                 CHK(hicom_readout16_gemm_role_fwd(g1.a, g1.w, g1.b, g1.b_dt, g1.M, g1.N, g1.K, g1.act, g1.out_f16, nullptr, 0, 0, 0, 0, &r1, sm));
+                // a deferred call's completion event rides on the step's last launch (a separate record costs the main stream a packet of
+                // its own: forward_deferred measured 4 us behind forward at N = 1)
+                if (fold_ev && a.defer_join && a.ev_join && !(a.nl_count > 0 && !a.local_out)) {
+                    hicom_host::set_stop_event(a.ev_join);
+                    join_folded = true;
+                }
                 CHK(hicom_readout16_gemm_role_fwd(g2.a, g2.w, g2.b, g2.b_dt, g2.M, g2.N, g2.K, g2.act, nullptr, g2.y, g2.y_dt, g2.ldy, g2.row0, g2.nl_group, &r2, sm));
             } else {
                 CHK(rc3);
@@ -522,7 +528,7 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
             if (!ro2_aux)
                 CHK(hicom_linear_to_rows_fwd(F(w.hid_g), HICOM_DT_F32, a.gw2, HICOM_DT_BF16, a.gb2, HICOM_DT_BF16, a.nq, a.hidden,
                                              a.hidden, HICOM_ACT_NONE, a.out, a.out_dt, a.ldo, a.global_row0, a.n_global_rows, sm));
-            if (a.defer_join && a.ev_join)      // (a deferred call's completion event: everything is on the main stream here)
+            if (a.defer_join && a.ev_join && !join_folded)      // (a deferred call's completion event: everything is on the main stream here)
                 HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_join, sm) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
             if (a.ev_done) {
                 HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_done, sm) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
