@@ -319,6 +319,7 @@ class _CompressorFn(torch.autograd.Function):
         from . import engine
         from .projector import _out_dtype
         ctx.adapt_serial = ctx.global_serial = None
+        ctx16 = None
         with torch.no_grad():
             gc_ = proj.global_compressor
             # guide off (32 learnable queries x 9 heads): operator by operator, so that the global stage's state and logits stay for the
@@ -333,6 +334,10 @@ class _CompressorFn(torch.autograd.Function):
                     # reference); the executor gets their outputs instead of running the four GEMMs itself
                     ctx.adapt_serial = store.fill(proj.local_compressor, ff, fe)
                 out = engine.run_dense(proj, ff, fe, guide, modal, nl, _out_dtype(proj), adapt_y=store.ys if store is not None else None)
+                # the window contexts as the forward's readout consumed them (fp16 plane in the executor's workspace): the backward's
+                # readout gradients take them instead of a pass over every token that recomputes them (55 us of a 1.0-ms release step,
+                # 96 us with k / v adaptors)
+                ctx16 = engine.last_window_contexts(proj, ff, modal) if getattr(proj, "share_window_contexts", True) else None
             else:                                                      # query-side adaptors / coarse / fine injection: operator by operator
                 gstore = _global_store(proj, ff)
                 gc = proj.global_compressor
@@ -346,12 +351,12 @@ class _CompressorFn(torch.autograd.Function):
                 if gstore is not None and gstore.bufs is not None:
                     ctx.global_serial = gstore.serial
         ctx.proj, ctx.modal, ctx.names = proj, modal, names
-        ctx.save_for_backward(ff, fe, guide, nl)
+        ctx.save_for_backward(ff, fe, guide, nl, ctx16)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        ff, fe, guide, nl = ctx.saved_tensors
+        ff, fe, guide, nl, ctx16 = ctx.saved_tensors
         need = ctx.needs_input_grad            # (proj, ff, fe, guide, modal, nl, names, *params)
         if need[1]:
             raise NotImplementedError("hicom_amd backward: the gradient w.r.t. frames_feature is not built (the tower body is "
@@ -374,10 +379,10 @@ class _CompressorFn(torch.autograd.Function):
                     gc.__dict__.pop("_train_store", None)
         gb = getattr(proj, "graph_backward", None)             # None: automatic; False: always eager
         if gb is None or gb:
-            res = _graphed_backward(dout, *args, store=store, gstore=gstore)
+            res = _graphed_backward(dout, *args, store=store, gstore=gstore, ctx16=ctx16)
         else:
             with torch.no_grad():
-                res = _backward_outputs(dout, *args, store=store, gstore=gstore)
+                res = _backward_outputs(dout, *args, store=store, gstore=gstore, ctx16=ctx16)
         flats, d_fe, d_guide, d_nl = res
         plist = dict(proj.named_parameters())
         out = [None] * len(ctx.names)
@@ -390,14 +395,14 @@ class _CompressorFn(torch.autograd.Function):
         return (None, None, d_fe, d_guide, None, d_nl, None, *out)
 
 
-def _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl, store=None, gstore=None):
+def _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl, store=None, gstore=None, ctx16=None):
     """({dtype: (flat gradient buffer, [(argument index, parameter name)])}, d frames_embed, d guide_embed, d image_newline) in
     the dtypes autograd hands on.  The parameter gradients leave as views of one buffer cast once (one concatenation + one cast
     instead of a cast per tensor)."""
     global LAST_FP32_GRADS
     grads, d_nl, d_fe, d_guide = compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=want_fe, want_guide=want_guide,
                                                      adaptor_saved=(store.k, store.v) if store is not None else None,
-                                                     global_saved=gstore.bufs if gstore is not None else None)
+                                                     global_saved=gstore.bufs if gstore is not None else None, ctx_local16=ctx16)
     LAST_FP32_GRADS = dict(grads)
     if d_guide is not None:
         LAST_FP32_GRADS["__guide_embed__"] = d_guide
@@ -414,7 +419,7 @@ def _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
 _MAX_BWD_GRAPHS = 4
 
 
-def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl, store=None, gstore=None):
+def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl, store=None, gstore=None, ctx16=None):
     """The backward as a captured hipGraph (the default; `proj.graph_backward = False` turns it off).
     The eager backward is ~130 small launches behind 1.4 ms of Python at the benchmark shape; its shapes are static, so the second
     backward of a problem SHAPE is captured and later ones are one graph launch.  The captured kernels read STATIC copies of the inputs
@@ -428,6 +433,7 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
     key = (tuple(ff.shape), None if fe is None else tuple(fe.shape), None if guide is None else tuple(guide.shape), modal,
            tuple(dout.shape), dout.dtype, want, want_fe, want_guide, None if nl is None else (tuple(nl.shape), nl.dtype, want_nl),
            torch.cuda.current_stream(ff.device).cuda_stream,
+           ctx16 is not None,
            None if store is None else id(store),          # (the captured kernels read the stores' buffers by address)
            None if gstore is None else tuple(b.data_ptr() for b in gstore.bufs))
     # what else the captured kernels read by ADDRESS: every parameter's storage and the cached device tables (pe / kpe / planes:
@@ -441,7 +447,7 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
 
     def eager():
         with torch.no_grad():
-            return _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl, store=store, gstore=gstore)
+            return _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl, store=store, gstore=gstore, ctx16=ctx16)
 
     if ent is None:                                                # first sight of the shape: eager (also the warm-up a capture needs)
         if len(cache) >= _MAX_BWD_GRAPHS:
@@ -455,12 +461,13 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
             gc = proj.global_compressor
             st = {"ff": ff.detach().clone(), "fe": None if fe is None else fe.detach().clone(),
                   "guide": None if guide is None else guide.detach().clone(), "dout": dout.detach().clone(),
+                  "ctx16": None if ctx16 is None else ctx16.detach().clone(),
                   "tables": None if gc is None else dict(gc._pe_cache)}       # (the cached tables the kernels read stay alive with the entry)
             torch.cuda.current_stream(ff.device).synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(g):
                 outs = _backward_outputs(st["dout"], proj, st["ff"], st["fe"], st["guide"], modal, nl, names, want, want_fe, want_guide, want_nl,
-                                         store=store, gstore=gstore)
+                                         store=store, gstore=gstore, ctx16=st["ctx16"])
             st["store"] = (store, gstore, None if gstore is None else gstore.bufs)   # (keeps the buffers the graph reads alive with the entry)
             if engine.plan_sig(proj) != sig:                       # (the pass inside the capture reallocated a table)
                 raise RuntimeError("cached device tables moved during capture")
@@ -477,6 +484,8 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
     if guide is not None:
         ent["guide"].copy_(guide)
     ent["dout"].copy_(dout)
+    if ctx16 is not None:
+        ent["ctx16"].copy_(ctx16)
     ent["graph"].replay()
     flats, d_fe, d_guide, d_nl = ent["outs"]
     # (image_newline -- the reference's scripts always pass it, hicom_arch.py:212, also where mm_newline_position = "no_token" leaves it
@@ -501,7 +510,7 @@ def _row_index(rows, dev):
 
 
 def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, want_guide=False, adaptor_saved=None, global_saved=None,
-                        stages=("local", "global"), is_anyres=False):
+                        stages=("local", "global"), is_anyres=False, ctx_local16=None):
     """(fp32 gradients {parameter name: tensor} of sum(out * dout), d image_newline, d frames_embed (bf16) or None,
     d guide_embed (fp32) or None).  Restates autograd through reference projector.py:524-559 (local), :634-646 + :166-228
     (global) and mm_utils.py:92-140 (packing).  The input gradients exist for the direct recipe only.
@@ -547,8 +556,11 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
             key_ = fe if fe is not None else ff
             rec_k = _adaptor_recompute(key_.reshape(-1, E), lc.k_proj) if lc.adapt_k else None
             rec_v = _adaptor_recompute(ff.reshape(-1, E), lc.v_proj) if lc.adapt_v else None
-        ctx_l, _ = lc.window_context(ff, fe, guide, modal, None, None,     # HIP: [Nw, E] fp32 window contexts
-                                     adapt_y=(rec_k[2] if rec_k else None, rec_v[2] if rec_v else None) if adapt else None)
+        if ctx_local16 is not None:                                         # kept by the training forward (the executor's fp16 plane)
+            ctx_l = ctx_local16.float()
+        else:
+            ctx_l, _ = lc.window_context(ff, fe, guide, modal, None, None,     # HIP: [Nw, E] fp32 window contexts
+                                         adapt_y=(rec_k[2] if rec_k else None, rec_v[2] if rec_v else None) if adapt else None)
         W0, b0 = f32["local_compressor.readout.0.weight"], f32["local_compressor.readout.0.bias"]
         W2 = f32["local_compressor.readout.2.weight"]
         pre = torch.addmm(b0, ctx_l, W0.t())

@@ -280,6 +280,13 @@ extern "C" int hicom_compressor_is_fused(const hicom_compressor_args* a) {
     return ((a->phases & HICOM_PHASE_STREAM) && can_fuse(*a)) ? 1 : 0;
 }
 
+extern "C" int64_t hicom_compressor_ctx16_offset(const hicom_compressor_args* a) {
+    if (!a || !a->has_local) return HICOM_EINVAL;
+    if (!(a->phases & HICOM_PHASE_STREAM) || !(a->lw0_f16 && a->lw2_f16) || a->E % 64 != 0 || a->hidden % 64 != 0) return HICOM_EUNSUP;
+    const WsLayout w = make_layout(*a);
+    return (int64_t)((a->has_global && can_fuse(*a)) ? w.ctx_hi : w.ctx16);
+}
+
 extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
     HICOM_REQUIRE(ap, HICOM_EINVAL, "compressor: NULL args");
     const hicom_compressor_args& a = *ap;

@@ -372,6 +372,22 @@ def _evict_one(plans: dict):
         ws.record_stream(res.side)
 
 
+def last_window_contexts(proj, ff, modal):
+    """fp16 [windows, E] copy of the local stage's window contexts the LAST run_dense call of `proj` left in its plan's workspace (the A
+    operand of readout GEMM 1), or None when that call did not read out through fp16 planes.  Valid until the plan's next call."""
+    plan = proj.__dict__.get("_last_plan")
+    lc = proj.local_compressor
+    if plan is None or lc is None or not plan.args.has_local:
+        return None
+    off = nv.compressor_ctx16_offset(plan.args)
+    if off < 0:
+        return None
+    T, H, W, E = ff.shape
+    at, ay, ax = lc.tilings(T, H, W, modal)
+    nw = at.nwin * ay.nwin * ax.nwin
+    return plan.ws[off:off + nw * E * 2].view(torch.float16).view(nw, E).clone()
+
+
 def run_anyres(proj, frames_feature, frames_embed, guide_embed, modal, image_newline, out_dtype):
     """HIComProjector.forward for the anyres DICT input of an image (reference projector.py:679-700) through hicom_compressor_fwd: one call
     for the base image (local stage; rows first), one for the patch grid (local stage with the anyres packing + global stage) -- two C
@@ -549,6 +565,7 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
     if plan.queries is not None:
         plan.queries(ff, guide, res)                   # pooling / adaptor / injector launches -> the plan's query rows
     nv.compressor_fwd(a)
+    proj.__dict__["_last_plan"] = plan                 # (the training forward picks the window contexts out of its workspace)
     if gc is not None and gc.use_guide in (None, "off") and gc.queries_native and not plan.fused:
         a.reuse_queries = 1                            # q_proj + fold of the learnable queries: weight-only, they stay in the plan's workspace
     if deferred:

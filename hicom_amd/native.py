@@ -15,7 +15,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 # HICOM_NATIVE_LIB: dev override (instrumented builds from tools/); the product loads the in-tree library
 LIB_PATH = os.environ.get("HICOM_NATIVE_LIB") or os.path.join(HERE, "libhicom_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 DT_BF16, DT_F32, DT_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_GELU_TANH = 0, 1, 2
@@ -37,6 +37,7 @@ EXPORTS = (
     "hicom_global_stream_marg_fwd", "hicom_global_stream_marg_width", "hicom_global_stream_has_marg", "hicom_global_merge_marg_fwd",
     "hicom_act_rows_fwd", "hicom_act_bwd_rows_fwd", "hicom_readout16_gemm_role_fwd", "hicom_r16_chain_state_bytes", "hicom_dense16_gemm_pair_fwd", "hicom_gemv_chain_fwd",
     "hicom_merge_vproj_sets_fwd", "hicom_readout_tail_fwd", "hicom_readout_tail_state_bytes",
+    "hicom_compressor_ctx16_offset",
 )
 
 PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
@@ -179,6 +180,8 @@ def lib() -> C.CDLL:
     L.hicom_readout_tail_fwd.argtypes = [C.POINTER(R16Gemm), C.POINTER(R16Gemm), C.POINTER(R16Role), C.POINTER(R16Role), vp, vp]
     L.hicom_readout_tail_state_bytes.argtypes = []
     L.hicom_readout_tail_state_bytes.restype = i64
+    L.hicom_compressor_ctx16_offset.argtypes = [C.POINTER(CompressorArgs)]
+    L.hicom_compressor_ctx16_offset.restype = i64
     L.hicom_to_f16_fwd.argtypes = [vp, i32, vp, i64, vp]
     L.hicom_splice_rows_fwd.argtypes = [vp, i64, i32, vp, vp]
     L.hicom_splice_labels_fwd.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i64, vp, vp, vp]
@@ -533,6 +536,12 @@ def compressor_workspace(args: CompressorArgs):
 
 def compressor_fwd(args: CompressorArgs):
     _check(lib().hicom_compressor_fwd(C.byref(args)), "hicom_compressor_fwd")
+
+
+def compressor_ctx16_offset(args) -> int:
+    """Workspace offset of the fp16 window-context plane a call with these arguments leaves behind, or -1 (hicom_compressor_ctx16_offset)."""
+    off = int(lib().hicom_compressor_ctx16_offset(C.byref(args)))
+    return off if off >= 0 else -1
 
 
 def compressor_is_fused(args: CompressorArgs) -> bool:

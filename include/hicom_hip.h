@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HICOM_ABI_VERSION 13
+#define HICOM_ABI_VERSION 14
 
 #define HICOM_OK         0
 #define HICOM_EINVAL    -1   /* bad argument (shape, alignment, NULL)        */
@@ -735,6 +735,11 @@ typedef struct hicom_compressor_args {
     } inj_l, inj_g;
 } hicom_compressor_args;
 
+/* Byte offset, inside the workspace, of the fp16 plane [windows, E] of the local stage's window contexts (the A operand of readout
+ * GEMM 1) that a hicom_compressor_fwd call with these arguments leaves behind -- what the training forward keeps for the backward
+ * (the readout's weight gradients need the contexts; recomputing them is a pass over every token).  Negative: HICOM_EUNSUP when the
+ * call does not read out through fp16 planes, HICOM_EINVAL without a local stage. */
+int64_t hicom_compressor_ctx16_offset(const hicom_compressor_args* args);
 /* 1 when hicom_compressor_fwd takes the release-recipe (single streaming kernel) path for these arguments. */
 int hicom_compressor_is_fused(const hicom_compressor_args* args);
 
