@@ -34,8 +34,10 @@ from . import native as nv
 LAST_FP32_GRADS = None      # test hook: the fp32 gradients of the last backward (before the cast to the parameter dtype)
 
 
-def _gelu_grad(x):
-    return 0.5 * (1.0 + torch.erf(x * 0.7071067811865476)) + x * torch.exp(-0.5 * x * x) * 0.3989422804014327
+def _gelu_bwd(dy, x):
+    """dy * GELU'(x) (erf form) in ONE launch: aten's own backward kernel of nn.GELU (the eight elementwise launches of the written-out
+    derivative were 77 us of a 1-ms training step)."""
+    return torch.ops.aten.gelu_backward(dy.contiguous(), x, approximate="none")
 
 
 def _supported(proj) -> bool:
@@ -230,7 +232,7 @@ def _coarse_backward(inj, prefix, vis, guide, dq, grads):
     dcs = torch.cat([(dz * vis).sum(0), dz.sum(0)])
     grads[prefix + "coarse_proj.2.weight"] = torch.outer(dcs, a)
     grads[prefix + "coarse_proj.2.bias"] = dcs
-    dh1 = (W2.t() @ dcs) * _gelu_grad(h1)
+    dh1 = _gelu_bwd(W2.t() @ dcs, h1)
     grads[prefix + "coarse_proj.0.weight"] = torch.outer(dh1, g)
     grads[prefix + "coarse_proj.0.bias"] = dh1
     return dz * (1.0 + sc), W1.t() @ dh1
@@ -416,6 +418,17 @@ def _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
             (d_nl.to(nl.dtype) if (want_nl and d_nl is not None) else None))
 
 
+def _reads_frames_embed(proj, want_fe, want_guide, have_ctx) -> bool:
+    """Whether compressor_backward reads frames_embed: for the window contexts (unless the forward kept them) and in the window-attention
+    backward (input gradients, adaptors, injected / adapted queries)."""
+    lc = proj.local_compressor
+    if lc is None:
+        return False
+    mode = lc.use_guide if lc.use_guide not in (None, "off") else None
+    query_params = mode in ("coarse", "fine") or lc.adapt_q or lc.adapt_guide
+    return (not have_ctx) or want_fe or lc.adapt_k or lc.adapt_v or query_params or (want_guide and mode is not None)
+
+
 _MAX_BWD_GRAPHS = 4
 
 
@@ -479,8 +492,8 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
                           "the eager backward (~2x slower per training step)", RuntimeWarning, stacklevel=2)
             return eager()
     ent["ff"].copy_(ff)
-    if fe is not None:
-        ent["fe"].copy_(fe)
+    if fe is not None and _reads_frames_embed(proj, want_fe, want_guide, ctx16 is not None):
+        ent["fe"].copy_(fe)                                        # (107 MB at 64 frames: only when a captured kernel reads it)
     if guide is not None:
         ent["guide"].copy_(guide)
     ent["dout"].copy_(dout)
@@ -567,7 +580,7 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         h = torch.nn.functional.gelu(pre)
         grads["local_compressor.readout.2.weight"] = dY.t() @ h
         grads["local_compressor.readout.2.bias"] = dY.sum(0)
-        dpre = (dY @ W2) * _gelu_grad(pre)
+        dpre = _gelu_bwd(dY @ W2, pre)
         grads["local_compressor.readout.0.weight"] = dpre.t() @ ctx_l
         grads["local_compressor.readout.0.bias"] = dpre.sum(0)
         mode = lc.use_guide if lc.use_guide not in (None, "off") else None
@@ -688,7 +701,7 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         P = "global_compressor."
         grads[P + "readout.2.weight"] = dtok.t() @ hid
         grads[P + "readout.2.bias"] = dtok.sum(0)
-        da1 = (dtok @ G2) * _gelu_grad(a1)
+        da1 = _gelu_bwd(dtok @ G2, a1)
         grads[P + "readout.0.weight"] = da1.t() @ pre
         grads[P + "readout.0.bias"] = da1.sum(0)
         dpre = da1 @ G0
