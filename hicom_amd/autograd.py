@@ -40,6 +40,12 @@ def _gelu_bwd(dy, x):
     return torch.ops.aten.gelu_backward(dy.contiguous(), x, approximate="none")
 
 
+def _sum0(x):
+    """x.sum(0); for ONE row the row itself (a view: torch's reduction of a [1, n] tensor is still a ~10-us launch, and the direct
+    recipe's global tail is one row throughout)."""
+    return x[0] if x.shape[0] == 1 else x.sum(0)
+
+
 def _supported(proj) -> bool:
     """Every injection mode and adaptor; not: text2qk projections (text width != query width), clip-scale."""
     from .projector import _plain_injector
@@ -700,15 +706,15 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         dtok = dout[n_local:n_local + n_rows].view(n_rows // nq, nq, -1).sum(0)   # direct: the 32 global rows are copies of one row
         P = "global_compressor."
         grads[P + "readout.2.weight"] = dtok.t() @ hid
-        grads[P + "readout.2.bias"] = dtok.sum(0)
+        grads[P + "readout.2.bias"] = _sum0(dtok)
         da1 = _gelu_bwd(dtok @ G2, a1)
         grads[P + "readout.0.weight"] = da1.t() @ pre
-        grads[P + "readout.0.bias"] = da1.sum(0)
+        grads[P + "readout.0.bias"] = _sum0(da1)
         dpre = da1 @ G0
         grads[P + "attn_layer.out_proj.weight"] = dpre.t() @ o
-        grads[P + "attn_layer.out_proj.bias"] = dpre.sum(0)
+        grads[P + "attn_layer.out_proj.bias"] = _sum0(dpre)
         do = dpre @ Wo                                                     # [nq, E]
-        grads[P + "attn_layer.v_proj.bias"] = do.sum(0)
+        grads[P + "attn_layer.v_proj.bias"] = _sum0(do)
         grads[P + "attn_layer.v_proj.weight"] = torch.einsum("qhj,qhe->hje", do.view(nq, nh, hd), ctxg).reshape(E, E)
         dctx = torch.einsum("hje,qhj->qhe", Wv.view(nh, hd, E), do.view(nq, nh, hd)).reshape(R, E).contiguous()
         delta = (dctx * ctxg.reshape(R, E)).sum(1).contiguous()
@@ -755,7 +761,7 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         grads[P + "attn_layer.k_proj.bias"] = torch.zeros(E, device=dev)   # a per-row logit shift: softmax cancels it exactly
         dqp = scale * torch.einsum("hje,qhe->qhj", Wk.view(nh, hd, E), dqt).reshape(nq, E)
         grads[P + "attn_layer.q_proj.weight"] = dqp.t() @ q32
-        grads[P + "attn_layer.q_proj.bias"] = dqp.sum(0)
+        grads[P + "attn_layer.q_proj.bias"] = _sum0(dqp)
         if gc.use_guide in (None, "off"):
             grads[P + "query"] = dqp @ Wq + dpre                           # the learnable queries: through q_proj and the residual
         elif gc.use_guide == "fine" or gc.adapt_guide:                     # fine injection / adapted guide: the small-tensor graph
@@ -773,7 +779,7 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
             if want_guide:
                 d_guide += dg
         elif want_guide:
-            d_guide += (dqp @ Wq + dpre).sum(0)                            # direct: the injected query IS the guide (:352-368)
+            d_guide += _sum0(dqp @ Wq + dpre)                            # direct: the injected query IS the guide (:352-368)
         # (direct: global_compressor.query does not enter the forward, ref :352-368 uses only its shape: no gradient)
     return grads, d_nl, d_fe, d_guide
 
