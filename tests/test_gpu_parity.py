@@ -931,8 +931,8 @@ def test_random_anyres_sweep_against_the_oracle():
     from oracle import hicom_oracle as orc
     rng = random.Random(4242)
     ran = 0
-    for k in range(14):
-        ptype = rng.choice(["local43_global32", "local22_global8", "local43", "local43_global32"])
+    for k in range(20):
+        ptype = rng.choice(["local43_global32", "local22_global8", "local43", "local43_global32", "global32"])
         mode = rng.choice(["direct", None, "coarse", "fine"])
         h, w = rng.choice([3, 6, 9]), rng.choice([3, 6, 9])
         ph, pw = rng.choice([3, 6, 9, 12]), rng.choice([6, 9, 12, 18])
