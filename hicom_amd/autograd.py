@@ -351,11 +351,20 @@ class _CompressorFn(torch.autograd.Function):
                 gc = proj.global_compressor
                 if gstore is not None:
                     gc.__dict__["_train_store"] = gstore               # partial_context fills it (and asks the kernel for the logits)
+                lc_ = proj.local_compressor
+                hold = [] if (lc_ is not None and getattr(proj, "share_window_contexts", True)) else None
+                if hold is not None:
+                    lc_.__dict__["_train_ctx"] = hold                  # (the forward's own fp32 window contexts: what the backward would recompute, bit for bit)
                 try:
                     out = proj.forward_stepwise(ff, fe, guide, modal, nl)
                 finally:
                     if gstore is not None:
                         gc.__dict__.pop("_train_store", None)
+                    if hold is not None:
+                        lc_.__dict__.pop("_train_ctx", None)
+                if hold:
+                    ctx16 = hold[0]
+                    ctx16.record_stream(torch.cuda.current_stream(ff.device))     # (made on the side stream of the two-stream forward)
                 if gstore is not None and gstore.bufs is not None:
                     ctx.global_serial = gstore.serial
         ctx.proj, ctx.modal, ctx.names = proj, modal, names
@@ -452,7 +461,7 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
     key = (tuple(ff.shape), None if fe is None else tuple(fe.shape), None if guide is None else tuple(guide.shape), modal,
            tuple(dout.shape), dout.dtype, want, want_fe, want_guide, None if nl is None else (tuple(nl.shape), nl.dtype, want_nl),
            torch.cuda.current_stream(ff.device).cuda_stream,
-           ctx16 is not None,
+           None if ctx16 is None else ctx16.dtype,
            None if store is None else id(store),          # (the captured kernels read the stores' buffers by address)
            None if gstore is None else tuple(b.data_ptr() for b in gstore.bufs))
     # what else the captured kernels read by ADDRESS: every parameter's storage and the cached device tables (pe / kpe / planes:
@@ -575,8 +584,8 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
             key_ = fe if fe is not None else ff
             rec_k = _adaptor_recompute(key_.reshape(-1, E), lc.k_proj) if lc.adapt_k else None
             rec_v = _adaptor_recompute(ff.reshape(-1, E), lc.v_proj) if lc.adapt_v else None
-        if ctx_local16 is not None:                                         # kept by the training forward (the executor's fp16 plane)
-            ctx_l = ctx_local16.float()
+        if ctx_local16 is not None:                                         # kept by the training forward (the executor's fp16 plane,
+            ctx_l = ctx_local16.float()                                     # or the operator-by-operator forward's own fp32 contexts)
         else:
             ctx_l, _ = lc.window_context(ff, fe, guide, modal, None, None,     # HIP: [Nw, E] fp32 window contexts
                                          adapt_y=(rec_k[2] if rec_k else None, rec_v[2] if rec_v else None) if adapt else None)

@@ -977,6 +977,7 @@ class HIComProjector(nn.Module):
             else:
                 ctx, grid = lc.window_context(frames_feature, frames_embed, guide_embed, modal,
                                               *self._logit_args("local"))
+                _keep_train_ctx(lc, ctx)
                 segments.append((ctx, self._layout(grid, modal, image_newline is not None, False)))
         n_local = sum(lay.n_rows for _, lay in segments)
         n_global = gc.num_queries if gc is not None else 0
@@ -997,6 +998,14 @@ class HIComProjector(nn.Module):
             gff = frames_feature["patch"].unsqueeze(0) if isinstance(frames_feature, dict) else frames_feature
             gc.forward_into(gff, guide_embed, self._logit_args("global")[0], out, row, self._logit_args("global")[1])
         return out
+
+
+def _keep_train_ctx(lc, ctx):
+    """The training forward (autograd._CompressorFn) asks for the window contexts of an operator-by-operator forward: the backward's
+    readout gradients need them, and recomputing them is a pass over every token."""
+    hold = lc.__dict__.get("_train_ctx")
+    if hold is not None:
+        hold.append(ctx)
 
 
 def _two_stream_forward(self, frames_feature, frames_embed, guide_embed, modal, image_newline=None):
@@ -1020,6 +1029,7 @@ def _two_stream_forward(self, frames_feature, frames_embed, guide_embed, modal, 
     res.side.wait_event(res.ev_fork)
     with torch.cuda.stream(res.side):
         ctx, _ = lc.window_context(ff, frames_embed, guide_embed, modal, *self._logit_args("local"))
+        _keep_train_ctx(lc, ctx)
         lc.readout_into(ctx, out, 0, lay.nl_group)
         if lay.newline_rows:
             nl = image_newline.contiguous()
