@@ -547,6 +547,7 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
                 nv.compressor_fwd(a)
             plan.graph = g
         plan.graph.replay()
+        proj.__dict__["_last_plan"] = plan             # (last_window_contexts reads the workspace of the call that just ran)
         return plan.static_out.clone()                 # callers own their result (no aliasing across calls)
     if segment is not None:
         if deferred:
