@@ -567,3 +567,33 @@ def test_captured_backward_with_image_newline(name, pass_newline):
         assert (got_nl is None) == (want_nl is None) and (want_nl is None or torch.equal(got_nl, want_nl))
     if name != "G1_direct_T8":
         assert want_nl is not None and float(want_nl.float().abs().max()) > 0
+
+
+def test_training_with_a_replayed_forward_graph_gives_the_same_gradients():
+    """`proj.graph_replay = True` replays the forward's launch sequence from a hipGraph; the training forward then still hands the backward
+    the window contexts of THAT call (they live in the plan's workspace): gradients equal the eager forward's bit for bit, on changing inputs."""
+    case = cases.build_case("G1_direct_T8")
+    m = build_module(case).train()
+    ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+    ff2 = (ff.float() * 0.5 + 0.25).to(ff.dtype)
+    cot = None
+
+    def grads_of(inp, graph):
+        nonlocal cot
+        m.graph_replay = graph
+        m.zero_grad(set_to_none=True)
+        out = m(inp, fe, g, case.modal, None)
+        if cot is None:
+            cot = torch.randn(out.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+        (out.float() * cot).sum().backward()
+        return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    try:
+        want_a, want_b = grads_of(ff, False), grads_of(ff2, False)
+        for _ in range(3):
+            got_a, got_b = grads_of(ff, True), grads_of(ff2, True)
+            assert all(torch.equal(got_a[n], want_a[n]) for n in want_a) and all(torch.equal(got_b[n], want_b[n]) for n in want_b)
+        assert not torch.equal(want_a["local_compressor.readout.0.weight"], want_b["local_compressor.readout.0.weight"])
+    finally:
+        m.graph_replay = False
+        m._invalidate_plans()
