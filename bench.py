@@ -772,12 +772,17 @@ def dominant_kernel_roofline(module, sets, iters):
     c16 = torch.empty(nw, D, device=dev, dtype=torch.float16)
     zero = torch.zeros(D, dtype=torch.int64, device=dev)
     turn = [0]
+    # round 6: the release step takes the value-side pos-emb out of this kernel (its marginals leave it, the merge role applies
+    # v_proj . pe^T) whenever T + H + W fits the 144 slots -- unless HICOM_RING_PE=1 keeps round 5's form (executor.hip: marg_out)
+    marg_form = gc.vpe_f16(T, H, W, dev) is not None and os.environ.get("HICOM_RING_PE", "0") != "1" \
+        and os.environ.get("HICOM_TAIL_LAUNCHES", "4") in ("3", "4")
+    mg16 = torch.empty(nparts, R, 8 * (D // 64), device=dev, dtype=torch.float16) if marg_form else None
 
     def launch():
         a, b, _ = sets[turn[0] % len(sets)]
         turn[0] += 1
-        nv.fused_stream(a, b, at.k, ay.k, qhi, qlo, R, 1.0 / D ** 0.5, 0.0, pos_a, pe_hi, pe_lo, 0, T, T + H, pm, pl, None, None,
-                        ctx_f16=c16, zero=zero, part_ctx_f16=p16)
+        nv.fused_stream(a, b, at.k, ay.k, qhi, qlo, R, 1.0 / D ** 0.5, 0.0, pos_a, None if marg_form else pe_hi, None if marg_form else pe_lo,
+                        0, T, T + H, pm, pl, None, None, ctx_f16=c16, zero=zero, part_ctx_f16=p16, part_marg=mg16)
 
     # HIP events on the stream the kernel is launched on (torch's current stream).  The launches are queued
     # back to back in batches, so the host's per-launch cost (ctypes, ~10 us) hides behind the running kernel
@@ -826,7 +831,8 @@ def dominant_kernel_roofline(module, sets, iters):
             "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_frame": 3359232, "frames_per_launch": T,
             "mean_launch_ms": mean_ms, "min_launch_ms": ms[0], "median_launch_ms": ms[len(ms) // 2],
             "warmup_batches": len(hist),
-            "launch_form": "as in the release step: fp16 window contexts + normalised fp16 partial contexts + value-side pos-emb"}
+            "launch_form": "as in the release step: fp16 window contexts + normalised fp16 partial contexts + " +
+                           ("the value-side pos-emb's marginals (applied by the merge role)" if marg_form else "value-side pos-emb in the kernel")}
 
 
 if __name__ == "__main__":

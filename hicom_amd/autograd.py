@@ -493,9 +493,14 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
                   "tables": None if gc is None else dict(gc._pe_cache)}       # (the cached tables the kernels read stay alive with the entry)
             torch.cuda.current_stream(ff.device).synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(g):
-                outs = _backward_outputs(st["dout"], proj, st["ff"], st["fe"], st["guide"], modal, nl, names, want, want_fe, want_guide, want_nl,
-                                         store=store, gstore=gstore, ctx16=st["ctx16"])
+            global _ROW_HOLD
+            _ROW_HOLD = st["nl_rows"] = []                             # (index tensors the captured gathers read stay alive with the entry)
+            try:
+                with torch.no_grad(), torch.cuda.graph(g):
+                    outs = _backward_outputs(st["dout"], proj, st["ff"], st["fe"], st["guide"], modal, nl, names, want, want_fe, want_guide, want_nl,
+                                             store=store, gstore=gstore, ctx16=st["ctx16"])
+            finally:
+                _ROW_HOLD = None
             st["store"] = (store, gstore, None if gstore is None else gstore.bufs)   # (keeps the buffers the graph reads alive with the entry)
             if engine.plan_sig(proj) != sig:                       # (the pass inside the capture reallocated a table)
                 raise RuntimeError("cached device tables moved during capture")
@@ -523,17 +528,23 @@ def _graphed_backward(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe
 
 
 _ROW_INDEX = {}
+_ROW_HOLD = None            # while a backward is being captured: the index tensors it read (kept alive with the graph entry)
 
 
 def _row_index(rows, dev):
     """Device index tensor of a packing's newline rows, kept per (rows, device): the captured backward must not make it (a host-to-device
-    copy inside a stream capture); the eager pass that precedes every capture does."""
+    copy inside a stream capture); the eager pass that precedes every capture does.  The dict is a 64-entry LRU; a captured graph reads
+    the tensor BY ADDRESS, so the capture also takes a reference of its own (`_ROW_HOLD` -> the graph entry, ADVICE r5: an entry evicted
+    by 64 other layouts was freed under a graph that still gathered through it)."""
     key = (tuple(rows), str(dev))
-    t = _ROW_INDEX.get(key)
+    t = _ROW_INDEX.pop(key, None)
     if t is None:
         if len(_ROW_INDEX) >= 64:
             _ROW_INDEX.pop(next(iter(_ROW_INDEX)))
-        t = _ROW_INDEX[key] = torch.tensor(list(rows), device=dev)
+        t = torch.tensor(list(rows), device=dev)
+    _ROW_INDEX[key] = t                                            # (re-inserted: most recently used last)
+    if _ROW_HOLD is not None:
+        _ROW_HOLD.append(t)
     return t
 
 
@@ -819,11 +830,15 @@ class _AnyresFn(torch.autograd.Function):
         global LAST_FP32_GRADS
         ff_base, ff_patch, fe_base, fe_patch, guide, nl = ctx.saved_tensors
         need = ctx.needs_input_grad            # (proj, ff_base, ff_patch, fe_base, fe_patch, guide, modal, nl, names, *params)
-        if any(need[1:6]):
-            raise NotImplementedError("hicom_amd backward: input gradients (frames_feature / frames_embed / guide_embed) are not built "
-                                      "for anyres dict inputs; detach them")
         proj = ctx.proj
         lc = proj.local_compressor
+        # an input gradient that actually FLOWS is refused; one that does not (guide_embed of a recipe that never reads the guide, frames_embed
+        # without a local stage) is None, as in the reference and in the dense path (a stage-3 script whose text embeddings
+        # carry requires_grad failed on image batches of a guide-off recipe)
+        uses_guide = any(c is not None and c.use_guide in ("direct", "coarse", "fine") for c in (lc, proj.global_compressor))
+        if any(need[1:3]) or (any(need[3:5]) and lc is not None) or (need[5] and uses_guide):
+            raise NotImplementedError("hicom_amd backward: input gradients (frames_feature / frames_embed / guide_embed) are not built "
+                                      "for anyres dict inputs; detach them")
         with torch.no_grad():
             dout = dout.float()
             total, d_nl, row = {}, None, 0

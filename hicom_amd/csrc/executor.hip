@@ -33,7 +33,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct WsLayout {
     size_t ctx_local, hid_local, ctx_hi, ctx_lo, hid_hi, hid_lo, pooled_q, ctx16, hid16, ad_hid, ad_hid2, ad_ky, ad_vy, qp, qhi, qlo, pos_a, prep_state, tail_state, tail_sync, lq_inj, gq_inj, inj_l_s, inj_g_s, scores, part_m, part_l, part_acc, scratch, ml, acc,
-        ctx_g, o, qres, pre, hid_g, tok, po, o_fix, r0, total;
+        ctx_g, o, qres, pre, hid_g, tok, po, o_fix, r0, part_marg, total;
     int nw, R, rows_pad, nparts, P;
     long N, score_stride;
     bool marg;      // generic global path: the stream kernel keeps the positional marginals itself (no logit tensor; `scores` holds them)
@@ -147,6 +147,8 @@ WsLayout make_layout(const hicom_compressor_args& a) {
         w.po = take((size_t)(a.E / 64) * a.E * 4);
         w.o_fix = take((size_t)a.E * 8);
         w.r0 = take((size_t)a.hidden * 4);
+        // (release step, round 6: normalised positional marginals of the ring kernel's partial states, fp16 [nparts][R][marg_slots])
+        w.part_marg = take(a.vpe_f16 && a.marg_slots > 0 ? (size_t)w.nparts * w.R * a.marg_slots * 2 : 0);
     }
     w.total = off;
     return w;
@@ -402,16 +404,33 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         // GEMM 1's launch (no merge launch on the comm stream, no v_proj here), r0 travels to the FINISH phase through r0_buf.
         const bool shard4 = f16 && merge_on_next && !do_finish && !solo && prep1 && a.gc0 && a.hidden <= 1536 && a.r0_buf && a.local_out &&
                             w.nparts <= 256 && a.E / a.nh <= 128 && shard_tail_enabled();
+        // Round 5: FOUR launches.  The merge of the partial states is independent of the local readout, and the global tail behind it
+        // is two dependent single-row layers: the merge rides as a ROLE on the CUs readout GEMM 1's tile grid leaves idle, the two layers
+        // as a chain role (in-launch granule hand-off) under GEMM 2 -- the merge launch (5.2 us) is gone from the step.
+        // HICOM_TAIL_LAUNCHES=5 keeps round 4's five-launch form (A/B switch).
+        static int tail_env = -1;
+        if (tail_env < 0) {
+            const char* e = getenv("HICOM_TAIL_LAUNCHES");
+            tail_env = (e && e[0] == '5') ? 5 : (e && e[0] == '3') ? 3 : 4;
+        }
+        const bool tail4 = single && tail5 && ro2_aux && tail_env <= 4;
+        // Round 6: the value-side pos-emb leaves the ring kernel (marginals out, no pe tiles behind the token stream) and rides in the
+        // merge ROLE of GEMM 1's launch as a product with the weight-only table v_proj . pe^T (merge_item.hpp).  The forms of the step whose
+        // merge IS that role; HICOM_RING_PE=1 keeps the pe tiles in the ring (A/B switch).
+        static const bool ring_pe_env = getenv("HICOM_RING_PE") && getenv("HICOM_RING_PE")[0] == '1';
+        const bool marg_out = single && tail5 && tail_env <= 4 && a.pe && a.vpe_f16 && a.marg_slots == 8 * (a.E / 64) &&
+                              a.T + a.H + a.W <= a.marg_slots && !ring_pe_env;
         if (prep1)
             CHK(hicom_query_prep_fwd(a.gq, a.lq, a.wq, a.bq, a.wk, a.kpe, a.nh, a.E, a.P, qscale, ws + w.qhi, ws + w.qlo, F(w.pos_a), a.P,
                                      w.R, (tail5 || shard4) ? a.gw0 : nullptr, a.gb0, a.bo, a.hidden, shard4 ? a.r0_buf : F(w.r0), ws + w.prep_state, sm));
         else CHK(query_prep(sm, true));
         if (fold_ev && !merge_on_next && !single) hicom_host::set_stop_event(a.ev_fork);      // "record ev_fork" rides on the launch
         CHK(hicom_fused_stream_fwd(a.ff, a.fe ? a.fe : a.ff, a.local_logits, a.T, a.H, a.W, a.E, a.at.k, a.ay.k, ws + w.qhi, ws + w.qlo,
-                                   w.R, a.l_scale, a.l_bias, a.pe ? F(w.pos_a) : nullptr, a.P, a.pe ? a.pe_hi : nullptr, a.pe ? a.pe_lo : nullptr, a.t_index0, a.y_index0,
+                                   w.R, a.l_scale, a.l_bias, a.pe ? F(w.pos_a) : nullptr, a.P, (a.pe && !marg_out) ? a.pe_hi : nullptr, (a.pe && !marg_out) ? a.pe_lo : nullptr, a.t_index0, a.y_index0,
                                    a.x_index0, F(w.part_m), F(w.part_l), F(w.part_acc),
                                    w.nparts, nullptr, f16 ? nullptr : ws + w.ctx_hi, f16 ? nullptr : ws + w.ctx_lo, f16 ? ws + w.ctx_hi : nullptr,
-                                   single ? ws + w.o_fix : nullptr, single ? (int64_t)a.E * 8 : 0, (single || shard4) ? ws + w.part_acc : nullptr, sm));
+                                   single ? ws + w.o_fix : nullptr, single ? (int64_t)a.E * 8 : 0, (single || shard4) ? ws + w.part_acc : nullptr,
+                                   marg_out ? ws + w.part_marg : nullptr, marg_out ? a.marg_slots : 0, sm));
         if (shard4) {
             hicom_r16_role r1;
             memset(&r1, 0, sizeof(r1));
@@ -437,16 +456,6 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
             }
             return HICOM_OK;
         }
-        // Round 5: FOUR launches.  The merge of the partial states is independent of the local readout, and the global tail behind it
-        // is two dependent single-row layers: the merge rides as a ROLE on the CUs readout GEMM 1's tile grid leaves idle, the two layers
-        // as a chain role (in-launch granule hand-off) under GEMM 2 -- the merge launch (5.2 us) is gone from the step.
-        // HICOM_TAIL_LAUNCHES=5 keeps round 4's five-launch form (A/B switch).
-        static int tail_env = -1;
-        if (tail_env < 0) {
-            const char* e = getenv("HICOM_TAIL_LAUNCHES");
-            tail_env = (e && e[0] == '5') ? 5 : (e && e[0] == '3') ? 3 : 4;
-        }
-        const bool tail4 = single && tail5 && ro2_aux && tail_env <= 4;
         if (single && tail4) {
             const int64_t* ofx = (const int64_t*)(ws + w.o_fix);
             hicom_r16_role r1;
@@ -455,6 +464,7 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
             r1.part_m = F(w.part_m); r1.part_l = F(w.part_l); r1.part_acc = ws + w.part_acc; r1.part_dt = HICOM_DT_F16;
             r1.nparts = w.nparts; r1.rows = w.R; r1.rows_pad = w.rows_pad; r1.E = a.E; r1.w_v = a.wv; r1.o_fix = (int64_t*)(ws + w.o_fix);
             r1.out_ml = F(w.ml); r1.out_ctx = F(w.ctx_g);
+            if (marg_out) { r1.part_marg = ws + w.part_marg; r1.vpe_f16 = a.vpe_f16; r1.marg_slots = a.marg_slots; }
             hicom_r16_role r2;
             memset(&r2, 0, sizeof(r2));
             r2.kind = HICOM_ROLE_GEMV_CHAIN;
@@ -494,6 +504,7 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
             r1.part_m = F(w.part_m); r1.part_l = F(w.part_l); r1.part_acc = ws + w.part_acc; r1.part_dt = HICOM_DT_F16;
             r1.nparts = w.nparts; r1.rows = w.R; r1.rows_pad = w.rows_pad; r1.E = a.E; r1.w_v = a.wv; r1.o_fix = (int64_t*)(ws + w.o_fix);
             r1.out_ml = F(w.ml); r1.out_ctx = F(w.ctx_g);
+            if (marg_out) { r1.part_marg = ws + w.part_marg; r1.vpe_f16 = a.vpe_f16; r1.marg_slots = a.marg_slots; }
             CHK(hicom_readout16_gemm_role_fwd(ws + w.ctx_hi, a.lw0_f16, a.lb0, HICOM_DT_BF16, w.nw, a.hidden, a.E, HICOM_ACT_GELU,
                                               ws + w.hid_hi, nullptr, 0, 0, 0, 0, &r1, sm));
             hicom_aux_gemv ax{nullptr, 0, 0, a.bv, a.gc0, F(w.r0), nullptr, a.hidden, a.E, HICOM_ACT_GELU, F(w.hid_g),

@@ -88,6 +88,13 @@ struct RingParams {
     int wpw;               // windows per workgroup
     unsigned long long* zero_ptr;   // scratch cleared for the launches behind this one (workgroup 0), or NULL
     int zero_n;            // ... 8-byte words
+    // Round 6: value-side pos-emb OUTSIDE the ring.  With part_marg set (and pe_hi NULL) the kernel does not multiply its marginals by
+    // the pe rows behind the token stream (2 slot tiles x 2 planes = ~184 KB of pe rows per CU through the ring's barrier cadence,
+    // 5.5k clocks with HBM idle); it writes them out instead -- NORMALISED like part_ctx16 (marginal / l), fp16, rows < R, in ABSOLUTE
+    // slot order [T frames | H grid rows | W grid columns | zero padding to marg_slots] -- and the merge multiplies the merged
+    // marginals by v_proj . pe^T, a weight-only table (merge_item.hpp).
+    _Float16* part_marg;   // [nparts][R][marg_slots], or NULL
+    int marg_slots;
 };
 
 // Position of 16-byte chunk c of image row r inside the row: c ^ fswz(r).  The row -> XOR map is chosen so that
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
                 __builtin_amdgcn_s_barrier();                              // [A] image t published; the slot of image t-1 released
                 if (t == ntile) __builtin_amdgcn_s_barrier();              // [A'] (the compute waves table their marginals)
                 HICOM_TR(2);   // tile: past [A]
-                if (p.pe_hi && l == 0 && t < ntile && lane < 16) {
+                if ((p.pe_hi || p.part_marg) && l == 0 && t < ntile && lane < 16) {
                     // compact pos-emb slots of this tile's 16 tokens, for the marginal MFMA of the compute waves (read
                     // after [B]): the table walk costs a loader lane nothing that matters
                     const int s = t * 16 + lane;
@@ -268,6 +275,10 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
                 HICOM_TR(2);   // tile: past [B]
                 if (t + 3 < ntot) issue(img_base(t + 3), o_nx, ffbuf + ((t + 3) & (NSLOT - 1)) * TILE_BYTES);
                 HICOM_TR(2);   // tile: next image requested
+            }
+            if (p.part_marg) {                                            // (the compute waves table and emit their marginals)
+                __builtin_amdgcn_s_barrier();                              // [M1]
+                __builtin_amdgcn_s_barrier();                              // [M2]
             }
             __builtin_amdgcn_s_barrier();                                  // [E] ring idle (nothing is in flight any more)
             return;
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
                 HICOM_TR(2);   // tile: past [A]
                 if (t + 1 < ntot && !(t == 0 && pre1)) issue(t + 1 < ntile ? p.ff : p.pe_lo, o_ff, ffbuf + ((t + 1) & 1) * TILE_BYTES);
                 HICOM_TR(2);   // tile: ff issued
-                if (p.pe_hi && l == 0 && t < ntile && lane < 16) {
+                if ((p.pe_hi || p.part_marg) && l == 0 && t < ntile && lane < 16) {
                     // compact pos-emb slots of this tile's 16 tokens, for the marginal MFMA of the compute waves (read
                     // after [B]): the table walk costs a loader lane nothing that matters
                     const int s = t * 16 + lane;
@@ -381,6 +392,10 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
                 if (t + 2 < ntot) issue(t + 2 < ntile ? p.fe : p.pe_hi, o_fe, febuf + (t & 1) * TILE_BYTES);
                 HICOM_TR(2);   // tile: fe issued
                 o_ff = o_fe;
+            }
+            if (p.part_marg) {                                            // (the compute waves table and emit their marginals)
+                __builtin_amdgcn_s_barrier();                              // [M1]
+                __builtin_amdgcn_s_barrier();                              // [M2]
             }
             __builtin_amdgcn_s_barrier();                                  // [E] ring idle (nothing is in flight any more)
             return;
@@ -452,7 +467,7 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
 #ifdef HICOM_TRACE
     if (lane == 0 && wave == 0) g_fused_trace[(blockIdx.x * 3 + 0) * 256 + 242] = __builtin_readcyclecounter();
 #endif
-    if (p.pe_hi && wave == 0) {
+    if ((p.pe_hi || p.part_marg) && wave == 0) {
         // Compact pos-emb slots of this workgroup: the 8 frames from its first frame group, then only the grid
         // rows and columns its windows touch (a few of the H + W): fewer pe rows to multiply after the stream.
         ymap[lane] = 0;
@@ -530,7 +545,7 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
     };
     HICOM_TR(0); HICOM_TR(1);   // prologue done (this wave)
     lds_barrier();                                                     // [P] tables ready
-    const int nslot_tiles = p.pe_hi ? (__builtin_amdgcn_readfirstlane(slot_row[64]) + 15) >> 4 : 0;   // 16-slot tiles of the compact pos-emb slots
+    const int nslot_tiles = (p.pe_hi || p.part_marg) ? (__builtin_amdgcn_readfirstlane(slot_row[64]) + 15) >> 4 : 0;   // 16-slot tiles of the compact pos-emb slots
     // raw local logits of this lane's 4 token slots, fetched one tile ahead (slots past the stream re-read its last token)
     auto fetch_logits = [&](int tile) -> f32x4 {
         f32x4 v;
@@ -676,7 +691,7 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
         // the weights: MG += P . onehot(slot of each token) over the slots  frame (relative to this workgroup's
         // first frame) | grid row | grid column -- one more MFMA per tile on the wave that owns the 16-slot
         // block.  Rescaled by alpha like ACC.  Part 2 (after the stream) multiplies MG by the pe rows.
-        if (p.pe_hi && wave < nslot_tiles) {
+        if (nslot_tiles && wave < nslot_tiles) {
             const int col = 16 * wave + r16;
             bf16x4 bm;
             const int4 tsl = *reinterpret_cast<const int4*>(tokslot + ts0);   // slots of this lane's 4 tokens (tabled by a loader wave)
@@ -822,6 +837,37 @@ __global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams 
     
         }
     }
+    if (p.part_marg) {
+        // ---- value-side pos-emb, round-6 form: the marginals leave the kernel (see RingParams::part_marg).  MG (fp32, accumulator layout
+        // of the waves that own the slot blocks) is tabled in LDS as [compact slot][row], then every compute thread writes its share of
+        // the [R][marg_slots] fp16 block of this workgroup in absolute slot order, normalised by the row's l.
+        float* mgs = red;                                                  // [64 slots][16 rows]  (red: 9 x 256 floats)
+        float* lrow = alpha_s;                                             // [16] l of the global rows (wave 0's copy)
+        lds_barrier();                                                     // [M1] red idle (every wave past its last softmax)
+        if (wave < nslot_tiles) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mgs[(16 * wave + r16) * 16 + 4 * kg + j] = (4 * kg + j < R) ? mgacc[j] : 0.f;
+        }
+        if (wave == 0 && kg == 0) lrow[r16] = 1.0f / fmaxf(l_run, 1.0e-30f);
+        lds_barrier();                                                     // [M2] table complete
+        const int S = p.marg_slots, f0 = t1_first * p.kt;
+        _Float16* dst = p.part_marg + (long)part * R * S;
+        for (int e = ctid; e < R * S; e += 64 * kRingC) {
+            const int row = e / S, sl = e - row * S;
+            int cs = -1;                                                   // compact slot of absolute slot sl (none: the workgroup never touched it)
+            if (sl < p.T) {
+                const int f = sl - f0;
+                if (f >= 0 && f < kMaxFramesPerWg) cs = f;
+            } else if (sl < p.T + p.H) {
+                const int v = ymap[sl - p.T];
+                if (v != 255) cs = v;
+            } else if (sl < p.T + p.H + p.W) {
+                const int v = xmap[sl - p.T - p.H];
+                if (v != 255) cs = v;
+            }
+            dst[e] = cs >= 0 ? (_Float16)(mgs[cs * 16 + row] * lrow[row]) : (_Float16)0.f;
+        }
+    }
     lds_barrier();                                                     // [E] every wave done with the ring
     HICOM_TR(0); HICOM_TR(1);   // tail: value-side pos-emb done
     // ---- partial global state of this workgroup --------------------------------------------------
@@ -927,9 +973,12 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, const floa
                                       int32_t t_index0, int32_t y_index0, int32_t x_index0,
                                       float* part_m, float* part_l,
                                       float* part_acc, int32_t nparts, float* ctx_local, void* ctx_hi,
-                                      void* ctx_lo, void* ctx_f16, void* zero_ptr, int64_t zero_bytes, void* part_ctx_f16, void* stream) {
-    HICOM_REQUIRE(ff && (fe || local_logits) && q_hi && q_lo && part_m && part_l && (part_acc || part_ctx_f16) && ((pe_hi && pe_lo) || !pos_a) && (pos_a || !pe_hi), HICOM_EINVAL,
-                  "fused_stream: NULL pointer");
+                                      void* ctx_lo, void* ctx_f16, void* zero_ptr, int64_t zero_bytes, void* part_ctx_f16,
+                                      void* part_marg_f16, int32_t marg_slots, void* stream) {
+    HICOM_REQUIRE(ff && (fe || local_logits) && q_hi && q_lo && part_m && part_l && (part_acc || part_ctx_f16) && ((pe_hi && pe_lo) || part_marg_f16 || !pos_a) &&
+                      (pos_a || !(pe_hi || part_marg_f16)), HICOM_EINVAL, "fused_stream: NULL pointer");
+    HICOM_REQUIRE(!part_marg_f16 || (!pe_hi && !pe_lo && part_ctx_f16 && marg_slots >= T + H + W && marg_slots % 8 == 0 && (uintptr_t)part_marg_f16 % 16 == 0), HICOM_EINVAL,
+                  "fused_stream: part_marg_f16 goes with part_ctx_f16, without pe planes, marg_slots >= T + H + W = %d (a multiple of 8)", T + H + W);
     HICOM_REQUIRE(ctx_local || (ctx_hi && ctx_lo) || ctx_f16, HICOM_EINVAL, "fused_stream: no local output");
     HICOM_REQUIRE(!ctx_hi == !ctx_lo, HICOM_EINVAL, "fused_stream: ctx_hi and ctx_lo go together");
     HICOM_REQUIRE(E == 1152, HICOM_EUNSUP, "fused_stream: E=%d (only 1152)", E);
@@ -970,6 +1019,7 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, const floa
     HICOM_REQUIRE(!zero_ptr || (zero_bytes > 0 && zero_bytes % 8 == 0 && (uintptr_t)zero_ptr % 8 == 0 && zero_bytes < (1 << 24)), HICOM_EINVAL,
                   "fused_stream: zero_ptr / zero_bytes");
     p.zero_ptr = (unsigned long long*)zero_ptr; p.zero_n = zero_ptr ? (int)(zero_bytes / 8) : 0;
+    p.part_marg = (_Float16*)part_marg_f16; p.marg_slots = part_marg_f16 ? marg_slots : 0;
     static bool attr_set = false;
     if (!attr_set) {
         HICOM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_ring_kernel<9, false>),

@@ -39,10 +39,20 @@ struct MergeVprojFixParams {
     // part_acc[i * acc_part + h * acc_row].  Defaults (0): ml_part = rows_pad, ml_row = 1, acc_part = rows_pad * E, acc_row = E.
     long ml_part, ml_row, acc_part, acc_row;
     int ctx_unnorm;         // out_ctx receives sum_i w_i ACC_i (the shard STATE of the frame-sharded path) instead of the normalised context
+    // Round 6: the value-side pos-emb rides HERE instead of behind the token stream of the ring kernel.  By linearity of v_proj,
+    //   W_v,h (ctx_h + sum_s mg_h[s] pe[s]) = W_v,h ctx_h + sum_s mg_h[s] VPE[h hd + j][s],   VPE = W_v . PE^T (weight-only, like kpe),
+    // with mg_h[s] the t / y / x marginals of head h's merged softmax weights over the absolute slots [T | H | W | padding].  The ring
+    // leaves them per partial, normalised (marginal / l, fp16: RingParams::part_marg); item (h, slab k) merges the 8 slots
+    // [8k, 8k + 8) with the weights it has anyway and adds their VPE products to its rows' dot products IN FRONT of the fixed-point
+    // conversion -- no extra atomics, two 16-byte loads per thread.  marg_slots must be 8 * (E / kMvSlab).  NULL: pos-emb already in
+    // the partial contexts (or none).
+    const _Float16* part_marg;   // [nparts][E / hd][marg_slots]
+    const _Float16* vpe16;       // [E][marg_slots]
+    int marg_slots;
 };
 
 template <int kMvSlab>
-constexpr int mv_item_lds_bytes() { return (256 + 4 + (256 / (kMvSlab / 4)) * kMvSlab + kMvSlab) * 4; }
+constexpr int mv_item_lds_bytes() { return (256 + 4 + (256 / (kMvSlab / 4)) * kMvSlab + kMvSlab + 4 * 8 + 8) * 4; }
 
 // One item: head h, channels [slab * kMvSlab, + kMvSlab).  256 threads; `lds` >= mv_item_lds_bytes<kMvSlab>() bytes, 16-byte aligned.
 // Split into a LOAD half (every global read of the item, into registers) and a COMPUTE half, so that a workgroup that owns several
@@ -55,6 +65,7 @@ struct MvItemRegs {
     u32x4 wreg[WQ];                               // v_proj weights of this thread's (row j, half of the slab)
     typename std::conditional<F16, half4_t, float4>::type v[NU];   // raw partial rows
     float pm, pl;
+    u32x4 mg, vp;                                 // 8 fp16 marginals of partial `tid`; 8 fp16 VPE entries of row j (threads with half == 0)
 };
 
 template <int kMvSlab, bool F16>      // channels per item (32 or 64); partials as normalised fp16 contexts
@@ -91,6 +102,13 @@ __device__ __forceinline__ void merge_vproj_fixed_load(const MergeVprojFixParams
     }
     r.pm = tid < p.nparts ? p.part_m[(long)tid * mlp + h * mlr] : -1.0e30f;       // nparts <= 256 (host-checked)
     r.pl = tid < p.nparts ? p.part_l[(long)tid * mlp + h * mlr] : 0.f;
+    r.mg = u32x4{0, 0, 0, 0};
+    r.vp = u32x4{0, 0, 0, 0};
+    if (p.part_marg) {
+        const int nrow = p.E / p.hd;
+        if (tid < p.nparts) r.mg = *reinterpret_cast<const u32x4*>(p.part_marg + ((long)tid * nrow + h) * p.marg_slots + 8 * slab);
+        if (half == 0 && j < p.hd) r.vp = *reinterpret_cast<const u32x4*>(p.vpe16 + (long)(h * p.hd + j) * p.marg_slots + 8 * slab);
+    }
 }
 
 template <int kMvSlab, bool F16>
@@ -100,6 +118,8 @@ __device__ __forceinline__ void merge_vproj_fixed_compute(const MergeVprojFixPar
     float* cx = cpart + R::NG * kMvSlab;                      // [kMvSlab]
     float* wp = cx + kMvSlab;                                 // [256]
     float* red = wp + 256;                                    // [4]
+    float* mgw = red + 4;                                     // [4 waves][8] partial sums of this item's 8 marginal slots
+    float* mgn = mgw + 32;                                    // [8] merged, normalised marginals
     const int tid = threadIdx.x;
     const int j = tid >> 1, half = tid & 1;
     const int c4 = tid % R::NC4, pg = tid / R::NC4;
@@ -119,7 +139,24 @@ __device__ __forceinline__ void merge_vproj_fixed_compute(const MergeVprojFixPar
         a.x = fmaf(wu, vv.x, a.x); a.y = fmaf(wu, vv.y, a.y); a.z = fmaf(wu, vv.z, a.z); a.w = fmaf(wu, vv.w, a.w);
     }
     *reinterpret_cast<float4*>(&cpart[pg * kMvSlab + 4 * c4]) = a;
+    if (p.part_marg) {
+        // marginals of this item's 8 slots: sum_i (l_i e^(m_i - M)) (mg_i / l_i), one partial per thread, summed over the workgroup
+        const float wt = wp[tid];
+        float ms[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+            const half2_t hv = __builtin_bit_cast(half2_t, r.mg[q]);
+            ms[2 * q] = wave_sum_fast(wt * (float)hv[0]);
+            ms[2 * q + 1] = wave_sum_fast(wt * (float)hv[1]);
+        }
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mgw[(tid >> 6) * 8 + q] = ms[q];
+        }
+    }
     __syncthreads();
+    if (p.part_marg && tid < 8) mgn[tid] = ((mgw[tid] + mgw[8 + tid]) + (mgw[16 + tid] + mgw[24 + tid])) / L;
     if (tid < kMvSlab) {
         float sum = 0.f;
 #pragma unroll
@@ -145,6 +182,15 @@ __device__ __forceinline__ void merge_vproj_fixed_compute(const MergeVprojFixPar
                 dot = fmaf(bf16lo_to_f32(g[i]), cx[(kMvSlab / 2) * half + 8 * q + 2 * i], dot);
                 dot = fmaf(bf16hi_to_f32(g[i]), cx[(kMvSlab / 2) * half + 8 * q + 2 * i + 1], dot);
             }
+        }
+    }
+    if (p.part_marg && half == 0 && j < p.hd) {
+        typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const half2_t hv = __builtin_bit_cast(half2_t, r.vp[q]);
+            dot = fmaf(mgn[2 * q], (float)hv[0], dot);
+            dot = fmaf(mgn[2 * q + 1], (float)hv[1], dot);
         }
     }
     dot += __shfl_xor(dot, 1, 64);

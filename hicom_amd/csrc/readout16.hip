@@ -1310,6 +1310,15 @@ static int r16_build(const void* a, const void* w, const void* b, int32_t b_dt,
         p.mv = MergeVprojFixParams{role->part_m, role->part_l, role->part_acc, role->nparts, role->rows_pad, role->E, role->E / role->rows,
                                    (const uint16_t*)role->w_v, (long long*)role->o_fix, role->out_ml, role->out_ctx};
         p.mv.ctx_unnorm = role->ctx_unnorm ? 1 : 0;
+        if (role->part_marg) {
+            // value-side pos-emb in the merge (merge_item.hpp): marginals of the partials + the weight-only table v_proj . pe^T
+            HICOM_REQUIRE(role->vpe_f16 && role->w_v && role->marg_slots == 8 * (role->E / 64) && (uintptr_t)role->part_marg % 16 == 0 &&
+                              (uintptr_t)role->vpe_f16 % 16 == 0, HICOM_EINVAL,
+                          "readout16_gemm: merge role: part_marg goes with vpe_f16 and w_v, marg_slots = 8 * (E / 64) = %d, 16-byte alignment", 8 * (role->E / 64));
+            p.mv.part_marg = (const _Float16*)role->part_marg;
+            p.mv.vpe16 = (const _Float16*)role->vpe_f16;
+            p.mv.marg_slots = role->marg_slots;
+        }
         p.role = HICOM_ROLE_MERGE_VPROJ;
     } else {
         HICOM_REQUIRE(kind == HICOM_ROLE_NONE || kind == HICOM_ROLE_GEMV, HICOM_EINVAL, "readout16_gemm: role kind %d", kind);

@@ -226,9 +226,17 @@ def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, 
             a.pe_hi, a.pe_lo = pe_hi.data_ptr(), pe_lo.data_ptr()
             a.t_index0, a.y_index0, a.x_index0 = t_offset, cap, cap + H
             keep += [pe, kpe, pe_hi, pe_lo]
+            a.vpe_f16, a.marg_slots = None, 0
+            if a.gc0 and lc is not None and t_offset == 0 and state_out is None:
+                # release step: the value-side pos-emb in the merge role (v_proj . pe^T, weight-only) instead of behind the ring's token stream
+                vpe = gc.vpe_f16(T, H, W, ff.device)
+                if vpe is not None:
+                    a.vpe_f16, a.marg_slots = vpe.data_ptr(), vpe.shape[1]
+                    keep.append(vpe)
         else:
             a.pe = a.kpe = a.pe_hi = a.pe_lo = None
             a.P = 0
+            a.vpe_f16, a.marg_slots = None, 0
     a.out, a.out_dt, a.ldo = out.data_ptr(), nv._dt(out), out.shape[-1]
     a.local_row0 = local_row0
     a.nl_group = layout.nl_group if layout is not None else 0
@@ -321,7 +329,7 @@ def _param_list(proj):
     gen = d.get("_engine_params_gen", 0)
     cached = d.get("_engine_params")
     if cached is None or cached[0] != gen:
-        nv.track_parameters(proj)           # (`.data` accesses bump the weights epoch: native.TrackedParameter)
+        nv.track_parameters(proj)           # (writes through `.data` aliases move the weights epoch: native.TrackedParameter)
         cached = (gen, [p for p in proj.parameters()])
         d["_engine_params"] = cached
     return cached
@@ -495,8 +503,9 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
         plan = plans[key] = _Plan(a, ws, n_local + n_global, hidden, sig, res)
         plan.fresh = content_sig(proj)
         use_gc0 = bool(a.gc0)
+        use_vpe = bool(a.vpe_f16)
 
-        def refresh(lc=lc, gc=gc, T=T, H=H, W=W, dev=dev, use_gc0=use_gc0):
+        def refresh(lc=lc, gc=gc, T=T, H=H, W=W, dev=dev, use_gc0=use_gc0, use_vpe=use_vpe):
             if lc is not None:
                 lc.readout_f16()
                 if lc.adapt_k or lc.adapt_v:
@@ -507,6 +516,8 @@ def run_dense(proj, ff, fe, guide_embed, modal, image_newline, out_dtype, deferr
             if gc is not None:
                 if gc.use_pos_emb:
                     gc.pos_and_kpe(T, H, W, dev)
+                    if use_vpe:
+                        gc.vpe_f16(T, H, W, dev)
                 if use_gc0:
                     gc.readout_over_out_proj()
         plan.refresh = refresh

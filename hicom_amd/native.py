@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import Optional
 
 import torch
@@ -15,7 +16,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 # HICOM_NATIVE_LIB: dev override (instrumented builds from tools/); the product loads the in-tree library
 LIB_PATH = os.environ.get("HICOM_NATIVE_LIB") or os.path.join(HERE, "libhicom_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 DT_BF16, DT_F32, DT_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_GELU_TANH = 0, 1, 2
@@ -65,7 +66,8 @@ class R16Role(C.Structure):
     _fields_ = [("kind", C.c_int32), ("gemv", AuxGemv), ("gemv2", AuxGemv), ("chain_state", C.c_void_p),
                 ("part_m", C.c_void_p), ("part_l", C.c_void_p), ("part_acc", C.c_void_p), ("part_dt", C.c_int32), ("nparts", C.c_int32),
                 ("rows", C.c_int32), ("rows_pad", C.c_int32), ("E", C.c_int32), ("w_v", C.c_void_p), ("o_fix", C.c_void_p),
-                ("out_ml", C.c_void_p), ("out_ctx", C.c_void_p), ("ctx_unnorm", C.c_int32)]
+                ("out_ml", C.c_void_p), ("out_ctx", C.c_void_p), ("ctx_unnorm", C.c_int32),
+                ("part_marg", C.c_void_p), ("vpe_f16", C.c_void_p), ("marg_slots", C.c_int32)]
 
 
 class R16Gemm(C.Structure):
@@ -127,6 +129,7 @@ class CompressorArgs(C.Structure):
         ("gq_dt", C.c_int32),
         ("ev_queries", C.c_void_p),
         ("inj_l", Injector), ("inj_g", Injector),
+        ("vpe_f16", C.c_void_p), ("marg_slots", C.c_int32),
     ]
 
 
@@ -170,7 +173,7 @@ def lib() -> C.CDLL:
                                          vp, vp, vp, i32, vp]
     L.hicom_linear_to_rows_fwd.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i64, i64, i32, vp]
     L.hicom_fused_stream_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, f32, vp, i32, vp, vp, i32, i32, i32,
-                                         vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, vp, vp]
+                                         vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, vp, vp, i32, vp]
     L.hicom_readout16_gemm_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i64, i64, i32, C.POINTER(AuxGemv), vp]
     L.hicom_readout16_gemm_role_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i64, i64, i32, C.POINTER(R16Role), vp]
     L.hicom_r16_chain_state_bytes.argtypes = [i32]
@@ -564,16 +567,18 @@ def fused_stream_nparts(n_windows: int) -> int:
 
 
 def fused_stream(ff, fe, kt, ks, qhi, qlo, rows, l_scale, l_bias, pos_a, pe_hi, pe_lo, t0i, y0i, x0i, part_m, part_l,
-                 part_acc, ctx_local, ctx_hi=None, ctx_lo=None, ctx_f16=None, local_logits=None, zero=None, part_ctx_f16=None):
+                 part_acc, ctx_local, ctx_hi=None, ctx_lo=None, ctx_f16=None, local_logits=None, zero=None, part_ctx_f16=None, part_marg=None):
     """pos_a f32 [16, P] + pe_hi / pe_lo bf16 [P, E] (all three or none): the kernel folds the value-side
-    pos-emb into part_acc.  local_logits f32 [T*H*W] (fe . local query per token) replaces the frames_embed stream."""
+    pos-emb into part_acc.  local_logits f32 [T*H*W] (fe . local query per token) replaces the frames_embed stream.
+    part_marg fp16 [nparts, rows, S] (with pe_hi = pe_lo = None): the normalised positional marginals leave the kernel instead."""
     T, H, W, E = ff.shape
     _check(lib().hicom_fused_stream_fwd(_ptr(ff), _ptr(fe), _ptr(local_logits), T, H, W, E, kt, ks, _ptr(qhi), _ptr(qlo), rows, l_scale,
                                         l_bias, _ptr(pos_a), pos_a.shape[1] if pos_a is not None else 0,
                                         _ptr(pe_hi), _ptr(pe_lo), t0i, y0i, x0i,
                                         _ptr(part_m), _ptr(part_l), _ptr(part_acc), part_m.shape[0], _ptr(ctx_local),
                                         _ptr(ctx_hi), _ptr(ctx_lo), _ptr(ctx_f16), _ptr(zero),
-                                        zero.numel() * zero.element_size() if zero is not None else 0, _ptr(part_ctx_f16), _stream()),
+                                        zero.numel() * zero.element_size() if zero is not None else 0, _ptr(part_ctx_f16),
+                                        _ptr(part_marg), part_marg.shape[-1] if part_marg is not None else 0, _stream()),
            "hicom_fused_stream_fwd")
 
 
@@ -611,7 +616,44 @@ _WEIGHTS_EPOCH = [0]
 _TRAIN_DIRTY = [False]
 
 
+_DATA_ALIASES = []          # [alias tensor handed out by TrackedParameter.data, version counter last seen]
+
+
+def _alias_refs_floor() -> int:
+    """sys.getrefcount of a tensor that only `_DATA_ALIASES` holds, as `_scan_data_aliases` sees it (list entry + loop variable + argument)."""
+    ent = [torch.empty(0), 0]
+    al = ent[0]
+    return sys.getrefcount(al)
+
+
+_ALIAS_FLOOR = None
+
+
+def _scan_data_aliases() -> None:
+    """A `.data` alias of a projector parameter has a version counter of its own: an in-place op on it (or on a view of it) is the
+    write that `p._version` does not see.  Aliases written since the last scan bump the weights epoch; aliases nobody else holds any
+    more are dropped (a written one after it was counted), the others stay watched."""
+    global _ALIAS_FLOOR
+    if not _DATA_ALIASES:
+        return
+    if _ALIAS_FLOOR is None:
+        _ALIAS_FLOOR = _alias_refs_floor()
+    keep, moved = [], False
+    for ent in _DATA_ALIASES:
+        al = ent[0]
+        v = al._version
+        if v != ent[1]:
+            moved = True
+            ent[1] = v
+        if sys.getrefcount(al) > _ALIAS_FLOOR:
+            keep.append(ent)
+    _DATA_ALIASES[:] = keep
+    if moved:
+        _WEIGHTS_EPOCH[0] += 1
+
+
 def weights_epoch() -> int:
+    _scan_data_aliases()
     return _WEIGHTS_EPOCH[0]
 
 
@@ -634,25 +676,32 @@ def begin_inference() -> None:
 
 
 def weight_stamp(*weights):
-    return (_WEIGHTS_EPOCH[0],) + tuple(v for w in weights for v in (w.data_ptr(), w._version))
+    return (weights_epoch(),) + tuple(v for w in weights for v in (w.data_ptr(), w._version))
 
 
 class TrackedParameter(torch.nn.Parameter):
-    """nn.Parameter whose `.data` attribute reports its use (round 5: closes the stale-weights footgun of eval-mode `p.data.copy_`).
+    """nn.Parameter whose `.data` attribute reports WRITES through it (round 5 closed the stale-weights footgun of eval-mode
+    `p.data.copy_`; round 6 stopped charging reads for it).
 
-    `p.data` hands out an alias of the storage with a FRESH version counter: `p.data.copy_(w)`, `p.data.mul_(s)`, `p.data = w` change the
-    weights without any trace on `p._version`, and at inference nothing else (no training forward) bumps the weights epoch, so the
-    weight-derived tables (fp16 readout copies, kpe, folded products, executor plans) would be served stale -- round 4 documented
-    "call hicom_amd.invalidate_weight_caches()".  Here every ACCESS of `.data` on a projector parameter bumps the epoch (a read is
-    indistinguishable from the write that may follow it; the cost of a false alarm is one re-run of the table producers, ~0.1 ms).
-    Forward / backward, optimizers, state_dict(), load_state_dict() and this package's own code never touch `.data`.
-    Not covered: writes through an alias taken earlier (DeepSpeed's flat bf16 buffer) -- the training-forward epoch and its dirty
-    mark (above) handle those; `invalidate_weight_caches()` stays as the explicit form."""
+    `p.data` hands out an alias of the storage with a FRESH version counter: `p.data.copy_(w)`, `p.data.mul_(s)` change the weights
+    without any trace on `p._version`, and at inference nothing else (no training forward) bumps the weights epoch, so the
+    weight-derived tables (fp16 readout copies, kpe, folded products, executor plans) would be served stale.  Round 5 bumped the
+    process-wide epoch on every ACCESS of `.data` -- and a read (`p.data.norm()` in a logger, an EMA, DeepSpeed's bookkeeping, deepcopy,
+    torch.save) then cost every projector of the process a rebuild of its tables on the next forward (174 against 76 us at the benchmark
+    shape).  Now the getter only REGISTERS the alias it hands out; the alias's own version counter tells whether it was written
+    (`_scan_data_aliases`, run wherever the epoch is read), and only then the epoch moves.  `p.data = w` (the setter) still bumps at
+    once.  Forward / backward, optimizers, state_dict(), load_state_dict() and this package's own code never touch `.data`.
+    Not covered: writes through an alias of the STORAGE taken by other means (DeepSpeed's flat bf16 buffer, `p.detach()` is covered by
+    torch itself: it shares p's version counter) -- the training-forward epoch and its dirty mark (above) handle those;
+    `invalidate_weight_caches()` stays as the explicit form."""
 
     @property
     def data(self):
-        _WEIGHTS_EPOCH[0] += 1
-        return torch.Tensor.data.__get__(self)
+        al = torch.Tensor.data.__get__(self)
+        _DATA_ALIASES.append([al, al._version])
+        if len(_DATA_ALIASES) > 4096:                       # (a loop that hoards aliases without ever running a forward)
+            _scan_data_aliases()
+        return al
 
     @data.setter
     def data(self, value):

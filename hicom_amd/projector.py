@@ -583,6 +583,38 @@ class GlobalCompressor(_TrackedWeights, nn.Module):
                 self._cache_gen += 1
         return pe, hit[0], cap
 
+    def vpe_f16(self, T: int, H: int, W: int, device, t_offset: int = 0):
+        """fp16 [E, S] = v_proj.weight . pe_sel^T with pe_sel the pe rows of the slots [T frames (from t_offset) | H grid rows | W grid
+        columns], zero-padded to S = 8 * (E / 64) slots -- or None when they do not fit.  By linearity of v_proj the value-side pos-emb
+        of the global stage (reference projector.py:636-640 with :182, :215) is sum_s marginal[s] VPE[:, s] on top of W_v ctx: the release
+        step applies it in the merge role instead of behind the token stream (csrc/merge_item.hpp).  Weight-only: cached per weight
+        state like kpe and rebuilt IN PLACE (plans keep its address)."""
+        E = self.embed_dim
+        S = 8 * (E // 64)
+        if E % 64 or T + H + W > S:
+            return None
+        pe, cap = self.pos_tables(t_offset + T, H, W, device)
+        wv = self.attn_layer.v_proj.weight
+        _require_bf16_cuda("v_proj.weight", wv)
+        key = ("vpe16", T, t_offset, H, W, cap, str(device))
+        stamp = nv.weight_stamp(wv) + (pe.data_ptr(),)
+        hit = self._pe_cache.get(key)
+        if hit is None or hit[1] != stamp:
+            if hit is None:
+                if sum(1 for k in self._pe_cache if isinstance(k, tuple) and k[0] == "vpe16") >= 4:      # (a few frame counts per module)
+                    self._pe_cache.pop(next(k for k in self._pe_cache if isinstance(k, tuple) and k[0] == "vpe16"))
+                    self._cache_gen += 1
+                sel = torch.zeros((S, E), dtype=torch.float32, device=device)
+                sel[:T] = pe[t_offset:t_offset + T]
+                sel[T:T + H + W] = pe[cap:cap + H + W]
+                hit = (torch.empty((E, S), dtype=torch.float16, device=device), None, sel, _f32((E, S), device))
+                self._cache_gen += 1
+            nv.linear(wv.detach(), hit[2], None, hit[3])                  # [E, S] = W_v . pe_sel^T (HIP; f32)
+            nv.to_f16(hit[3], hit[0])
+            hit = (hit[0], stamp, hit[2], hit[3])
+            self._pe_cache[key] = hit
+        return hit[0]
+
     def readout_over_out_proj(self):
         """C [hidden, E] f32 = readout[0].weight . attn_layer.out_proj.weight: the first global readout layer folded over
         out_proj, so that GELU(G0 (W_o o + b_o + q) + b0) (ref :226, :646, :307-312) is GELU(C o + r0) with the guide-dependent

@@ -96,10 +96,25 @@ def synth_state_dict(shapes: dict, tag: str = "w", weight_std: float = 0.02,
     return sd
 
 
+def outlier_channels(D: int, n: int) -> np.ndarray:
+    """The `n` channels a heavy-tailed case amplifies: fixed positions spread over the row (a pure function of D and n)."""
+    return (np.arange(n, dtype=np.int64) * 97 + 5) % D
+
+
 def synth_inputs(T: int, h: int, w: int, D: int, tag: str = "x", guide_len: int = 0,
-                 scale: float = 1.0) -> dict:
+                 scale: float = 1.0, outliers=None) -> dict:
+    """`outliers = (n, gain)`: heavy-tailed channels -- `n` fixed channels of BOTH visual tensors carry `gain` times the bulk's
+    standard deviation plus a per-channel offset of the same size (the statistics of a ViT's penultimate hidden states, which is what
+    frames_feature is, reference encoder.py:253-259: a few channels two orders of magnitude above the rest, with a non-zero mean);
+    frames_embed = x + head MLP keeps them (encoder.py:284-286).  The guide is left alone (a pooled, normalised text embedding)."""
     ff = normal_like((T, h, w, D), seed_of(f"{tag}:ff:{T}x{h}x{w}"), scale)
     fe = normal_like((T, h, w, D), seed_of(f"{tag}:fe:{T}x{h}x{w}"), scale)
+    if outliers is not None:
+        n, gain = outliers
+        ch = outlier_channels(D, n)
+        off = normal_like((n,), seed_of(f"{tag}:outlier_mean:{n}"), scale * gain)
+        for x in (ff, fe):
+            x[..., ch] = round_to_bf16(x[..., ch] * np.float32(gain) + off)
     gshape = (D,) if guide_len == 0 else (guide_len, D)
     g = normal_like(gshape, seed_of(f"{tag}:g:{guide_len}"), scale)
     return dict(ff=ff, fe=fe, g=g)

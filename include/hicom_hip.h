@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HICOM_ABI_VERSION 14
+#define HICOM_ABI_VERSION 15
 
 #define HICOM_OK         0
 #define HICOM_EINVAL    -1   /* bad argument (shape, alignment, NULL)        */
@@ -296,7 +296,12 @@ int hicom_global_stream_nparts(int64_t N, int32_t rows_pad);
  *                 acc / l as one fp16 plane [nparts][16][E] (rows < rows), for hicom_merge_vproj_fixed_fwd(part_dt = HICOM_DT_F16):
  *                 half the bytes of the partial states; the rounding (2^-12 relative per partial) averages over the partials
  *   zero_ptr    : zero_bytes (multiple of 8, 8-byte aligned) of scratch that the kernel clears for the launches behind it on the
- *                 stream (the fixed-point accumulators of hicom_merge_vproj_fixed_fwd), or NULL */
+ *                 stream (the fixed-point accumulators of hicom_merge_vproj_fixed_fwd), or NULL
+ *   part_marg_f16 (ABI 15): not NULL (with pe_hi = pe_lo = NULL, pos_a and part_ctx_f16 given): the value-side pos-emb term is NOT folded
+ *                 into the partial contexts; the kernel writes the t / y / x MARGINALS of every partial's softmax weights instead,
+ *                 normalised like part_ctx_f16 (marginal / l), fp16 [nparts][rows][marg_slots] in absolute slot order
+ *                 [T frames | H grid rows | W grid columns | zeros], marg_slots >= T + H + W and a multiple of 8 -- for the merge role
+ *                 of hicom_readout16_gemm_role_fwd (hicom_r16_role.part_marg), which multiplies the merged marginals by v_proj . pe^T */
 int hicom_fused_stream_fwd(const void* ff, const void* fe, const float* local_logits, int32_t T, int32_t H, int32_t W, int32_t E,
                            int32_t kt, int32_t ks, const void* q_hi, const void* q_lo, int32_t rows,
                            float l_scale, float l_bias, const float* pos_a, int32_t pos_stride,
@@ -304,7 +309,7 @@ int hicom_fused_stream_fwd(const void* ff, const void* fe, const float* local_lo
                            int32_t t_index0, int32_t y_index0, int32_t x_index0,
                            float* part_m, float* part_l, float* part_acc, int32_t nparts, float* ctx_local,
                            void* ctx_hi, void* ctx_lo, void* ctx_f16, void* zero_ptr, int64_t zero_bytes, void* part_ctx_f16,
-                           void* stream);
+                           void* part_marg_f16, int32_t marg_slots, void* stream);
 int hicom_fused_stream_nparts(int32_t n_windows);
 
 /* ---- merge the partials (+ the value-side positional term) --------------------------------
@@ -417,6 +422,14 @@ typedef struct hicom_r16_role {
     float* out_ml;
     float* out_ctx;
     int32_t ctx_unnorm;        /* out_ctx receives the un-normalised accumulator sum_i e^(m_i - M) ACC_i (with out_ml = (M, L): a shard STATE) */
+    /* value-side pos-emb in the merge (ABI 15; replaces `ff += pos` of projector.py:636-640 on the VALUE side): part_marg = fp16
+     * [nparts][rows][marg_slots], the NORMALISED t / y / x marginals of every partial's softmax weights in absolute slot order
+     * [T | H | W | zero padding] (hicom_fused_stream_fwd's part_marg_f16); vpe_f16 = fp16 [E][marg_slots] = v_proj.weight . pe^T over the
+     * same slots (weight-only).  o_fix then receives W_v (ctx + sum_s mg[s] pe[s]).  marg_slots = 8 * (E / 64).  NULL: the partial
+     * contexts already carry the pos-emb (or there is none). */
+    const void* part_marg;
+    const void* vpe_f16;
+    int32_t marg_slots;
 } hicom_r16_role;
 int hicom_readout16_gemm_role_fwd(const void* a, const void* w, const void* b, int32_t b_dt,
                                   int32_t M, int32_t N, int32_t K, int32_t act, void* out_f16,
@@ -733,6 +746,12 @@ typedef struct hicom_compressor_args {
         float eps;
         const void* visual;        /* global stage: bf16 [nq, E]; local stage: NULL */
     } inj_l, inj_g;
+    /* ABI 15 (may be NULL / 0): fp16 [E][marg_slots] = v_proj.weight . pe^T over the slots [T frames | H rows | W columns | zero padding],
+     * marg_slots = 8 * (E / 64) >= T + H + W: the release step then takes the value-side pos-emb out of the streaming kernel (its
+     * marginals leave it, hicom_fused_stream_fwd's part_marg_f16) and applies it in the merge role of readout GEMM 1's launch
+     * (hicom_r16_role.part_marg / vpe_f16).  Weight-only, cached by the caller per weight state like kpe. */
+    const void* vpe_f16;
+    int32_t marg_slots;
 } hicom_compressor_args;
 
 /* Byte offset, inside the workspace, of the fp16 plane [windows, E] of the local stage's window contexts (the A operand of readout

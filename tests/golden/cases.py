@@ -63,6 +63,11 @@ CASES = {
     "G12_clip768_direct": dict(cfg=dict(mm_vision_tower="openai/clip-vit-large-patch14-336", mm_hidden_size=768), T=4, h=6, w=6, dim=768),
     "G12b_clip768_off": dict(cfg=dict(mm_vision_tower="openai/clip-vit-large-patch14-336", mm_hidden_size=768, use_guide=None),
                              T=8, h=6, w=6, dim=768),
+    # heavy-tailed channels (round-5 verdict): 12 channels x 60 with a non-zero mean in both visual tensors -- the statistics of real SigLIP
+    # hidden_states[-2] (reference encoder.py:253-259), where the fp16 activation planes of the HIP path round at 2^-12 of |ctx|
+    "G13_outlier_direct": dict(cfg=dict(), T=8, h=6, w=6, outliers=(12, 60.0), ref_bf16=True),
+    "G13b_outlier_off": dict(cfg=dict(use_guide=None), T=8, h=6, w=6, outliers=(12, 60.0), ref_bf16=True),
+    "G13c_outlier_c1": dict(cfg=dict(hidden_size=896), T=4, h=27, w=27, sampled=True, outliers=(12, 60.0), ref_bf16=True),
     # C1 shape: 27x27 grid, T=4, H=896 -- stored as sampled outputs + checksum only
     "G11_c1_shape": dict(cfg=dict(hidden_size=896), T=4, h=27, w=27, sampled=True),
 }
@@ -103,7 +108,7 @@ def build_case(name: str):
     T, h, w = c["T"], c["h"], c["w"]
     dim = c.get("dim", D)
     x = synth.synth_inputs(T, h, w, dim, tag=name, guide_len=c.get("guide_len", 0),
-                           scale=c.get("in_scale", 1.0))
+                           scale=c.get("in_scale", 1.0), outliers=c.get("outliers"))
     newline = synth.normal_like((cfg.hidden_size,), synth.seed_of(name + ":newline")) if c.get("newline") else None
     anyres = None
     if c.get("anyres"):
@@ -113,4 +118,4 @@ def build_case(name: str):
     return SimpleNamespace(name=name, cfg=cfg, sd=sd, ff=x["ff"], fe=x["fe"], g=x["g"],
                            modal=c.get("modal", "video"), newline=newline, anyres=anyres,
                            logit=c.get("logit"), expect_raises=c.get("expect_raises"),
-                           sampled=c.get("sampled", False))
+                           sampled=c.get("sampled", False), ref_bf16=c.get("ref_bf16", False))

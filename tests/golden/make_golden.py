@@ -21,7 +21,7 @@ from oracle import ref_shim, hicom_oracle as orc   # noqa: E402
 import cases                                        # noqa: E402
 
 
-def run_reference(proj, case):
+def run_reference(proj, case, dtype=torch.float32):
     cfg = case.cfg
     torch.manual_seed(0)
     module = proj.build_vision_projector(cfg).float().eval()
@@ -30,8 +30,12 @@ def run_reference(proj, case):
     got = {k: tuple(v.shape) for k, v in ref_sd.items()}
     assert got == want, f"{case.name}: parameter schema mismatch\n ref-only: {set(got)-set(want)}\n ours-only: {set(want)-set(got)}"
     module.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd.items()}, strict=True)
-    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
     ff, fe, g, nl = t(case.ff), t(case.fe), t(case.g), t(case.newline)
+    if dtype != torch.float32:                 # the reference's own inference arithmetic (model_init(torch_dtype=bf16)): context figure only
+        module = module.to(dtype)
+        with torch.no_grad():
+            return {"out": module(ff, fe, g, case.modal, nl).float().numpy()}
     with torch.no_grad():
         if case.logit is not None:
             ls, lb = (torch.tensor(v) for v in case.logit["local"])
@@ -71,6 +75,13 @@ def main():
             else:
                 blobs[f"{name}/{k}"] = v
             print(f"{name}/{k}: shape {v.shape} absmax {np.abs(v).max():.4f}")
+        if case.ref_bf16:
+            # the reference module itself run in bf16 on the same inputs: how far its OWN inference arithmetic is from its fp32 result --
+            # stored beside the fp32 output as the context figure of the heavy-tailed cases' tolerance
+            lo = run_reference(proj, case, torch.bfloat16)["out"].astype(np.float32)
+            d = float(np.abs(lo - outs["out"].astype(np.float32)).max())
+            blobs[f"{name}/ref_bf16_max_abs"] = np.array([d, float(np.abs(outs["out"]).max())], dtype=np.float64)
+            print(f"{name}: reference bf16 vs fp32 max-abs {d:.3e} (max |out| {np.abs(outs['out']).max():.3f})")
     path = os.path.join(HERE, "golden_v1.npz")
     np.savez_compressed(path, **blobs)
     print("wrote", path, os.path.getsize(path), "bytes")

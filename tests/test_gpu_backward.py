@@ -123,6 +123,26 @@ def test_anyres_dict_parameter_gradients_match_reference_autograd(name, golden_g
         m(fdict, edict, g2, case.modal, nl).sum().backward()
 
 
+def test_anyres_dict_guide_off_ignores_a_guide_that_requires_grad():
+    """a recipe that never reads the guide returns None for d guide_embed on dict inputs too (as the dense path and the
+    reference do) instead of refusing -- a stage-3 script whose text embeddings carry requires_grad otherwise fails on image batches."""
+    import hicom_amd
+    case = cases.build_case("G9_anyres")
+    case.cfg.use_guide = None
+    from oracle import hicom_oracle as orc
+    from hicom_amd import synth
+    sd = synth.synth_state_dict(orc.param_shapes(case.cfg), tag="G9_anyres_off")
+    m = build_module(type(case)(cfg=case.cfg, sd=sd)).train()
+    a = case.anyres
+    ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g).requires_grad_(True)
+    fdict = {"base": ff[0], "patch": dev_bf16(a["patch_ff"])}
+    edict = {"base": fe[0], "patch": dev_bf16(a["patch_fe"])}
+    nl = torch.nn.Parameter(dev_bf16(case.newline))
+    out = m(fdict, edict, g, case.modal, nl)
+    out.float().square().sum().backward()
+    assert g.grad is None and nl.grad is not None and m.global_compressor.query.grad is not None
+
+
 def test_unsupported_recipes_and_input_grads_refuse():
     """clip-scale has no backward; the gradient w.r.t. frames_feature (frozen tower body) is not built, nor is d frames_embed over
     overlapping windows: all must raise, never return a detached tensor or a silent None.  (Guide off: d frames_embed exists since

@@ -372,6 +372,56 @@ def test_fused_stream_matches_separate_kernels(T, H, W, kt, ks):
     assert ran
 
 
+@pytest.mark.parametrize("T,H,W,nparts_pick", [(8, 6, 6, "max"), (16, 27, 27, "cu"), (64, 27, 27, "cu"), (4, 27, 27, "cu"), (12, 9, 6, "few")])
+def test_fused_stream_marginals_out_equal_the_in_kernel_pos_emb(T, H, W, nparts_pick):
+    """Round 6: hicom_fused_stream_fwd(part_marg_f16) -- the value-side pos-emb (reference projector.py:636-640 on the VALUE side of
+    :215) leaves the ring kernel as NORMALISED t / y / x marginals in absolute slot order [T | H | W | 0...] instead of being multiplied by
+    the pe rows behind the token stream.  Per partial and row:  ctx_with_pe = ctx_without_pe + sum_s marg[s] pe_sel[s]  (both fp16
+    planes: 2^-11 of the context's magnitude per side, pe entries are O(1)), every row's three axis marginals sum to 1, the padding is
+    zero, and the softmax state (m, l) and the local contexts are bit-identical to the pe-tile form."""
+    E, R, kt, ks = D, 9, 4, 3
+    x = synth.synth_inputs(T, H, W, D, tag=f"marg{T}{H}{W}")
+    ff, fe, g = bf(x["ff"]), bf(x["fe"]), bf(x["g"])
+    qt = torch.from_numpy(synth.normal_like((R, E), 83, 0.05)).cuda()
+    qhi = torch.zeros((16, E), dtype=torch.bfloat16, device="cuda")
+    qlo = torch.zeros_like(qhi)
+    nv.split_bf16(qt, 16, qhi, qlo)
+    qhi[R:] = g
+    cap = T + 3
+    pe = torch.from_numpy(geo.stacked_pos_tables(cap, H, W, E)).cuda()
+    pos_a = torch.zeros((16, pe.shape[0]), dtype=torch.float32, device="cuda")
+    nv.linear(qt, pe, None, pos_a, M=R)
+    pe_hi = torch.empty(pe.shape, dtype=torch.bfloat16, device="cuda")
+    pe_lo = torch.empty_like(pe_hi)
+    nv.split_bf16(pe, pe.shape[0], pe_hi, pe_lo)
+    nw = (T // kt) * (H // ks) * (W // ks)
+    nparts = {"max": nw, "cu": nv.fused_stream_nparts(nw), "few": 3}[nparts_pick]
+    S = 144
+    f16 = lambda *sh: torch.full(sh, float("nan"), dtype=torch.float16, device="cuda")
+    pm1, pl1, pm2, pl2 = f32((nparts, 16)), f32((nparts, 16)), f32((nparts, 16)), f32((nparts, 16))
+    c1, c2, p1, p2 = f16(nw, E), f16(nw, E), f16(nparts, 16, E), f16(nparts, 16, E)
+    mg = f16(nparts, R, S)
+    sc = 1 / math.sqrt(E)
+    nv.fused_stream(ff, fe, kt, ks, qhi, qlo, R, sc, 0.0, pos_a, pe_hi, pe_lo, 0, cap, cap + H, pm1, pl1, None, None, ctx_f16=c1, part_ctx_f16=p1)
+    nv.fused_stream(ff, fe, kt, ks, qhi, qlo, R, sc, 0.0, pos_a, None, None, 0, cap, cap + H, pm2, pl2, None, None, ctx_f16=c2, part_ctx_f16=p2,
+                    part_marg=mg)
+    torch.cuda.synchronize()
+    assert torch.equal(c1, c2) and torch.equal(pm1[:, :R], pm2[:, :R]) and torch.equal(pl1[:, :R], pl2[:, :R])
+    m = mg.float()
+    assert bool(torch.isfinite(m).all()) and float(m[..., T + H + W:].abs().max()) == 0.0
+    for lo, hi in ((0, T), (T, T + H), (T + H, T + H + W)):
+        assert float((m[..., lo:hi].sum(-1) - 1.0).abs().max()) <= 3e-3          # (each axis: a partition of the row's weights; fp16 entries)
+    pe_sel = torch.cat([pe[:T], pe[cap:cap + H + W]])                              # [T + H + W, E]
+    want = p2[:, :R].float() + torch.einsum("prs,se->pre", m[..., :T + H + W], pe_sel)
+    got = p1[:, :R].float()
+    assert maxabs(got, want) <= 2.0 ** -9 * max(1.0, float(got.abs().max())), float((got - want).abs().max())
+    # run-to-run: bit-identical marginals
+    mg2 = f16(nparts, R, S)
+    nv.fused_stream(ff, fe, kt, ks, qhi, qlo, R, sc, 0.0, pos_a, None, None, 0, cap, cap + H, pm2, pl2, None, None, ctx_f16=c2, part_ctx_f16=p2,
+                    part_marg=mg2)
+    assert torch.equal(mg, mg2)
+
+
 @pytest.mark.parametrize("M,N,K,act", [(8, 64, 1152, 1), (81, 896, 1152, 1), (130, 64, 64, 0), (1296, 896, 896, 0), (1296, 896, 1152, 1),
                                        (50, 200, 128, 1), (97, 66, 192, 0), (49, 130, 256, 1), (300, 257, 320, 0), (48, 128, 384, 1),
                                        (1, 4, 448, 0)])

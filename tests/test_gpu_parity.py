@@ -49,6 +49,36 @@ def test_matches_reference_golden(name, golden):
     assert err <= TOL, f"{name}: max-abs {err:.3e}"
 
 
+# Heavy-tailed channels (round-5 verdict, weak #2): 12 channels x 60 with a non-zero mean in both visual tensors, the statistics of real
+# SigLIP hidden_states[-2] (reference encoder.py:253-259).  The outputs grow with them (max |out| 2.1 at hidden 64, 11.5 at the C1 shape)
+# and so does every rounding: the HIP path carries window contexts / hidden activations as ONE fp16 plane (2^-12 relative), the
+# reference's own bf16 inference arithmetic rounds at 2^-9.  Tolerance: HEAVY_REL of max |out| (the absolute 1e-3 of the N(0,1) cases is
+# the same bar at max |out| ~ 1), asserted beside the reference-bf16-vs-reference-fp32 figure stored in the fixture, which the HIP path
+# must beat by HEAVY_VS_REF_BF16.
+HEAVY_REL = 1e-3
+HEAVY_VS_REF_BF16 = 8.0
+
+
+@pytest.mark.parametrize("name", ["G13_outlier_direct", "G13b_outlier_off", "G13c_outlier_c1"])
+def test_heavy_tailed_channels_match_reference_golden(name, golden):
+    case = cases.build_case(name)
+    got = run_native(case)["out"].float().cpu().numpy()
+    ref_bf16_err, out_max = (float(v) for v in golden[f"{name}/ref_bf16_max_abs"])
+    if case.sampled:
+        assert tuple(golden[f"{name}/out_shape"]) == got.shape
+        r, c = cases.sample_index(*got.shape)
+        err = np.abs(got[r, c] - golden[f"{name}/out_samples"]).max()
+        want = run_oracle(case)["out"].numpy()            # full tensor through the pinned oracle
+        err = max(err, np.abs(got - want).max())
+    else:
+        ref = golden[f"{name}/out"]
+        assert got.shape == ref.shape
+        err = np.abs(got - ref).max()
+    print(f"{name}: max-abs {err:.3e}  max|out| {out_max:.3f}  relative {err / out_max:.3e}  reference bf16 vs fp32 {ref_bf16_err:.3e}")
+    assert err <= HEAVY_REL * max(out_max, 1.0), f"{name}: max-abs {err:.3e} of max|out| {out_max:.3f}"
+    assert err * HEAVY_VS_REF_BF16 <= ref_bf16_err, f"{name}: {err:.3e} against the reference's own bf16 deviation {ref_bf16_err:.3e}"
+
+
 @pytest.mark.parametrize("name", ["G8_clip_scale", "G8b_clip_coarse", "G8c_clip_fine", "G8d_clip_direct_adaptg", "G8e_clip_adaptkv"])
 def test_clip_scale_local_matches_golden(golden, name):
     """Clip-scale on the LOCAL stage (reference projector.py:527-529, :549); with an injector or an adapted guide the guide rows are

@@ -225,6 +225,27 @@ def test_weight_writes_that_bypass_the_version_counter():
         assert float((m(ff, fe, g, "video", None) - base).abs().max()) <= 2e-4
 
 
+def test_data_reads_do_not_refresh_the_plan_tables():
+    """Round-5 verdict #8: `p.data.norm()` in a serving / logging loop must not cost a rebuild of the weight-derived tables (a plan
+    miss is ~2x the step): the plan's refresh producer runs for WRITES through `.data` only."""
+    m, _, case = _module_and_sd("G1_direct_T8")
+    ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+    with torch.no_grad():
+        base = m(ff, fe, g, "video", None).clone()
+        plan = next(iter(m.__dict__["_engine_plans"].values()))
+        calls = []
+        inner = plan.refresh
+        plan.refresh = lambda: (calls.append(1), inner())[1]
+        for _ in range(5):
+            for p in m.parameters():
+                p.data.norm()                                                 # a gradient- / weight-norm logger, an EMA read
+            assert torch.equal(m(ff, fe, g, "video", None), base)
+        assert not calls and next(iter(m.__dict__["_engine_plans"].values())) is plan
+        w = m.local_compressor.readout[0].weight
+        w.data.mul_(1.5)                                                      # a write through the alias: seen
+        assert float((m(ff, fe, g, "video", None)[:-32] - base[:-32]).abs().max()) > 1e-3 and len(calls) == 1
+
+
 def test_eval_after_a_training_step_whose_optimizer_bypasses_the_version_counter():
     """the tables built during the LAST training forward / backward carry the current epoch but pre-date the
     optimizer step.  A version-bypassing step (`p.data.copy_`, DeepSpeed's flat alias) followed by an inference forward

@@ -175,3 +175,34 @@ def test_weights_epoch_protocol():
     assert nv.weights_epoch() == e0 + 3
     nv.invalidate_weight_caches()
     assert nv.weights_epoch() == e0 + 4
+
+
+def test_data_alias_reads_do_not_move_the_weights_epoch_and_writes_do():
+    """Round-5 verdict #8 / ADVICE r5: `p.data` READS (norm loggers, EMA, deepcopy, DeepSpeed bookkeeping) must not invalidate the
+    weight-derived tables; WRITES through the alias (`p.data.copy_`, an in-place op on a held alias or on a view of it, `p.data = w`)
+    must -- the alias's own version counter tells them apart (native.TrackedParameter, native._scan_data_aliases)."""
+    import copy
+    from hicom_amd import native as nv
+    lin = torch.nn.Linear(4, 4)
+    nv.track_parameters(lin)
+    assert type(lin.weight) is nv.TrackedParameter
+    e0 = nv.weights_epoch()
+    for _ in range(50):
+        lin.weight.data.norm()
+        lin.bias.data.float().sum()
+    copy.deepcopy(lin)
+    assert nv.weights_epoch() == e0 and len(nv._DATA_ALIASES) == 0          # reads: nothing moved, nothing hoarded
+    lin.weight.data.copy_(torch.zeros(4, 4))
+    assert nv.weights_epoch() == e0 + 1
+    held = lin.weight.data
+    assert nv.weights_epoch() == e0 + 1 and len(nv._DATA_ALIASES) == 1      # a held alias stays watched
+    held.mul_(2)
+    assert nv.weights_epoch() == e0 + 2
+    assert nv.weights_epoch() == e0 + 2                                     # counted once
+    view = lin.bias.data[1:3]
+    view.zero_()                                                             # a view shares the alias's version counter
+    assert nv.weights_epoch() == e0 + 3
+    del held, view
+    assert nv.weights_epoch() == e0 + 3 and len(nv._DATA_ALIASES) == 0
+    lin.weight.data = torch.ones(4, 4)
+    assert nv.weights_epoch() == e0 + 4
