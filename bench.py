@@ -384,6 +384,19 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 extras[k]["median"] = float(t.item())
 
+    # in-launch hand-offs (query prep granules, the GEMV chain under readout GEMM 2 / in the FINISH phase) whose bounded spin expired
+    # during everything above: such a step returns NaN rows and only counts it -- the line carries the counters
+    handoff = {"query_prep": 0, "gemv_chain": 0, "checked_workspaces": 0}
+    blocks = [p.args for p in module.__dict__.get("_engine_plans", {}).values()]
+    for sp in module.__dict__.get("_shard_plans", {}).values():
+        blocks += [b for st in sp.sets for b in (st.a_stream, st.a_finish)]
+    for blk in blocks:
+        qp, ch = nv.compressor_handoff_failures(blk)
+        handoff["query_prep"] += qp
+        handoff["gemv_chain"] += ch
+        handoff["checked_workspaces"] += 1
+    assert handoff["query_prep"] == 0 and handoff["gemv_chain"] == 0, f"failed in-launch hand-offs during the bench: {handoff}"
+
     # ---- roofline of the dominant kernel (HIP events on the stream it is launched on) ----------
     roofline = dominant_kernel_roofline(module, sets, args.steps)
 
@@ -405,6 +418,7 @@ def main():
         "input_visual_tokens_per_sec": total_frames * GRID * GRID / (ms_per_step * 1e-3),
         "whole_step_hbm_frac": (alg_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if args.hidden == 896 else None,
         **extras,
+        "handoff_failures": handoff,
         "roofline": roofline,
     }
     if args.hidden == 896 and "ms_per_step_batches" in extras:
@@ -772,9 +786,9 @@ def dominant_kernel_roofline(module, sets, iters):
     c16 = torch.empty(nw, D, device=dev, dtype=torch.float16)
     zero = torch.zeros(D, dtype=torch.int64, device=dev)
     turn = [0]
-    # round 6: the release step takes the value-side pos-emb out of this kernel (its marginals leave it, the merge role applies
-    # v_proj . pe^T) whenever T + H + W fits the 144 slots -- unless HICOM_RING_PE=1 keeps round 5's form (executor.hip: marg_out)
-    marg_form = gc.vpe_f16(T, H, W, dev) is not None and os.environ.get("HICOM_RING_PE", "0") != "1" \
+    # round 6: with HICOM_RING_MARG=1 the release step takes the value-side pos-emb out of this kernel (its marginals leave it, the merge
+    # role applies v_proj . pe^T; opt-in: measured a net loss, executor.hip: marg_out) -- the kernel is then timed in that form
+    marg_form = gc.vpe_f16(T, H, W, dev) is not None and os.environ.get("HICOM_RING_MARG", "0") == "1" \
         and os.environ.get("HICOM_TAIL_LAUNCHES", "4") in ("3", "4")
     mg16 = torch.empty(nparts, R, 8 * (D // 64), device=dev, dtype=torch.float16) if marg_form else None
 

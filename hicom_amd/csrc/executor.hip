@@ -200,6 +200,20 @@ bool shard_tail_enabled() {
     return v == 1;
 }
 
+// Frame-sharded release step in the four-launch form (round 5): the shard's state (M, L, ACC) comes out of the merge ROLE of GEMM 1's
+// launch, r0 travels to the FINISH phase through r0_buf.  ONE predicate for the STREAM call and for hicom_compressor_takes_shard4 (the
+// caller clears r0_buf in both blocks when it is false, so FINISH never consumes an r0 that STREAM did not write: ADVICE r5).
+bool shard4_form(const hicom_compressor_args& a, const WsLayout& w) {
+    const bool do_stream = a.phases & HICOM_PHASE_STREAM, do_finish = a.phases & HICOM_PHASE_FINISH;
+    const bool fused = do_stream && can_fuse(a);
+    const bool merge_on_next = fused && (a.phases & HICOM_PHASE_MERGE_ON_NEXT);
+    const bool f16 = a.lw0_f16 && a.lw2_f16;
+    const bool solo = a.state_out == nullptr;
+    const bool prep1 = a.nq == 1 && a.E % 128 == 0 && a.E <= 1536 && a.E / a.nh <= 128;
+    return fused && f16 && merge_on_next && !do_finish && !solo && prep1 && a.gc0 && a.hidden <= 1536 && a.hidden % 8 == 0 && a.r0_buf && a.local_out &&
+           w.nparts <= 256 && a.E / a.nh <= 128 && a.E % 64 == 0 && shard_tail_enabled();
+}
+
 int check_args(const hicom_compressor_args& a) {
     HICOM_REQUIRE(a.has_local || a.has_global, HICOM_EINVAL, "compressor: nothing to do");
     HICOM_REQUIRE(a.ff && a.out && a.ws, HICOM_EINVAL, "compressor: NULL pointer");
@@ -274,7 +288,32 @@ extern "C" int64_t hicom_compressor_workspace_bytes(const hicom_compressor_args*
 extern "C" int64_t hicom_compressor_zero_prefix_bytes(const hicom_compressor_args* a) {
     if (!a) return HICOM_EINVAL;
     const WsLayout w = make_layout(*a);
+    // a FINISH-only block (frame-sharded step): everything -- its fixed-point accumulators o_fix are cleared by the chain launch BEHIND
+    // each use (hicom_aux_gemv.x_fixed_clear), so they have to start at zero
+    if (!(a->phases & HICOM_PHASE_STREAM)) return (int64_t)w.total;
     return (int64_t)(a->has_local ? w.ctx_local : w.qp);      // qhi | qlo | pos_a | prep_state | tail_state | tail_sync
+}
+
+extern "C" int hicom_compressor_takes_shard4(const hicom_compressor_args* a) {
+    if (!a) return 0;
+    return shard4_form(*a, make_layout(*a)) ? 1 : 0;
+}
+
+extern "C" int hicom_compressor_handoff_failures(const hicom_compressor_args* a, int32_t* out, void* stream) {
+    HICOM_REQUIRE(a && out && a->ws, HICOM_EINVAL, "handoff_failures: NULL pointer");
+    const WsLayout w = make_layout(*a);
+    out[0] = out[1] = 0;
+    if (!a->has_global) return HICOM_OK;
+    const char* ws = (const char*)a->ws;
+    unsigned v[2] = {0, 0};
+    hipStream_t st = (hipStream_t)stream;
+    // word 2 of each state block: the sticky count of expired hand-off spins (query_prep.hip, readout16.hip: gemv_chain_role)
+    HICOM_REQUIRE(hipMemcpyAsync(&v[0], ws + w.prep_state + 8, 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                      hipMemcpyAsync(&v[1], ws + w.tail_state + 8, 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                      hipStreamSynchronize(st) == hipSuccess, HICOM_ELAUNCH, "handoff_failures: device read");
+    out[0] = (int32_t)v[0];
+    out[1] = (int32_t)v[1];
+    return HICOM_OK;
 }
 
 extern "C" int hicom_compressor_is_fused(const hicom_compressor_args* a) {
@@ -287,6 +326,12 @@ extern "C" int64_t hicom_compressor_ctx16_offset(const hicom_compressor_args* a)
     if (!(a->phases & HICOM_PHASE_STREAM) || !(a->lw0_f16 && a->lw2_f16) || a->E % 64 != 0 || a->hidden % 64 != 0) return HICOM_EUNSUP;
     const WsLayout w = make_layout(*a);
     return (int64_t)((a->has_global && can_fuse(*a)) ? w.ctx_hi : w.ctx16);
+}
+
+extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap);
+extern "C" int hicom_compressor_fwd2(const hicom_compressor_args* first, const hicom_compressor_args* second) {
+    if (int rc = hicom_compressor_fwd(first)) return rc;
+    return hicom_compressor_fwd(second);
 }
 
 extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
@@ -308,6 +353,9 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
     const bool fused = do_stream && can_fuse(a);
     HICOM_REQUIRE(!a.local_logits || fused, HICOM_EINVAL, "compressor: local_logits is an input of the fused stream kernel only (release recipe)");
     const bool merge_on_next = fused && (a.phases & HICOM_PHASE_MERGE_ON_NEXT);
+    // HICOM_PHASE_NEXT_IS_MAIN: what follows the STREAM phase runs on THIS call's main stream (a joined frame-sharded step: both phases on the
+    // caller's stream) -- no event wait between the phases; stream_next is ignored (the caller's stream may be the null stream: handle 0)
+    const bool next_same = (a.phases & HICOM_PHASE_NEXT_IS_MAIN) != 0;
     // event records folded into the launches they follow (release recipe); HICOM_FOLD_EVENTS=0 keeps separate records
     static const bool fold_env = !(getenv("HICOM_FOLD_EVENTS") && getenv("HICOM_FOLD_EVENTS")[0] == '0');
     // ... but never while the main stream is being captured into a hipGraph: the stop event of hipExtLaunchKernelGGL is
@@ -317,7 +365,7 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
     const bool fold_ev = fused && fold_env && !capturing;
     bool join_folded = false, done_folded = false;
     if (a.phases & HICOM_PHASE_MERGE_ON_NEXT)
-        HICOM_REQUIRE(fused && a.ev_done && a.stream_next, HICOM_EINVAL, "compressor: MERGE_ON_NEXT needs the release recipe, ev_done and stream_next");
+        HICOM_REQUIRE(fused && a.ev_done && (a.stream_next || next_same), HICOM_EINVAL, "compressor: MERGE_ON_NEXT needs the release recipe, ev_done and stream_next");
     // the global chain runs on the side stream only when there is local work to overlap it with
     hipStream_t sg = (both && do_stream) ? ss : sm;
     const float qscale = a.has_global ? 1.0f / sqrtf((float)(a.E / a.nh)) : 0.f;
@@ -402,8 +450,7 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         const bool ro2_aux = tail5 && a.hidden <= 1536;    // ... and its last layer inside GEMM 2's launch (aux GEMV: K <= 1536)
         // Frame-sharded release step in the four-launch form (round 5): the shard's state (M, L, ACC) comes out of the merge ROLE of
         // GEMM 1's launch (no merge launch on the comm stream, no v_proj here), r0 travels to the FINISH phase through r0_buf.
-        const bool shard4 = f16 && merge_on_next && !do_finish && !solo && prep1 && a.gc0 && a.hidden <= 1536 && a.r0_buf && a.local_out &&
-                            w.nparts <= 256 && a.E / a.nh <= 128 && shard_tail_enabled();
+        const bool shard4 = shard4_form(a, w);
         // Round 5: FOUR launches.  The merge of the partial states is independent of the local readout, and the global tail behind it
         // is two dependent single-row layers: the merge rides as a ROLE on the CUs readout GEMM 1's tile grid leaves idle, the two layers
         // as a chain role (in-launch granule hand-off) under GEMM 2 -- the merge launch (5.2 us) is gone from the step.
@@ -414,12 +461,13 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
             tail_env = (e && e[0] == '5') ? 5 : (e && e[0] == '3') ? 3 : 4;
         }
         const bool tail4 = single && tail5 && ro2_aux && tail_env <= 4;
-        // Round 6: the value-side pos-emb leaves the ring kernel (marginals out, no pe tiles behind the token stream) and rides in the
-        // merge ROLE of GEMM 1's launch as a product with the weight-only table v_proj . pe^T (merge_item.hpp).  The forms of the step whose
-        // merge IS that role; HICOM_RING_PE=1 keeps the pe tiles in the ring (A/B switch).
-        static const bool ring_pe_env = getenv("HICOM_RING_PE") && getenv("HICOM_RING_PE")[0] == '1';
+        // Round 6: the value-side pos-emb OUT of the ring kernel (marginals out, no pe tiles behind the token stream) and into the merge ROLE
+        // of GEMM 1's launch as a product with the weight-only table v_proj . pe^T (merge_item.hpp) -- the round-4 / round-5 verdicts' lever.
+        // Built, parity-green, bit-stable, MEASURED: the ring kernel gains 0.4-1.2 us, GEMM 1's launch loses 1.1-1.4 us (the
+        // merge role becomes its critical path), the step 0.3-0.6 us -- so it is OPT-IN: HICOM_RING_MARG=1.
+        static const bool ring_marg_env = getenv("HICOM_RING_MARG") && getenv("HICOM_RING_MARG")[0] == '1';
         const bool marg_out = single && tail5 && tail_env <= 4 && a.pe && a.vpe_f16 && a.marg_slots == 8 * (a.E / 64) &&
-                              a.T + a.H + a.W <= a.marg_slots && !ring_pe_env;
+                              a.T + a.H + a.W <= a.marg_slots && ring_marg_env;
         if (prep1)
             CHK(hicom_query_prep_fwd(a.gq, a.lq, a.wq, a.bq, a.wk, a.kpe, a.nh, a.E, a.P, qscale, ws + w.qhi, ws + w.qlo, F(w.pos_a), a.P,
                                      w.R, (tail5 || shard4) ? a.gw0 : nullptr, a.gb0, a.bo, a.hidden, shard4 ? a.r0_buf : F(w.r0), ws + w.prep_state, sm));
@@ -447,11 +495,11 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
             CHK(hicom_readout16_gemm_fwd(ws + w.hid_hi, a.lw2_f16, a.lb2, HICOM_DT_BF16, w.nw, a.hidden, a.hidden, HICOM_ACT_NONE,
                                          nullptr, a.local_out, a.out_dt, a.hidden, 0, 0, nullptr, sm));
             if (a.ev_done && done_folded) {
-                if (a.stream_next)
+                if (a.stream_next && !next_same)
                     HICOM_REQUIRE(hipStreamWaitEvent((hipStream_t)a.stream_next, (hipEvent_t)a.ev_done, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
             } else if (a.ev_done) {
                 HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_done, sm) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
-                if (a.stream_next)
+                if (a.stream_next && !next_same)
                     HICOM_REQUIRE(hipStreamWaitEvent((hipStream_t)a.stream_next, (hipEvent_t)a.ev_done, 0) == hipSuccess, HICOM_ELAUNCH, "compressor: stream wait");
             }
             return HICOM_OK;
@@ -550,7 +598,7 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                 HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_join, sm) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
             if (a.ev_done) {
                 HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_done, sm) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
-                if (a.stream_next)
+                if (a.stream_next && !next_same)
                     HICOM_REQUIRE(hipStreamWaitEvent((hipStream_t)a.stream_next, (hipEvent_t)a.ev_done, 0) == hipSuccess, HICOM_ELAUNCH,
                                   "compressor: stream wait");
             }
@@ -694,6 +742,14 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
     }
 
     // ------------------------------------------------------------------ global chain, part 2
+    if (a.ag_fn && do_finish && !do_stream) {
+        // the all-gather of the exchange buffers, enqueued by this call (RCCL's ncclAllGather through the caller's communicator):
+        // [world][ag_bytes] <- every rank's [ag_bytes]; everything below reads the gathered buffer in stream order behind it
+        typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+        HICOM_REQUIRE(a.ag_comm && a.ag_send && a.ag_recv && a.ag_bytes > 0, HICOM_EINVAL, "compressor: all-gather arguments");
+        const int nrc = ((allgather_fn)a.ag_fn)(a.ag_send, a.ag_recv, (size_t)a.ag_bytes, /* ncclUint8 */ 1, a.ag_comm, sm);
+        HICOM_REQUIRE(nrc == 0, HICOM_ELAUNCH, "compressor: ncclAllGather returned %d", nrc);
+    }
     const bool finish4 = a.has_global && do_finish && !do_stream && a.state_sets && a.nsets > 0 && a.nsets <= 256 && a.r0_buf && a.gc0 && a.nq == 1 &&
                          a.hidden <= 1536 && a.hidden % 8 == 0 && a.E % 64 == 0 && a.E / a.nh <= 128 && a.E <= 1536 && a.lw0_f16 && shard_tail_enabled();
     if (finish4) {
@@ -701,13 +757,14 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         // GELU(C o + r0) -> granule hand-off -> last readout layer -> the 32 global rows] -- three launches where the generic form
         // below has five (combine, v_proj, out_proj, two readout layers)
         HICOM_REQUIRE(a.state_set_stride >= (int64_t)(2 * w.R + (long)w.R * a.E), HICOM_EINVAL, "compressor: state set layout");
-        HICOM_REQUIRE(hipMemsetAsync(ws + w.o_fix, 0, (size_t)a.E * 8, sg) == hipSuccess, HICOM_ELAUNCH, "compressor: memset");
+        // (no memset: the chain launch below clears the accumulators behind its own read of them -- x_fixed_clear -- and the workspace
+        // starts zeroed: hicom_compressor_zero_prefix_bytes covers o_fix for a FINISH-only block)
         CHK(hicom_merge_vproj_sets_fwd((const float*)a.state_sets, a.state_set_stride, a.nsets, w.R, a.E, a.wv, (int64_t*)(ws + w.o_fix), nullptr, nullptr, sg));
         hicom_r16_role r2;
         memset(&r2, 0, sizeof(r2));
         r2.kind = HICOM_ROLE_GEMV_CHAIN;
         r2.gemv = hicom_aux_gemv{nullptr, 0, 0, a.bv, a.gc0, a.r0_buf, nullptr, a.hidden, a.E, HICOM_ACT_GELU, nullptr,
-                                 HICOM_DT_F32, HICOM_DT_F32, nullptr, 0, 0, 0, 0, (const int64_t*)(ws + w.o_fix)};
+                                 HICOM_DT_F32, HICOM_DT_F32, nullptr, 0, 0, 0, 0, (const int64_t*)(ws + w.o_fix), 1};
         r2.gemv2 = hicom_aux_gemv{nullptr, 0, 0, nullptr, a.gw2, a.gb2, nullptr, a.hidden, a.hidden, HICOM_ACT_NONE, nullptr,
                                   HICOM_DT_BF16, HICOM_DT_BF16, a.out, a.out_dt, a.n_global_rows, a.ldo, a.global_row0, nullptr};
         r2.chain_state = ws + w.tail_state;
@@ -751,17 +808,17 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
                                    a.ldo * esz, 0, a.nl_group, sm));
     }
     if (a.ev_done && done_folded) {
-        if (a.stream_next)
+        if (a.stream_next && !next_same)
             HICOM_REQUIRE(hipStreamWaitEvent((hipStream_t)a.stream_next, (hipEvent_t)a.ev_done, 0) == hipSuccess, HICOM_ELAUNCH,
                           "compressor: stream wait");
     } else if (a.ev_done) {
         HICOM_REQUIRE(hipEventRecord((hipEvent_t)a.ev_done, sm) == hipSuccess, HICOM_ELAUNCH, "compressor: event record");
-        if (a.stream_next)
+        if (a.stream_next && !next_same)
             HICOM_REQUIRE(hipStreamWaitEvent((hipStream_t)a.stream_next, (hipEvent_t)a.ev_done, 0) == hipSuccess, HICOM_ELAUNCH,
                           "compressor: stream wait");
     }
     if (merge_on_next)
         CHK(hicom_global_merge_fwd(F(w.part_m), F(w.part_l), F(w.part_acc), w.nparts, w.R, w.rows_pad, a.E, nullptr, 0, w.N,
-                                   a.H, a.W, nullptr, 0, 0, 0, nullptr, ml_out, acc_out, solo ? 1 : 0, (hipStream_t)a.stream_next));
+                                   a.H, a.W, nullptr, 0, 0, 0, nullptr, ml_out, acc_out, solo ? 1 : 0, next_same ? sm : (hipStream_t)a.stream_next));
     return HICOM_OK;
 }

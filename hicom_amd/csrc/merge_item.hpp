@@ -9,6 +9,12 @@
 
 namespace hicom {
 
+// fp16 halves of a dword as f32.  NOT `__builtin_bit_cast(half2, vec[q])`: hipcc (ROCm 7.2) reads ELEMENT 0 for every q when a
+// bit_cast is applied to an element of an ext_vector (the same toolchain bug as DESIGN.md §3.2's fdot2 note: tools/marg_role_debug.py
+// showed every dword of a 16-byte load decoding as its first) -- shift the scalar instead.
+__device__ __forceinline__ float mv_f16lo(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xFFFFu)); }
+__device__ __forceinline__ float mv_f16hi(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
+
 __device__ __forceinline__ float mv_block_max(float v, float* red) {
     v = wave_max_fast(v);
     __syncthreads();
@@ -52,7 +58,7 @@ struct MergeVprojFixParams {
 };
 
 template <int kMvSlab>
-constexpr int mv_item_lds_bytes() { return (256 + 4 + (256 / (kMvSlab / 4)) * kMvSlab + kMvSlab + 4 * 8 + 8) * 4; }
+constexpr int mv_item_lds_bytes() { return (256 + 4 + (256 / (kMvSlab / 4)) * kMvSlab + kMvSlab + 4 * 8 + 8 + 256 * 4) * 4; }
 
 // One item: head h, channels [slab * kMvSlab, + kMvSlab).  256 threads; `lds` >= mv_item_lds_bytes<kMvSlab>() bytes, 16-byte aligned.
 // Split into a LOAD half (every global read of the item, into registers) and a COMPUTE half, so that a workgroup that owns several
@@ -102,12 +108,18 @@ __device__ __forceinline__ void merge_vproj_fixed_load(const MergeVprojFixParams
     }
     r.pm = tid < p.nparts ? p.part_m[(long)tid * mlp + h * mlr] : -1.0e30f;       // nparts <= 256 (host-checked)
     r.pl = tid < p.nparts ? p.part_l[(long)tid * mlp + h * mlr] : 0.f;
-    r.mg = u32x4{0, 0, 0, 0};
-    r.vp = u32x4{0, 0, 0, 0};
-    if (p.part_marg) {
+    // (straight-line, unconditional loads with clamped indices: a load inside a branch makes hipcc wait for EVERYTHING in flight at the
+    // join, and a role workgroup's three items then cost three round trips instead of one -- GEMM 1's launch 15.1 against 12.1 us.
+    // Without marginals both pointers fall back to the v_proj weights: valid memory, the values are dropped by the compute half.)
+    {
         const int nrow = p.E / p.hd;
-        if (tid < p.nparts) r.mg = *reinterpret_cast<const u32x4*>(p.part_marg + ((long)tid * nrow + h) * p.marg_slots + 8 * slab);
-        if (half == 0 && j < p.hd) r.vp = *reinterpret_cast<const u32x4*>(p.vpe16 + (long)(h * p.hd + j) * p.marg_slots + 8 * slab);
+        const int ti = tid < p.nparts ? tid : p.nparts - 1, jj = j < p.hd ? j : p.hd - 1;
+        const char* mgp = p.part_marg ? reinterpret_cast<const char*>(p.part_marg + ((long)ti * nrow + h) * p.marg_slots + 8 * slab)
+                                      : reinterpret_cast<const char*>(p.wv ? (const void*)p.wv : (const void*)p.part_m);
+        const char* vpp = p.part_marg ? reinterpret_cast<const char*>(p.vpe16 + (long)(h * p.hd + jj) * p.marg_slots + 8 * slab)
+                                      : reinterpret_cast<const char*>(p.wv ? (const void*)p.wv : (const void*)p.part_m);
+        r.mg = *reinterpret_cast<const u32x4*>(mgp);
+        r.vp = *reinterpret_cast<const u32x4*>(vpp);
     }
 }
 
@@ -120,6 +132,7 @@ __device__ __forceinline__ void merge_vproj_fixed_compute(const MergeVprojFixPar
     float* red = wp + 256;                                    // [4]
     float* mgw = red + 4;                                     // [4 waves][8] partial sums of this item's 8 marginal slots
     float* mgn = mgw + 32;                                    // [8] merged, normalised marginals
+    u32x4* mgl = reinterpret_cast<u32x4*>(mgn + 8);           // [256] the partials' 8 fp16 marginals, one 16-byte entry per partial
     const int tid = threadIdx.x;
     const int j = tid >> 1, half = tid & 1;
     const int c4 = tid % R::NC4, pg = tid / R::NC4;
@@ -127,6 +140,7 @@ __device__ __forceinline__ void merge_vproj_fixed_compute(const MergeVprojFixPar
     const float M = mv_block_max(pm, red);
     const float w = tid < p.nparts ? expf(pm - M) : 0.f;
     wp[tid] = F16 ? w * pl : w;                          // (normalised contexts are weighed with l e^(m - M))
+    if (p.part_marg) mgl[tid] = r.mg;                    // (visible behind the barriers below, like wp[])
     const float L = mv_block_sum(w * pl, red);           // (barriers inside: wp[] is visible afterwards)
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -140,20 +154,23 @@ __device__ __forceinline__ void merge_vproj_fixed_compute(const MergeVprojFixPar
     }
     *reinterpret_cast<float4*>(&cpart[pg * kMvSlab + 4 * c4]) = a;
     if (p.part_marg) {
-        // marginals of this item's 8 slots: sum_i (l_i e^(m_i - M)) (mg_i / l_i), one partial per thread, summed over the workgroup
-        const float wt = wp[tid];
-        float ms[8];
+        // marginals of this item's 8 slots: sum_i (l_i e^(m_i - M)) (mg_i / l_i).  Transposed through LDS: thread (slot q = tid % 8, group
+        // g = tid / 8) sums the partials g, g + 32, ... (8 of them), a wave then holds 8 groups x 8 slots and three lane-exchange steps
+        // finish its share -- eight whole-wave reductions per item (one per slot, ~100 dependent VALU steps, three items per role workgroup)
+        // lengthened readout GEMM 1's launch by 1.1 us
+        const int q = tid & 7, g = tid >> 3;
+        const unsigned short* mh = reinterpret_cast<const unsigned short*>(mgl);
+        float s = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-            const half2_t hv = __builtin_bit_cast(half2_t, r.mg[q]);
-            ms[2 * q] = wave_sum_fast(wt * (float)hv[0]);
-            ms[2 * q + 1] = wave_sum_fast(wt * (float)hv[1]);
+        for (int u = 0; u < 8; ++u) {
+            const int i = g + 32 * u;                                       // i < 256; partials >= nparts carry weight 0 and a clamped (finite) entry
+            s = fmaf(wp[i], (float)__builtin_bit_cast(_Float16, mh[8 * i + q]), s);
         }
-        if ((tid & 63) == 0) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) mgw[(tid >> 6) * 8 + q] = ms[q];
-        }
+        // lanes of a wave: q = lane % 8, group = lane / 8 (8 groups): sum over the groups
+        s += __shfl_xor(s, 8, 64);
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if ((tid & 63) < 8) mgw[(tid >> 6) * 8 + q] = s;
     }
     __syncthreads();
     if (p.part_marg && tid < 8) mgn[tid] = ((mgw[tid] + mgw[8 + tid]) + (mgw[16 + tid] + mgw[24 + tid])) / L;
@@ -185,12 +202,11 @@ __device__ __forceinline__ void merge_vproj_fixed_compute(const MergeVprojFixPar
         }
     }
     if (p.part_marg && half == 0 && j < p.hd) {
-        typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const half2_t hv = __builtin_bit_cast(half2_t, r.vp[q]);
-            dot = fmaf(mgn[2 * q], (float)hv[0], dot);
-            dot = fmaf(mgn[2 * q + 1], (float)hv[1], dot);
+            const unsigned u = r.vp[q];
+            dot = fmaf(mgn[2 * q], mv_f16lo(u), dot);
+            dot = fmaf(mgn[2 * q + 1], mv_f16hi(u), dot);
         }
     }
     dot += __shfl_xor(dot, 1, 64);

@@ -54,6 +54,7 @@ struct AuxGemv {
     int dst_f32, reps;
     long ldd, row0;
     const long long* x_fixed;   // alternative x: fixed-point accumulators (value * HICOM_FIXED_SCALE), or NULL
+    int x_clear;                // GEMV_CHAIN: role workgroup 0 clears x_fixed once every workgroup has read it
 };
 
 struct R16Params {
@@ -476,6 +477,10 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
     }
     __syncthreads();
     R16_TR(4);   // hand-off complete
+    // (every granule carries this launch's epoch: every role workgroup has published, i.e. has read x -- the accumulators can be
+    // cleared for the next step's merge; a failed hand-off has poisoned this launch anyway and the next one starts behind it)
+    if (g1.x_clear && ai == 0)
+        for (int k = tid; k < g1.K; k += 256) const_cast<long long*>(g1.x_fixed)[k] = 0ll;
     // ---- second layer (bf16 rows, K2 = N1) ----
     for (int b0 = m_lo; b0 < m_hi; b0 += cg.r2) {
         const int b1 = min(m_hi, b0 + cg.r2);
@@ -1261,7 +1266,7 @@ static int r16_build(const void* a, const void* w, const void* b, int32_t b_dt,
     const int nbx = (N + tn - 1) / tn;
     p.n_gemm = role_only ? 0 : 8 * ((nbx * nby + 7) / 8);
     n_aux = 0;
-    const AuxGemv none{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, 0, 0, 0, nullptr};
+    const AuxGemv none{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, 0, 0, 0, nullptr, 0};
     p.aux = none;
     p.aux2 = none;
     p.role = HICOM_ROLE_NONE;
@@ -1272,7 +1277,7 @@ static int r16_build(const void* a, const void* w, const void* b, int32_t b_dt,
         return AuxGemv{aux->xs, aux->x_parts, (long)aux->x_stride, (const uint16_t*)aux->xb, aux->w,
                        aux->b, (const uint16_t*)aux->res, aux->N, aux->K, aux->act, aux->y, aux->w_dt == HICOM_DT_F32, aux->b_dt == HICOM_DT_F32,
                        aux->rows_dst, aux->rows_dt == HICOM_DT_F32, aux->rows_dst ? aux->rows_reps : 0, (long)aux->rows_ld, (long)aux->rows_row0,
-                       (const long long*)aux->x_fixed};
+                       (const long long*)aux->x_fixed, aux->x_fixed_clear ? 1 : 0};
     };
     auto check_gemv = [](const hicom_aux_gemv* aux, bool needs_x, bool needs_out = true) -> int {
         HICOM_REQUIRE(aux->w && (!needs_out || aux->y || aux->rows_dst) && aux->N > 0 && aux->K > 0 && aux->K % 8 == 0 && aux->K <= 1536 && ((uintptr_t)aux->w % 16 == 0), HICOM_EINVAL,
@@ -1333,7 +1338,12 @@ static int r16_build(const void* a, const void* w, const void* b, int32_t b_dt,
         // the two-layer chain is bound by the bytes a role CU pulls (4.1 + 1.6 MB of weights beside the streaming tiles): every CU the
         // tile grid leaves free takes a share (the four tile slots beyond the 196 tiles exit at once)
         if (p.role == HICOM_ROLE_GEMV_CHAIN && 256 - p.n_gemm >= 16) n_aux = 256 - p.n_gemm < 72 ? 256 - p.n_gemm : 72;
-        if (role_only) n_aux = 64;             // (alone on the chip: one workgroup per four CUs' worth of weights is plenty; a fixed count per state block)
+        // a launch of its own (the FINISH phase of the frame-sharded step, on the comm stream): it runs BESIDE the next step's ring kernel,
+        // which holds 216 of the 256 CUs with 160 KB of LDS each -- 32 role workgroups (one per CU: the role takes the whole LDS too) all
+        // find a CU among the 40 it leaves free.  With 64, two dozen waited for the ring kernel to end while the resident ones spun on their
+        // hand-off, and then competed with readout GEMM 1 for CUs: the pipelined step read 93.8 us against 76 for the plain one.  A fixed
+        // count per state block (the epoch arithmetic of the hand-off).
+        if (role_only) n_aux = 32;
         if (p.role == HICOM_ROLE_MERGE_VPROJ) {
             // every item of a role workgroup in flight at once: ceil(items / kMvRoleItems) workgroups (162 items -> 54), never more than
             // the CUs the tile grid leaves free (one workgroup per CU: the launch asks for 160 KB of LDS)

@@ -135,7 +135,7 @@ def exchange(state: torch.Tensor, local_tokens: torch.Tensor, group=None):
 class _ShardSet:
     """One set of exchange buffers + argument blocks + workspaces (two sets alternate so that the all-gather of step i
     can still be reading its send buffer while step i+1 streams into the other one)."""
-    __slots__ = ("mine", "everyone", "a_stream", "a_finish", "ws_stream", "ws_finish", "ev_stream", "ev_tok", "out", "fused", "r0")
+    __slots__ = ("mine", "everyone", "a_stream", "a_finish", "ws_stream", "ws_finish", "ev_stream", "ev_tok", "out", "fused", "r0", "direct_ag", "on_comm")
 
 
 class _ShardPlan:
@@ -159,6 +159,27 @@ class _ShardPlan:
 
 
 _MAX_SHARD_PLANS = 8
+_N_SETS = 4
+
+
+def _rccl_comm(group, dev, world) -> Optional[int]:
+    """ncclComm_t of `group`'s RCCL backend as an integer (torch: ProcessGroupNCCL._comm_ptr()), or None when the backend is not RCCL / the
+    torch build does not expose it / HICOM_SHARD_DIRECT_AG=0 -- the step then issues its all-gather through torch.distributed.  The
+    communicator is created lazily by torch: one (tiny) c10d collective on this device makes sure it exists."""
+    import os
+    if os.environ.get("HICOM_SHARD_DIRECT_AG", "1") == "0" or not dist.is_initialized():
+        return None
+    try:
+        g = group if group is not None else dist.group.WORLD
+        if dist.get_backend(g) != "nccl":
+            return None
+        probe = torch.zeros(world, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(probe, probe[:1].clone(), group=g)
+        torch.cuda.current_stream(dev).synchronize()
+        ptr = int(g._get_backend(torch.device(dev))._comm_ptr())
+        return ptr or None
+    except Exception:  # noqa: BLE001  (a torch without _comm_ptr, a wrapped backend: fall back to c10d)
+        return None
 
 
 def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group, rank=None, world=None) -> _ShardPlan:
@@ -172,6 +193,7 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
     lc, gc = projector.local_compressor, projector.global_compressor
     dev = ff_shard.device
     cur = torch.cuda.current_stream(dev)
+    _explicit = rank
     if rank is None or world is None:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     key = (tuple(ff_shard.shape), fe_shard is not None, None if guide_embed is None else tuple(guide_embed.shape),
@@ -196,7 +218,16 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
     R = q_in.shape[0] * gc.attn_layer.num_heads
     lay = projector._layout((at.nwin * world, ay.nwin, ax.nwin), "video", image_newline is not None, False)
     plan = _ShardPlan()
-    plan.comm = torch.cuda.Stream(device=dev, priority=-1)
+    import os
+    # the comm stream carries the FINISH phase of step i under the streaming of step i + 1.  HIGH priority (the device offers -1 and 0):
+    # measured at world size 1, pipelined loop -- -1: 82.5-82.9 us per step, 0: 111.8-113.3 (the chain launch's 32 workgroups hand a vector
+    # over inside the launch: at equal priority some of them queue behind the ring kernel's workgroups while the resident ones spin).
+    # HICOM_COMM_PRIORITY: dev / A-B switch.
+    prio = int(os.environ.get("HICOM_COMM_PRIORITY", "-1"))
+    try:
+        plan.comm = torch.cuda.Stream(device=dev, priority=prio)
+    except Exception:  # noqa: BLE001  (a priority outside the device's range)
+        plan.comm = torch.cuda.Stream(device=dev)
     plan.res = engine._resources(dev)                  # side stream + fork/join events of the caller's stream
     plan.lay, plan.nw, plan.hidden, plan.odt, plan.world, plan.rank = lay, nw, hidden, odt, world, rank
     plan.n_rows_total = lay.n_rows + n_rows
@@ -205,7 +236,12 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
     # of a torch.distributed call, not the wire, is what a second collective would add)
     plan.pack = pack = PackLayout(2 * R + R * E, nw, hidden, torch.empty((), dtype=odt).element_size())
     probe = torch.empty((plan.n_rows_total, hidden), dtype=odt, device=dev)      # any valid `out` for the argument blocks
-    plan.xs = ExchangeSets(pack, dev, world)
+    # FOUR buffer sets, and the HOST is what keeps a set's next step behind its previous exchange (sharded_forward: a host-side wait on
+    # ev_tok when the set is still busy, which also bounds how far the enqueueing thread runs ahead of the device): with two sets the
+    # dependency had to be a device-side wait on the MAIN stream in every steady-state step -- a barrier packet there is a ~10-us bubble
+    # between readout GEMM 2 and the next step's query prep (tools/shard_trace.py: 89.9 us from ring to ring against 75 of kernels)
+    plan.xs = ExchangeSets(pack, dev, world, n=_N_SETS)
+    comm_ptr = _rccl_comm(group, dev, world) if _explicit is None else None      # (explicit rank / world: the one-GPU emulations, no collective)
     for mine, everyone in plan.xs.pairs:
         st = _ShardSet()
         st.mine, st.everyone = mine, everyone
@@ -237,7 +273,7 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
         if st.fused:
             # four-launch form of the sharded step (executor.hip: shard4 / finish4): r0 travels from the STREAM phase's query prep to the
             # FINISH phase's chain launch through this buffer (their workspaces are separate)
-            st.r0 = torch.empty(hidden, dtype=torch.float32, device=dev)
+            st.r0 = torch.zeros(hidden, dtype=torch.float32, device=dev)
             st.a_stream.r0_buf = st.a_finish.r0_buf = st.r0.data_ptr()
         if st.fused:
             # release recipe: no side stream -- the merge of the partials runs on the comm stream, in front of the
@@ -248,6 +284,15 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
         st.a_finish.place_block_stride = pack.total
         st.a_finish.nl_group = lay.nl_group
         st.a_finish.ev_done = st.ev_tok.cuda_event
+        if st.fused and not nv.compressor_takes_shard4(st.a_stream):
+            # FINISH's four-launch form consumes the r0 that ONLY the STREAM call's four-launch form writes -- both or neither
+            st.a_stream.r0_buf = st.a_finish.r0_buf = None
+        # the all-gather enqueued by the FINISH call itself (RCCL through the group's own communicator): one host call per step
+        st.on_comm = True
+        st.direct_ag = comm_ptr is not None
+        if st.direct_ag:
+            st.a_finish.ag_fn, st.a_finish.ag_comm = nv.rccl_allgather_fn(), comm_ptr
+            st.a_finish.ag_send, st.a_finish.ag_recv, st.a_finish.ag_bytes = st.mine.data_ptr(), st.everyone.data_ptr(), pack.total
         plan.sets.append(st)
     plan.sig = engine.weights_sig(projector)
     if len(plans) >= _MAX_SHARD_PLANS:
@@ -309,37 +354,59 @@ def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: in
     else:
         out = torch.empty((plan.n_rows_total, plan.hidden), dtype=plan.odt, device=dev)
         out.record_stream(comm)
-    # this buffer set's previous exchange (two steps ago) has drained.  In the steady state it has long done so: ask the event on the
-    # host first -- a wait that is not needed still costs the main stream a barrier packet (a 4-5 us bubble in its launch pipeline,
-    # DESIGN.md §3.1 "speculative query prep")
+    # this buffer set's previous exchange (_N_SETS steps ago) has to have drained before the step overwrites the set.  Enforced on the
+    # HOST: a device-side wait costs the main stream a barrier packet -- a ~10-us bubble in its launch pipeline, every step, because the
+    # enqueueing thread runs ahead of the device and the event is never complete yet at enqueue time.  Blocking here instead bounds that
+    # run-ahead to _N_SETS steps and keeps the main stream free of cross-stream waits.
     if not st.ev_tok.query():
-        main.wait_event(st.ev_tok)
+        st.ev_tok.synchronize()
+    if deferred != st.on_comm:
+        _route_finish(plan, st, main, deferred)
     plan.set_inputs(st, ff_shard, fe_shard, guide_embed, out)
     # main: prep, stream kernel, readout GEMMs, ev_stream; the comm stream waits for it and merges the partials -> state
-    nv.compressor_fwd(st.a_stream)
-    _comm_step(plan, st, out, image_newline, group, main)
+    if st.direct_ag and not plan.lay.newline_rows:
+        # ONE host call for the step: STREAM on the main stream, then -- on the comm stream, behind ev_stream -- ncclAllGather, the merge
+        # of the gathered states, the chain, the token placement and ev_tok (executor.hip)
+        nv.compressor_fwd2(st.a_stream, st.a_finish)
+    else:
+        nv.compressor_fwd(st.a_stream)
+        _comm_step(plan, st, out, image_newline, group, main)
     if deferred:
         # the comm stream reads the guide (residual of out_proj) and the newline token after this call has returned
         for t in (guide_embed, image_newline):
             if t is not None:
                 t.record_stream(comm)
         return out, st.ev_tok
-    main.wait_event(st.ev_tok)
-    return out
+    return out                                     # (joined: the whole step ran on the caller's stream, _route_finish)
+
+
+def _route_finish(plan, st, main, on_comm: bool):
+    """Where a buffer set's FINISH phase runs.  Pipelined serving (deferred=True): on the plan's comm stream, behind ev_stream, under the
+    next step's streaming.  Joined call: on the CALLER's stream, right behind STREAM -- the result is needed at once, and two cross-stream
+    hops (main -> comm -> main, ~10 us each on this platform) bought nothing: world-1 joined step 133 -> ~100 us."""
+    from . import native as nv
+    st.a_finish.stream_main = (plan.comm if on_comm else main).cuda_stream
+    if on_comm:
+        st.a_stream.phases &= ~nv.PHASE_NEXT_IS_MAIN
+    else:
+        st.a_stream.phases |= nv.PHASE_NEXT_IS_MAIN    # (the executor then puts no event wait between the phases; stream_next is ignored)
+    st.on_comm = on_comm
 
 
 def _comm_step(plan, st, out, image_newline, group, restore=None):
     """Comm-stream half of a step: ONE all-gather, then (one C call) combine + the global chain -> the 32 global
     rows, every rank's token block into the packed output, ev_tok."""
     from . import native as nv
-    comm = plan.comm
-    _set_stream(comm)                              # c10d orders a collective after the CURRENT (thread-local) stream
-    try:
-        gather_packed(st.mine, st.everyone, group)
-    finally:
-        if restore is not None:
-            _set_stream(restore)
-    nv.compressor_fwd(st.a_finish)                 # (records ev_tok = its ev_done behind the token placement, from C)
+    comm = plan.comm if st.on_comm else (restore if restore is not None else torch.cuda.current_stream(st.mine.device))
+    if not st.direct_ag:
+        if st.on_comm:
+            _set_stream(comm)                      # c10d orders a collective after the CURRENT (thread-local) stream
+        try:
+            gather_packed(st.mine, st.everyone, group)
+        finally:
+            if st.on_comm and restore is not None:
+                _set_stream(restore)
+    nv.compressor_fwd(st.a_finish)                 # (direct_ag: enqueues ncclAllGather itself, in front of everything else)                 # (records ev_tok = its ev_done behind the token placement, from C)
     fenced = bool(st.a_finish.ev_done)
     if plan.lay.newline_rows:
         first = plan.lay.newline_rows[0]

@@ -27,6 +27,7 @@ EXPORTS = (
     "hicom_global_stream_nparts", "hicom_global_merge_fwd", "hicom_global_combine_fwd",
     "hicom_readout_gemm_fwd", "hicom_scatter_rows_fwd", "hicom_fold_query_split_fwd",
     "hicom_global_combine_strided_fwd", "hicom_compressor_workspace_bytes", "hicom_compressor_zero_prefix_bytes", "hicom_compressor_is_fused",
+    "hicom_compressor_fwd2", "hicom_compressor_takes_shard4", "hicom_compressor_handoff_failures",
     "hicom_compressor_fwd", "hicom_linear_to_rows_fwd", "hicom_fused_stream_fwd", "hicom_fused_stream_nparts",
     "hicom_planes_gemm_fwd", "hicom_row_ln_fwd", "hicom_small_mha_fwd", "hicom_place_blocks_fwd",
     "hicom_global_stream_bwd", "hicom_readout16_gemm_fwd", "hicom_to_f16_fwd", "hicom_merge_vproj_fwd",
@@ -41,7 +42,7 @@ EXPORTS = (
     "hicom_compressor_ctx16_offset",
 )
 
-PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT = 1, 2, 4
+PHASE_STREAM, PHASE_FINISH, PHASE_MERGE_ON_NEXT, PHASE_NEXT_IS_MAIN = 1, 2, 4, 8
 
 
 class HicomNativeError(RuntimeError):
@@ -58,7 +59,7 @@ class AuxGemv(C.Structure):
     _fields_ = [("xs", C.c_void_p), ("x_parts", C.c_int32), ("x_stride", C.c_int64), ("xb", C.c_void_p), ("w", C.c_void_p),
                 ("b", C.c_void_p), ("res", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32), ("act", C.c_int32), ("y", C.c_void_p),
                 ("w_dt", C.c_int32), ("b_dt", C.c_int32), ("rows_dst", C.c_void_p), ("rows_dt", C.c_int32), ("rows_reps", C.c_int32),
-                ("rows_ld", C.c_int64), ("rows_row0", C.c_int64), ("x_fixed", C.c_void_p)]
+                ("rows_ld", C.c_int64), ("rows_row0", C.c_int64), ("x_fixed", C.c_void_p), ("x_fixed_clear", C.c_int32)]
 
 
 class R16Role(C.Structure):
@@ -130,6 +131,7 @@ class CompressorArgs(C.Structure):
         ("ev_queries", C.c_void_p),
         ("inj_l", Injector), ("inj_g", Injector),
         ("vpe_f16", C.c_void_p), ("marg_slots", C.c_int32),
+        ("ag_fn", C.c_void_p), ("ag_comm", C.c_void_p), ("ag_send", C.c_void_p), ("ag_recv", C.c_void_p), ("ag_bytes", C.c_int64),
     ]
 
 
@@ -227,6 +229,9 @@ def lib() -> C.CDLL:
     L.hicom_compressor_workspace_bytes.argtypes = [ap]
     L.hicom_compressor_zero_prefix_bytes.argtypes = [ap]
     L.hicom_compressor_is_fused.argtypes = [ap]
+    L.hicom_compressor_fwd2.argtypes = [ap, ap]
+    L.hicom_compressor_takes_shard4.argtypes = [ap]
+    L.hicom_compressor_handoff_failures.argtypes = [ap, C.POINTER(C.c_int32), vp]
     L.hicom_compressor_fwd.argtypes = [ap]
     L.hicom_global_combine_fwd.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     L.hicom_readout_gemm_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i64, i64, i32, vp]
@@ -539,6 +544,37 @@ def compressor_workspace(args: CompressorArgs):
 
 def compressor_fwd(args: CompressorArgs):
     _check(lib().hicom_compressor_fwd(C.byref(args)), "hicom_compressor_fwd")
+
+
+def compressor_fwd2(first: CompressorArgs, second: CompressorArgs):
+    """hicom_compressor_fwd(first) then hicom_compressor_fwd(second) in ONE host call (the two phases of a frame-sharded step)."""
+    _check(lib().hicom_compressor_fwd2(C.byref(first), C.byref(second)), "hicom_compressor_fwd2")
+
+
+def compressor_takes_shard4(args: CompressorArgs) -> bool:
+    return bool(lib().hicom_compressor_takes_shard4(C.byref(args)))
+
+
+def compressor_handoff_failures(args: CompressorArgs, stream=None):
+    """(query prep, GEMV chain): in-launch hand-offs of this workspace whose bounded spin expired (their rows were poisoned with NaN).
+    Synchronises the stream: tests / bench / debug only."""
+    out = (C.c_int32 * 2)()
+    _check(lib().hicom_compressor_handoff_failures(C.byref(args), out, _stream() if stream is None else stream), "hicom_compressor_handoff_failures")
+    return int(out[0]), int(out[1])
+
+
+def rccl_allgather_fn() -> int:
+    """Address of ncclAllGather in the RCCL that torch has loaded (torch/lib/librccl.so): handed to hicom_compressor_args.ag_fn so that
+    the FINISH call of a frame-sharded step enqueues the collective itself.  libhicom_hip.so does not link RCCL."""
+    global _RCCL
+    if _RCCL is None:
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        L = C.CDLL(path if os.path.exists(path) else "librccl.so")        # (already mapped by torch.distributed: the same instance)
+        _RCCL = C.cast(L.ncclAllGather, C.c_void_p).value
+    return _RCCL
+
+
+_RCCL = None
 
 
 def compressor_ctx16_offset(args) -> int:
@@ -871,6 +907,8 @@ def _merge_role(merge):
     role.w_v, role.o_fix = _ptr(merge.get("w_v")), _ptr(merge.get("o_fix"))
     role.out_ml, role.out_ctx = _ptr(merge.get("out_ml")), _ptr(merge.get("out_ctx"))
     role.ctx_unnorm = int(bool(merge.get("unnorm", False)))
+    if merge.get("part_marg") is not None:               # value-side pos-emb in the merge: fp16 [nparts, rows, S] marginals + fp16 [E, S] = W_v . pe^T
+        role.part_marg, role.vpe_f16, role.marg_slots = merge["part_marg"].data_ptr(), merge["vpe_f16"].data_ptr(), merge["part_marg"].shape[-1]
     return role
 
 

@@ -387,6 +387,10 @@ typedef struct hicom_aux_gemv {
     /* alternative source of x: x[k] = x_fixed[k] / HICOM_FIXED_SCALE + xb[k] (hicom_merge_vproj_fixed_fwd's accumulators); then xs
      * may be NULL and x_parts is ignored */
     const int64_t* x_fixed;
+    /* GEMV_CHAIN only (ABI 15): once every role workgroup has read x (= when a workgroup has swept every granule of the first layer),
+     * role workgroup 0 clears the x_fixed accumulators for the next step -- the FINISH phase of the frame-sharded step then needs no
+     * memset launch in front of its merge.  The accumulators must be zero before the FIRST step. */
+    int32_t x_fixed_clear;
 } hicom_aux_gemv;
 int hicom_readout16_gemm_fwd(const void* a, const void* w, const void* b, int32_t b_dt,
                              int32_t M, int32_t N, int32_t K, int32_t act, void* out_f16,
@@ -627,6 +631,9 @@ int hicom_splice_labels_fwd(const void* labels, const void* mask, int32_t mask_e
  * step); the caller gives every buffer set its own workspace, since the merge then reads the partials while the
  * main stream may already run the next step. */
 #define HICOM_PHASE_MERGE_ON_NEXT 4
+/* With HICOM_PHASE_MERGE_ON_NEXT (ABI 15): "next" is this call's own stream_main -- a JOINED frame-sharded step runs both phases on the
+ * caller's stream (which may be the null stream, handle 0: stream_next is ignored) and the executor puts no event wait between them. */
+#define HICOM_PHASE_NEXT_IS_MAIN 8
 
 typedef struct hicom_compressor_args {
     /* inputs: frames_feature (values; keys/values of the global stage), frames_embed (local keys, may be NULL) */
@@ -752,6 +759,16 @@ typedef struct hicom_compressor_args {
      * (hicom_r16_role.part_marg / vpe_f16).  Weight-only, cached by the caller per weight state like kpe. */
     const void* vpe_f16;
     int32_t marg_slots;
+    /* ABI 15, FINISH phase of the frame-sharded step (all NULL / 0 otherwise): the all-gather of the per-rank exchange buffers enqueued
+     * BY THIS CALL, on stream_main, in front of everything else -- `ag_fn` = address of ncclAllGather of the RCCL the process has loaded
+     * (ncclResult_t (*)(const void* send, void* recv, size_t count, ncclDataType_t, ncclComm_t, hipStream_t)), `ag_comm` = the
+     * ncclComm_t of the caller's process group (torch: ProcessGroupNCCL._comm_ptr()), ag_bytes per rank as ncclUint8.  The library does not
+     * link RCCL: one host call per phase instead of a torch.distributed call between two (the sharded step is host-bound). */
+    void* ag_fn;
+    void* ag_comm;
+    const void* ag_send;
+    void* ag_recv;
+    int64_t ag_bytes;
 } hicom_compressor_args;
 
 /* Byte offset, inside the workspace, of the fp16 plane [windows, E] of the local stage's window contexts (the A operand of readout
@@ -759,6 +776,15 @@ typedef struct hicom_compressor_args {
  * (the readout's weight gradients need the contexts; recomputing them is a pass over every token).  Negative: HICOM_EUNSUP when the
  * call does not read out through fp16 planes, HICOM_EINVAL without a local stage. */
 int64_t hicom_compressor_ctx16_offset(const hicom_compressor_args* args);
+/* Two calls of hicom_compressor_fwd in one (the STREAM and the FINISH block of a frame-sharded step; stops at the first error). */
+int hicom_compressor_fwd2(const hicom_compressor_args* first, const hicom_compressor_args* second);
+/* 1 when a STREAM-phase call with these arguments takes the four-launch sharded form that hands r0 to the FINISH phase through r0_buf,
+ * 0 otherwise (the caller then clears r0_buf in BOTH blocks so that FINISH takes its generic form too: ADVICE r5). */
+int hicom_compressor_takes_shard4(const hicom_compressor_args* args);
+/* Failed in-launch hand-offs (bounded spins that expired: the affected rows were poisoned with NaN) counted so far in this workspace's
+ * state blocks: out[0] = query prep, out[1] = the GEMV chain.  Synchronous (two 4-byte device reads on `stream` + a stream sync):
+ * for tests, benches and debug checks, not for the hot loop. */
+int hicom_compressor_handoff_failures(const hicom_compressor_args* args, int32_t* out, void* stream);
 /* 1 when hicom_compressor_fwd takes the release-recipe (single streaming kernel) path for these arguments. */
 int hicom_compressor_is_fused(const hicom_compressor_args* args);
 

@@ -686,6 +686,44 @@ def test_merge_role_inside_the_readout_gemm_launch_equals_the_merge_launch(npart
         assert torch.equal(o16, o_ref)
 
 
+@pytest.mark.parametrize("nparts", [216, 81, 12, 1])
+def test_merge_role_applies_the_value_side_pos_emb_from_marginals(nparts):
+    """Round 6: HICOM_ROLE_MERGE_VPROJ with part_marg / vpe_f16 -- o = W_v (merged ctx) + sum_s (merged marginal[s]) VPE[:, s], the
+    marginals merged with the same weights l_i e^(m_i - M) / L as the contexts.  Against float64 torch; bit-identical from launch to launch."""
+    g = torch.Generator().manual_seed(170 + nparts)
+    E, nh, S = 1152, 9, 144
+    pm = torch.randn(nparts, 16, generator=g).cuda() * 3
+    pl = (torch.rand(nparts, 16, generator=g) + 0.5).cuda()
+    p16 = torch.randn(nparts, 16, E, generator=g).cuda().to(torch.float16)
+    mg = torch.rand(nparts, nh, S, generator=g)
+    mg[..., 118:] = 0
+    mg = (mg / mg.sum(-1, keepdim=True) * 3).cuda().to(torch.float16)
+    vpe = (torch.randn(E, S, generator=g) * 0.5).cuda().to(torch.float16)
+    wv = bf(torch.randn(E, E, generator=g) * 0.02)
+    M, N, K = 1296, 896, 1152
+    a16 = nv.to_f16(torch.randn(M, K, generator=g).cuda())
+    w16 = nv.to_f16(torch.randn(N, K, generator=g).cuda() * 0.02)
+    # reference in float64
+    m64, l64 = pm[:, :nh].double(), pl[:, :nh].double()
+    wgt = l64 * torch.exp(m64 - m64.max(0, keepdim=True).values)              # [nparts, nh]
+    wgt = wgt / wgt.sum(0, keepdim=True)
+    ctx = torch.einsum("ph,phe->he", wgt, p16[:, :nh].double())
+    mgm = torch.einsum("ph,phs->hs", wgt, mg.double())
+    hd = E // nh
+    want = torch.einsum("hje,he->hj", wv.double().view(nh, hd, E), ctx) + torch.einsum("hjs,hs->hj", vpe.double().view(nh, hd, S), mgm)
+    outs = []
+    for _ in range(2):
+        ofx = torch.zeros(E, dtype=torch.int64, device="cuda")
+        o16 = torch.empty(M, N, dtype=torch.float16, device="cuda")
+        nv.readout16_gemm(a16, w16, None, act=nv.ACT_GELU, out_f16=o16,
+                          merge=dict(part_m=pm, part_l=pl, part_ctx16=p16, rows=nh, w_v=wv, o_fix=ofx, part_marg=mg, vpe_f16=vpe))
+        torch.cuda.synchronize()
+        outs.append(ofx.clone())
+    got = outs[0].double() / 2.0 ** 36
+    assert torch.equal(outs[0], outs[1])
+    assert maxabs(got, want.reshape(-1)) <= 2e-5 * max(1.0, float(want.abs().max())), float((got - want.reshape(-1)).abs().max())
+
+
 @pytest.mark.parametrize("n_mid,n_out,tile_rows", [(896, 896, 1296), (896, 896, 200), (3584 // 4, 512, 648), (1536, 1000, 96)])
 def test_gemv_chain_role_hands_the_hidden_layer_over_inside_the_launch(n_mid, n_out, tile_rows):
     """Round 5: HICOM_ROLE_GEMV_CHAIN -- h = GELU(C (o + b_v) + r0) and y = W2 h + b2 -> replicated output rows in ONE launch, h handed
