@@ -47,7 +47,8 @@ def _sum0(x):
 
 
 def _supported(proj) -> bool:
-    """Every injection mode and adaptor; not: text2qk projections (text width != query width), clip-scale."""
+    """Every injection mode and adaptor, clip-scale on the LOCAL stage (round 6; not together with k / v adaptors); not: text2qk
+    projections (text width != query width), clip-scale on the global stage."""
     from .projector import _plain_injector
     lc, gc = proj.local_compressor, proj.global_compressor
     for c in (lc, gc):
@@ -55,7 +56,9 @@ def _supported(proj) -> bool:
             continue
         if c.use_guide not in ("direct", None, "off", "coarse", "fine") or not _plain_injector(c.guide_injector):
             return False
-    return proj.local_logit is None and proj.global_logit is None
+    if proj.local_logit is not None and lc is not None and (lc.adapt_k or lc.adapt_v):
+        return False
+    return proj.global_logit is None
 
 
 def _f32_params(proj):
@@ -441,7 +444,7 @@ def _reads_frames_embed(proj, want_fe, want_guide, have_ctx) -> bool:
         return False
     mode = lc.use_guide if lc.use_guide not in (None, "off") else None
     query_params = mode in ("coarse", "fine") or lc.adapt_q or lc.adapt_guide
-    return (not have_ctx) or want_fe or lc.adapt_k or lc.adapt_v or query_params or (want_guide and mode is not None)
+    return (not have_ctx) or want_fe or lc.adapt_k or lc.adapt_v or query_params or (want_guide and mode is not None) or proj.local_logit is not None
 
 
 _MAX_BWD_GRAPHS = 4
@@ -598,7 +601,7 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         if ctx_local16 is not None:                                         # kept by the training forward (the executor's fp16 plane,
             ctx_l = ctx_local16.float()                                     # or the operator-by-operator forward's own fp32 contexts)
         else:
-            ctx_l, _ = lc.window_context(ff, fe, guide, modal, None, None,     # HIP: [Nw, E] fp32 window contexts
+            ctx_l, _ = lc.window_context(ff, fe, guide, modal, *proj._logit_args("local"),     # HIP: [Nw, E] fp32 window contexts
                                          adapt_y=(rec_k[2] if rec_k else None, rec_v[2] if rec_v else None) if adapt else None)
         W0, b0 = f32["local_compressor.readout.0.weight"], f32["local_compressor.readout.0.bias"]
         W2 = f32["local_compressor.readout.2.weight"]
@@ -612,7 +615,27 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         mode = lc.use_guide if lc.use_guide not in (None, "off") else None
         plain_q = not (lc.adapt_q or lc.adapt_guide)                       # plain direct / coarse / off: the hand-written paths below
         query_params = mode in ("coarse", "fine") or lc.adapt_q or lc.adapt_guide
-        if want_fe or adapt or query_params or (want_guide and mode is not None):
+        # clip-scale on the local stage (reference projector.py:527-529, :549; `local_logit_scale` / `local_logit_bias` are trainable under
+        # `attn_scale`, train.py:730-733): frames_embed and guide_embed enter L2-normalised (only when frames_embed is given), the logits
+        # are e^ls (q . khat) + lb.  The window backward takes the normalisation of the keys itself (l2norm_key); the guide's -- a
+        # handful of rows -- is differentiated here: ghat = g / ||g||, d g = (d ghat - ghat (ghat . d ghat)) / ||g||.
+        clip = proj.local_logit if "local" in stages else None
+        l2k = clip is not None and fe is not None
+        guide_q, g_nrm = guide, None
+        if l2k and mode is not None:
+            g_rows = guide.detach().float().reshape(-1, E)
+            g_nrm = g_rows.norm(dim=-1, keepdim=True)
+            guide_q = (g_rows / g_nrm).reshape(guide.shape)
+
+        def through_guide_norm(dgh):
+            """d guide_embed from the gradient w.r.t. the normalised guide rows (identity without clip-scale)."""
+            if g_nrm is None or dgh is None:
+                return dgh
+            gh = guide_q.reshape(-1, E)
+            dgh = dgh.reshape(-1, E)
+            return ((dgh - gh * (gh * dgh).sum(-1, keepdim=True)) / g_nrm).reshape(guide.shape)
+
+        if want_fe or adapt or query_params or (want_guide and mode is not None) or clip is not None:
             # ---- attention backward of the windows: dq per window, d key stream, d value stream -------------------------
             from . import injector as inj
             exact = all(a.nwin * a.k == a.n for a in (at, ay, ax))
@@ -621,11 +644,11 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
                                           f"partition (T, H, W = {T}, {H}, {W} against kernel {at.k}, {ay.k}, {ax.k})")
             axes = tuple(nv.Axis(a.n, a.k, a.nwin, a.nfull) for a in (at, ay, ax))
             dctx_l = (dpre @ W0).contiguous()
-            scale = 1.0 / math.sqrt(lc.qk_dim)
+            scale, bias = (math.exp(clip[0]), float(clip[1])) if clip is not None else (1.0 / math.sqrt(lc.qk_dim), 0.0)
             key = fe if fe is not None else ff
             pooled = None
             if mode == "direct":
-                q, _ = inj.inject(lc.guide_injector, "direct", None, guide.contiguous())       # the (adapted) guide, one row
+                q, _ = inj.inject(lc.guide_injector, "direct", None, guide_q.contiguous())     # the (adapted) guide, one row
                 q = q.reshape(-1).contiguous()
             else:
                 pooled = torch.empty((*grid, E), dtype=torch.float32, device=dev)
@@ -635,7 +658,7 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
                 if lc.adapt_q:
                     q = inj.adapt_query(q, lc.q_proj, lc.q_norm, lc.q_alpha)                    # HIP (ref :541)
                 if mode in ("coarse", "fine"):
-                    q, _ = inj.inject(lc.guide_injector, mode, q.reshape(nw, E), guide.contiguous())   # HIP (ref :369-397)
+                    q, _ = inj.inject(lc.guide_injector, mode, q.reshape(nw, E), guide_q.contiguous())   # HIP (ref :369-397)
             if adapt:
                 # ---- k / v adaptors: window-attention backward with the blends (two streaming passes over x_k, y_k, x_v, y_v), then
                 # the adaptor MLPs' backward per stream; everything token-stream sized runs on HIP kernels --------------------------
@@ -685,19 +708,23 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
                 dq_w = torch.empty((nw, E), dtype=torch.float32, device=dev)
                 if want_fe and fe is not None:
                     d_fe = torch.empty_like(fe)
-                nv.local_attn_bwd(key, ff, axes, q, 0 if mode == "direct" else E, scale, 0.0, dctx_l, dq_w, d_fe)
+                dls = torch.empty((nw,), dtype=torch.float32, device=dev) if clip is not None else None
+                nv.local_attn_bwd(key, ff, axes, q, 0 if mode == "direct" else E, scale, bias, dctx_l, dq_w, d_fe, l2norm_key=l2k, dls=dls)
+                if clip is not None:
+                    grads["local_logit_scale"] = dls.sum().reshape(1)       # d s_i / d ls = s_i - lb
+                    grads["local_logit_bias"] = torch.zeros(1, dtype=torch.float32, device=dev)   # a shift of a window's logits: softmax cancels it
             if mode == "direct" and plain_q:
                 if want_guide:
-                    d_guide += dq_w.sum(0)
+                    d_guide += through_guide_norm(dq_w.sum(0)).reshape(d_guide.shape)
             elif mode == "coarse" and plain_q:
-                _, dg = _coarse_backward(lc.guide_injector, "local_compressor.guide_injector.", pooled, guide, dq_w, grads)
+                _, dg = _coarse_backward(lc.guide_injector, "local_compressor.guide_injector.", pooled, guide_q, dq_w, grads)
                 if want_guide:
-                    d_guide += dg
+                    d_guide += through_guide_norm(dg).reshape(d_guide.shape)
             elif query_params or (want_guide and mode is not None):
                 d_inj = dq_w.sum(0, keepdim=True) if mode == "direct" else dq_w
-                _, dg = _query_chain_backward(lc, "local_compressor.", pooled, guide, d_inj, f32, grads, want_guide)
+                _, dg = _query_chain_backward(lc, "local_compressor.", pooled, guide_q, d_inj, f32, grads, want_guide)
                 if want_guide and dg is not None:
-                    d_guide += dg.reshape(d_guide.shape)
+                    d_guide += through_guide_norm(dg).reshape(d_guide.shape)
     if gc is not None:
         att = gc.attn_layer
         nh, hd = att.num_heads, att.head_dim
@@ -869,9 +896,10 @@ def forward_with_grad(proj, frames_feature, frames_embed, guide_embed, modal, im
     some = frames_feature["patch"] if isinstance(frames_feature, dict) else frames_feature
     _require_bf16_cuda("frames_feature", some)
     if not _supported(proj):
-        raise NotImplementedError("hicom_amd: the backward pass covers every injection mode and adaptor, without clip-scale and without "
-                                  "a text2qk projection; run other configurations under torch.no_grad() / inference_mode() -- forward() "
-                                  "never returns a silently detached tensor")
+        raise NotImplementedError("hicom_amd: the backward pass covers every injection mode and adaptor and clip-scale on the local stage "
+                                  "(not together with k / v adaptors); not clip-scale on the global stage, not a text2qk projection; run "
+                                  "other configurations under torch.no_grad() / inference_mode() -- forward() never returns a silently "
+                                  "detached tensor")
     names, params = zip(*[(n, p) for n, p in proj.named_parameters()])
     if isinstance(frames_feature, dict):
         c = lambda t: None if t is None else t.contiguous()

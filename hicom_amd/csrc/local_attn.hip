@@ -415,6 +415,12 @@ struct LocalBwdParams {
     const float* dctx;     // [Nw, D]
     float* dq;             // [Nw, D]
     uint16_t* dkey;        // bf16 [N, D] or NULL
+    // clip-scale (reference projector.py:527-529, :549; round 6): the key rows are L2-normalised, khat_i = k_i / ||k_i||, and
+    // s_i = e^ls (q . khat_i) + lb  (scale = e^ls, bias = lb).  Then  dq = scale sum_i dS_i khat_i,
+    // dk_i = scale dS_i (q - khat_i (q . khat_i)) / ||k_i||  (through the normalisation), and -- since ds_i / d ls = s_i - lb --
+    // dls[w] = sum_i dS_i (s_i - lb) per window (d lb = sum_i dS_i = 0 exactly: the softmax cancels a shift).
+    int l2norm_key;
+    float* dls;            // [Nw] or NULL
 };
 
 template <int NV>
@@ -426,7 +432,9 @@ __global__ __launch_bounds__(256) void local_attn_bwd_kernel(LocalBwdParams p) {
     const int WP = (WIN + 3) & ~3;
     float* sc = lsm;                              // [WIN] scores, then dS
     float* dp = lsm + WP;                         // [WIN] dP
-    float* part = lsm + 2 * WP;                   // [4][D] partial dq
+    float* rin = lsm + 2 * WP;                    // [WIN] 1 / ||k_i|| (1 without l2norm_key)
+    float* sraw = lsm + 3 * WP;                   // [WIN] q . khat_i
+    float* part = lsm + 4 * WP;                   // [4][D] partial dq
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int win = blockIdx.x;
@@ -470,17 +478,23 @@ __global__ __launch_bounds__(256) void local_attn_bwd_kernel(LocalBwdParams p) {
         for (int u = 0; u < 2; ++u) {
             const int i = i0 + 4 * u;
             if (i < WIN) {
-                float dot = 0.f, dd = 0.f;
+                float dot = 0.f, dd = 0.f, kk = 0.f;
 #pragma unroll
                 for (int s = 0; s < NV; ++s)
 #pragma unroll
                     for (int j = 0; j < 6; ++j) {
                         dot = fmaf(q[s][j], k[u][s][j], dot);
                         dd = fmaf(g[s][j], v[u][s][j], dd);
+                        kk = fmaf(k[u][s][j], k[u][s][j], kk);
                     }
                 dot = wave_sum_fast(dot);
                 dd = wave_sum_fast(dd);
-                if (lane == 0) { sc[i] = dot * p.scale + p.bias; dp[i] = dd; }
+                float ri = 1.0f;
+                if (p.l2norm_key) {
+                    ri = 1.0f / sqrtf(wave_sum_fast(kk));
+                    dot *= ri;
+                }
+                if (lane == 0) { sc[i] = dot * p.scale + p.bias; dp[i] = dd; rin[i] = ri; sraw[i] = dot; }
             }
         }
     }
@@ -499,8 +513,18 @@ __global__ __launch_bounds__(256) void local_attn_bwd_kernel(LocalBwdParams p) {
     const float inv_sum = 1.0f / wave_sum_fast(sum);
     const float delta = wave_sum_fast(pd) * inv_sum;
     __syncthreads();                               // every wave has read sc / dp as scores
-    if (wave == 0)
-        for (int i = lane; i < WIN; i += 64) sc[i] = expf(sc[i] - mx) * inv_sum * (dp[i] - delta);     // dS
+    if (wave == 0) {
+        float dl = 0.f;
+        for (int i = lane; i < WIN; i += 64) {
+            const float s_i = sc[i], dS = expf(s_i - mx) * inv_sum * (dp[i] - delta);
+            dl = fmaf(dS, s_i - p.bias, dl);
+            sc[i] = dS;
+        }
+        if (p.dls) {
+            dl = wave_sum_fast(dl);
+            if (lane == 0) p.dls[win] = dl;
+        }
+    }
     __syncthreads();
 
     // ---- phase 2: dq = scale sum_i dS_i k_i ;  dkey_i = scale dS_i q -----------------------------------------
@@ -520,19 +544,24 @@ __global__ __launch_bounds__(256) void local_attn_bwd_kernel(LocalBwdParams p) {
         for (int u = 0; u < 3; ++u) {
             const int i = i0 + 4 * u;
             if (i < WIN) {
-                const float ds = sc[i] * p.scale;
+                // (plain: dsk = ds, kc = 0.  clip-scale: d k_i = ds / ||k|| (q - khat (q . khat)) = dsk q - kc k with dsk = ds / ||k||,
+                // kc = dsk (q . khat) / ||k||; the dq sum runs over khat = k / ||k||)
+                const float ds = sc[i] * p.scale, dsk = ds * rin[i], kc = p.l2norm_key ? dsk * sraw[i] * rin[i] : 0.f;
 #pragma unroll
                 for (int s = 0; s < NV; ++s)
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) acc[s][j] = fmaf(ds, k[u][s][j], acc[s][j]);
+                    for (int j = 0; j < 6; ++j) acc[s][j] = fmaf(dsk, k[u][s][j], acc[s][j]);
                 if (p.dkey) {
                     uint16_t* o = p.dkey + token_of(i) * D;
 #pragma unroll
                     for (int s = 0; s < NV; ++s) {
+                        float e[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) e[j] = fmaf(dsk, q[s][j], -kc * k[u][s][j]);
                         Seg12 w;
-                        w.a = f32_to_bf16(ds * q[s][0]) | ((uint32_t)f32_to_bf16(ds * q[s][1]) << 16);
-                        w.b = f32_to_bf16(ds * q[s][2]) | ((uint32_t)f32_to_bf16(ds * q[s][3]) << 16);
-                        w.c = f32_to_bf16(ds * q[s][4]) | ((uint32_t)f32_to_bf16(ds * q[s][5]) << 16);
+                        w.a = f32_to_bf16(e[0]) | ((uint32_t)f32_to_bf16(e[1]) << 16);
+                        w.b = f32_to_bf16(e[2]) | ((uint32_t)f32_to_bf16(e[3]) << 16);
+                        w.c = f32_to_bf16(e[4]) | ((uint32_t)f32_to_bf16(e[5]) << 16);
                         *reinterpret_cast<Seg12*>(o + 384 * s + 6 * lane) = w;
                     }
                 }
@@ -1128,7 +1157,8 @@ extern "C" int hicom_local_attn_adapt_fwd(const void* key_x, const void* key_y, 
 extern "C" int hicom_local_attn_bwd(const void* key, const void* value, int32_t D,
                                     hicom_axis at, hicom_axis ay, hicom_axis ax,
                                     const void* query, int32_t query_dt, int64_t query_stride,
-                                    float scale, float bias, const float* dctx, float* dq, void* dkey, void* stream) {
+                                    float scale, float bias, const float* dctx, float* dq, void* dkey,
+                                    int32_t l2norm_key, float* dls, void* stream) {
     HICOM_REQUIRE(key && value && query && dctx && dq, HICOM_EINVAL, "local_attn_bwd: NULL pointer");
     HICOM_REQUIRE(D == 1152 || D == 768, HICOM_EUNSUP, "local_attn_bwd: D=%d (only 1152 / 768)", D);
     HICOM_REQUIRE(query_dt == HICOM_DT_BF16 || query_dt == HICOM_DT_F32, HICOM_EINVAL, "local_attn_bwd: query dtype");
@@ -1145,8 +1175,8 @@ extern "C" int hicom_local_attn_bwd(const void* key, const void* value, int32_t 
     const long nwin = (long)at.nwin * ay.nwin * ax.nwin;
     HICOM_REQUIRE(nwin < (1L << 31), HICOM_EINVAL, "local_attn_bwd: too many windows");
     LocalBwdParams p{(const uint16_t*)key, (const uint16_t*)value, query, query_dt == HICOM_DT_F32, (long)query_stride, at, ay, ax,
-                     scale, bias, dctx, dq, (uint16_t*)dkey};
-    const size_t smem = 2 * (((size_t)win + 3) & ~(size_t)3) * 4 + 4 * (size_t)D * 4;
+                     scale, bias, dctx, dq, (uint16_t*)dkey, l2norm_key ? 1 : 0, dls};
+    const size_t smem = 4 * (((size_t)win + 3) & ~(size_t)3) * 4 + 4 * (size_t)D * 4;
     hipStream_t s = (hipStream_t)stream;
     if (D == 1152) hipLaunchKernelGGL(local_attn_bwd_kernel<3>, dim3((unsigned)nwin), dim3(256), smem, s, p);
     else hipLaunchKernelGGL(local_attn_bwd_kernel<2>, dim3((unsigned)nwin), dim3(256), smem, s, p);

@@ -445,6 +445,42 @@ __global__ __launch_bounds__(256) void partials_sum_tall_kernel(const float* par
 
 using namespace hicom;
 
+// 16-bit <-> 16-bit cast of a contiguous tensor: fp16 -> bf16 (round to nearest even: the boundary accepts fp16 modules and inputs -- the
+// reference's inference default, inference_video_mcqa_videomme.py:323 -- and runs them on the bf16 kernels) and bf16 -> fp16 (saturating:
+// the result of such a call).  Eight elements per thread, 16-byte accesses.
+__global__ __launch_bounds__(256) void cast16_kernel(const uint16_t* src, uint16_t* dst, long n8, long n, int to_bf16) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    auto conv = [&](uint16_t h) -> uint16_t {
+        if (to_bf16) return f32_to_bf16((float)__builtin_bit_cast(_Float16, h));
+        const float v = fminf(fmaxf(bf16_to_f32(h), -65504.f), 65504.f);
+        const _Float16 o = (_Float16)v;
+        return __builtin_bit_cast(uint16_t, o);
+    };
+    if (8 * i + 8 <= n) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + 8 * i);
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned u = v[q];
+            o[q] = (unsigned)conv((uint16_t)(u & 0xFFFFu)) | ((unsigned)conv((uint16_t)(u >> 16)) << 16);
+        }
+        *reinterpret_cast<u32x4*>(dst + 8 * i) = o;
+    } else {
+        for (long k = 8 * i; k < n; ++k) dst[k] = conv(src[k]);
+    }
+}
+
+extern "C" int hicom_cast16_fwd(const void* src, int32_t src_dt, void* dst, int32_t dst_dt, int64_t n, void* stream) {
+    HICOM_REQUIRE(src && dst && n > 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0), HICOM_EINVAL, "cast16: bad arguments (16-byte aligned tensors)");
+    HICOM_REQUIRE((src_dt == HICOM_DT_F16 && dst_dt == HICOM_DT_BF16) || (src_dt == HICOM_DT_BF16 && dst_dt == HICOM_DT_F16), HICOM_EINVAL,
+                  "cast16: fp16 -> bf16 or bf16 -> fp16");
+    const long n8 = (n + 7) / 8;
+    hipLaunchKernelGGL(cast16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, (uint16_t*)dst, n8,
+                       (long)n, dst_dt == HICOM_DT_BF16 ? 1 : 0);
+    return hicom_host::check_launch("cast16");
+}
+
 extern "C" int hicom_partials_sum_fwd(const float* parts, int32_t nparts, int64_t M, float* out, void* stream) {
     HICOM_REQUIRE(parts && out && nparts > 0 && M > 0, HICOM_EINVAL, "partials_sum: bad arguments");
     if (nparts >= 64 && M <= 65536)

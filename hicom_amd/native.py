@@ -27,7 +27,7 @@ EXPORTS = (
     "hicom_global_stream_nparts", "hicom_global_merge_fwd", "hicom_global_combine_fwd",
     "hicom_readout_gemm_fwd", "hicom_scatter_rows_fwd", "hicom_fold_query_split_fwd",
     "hicom_global_combine_strided_fwd", "hicom_compressor_workspace_bytes", "hicom_compressor_zero_prefix_bytes", "hicom_compressor_is_fused",
-    "hicom_compressor_fwd2", "hicom_compressor_takes_shard4", "hicom_compressor_handoff_failures",
+    "hicom_compressor_fwd2", "hicom_compressor_takes_shard4", "hicom_compressor_handoff_failures", "hicom_cast16_fwd",
     "hicom_compressor_fwd", "hicom_linear_to_rows_fwd", "hicom_fused_stream_fwd", "hicom_fused_stream_nparts",
     "hicom_planes_gemm_fwd", "hicom_row_ln_fwd", "hicom_small_mha_fwd", "hicom_place_blocks_fwd",
     "hicom_global_stream_bwd", "hicom_readout16_gemm_fwd", "hicom_to_f16_fwd", "hicom_merge_vproj_fwd",
@@ -156,7 +156,7 @@ def lib() -> C.CDLL:
         raise HicomNativeError(f"ABI mismatch: library {L.hicom_abi_version()} vs binding {ABI_VERSION}; rebuild")
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     L.hicom_local_attn_fwd.argtypes = [vp, i32, vp, i32, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32, i32, vp, vp, vp]
-    L.hicom_local_attn_bwd.argtypes = [vp, vp, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32, vp, vp, vp, vp]
+    L.hicom_local_attn_bwd.argtypes = [vp, vp, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32, vp, vp, vp, i32, vp, vp]
     L.hicom_trilinear_pool_fwd.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.hicom_linear_fwd.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.hicom_fold_query_fwd.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp]
@@ -230,6 +230,7 @@ def lib() -> C.CDLL:
     L.hicom_compressor_zero_prefix_bytes.argtypes = [ap]
     L.hicom_compressor_is_fused.argtypes = [ap]
     L.hicom_compressor_fwd2.argtypes = [ap, ap]
+    L.hicom_cast16_fwd.argtypes = [vp, i32, vp, i32, i64, vp]
     L.hicom_compressor_takes_shard4.argtypes = [ap]
     L.hicom_compressor_handoff_failures.argtypes = [ap, C.POINTER(C.c_int32), vp]
     L.hicom_compressor_fwd.argtypes = [ap]
@@ -376,11 +377,13 @@ def colsum(x_bf16, nparts=128):
     return out
 
 
-def local_attn_bwd(key, value, axes, query, query_stride, scale, bias, dctx, dq, dkey=None):
+def local_attn_bwd(key, value, axes, query, query_stride, scale, bias, dctx, dq, dkey=None, l2norm_key=False, dls=None):
+    """l2norm_key / dls: clip-scale on the local stage -- key rows L2-normalised, dls f32 [Nw] = per-window share of d logit_scale."""
     D = value.shape[-1]
     assert key.dtype == torch.bfloat16 and value.dtype == torch.bfloat16 and dctx.dtype == torch.float32 and dq.dtype == torch.float32
     _check(lib().hicom_local_attn_bwd(_ptr(key), _ptr(value), D, axes[0], axes[1], axes[2], _ptr(query), _dt(query), query_stride,
-                                      scale, bias, _ptr(dctx), _ptr(dq), _ptr(dkey), _stream()), "hicom_local_attn_bwd")
+                                      scale, bias, _ptr(dctx), _ptr(dq), _ptr(dkey), int(bool(l2norm_key)), _ptr(dls), _stream()),
+           "hicom_local_attn_bwd")
 
 
 def trilinear_pool(x, out):
@@ -625,6 +628,15 @@ def planes_gemm(a_hi, a_lo, w, b, act=ACT_NONE, out_hi=None, out_lo=None, y=None
                                        act, _ptr(out_hi), _ptr(out_lo), _ptr(y), _dt(y) if y is not None else 0,
                                        y.shape[-1] if y is not None else 0, row0, nl_group, _stream()),
            "hicom_planes_gemm_fwd")
+
+
+def cast16(src, dtype):
+    """fp16 -> bf16 (round to nearest even) or bf16 -> fp16 (saturating) copy of a contiguous tensor (hicom_cast16_fwd)."""
+    src = src.contiguous()
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    if src.numel():
+        _check(lib().hicom_cast16_fwd(_ptr(src), _dt(src), _ptr(dst), _dt(dst), src.numel(), _stream()), "hicom_cast16_fwd")
+    return dst
 
 
 def to_f16(src, dst=None):

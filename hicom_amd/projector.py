@@ -912,6 +912,9 @@ class HIComProjector(nn.Module):
         """Reference signature (projector.py:676).  Extension for the producer of frames_embed:
         `local_logits` = fp32 [T,H,W] raw dot products frames_embed_n . guide from `hicom_amd.siglip_head_scores`, passed with
         frames_embed=None -- the release recipe then streams frames_feature only (half the bytes)."""
+        p0 = next(self.parameters(), None)
+        if p0 is not None and p0.dtype == torch.float16:
+            return self._forward_half(frames_feature, frames_embed, guide_embed, modal, image_newline, local_logits)
         self._check_clip_logits()
         if local_logits is not None:
             return self._forward_with_logits(frames_feature, frames_embed, guide_embed, modal, image_newline, local_logits)
@@ -930,6 +933,53 @@ class HIComProjector(nn.Module):
             return engine.run_dense(self, frames_feature, frames_embed, guide_embed, modal, image_newline,
                                     _out_dtype(self))
         return self.forward_stepwise(frames_feature, frames_embed, guide_embed, modal, image_newline)
+
+    def _forward_half(self, frames_feature, frames_embed, guide_embed, modal, image_newline, local_logits):
+        """An fp16 projector with fp16 inputs -- the reference's inference default (`--dtype float16`,
+        inference_video_mcqa_videomme.py:323; `load_mm_projector` casts the loaded weights to fp16, projector.py:53).  The kernels
+        compute on bf16 tokens and weights, so the call runs on a bf16 TWIN of this module: its weights are cast once per weight state
+        (a checkpoint trained in bf16 and loaded as fp16 converts back exactly; a genuinely fp16-trained weight is rounded to 8
+        significand bits), the inputs are cast per call by hicom_cast16_fwd (fp16 activations are ROUNDED to bf16: 2^-9 relative -- the
+        price of this width, stated here rather than hidden), the result is cast back to fp16.  Inference only."""
+        import copy
+        from . import engine
+        if local_logits is not None:
+            raise NotImplementedError("local_logits= takes a bfloat16 projector")
+        if self._needs_grad(frames_feature, frames_embed, guide_embed, image_newline):
+            raise NotImplementedError("hicom_amd: training takes a bfloat16 projector (the fp16 width is an inference path)")
+        sig = engine.content_sig(self) + (engine.plan_sig(self)[1:3],)
+        twin = self.__dict__.get("_bf16_twin")
+        if twin is None or twin[1] != sig:
+            with torch.no_grad():
+                if twin is None:
+                    saved = {k: self.__dict__.pop(k) for k in ("_bf16_twin", "_engine_plans", "_shard_plans", "_bwd_graphs", "_last_plan")
+                             if k in self.__dict__}
+                    try:
+                        mod = copy.deepcopy(self).to(torch.bfloat16)
+                    finally:
+                        self.__dict__.update(saved)
+                else:
+                    mod = twin[0]
+                    for pt, ps in zip(mod.parameters(), self.parameters()):
+                        pt.copy_(ps)                                   # in place: the twin's plans keep their addresses
+                mod.train(self.training)
+                mod.return_fp32 = getattr(self, "return_fp32", False)
+            twin = (mod, sig)
+            self.__dict__["_bf16_twin"] = twin
+
+        def down(t):
+            if t is None:
+                return None
+            if isinstance(t, dict):
+                return {k: down(v) for k, v in t.items()}
+            if t.dtype == torch.bfloat16:
+                return t
+            if t.dtype != torch.float16 or not t.is_cuda:
+                raise NotImplementedError(f"hicom_amd: an fp16 projector takes fp16 (or bf16) CUDA tensors (got {t.dtype} on {t.device})")
+            return nv.cast16(t, torch.bfloat16)
+        with torch.no_grad():
+            out = twin[0](down(frames_feature), down(frames_embed), down(guide_embed), modal, down(image_newline))
+        return out if out.dtype == torch.float32 else nv.cast16(out, torch.float16)
 
     def _executor_covers(self) -> bool:
         """Recipes whose token-stream work hicom_compressor_fwd runs in one call: every injection mode (coarse / fine / the query-side

@@ -119,11 +119,17 @@ int hicom_colsum_fwd(const void* x_bf16, int64_t N, int32_t D, float* parts, int
  * w.r.t. the key stream frames_embed and the query are needed.
  *   key, value : bf16 [T,H,W,D];  query as in hicom_local_attn_fwd;  dctx : f32 [Nw, D] upstream gradient of ctx
  *   dq         : f32 [Nw, D]  scale * sum_i dS_i k_i per window (a shared query's gradient is the sum over windows)
- *   dkey       : bf16 [T,H,W,D] scale * dS_i * q, or NULL; needs an exact window partition (plain stores) */
+ *   dkey       : bf16 [T,H,W,D] scale * dS_i * q, or NULL; needs an exact window partition (plain stores)
+ *   l2norm_key (ABI 15): clip-scale on the local stage (projector.py:527-529, :549; trainable under `attn_scale`, train.py:730-733):
+ *                the key rows enter L2-normalised, s_i = scale (q . k_i / ||k_i||) + bias with scale = e^logit_scale, bias = logit_bias;
+ *                dq and dkey then go through the normalisation.  The query is used as given (the caller normalises the guide).
+ *   dls        : f32 [Nw] or NULL: sum_i dS_i (s_i - bias) per window = this window's share of d logit_scale (d logit_bias is 0: the
+ *                softmax cancels a shift) */
 int hicom_local_attn_bwd(const void* key, const void* value, int32_t D,
                          hicom_axis at, hicom_axis ay, hicom_axis ax,
                          const void* query, int32_t query_dt, int64_t query_stride,
-                         float scale, float bias, const float* dctx, float* dq, void* dkey, void* stream);
+                         float scale, float bias, const float* dctx, float* dq, void* dkey,
+                         int32_t l2norm_key, float* dls, void* stream);
 
 /* ---- pooled per-window query: F.interpolate(..., 'trilinear', align_corners=False) --------
  * Replaces projector.py:539-540.  x bf16 [T,H,W,D] -> out f32 [t',h',w',D]. */
@@ -469,6 +475,11 @@ int hicom_merge_vproj_sets_fwd(const float* sets, int64_t set_stride, int32_t ns
                                float* out_ml, float* out_ctx, void* stream);
 /* dst fp16 [rows, ld_dst] = saturating cast of src (bf16 or f32) [rows, cols]; columns [cols, ld_dst) are zero-filled */
 int hicom_to_f16_fwd(const void* src, int32_t src_dt, void* dst, int64_t n, void* stream);
+/* ABI 15: contiguous 16-bit <-> 16-bit cast, fp16 -> bf16 (round to nearest even) or bf16 -> fp16 (saturating); 16-byte aligned tensors.
+ * The boundary's fp16 width: the reference's inference default is fp16 (inference_video_mcqa_videomme.py:323, model/__init__.py:44,
+ * projector.py:53 `load_mm_projector` casts to fp16) -- an fp16 projector runs on the bf16 kernels through casts of its inputs and of its
+ * result (hicom_amd/projector.py: HIComProjector._forward_half). */
+int hicom_cast16_fwd(const void* src, int32_t src_dt, void* dst, int32_t dst_dt, int64_t n, void* stream);
 int hicom_to_f16_padded_fwd(const void* src, int32_t src_dt, int64_t rows, int64_t cols, void* dst, int64_t ld_dst, void* stream);
 
 /* Release recipe, one query row per head: merge of the ring kernel's partial states fused with v_proj

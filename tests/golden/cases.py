@@ -72,6 +72,18 @@ CASES = {
     "G11_c1_shape": dict(cfg=dict(hidden_size=896), T=4, h=27, w=27, sampled=True),
 }
 
+# Cases of the GRADIENT fixtures only (make_golden_grad.py -> golden_grad_v3.npz; not part of golden_v1's forward matrix): clip-scale on
+# the local stage under autograd (reference projector.py:527-529, :549; trainable under `attn_scale`, train.py:730-733), taken through
+# direct LocalCompressor calls with logit tensors as the forward fixtures G8* do (the reference's projector cannot be CONSTRUCTED with
+# use_clip_scale offline: it reads the logits from the SigLIP checkpoint on the hub, :660-670).  Local-only projector types, so that
+# HIComProjector.forward of the build is exactly that call + the flatten packing.
+CASES_EXTRA = {
+    "G8f_clip_local_direct": dict(cfg=dict(mm_projector_type="local43"), T=8, h=6, w=6, logit=dict(local=(2.0, -3.0), glob=None)),
+    "G8g_clip_local_off": dict(cfg=dict(mm_projector_type="local43", use_guide=None), T=4, h=6, w=6, logit=dict(local=(1.5, 0.5), glob=None)),
+    "G8h_clip_local_coarse": dict(cfg=dict(mm_projector_type="local43", use_guide="coarse"), T=4, h=6, w=9, logit=dict(local=(2.0, -3.0), glob=None)),
+    "G8i_clip_local_fine": dict(cfg=dict(mm_projector_type="local43", use_guide="fine"), T=4, h=6, w=6, guide_len=9, logit=dict(local=(2.5, 1.0), glob=None)),
+}
+
 DEFAULT_CFG = dict(mm_projector_type="local43_global32_coarse", use_guide="direct", use_clip_scale="",
                    mm_patch_merge_type="spatial_unpad", mm_newline_position="no_token",
                    mm_vision_tower=TOWER, mm_hidden_size=D, hidden_size=64, max_num_frames=16)
@@ -79,7 +91,7 @@ DEFAULT_CFG = dict(mm_projector_type="local43_global32_coarse", use_guide="direc
 
 def case_config(name: str) -> dict:
     cfg = dict(DEFAULT_CFG)
-    cfg.update(CASES[name]["cfg"])
+    cfg.update((CASES.get(name) or CASES_EXTRA[name])["cfg"])
     return cfg
 
 
@@ -101,7 +113,7 @@ def build_case(name: str):
     from hicom_amd import synth
     from oracle import hicom_oracle as orc
 
-    c = CASES[name]
+    c = CASES.get(name) or CASES_EXTRA[name]
     cfg = SimpleNamespace(**case_config(name))
     shapes = orc.param_shapes(cfg)
     sd = synth.synth_state_dict(shapes, tag=name, peaky=c.get("peaky", 1.0))

@@ -75,8 +75,44 @@ def anyres_grads(proj, blobs2):
         print(name, "(anyres) params with grad:", sum(1 for _, gr in items if gr is not None), "/", len(items))
 
 
+CLIP_LOCAL_CASES = list(cases.CASES_EXTRA)               # clip-scale on the local stage under autograd, into golden_grad_v3.npz
+
+
+def clip_local_grads(proj, blobs3):
+    """LocalCompressor.forward(ff, fe, g, modal, logit_scale, logit_bias) of the reference with the two logits as leaf tensors
+    (reference projector.py:524-559; HIComProjector.forward passes its `local_logit_scale` / `local_logit_bias` parameters there,
+    :691-692): gradients of the compressor's parameters, of both logits, of guide_embed and of frames_embed for loss = sum(out * R)."""
+    for name in CLIP_LOCAL_CASES:
+        case = cases.build_case(name)
+        torch.manual_seed(0)
+        module = proj.build_vision_projector(case.cfg).float().train()
+        module.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd.items()}, strict=True)
+        t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))
+        ff, fe, g = t(case.ff), t(case.fe).clone().requires_grad_(True), t(case.g)
+        uses_guide = getattr(case.cfg, "use_guide", None) in ("direct", "coarse", "fine")
+        if uses_guide:
+            g = g.clone().requires_grad_(True)
+        ls = torch.tensor(float(case.logit["local"][0]), requires_grad=True)
+        lb = torch.tensor(float(case.logit["local"][1]), requires_grad=True)
+        out = module.local_compressor(ff, fe, g, case.modal, ls, lb)
+        out = out.reshape(-1, out.shape[-1])                               # (= post_process_visual_feature's flatten, mm_utils.py:96-97)
+        R = torch.from_numpy(cotangent(name, out.shape))
+        (out * R).sum().backward()
+        items = [(k, p.grad) for k, p in module.named_parameters()]
+        items += [("local_logit_scale", ls.grad.reshape(1)), ("local_logit_bias", lb.grad.reshape(1)), ("__frames_embed__", fe.grad)]
+        if uses_guide:
+            items.append(("__guide_embed__", g.grad))
+        store(blobs3, name, items)
+        blobs3[f"{name}/out_shape"] = np.array(out.shape, dtype=np.int64)
+        blobs3[f"{name}/out"] = out.detach().numpy().astype(np.float32)
+        print(name, "(clip-scale local) d logit_scale", float(ls.grad), "d logit_bias", float(lb.grad), "params with grad:",
+              sum(1 for _, gr in items if gr is not None), "/", len(items))
+
+
 def main():
     proj, _ = ref_shim.load()
+    blobs3 = {}
+    clip_local_grads(proj, blobs3)
     blobs = {}
     blobs2 = {}     # golden_grad_v2.npz: d frames_embed of the recipes that do NOT inject the guide (guide off: frames_embed are the window
     #                 keys), and the parameter gradients of anyres dict inputs
@@ -123,7 +159,7 @@ def main():
             dst[f"{name}/{k}/sums"] = np.array([v.astype(np.float64).sum(), np.abs(v.astype(np.float64)).sum(),
                                                 np.abs(v).max()], dtype=np.float64)
         print(name, "params with grad:", sum(1 for _, gr in items if gr is not None), "/", len(items))
-    for fname, data in (("golden_grad_v1.npz", blobs), ("golden_grad_v2.npz", blobs2)):
+    for fname, data in (("golden_grad_v1.npz", blobs), ("golden_grad_v2.npz", blobs2), ("golden_grad_v3.npz", blobs3)):
         path = os.path.join(HERE, fname)
         np.savez_compressed(path, **data)
         print("wrote", path, os.path.getsize(path), "bytes", len(data), "arrays")
