@@ -323,6 +323,106 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
     }
 }
 
+// MODE 2's job for RG rows at once (round 6): apply the weight records [M, L | nparts partial weights | T + H + W positional weights]
+// that MODE 1 / merge_marg_weights_kernel left at the head of each row's scratch region.  MODE 2 ran one workgroup per (row, 32-column
+// slab) -- 10 368 at 288 rows -- and each walked a dependent chain of three memory round trips (weight record -> its ONE partial row per
+// thread at 32 partials -> four pe rows), re-reading the 15-KB pe slab that every row of the slab shares: 24-33 us for 43 MB
+// (profiles/r05_d_recipe_traces.txt).  Here a workgroup owns RG rows x 32 columns: the pe rows of a thread's columns are loaded ONCE into
+// registers and serve all RG rows, the RG weight records and the thread's RG partial rows are requested together with them -- one round
+// trip -- and 256 threads finish RG x 32 outputs.  Same sums in the same order per output as MODE 2 (bit-identical).
+template <int RG>
+__global__ __launch_bounds__(256) void merge_ctx_apply_kernel(MergeCtxParams p, int rows) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    const int tid = threadIdx.x, r0 = blockIdx.x * RG;
+    const int S = p.H + p.W + 2, HW2 = p.H + p.W, npos = p.T + HW2, rec = 2 + p.nparts + npos;
+    float* cred = wsm;                                   // [RG][32 partial groups][32 columns]
+    float* wrec = cred + RG * 1024;                      // [RG][rec]
+    const int pgp = tid >> 3, l4 = tid & 7;
+    const int c4 = blockIdx.y * 32 + 4 * l4;
+    const bool col_ok = c4 < p.E;
+    const long pstride = (long)p.rows_pad * p.E;
+    // ---- every request first: the thread's first partial row of each of the RG rows, its (up to) four pe rows, the weight records ----
+    float4 v0[RG];
+#pragma unroll
+    for (int rr = 0; rr < RG; ++rr) {
+        const int r = r0 + rr;
+        v0[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rows && col_ok && pgp < p.nparts) v0[rr] = *reinterpret_cast<const float4*>(p.part_acc + (long)pgp * pstride + (long)r * p.E + c4);
+    }
+    float4 pev[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = pgp + 32 * u, jc = j < npos ? j : npos - 1;
+        const int row = jc < p.T ? p.t0i + jc : (jc < p.T + p.H ? p.y0i + (jc - p.T) : p.x0i + (jc - p.T - p.H));
+        pev[u] = col_ok ? *reinterpret_cast<const float4*>(p.pe + (long)row * p.E + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int idx = tid; idx < RG * rec; idx += 256) {
+        const int rr = idx / rec, k = idx - rr * rec, r = r0 + rr;
+        wrec[idx] = r < rows ? p.scratch[(long)r * p.T * S + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < RG; ++rr) {
+        const int r = r0 + rr;
+        const float* w = wrec + rr * rec;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rows && col_ok) {
+            if (pgp < p.nparts) {
+                const float wu = w[2 + pgp];
+                a.x = fmaf(wu, v0[rr].x, a.x); a.y = fmaf(wu, v0[rr].y, a.y); a.z = fmaf(wu, v0[rr].z, a.z); a.w = fmaf(wu, v0[rr].w, a.w);
+            }
+            for (int i = pgp + 32; i < p.nparts; i += 32) {          // (more than 32 partials: the rest, one at a time)
+                const float4 v = *reinterpret_cast<const float4*>(p.part_acc + (long)i * pstride + (long)r * p.E + c4);
+                const float wu = w[2 + i];
+                a.x = fmaf(wu, v.x, a.x); a.y = fmaf(wu, v.y, a.y); a.z = fmaf(wu, v.z, a.z); a.w = fmaf(wu, v.w, a.w);
+            }
+            const float* wpos = w + 2 + p.nparts;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = pgp + 32 * u;
+                const float wu = j < npos ? wpos[j] : 0.f;
+                a.x = fmaf(wu, pev[u].x, a.x); a.y = fmaf(wu, pev[u].y, a.y); a.z = fmaf(wu, pev[u].z, a.z); a.w = fmaf(wu, pev[u].w, a.w);
+            }
+            for (int j0 = pgp + 128; j0 < npos; j0 += 128) {         // (more than 128 positional rows: long clips)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + 32 * u;
+                    if (j < npos) {
+                        const int row = j < p.T ? p.t0i + j : (j < p.T + p.H ? p.y0i + (j - p.T) : p.x0i + (j - p.T - p.H));
+                        const float4 v = *reinterpret_cast<const float4*>(p.pe + (long)row * p.E + c4);
+                        const float wu = wpos[j];
+                        a.x = fmaf(wu, v.x, a.x); a.y = fmaf(wu, v.y, a.y); a.z = fmaf(wu, v.z, a.z); a.w = fmaf(wu, v.w, a.w);
+                    }
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(cred + rr * 1024 + pgp * 32 + 4 * l4) = a;
+    }
+    __syncthreads();
+    for (int o = tid; o < RG * 32; o += 256) {
+        const int rr = o >> 5, cc = o & 31, r = r0 + rr, c = blockIdx.y * 32 + cc;
+        if (r < rows && c < p.E) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 32; ++g) v += cred[rr * 1024 + g * 32 + cc];
+            if (p.normalize) v /= wrec[rr * rec + 1];
+            p.out_acc[(long)r * p.E + c] = v;
+        }
+    }
+}
+
+// launches the apply step: RG = 8 rows per workgroup when the records fit the LDS budget, else MODE 2 (one row per workgroup)
+static void launch_merge_apply(const MergeCtxParams& p, int rows, size_t smem2, hipStream_t s) {
+    constexpr int RG = 8;
+    const size_t rec = (size_t)2 + p.nparts + p.T + p.H + p.W;
+    const size_t smem = ((size_t)RG * 1024 + RG * rec) * 4;
+    if (smem <= 64 * 1024 && p.scratch && p.pe) {
+        HICOM_LAUNCH(merge_ctx_apply_kernel<RG>, dim3((unsigned)((rows + RG - 1) / RG), (unsigned)((p.E + 31) / 32)), dim3(256), smem, s, p, rows);
+    } else {
+        HICOM_LAUNCH(merge_ctx_kernel<2>, dim3((unsigned)rows, (unsigned)((p.E + 31) / 32)), dim3(256), smem2, s, p);
+    }
+}
+
 // Row weights from the marginals the wide stream kernel accumulated itself (hicom_global_stream_marg_fwd): grid = rows.  Leaves
 // the record merge_ctx_kernel<2> applies -- [M, L | nparts partial weights | T + H + W positional weights] -- at the head of the
 // row's scratch region.  part_marg[i][r] holds chunk i's marginals relative to the chunk's own max m_i, like part_acc: the
@@ -541,7 +641,7 @@ extern "C" int hicom_global_merge_fwd(const float* part_m, const float* part_l, 
     HICOM_REQUIRE(smem2 <= 60000, HICOM_EUNSUP, "global_merge: too many partials/frames for one pass");
     if (pe && (long)nparts + T + H + W + 2 <= (long)min(kTC, T) * (H + W + 2)) {
         HICOM_LAUNCH(merge_ctx_kernel<1>, dim3((unsigned)rows), dim3(256), smem2, s, p);
-        HICOM_LAUNCH(merge_ctx_kernel<2>, dim3((unsigned)rows, (unsigned)((E + 31) / 32)), dim3(256), smem2, s, p);
+        launch_merge_apply(p, rows, smem2, s);
     } else {
         HICOM_LAUNCH(merge_ctx_kernel<0>, dim3((unsigned)rows, (unsigned)((E + 31) / 32)), dim3(256), smem2, s, p);
     }
@@ -567,7 +667,7 @@ extern "C" int hicom_global_merge_marg_fwd(const float* part_m, const float* par
     HICOM_REQUIRE(smem2 <= 60000, HICOM_EUNSUP, "global_merge_marg: too many partials/frames for one pass");
     HICOM_LAUNCH(merge_marg_weights_kernel, dim3((unsigned)rows), dim3(256), smem1, s, p, part_marg, hicom_global_stream_marg_width(H, W),
                  (int)((N + 15) / 16));
-    HICOM_LAUNCH(merge_ctx_kernel<2>, dim3((unsigned)rows, (unsigned)((E + 31) / 32)), dim3(256), smem2, s, p);
+    launch_merge_apply(p, rows, smem2, s);
     return hicom_host::check_launch("global_merge_marg");
 }
 

@@ -325,12 +325,10 @@ def sharded_forward(projector, ff_shard, fe_shard, guide_embed, total_frames: in
     if lc is None or gc is None:
         raise NotImplementedError("sharded_forward expects both compressors")
     projector._check_clip_logits()
-    if projector.global_logit is not None:
-        raise NotImplementedError("sharded_forward: no clip-scale global stage (use forward_stepwise, unsharded)")
     if torch.is_grad_enabled() and projector._needs_grad(ff_shard, fe_shard, guide_embed, image_newline):
         raise RuntimeError("sharded_forward is an inference path: call it under torch.no_grad() / inference_mode()")
     nv.begin_inference()
-    if not projector._executor_covers() or not projector._queries_native():
+    if not projector._executor_covers() or not projector._queries_native() or projector.global_logit is not None:
         # coarse / fine / query-side adaptor recipes (reference projector.py:369-397, :431-441): their injected queries are computed
         # per call from the guide -- redundantly on every rank for the 32 global rows, from the shard's own frames for the pooled
         # window queries (window-local: projector.py:539-542) -- so they shard operator by operator (round 5)
@@ -436,7 +434,9 @@ def stepwise_shard_send(projector, ff_shard, fe_shard, guide_embed, total_frames
     ctx, grid = lc.window_context(ff_shard, fe_shard, guide_embed, "video", *projector._logit_args("local"))
     nw = grid[0] * grid[1] * grid[2]
     q_in, n_rows = gc.injected_queries(guide_embed)
-    ml, acc, _ = gc.partial_context(ff_shard, q_in, t_offset=t0)
+    # (clip-scale on the global stage, reference projector.py:184-191: the key norms are per token, i.e. shard-local like the windows; the
+    # shard states merge like any others -- round 6)
+    ml, acc, _ = gc.partial_context(ff_shard, q_in, t_offset=t0, logit_scale=projector._logit_args("global")[0])
     R, E = acc.shape
     lay = PackLayout(2 * R + R * E, nw, hidden, torch.empty((), dtype=odt).element_size())
     mine = lay.new_buffer(dev)

@@ -794,7 +794,8 @@ def test_large_video_local_tokens_are_frame_group_local(c2):
 
 
 @pytest.mark.parametrize("recipe,world,newline", [("coarse", 2, None), ("coarse", 4, "grid"), ("fine", 2, "frame"), ("fine", 4, None),
-                                                  ("adaptqg_coarse", 2, None), ("clip_local_coarse", 4, None)])
+                                                  ("adaptqg_coarse", 2, None), ("clip_local_coarse", 4, None),
+                                                  ("clip_global_direct", 4, None), ("clip_global_off", 2, "grid")])
 def test_sharded_stepwise_recipes_emulated_on_one_gpu(recipe, world, newline):
     """Round 5 (verdict r4 #6): coarse / fine injection and the query-side adaptors shard over frames, operator by operator
     (`dist.stepwise_shard_send` / `stepwise_shard_finish`, the two halves of `sharded_forward_stepwise` around its one all-gather).
@@ -810,6 +811,10 @@ def test_sharded_stepwise_recipes_emulated_on_one_gpu(recipe, world, newline):
         over.update(mm_projector_type="local43_global32", use_guide=recipe)
     elif recipe == "adaptqg_coarse":
         over.update(mm_projector_type="local43_adaptqg_global32_adaptg", use_guide="coarse")
+    elif recipe == "clip_global_direct":                       # round 6: clip-scale on the GLOBAL stage shards too (key norms are per token)
+        over.update(mm_projector_type="local43_global32", use_guide="direct", use_clip_scale="global")
+    elif recipe == "clip_global_off":
+        over.update(mm_projector_type="local43_global32", use_guide=None, use_clip_scale="global")
     else:
         over.update(mm_projector_type="local43_global32", use_guide="coarse", use_clip_scale="local")
     if newline:
@@ -824,6 +829,9 @@ def test_sharded_stepwise_recipes_emulated_on_one_gpu(recipe, world, newline):
     if recipe == "clip_local_coarse":
         logit = (2.0, -3.0)
         m.set_clip_logits(local=logit)
+    if recipe in ("clip_global_direct", "clip_global_off"):
+        logit = (1.5, -2.0)
+        m.set_clip_logits(glob=logit)
     per = T // world
     with torch.no_grad():
         want = m(ff, fe, g, "video", nl)
