@@ -747,8 +747,20 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
         // [world][ag_bytes] <- every rank's [ag_bytes]; everything below reads the gathered buffer in stream order behind it
         typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
         HICOM_REQUIRE(a.ag_comm && a.ag_send && a.ag_recv && a.ag_bytes > 0, HICOM_EINVAL, "compressor: all-gather arguments");
+        typedef int (*group_fn)(void);
+        const bool two = a.ag_bytes2 > 0;
+        if (two) {
+            HICOM_REQUIRE(a.ag_group_start && a.ag_group_end && a.ag_send2 && a.ag_recv2, HICOM_EINVAL, "compressor: grouped all-gather arguments");
+            const int grc = ((group_fn)a.ag_group_start)();
+            HICOM_REQUIRE(grc == 0, HICOM_ELAUNCH, "compressor: ncclGroupStart returned %d", grc);
+        }
         const int nrc = ((allgather_fn)a.ag_fn)(a.ag_send, a.ag_recv, (size_t)a.ag_bytes, /* ncclUint8 */ 1, a.ag_comm, sm);
-        HICOM_REQUIRE(nrc == 0, HICOM_ELAUNCH, "compressor: ncclAllGather returned %d", nrc);
+        int nrc2 = 0, nrc3 = 0;
+        if (two) {
+            nrc2 = ((allgather_fn)a.ag_fn)(a.ag_send2, a.ag_recv2, (size_t)a.ag_bytes2, 1, a.ag_comm, sm);
+            nrc3 = ((group_fn)a.ag_group_end)();                     // (always closed: an open group would swallow every later collective)
+        }
+        HICOM_REQUIRE(nrc == 0 && nrc2 == 0 && nrc3 == 0, HICOM_ELAUNCH, "compressor: ncclAllGather / ncclGroupEnd returned %d / %d / %d", nrc, nrc2, nrc3);
     }
     const bool finish4 = a.has_global && do_finish && !do_stream && a.state_sets && a.nsets > 0 && a.nsets <= 256 && a.r0_buf && a.gc0 && a.nq == 1 &&
                          a.hidden <= 1536 && a.hidden % 8 == 0 && a.E % 64 == 0 && a.E / a.nh <= 128 && a.E <= 1536 && a.lw0_f16 && shard_tail_enabled();

@@ -329,30 +329,38 @@ __global__ __launch_bounds__(256) void merge_ctx_kernel(MergeCtxParams p) {
 // thread at 32 partials -> four pe rows), re-reading the 15-KB pe slab that every row of the slab shares: 24-33 us for 43 MB
 // (profiles/r05_d_recipe_traces.txt).  Here a workgroup owns RG rows x 32 columns: the pe rows of a thread's columns are loaded ONCE into
 // registers and serve all RG rows, the RG weight records and the thread's RG partial rows are requested together with them -- one round
-// trip -- and 256 threads finish RG x 32 outputs.  Same sums in the same order per output as MODE 2 (bit-identical).
+// trip.  (The per-output summation order differs from MODE 2's -- 16 groups instead of 32 -- by fp32 re-association only.)
 template <int RG>
 __global__ __launch_bounds__(256) void merge_ctx_apply_kernel(MergeCtxParams p, int rows) {
+    // a workgroup owns RG rows x 64 columns: 16 lanes x float4 across the columns (256 contiguous bytes per partial row: whole DRAM
+    // bursts; 32-column slabs read 128-byte pieces 4.6 KB apart), 16 partial groups down the partials / positional rows
+    constexpr int CW = 64, NL = CW / 4, NGR = 256 / NL;      // columns, lanes across them, groups
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int tid = threadIdx.x, r0 = blockIdx.x * RG;
     const int S = p.H + p.W + 2, HW2 = p.H + p.W, npos = p.T + HW2, rec = 2 + p.nparts + npos;
-    float* cred = wsm;                                   // [RG][32 partial groups][32 columns]
-    float* wrec = cred + RG * 1024;                      // [RG][rec]
-    const int pgp = tid >> 3, l4 = tid & 7;
-    const int c4 = blockIdx.y * 32 + 4 * l4;
+    float* cred = wsm;                                   // [RG][NGR groups][CW columns]
+    float* wrec = cred + RG * NGR * CW;                  // [RG][rec]
+    const int pgp = tid / NL, l4 = tid % NL;
+    const int c4 = blockIdx.y * CW + 4 * l4;
     const bool col_ok = c4 < p.E;
     const long pstride = (long)p.rows_pad * p.E;
-    // ---- every request first: the thread's first partial row of each of the RG rows, its (up to) four pe rows, the weight records ----
-    float4 v0[RG];
+    constexpr int PV = 2, PE = 8;                        // partials / positional rows a thread keeps in registers (2 x 16 = 32, 8 x 16 = 128)
+    // ---- every request first: the thread's first PV partial rows of each of the RG rows, its PE pe rows, the weight records ----
+    float4 v0[RG][PV];
 #pragma unroll
     for (int rr = 0; rr < RG; ++rr) {
         const int r = r0 + rr;
-        v0[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < rows && col_ok && pgp < p.nparts) v0[rr] = *reinterpret_cast<const float4*>(p.part_acc + (long)pgp * pstride + (long)r * p.E + c4);
-    }
-    float4 pev[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int j = pgp + 32 * u, jc = j < npos ? j : npos - 1;
+        for (int u = 0; u < PV; ++u) {
+            const int i = pgp + NGR * u;
+            v0[rr][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rows && col_ok && i < p.nparts) v0[rr][u] = *reinterpret_cast<const float4*>(p.part_acc + (long)i * pstride + (long)r * p.E + c4);
+        }
+    }
+    float4 pev[PE];
+#pragma unroll
+    for (int u = 0; u < PE; ++u) {
+        const int j = pgp + NGR * u, jc = j < npos ? j : npos - 1;
         const int row = jc < p.T ? p.t0i + jc : (jc < p.T + p.H ? p.y0i + (jc - p.T) : p.x0i + (jc - p.T - p.H));
         pev[u] = col_ok ? *reinterpret_cast<const float4*>(p.pe + (long)row * p.E + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -367,44 +375,40 @@ __global__ __launch_bounds__(256) void merge_ctx_apply_kernel(MergeCtxParams p, 
         const float* w = wrec + rr * rec;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < rows && col_ok) {
-            if (pgp < p.nparts) {
-                const float wu = w[2 + pgp];
-                a.x = fmaf(wu, v0[rr].x, a.x); a.y = fmaf(wu, v0[rr].y, a.y); a.z = fmaf(wu, v0[rr].z, a.z); a.w = fmaf(wu, v0[rr].w, a.w);
+#pragma unroll
+            for (int u = 0; u < PV; ++u) {
+                const int i = pgp + NGR * u;
+                const float wu = i < p.nparts ? w[2 + i] : 0.f;
+                a.x = fmaf(wu, v0[rr][u].x, a.x); a.y = fmaf(wu, v0[rr][u].y, a.y); a.z = fmaf(wu, v0[rr][u].z, a.z); a.w = fmaf(wu, v0[rr][u].w, a.w);
             }
-            for (int i = pgp + 32; i < p.nparts; i += 32) {          // (more than 32 partials: the rest, one at a time)
+            for (int i = pgp + NGR * PV; i < p.nparts; i += NGR) {       // (more than 32 partials: the rest, one at a time)
                 const float4 v = *reinterpret_cast<const float4*>(p.part_acc + (long)i * pstride + (long)r * p.E + c4);
                 const float wu = w[2 + i];
                 a.x = fmaf(wu, v.x, a.x); a.y = fmaf(wu, v.y, a.y); a.z = fmaf(wu, v.z, a.z); a.w = fmaf(wu, v.w, a.w);
             }
             const float* wpos = w + 2 + p.nparts;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = pgp + 32 * u;
+            for (int u = 0; u < PE; ++u) {
+                const int j = pgp + NGR * u;
                 const float wu = j < npos ? wpos[j] : 0.f;
                 a.x = fmaf(wu, pev[u].x, a.x); a.y = fmaf(wu, pev[u].y, a.y); a.z = fmaf(wu, pev[u].z, a.z); a.w = fmaf(wu, pev[u].w, a.w);
             }
-            for (int j0 = pgp + 128; j0 < npos; j0 += 128) {         // (more than 128 positional rows: long clips)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = j0 + 32 * u;
-                    if (j < npos) {
-                        const int row = j < p.T ? p.t0i + j : (j < p.T + p.H ? p.y0i + (j - p.T) : p.x0i + (j - p.T - p.H));
-                        const float4 v = *reinterpret_cast<const float4*>(p.pe + (long)row * p.E + c4);
-                        const float wu = wpos[j];
-                        a.x = fmaf(wu, v.x, a.x); a.y = fmaf(wu, v.y, a.y); a.z = fmaf(wu, v.z, a.z); a.w = fmaf(wu, v.w, a.w);
-                    }
-                }
+            for (int j = pgp + NGR * PE; j < npos; j += NGR) {            // (more than 128 positional rows: long clips)
+                const int row = j < p.T ? p.t0i + j : (j < p.T + p.H ? p.y0i + (j - p.T) : p.x0i + (j - p.T - p.H));
+                const float4 v = *reinterpret_cast<const float4*>(p.pe + (long)row * p.E + c4);
+                const float wu = wpos[j];
+                a.x = fmaf(wu, v.x, a.x); a.y = fmaf(wu, v.y, a.y); a.z = fmaf(wu, v.z, a.z); a.w = fmaf(wu, v.w, a.w);
             }
         }
-        *reinterpret_cast<float4*>(cred + rr * 1024 + pgp * 32 + 4 * l4) = a;
+        *reinterpret_cast<float4*>(cred + (rr * NGR + pgp) * CW + 4 * l4) = a;
     }
     __syncthreads();
-    for (int o = tid; o < RG * 32; o += 256) {
-        const int rr = o >> 5, cc = o & 31, r = r0 + rr, c = blockIdx.y * 32 + cc;
+    for (int o = tid; o < RG * CW; o += 256) {
+        const int rr = o / CW, cc = o % CW, r = r0 + rr, c = blockIdx.y * CW + cc;
         if (r < rows && c < p.E) {
             float v = 0.f;
 #pragma unroll
-            for (int g = 0; g < 32; ++g) v += cred[rr * 1024 + g * 32 + cc];
+            for (int g = 0; g < NGR; ++g) v += cred[(rr * NGR + g) * CW + cc];
             if (p.normalize) v /= wrec[rr * rec + 1];
             p.out_acc[(long)r * p.E + c] = v;
         }
@@ -415,9 +419,9 @@ __global__ __launch_bounds__(256) void merge_ctx_apply_kernel(MergeCtxParams p, 
 static void launch_merge_apply(const MergeCtxParams& p, int rows, size_t smem2, hipStream_t s) {
     constexpr int RG = 8;
     const size_t rec = (size_t)2 + p.nparts + p.T + p.H + p.W;
-    const size_t smem = ((size_t)RG * 1024 + RG * rec) * 4;
+    const size_t smem = ((size_t)RG * 16 * 64 + RG * rec) * 4;
     if (smem <= 64 * 1024 && p.scratch && p.pe) {
-        HICOM_LAUNCH(merge_ctx_apply_kernel<RG>, dim3((unsigned)((rows + RG - 1) / RG), (unsigned)((p.E + 31) / 32)), dim3(256), smem, s, p, rows);
+        HICOM_LAUNCH(merge_ctx_apply_kernel<RG>, dim3((unsigned)((rows + RG - 1) / RG), (unsigned)((p.E + 63) / 64)), dim3(256), smem, s, p, rows);
     } else {
         HICOM_LAUNCH(merge_ctx_kernel<2>, dim3((unsigned)rows, (unsigned)((p.E + 31) / 32)), dim3(256), smem2, s, p);
     }

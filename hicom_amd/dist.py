@@ -135,7 +135,8 @@ def exchange(state: torch.Tensor, local_tokens: torch.Tensor, group=None):
 class _ShardSet:
     """One set of exchange buffers + argument blocks + workspaces (two sets alternate so that the all-gather of step i
     can still be reading its send buffer while step i+1 streams into the other one)."""
-    __slots__ = ("mine", "everyone", "a_stream", "a_finish", "ws_stream", "ws_finish", "ev_stream", "ev_tok", "out", "fused", "r0", "direct_ag", "on_comm")
+    __slots__ = ("mine", "everyone", "a_stream", "a_finish", "ws_stream", "ws_finish", "ev_stream", "ev_tok", "out", "fused", "r0", "direct_ag", "on_comm",
+                 "states_all", "tok_direct")
 
 
 class _ShardPlan:
@@ -152,6 +153,8 @@ class _ShardPlan:
                 for f in self.guide_fields:
                     setattr(a, f, guide.data_ptr())
             a.out = out.data_ptr()
+        if st.tok_direct:
+            st.a_finish.ag_recv = out.data_ptr()       # (the token all-gather lands in the output's first world * nw rows)
 
     def release(self):
         """Before the plan's buffers go back to the allocator: everything its comm stream still does with them."""
@@ -290,9 +293,22 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
         # the all-gather enqueued by the FINISH call itself (RCCL through the group's own communicator): one host call per step
         st.on_comm = True
         st.direct_ag = comm_ptr is not None
+        st.states_all, st.tok_direct = None, False
         if st.direct_ag:
-            st.a_finish.ag_fn, st.a_finish.ag_comm = nv.rccl_allgather_fn(), comm_ptr
+            fn_ag, fn_gs, fn_ge = nv.rccl_fns()
+            st.a_finish.ag_fn, st.a_finish.ag_comm = fn_ag, comm_ptr
             st.a_finish.ag_send, st.a_finish.ag_recv, st.a_finish.ag_bytes = st.mine.data_ptr(), st.everyone.data_ptr(), pack.total
+            if not lay.newline_rows and lay.nl_group == 0 and os.environ.get("HICOM_SHARD_PLACE", "0") != "1":
+                # no newline rows: the ranks' token blocks are CONSECUTIVE rows of the output -- the token all-gather writes them there
+                # itself, a second all-gather in the same RCCL group carries the states: no placement launch (a 2.3 x world MB copy on the
+                # comm stream beside the next step's ring kernel; HICOM_SHARD_PLACE=1: the one-buffer form + placement, A/B switch)
+                st.tok_direct = True
+                st.states_all = torch.zeros((world, pack.state_floats), dtype=torch.float32, device=dev)
+                st.a_finish.ag_group_start, st.a_finish.ag_group_end = fn_gs, fn_ge
+                st.a_finish.ag_send, st.a_finish.ag_bytes = st.mine.data_ptr() + pack.tok_off, pack.tok_bytes
+                st.a_finish.ag_send2, st.a_finish.ag_recv2, st.a_finish.ag_bytes2 = st.mine.data_ptr(), st.states_all.data_ptr(), pack.state_bytes
+                st.a_finish.state_sets, st.a_finish.state_set_stride = st.states_all.data_ptr(), pack.state_floats
+                st.a_finish.place_src = None
         plan.sets.append(st)
     plan.sig = engine.weights_sig(projector)
     if len(plans) >= _MAX_SHARD_PLANS:

@@ -132,6 +132,7 @@ class CompressorArgs(C.Structure):
         ("inj_l", Injector), ("inj_g", Injector),
         ("vpe_f16", C.c_void_p), ("marg_slots", C.c_int32),
         ("ag_fn", C.c_void_p), ("ag_comm", C.c_void_p), ("ag_send", C.c_void_p), ("ag_recv", C.c_void_p), ("ag_bytes", C.c_int64),
+        ("ag_group_start", C.c_void_p), ("ag_group_end", C.c_void_p), ("ag_send2", C.c_void_p), ("ag_recv2", C.c_void_p), ("ag_bytes2", C.c_int64),
     ]
 
 
@@ -566,15 +567,20 @@ def compressor_handoff_failures(args: CompressorArgs, stream=None):
     return int(out[0]), int(out[1])
 
 
-def rccl_allgather_fn() -> int:
-    """Address of ncclAllGather in the RCCL that torch has loaded (torch/lib/librccl.so): handed to hicom_compressor_args.ag_fn so that
-    the FINISH call of a frame-sharded step enqueues the collective itself.  libhicom_hip.so does not link RCCL."""
+def rccl_fns():
+    """Addresses of (ncclAllGather, ncclGroupStart, ncclGroupEnd) in the RCCL that torch has loaded (torch/lib/librccl.so): handed to
+    hicom_compressor_args.ag_fn / ag_group_* so that the FINISH call of a frame-sharded step enqueues its collective itself.
+    libhicom_hip.so does not link RCCL."""
     global _RCCL
     if _RCCL is None:
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         L = C.CDLL(path if os.path.exists(path) else "librccl.so")        # (already mapped by torch.distributed: the same instance)
-        _RCCL = C.cast(L.ncclAllGather, C.c_void_p).value
+        _RCCL = tuple(C.cast(getattr(L, n), C.c_void_p).value for n in ("ncclAllGather", "ncclGroupStart", "ncclGroupEnd"))
     return _RCCL
+
+
+def rccl_allgather_fn() -> int:
+    return rccl_fns()[0]
 
 
 _RCCL = None

@@ -780,6 +780,15 @@ typedef struct hicom_compressor_args {
     const void* ag_send;
     void* ag_recv;
     int64_t ag_bytes;
+    /* ... or TWO all-gathers in one RCCL group (ag_group_start / ag_group_end = addresses of ncclGroupStart / ncclGroupEnd): the second
+     * one (ag_send2 -> ag_recv2, ag_bytes2 per rank) carries the shard STATES into a [world][ag_bytes2] buffer (= state_sets), the first
+     * the local token rows STRAIGHT into their rows of the output (ag_recv = out: without newline rows the ranks' blocks are consecutive
+     * rows) -- no placement launch behind the collective (place_src NULL). */
+    void* ag_group_start;
+    void* ag_group_end;
+    const void* ag_send2;
+    void* ag_recv2;
+    int64_t ag_bytes2;
 } hicom_compressor_args;
 
 /* Byte offset, inside the workspace, of the fp16 plane [windows, E] of the local stage's window contexts (the A operand of readout
