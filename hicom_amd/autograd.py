@@ -378,10 +378,10 @@ class _CompressorFn(torch.autograd.Function):
     def backward(ctx, dout):
         ff, fe, guide, nl, ctx16 = ctx.saved_tensors
         need = ctx.needs_input_grad            # (proj, ff, fe, guide, modal, nl, names, *params)
-        if need[1]:
-            raise NotImplementedError("hicom_amd backward: the gradient w.r.t. frames_feature is not built (the tower body is "
-                                      "frozen in every stage of the reference's script, train.py:703); detach it")
         proj = ctx.proj
+        if need[1] and not _ff_grad_supported(proj):
+            raise NotImplementedError("hicom_amd backward: the gradient w.r.t. frames_feature (`pure_vision_model`, reference train.py:712-715) "
+                                      "is built for the direct recipe without adaptors or clip-scale (the release recipe); detach it otherwise")
         want = tuple(bool(need[7 + k]) for k in range(len(ctx.names)))
         args = (proj, ff, fe, guide, ctx.modal, nl, ctx.names, want, bool(need[2]), bool(need[3]), bool(nl is not None and need[5]))
         store = _adaptor_store(proj, ff) if ctx.adapt_serial is not None else None
@@ -398,7 +398,14 @@ class _CompressorFn(torch.autograd.Function):
                 finally:
                     gc.__dict__.pop("_train_store", None)
         gb = getattr(proj, "graph_backward", None)             # None: automatic; False: always eager
-        if gb is None or gb:
+        d_ff = None
+        if need[1]:
+            # d frames_feature (round 6): the eager backward (the tower body trains in no stage of the reference's scripts: not worth a graph)
+            hold = {}
+            with torch.no_grad():
+                res = _backward_outputs(dout, *args, store=store, gstore=gstore, ctx16=ctx16, ff_grad=hold)
+            d_ff = hold["d_ff"]
+        elif gb is None or gb:
             res = _graphed_backward(dout, *args, store=store, gstore=gstore, ctx16=ctx16)
         else:
             with torch.no_grad():
@@ -412,17 +419,32 @@ class _CompressorFn(torch.autograd.Function):
                 n = plist[name].numel()
                 out[k] = flat[o:o + n].view(plist[name].shape)
                 o += n
-        return (None, None, d_fe, d_guide, None, d_nl, None, *out)
+        return (None, d_ff, d_fe, d_guide, None, d_nl, None, *out)
 
 
-def _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl, store=None, gstore=None, ctx16=None):
+def _ff_grad_supported(proj) -> bool:
+    """d frames_feature: both stages inject the guide directly (the release recipe), no adaptors, no clip-scale -- the value-side
+    gradient of the windows is rank-1 per token and the global stage has <= 16 folded rows."""
+    lc, gc = proj.local_compressor, proj.global_compressor
+    if proj.local_logit is not None or proj.global_logit is not None:
+        return False
+    if lc is not None and (lc.use_guide != "direct" or not lc.is_plain or lc.adapt_q or lc.adapt_k or lc.adapt_v):
+        return False
+    if gc is not None and (gc.use_guide != "direct" or not gc.is_plain or gc.attn_layer.num_heads > 16):
+        return False
+    return True
+
+
+def _backward_outputs(dout, proj, ff, fe, guide, modal, nl, names, want, want_fe, want_guide, want_nl, store=None, gstore=None, ctx16=None,
+                      ff_grad=None):
     """({dtype: (flat gradient buffer, [(argument index, parameter name)])}, d frames_embed, d guide_embed, d image_newline) in
     the dtypes autograd hands on.  The parameter gradients leave as views of one buffer cast once (one concatenation + one cast
     instead of a cast per tensor)."""
     global LAST_FP32_GRADS
     grads, d_nl, d_fe, d_guide = compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=want_fe, want_guide=want_guide,
                                                      adaptor_saved=(store.k, store.v) if store is not None else None,
-                                                     global_saved=gstore.bufs if gstore is not None else None, ctx_local16=ctx16)
+                                                     global_saved=gstore.bufs if gstore is not None else None, ctx_local16=ctx16,
+                                                     ff_grad=ff_grad)
     LAST_FP32_GRADS = dict(grads)
     if d_guide is not None:
         LAST_FP32_GRADS["__guide_embed__"] = d_guide
@@ -552,7 +574,7 @@ def _row_index(rows, dev):
 
 
 def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, want_guide=False, adaptor_saved=None, global_saved=None,
-                        stages=("local", "global"), is_anyres=False, ctx_local16=None):
+                        stages=("local", "global"), is_anyres=False, ctx_local16=None, ff_grad=None):
     """(fp32 gradients {parameter name: tensor} of sum(out * dout), d image_newline, d frames_embed (bf16) or None,
     d guide_embed (fp32) or None).  Restates autograd through reference projector.py:524-559 (local), :634-646 + :166-228
     (global) and mm_utils.py:92-140 (packing).  The input gradients exist for the direct recipe only.
@@ -635,7 +657,7 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
             dgh = dgh.reshape(-1, E)
             return ((dgh - gh * (gh * dgh).sum(-1, keepdim=True)) / g_nrm).reshape(guide.shape)
 
-        if want_fe or adapt or query_params or (want_guide and mode is not None) or clip is not None:
+        if want_fe or adapt or query_params or (want_guide and mode is not None) or clip is not None or ff_grad is not None:
             # ---- attention backward of the windows: dq per window, d key stream, d value stream -------------------------
             from . import injector as inj
             exact = all(a.nwin * a.k == a.n for a in (at, ay, ax))
@@ -709,7 +731,15 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
                 if want_fe and fe is not None:
                     d_fe = torch.empty_like(fe)
                 dls = torch.empty((nw,), dtype=torch.float32, device=dev) if clip is not None else None
-                nv.local_attn_bwd(key, ff, axes, q, 0 if mode == "direct" else E, scale, bias, dctx_l, dq_w, d_fe, l2norm_key=l2k, dls=dls)
+                d_ffl = None
+                if ff_grad is not None:
+                    # d frames_feature, local share: dv_n = p_n dctx_w (rank 1 per token, written by the same window backward); without
+                    # frames_embed the keys are these rows too (projector.py:532) and their gradient is added in
+                    if not exact:
+                        raise NotImplementedError("hicom_amd backward: d frames_feature needs an exact window partition")
+                    d_ffl = ff_grad["d_ff"] = torch.empty_like(ff)
+                nv.local_attn_bwd(key, ff, axes, q, 0 if mode == "direct" else E, scale, bias, dctx_l, dq_w, d_fe, l2norm_key=l2k, dls=dls,
+                                  dvalue=d_ffl, value_is_key=(d_ffl is not None and fe is None))
                 if clip is not None:
                     grads["local_logit_scale"] = dls.sum().reshape(1)       # d s_i / d ls = s_i - lb
                     grads["local_logit_bias"] = torch.zeros(1, dtype=torch.float32, device=dev)   # a shift of a window's logits: softmax cancels it
@@ -781,7 +811,7 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
             nv.linear(dctx, pe, None, pos_b, M=R)
         nparts = nv.global_stream_nparts(N, rows_pad)
         part = torch.empty((nparts, rows_pad, E), dtype=torch.float32, device=dev)
-        in_kernel = pe is not None and nv.global_stream_has_marg(N, E, rows_pad, H, W, nparts)
+        in_kernel = pe is not None and nv.global_stream_has_marg(N, E, rows_pad, H, W, nparts) and ff_grad is None   # (d frames_feature reads dS)
         if in_kernel:
             # many rows: the stream kernel leaves the t / y / x marginals of dS per token chunk -- the [rows, N] dS tensor is never written
             pm = torch.empty((nparts, rows_pad, nv.global_stream_marg_width(H, W)), dtype=torch.float32, device=dev)
@@ -794,6 +824,15 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
             ds = torch.empty_like(scores)
             nv.global_stream_bwd(ff.view(N, E), N, dhi, dlo, pos_b, H if pe is not None else 1, W if pe is not None else N,
                                  t0i, y0i, x0i, scores, ml, delta, ds, part, R)
+            if ff_grad is not None:
+                # d frames_feature, global share: d x_n = sum_r dS[r, n] qt_r + p[r, n] dctx_r (scores and values are both x in the folded
+                # form; the positional terms do not depend on x), added to the local stage's share
+                qp_ = (q_in.float() @ Wq.t() + bq).view(nq, nh, hd)
+                qt_ = (att.scale * torch.einsum("hje,qhj->qhe", Wk.view(nh, hd, E), qp_)).reshape(R, E).contiguous()
+                have = ff_grad.get("d_ff") is not None
+                if not have:
+                    ff_grad["d_ff"] = torch.empty_like(ff)
+                nv.global_dx(scores, ds, ml, qt_, dctx, N, ff_grad["d_ff"].view(N, E), accumulate=have)
             if pe is not None:
                 dS = ds[:R, :N].view(R, T, H, W)
                 mT, mY, mX = dS.sum((2, 3)), dS.sum((1, 3)), dS.sum((1, 2))

@@ -421,6 +421,11 @@ struct LocalBwdParams {
     // dls[w] = sum_i dS_i (s_i - lb) per window (d lb = sum_i dS_i = 0 exactly: the softmax cancels a shift).
     int l2norm_key;
     float* dls;            // [Nw] or NULL
+    // d VALUE stream (round 6: d frames_feature, reference train.py:712-715 `pure_vision_model` trains the tower body): dv_i = p_i dctx_w,
+    // bf16 [N, D], plain stores (exact partition) -- or NULL.  value_is_key (frames_embed is None: the keys ARE the value rows,
+    // projector.py:532): the key-side gradient of the same row is added in, d x_i = p_i dctx_w + dk_i.
+    uint16_t* dvalue;
+    int value_is_key;
 };
 
 template <int NV>
@@ -434,7 +439,8 @@ __global__ __launch_bounds__(256) void local_attn_bwd_kernel(LocalBwdParams p) {
     float* dp = lsm + WP;                         // [WIN] dP
     float* rin = lsm + 2 * WP;                    // [WIN] 1 / ||k_i|| (1 without l2norm_key)
     float* sraw = lsm + 3 * WP;                   // [WIN] q . khat_i
-    float* part = lsm + 4 * WP;                   // [4][D] partial dq
+    float* pwt = lsm + 4 * WP;                    // [WIN] softmax weights p_i
+    float* part = lsm + 5 * WP;                   // [4][D] partial dq
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int win = blockIdx.x;
@@ -516,9 +522,10 @@ __global__ __launch_bounds__(256) void local_attn_bwd_kernel(LocalBwdParams p) {
     if (wave == 0) {
         float dl = 0.f;
         for (int i = lane; i < WIN; i += 64) {
-            const float s_i = sc[i], dS = expf(s_i - mx) * inv_sum * (dp[i] - delta);
+            const float s_i = sc[i], pi_ = expf(s_i - mx) * inv_sum, dS = pi_ * (dp[i] - delta);
             dl = fmaf(dS, s_i - p.bias, dl);
             sc[i] = dS;
+            pwt[i] = pi_;
         }
         if (p.dls) {
             dl = wave_sum_fast(dl);
@@ -558,6 +565,24 @@ __global__ __launch_bounds__(256) void local_attn_bwd_kernel(LocalBwdParams p) {
                         float e[6];
 #pragma unroll
                         for (int j = 0; j < 6; ++j) e[j] = fmaf(dsk, q[s][j], -kc * k[u][s][j]);
+                        Seg12 w;
+                        w.a = f32_to_bf16(e[0]) | ((uint32_t)f32_to_bf16(e[1]) << 16);
+                        w.b = f32_to_bf16(e[2]) | ((uint32_t)f32_to_bf16(e[3]) << 16);
+                        w.c = f32_to_bf16(e[4]) | ((uint32_t)f32_to_bf16(e[5]) << 16);
+                        *reinterpret_cast<Seg12*>(o + 384 * s + 6 * lane) = w;
+                    }
+                }
+                if (p.dvalue) {
+                    uint16_t* o = p.dvalue + token_of(i) * D;
+                    const float pi_ = pwt[i];
+#pragma unroll
+                    for (int s = 0; s < NV; ++s) {
+                        float e[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            e[j] = pi_ * g[s][j];
+                            if (p.value_is_key) e[j] += fmaf(dsk, q[s][j], -kc * k[u][s][j]);
+                        }
                         Seg12 w;
                         w.a = f32_to_bf16(e[0]) | ((uint32_t)f32_to_bf16(e[1]) << 16);
                         w.b = f32_to_bf16(e[2]) | ((uint32_t)f32_to_bf16(e[3]) << 16);
@@ -1158,7 +1183,7 @@ extern "C" int hicom_local_attn_bwd(const void* key, const void* value, int32_t 
                                     hicom_axis at, hicom_axis ay, hicom_axis ax,
                                     const void* query, int32_t query_dt, int64_t query_stride,
                                     float scale, float bias, const float* dctx, float* dq, void* dkey,
-                                    int32_t l2norm_key, float* dls, void* stream) {
+                                    int32_t l2norm_key, float* dls, void* dvalue, int32_t value_is_key, void* stream) {
     HICOM_REQUIRE(key && value && query && dctx && dq, HICOM_EINVAL, "local_attn_bwd: NULL pointer");
     HICOM_REQUIRE(D == 1152 || D == 768, HICOM_EUNSUP, "local_attn_bwd: D=%d (only 1152 / 768)", D);
     HICOM_REQUIRE(query_dt == HICOM_DT_BF16 || query_dt == HICOM_DT_F32, HICOM_EINVAL, "local_attn_bwd: query dtype");
@@ -1168,15 +1193,16 @@ extern "C" int hicom_local_attn_bwd(const void* key, const void* value, int32_t 
         const int last = axis_start(*a, a->nwin - 1);
         HICOM_REQUIRE(last >= 0 && last + a->k <= a->n, HICOM_EINVAL, "local_attn_bwd: window runs off the axis");
         // dkey is written with plain stores: windows must not overlap
-        if (dkey) HICOM_REQUIRE((long)a->nwin * a->k == a->n, HICOM_EUNSUP, "local_attn_bwd: dkey needs an exact window partition (n=%d k=%d)", a->n, a->k);
+        if (dkey || dvalue) HICOM_REQUIRE((long)a->nwin * a->k == a->n, HICOM_EUNSUP, "local_attn_bwd: dkey / dvalue need an exact window partition (n=%d k=%d)", a->n, a->k);
     }
     const long win = (long)at.k * ay.k * ax.k;
     HICOM_REQUIRE(win <= 4096, HICOM_EUNSUP, "local_attn_bwd: window of %ld tokens is too large", win);
     const long nwin = (long)at.nwin * ay.nwin * ax.nwin;
     HICOM_REQUIRE(nwin < (1L << 31), HICOM_EINVAL, "local_attn_bwd: too many windows");
     LocalBwdParams p{(const uint16_t*)key, (const uint16_t*)value, query, query_dt == HICOM_DT_F32, (long)query_stride, at, ay, ax,
-                     scale, bias, dctx, dq, (uint16_t*)dkey, l2norm_key ? 1 : 0, dls};
-    const size_t smem = 4 * (((size_t)win + 3) & ~(size_t)3) * 4 + 4 * (size_t)D * 4;
+                     scale, bias, dctx, dq, (uint16_t*)dkey, l2norm_key ? 1 : 0, dls, (uint16_t*)dvalue, value_is_key ? 1 : 0};
+    HICOM_REQUIRE(!(value_is_key && dkey), HICOM_EINVAL, "local_attn_bwd: value_is_key writes the summed gradient to dvalue (dkey must be NULL)");
+    const size_t smem = 5 * (((size_t)win + 3) & ~(size_t)3) * 4 + 4 * (size_t)D * 4;
     hipStream_t s = (hipStream_t)stream;
     if (D == 1152) hipLaunchKernelGGL(local_attn_bwd_kernel<3>, dim3((unsigned)nwin), dim3(256), smem, s, p);
     else hipLaunchKernelGGL(local_attn_bwd_kernel<2>, dim3((unsigned)nwin), dim3(256), smem, s, p);

@@ -445,6 +445,69 @@ __global__ __launch_bounds__(256) void partials_sum_tall_kernel(const float* par
 
 using namespace hicom;
 
+// d frames_feature of the global stage (direct recipe: <= 16 folded rows).  A workgroup takes 64 tokens; thread t owns channels
+// 4t .. 4t+3 with the 2 * rows coefficient rows (qt | dctx) of those channels in registers and walks the tokens: per token 2 * rows
+// broadcast LDS reads of the coefficients (dS, p), 8 * rows FMAs, one 8-byte store.
+template <int RMAX>
+__global__ __launch_bounds__(320) void global_dx_kernel(const float* S, const float* dS, long stride, const float* ml, const float* qt, const float* dctx,
+                                                          int rows, long N, int E, uint16_t* dx, int accumulate) {
+    __shared__ float coef[64][2 * RMAX];
+    const int tid = threadIdx.x;
+    const long n0 = (long)blockIdx.x * 64;
+    for (int idx = tid; idx < 64 * rows; idx += blockDim.x) {
+        const int r = idx / 64, t = idx - r * 64;
+        const long n = n0 + t;
+        float a = 0.f, b = 0.f;
+        if (n < N) {
+            a = dS[(long)r * stride + n];
+            b = expf(S[(long)r * stride + n] - ml[2 * r]) / ml[2 * r + 1];
+        }
+        coef[t][r] = a;
+        coef[t][RMAX + r] = b;
+    }
+    const int c4 = 4 * tid;
+    float4 wq[RMAX], wd[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        wq[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        wd[r] = wq[r];
+        if (r < rows && c4 < E) {
+            wq[r] = *reinterpret_cast<const float4*>(qt + (long)r * E + c4);
+            wd[r] = *reinterpret_cast<const float4*>(dctx + (long)r * E + c4);
+        }
+    }
+    __syncthreads();
+    if (c4 >= E) return;
+    for (int t = 0; t < 64 && n0 + t < N; ++t) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint16_t* o = dx + (n0 + t) * (long)E + c4;
+        if (accumulate) {
+            const uint2 old = *reinterpret_cast<const uint2*>(o);
+            a = make_float4(bf16lo_to_f32(old.x), bf16hi_to_f32(old.x), bf16lo_to_f32(old.y), bf16hi_to_f32(old.y));
+        }
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const float ca = coef[t][r], cb = coef[t][RMAX + r];
+            a.x = fmaf(ca, wq[r].x, a.x); a.y = fmaf(ca, wq[r].y, a.y); a.z = fmaf(ca, wq[r].z, a.z); a.w = fmaf(ca, wq[r].w, a.w);
+            a.x = fmaf(cb, wd[r].x, a.x); a.y = fmaf(cb, wd[r].y, a.y); a.z = fmaf(cb, wd[r].z, a.z); a.w = fmaf(cb, wd[r].w, a.w);
+        }
+        *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)f32_to_bf16(a.x) | ((unsigned)f32_to_bf16(a.y) << 16),
+                                                  (unsigned)f32_to_bf16(a.z) | ((unsigned)f32_to_bf16(a.w) << 16));
+    }
+}
+
+extern "C" int hicom_global_dx_fwd(const float* S, const float* dS, int64_t score_stride, const float* ml, const float* qt, const float* dctx,
+                                   int32_t rows, int64_t N, int32_t E, void* dx, int32_t accumulate, void* stream) {
+    HICOM_REQUIRE(S && dS && ml && qt && dctx && dx, HICOM_EINVAL, "global_dx: NULL pointer");
+    HICOM_REQUIRE(rows > 0 && rows <= 16 && N > 0 && E > 0 && E % 4 == 0 && E <= 1280 && score_stride >= N && ((uintptr_t)dx % 8 == 0) &&
+                      ((uintptr_t)qt % 16 == 0) && ((uintptr_t)dctx % 16 == 0), HICOM_EUNSUP,
+                  "global_dx: rows=%d (<= 16: the direct recipe's folded rows), E=%d (<= 1280, %% 4)", rows, E);
+    const unsigned grid = (unsigned)((N + 63) / 64);
+    if (rows <= 9) hipLaunchKernelGGL(global_dx_kernel<9>, dim3(grid), dim3(320), 0, (hipStream_t)stream, S, dS, (long)score_stride, ml, qt, dctx, rows, (long)N, E, (uint16_t*)dx, accumulate);
+    else hipLaunchKernelGGL(global_dx_kernel<16>, dim3(grid), dim3(320), 0, (hipStream_t)stream, S, dS, (long)score_stride, ml, qt, dctx, rows, (long)N, E, (uint16_t*)dx, accumulate);
+    return hicom_host::check_launch("global_dx");
+}
+
 // 16-bit <-> 16-bit cast of a contiguous tensor: fp16 -> bf16 (round to nearest even: the boundary accepts fp16 modules and inputs -- the
 // reference's inference default, inference_video_mcqa_videomme.py:323 -- and runs them on the bf16 kernels) and bf16 -> fp16 (saturating:
 // the result of such a call).  Eight elements per thread, 16-byte accesses.

@@ -27,7 +27,7 @@ EXPORTS = (
     "hicom_global_stream_nparts", "hicom_global_merge_fwd", "hicom_global_combine_fwd",
     "hicom_readout_gemm_fwd", "hicom_scatter_rows_fwd", "hicom_fold_query_split_fwd",
     "hicom_global_combine_strided_fwd", "hicom_compressor_workspace_bytes", "hicom_compressor_zero_prefix_bytes", "hicom_compressor_is_fused",
-    "hicom_compressor_fwd2", "hicom_compressor_takes_shard4", "hicom_compressor_handoff_failures", "hicom_cast16_fwd",
+    "hicom_compressor_fwd2", "hicom_compressor_takes_shard4", "hicom_compressor_handoff_failures", "hicom_cast16_fwd", "hicom_global_dx_fwd",
     "hicom_compressor_fwd", "hicom_linear_to_rows_fwd", "hicom_fused_stream_fwd", "hicom_fused_stream_nparts",
     "hicom_planes_gemm_fwd", "hicom_row_ln_fwd", "hicom_small_mha_fwd", "hicom_place_blocks_fwd",
     "hicom_global_stream_bwd", "hicom_readout16_gemm_fwd", "hicom_to_f16_fwd", "hicom_merge_vproj_fwd",
@@ -157,7 +157,8 @@ def lib() -> C.CDLL:
         raise HicomNativeError(f"ABI mismatch: library {L.hicom_abi_version()} vs binding {ABI_VERSION}; rebuild")
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     L.hicom_local_attn_fwd.argtypes = [vp, i32, vp, i32, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32, i32, vp, vp, vp]
-    L.hicom_local_attn_bwd.argtypes = [vp, vp, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32, vp, vp, vp, i32, vp, vp]
+    L.hicom_local_attn_bwd.argtypes = [vp, vp, i32, Axis, Axis, Axis, vp, i32, i64, f32, f32, vp, vp, vp, i32, vp, vp, i32, vp]
+    L.hicom_global_dx_fwd.argtypes = [vp, vp, i64, vp, vp, vp, i32, i64, i32, vp, i32, vp]
     L.hicom_trilinear_pool_fwd.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.hicom_linear_fwd.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.hicom_fold_query_fwd.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp]
@@ -378,13 +379,22 @@ def colsum(x_bf16, nparts=128):
     return out
 
 
-def local_attn_bwd(key, value, axes, query, query_stride, scale, bias, dctx, dq, dkey=None, l2norm_key=False, dls=None):
-    """l2norm_key / dls: clip-scale on the local stage -- key rows L2-normalised, dls f32 [Nw] = per-window share of d logit_scale."""
+def local_attn_bwd(key, value, axes, query, query_stride, scale, bias, dctx, dq, dkey=None, l2norm_key=False, dls=None, dvalue=None,
+                   value_is_key=False):
+    """l2norm_key / dls: clip-scale on the local stage -- key rows L2-normalised, dls f32 [Nw] = per-window share of d logit_scale.
+    dvalue bf16 [T,H,W,D]: gradient w.r.t. the value stream (value_is_key: the key-side gradient of the same rows is added in)."""
     D = value.shape[-1]
     assert key.dtype == torch.bfloat16 and value.dtype == torch.bfloat16 and dctx.dtype == torch.float32 and dq.dtype == torch.float32
     _check(lib().hicom_local_attn_bwd(_ptr(key), _ptr(value), D, axes[0], axes[1], axes[2], _ptr(query), _dt(query), query_stride,
-                                      scale, bias, _ptr(dctx), _ptr(dq), _ptr(dkey), int(bool(l2norm_key)), _ptr(dls), _stream()),
-           "hicom_local_attn_bwd")
+                                      scale, bias, _ptr(dctx), _ptr(dq), _ptr(dkey), int(bool(l2norm_key)), _ptr(dls), _ptr(dvalue),
+                                      int(bool(value_is_key)), _stream()), "hicom_local_attn_bwd")
+
+
+def global_dx(S, dS, ml, qt, dctx, N, dx, accumulate):
+    """d frames_feature of the global stage, direct recipe: dx[n] (+)= sum_r dS[r, n] qt[r] + softmax(S)[r, n] dctx[r] (hicom_global_dx_fwd)."""
+    rows, E = qt.shape
+    _check(lib().hicom_global_dx_fwd(_ptr(S), _ptr(dS), S.shape[1], _ptr(ml), _ptr(qt), _ptr(dctx), rows, N, E, _ptr(dx), int(bool(accumulate)),
+                                     _stream()), "hicom_global_dx_fwd")
 
 
 def trilinear_pool(x, out):

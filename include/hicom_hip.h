@@ -129,7 +129,17 @@ int hicom_local_attn_bwd(const void* key, const void* value, int32_t D,
                          hicom_axis at, hicom_axis ay, hicom_axis ax,
                          const void* query, int32_t query_dt, int64_t query_stride,
                          float scale, float bias, const float* dctx, float* dq, void* dkey,
-                         int32_t l2norm_key, float* dls, void* stream);
+                         int32_t l2norm_key, float* dls, void* dvalue, int32_t value_is_key, void* stream);
+/* (dvalue, ABI 15: bf16 [T,H,W,D] = p_i dctx_w, the gradient w.r.t. the VALUE stream frames_feature, or NULL; value_is_key: the keys are
+ * the value rows -- frames_embed None, projector.py:532 -- and the key-side gradient is added into dvalue, dkey NULL.)
+ *
+ * d frames_feature of the GLOBAL stage, direct recipe (<= 16 folded rows), from the tensors the attention backward leaves:
+ *   dx[n, :] (+)= sum_r dS[r, n] qt[r, :] + exp(S[r, n] - M_r) / L_r dctx[r, :]
+ * S = the forward's logits, dS = hicom_global_stream_bwd's ds_out (both f32 [rows_pad, score_stride]), ml f32 [rows][2], qt / dctx f32
+ * [rows, E] (folded queries incl. the attention scale; upstream gradients of the per-head contexts), dx bf16 [N, E]; accumulate != 0:
+ * dx already holds the local stage's share (read, added in fp32, written back).  The positional terms do not depend on x. */
+int hicom_global_dx_fwd(const float* S, const float* dS, int64_t score_stride, const float* ml, const float* qt, const float* dctx,
+                        int32_t rows, int64_t N, int32_t E, void* dx, int32_t accumulate, void* stream);
 
 /* ---- pooled per-window query: F.interpolate(..., 'trilinear', align_corners=False) --------
  * Replaces projector.py:539-540.  x bf16 [T,H,W,D] -> out f32 [t',h',w',D]. */

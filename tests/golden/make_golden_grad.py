@@ -109,10 +109,37 @@ def clip_local_grads(proj, blobs3):
               sum(1 for _, gr in items if gr is not None), "/", len(items))
 
 
+FF_GRAD_CASES = ["G1_direct_T8", "G9_local_only", "G9_global_only", "G4_direct_T1", "G10_peaky_direct", "G12_clip768_direct"]
+
+
+def ff_grads(proj, blobs3):
+    """d frames_feature of the direct recipe (`pure_vision_model` trains the tower body, reference train.py:712-715): the reference's
+    autograd with frames_feature as a leaf (frames_embed and the guide leaves too, so that every input gradient of one backward is
+    on record), loss = sum(out * R) with the case's usual cotangent."""
+    for name in FF_GRAD_CASES:
+        case = cases.build_case(name)
+        torch.manual_seed(0)
+        module = proj.build_vision_projector(case.cfg).float().train()
+        module.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd.items()}, strict=True)
+        t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))
+        ff, fe, g = t(case.ff).clone().requires_grad_(True), t(case.fe).clone().requires_grad_(True), t(case.g).clone().requires_grad_(True)
+        out = module(ff, fe, g, case.modal, None)
+        (out * torch.from_numpy(cotangent(name, out.shape))).sum().backward()
+        store(blobs3, name, [("__frames_feature__", ff.grad)])
+        # ... and with frames_embed = None (the keys are the value rows, projector.py:532)
+        ff2 = t(case.ff).clone().requires_grad_(True)
+        module.zero_grad()
+        out2 = module(ff2, None, t(case.g), case.modal, None)
+        (out2 * torch.from_numpy(cotangent(name, out2.shape))).sum().backward()
+        store(blobs3, name + "@nofe", [("__frames_feature__", ff2.grad)])
+        print(name, "d frames_feature max", float(ff.grad.abs().max()), " without frames_embed", float(ff2.grad.abs().max()))
+
+
 def main():
     proj, _ = ref_shim.load()
     blobs3 = {}
     clip_local_grads(proj, blobs3)
+    ff_grads(proj, blobs3)
     blobs = {}
     blobs2 = {}     # golden_grad_v2.npz: d frames_embed of the recipes that do NOT inject the guide (guide off: frames_embed are the window
     #                 keys), and the parameter gradients of anyres dict inputs

@@ -178,6 +178,38 @@ def test_clip_scale_local_gradients_match_reference_autograd(name):
     assert abs(float(m.local_logit_scale.grad)) > 1e-3                      # (a real number, not a placeholder)
 
 
+@pytest.mark.parametrize("name", ["G1_direct_T8", "G9_local_only", "G9_global_only", "G4_direct_T1", "G10_peaky_direct", "G12_clip768_direct"])
+@pytest.mark.parametrize("with_fe", [True, False])
+def test_frames_feature_gradient_matches_reference_autograd(name, with_fe):
+    """Round 6 (verdict r5 missing #3): d frames_feature -- `pure_vision_model` trains the tower body (reference train.py:712-715) -- for the
+    direct recipe: the value-side gradient of the windows (p_n dctx_w, out of the window backward kernel; without frames_embed the
+    key-side gradient of the same rows too, projector.py:532) plus the global stage's sum_r dS[r, n] qt_r + p[r, n] dctx_r
+    (hicom_global_dx_fwd).  Against the reference's own autograd (golden_grad_v3.npz), bf16 result: 2^-7 of the largest entry + the
+    gradient tolerance; the parameter gradients of the same backward are unchanged (bit-equal to a backward without the input gradient)."""
+    import make_golden_grad as mg
+    z = np.load(os.path.join(ROOT, "tests", "golden", "golden_grad_v3.npz"))
+    key = name + ("" if with_fe else "@nofe")
+    want, (s, sabs, mx) = z[f"{key}/__frames_feature__/samples"], z[f"{key}/__frames_feature__/sums"]
+    case = cases.build_case(name)
+    m = build_module(case).train()
+    ff, fe, g = dev_bf16(case.ff).requires_grad_(True), (dev_bf16(case.fe) if with_fe else None), dev_bf16(case.g)
+    out = m(ff, fe, g, case.modal, None)
+    R = torch.from_numpy(mg.cotangent(name, out.shape)).cuda()
+    (out * R).sum().backward()
+    assert ff.grad is not None and ff.grad.shape == ff.shape and ff.grad.dtype == ff.dtype
+    got = ff.grad.float().reshape(-1)[torch.from_numpy(mg.sample_positions(ff.numel())).cuda()].cpu().numpy()
+    tol = 2e-3 * mx + 1e-6
+    assert np.abs(got - want).max() <= 2 ** -7 * mx + tol, (float(np.abs(got - want).max()), mx)
+    assert abs(float(ff.grad.double().sum()) - s) <= 2e-2 * sabs + 1e-6
+    pg = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad(set_to_none=True)
+    out2 = m(ff.detach(), fe, g, case.modal, None)
+    (out2 * R).sum().backward()
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, pg[n]), n
+
+
 def test_unsupported_recipes_and_input_grads_refuse():
     """clip-scale on the GLOBAL stage has no backward (the local stage's: round 6, test above); the gradient w.r.t. frames_feature (frozen tower body) is not built, nor is d frames_embed over
     overlapping windows: all must raise, never return a detached tensor or a silent None.  (Guide off: d frames_embed exists since
@@ -191,7 +223,7 @@ def test_unsupported_recipes_and_input_grads_refuse():
     m.set_clip_logits(local=case.logit["local"], glob=case.logit["glob"])
     with pytest.raises(NotImplementedError):
         m(dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g), case.modal, None)
-    for name, which in (("G1_direct_T8", "ff"), ("G3_direct_T7", "fe")):
+    for name, which in (("G2_off_T8", "ff"), ("G3_direct_T7", "fe"), ("G3_direct_T7", "ff"), ("G5_adaptkv", "ff")):
         case = cases.build_case(name)
         m = build_module(case).train()
         t = {"ff": dev_bf16(case.ff), "fe": dev_bf16(case.fe), "g": dev_bf16(case.g)}
