@@ -420,7 +420,10 @@ static void launch_merge_apply(const MergeCtxParams& p, int rows, size_t smem2, 
     constexpr int RG = 8;
     const size_t rec = (size_t)2 + p.nparts + p.T + p.H + p.W;
     const size_t smem = ((size_t)RG * 16 * 64 + RG * rec) * 4;
-    if (smem <= 64 * 1024 && p.scratch && p.pe) {
+    // (the many-row stage: >= 64 rows of <= 32 partials each.  Few rows of many partials -- the direct recipe's 9 rows x 256 partials in the
+    // training path -- keep MODE 2: 324 workgroups with eight partial rows in flight per thread; this kernel would run them on 36
+    // workgroups, one partial at a time behind the first two: 84 us instead of 9)
+    if (smem <= 64 * 1024 && p.scratch && p.pe && rows >= 64 && p.nparts <= 32) {
         HICOM_LAUNCH(merge_ctx_apply_kernel<RG>, dim3((unsigned)((rows + RG - 1) / RG), (unsigned)((p.E + 63) / 64)), dim3(256), smem, s, p, rows);
     } else {
         HICOM_LAUNCH(merge_ctx_kernel<2>, dim3((unsigned)rows, (unsigned)((p.E + 31) / 32)), dim3(256), smem2, s, p);

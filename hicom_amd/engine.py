@@ -11,6 +11,7 @@ hicom_arch.py:162-164) therefore pays one ctypes call per forward, not a plan bu
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -227,8 +228,10 @@ def build_args(proj, ff, fe, guide_embed, modal, image_newline, out, layout, *, 
             a.t_index0, a.y_index0, a.x_index0 = t_offset, cap, cap + H
             keep += [pe, kpe, pe_hi, pe_lo]
             a.vpe_f16, a.marg_slots = None, 0
-            if a.gc0 and lc is not None and t_offset == 0 and state_out is None:
-                # release step: the value-side pos-emb in the merge role (v_proj . pe^T, weight-only) instead of behind the ring's token stream
+            if a.gc0 and lc is not None and t_offset == 0 and state_out is None and os.environ.get("HICOM_RING_MARG", "0") == "1":
+                # release step, opt-in (measured a net loss): the value-side pos-emb in the merge role (v_proj . pe^T,
+                # weight-only) instead of behind the ring's token stream.  The table is only built -- and rebuilt by every training
+                # step's refresh -- when the switch is on.
                 vpe = gc.vpe_f16(T, H, W, ff.device)
                 if vpe is not None:
                     a.vpe_f16, a.marg_slots = vpe.data_ptr(), vpe.shape[1]
