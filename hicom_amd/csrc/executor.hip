@@ -460,7 +460,15 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
             const char* e = getenv("HICOM_TAIL_LAUNCHES");
             tail_env = (e && e[0] == '5') ? 5 : (e && e[0] == '3') ? 3 : 4;
         }
-        const bool tail4 = single && tail5 && ro2_aux && tail_env <= 4;
+        // Round 6: the chain role takes hidden layers up to 4096 wide (the 7B model's 3584: readout16.hip, BIG form): the fifth launch of
+        // that width (the last global layer, a 25.7-MB GEMV) then rides under GEMM 2 -- where GEMM 2 is long enough to hide a role that
+        // pulls 750 KB per CU in seven round trips (~40 us): 64 frames at hidden 3584: 153.1 -> 145.2 us; at 32 frames (BASELINE
+        // configs[3]: GEMM 2 ~25 us) the role becomes the launch's critical path and gives the 8 us back (95.7 against 95.9 us), so
+        // that shape keeps round 5's form.  HICOM_CHAIN_WIDE=0 / =1: never / always (A/B switch).
+        static const int chain_wide_env = getenv("HICOM_CHAIN_WIDE") ? (getenv("HICOM_CHAIN_WIDE")[0] == '0' ? 0 : 1) : -1;
+        const bool chain_wide = chain_wide_env == 1 || (chain_wide_env < 0 && w.nw >= 1000);
+        const bool chain_ok = tail5 && (a.hidden <= 1536 || (chain_wide && a.hidden <= 4096 && a.hidden % 8 == 0));
+        const bool tail4 = single && tail5 && chain_ok && tail_env <= 4;
         // Round 6: the value-side pos-emb OUT of the ring kernel (marginals out, no pe tiles behind the token stream) and into the merge ROLE
         // of GEMM 1's launch as a product with the weight-only table v_proj . pe^T (merge_item.hpp) -- the round-4 / round-5 verdicts' lever.
         // Built, parity-green, bit-stable, MEASURED: the ring kernel gains 0.4-1.2 us, GEMM 1's launch loses 1.1-1.4 us (the
@@ -591,7 +599,7 @@ extern "C" int hicom_compressor_fwd(const hicom_compressor_args* ap) {
             if (a.nl_count > 0 && !a.local_out)
                 CHK(hicom_scatter_rows_fwd(a.newline, a.newline_dt, 1, a.hidden, a.out, a.out_dt, a.ldo, a.nl_first, a.nl_step,
                                            0, a.nl_count, sm));
-            if (!ro2_aux)
+            if (!ro2_aux && !tail4)
                 CHK(hicom_linear_to_rows_fwd(F(w.hid_g), HICOM_DT_F32, a.gw2, HICOM_DT_BF16, a.gb2, HICOM_DT_BF16, a.nq, a.hidden,
                                              a.hidden, HICOM_ACT_NONE, a.out, a.out_dt, a.ldo, a.global_row0, a.n_global_rows, sm));
             if (a.defer_join && a.ev_join && !join_folded)      // (a deferred call's completion event: everything is on the main stream here)

@@ -254,9 +254,14 @@ typedef __attribute__((address_space(1))) unsigned int r16_gu32;
 constexpr int kChainStateHead = 256;              // state words (arrival counter: an atomic per role workgroup) on lines of their own, granules behind
 constexpr int kChainLds = 160 * 1024, kChainVec = 1536 * 4, kChainBias = 2 * 256 * 4, kChainOut = 256 * 4;
 constexpr int kChainW2Max = 40 * 1024;             // second-layer rows resident per batch (all of a workgroup's at the release shape: 16 x 1792 B)
+// Round 6: hidden layers up to 4096 wide (the 7B model's 3584, BASELINE configs[3]): the vector area holds 4096 floats, a lane sweeps up to
+// 16 granules, a second-layer row is up to 8 KB.  The first batch of second-layer rows is prefetched as before; once the first layer is
+// through, its weight region is free and the later batches take both regions (19 rows of 7 KB instead of 5 per round trip).
+constexpr int kChainBigN = 4096, kChainVecBig = kChainBigN * 4;
 
 struct ChainGeom { int cpw1, cpw2, r1, r2; long row1, row2; };
 __host__ __device__ inline long chain_pad1k(long b) { return (b + 1023) & ~1023L; }
+__host__ __device__ inline int chain_vec_bytes(int N1) { return N1 > 1536 ? kChainVecBig : kChainVec; }
 __host__ __device__ inline ChainGeom chain_geom(int N1, int K1, bool w1f32, int N2, int an) {
     ChainGeom g;
     g.cpw1 = (N1 + an - 1) / an;
@@ -265,7 +270,7 @@ __host__ __device__ inline ChainGeom chain_geom(int N1, int K1, bool w1f32, int 
     g.row2 = (long)N1 * 2;
     g.r2 = (int)(kChainW2Max / g.row2) < g.cpw2 ? (int)(kChainW2Max / g.row2) : g.cpw2;
     // (a batch lands in whole 1-KB pieces: each region is rounded up to the piece size, so a tail piece never reaches the next region)
-    const long left = kChainLds - kChainVec - kChainBias - kChainOut - chain_pad1k((long)g.r2 * g.row2) - 1024;
+    const long left = kChainLds - chain_vec_bytes(N1) - kChainBias - kChainOut - chain_pad1k((long)g.r2 * g.row2) - 1024;
     g.r1 = (int)(left / g.row1) < g.cpw1 ? (int)(left / g.row1) : g.cpw1;
     return g;
 }
@@ -283,9 +288,11 @@ struct ChainNoMid {
     __device__ __forceinline__ void reduce() {}                                // (the mid work itself, up to this workgroup's arrival at the gate)
     __device__ __forceinline__ bool wait() { return false; }                   // (the gate; returns whether x must be treated as lost)
 };
-template <bool W1F32, class Mid>
+template <bool W1F32, class Mid, bool BIG = false>
 __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int an, char* lds, Mid& mid) {
     constexpr bool kGated = !std::is_same<Mid, ChainNoMid>::value;
+    constexpr int XV = BIG ? kChainBigN : 1536;                       // floats of the vector area (x, later h)
+    static_assert(!(BIG && kGated), "the gated (fused tail) form takes the release widths only");
     const AuxGemv& g1 = p.aux;
     const AuxGemv& g2 = p.aux2;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -294,11 +301,11 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
     ChainGeom cg;                                                     // (host-computed: four integer divisions off the role's critical path)
     cg.cpw1 = p.cg_cpw1; cg.cpw2 = p.cg_cpw2; cg.r1 = p.cg_r1; cg.r2 = p.cg_r2;
     cg.row1 = (long)g1.K * (W1F32 ? 4 : 2); cg.row2 = (long)g1.N * 2;
-    float* xl = reinterpret_cast<float*>(lds);                       // [1536] x, later h
-    float* bl1 = xl + 1536;                                          // [256] first-layer biases of this workgroup's columns
+    float* xl = reinterpret_cast<float*>(lds);                       // [XV] x, later h
+    float* bl1 = xl + XV;                                            // [256] first-layer biases of this workgroup's columns
     float* bl2 = bl1 + 256;                                          // [256] second-layer biases
     float* yl = bl2 + 256;                                           // [256] second-layer results of this workgroup
-    char* w2l = lds + kChainVec + kChainBias + kChainOut;            // [r2][row2]
+    char* w2l = lds + XV * 4 + kChainBias + kChainOut;               // [r2][row2]
     char* w1l = w2l + chain_pad1k((long)cg.r2 * cg.row2);            // [r1][row1]
     r16_gu64* cnt = (r16_gu64*)p.chain_state;
     r16_gu64* gran = (r16_gu64*)((char*)p.chain_state + kChainStateHead);
@@ -393,7 +400,7 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
     auto dots_bf16 = [&](const char* row0, long stride, int nrows, int K, float (&out)[4]) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < (BIG ? 8 : 3); ++c) {
             const int k = 8 * lane + 512 * c;
             if (k < K) {
                 const f32x4 x0 = *reinterpret_cast<const f32x4*>(xl + k), x1 = *reinterpret_cast<const f32x4*>(xl + k + 4);
@@ -447,7 +454,7 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
     R16_TR(3);   // first layer done, granules stored
     // ---- sweep: wave w collects granules [w * q, (w + 1) * q) of h until every tag carries this launch's epoch ----
     {
-        constexpr int GPL = 6;                        // granules per lane and wave: N1 <= 4 * 64 * 6 = 1536
+        constexpr int GPL = BIG ? 16 : 6;             // granules per lane and wave: N1 <= 4 * 64 * GPL = 1536 (4096)
         const int q = (g1.N + 3) >> 2, lo = wave * q, hi = min(g1.N, lo + q);
         unsigned long long gv[GPL];
         unsigned spins = 0;
@@ -482,8 +489,9 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
     if (g1.x_clear && ai == 0)
         for (int k = tid; k < g1.K; k += 256) const_cast<long long*>(g1.x_fixed)[k] = 0ll;
     // ---- second layer (bf16 rows, K2 = N1) ----
-    for (int b0 = m_lo; b0 < m_hi; b0 += cg.r2) {
-        const int b1 = min(m_hi, b0 + cg.r2);
+    // (BIG: behind the first, prefetched batch the first layer's weight region is free too -- later batches take [w2l, end of the LDS))
+    const int r2b = BIG ? max(cg.r2, (int)((kChainLds - (XV * 4 + kChainBias + kChainOut) - 1024) / cg.row2)) : cg.r2;
+    for (int b0 = m_lo, b1 = min(m_hi, m_lo + cg.r2); b0 < m_hi; b0 = b1, b1 = min(m_hi, b0 + r2b)) {
         if (b0 != m_lo) {
             __syncthreads();
             dma_rows(g2.w, cg.row2, g2.N, b0, b1, w2l);
@@ -1031,7 +1039,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             return;
         }
         if (p.role == HICOM_ROLE_GEMV_CHAIN) {
-            if (p.aux.w_f32) gemv_chain_role<true>(p, ai, an, lds);
+            if (p.aux.N > 1536) {                 // (hidden 3584: wide vector area, more granules per lane, 8-KB second-layer rows)
+                ChainNoMid none;
+                if (p.aux.w_f32) gemv_chain_role<true, ChainNoMid, true>(p, ai, an, lds, none);
+                else gemv_chain_role<false, ChainNoMid, true>(p, ai, an, lds, none);
+            } else if (p.aux.w_f32) gemv_chain_role<true>(p, ai, an, lds);
             else gemv_chain_role<false>(p, ai, an, lds);
             R16_TR(7);
             return;
@@ -1279,8 +1291,8 @@ static int r16_build(const void* a, const void* w, const void* b, int32_t b_dt,
                        aux->rows_dst, aux->rows_dt == HICOM_DT_F32, aux->rows_dst ? aux->rows_reps : 0, (long)aux->rows_ld, (long)aux->rows_row0,
                        (const long long*)aux->x_fixed, aux->x_fixed_clear ? 1 : 0};
     };
-    auto check_gemv = [](const hicom_aux_gemv* aux, bool needs_x, bool needs_out = true) -> int {
-        HICOM_REQUIRE(aux->w && (!needs_out || aux->y || aux->rows_dst) && aux->N > 0 && aux->K > 0 && aux->K % 8 == 0 && aux->K <= 1536 && ((uintptr_t)aux->w % 16 == 0), HICOM_EINVAL,
+    auto check_gemv = [](const hicom_aux_gemv* aux, bool needs_x, bool needs_out = true, int kmax = 1536) -> int {
+        HICOM_REQUIRE(aux->w && (!needs_out || aux->y || aux->rows_dst) && aux->N > 0 && aux->K > 0 && aux->K % 8 == 0 && aux->K <= kmax && ((uintptr_t)aux->w % 16 == 0), HICOM_EINVAL,
                       "readout16_gemm: aux GEMV arguments");
         if (aux->x_fixed) HICOM_REQUIRE((uintptr_t)aux->x_fixed % 8 == 0, HICOM_EINVAL, "readout16_gemm: aux x_fixed alignment");
         else if (needs_x) HICOM_REQUIRE(aux->xs && aux->x_parts > 0 && aux->x_stride % 4 == 0 && ((uintptr_t)aux->xs % 16 == 0) && (long)aux->x_parts * aux->K <= 28 * 1024 &&
@@ -1295,7 +1307,8 @@ static int r16_build(const void* a, const void* w, const void* b, int32_t b_dt,
         p.role = HICOM_ROLE_GEMV;
     } else if (kind == HICOM_ROLE_GEMV_CHAIN) {
         if (int rc = check_gemv(&role->gemv, true, false)) return rc;          // (the first layer's result travels as granules: y optional)
-        if (int rc = check_gemv(&role->gemv2, false)) return rc;
+        if (int rc = check_gemv(&role->gemv2, false, true, kChainBigN)) return rc;      // (the second layer's K is the first layer's width: up to 4096)
+        HICOM_REQUIRE(role->gemv.N <= kChainBigN, HICOM_EUNSUP, "readout16_gemm: GEMV chain: first layer of %d columns (<= %d)", role->gemv.N, kChainBigN);
         HICOM_REQUIRE(role->gemv.x_fixed && role->gemv2.K == role->gemv.N && role->gemv2.w_dt == HICOM_DT_BF16 && role->chain_state &&
                           (uintptr_t)role->chain_state % 16 == 0, HICOM_EINVAL,
                       "readout16_gemm: GEMV chain (first layer from x_fixed, second layer bf16 with K = the first layer's N, state block)");

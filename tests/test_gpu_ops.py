@@ -724,7 +724,8 @@ def test_merge_role_applies_the_value_side_pos_emb_from_marginals(nparts):
     assert maxabs(got, want.reshape(-1)) <= 2e-5 * max(1.0, float(want.abs().max())), float((got - want.reshape(-1)).abs().max())
 
 
-@pytest.mark.parametrize("n_mid,n_out,tile_rows", [(896, 896, 1296), (896, 896, 200), (3584 // 4, 512, 648), (1536, 1000, 96)])
+@pytest.mark.parametrize("n_mid,n_out,tile_rows", [(896, 896, 1296), (896, 896, 200), (3584 // 4, 512, 648), (1536, 1000, 96),
+                                                   (3584, 3584, 648), (2048, 520, 200), (4096, 1000, 96)])      # round 6: layers up to 4096 wide
 def test_gemv_chain_role_hands_the_hidden_layer_over_inside_the_launch(n_mid, n_out, tile_rows):
     """Round 5: HICOM_ROLE_GEMV_CHAIN -- h = GELU(C (o + b_v) + r0) and y = W2 h + b2 -> replicated output rows in ONE launch, h handed
     over between the role's workgroups as {epoch, value} granules.  Against float64 torch; repeated launches on one state block (the
