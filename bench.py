@@ -384,6 +384,9 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 extras[k]["median"] = float(t.item())
 
+    # ---- roofline of the dominant kernel (HIP events on the stream it is launched on) ----------
+    roofline = dominant_kernel_roofline(module, sets, args.steps)
+
     # in-launch hand-offs (query prep granules, the GEMV chain under readout GEMM 2 / in the FINISH phase) whose bounded spin expired
     # during everything above: such a step returns NaN rows and only counts it -- the line carries the counters
     handoff = {"query_prep": 0, "gemv_chain": 0, "checked_workspaces": 0}
@@ -396,9 +399,6 @@ def main():
         handoff["gemv_chain"] += ch
         handoff["checked_workspaces"] += 1
     assert handoff["query_prep"] == 0 and handoff["gemv_chain"] == 0, f"failed in-launch hand-offs during the bench: {handoff}"
-
-    # ---- roofline of the dominant kernel (HIP events on the stream it is launched on) ----------
-    roofline = dominant_kernel_roofline(module, sets, args.steps)
 
     alg_step = 3359232 * fpg + 18046976 * (args.hidden == 896) + n_out * args.hidden * 2 + 2304
     result = {
@@ -817,7 +817,9 @@ def dominant_kernel_roofline(module, sets, iters):
         b.record(stream)
         b.synchronize()
         hist.append(a.elapsed_time(b))
-        if len(hist) >= 5 and max(hist[-5:]) - min(hist[-5:]) <= 0.02 * min(hist[-5:]):
+        # (at least 30 batches = ~14 ms: the overshoot CRESTS around batch 10-15 and five batches on the crest agree within 2 % too --
+        # a run that stopped there after 10 batches read 49.2 us where the kernel trace of the same build shows 43.9, round 6)
+        if len(hist) >= 30 and max(hist[-5:]) - min(hist[-5:]) <= 0.02 * min(hist[-5:]):
             break
     for a, b in evs:
         a.record(stream)

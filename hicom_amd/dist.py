@@ -163,6 +163,7 @@ class _ShardPlan:
 
 _MAX_SHARD_PLANS = 8
 _N_SETS = 4
+_COMM_PTRS = {}          # (process group, device) -> ncclComm_t of its RCCL backend, or None
 
 
 def _rccl_comm(group, dev, world) -> Optional[int]:
@@ -172,17 +173,27 @@ def _rccl_comm(group, dev, world) -> Optional[int]:
     import os
     if os.environ.get("HICOM_SHARD_DIRECT_AG", "1") == "0" or not dist.is_initialized():
         return None
+    g = group if group is not None else dist.group.WORLD
     try:
-        g = group if group is not None else dist.group.WORLD
         if dist.get_backend(g) != "nccl":
             return None
+        backend = g._get_backend(torch.device(dev))
+        # (one probe collective per backend INSTANCE -- its `uid` tells a re-created process group from a destroyed one whose id() was reused)
+        uid = getattr(backend, "uid", None)
+        key = (uid, str(dev))
+        if uid is not None and key in _COMM_PTRS:
+            return _COMM_PTRS[key]
         probe = torch.zeros(world, dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(probe, probe[:1].clone(), group=g)
         torch.cuda.current_stream(dev).synchronize()
-        ptr = int(g._get_backend(torch.device(dev))._comm_ptr())
-        return ptr or None
+        ptr = int(backend._comm_ptr()) or None
     except Exception:  # noqa: BLE001  (a torch without _comm_ptr, a wrapped backend: fall back to c10d)
         return None
+    if uid is not None:
+        if len(_COMM_PTRS) > 16:
+            _COMM_PTRS.clear()
+        _COMM_PTRS[key] = ptr
+    return ptr
 
 
 def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group, rank=None, world=None) -> _ShardPlan:

@@ -912,8 +912,7 @@ class HIComProjector(nn.Module):
         """Reference signature (projector.py:676).  Extension for the producer of frames_embed:
         `local_logits` = fp32 [T,H,W] raw dot products frames_embed_n . guide from `hicom_amd.siglip_head_scores`, passed with
         frames_embed=None -- the release recipe then streams frames_feature only (half the bytes)."""
-        p0 = next(self.parameters(), None)
-        if p0 is not None and p0.dtype == torch.float16:
+        if (self.local_compressor or self.global_compressor).readout[0].weight.dtype == torch.float16:      # (one attribute chain on the hot path)
             return self._forward_half(frames_feature, frames_embed, guide_embed, modal, image_newline, local_logits)
         self._check_clip_logits()
         if local_logits is not None:
