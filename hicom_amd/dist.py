@@ -196,11 +196,14 @@ def _rccl_comm(group, dev, world) -> Optional[int]:
     return ptr
 
 
-def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group, rank=None, world=None) -> _ShardPlan:
-    """Plan of one (problem shape, rank, world, caller stream, weight state): two buffer sets, each with its own argument
+def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group, rank=None, world=None,
+                collective=None) -> _ShardPlan:
+    """Plan of one (problem shape, rank, world, caller stream, weight state): `_N_SETS` buffer sets, each with its own argument
     blocks, exchange buffers and workspaces, and the plan's comm stream.  The input pointers are patched per call
     (`set_inputs`).  `rank` / `world` default to the process group's; the single-GPU tests of the N > 1 device path pass
-    them explicitly (no collective)."""
+    them explicitly (no collective) -- or, with `collective` = (all-gather fn, group-start fn, group-end fn, comm token) as C function
+    addresses, a TEST DOUBLE of RCCL's entry points: the FINISH call then takes exactly the path it takes under a real process group
+    (hicom_compressor_args.ag_*), with the double doing the copies (tests/test_gpu_parity.py::test_direct_all_gather_form_emulated)."""
     from . import engine
     from . import native as nv
     from .projector import _out_dtype
@@ -211,7 +214,7 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
     if rank is None or world is None:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     key = (tuple(ff_shard.shape), fe_shard is not None, None if guide_embed is None else tuple(guide_embed.shape),
-           image_newline is not None, _out_dtype(projector), world, rank, total_frames, cur.cuda_stream, id(group))
+           image_newline is not None, _out_dtype(projector), world, rank, total_frames, cur.cuda_stream, id(group), collective)
     plans = projector.__dict__.setdefault("_shard_plans", {})
     plan = plans.get(key)
     sig = engine.weights_sig(projector)
@@ -256,6 +259,8 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
     # between readout GEMM 2 and the next step's query prep (tools/shard_trace.py: 89.9 us from ring to ring against 75 of kernels)
     plan.xs = ExchangeSets(pack, dev, world, n=_N_SETS)
     comm_ptr = _rccl_comm(group, dev, world) if _explicit is None else None      # (explicit rank / world: the one-GPU emulations, no collective)
+    if collective is not None:
+        comm_ptr = collective[3]
     for mine, everyone in plan.xs.pairs:
         st = _ShardSet()
         st.mine, st.everyone = mine, everyone
@@ -306,7 +311,7 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
         st.direct_ag = comm_ptr is not None
         st.states_all, st.tok_direct = None, False
         if st.direct_ag:
-            fn_ag, fn_gs, fn_ge = nv.rccl_fns()
+            fn_ag, fn_gs, fn_ge = collective[:3] if collective is not None else nv.rccl_fns()
             st.a_finish.ag_fn, st.a_finish.ag_comm = fn_ag, comm_ptr
             st.a_finish.ag_send, st.a_finish.ag_recv, st.a_finish.ag_bytes = st.mine.data_ptr(), st.everyone.data_ptr(), pack.total
             if not lay.newline_rows and lay.nl_group == 0 and os.environ.get("HICOM_SHARD_PLACE", "0") != "1":

@@ -681,6 +681,94 @@ def test_c3_c5_eight_rank_emulation(per, finish_rank):
     assert float((got[-32:].cpu() - ref.reshape(32, 896)).abs().max()) <= TOL
 
 
+@pytest.mark.parametrize("world,per,newline", [(2, 8, None), (4, 4, None), (8, 8, None), (2, 8, "grid")])
+def test_direct_all_gather_form_emulated(world, per, newline):
+    """Round 6: the FINISH call of the frame-sharded step enqueues its all-gather ITSELF (hicom_compressor_args.ag_fn: RCCL's ncclAllGather
+    through the process group's communicator; without newline rows the token blocks go straight into the output's rows and a second
+    all-gather of the same group carries the states).  On the pool's one-GPU boxes that path only ever runs at world size 1 through
+    real RCCL, so here every rank of a 2 / 4 / 8-rank world runs it on ONE GPU with a TEST DOUBLE behind the same three C entry points:
+    the double copies every rank's send buffer into its slot of the receive buffer (what an all-gather does) -- offsets, strides, the
+    grouped form, the state sets and the FINISH phase are the product's.  Every rank's result against the unsharded forward."""
+    import ctypes
+    from types import SimpleNamespace
+    from hicom_amd import dist as hd, native as nv_, synth
+    from oracle import hicom_oracle as orc
+    T = world * per
+    over = {"hidden_size": 128, "max_num_frames": max(16, T)}
+    if newline:
+        over.update(mm_patch_merge_type="spatial_unpad", mm_newline_position=newline)
+    cfg = SimpleNamespace(**{**cases.DEFAULT_CFG, **over})
+    sd = synth.synth_state_dict(orc.param_shapes(cfg), tag="dag")
+    m = build_module(SimpleNamespace(cfg=cfg, sd=sd))
+    x = synth.synth_inputs(T, 27, 27, 1152, tag=f"dag{world}")
+    ff, fe, g = dev_bf16(x["ff"]), dev_bf16(x["fe"]), dev_bf16(x["g"])
+    nl = dev_bf16(synth.normal_like((128,), 993)) if newline else None
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    sends = {}                                              # send pointer -> (kind, rank); kind -> [pointer of every rank]
+    by_kind = {}
+    calls = []
+
+    @ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
+    def fake_all_gather(send, recv, count, dtype, comm, stream):
+        kind, _ = sends[send]
+        assert dtype == 1 and comm == 0x5EED                # ncclUint8, the token handed in as the communicator
+        calls.append(kind)
+        for r, src in enumerate(by_kind[kind]):
+            if hip.hipMemcpyAsync(recv + r * count, src, count, 3, stream) != 0:      # hipMemcpyDeviceToDevice
+                return 1
+        return 0
+
+    depth = [0]
+
+    @ctypes.CFUNCTYPE(ctypes.c_int)
+    def fake_group_start():
+        depth[0] += 1
+        return 0
+
+    @ctypes.CFUNCTYPE(ctypes.c_int)
+    def fake_group_end():
+        depth[0] -= 1
+        return 0
+    addr = lambda f: ctypes.cast(f, ctypes.c_void_p).value
+    coll = (addr(fake_all_gather), addr(fake_group_start), addr(fake_group_end), 0x5EED)
+    with torch.no_grad():
+        want = m(ff, fe, g, "video", nl)
+        plans = [hd._shard_plan(m, ff[r * per:(r + 1) * per], fe[r * per:(r + 1) * per], g, T, nl, None, rank=r, world=world, collective=coll)
+                 for r in range(world)]
+        outs = []
+        for r, plan in enumerate(plans):
+            st = plan.sets[0]
+            assert st.direct_ag and st.tok_direct == (newline is None)
+            out = torch.empty((plan.n_rows_total, plan.hidden), dtype=plan.odt, device="cuda")
+            plan.set_inputs(st, ff[r * per:(r + 1) * per], fe[r * per:(r + 1) * per], g, out)
+            outs.append(out)
+            tok_ptr, state_ptr = st.mine.data_ptr() + plan.pack.tok_off, st.mine.data_ptr()
+            if st.tok_direct:
+                sends[tok_ptr], sends[state_ptr] = ("tokens", r), ("states", r)
+                by_kind.setdefault("tokens", []).append(tok_ptr)
+                by_kind.setdefault("states", []).append(state_ptr)
+            else:
+                sends[state_ptr] = ("packed", r)
+                by_kind.setdefault("packed", []).append(state_ptr)
+            nv_.compressor_fwd(st.a_stream)                 # STREAM phase of rank r (main stream; the comm stream waits for its event)
+        torch.cuda.synchronize()                            # (every rank's send buffer is complete: what the collective's own sync guarantees)
+        for r, plan in enumerate(plans):
+            st = plan.sets[0]
+            nv_.compressor_fwd(st.a_finish)                 # FINISH phase of rank r: the double "gathers", the states merge, the tokens land
+            if plan.lay.newline_rows:
+                first = plan.lay.newline_rows[0]
+                step = plan.lay.newline_rows[1] - first if len(plan.lay.newline_rows) > 1 else 1
+                nv_.scatter_rows(nl.view(1, -1), outs[r], first, len(plan.lay.newline_rows), row_step=step, stream=plan.comm.cuda_stream)
+        torch.cuda.synchronize()
+    assert depth[0] == 0 and len(calls) == world * (2 if newline is None else 1)
+    for r in range(world):
+        assert outs[r].shape == want.shape
+        assert float((outs[r].float() - want.float()).abs().max()) <= PATH_TOL, r
+    for plan in plans:
+        plan.release()
+
+
 def test_sharded_forward_world1_equals_forward(c2):
     """sharded_forward with a 1-rank RCCL group (STREAM phase -> all-gather -> FINISH phase) reproduces
     the single-call forward at the full C2 size."""
