@@ -18,7 +18,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhicom_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# -amdgpu-kernarg-preload-count: leading SCALAR kernel arguments arrive in SGPRs at wave launch (struct arguments are not preloaded: the hot
+# kernels repeat the fields their first requests need as leading scalars); a device without the feature runs the s_load prologue hipcc keeps
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-mllvm",
+         "-amdgpu-kernarg-preload-count=" + os.environ.get("HICOM_KERNARG_PRELOAD", "14")]      # (0: dev A/B, tools/gpu_kernarg_ab.sh)
 
 
 def hipcc() -> str:

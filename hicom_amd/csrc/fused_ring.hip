@@ -122,7 +122,12 @@ __device__ __forceinline__ void ring_wait_vm() {
 // waves fetch the 4 logits of their token slots one tile ahead with ordinary loads, no local score MFMAs.  ONE kernel body: the
 // two forms differ in the loader schedule, the score operand and the cadence of the pos-emb images behind the stream.
 template <int NB, bool LOGITS>
-__global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(RingParams p) {
+__global__ __launch_bounds__(kRingThreads, 1) void fused_ring_kernel(const uint16_t* ff0, const uint16_t* fe0, int H0, int W0, int kt0, int ks0, int nwy0, int nwx0, int NW0, int WSZ0, int wpw0,
+                                                                     RingParams p_in) {
+    // (the leading scalars repeat what the loaders' FIRST requests depend on -- stream bases and the window geometry: preloaded into SGPRs at
+    // wave launch, build_native.py -amdgpu-kernarg-preload-count; the rest of the argument block is fetched under the prologue as before)
+    RingParams p = p_in;
+    p.ff = ff0; p.fe = fe0; p.H = H0; p.W = W0; p.kt = kt0; p.ks = ks0; p.nwy = nwy0; p.nwx = nwx0; p.NW = NW0; p.WSZ = WSZ0; p.wpw = wpw0;
 #ifdef HICOM_TRACE
     const unsigned long long tr_entry = __builtin_readcyclecounter();
     const unsigned long long tr_entry_rt = __builtin_amdgcn_s_memrealtime();      // 100 MHz, chip-wide: workgroups are comparable
@@ -1030,7 +1035,9 @@ extern "C" int hicom_fused_stream_fwd(const void* ff, const void* fe, const floa
         attr_set = true;
     }
     // precomputed local logits win over frames_embed when both are given: frames_embed is then not read at all
-    if (local_logits) HICOM_LAUNCH((fused_ring_kernel<9, true>), dim3((unsigned)nparts), dim3(kRingThreads), smem, (hipStream_t)stream, p);
-    else HICOM_LAUNCH((fused_ring_kernel<9, false>), dim3((unsigned)nparts), dim3(kRingThreads), smem, (hipStream_t)stream, p);
+    if (local_logits) HICOM_LAUNCH((fused_ring_kernel<9, true>), dim3((unsigned)nparts), dim3(kRingThreads), smem, (hipStream_t)stream,
+                                   p.ff, p.fe, p.H, p.W, p.kt, p.ks, p.nwy, p.nwx, p.NW, p.WSZ, p.wpw, p);
+    else HICOM_LAUNCH((fused_ring_kernel<9, false>), dim3((unsigned)nparts), dim3(kRingThreads), smem, (hipStream_t)stream,
+                      p.ff, p.fe, p.H, p.W, p.kt, p.ks, p.nwy, p.nwx, p.NW, p.WSZ, p.wpw, p);
     return hicom_host::check_launch("fused_stream");
 }

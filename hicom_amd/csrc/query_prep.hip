@@ -133,7 +133,11 @@ __device__ __forceinline__ unsigned read_epoch(gu64* cnt) {
     return (unsigned)(c / gridDim.x) + 1u;
 }
 
-__global__ __launch_bounds__(256) void query_prep_kernel(PrepParams p) {
+__global__ __launch_bounds__(256) void query_prep_kernel(const uint16_t* g0, const uint16_t* wq0, const uint16_t* bq0, unsigned* state0, int E0, int nq_wg0, int nr_wg0, PrepParams p_in) {
+    // (leading scalars: what the q_proj workgroups' first requests depend on -- they head the launch's critical path; preloaded into SGPRs at
+    // wave launch, build_native.py -amdgpu-kernarg-preload-count)
+    PrepParams p = p_in;
+    p.g = g0; p.wq = wq0; p.bq = bq0; p.state = state0; p.E = E0; p.nq_wg = nq_wg0; p.nr_wg = nr_wg0;
     __shared__ float qs[128];                                        // q_proj outputs of this workgroup's head
     __shared__ __attribute__((aligned(16))) float red[16][128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -335,6 +339,6 @@ extern "C" int hicom_query_prep_fwd(const void* guide, const void* local_q, cons
     p.nf_wg = nh * (E / 128);
     p.np_wg = p.P ? nh * ((p.P + 63) / 64) : 0;
     const int grid = p.nq_wg + p.nr_wg + p.nf_wg + p.np_wg;
-    HICOM_LAUNCH(query_prep_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+    HICOM_LAUNCH(query_prep_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p.g, p.wq, p.bq, p.state, p.E, p.nq_wg, p.nr_wg, p);
     return hicom_host::check_launch("query_prep");
 }

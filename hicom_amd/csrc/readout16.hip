@@ -288,8 +288,21 @@ struct ChainNoMid {
     __device__ __forceinline__ void reduce() {}                                // (the mid work itself, up to this workgroup's arrival at the gate)
     __device__ __forceinline__ bool wait() { return false; }                   // (the gate; returns whether x must be treated as lost)
 };
-template <bool W1F32, class Mid, bool BIG = false>
-__device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int an, char* lds, Mid& mid) {
+// What the chain role reads BEHIND its first requests.  LATE (the kernel whose preloaded leading arguments are the role's, PRE = 1): filled from the
+// kernel-argument block through a pointer the compiler cannot see through before that point -- otherwise hipcc fetches these fields at the
+// role's entry and waits for them in front of the first request (an SGPR it spills there is enough).
+struct ChainLate {
+    const uint16_t* xb;
+    const void *b1, *b2;
+    const uint16_t *res1, *res2;
+    float *y1, *y2;
+    void* dst;
+    long ldd, row0;
+    int b1_f32, b2_f32, act1, act2, dst_f32, reps, x_clear, K2;
+};
+typedef const __attribute__((address_space(4))) R16Params* r16_kernarg_ptr;
+template <bool W1F32, class Mid, bool BIG = false, bool LATE = false>
+__device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int an, char* lds, Mid& mid, r16_kernarg_ptr late = nullptr) {
     constexpr bool kGated = !std::is_same<Mid, ChainNoMid>::value;
     constexpr int XV = BIG ? kChainBigN : 1536;                       // floats of the vector area (x, later h)
     static_assert(!(BIG && kGated), "the gated (fused tail) form takes the release widths only");
@@ -324,12 +337,11 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
         for (int u = 0; u < 6; ++u) xf[u] = g1.x_fixed[min(tid + 256 * u, g1.K - 1)];
     }
     R16_TR(9);
-    auto bias_raw = [&](const AuxGemv& g, int n) -> unsigned {
-        n = n < g.N ? n : g.N - 1;
-        const char* bp = reinterpret_cast<const char*>(g.b ? g.b : g.w) + (long)n * (g.b_f32 ? 4 : 2);
-        return g.b_f32 ? *reinterpret_cast<const unsigned*>(bp) : (unsigned)*reinterpret_cast<const uint16_t*>(bp);
+    auto bias_raw = [&](const void* b, int b_f32, const void* w, int N, int n) -> unsigned {
+        n = n < N ? n : N - 1;
+        const char* bp = reinterpret_cast<const char*>(b ? b : w) + (long)n * (b_f32 ? 4 : 2);
+        return b_f32 ? *reinterpret_cast<const unsigned*>(bp) : (unsigned)*reinterpret_cast<const uint16_t*>(bp);
     };
-    const unsigned b1raw = bias_raw(g1, n_lo + tid), b2raw = bias_raw(g2, m_lo + tid);
     // DMA of rows [r_lo, r_hi) of a row-major matrix (a CONTIGUOUS byte range) into `dst`, 1-KB pieces dealt over the four waves;
     // a piece's tail beyond the range re-reads the matrix's last 16 bytes (lands in unread LDS)
     auto dma_rows = [&](const void* w, long rowbytes, long total_rows, int r_lo, int r_hi, char* dst) -> int {
@@ -355,6 +367,20 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
     R16_TR(11);
     dma_rows(g2.w, cg.row2, g2.N, m_lo, min(m_hi, m_lo + cg.r2), w2l);
     __builtin_amdgcn_sched_barrier(0);
+    // (the biases LAST: their pointers are not among the preloaded kernel arguments -- everything above leaves without waiting for the argument block)
+    ChainLate L;
+    if constexpr (LATE) {
+        asm volatile("" : "+s"(late));
+        L.xb = late->aux.xb; L.b1 = late->aux.b; L.b2 = late->aux2.b; L.res1 = late->aux.res; L.res2 = late->aux2.res; L.y1 = late->aux.y; L.y2 = late->aux2.y;
+        L.dst = late->aux2.dst; L.ldd = late->aux2.ldd; L.row0 = late->aux2.row0; L.b1_f32 = late->aux.b_f32; L.b2_f32 = late->aux2.b_f32;
+        L.act1 = late->aux.act; L.act2 = late->aux2.act; L.dst_f32 = late->aux2.dst_f32; L.reps = late->aux2.reps; L.x_clear = late->aux.x_clear; L.K2 = late->aux2.K;
+    } else {
+        L.xb = g1.xb; L.b1 = g1.b; L.b2 = g2.b; L.res1 = g1.res; L.res2 = g2.res; L.y1 = g1.y; L.y2 = g2.y;
+        L.dst = g2.dst; L.ldd = g2.ldd; L.row0 = g2.row0; L.b1_f32 = g1.b_f32; L.b2_f32 = g2.b_f32;
+        L.act1 = g1.act; L.act2 = g2.act; L.dst_f32 = g2.dst_f32; L.reps = g2.reps; L.x_clear = g1.x_clear; L.K2 = g2.K;
+    }
+    const unsigned b1raw = bias_raw(L.b1, L.b1_f32, g1.w, g1.N, n_lo + tid), b2raw = bias_raw(L.b2, L.b2_f32, g2.w, g2.N, m_lo + tid);
+    __builtin_amdgcn_sched_barrier(0);
     R16_TR(1);   // every load requested
     bool xlost = false;
     if constexpr (kGated) {
@@ -366,10 +392,10 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
         const int k = tid + 256 * u;
-        if (k < g1.K) xl[k] = xlost ? __uint_as_float(0x7FC00000u) : (float)xf[u] * (1.0f / HICOM_FIXED_SCALE) + (g1.xb ? bf16_to_f32(g1.xb[k]) : 0.f);
+        if (k < g1.K) xl[k] = xlost ? __uint_as_float(0x7FC00000u) : (float)xf[u] * (1.0f / HICOM_FIXED_SCALE) + (L.xb ? bf16_to_f32(L.xb[k]) : 0.f);
     }
-    bl1[tid] = g1.b ? __uint_as_float(g1.b_f32 ? b1raw : b1raw << 16) : 0.f;
-    bl2[tid] = g2.b ? __uint_as_float(g2.b_f32 ? b2raw : b2raw << 16) : 0.f;
+    bl1[tid] = L.b1 ? __uint_as_float(L.b1_f32 ? b1raw : b1raw << 16) : 0.f;
+    bl2[tid] = L.b2 ? __uint_as_float(L.b2_f32 ? b2raw : b2raw << 16) : 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's DMA pieces (both layers') have landed
     __syncthreads();
     R16_TR(2);   // x and the weights landed
@@ -437,11 +463,11 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
             const int nn = n + 4 * lane;
             if (lane < nrows) {
                 v += bl1[nn - n_lo];
-                if (g1.act == HICOM_ACT_GELU) v = gelu_erf(v);
-                if (g1.res) v += bf16_to_f32(g1.res[nn]);
+                if (L.act1 == HICOM_ACT_GELU) v = gelu_erf(v);
+                if (L.res1) v += bf16_to_f32(L.res1[nn]);
                 __hip_atomic_store(gran + nn, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
-                if (g1.y) g1.y[nn] = v;
+                if (L.y1) L.y1[nn] = v;
             }
         }
     }
@@ -486,7 +512,7 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
     R16_TR(4);   // hand-off complete
     // (every granule carries this launch's epoch: every role workgroup has published, i.e. has read x -- the accumulators can be
     // cleared for the next step's merge; a failed hand-off has poisoned this launch anyway and the next one starts behind it)
-    if (g1.x_clear && ai == 0)
+    if (L.x_clear && ai == 0)
         for (int k = tid; k < g1.K; k += 256) const_cast<long long*>(g1.x_fixed)[k] = 0ll;
     // ---- second layer (bf16 rows, K2 = N1) ----
     // (BIG: behind the first, prefetched batch the first layer's weight region is free too -- later batches take [w2l, end of the LDS))
@@ -501,27 +527,27 @@ __device__ __forceinline__ void gemv_chain_role(const R16Params& p, int ai, int 
         for (int m = b0 + wave; m < b1; m += 16) {
             const int nrows = min(4, (b1 - m + 3) >> 2);
             float d[4];
-            dots_bf16(w2l + (long)(m - b0) * cg.row2, 4 * cg.row2, nrows, g2.K, d);
+            dots_bf16(w2l + (long)(m - b0) * cg.row2, 4 * cg.row2, nrows, L.K2, d);
             float v = lane == 0 ? d[0] : lane == 1 ? d[1] : lane == 2 ? d[2] : d[3];
             const int mm = m + 4 * lane;
             if (lane < nrows) {
                 v += bl2[mm - m_lo];
-                if (g2.act == HICOM_ACT_GELU) v = gelu_erf(v);
-                if (g2.res) v += bf16_to_f32(g2.res[mm]);
+                if (L.act2 == HICOM_ACT_GELU) v = gelu_erf(v);
+                if (L.res2) v += bf16_to_f32(L.res2[mm]);
                 yl[mm - m_lo] = v;
-                if (g2.y) g2.y[mm] = v;
+                if (L.y2) L.y2[mm] = v;
             }
         }
     }
     __syncthreads();
-    if (g2.dst) {
+    if (L.dst) {
         // the workgroup's columns of every replica row: consecutive threads write consecutive columns
         const int ncol = m_hi - m_lo;
-        for (int idx = tid; idx < g2.reps * ncol; idx += 256) {
+        for (int idx = tid; idx < L.reps * ncol; idx += 256) {
             const int rr = idx / ncol, c = idx - rr * ncol;
-            const long o = (g2.row0 + rr) * g2.ldd + m_lo + c;
-            if (g2.dst_f32) reinterpret_cast<float*>(g2.dst)[o] = yl[c];
-            else reinterpret_cast<uint16_t*>(g2.dst)[o] = f32_to_bf16(yl[c]);
+            const long o = (L.row0 + rr) * L.ldd + m_lo + c;
+            if (L.dst_f32) reinterpret_cast<float*>(L.dst)[o] = yl[c];
+            else reinterpret_cast<uint16_t*>(L.dst)[o] = f32_to_bf16(yl[c]);
         }
     }
     // the arrival: after every wave of the workgroup has read the counter (all did before the first barrier)
@@ -1027,14 +1053,45 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
     return true;
 }
 
-template <int kRRing, int TN = kRN, int TM = kRM>
-__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void readout16_gemm_kernel(R16Params p) {
+// The leading scalar arguments repeat what a workgroup's FIRST requests depend on: hipcc preloads them into SGPRs at wave launch (-mllvm
+// -amdgpu-kernarg-preload-count, build_native.py; 14 dwords at most), so those requests do not wait for a kernel-argument fetch -- a memory
+// round trip beside ~250 workgroups that start together.  Everything else is read from the argument block as before.  WHOSE first requests:
+//   PRE = 0  the tiles':  q0 = a, q1 = w, i0..i2 = M, N, K, i3 = n_gemm, i4 = role, i5 = role workgroups        (the tiles end the launch)
+//   PRE = 1  the GEMV chain role's (the launch it ends: its x, counter and weight requests leave beside the tiles' first DMA instead of behind
+//            31 MB of them):  q0 = chain_state, q1 = aux.x_fixed, q2 = aux.w, q3 = aux2.w, i0 = aux.K, i1 = aux.N | aux2.N << 16,
+//            i2 = cg_cpw1 | cg_cpw2 << 16, i3 = n_gemm | role workgroups << 16, i4 = role | aux.w_f32 << 8, i5 = cg_r1 | cg_r2 << 16; the tiles fetch their operand bases
+template <int kRRing, int TN = kRN, int TM = kRM, int PRE = 0>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void readout16_gemm_kernel(const void* q0, const void* q1, const void* q2, const void* q3,
+                                                                                                            int i0, int i1, int i2, int i3, int i4, int i5, R16Params p_in) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [kRRing][stage]; the roles take the whole 160 KB
+    R16Params p = p_in;
+    if constexpr (PRE == 0) {
+        p.a = (const _Float16*)q0; p.w = (const _Float16*)q1; p.M = i0; p.N = i1; p.K = i2; p.n_gemm = i3; p.role = i4;
+    } else {
+        p.chain_state = (unsigned*)const_cast<void*>(q0); p.aux.x_fixed = (const long long*)q1; p.aux.w = q2; p.aux2.w = q3;
+        p.aux.K = i0; p.aux.N = i1 & 0xffff; p.aux2.N = (int)((unsigned)i1 >> 16);
+        p.cg_cpw1 = i2 & 0xffff; p.cg_cpw2 = (int)((unsigned)i2 >> 16); p.cg_r1 = i5 & 0xffff; p.cg_r2 = (int)((unsigned)i5 >> 16);
+        p.n_gemm = i3 & 0xffff; p.role = i4 & 0xff; p.aux.w_f32 = i4 >> 8;
+    }
+    // (the role size rides in the preloaded arguments too: gridDim.x is a fetch from the argument block's hidden tail)
+    const int n_aux_pre = PRE == 0 ? i5 : (int)((unsigned)i3 >> 16);
     R16_TR(0);
     if ((int)blockIdx.x >= p.n_gemm) {
-        const int ai = (int)blockIdx.x - p.n_gemm, an = (int)gridDim.x - p.n_gemm;
+        const int ai = (int)blockIdx.x - p.n_gemm, an = n_aux_pre;
         if (p.role == HICOM_ROLE_MERGE_VPROJ) {
             merge_vproj_role(p, ai, an, lds);
+            R16_TR(7);
+            return;
+        }
+        if constexpr (PRE == 1) {
+            // (the argument block sits behind the 14 preloaded dwords)
+            r16_kernarg_ptr late = (r16_kernarg_ptr)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + 56);
+            ChainNoMid none;
+            if (p.aux.N > 1536) {
+                if (p.aux.w_f32) gemv_chain_role<true, ChainNoMid, true, true>(p, ai, an, lds, none, late);
+                else gemv_chain_role<false, ChainNoMid, true, true>(p, ai, an, lds, none, late);
+            } else if (p.aux.w_f32) gemv_chain_role<true, ChainNoMid, false, true>(p, ai, an, lds, none, late);
+            else gemv_chain_role<false, ChainNoMid, false, true>(p, ai, an, lds, none, late);
             R16_TR(7);
             return;
         }
@@ -1386,15 +1443,26 @@ static int readout16_launch(const void* a, const void* w, const void* b, int32_t
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(readout16_gemm_kernel<8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kRStage);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(readout16_gemm_kernel<8, 64, 96, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kRStage);
         hipFuncSetAttribute(reinterpret_cast<const void*>(readout16_gemm_kernel<5, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kRStage);
         hipFuncSetAttribute(reinterpret_cast<const void*>(readout16_gemm_kernel<4, 128, 192>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kRStage);
         attr_set = true;
     }
     // role workgroups first in dispatch order would delay tiles on their CUs; they go last and land on the free CUs
     // (both forms ask for the whole 160 KB: one workgroup per CU, and the roles use it)
-    if (p.tm == 192) HICOM_LAUNCH((readout16_gemm_kernel<4, 128, 192>), dim3((unsigned)(p.n_gemm + n_aux)), dim3(256), 8 * kRStage, (hipStream_t)stream, p);
-    else if (p.tn == 128) HICOM_LAUNCH((readout16_gemm_kernel<5, 128>), dim3((unsigned)(p.n_gemm + n_aux)), dim3(256), 8 * kRStage, (hipStream_t)stream, p);
-    else HICOM_LAUNCH((readout16_gemm_kernel<8, 64>), dim3((unsigned)(p.n_gemm + n_aux)), dim3(256), 8 * kRStage, (hipStream_t)stream, p);
+    const dim3 grid((unsigned)(p.n_gemm + n_aux));
+#define R16_ARGS0 (const void*)p.a, (const void*)p.w, (const void*)nullptr, (const void*)nullptr, p.M, p.N, p.K, p.n_gemm, p.role, n_aux, p
+    if (p.tm == 192) HICOM_LAUNCH((readout16_gemm_kernel<4, 128, 192>), grid, dim3(256), 8 * kRStage, (hipStream_t)stream, R16_ARGS0);
+    else if (p.tn == 128) HICOM_LAUNCH((readout16_gemm_kernel<5, 128>), grid, dim3(256), 8 * kRStage, (hipStream_t)stream, R16_ARGS0);
+    // (HICOM_R16_PRE=0: dev A/B switch -- the chain launch with the tiles' arguments preloaded, like every other launch)
+    static const bool pre_role = !(getenv("HICOM_R16_PRE") && getenv("HICOM_R16_PRE")[0] == '0');
+    if (p.tm == 192 || p.tn == 128) {
+    } else if (pre_role && p.role == HICOM_ROLE_GEMV_CHAIN && p.n_gemm > 0 && p.n_gemm < 65536 && p.aux.N < 65536 && p.aux2.N < 65536)
+        HICOM_LAUNCH((readout16_gemm_kernel<8, 64, 96, 1>), grid, dim3(256), 8 * kRStage, (hipStream_t)stream, (const void*)p.chain_state, (const void*)p.aux.x_fixed,
+                     (const void*)p.aux.w, (const void*)p.aux2.w, p.aux.K, p.aux.N | (p.aux2.N << 16), p.cg_cpw1 | (p.cg_cpw2 << 16), p.n_gemm | (n_aux << 16),
+                     p.role | ((p.aux.w_f32 ? 1 : 0) << 8), p.cg_r1 | (p.cg_r2 << 16), p);
+    else HICOM_LAUNCH((readout16_gemm_kernel<8, 64>), grid, dim3(256), 8 * kRStage, (hipStream_t)stream, R16_ARGS0);
+#undef R16_ARGS0
     return hicom_host::check_launch("readout16_gemm");
 }
 
