@@ -85,8 +85,10 @@ struct R16Params {
 #ifdef HICOM_TRACE
 __device__ unsigned long long g_r16_trace[512 * 16];
 #define R16_TR(k) do { if (threadIdx.x == 0) g_r16_trace[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define R16_TR_XCC() do { if (threadIdx.x == 0) { unsigned x_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x_)); g_r16_trace[blockIdx.x * 16 + 14] = 1000u + (x_ & 15); } } while (0)
 #else
 #define R16_TR(k) do {} while (0)
+#define R16_TR_XCC() do {} while (0)
 #endif
 
 constexpr int kRM = 96, kRN = 64;
@@ -919,7 +921,6 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
     // MFMA results -> VALU reads (CDNA4 ISA §4.1 "XDL write VGPR -> VALU read": do not rely on hipcc's padding, see fused_ring.hip)
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
     R16_TR(2 + kTrOff);   // tile: main loop done
-
     // Row-line epilogue (one 16-bit output, whole 64-column tiles): the results go through the (idle) ring as a [96][64] 16-bit image
     // and leave as 16-byte stores, eight consecutive lanes writing one 128-byte line of an output row.  The straight form -- every lane
     // storing its four columns of six accumulator blocks, 8 bytes at a time, 16 partial lines per instruction -- is store-ISSUE bound
@@ -1076,6 +1077,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     // (the role size rides in the preloaded arguments too: gridDim.x is a fetch from the argument block's hidden tail)
     const int n_aux_pre = PRE == 0 ? i5 : (int)((unsigned)i3 >> 16);
     R16_TR(0);
+    R16_TR_XCC();
     if ((int)blockIdx.x >= p.n_gemm) {
         const int ai = (int)blockIdx.x - p.n_gemm, an = n_aux_pre;
         if (p.role == HICOM_ROLE_MERGE_VPROJ) {

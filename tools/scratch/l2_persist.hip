@@ -41,6 +41,14 @@ __global__ __launch_bounds__(256) void touch(const char* region, unsigned long l
     if (v == 0x12345678u) sink[0] = v;
 }
 
+// one 4-byte load per `stride` bytes of the chunk (is a line filled whole by a partial touch?)
+__global__ __launch_bounds__(256) void touch_sparse(const char* region, unsigned long long bytes, unsigned stride, unsigned* sink) {
+    const char* chunk = region + xcc_id() * kChunk;
+    unsigned acc = 0;
+    for (unsigned long long off = (unsigned long long)threadIdx.x * stride; off < bytes; off += 256ull * stride) acc ^= *reinterpret_cast<const unsigned*>(chunk + off);
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 __global__ __launch_bounds__(256) void read_timed(const char* region, unsigned long long bytes, int passes, unsigned* sink, unsigned* ticks) {
     const char* chunk = region + xcc_id() * kChunk;
     unsigned v = 0;
@@ -93,6 +101,14 @@ int main() {
             hipLaunchKernelGGL(stream, dim3(256), dim3(256), 0, 0, big, (16ull << 20) / 256, sink);              // 16 MB = 2 MB through each L2
             hipLaunchKernelGGL(read_timed, dim3(256), dim3(256), 0, 0, r, bytes, 1, sink, ticks);
             report("touched two launches ago, 2 MB per L2 streamed in between", bytes);
+            for (unsigned stride : {128u, 64u, 32u}) {
+                flush();
+                hipLaunchKernelGGL(touch_sparse, dim3(256), dim3(256), 0, 0, r, bytes, stride, sink);
+                hipLaunchKernelGGL(read_timed, dim3(256), dim3(256), 0, 0, r, bytes, 1, sink, ticks);
+                char nm[96];
+                snprintf(nm, sizeof nm, "previous launch touched 4 B per %u B", stride);
+                report(nm, bytes);
+            }
             flush();
             hipLaunchKernelGGL(touch, dim3(256), dim3(256), 0, 0, r, bytes, sink);
             hipLaunchKernelGGL(stream, dim3(1024), dim3(256), 0, 0, big, (256ull << 20) / 1024, sink);          // 256 MB: beyond every L2

@@ -53,3 +53,10 @@ for k, nm in ((0, "entry"), (6, "role entered (kernargs read)"), (8, "counter re
               (5, "second layer done"), (7, "exit")):
     x = ((tr[:, n_gemm:n_gemm + 80, k] - t0) / 100.0)[:, used]
     show(nm, x.ravel())
+
+xc = tr[:, :, 14]
+have = xc >= 1000
+blk = np.arange(tr.shape[1])[None, :].repeat(tr.shape[0], 0)
+off = ((xc - 1000) - blk) % 8
+print("XCC of workgroup b minus b, mod 8 (launches x workgroups):", {int(k): int((off[have] == k).sum()) for k in range(8)})
+print("  per launch (first 8 launches), offset of block 0 / consistent within the launch:", [(int(off[r][have[r]][0]), bool((off[r][have[r]] == off[r][have[r]][0]).all())) for r in range(min(8, tr.shape[0]))])
