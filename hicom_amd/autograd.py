@@ -247,7 +247,7 @@ def _coarse_backward(inj, prefix, vis, guide, dq, grads):
     return dz * (1.0 + sc), W1.t() @ dh1
 
 
-def _query_chain_backward(stage, prefix, vis, guide, d_inj, f32, grads, want_guide, vis_param=None):
+def _query_chain_backward(stage, prefix, vis, guide, d_inj, f32, grads, want_guide, vis_param=None, want_vis=False):
     """Backward of the QUERY side of a compressor stage: the adapt_q blend (reference projector.py:541), the adapt_guide blend
     (:365 / :389) and direct / coarse / fine injection (:352-397).  These act on small tensors only -- the [Nw | 32, D] queries and
     the 1..64 guide rows, never the token stream -- and are restated here as a torch graph over fp32 leaf copies of the stage's
@@ -273,7 +273,7 @@ def _query_chain_backward(stage, prefix, vis, guide, d_inj, f32, grads, want_gui
     with torch.enable_grad():
         v = None
         if vis is not None:
-            v = vis.detach().clone().requires_grad_(vis_param is not None)
+            v = vis.detach().clone().requires_grad_(vis_param is not None or want_vis)
             vq = v
             if getattr(stage, "adapt_q", False):                                   # (1 - a) q + a LN(q W^T)  (:541; Linear without bias)
                 qa = leaf("q_alpha")
@@ -308,7 +308,7 @@ def _query_chain_backward(stage, prefix, vis, guide, d_inj, f32, grads, want_gui
         extra = []
         if g is not None and want_guide:
             extra.append(g)
-        if v is not None and vis_param is not None:
+        if v is not None and (vis_param is not None or want_vis):
             extra.append(v)
         if not wrt and not extra:
             return None, None
@@ -318,8 +318,8 @@ def _query_chain_backward(stage, prefix, vis, guide, d_inj, f32, grads, want_gui
             grads[prefix + n] = gr
     rest = list(got[len(names):])
     d_guide = rest.pop(0) if (g is not None and want_guide) else None
-    d_vis = rest.pop(0) if (v is not None and vis_param is not None) else None
-    if d_vis is not None:
+    d_vis = rest.pop(0) if (v is not None and (vis_param is not None or want_vis)) else None
+    if d_vis is not None and vis_param is not None:
         grads[prefix + vis_param] = d_vis
     return d_vis, d_guide
 
@@ -381,7 +381,7 @@ class _CompressorFn(torch.autograd.Function):
         proj = ctx.proj
         if need[1] and not _ff_grad_supported(proj):
             raise NotImplementedError("hicom_amd backward: the gradient w.r.t. frames_feature (`pure_vision_model`, reference train.py:712-715) "
-                                      "is built for the direct recipe without adaptors or clip-scale (the release recipe); detach it otherwise")
+                                      "is built without k / v adaptors and clip-scale; detach it otherwise")
         want = tuple(bool(need[7 + k]) for k in range(len(ctx.names)))
         args = (proj, ff, fe, guide, ctx.modal, nl, ctx.names, want, bool(need[2]), bool(need[3]), bool(nl is not None and need[5]))
         store = _adaptor_store(proj, ff) if ctx.adapt_serial is not None else None
@@ -423,14 +423,14 @@ class _CompressorFn(torch.autograd.Function):
 
 
 def _ff_grad_supported(proj) -> bool:
-    """d frames_feature: both stages inject the guide directly (the release recipe), no adaptors, no clip-scale -- the value-side
-    gradient of the windows is rank-1 per token and the global stage has <= 16 folded rows."""
+    """d frames_feature: every injection mode (direct, off, coarse, fine) and the query-side adaptors -- the window backward leaves the value-side
+    (and, without frames_embed, key-side) gradient per token, the pooled per-window queries send theirs back through the trilinear pooling
+    (reference projector.py:539-540), the global stage's is dS^T qt + P^T dctx.  Not with k / v adaptors (their MLPs' input gradient on the value
+    stream is not built) or clip-scale."""
     lc, gc = proj.local_compressor, proj.global_compressor
     if proj.local_logit is not None or proj.global_logit is not None:
         return False
-    if lc is not None and (lc.use_guide != "direct" or not lc.is_plain or lc.adapt_q or lc.adapt_k or lc.adapt_v):
-        return False
-    if gc is not None and (gc.use_guide != "direct" or not gc.is_plain or gc.attn_layer.num_heads > 16):
+    if lc is not None and (lc.adapt_k or lc.adapt_v):
         return False
     return True
 
@@ -743,18 +743,28 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
                 if clip is not None:
                     grads["local_logit_scale"] = dls.sum().reshape(1)       # d s_i / d ls = s_i - lb
                     grads["local_logit_bias"] = torch.zeros(1, dtype=torch.float32, device=dev)   # a shift of a window's logits: softmax cancels it
+            d_pool = None                                                   # gradient of the pooled per-window queries (d frames_feature only)
             if mode == "direct" and plain_q:
                 if want_guide:
                     d_guide += through_guide_norm(dq_w.sum(0)).reshape(d_guide.shape)
             elif mode == "coarse" and plain_q:
-                _, dg = _coarse_backward(lc.guide_injector, "local_compressor.guide_injector.", pooled, guide_q, dq_w, grads)
+                d_pool, dg = _coarse_backward(lc.guide_injector, "local_compressor.guide_injector.", pooled, guide_q, dq_w, grads)
                 if want_guide:
                     d_guide += through_guide_norm(dg).reshape(d_guide.shape)
             elif query_params or (want_guide and mode is not None):
                 d_inj = dq_w.sum(0, keepdim=True) if mode == "direct" else dq_w
-                _, dg = _query_chain_backward(lc, "local_compressor.", pooled, guide_q, d_inj, f32, grads, want_guide)
+                d_pool, dg = _query_chain_backward(lc, "local_compressor.", pooled, guide_q, d_inj, f32, grads, want_guide,
+                                                   want_vis=ff_grad is not None and mode != "direct")
                 if want_guide and dg is not None:
                     d_guide += through_guide_norm(dg).reshape(d_guide.shape)
+            elif mode is None:
+                d_pool = dq_w                                               # guide off, no query adaptor: the pooled rows ARE the queries (:544)
+            if ff_grad is not None and d_pool is not None and mode != "direct":
+                # through the trilinear pooling of frames_feature to the window grid (reference :539-540: F.interpolate(size = grid, 'trilinear')):
+                # its adjoint on a [1, E, t', h', w'] cotangent (an ATen library call on a window-count sized tensor), added to the value-side share
+                g5 = d_pool.reshape(*grid, E).permute(3, 0, 1, 2).unsqueeze(0).contiguous().float()
+                dpf = torch.ops.aten.upsample_trilinear3d_backward(g5, list(grid), [1, E, T, H, W], False, None, None, None)
+                ff_grad["d_ff"] = (ff_grad["d_ff"].float() + dpf[0].permute(1, 2, 3, 0)).to(ff.dtype)
     if gc is not None:
         att = gc.attn_layer
         nh, hd = att.num_heads, att.head_dim
@@ -832,7 +842,14 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
                 have = ff_grad.get("d_ff") is not None
                 if not have:
                     ff_grad["d_ff"] = torch.empty_like(ff)
-                nv.global_dx(scores, ds, ml, qt_, dctx, N, ff_grad["d_ff"].view(N, E), accumulate=have)
+                if R <= 16 and E <= 1280:
+                    nv.global_dx(scores, ds, ml, qt_, dctx, N, ff_grad["d_ff"].view(N, E), accumulate=have)
+                else:
+                    # 32 distinct queries x heads (guide off / coarse / fine): a [N, 2 R] x [2 R, E] product -- plain library GEMMs
+                    pr = torch.exp(scores[:R, :N] - ml[:, 0:1]) / ml[:, 1:2]
+                    dxg = ds[:R, :N].t() @ qt_ + pr.t() @ dctx
+                    cur = ff_grad["d_ff"].view(N, E)
+                    cur.copy_(dxg + cur.float() if have else dxg)
             if pe is not None:
                 dS = ds[:R, :N].view(R, T, H, W)
                 mT, mY, mX = dS.sum((2, 3)), dS.sum((1, 3)), dS.sum((1, 2))

@@ -1459,7 +1459,7 @@ static int readout16_launch(const void* a, const void* w, const void* b, int32_t
     // (HICOM_R16_PRE=0: dev A/B switch -- the chain launch with the tiles' arguments preloaded, like every other launch)
     static const bool pre_role = !(getenv("HICOM_R16_PRE") && getenv("HICOM_R16_PRE")[0] == '0');
     if (p.tm == 192 || p.tn == 128) {
-    } else if (pre_role && p.role == HICOM_ROLE_GEMV_CHAIN && p.n_gemm > 0 && p.n_gemm < 65536 && p.aux.N < 65536 && p.aux2.N < 65536)
+    } else if (pre_role && p.role == HICOM_ROLE_GEMV_CHAIN && p.n_gemm >= 0 && p.n_gemm < 65536 && p.aux.N < 65536 && p.aux2.N < 65536)
         HICOM_LAUNCH((readout16_gemm_kernel<8, 64, 96, 1>), grid, dim3(256), 8 * kRStage, (hipStream_t)stream, (const void*)p.chain_state, (const void*)p.aux.x_fixed,
                      (const void*)p.aux.w, (const void*)p.aux2.w, p.aux.K, p.aux.N | (p.aux2.N << 16), p.cg_cpw1 | (p.cg_cpw2 << 16), p.n_gemm | (n_aux << 16),
                      p.role | ((p.aux.w_f32 ? 1 : 0) << 8), p.cg_r1 | (p.cg_r2 << 16), p);
