@@ -381,7 +381,7 @@ class _CompressorFn(torch.autograd.Function):
         proj = ctx.proj
         if need[1] and not _ff_grad_supported(proj):
             raise NotImplementedError("hicom_amd backward: the gradient w.r.t. frames_feature (`pure_vision_model`, reference train.py:712-715) "
-                                      "is built without k / v adaptors and clip-scale; detach it otherwise")
+                                      "is not built beside clip-scale; detach it otherwise")
         want = tuple(bool(need[7 + k]) for k in range(len(ctx.names)))
         args = (proj, ff, fe, guide, ctx.modal, nl, ctx.names, want, bool(need[2]), bool(need[3]), bool(nl is not None and need[5]))
         store = _adaptor_store(proj, ff) if ctx.adapt_serial is not None else None
@@ -425,12 +425,10 @@ class _CompressorFn(torch.autograd.Function):
 def _ff_grad_supported(proj) -> bool:
     """d frames_feature: every injection mode (direct, off, coarse, fine) and the query-side adaptors -- the window backward leaves the value-side
     (and, without frames_embed, key-side) gradient per token, the pooled per-window queries send theirs back through the trilinear pooling
-    (reference projector.py:539-540), the global stage's is dS^T qt + P^T dctx.  Not with k / v adaptors (their MLPs' input gradient on the value
-    stream is not built) or clip-scale."""
+    (reference projector.py:539-540), the global stage's is dS^T qt + P^T dctx; with k / v adaptors the streams' input gradients come out of
+    the adaptor MLPs' backward (their skip path included).  Not with clip-scale."""
     lc, gc = proj.local_compressor, proj.global_compressor
     if proj.local_logit is not None or proj.global_logit is not None:
-        return False
-    if lc is not None and (lc.adapt_k or lc.adapt_v):
         return False
     return True
 
@@ -701,17 +699,21 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
                 L = "local_compressor."
                 qf = qc.float().reshape(1 if shared_q else nw, E)
                 d_kx = None
+                # the key stream's input gradient is wanted for d frames_embed, or -- without frames_embed the keys are frames_feature rows
+                # (reference :532) -- for d frames_feature
+                want_kx = (want_fe and fe is not None) or (ff_grad is not None and fe is None)
+                if ff_grad is not None and not exact:
+                    raise NotImplementedError("hicom_amd backward: d frames_feature needs an exact window partition")
                 if lc.adapt_k:
                     ak, gk = lc.k_alpha.detach().float(), f32[L + "k_norm.weight"]
                     dq_w = (1.0 - ak) * sxk + ak * gk * syk
                     grads[L + "k_alpha"] = (qf * (gk * syk - sxk)).sum().reshape(1)
                     grads[L + "k_norm.weight"] = ak * (qf * syk).sum(0)
                     grads[L + "k_norm.bias"] = torch.zeros(E, dtype=torch.float32, device=dev)    # a k sum_w q_w sum_n dS_n: the dS of a window sum to zero
-                    d_kx = _adaptor_mlp_backward(kx2, lc.k_proj, lc.k_norm, lc.k_alpha, rec_k, ds, qc, q_stride, axes, L, "k", grads,
-                                                 want_fe and fe is not None)
+                    d_kx = _adaptor_mlp_backward(kx2, lc.k_proj, lc.k_norm, lc.k_alpha, rec_k, ds, qc, q_stride, axes, L, "k", grads, want_kx)
                 else:
                     dq_w = sxk
-                    if want_fe and fe is not None:
+                    if want_kx:
                         # plain key stream beside a value adaptor: d key_n = ds_n q_w, written by the rank-1 branch of hicom_adapt_dy_fwd (alpha = 0)
                         d_kx = torch.empty((N, E), dtype=torch.bfloat16, device=dev)
                         junk = torch.empty((N, E), dtype=torch.bfloat16, device=dev)
@@ -723,9 +725,21 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
                     grads[L + "v_alpha"] = (dctx_l * (gv * syv + bvv - sxv)).sum().reshape(1)
                     grads[L + "v_norm.weight"] = av * (dctx_l * syv).sum(0)
                     grads[L + "v_norm.bias"] = av * dctx_l.sum(0)
-                    _adaptor_mlp_backward(vx2, lc.v_proj, lc.v_norm, lc.v_alpha, rec_v, pw, dctx_l, E, axes, L, "v", grads, False)
+                    d_vx = _adaptor_mlp_backward(vx2, lc.v_proj, lc.v_norm, lc.v_alpha, rec_v, pw, dctx_l, E, axes, L, "v", grads, ff_grad is not None)
+                elif ff_grad is not None:
+                    # plain value stream beside a key adaptor: d value_n = p_n dctx_w, the rank-1 branch of hicom_adapt_dy_fwd (alpha = 0)
+                    d_vx = torch.empty((N, E), dtype=torch.bfloat16, device=dev)
+                    junk = torch.empty((N, E), dtype=torch.bfloat16, device=dev)
+                    nv.adapt_dy(rec_k[2], lc.k_norm.weight.detach(), dctx_l, E, pw, torch.zeros(1, dtype=torch.float32, device=dev), axes, junk, d_vx,
+                                eps=lc.k_norm.eps)
+                    del junk
                 if want_fe and fe is not None:
                     d_fe = d_kx.to(fe.dtype).view(fe.shape)
+                if ff_grad is not None:
+                    # d frames_feature, local share: the value stream's input gradient (through the v adaptor's MLP and its skip path) and --
+                    # without frames_embed -- the key stream's
+                    dff = d_vx.float() + d_kx.float() if fe is None else d_vx
+                    ff_grad["d_ff"] = dff.to(ff.dtype).view(ff.shape)
             else:
                 dq_w = torch.empty((nw, E), dtype=torch.float32, device=dev)
                 if want_fe and fe is not None:

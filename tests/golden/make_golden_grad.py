@@ -111,7 +111,9 @@ def clip_local_grads(proj, blobs3):
 
 FF_GRAD_CASES = ["G1_direct_T8", "G9_local_only", "G9_global_only", "G4_direct_T1", "G10_peaky_direct", "G12_clip768_direct",
                  # every other injection mode: guide off (pooled per-window queries, 32 learnable global queries), coarse, fine, a mixed override
-                 "G2_off_T8", "G2b_off_string", "G6_coarse", "G7_fine", "G7b_guide_override", "G12b_clip768_off"]
+                 "G2_off_T8", "G2b_off_string", "G6_coarse", "G7_fine", "G7b_guide_override", "G12b_clip768_off",
+                 # k / v adaptors (the second released recipe) and every adaptor at once
+                 "G5_adaptkv", "G5b_adaptqkvg_off"]
 
 
 def ff_grads(proj, blobs3):

@@ -179,14 +179,16 @@ def test_clip_scale_local_gradients_match_reference_autograd(name):
 
 
 @pytest.mark.parametrize("name", ["G1_direct_T8", "G9_local_only", "G9_global_only", "G4_direct_T1", "G10_peaky_direct", "G12_clip768_direct",
-                                  "G2_off_T8", "G2b_off_string", "G6_coarse", "G7_fine", "G7b_guide_override", "G12b_clip768_off"])
+                                  "G2_off_T8", "G2b_off_string", "G6_coarse", "G7_fine", "G7b_guide_override", "G12b_clip768_off",
+                                  "G5_adaptkv", "G5b_adaptqkvg_off"])
 @pytest.mark.parametrize("with_fe", [True, False])
 def test_frames_feature_gradient_matches_reference_autograd(name, with_fe):
     """Round 6 (verdict r5 missing #3): d frames_feature -- `pure_vision_model` trains the tower body (reference train.py:712-715) -- for
     every injection mode: the value-side gradient of the windows (p_n dctx_w, out of the window backward kernel; without frames_embed the
     key-side gradient of the same rows too, projector.py:532) plus the global stage's sum_r dS[r, n] qt_r + p[r, n] dctx_r
     (hicom_global_dx_fwd for the direct recipe's <= 16 folded rows, two library GEMMs for 32 queries x heads) plus -- guide off / coarse / fine: the
-    per-window queries are pooled from frames_feature, :539-540 -- the query gradient through the trilinear pooling.  Against the reference's own autograd (golden_grad_v3.npz), bf16 result: 2^-7 of the largest entry + the
+    per-window queries are pooled from frames_feature, :539-540 -- the query gradient through the trilinear pooling; with k / v adaptors the streams' input
+    gradients out of the adaptor MLPs' backward.  Against the reference's own autograd (golden_grad_v3.npz), bf16 result: 2^-7 of the largest entry + the
     gradient tolerance; the parameter gradients of the same backward are unchanged (bit-equal to a backward without the input gradient)."""
     import make_golden_grad as mg
     z = np.load(os.path.join(ROOT, "tests", "golden", "golden_grad_v3.npz"))
@@ -219,8 +221,8 @@ def test_frames_feature_gradient_matches_reference_autograd(name, with_fe):
 
 
 def test_unsupported_recipes_and_input_grads_refuse():
-    """clip-scale on the GLOBAL stage has no backward (the local stage's: round 6, test above); the gradient w.r.t. frames_feature is not built beside k / v adaptors
-    (every injection mode without them: round 6, test above), nor are input gradients over overlapping windows: all must raise, never return a detached tensor or a silent None.  (Guide off: d frames_embed exists since
+    """clip-scale on the GLOBAL stage has no backward (the local stage's: round 6, test above); input gradients over overlapping windows are not built
+    (d frames_feature for every recipe on exact partitions: round 6, test above): all must raise, never return a detached tensor or a silent None.  (Guide off: d frames_embed exists since
     round 5 -- fixture golden_grad_v2 -- and d guide_embed is None, as in the reference: the guide does not enter that forward.)"""
     import hicom_amd
     case = cases.build_case("G8_clip_scale")
@@ -231,7 +233,7 @@ def test_unsupported_recipes_and_input_grads_refuse():
     m.set_clip_logits(local=case.logit["local"], glob=case.logit["glob"])
     with pytest.raises(NotImplementedError):
         m(dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g), case.modal, None)
-    for name, which in (("G3_direct_T7", "fe"), ("G3_direct_T7", "ff"), ("G5_adaptkv", "ff")):
+    for name, which in (("G3_direct_T7", "fe"), ("G3_direct_T7", "ff")):
         case = cases.build_case(name)
         m = build_module(case).train()
         t = {"ff": dev_bf16(case.ff), "fe": dev_bf16(case.fe), "g": dev_bf16(case.g)}
