@@ -659,8 +659,8 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
             # ---- attention backward of the windows: dq per window, d key stream, d value stream -------------------------
             from . import injector as inj
             exact = all(a.nwin * a.k == a.n for a in (at, ay, ax))
-            if (want_fe or adapt) and not exact:
-                raise NotImplementedError("hicom_amd backward: d frames_embed / the adaptor gradients need an exact window "
+            if adapt and not exact:
+                raise NotImplementedError("hicom_amd backward: the adaptor gradients need an exact window "
                                           f"partition (T, H, W = {T}, {H}, {W} against kernel {at.k}, {ay.k}, {ax.k})")
             axes = tuple(nv.Axis(a.n, a.k, a.nwin, a.nfull) for a in (at, ay, ax))
             dctx_l = (dpre @ W0).contiguous()
@@ -749,9 +749,7 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
                 if ff_grad is not None:
                     # d frames_feature, local share: dv_n = p_n dctx_w (rank 1 per token, written by the same window backward); without
                     # frames_embed the keys are these rows too (projector.py:532) and their gradient is added in
-                    if not exact:
-                        raise NotImplementedError("hicom_amd backward: d frames_feature needs an exact window partition")
-                    d_ffl = ff_grad["d_ff"] = torch.empty_like(ff)
+                    d_ffl = ff_grad["d_ff"] = torch.empty_like(ff)      # (overlapping windows: the kernel accumulates per parity class, csrc/local_attn.hip)
                 nv.local_attn_bwd(key, ff, axes, q, 0 if mode == "direct" else E, scale, bias, dctx_l, dq_w, d_fe, l2norm_key=l2k, dls=dls,
                                   dvalue=d_ffl, value_is_key=(d_ffl is not None and fe is None))
                 if clip is not None:

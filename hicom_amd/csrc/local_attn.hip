@@ -426,7 +426,18 @@ struct LocalBwdParams {
     // projector.py:532): the key-side gradient of the same row is added in, d x_i = p_i dctx_w + dk_i.
     uint16_t* dvalue;
     int value_is_key;
+    // Overlapping windows (an axis the kernel does not divide: reference projector.py:501-522 shifts the trailing windows by k - 1, so a window
+    // shares ONE plane of tokens with its predecessor): the per-token outputs are then ACCUMULATED (read-modify-write of the bf16 rows, cleared by
+    // the host), one launch per parity class of the window index along every such axis -- windows of one class never share a token, so the
+    // sums are ordered by the launches: deterministic, no atomics.  par_mask: bit a set = axis a (t, y, x) is filtered; par_val: the class.
+    int accumulate, par_mask, par_val;
 };
+
+__device__ __forceinline__ void seg12_add(float (&e)[6], const uint16_t* o) {
+    const Seg12 w = *reinterpret_cast<const Seg12*>(o);
+    e[0] += bf16lo_to_f32(w.a); e[1] += bf16hi_to_f32(w.a); e[2] += bf16lo_to_f32(w.b); e[3] += bf16hi_to_f32(w.b);
+    e[4] += bf16lo_to_f32(w.c); e[5] += bf16hi_to_f32(w.c);
+}
 
 template <int NV>
 __global__ __launch_bounds__(256) void local_attn_bwd_kernel(LocalBwdParams p) {
@@ -449,6 +460,7 @@ __global__ __launch_bounds__(256) void local_attn_bwd_kernel(LocalBwdParams p) {
     const int t1 = win / (p.ax.nwin * p.ay.nwin);
     const int t0 = axis_start(p.at, t1), y0 = axis_start(p.ay, h1), x0 = axis_start(p.ax, w1);
     const int H = p.ay.n, W = p.ax.n;
+    if ((((t1 & 1) | ((h1 & 1) << 1) | ((w1 & 1) << 2)) & p.par_mask) != p.par_val) return;      // (another launch's parity class)
 
     float q[NV][6], g[NV][6];
     if (p.query_f32) {
@@ -565,6 +577,7 @@ __global__ __launch_bounds__(256) void local_attn_bwd_kernel(LocalBwdParams p) {
                         float e[6];
 #pragma unroll
                         for (int j = 0; j < 6; ++j) e[j] = fmaf(dsk, q[s][j], -kc * k[u][s][j]);
+                        if (p.accumulate) seg12_add(e, o + 384 * s + 6 * lane);
                         Seg12 w;
                         w.a = f32_to_bf16(e[0]) | ((uint32_t)f32_to_bf16(e[1]) << 16);
                         w.b = f32_to_bf16(e[2]) | ((uint32_t)f32_to_bf16(e[3]) << 16);
@@ -583,6 +596,7 @@ __global__ __launch_bounds__(256) void local_attn_bwd_kernel(LocalBwdParams p) {
                             e[j] = pi_ * g[s][j];
                             if (p.value_is_key) e[j] += fmaf(dsk, q[s][j], -kc * k[u][s][j]);
                         }
+                        if (p.accumulate) seg12_add(e, o + 384 * s + 6 * lane);
                         Seg12 w;
                         w.a = f32_to_bf16(e[0]) | ((uint32_t)f32_to_bf16(e[1]) << 16);
                         w.b = f32_to_bf16(e[2]) | ((uint32_t)f32_to_bf16(e[3]) << 16);
@@ -1192,20 +1206,36 @@ extern "C" int hicom_local_attn_bwd(const void* key, const void* value, int32_t 
                       HICOM_EINVAL, "local_attn_bwd: bad axis n=%d k=%d nwin=%d nfull=%d", a->n, a->k, a->nwin, a->nfull);
         const int last = axis_start(*a, a->nwin - 1);
         HICOM_REQUIRE(last >= 0 && last + a->k <= a->n, HICOM_EINVAL, "local_attn_bwd: window runs off the axis");
-        // dkey is written with plain stores: windows must not overlap
-        if (dkey || dvalue) HICOM_REQUIRE((long)a->nwin * a->k == a->n, HICOM_EUNSUP, "local_attn_bwd: dkey / dvalue need an exact window partition (n=%d k=%d)", a->n, a->k);
     }
     const long win = (long)at.k * ay.k * ax.k;
     HICOM_REQUIRE(win <= 4096, HICOM_EUNSUP, "local_attn_bwd: window of %ld tokens is too large", win);
     const long nwin = (long)at.nwin * ay.nwin * ax.nwin;
     HICOM_REQUIRE(nwin < (1L << 31), HICOM_EINVAL, "local_attn_bwd: too many windows");
     LocalBwdParams p{(const uint16_t*)key, (const uint16_t*)value, query, query_dt == HICOM_DT_F32, (long)query_stride, at, ay, ax,
-                     scale, bias, dctx, dq, (uint16_t*)dkey, l2norm_key ? 1 : 0, dls, (uint16_t*)dvalue, value_is_key ? 1 : 0};
+                     scale, bias, dctx, dq, (uint16_t*)dkey, l2norm_key ? 1 : 0, dls, (uint16_t*)dvalue, value_is_key ? 1 : 0, 0, 0, 0};
     HICOM_REQUIRE(!(value_is_key && dkey), HICOM_EINVAL, "local_attn_bwd: value_is_key writes the summed gradient to dvalue (dkey must be NULL)");
     const size_t smem = 5 * (((size_t)win + 3) & ~(size_t)3) * 4 + 4 * (size_t)D * 4;
     hipStream_t s = (hipStream_t)stream;
-    if (D == 1152) hipLaunchKernelGGL(local_attn_bwd_kernel<3>, dim3((unsigned)nwin), dim3(256), smem, s, p);
-    else hipLaunchKernelGGL(local_attn_bwd_kernel<2>, dim3((unsigned)nwin), dim3(256), smem, s, p);
+    // per-token outputs over OVERLAPPING windows: cleared, then one accumulating launch per parity class of the axes that overlap
+    int mask = 0;
+    if (dkey || dvalue) {
+        const hicom_axis* axs[3] = {&at, &ay, &ax};
+        for (int a = 0; a < 3; ++a)
+            if ((long)axs[a]->nwin * axs[a]->k != axs[a]->n) mask |= 1 << a;
+    }
+    if (mask) {
+        const size_t bytes = (size_t)at.n * ay.n * ax.n * D * 2;
+        if (dkey) HICOM_REQUIRE(hipMemsetAsync(dkey, 0, bytes, s) == hipSuccess, HICOM_ELAUNCH, "local_attn_bwd: memset");
+        if (dvalue) HICOM_REQUIRE(hipMemsetAsync(dvalue, 0, bytes, s) == hipSuccess, HICOM_ELAUNCH, "local_attn_bwd: memset");
+        p.accumulate = 1;
+        p.par_mask = mask;
+    }
+    for (int val = 0; val < 8; ++val) {
+        if (val & ~mask) continue;
+        p.par_val = val;
+        if (D == 1152) hipLaunchKernelGGL(local_attn_bwd_kernel<3>, dim3((unsigned)nwin), dim3(256), smem, s, p);
+        else hipLaunchKernelGGL(local_attn_bwd_kernel<2>, dim3((unsigned)nwin), dim3(256), smem, s, p);
+    }
     return hicom_host::check_launch("local_attn_bwd");
 }
 

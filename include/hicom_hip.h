@@ -119,7 +119,9 @@ int hicom_colsum_fwd(const void* x_bf16, int64_t N, int32_t D, float* parts, int
  * w.r.t. the key stream frames_embed and the query are needed.
  *   key, value : bf16 [T,H,W,D];  query as in hicom_local_attn_fwd;  dctx : f32 [Nw, D] upstream gradient of ctx
  *   dq         : f32 [Nw, D]  scale * sum_i dS_i k_i per window (a shared query's gradient is the sum over windows)
- *   dkey       : bf16 [T,H,W,D] scale * dS_i * q, or NULL; needs an exact window partition (plain stores)
+ *   dkey       : bf16 [T,H,W,D] scale * dS_i * q, or NULL.  Where the kernel does not divide an axis the trailing windows overlap by one plane
+ *                (projector.py:501-522): dkey / dvalue are then cleared and accumulated by one launch per parity class of the window index along
+ *                every such axis (windows of one class share no token: ordered sums, no atomics)
  *   l2norm_key (ABI 15): clip-scale on the local stage (projector.py:527-529, :549; trainable under `attn_scale`, train.py:730-733):
  *                the key rows enter L2-normalised, s_i = scale (q . k_i / ||k_i||) + bias with scale = e^logit_scale, bias = logit_bias;
  *                dq and dkey then go through the normalisation.  The query is used as given (the caller normalises the guide).

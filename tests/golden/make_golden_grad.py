@@ -113,7 +113,9 @@ FF_GRAD_CASES = ["G1_direct_T8", "G9_local_only", "G9_global_only", "G4_direct_T
                  # every other injection mode: guide off (pooled per-window queries, 32 learnable global queries), coarse, fine, a mixed override
                  "G2_off_T8", "G2b_off_string", "G6_coarse", "G7_fine", "G7b_guide_override", "G12b_clip768_off",
                  # k / v adaptors (the second released recipe) and every adaptor at once
-                 "G5_adaptkv", "G5b_adaptqkvg_off"]
+                 "G5_adaptkv", "G5b_adaptqkvg_off",
+                 # window partitions that do not divide the axes (T = 7 under a temporal kernel of 4; 7 x 7 under 2 x 2: the trailing windows overlap)
+                 "G3_direct_T7", "G9_local22"]
 
 
 def ff_grads(proj, blobs3):

@@ -786,8 +786,8 @@ def test_fused_stream_clears_the_scratch_it_is_given():
 
 @pytest.mark.parametrize("T,H,W,kt,ks,shared_query", [(8, 6, 6, 4, 3, True), (7, 7, 5, 4, 3, False), (4, 6, 6, 4, 3, False)])
 def test_local_attn_bwd_matches_torch_autograd(T, H, W, kt, ks, shared_query):
-    """dq per window (any geometry, overlapping windows included) and d key (exact partitions) of the windowed attention against
-    torch autograd on the oracle's window gather (double precision)."""
+    """dq per window and d key of the windowed attention -- any geometry, overlapping windows included (round 6: d key accumulated over the
+    shared planes by one launch per parity class) -- against torch autograd on the oracle's window gather (double precision)."""
     x = synth.synth_inputs(T, H, W, D, tag=f"lb{T}{H}{W}")
     at, ay, ax = geo.axis_tiling(T, kt), geo.axis_tiling(H, ks), geo.axis_tiling(W, ks)
     axes = tuple(nv.Axis(a.n, a.k, a.nwin, a.nfull) for a in (at, ay, ax))
@@ -811,7 +811,7 @@ def test_local_attn_bwd_matches_torch_autograd(T, H, W, kt, ks, shared_query):
     dctx = torch.from_numpy(synth.normal_like((nw, D), 78)).cuda()
     (ctx * dctx.double()).sum().backward()
     dq = f32((nw, D))
-    dkey = torch.zeros_like(kb) if exact else None
+    dkey = torch.full_like(kb, 3.0)                                                  # (stale content: the overlap path clears it itself)
     nv.local_attn_bwd(kb, vb, axes, qd.reshape(-1) if shared_query else qd, 0 if shared_query else D, scale, 0.0, dctx, dq, dkey)
     torch.cuda.synchronize()
     want_dq = q.grad if not shared_query else None
@@ -819,12 +819,16 @@ def test_local_attn_bwd_matches_torch_autograd(T, H, W, kt, ks, shared_query):
         assert maxabs(dq.sum(0), q.grad.reshape(-1)) <= 2e-5 * max(1.0, float(q.grad.abs().max()))
     else:
         assert maxabs(dq, want_dq) <= 2e-5 * max(1.0, float(want_dq.abs().max()))
-    if exact:
-        mx = float(key.grad.abs().max())
-        assert maxabs(dkey.float().reshape(-1, D), key.grad) <= 2 ** -8 * mx + 1e-7       # bf16 store of the fp32 value
-    else:
-        with pytest.raises(nv.HicomNativeError):
-            nv.local_attn_bwd(kb, vb, axes, qd, D, scale, 0.0, dctx, dq, torch.zeros_like(kb))
+    mx = float(key.grad.abs().max())
+    # bf16 store of the fp32 value; a token shared by up to 8 windows is rounded once per contribution
+    assert maxabs(dkey.float().reshape(-1, D), key.grad) <= (2 ** -8 if exact else 2 ** -6) * mx + 1e-7
+    # d value = p_i dctx_w, with the key gradient added where the keys ARE the value rows
+    dv = torch.full_like(kb, -2.0)
+    nv.local_attn_bwd(vb, vb, axes, qd.reshape(-1) if shared_query else qd, 0 if shared_query else D, scale, 0.0, dctx, dq, None, dvalue=dv, value_is_key=True)
+    v2 = vb.double().reshape(-1, D).requires_grad_(True)
+    s2 = torch.einsum("wd,wnd->wn", qw.detach(), v2[idx]) * scale
+    (torch.einsum("wn,wnd->wd", torch.softmax(s2, dim=1), v2[idx]) * dctx.double()).sum().backward()
+    assert maxabs(dv.float().reshape(-1, D), v2.grad) <= (2 ** -8 if exact else 2 ** -6) * float(v2.grad.abs().max()) + 1e-7
 
 
 def test_small_op_dispatch_boundaries_random_sweep():
