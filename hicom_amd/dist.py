@@ -25,6 +25,8 @@ from typing import Optional, Tuple
 import torch
 import torch.distributed as dist
 
+from .events import device_event
+
 
 @dataclass(frozen=True)
 class FrameShardPlan:
@@ -196,46 +198,6 @@ def _rccl_comm(group, dev, world) -> Optional[int]:
     return ptr
 
 
-class _RawEvent:
-    """A HIP event created with hipEventDisableTiming | hipEventDisableSystemFence: ordering between two streams of ONE device (STREAM block ->
-    comm stream).  torch.cuda.Event() cannot ask for the second flag, and without it the event's completion performs a system-scope fence in front
-    of the NEXT launch of the recording stream (tools/shard_trace.py: a 5-6-us gap between readout GEMM 2 and the next step's query prep)."""
-    _hip = None
-
-    def __init__(self):
-        import ctypes
-        if _RawEvent._hip is None:
-            _RawEvent._hip = ctypes.CDLL("libamdhip64.so")
-        h = ctypes.c_void_p()
-        rc = _RawEvent._hip.hipEventCreateWithFlags(ctypes.byref(h), ctypes.c_uint(0x2 | 0x20000000))
-        if rc != 0 or not h.value:
-            raise RuntimeError(f"hipEventCreateWithFlags failed ({rc})")
-        self.cuda_event = h.value
-
-    def record(self, stream):
-        import ctypes
-        rc = _RawEvent._hip.hipEventRecord(ctypes.c_void_p(self.cuda_event), ctypes.c_void_p(stream.cuda_stream))
-        if rc != 0:
-            raise RuntimeError(f"hipEventRecord failed ({rc})")
-
-    def __del__(self):
-        try:
-            import ctypes
-            _RawEvent._hip.hipEventDestroy(ctypes.c_void_p(self.cuda_event))
-        except Exception:  # noqa: BLE001  (interpreter shutdown)
-            pass
-
-
-def _device_event():
-    import os
-    if os.environ.get("HICOM_SHARD_EVENT_NOFENCE", "1") == "0":
-        return torch.cuda.Event()
-    try:
-        return _RawEvent()
-    except Exception:  # noqa: BLE001  (no libamdhip64 by that name: the torch event does the same job with the fence)
-        return torch.cuda.Event()
-
-
 def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_newline, group, rank=None, world=None,
                 collective=None) -> _ShardPlan:
     """Plan of one (problem shape, rank, world, caller stream, weight state): `_N_SETS` buffer sets, each with its own argument
@@ -320,7 +282,7 @@ def _shard_plan(projector, ff_shard, fe_shard, guide_embed, total_frames, image_
         plan.guide_fields = st.a_stream._guide_ptr_fields
         st.a_stream._keep = st.a_finish._keep = None
         st.out = torch.empty((plan.n_rows_total, hidden), dtype=odt, device=dev)
-        st.ev_stream, st.ev_tok = _device_event(), torch.cuda.Event()
+        st.ev_stream, st.ev_tok = device_event(), torch.cuda.Event()      # (ev_stream: stream-to-stream on this device -- no system-scope fence, events.py)
         st.ev_stream.record(cur)                   # (hipEventRecord from C needs created events)
         st.ev_tok.record(cur)
         # what follows each phase on its stream rides in the same C call (every separate host call is 3-6 us and the

@@ -17,6 +17,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import native as nv
+from .events import device_event
 
 
 class _DeviceResources:
@@ -24,9 +25,10 @@ class _DeviceResources:
         # high priority: the global chain is a string of small kernels that must not queue behind the
         # thousands of workgroups of the local streaming kernel
         self.side = torch.cuda.Stream(device=device, priority=-1)
-        self.ev_fork = torch.cuda.Event()
-        self.ev_join = torch.cuda.Event()
-        self.ev_merge = torch.cuda.Event()
+        # (stream-to-stream ordering on one device: events without the system-scope fence, events.py)
+        self.ev_fork = device_event()
+        self.ev_join = device_event()
+        self.ev_merge = device_event()
         # hipEventRecord needs created events: torch creates them lazily on first record
         cur = torch.cuda.current_stream(device)
         self.ev_fork.record(cur)
@@ -34,7 +36,7 @@ class _DeviceResources:
         self.ev_merge.record(cur)
         # injected local queries (coarse / fine / adapt_q recipes) are made on a stream of their own, beside the global stage's stream kernel
         self.inj = torch.cuda.Stream(device=device, priority=-1)
-        self.ev_lq = torch.cuda.Event()
+        self.ev_lq = device_event()
         self.ev_lq.record(cur)
         self.done = [torch.cuda.Event() for _ in range(16)]     # per-call completion events of deferred forwards
         for ev in self.done:

@@ -1107,7 +1107,7 @@ def _two_stream_forward(self, frames_feature, frames_embed, guide_embed, modal, 
     res = engine._resources(dev)
     main = torch.cuda.current_stream(dev)
     res.ev_fork.record(main)
-    res.side.wait_event(res.ev_fork)
+    res.ev_fork.wait(res.side)
     with torch.cuda.stream(res.side):
         ctx, _ = lc.window_context(ff, frames_embed, guide_embed, modal, *self._logit_args("local"))
         _keep_train_ctx(lc, ctx)
@@ -1123,7 +1123,7 @@ def _two_stream_forward(self, frames_feature, frames_embed, guide_embed, modal, 
         if isinstance(t, torch.Tensor):
             t.record_stream(res.side)
     gc.forward_into(ff, guide_embed, self._logit_args("global")[0], out, lay.n_rows, self._logit_args("global")[1])
-    main.wait_event(res.ev_join)
+    res.ev_join.wait(main)
     return out
 
 
