@@ -145,6 +145,31 @@ N_INPUT_SETS = 3      # distinct (frames_feature, frames_embed, guide) sets rota
                       # GPU do not fit the 256 MiB Infinity Cache, so every step reads its inputs from HBM
 
 
+def dist_parity(module, shard_inputs, sharded_out, total_frames, world, device):
+    """N > 1 (and the forced world-1 branch): the frame-sharded step against the PLAIN forward of the whole clip on this rank -- every rank's
+    shard of the first input set gathered with torch.distributed, one un-sharded call, max-abs difference of the two results.  The reference
+    never shards a video; this is what says the sharded step computes the same tokens.  Never fatal: a failure is reported in the line."""
+    try:
+        import torch.distributed as dist
+        ff, fe, g = shard_inputs
+        full = []
+        for t in (ff, fe):
+            buf = torch.empty((world * t.shape[0], *t.shape[1:]), dtype=t.dtype, device=device)
+            dist.all_gather_into_tensor(buf, t.contiguous())
+            full.append(buf)
+        want = module(full[0], full[1], g, "video", None)
+        torch.cuda.synchronize()
+        d = float((want.float() - sharded_out.float()).abs().max())
+        t = torch.tensor([d], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        del full, want
+        torch.cuda.empty_cache()
+        return {"max_abs_vs_unsharded_forward": float(t.item()), "frames": int(total_frames), "ok": bool(t.item() <= 2e-2),
+                "note": "same guide on every rank (the step's first input set); tolerance 2e-2 = the tests' path tolerance for bf16 rows"}
+    except Exception as e:                                     # noqa: BLE001
+        return {"skipped": f"{type(e).__name__}: {e}"}
+
+
 def spawn_ranks(args, child_cmd=None, n_devices=None, timeout_s: float = 1500.0) -> int:
     """`python bench.py --gpus N` (N > 1) without a launcher: start N fresh child processes, one per GPU, BEFORE this
     process has touched the GPU (a process that has initialised HIP must not be re-exec'ed; device_count() does not
@@ -304,8 +329,29 @@ def main():
         # sharded path -- sharded_forward(deferred=True), the token exchange of step i under the streaming of step i + 1,
         # same rotating inputs, fence() waits for every stream of every rank -- and the joined latency is reported beside it
         headline = step_pipelined if distributed else step
+        dist_guard = None
+        if distributed:
+            # The sharded step enqueues RCCL's all-gather itself (hicom_amd/dist.py: the process group's own communicator).  First call under a
+            # guard every rank agrees on: if that path fails on ANY rank, all of them fall back to torch.distributed's all-gather between two C
+            # calls (HICOM_SHARD_DIRECT_AG=0) -- a slower line, not a lost one.
+            ok = 1
+            try:
+                out = step()
+                torch.cuda.synchronize()
+            except Exception as e:                             # noqa: BLE001
+                ok = 0
+                print(f"bench.py: rank {rank}: direct all-gather path failed ({type(e).__name__}: {e}); falling back to torch.distributed", file=sys.stderr)
+            flag = torch.tensor([ok], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            dist_guard = {"direct_all_gather": bool(flag.item())}
+            if not flag.item():
+                os.environ["HICOM_SHARD_DIRECT_AG"] = "0"
+                for pl in module.__dict__.pop("_shard_plans", {}).values():
+                    pl.release()
         out = step()
         assert out.shape == (n_out, args.hidden)
+        if distributed:
+            dist_guard["parity"] = dist_parity(module, sets[0], sharded_forward(module, *sets[0], total_frames), total_frames, world, device)
         # ---- pre-warm-up: convergence rule (PREWARM_* above); every rank follows rank 0's decision ----
         t_pw = time.perf_counter()
         windows = []
@@ -418,6 +464,7 @@ def main():
         "input_visual_tokens_per_sec": total_frames * GRID * GRID / (ms_per_step * 1e-3),
         "whole_step_hbm_frac": (alg_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if args.hidden == 896 else None,
         **extras,
+        **({"sharded_step": dist_guard} if dist_guard is not None else {}),
         "handoff_failures": handoff,
         "roofline": roofline,
     }
