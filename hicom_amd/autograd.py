@@ -47,8 +47,8 @@ def _sum0(x):
 
 
 def _supported(proj) -> bool:
-    """Every injection mode and adaptor, clip-scale on the LOCAL stage (round 6; not together with k / v adaptors); not: text2qk
-    projections (text width != query width), clip-scale on the global stage."""
+    """Every injection mode and adaptor, clip-scale on either stage (round 6; on the local stage not together with k / v adaptors); not:
+    text2qk projections (text width != query width)."""
     from .projector import _plain_injector
     lc, gc = proj.local_compressor, proj.global_compressor
     for c in (lc, gc):
@@ -58,7 +58,7 @@ def _supported(proj) -> bool:
             return False
     if proj.local_logit is not None and lc is not None and (lc.adapt_k or lc.adapt_v):
         return False
-    return proj.global_logit is None
+    return True
 
 
 def _f32_params(proj):
@@ -405,7 +405,9 @@ class _CompressorFn(torch.autograd.Function):
             with torch.no_grad():
                 res = _backward_outputs(dout, *args, store=store, gstore=gstore, ctx16=ctx16, ff_grad=hold)
             d_ff = hold["d_ff"]
-        elif gb is None or gb:
+        elif (gb is None or gb) and proj.local_logit is None and proj.global_logit is None:
+            # (clip-scale: the logits are TRAINABLE numbers the launches take by value -- a captured graph would keep replaying the values
+            # of the step it was captured in; that recipe takes the eager backward)
             res = _graphed_backward(dout, *args, store=store, gstore=gstore, ctx16=ctx16)
         else:
             with torch.no_grad():
@@ -569,6 +571,52 @@ def _row_index(rows, dev):
     if _ROW_HOLD is not None:
         _ROW_HOLD.append(t)
     return t
+
+
+def _global_clip_backward(ff, pe, pos0, scores, ds, R, nq, nh, hd, q32, Wq, bq, Wk, bk, log_scale, grads, P):
+    """Clip-scale on the GLOBAL stage under autograd (reference projector.py:184-191; `global_logit_scale` / `global_logit_bias` are trainable
+    under `attn_scale`, train.py:730-733): projected queries and keys are L2-normalised over the FULL width before the heads are split,
+        s[(q,h), n] = e^ls  qhat_{q,h} . k_{n,h} / ||k_n|| + lb,     k_n = W_k (x_n + pe_n) + b_k,     qhat_q = (W_q q + b_q) / ||.||
+    Given dS (= p (dP - delta), out of the stream backward kernel) this fills d logit_scale / d logit_bias and d k_proj, and returns the
+    gradient w.r.t. the RAW projected queries W_q q + b_q (the caller goes on from there exactly as without clip-scale).  With
+    inv_n = 1 / ||k_n||, u = s / inv (the un-normalised logits) and du = dS inv:
+        d qt_r = sum_n du[r,n] (x_n + pe_n)   (qt_r = e^ls W_k,h^T qhat_h: the fold),      d c_r = sum_n du[r,n]   (c_r = e^ls qhat_h . b_k,h)
+        d inv_n = sum_r dS[r,n] u[r,n]   =>   d k_n (norm path) = w_n k_n,   w_n = -inv_n^2 sum_r dS[r,n] s[r,n]
+        d W_k = e^ls qhat (x) d qt  +  W_k G + b_k g^T,     G = sum_n w_n x'_n x'_n^T,   g = sum_n w_n x'_n       (x' = x + pe)
+        d b_k = e^ls qhat d c       +  W_k g + b_k sum_n w_n
+    The token-stream sized products (k, G) are plain library GEMMs in fp32: this recipe appears in none of the reference's scripts."""
+    T, H, W, E = ff.shape
+    N = T * H * W
+    dev = ff.device
+    sc = math.exp(log_scale)
+    xp = ff.view(N, E).float()
+    if pe is not None:
+        t0i, y0i, x0i = pos0
+        xp = (xp.view(T, H, W, E) + pe[t0i:t0i + T].view(T, 1, 1, E) + pe[y0i:y0i + H].view(1, H, 1, E) + pe[x0i:x0i + W].view(1, 1, W, E)).view(N, E)
+    bk_ = bk if bk is not None else torch.zeros(E, dtype=torch.float32, device=dev)
+    k = torch.addmm(bk_, xp, Wk.t())                                       # [N, E]
+    inv = 1.0 / k.norm(dim=-1)
+    del k
+    S, dS = scores[:R, :N], ds[:R, :N]
+    du = dS * inv.unsqueeze(0)
+    dqt = (du @ xp).view(nq, nh, E)
+    dc = du.sum(1).view(nq, nh)
+    wn = -(inv * inv) * (dS * S).sum(0)                                    # [N]
+    xw = xp * wn.unsqueeze(1)
+    G = xw.t() @ xp                                                        # [E, E]
+    g = xw.sum(0)
+    del xw
+    qraw = q32 @ Wq.t() + bq
+    nrm = qraw.norm(dim=-1, keepdim=True)
+    qhat = qraw / nrm
+    qh = qhat.view(nq, nh, hd)
+    grads[P + "attn_layer.k_proj.weight"] = sc * torch.einsum("qhj,qhe->hje", qh, dqt).reshape(E, E) + Wk @ G + torch.outer(bk_, g)
+    if bk is not None:
+        grads[P + "attn_layer.k_proj.bias"] = sc * torch.einsum("qhj,qh->hj", qh, dc).reshape(E) + Wk @ g + bk_ * wn.sum()
+    dqhat = sc * (torch.einsum("hje,qhe->qhj", Wk.view(nh, hd, E), dqt) + bk_.view(1, nh, hd) * dc.unsqueeze(2)).reshape(nq, E)
+    grads["global_logit_scale"] = (dS * S).sum().reshape(1)                # d s / d ls = s - lb, and the logits here are kept without lb
+    grads["global_logit_bias"] = torch.zeros(1, dtype=torch.float32, device=dev)   # a per-row shift: softmax cancels it
+    return (dqhat - qhat * (qhat * dqhat).sum(-1, keepdim=True)) / nrm
 
 
 def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, want_guide=False, adaptor_saved=None, global_saved=None,
@@ -784,10 +832,12 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
         # (guide off, reference stage 1: IdentityMap injector, :586-587)
         q_in, n_rows = gc.injected_queries(guide)
         nq = q_in.shape[0]
-        if global_saved is not None:
+        clip_g = proj.global_logit if "global" in stages else None        # (log scale, bias): clip-scale on the global stage (reference :184-191)
+        if global_saved is not None and clip_g is None:
             ml, acc, scores = global_saved                                 # kept by the training forward (_GlobalStore)
         else:
-            ml, acc, scores = gc.partial_context(ff, q_in, need_scores=True)   # HIP: forward logits + softmax state, rows q*nh + h
+            ml, acc, scores = gc.partial_context(ff, q_in, need_scores=True,   # HIP: forward logits + softmax state, rows q*nh + h
+                                                 logit_scale=None if clip_g is None else clip_g[0])
         R = ml.shape[0]
         ctxg = (acc / ml[:, 1:2]).view(nq, nh, E)                          # per-(query, head) contexts
         q32 = q_in.float()
@@ -833,7 +883,8 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
             nv.linear(dctx, pe, None, pos_b, M=R)
         nparts = nv.global_stream_nparts(N, rows_pad)
         part = torch.empty((nparts, rows_pad, E), dtype=torch.float32, device=dev)
-        in_kernel = pe is not None and nv.global_stream_has_marg(N, E, rows_pad, H, W, nparts) and ff_grad is None   # (d frames_feature reads dS)
+        in_kernel = (pe is not None and nv.global_stream_has_marg(N, E, rows_pad, H, W, nparts) and ff_grad is None   # (d frames_feature reads dS)
+                     and clip_g is None)                                  # (so does clip-scale: the key norms scale it per token)
         if in_kernel:
             # many rows: the stream kernel leaves the t / y / x marginals of dS per token chunk -- the [rows, N] dS tensor is never written
             pm = torch.empty((nparts, rows_pad, nv.global_stream_marg_width(H, W)), dtype=torch.float32, device=dev)
@@ -865,16 +916,20 @@ def compressor_backward(proj, ff, fe, guide, modal, nl, dout, want_fe=False, wan
             if pe is not None:
                 dS = ds[:R, :N].view(R, T, H, W)
                 mT, mY, mX = dS.sum((2, 3)), dS.sum((1, 3)), dS.sum((1, 2))
-        dqt = part.sum(0)[:R]                                              # sum_n dS[r, n] x_n
-        if pe is not None:
-            dqt = dqt + mT @ pe[t0i:t0i + T] + mY @ pe[y0i:y0i + H] + mX @ pe[x0i:x0i + W]
-        dqt = dqt.view(nq, nh, E)
-        # ---- through the fold: qt[q,h] = scale W_k,h^T (W_q q + b_q)[q, h-slice]  (ref :180-181,:193-197) ---------
-        scale = att.scale
-        qp = (q32 @ Wq.t() + bq).view(nq, nh, hd)
-        grads[P + "attn_layer.k_proj.weight"] = scale * torch.einsum("qhj,qhe->hje", qp, dqt).reshape(E, E)
-        grads[P + "attn_layer.k_proj.bias"] = torch.zeros(E, device=dev)   # a per-row logit shift: softmax cancels it exactly
-        dqp = scale * torch.einsum("hje,qhe->qhj", Wk.view(nh, hd, E), dqt).reshape(nq, E)
+        if clip_g is None:
+            dqt = part.sum(0)[:R]                                          # sum_n dS[r, n] x_n
+            if pe is not None:
+                dqt = dqt + mT @ pe[t0i:t0i + T] + mY @ pe[y0i:y0i + H] + mX @ pe[x0i:x0i + W]
+            dqt = dqt.view(nq, nh, E)
+            # ---- through the fold: qt[q,h] = scale W_k,h^T (W_q q + b_q)[q, h-slice]  (ref :180-181,:193-197) ---------
+            scale = att.scale
+            qp = (q32 @ Wq.t() + bq).view(nq, nh, hd)
+            grads[P + "attn_layer.k_proj.weight"] = scale * torch.einsum("qhj,qhe->hje", qp, dqt).reshape(E, E)
+            grads[P + "attn_layer.k_proj.bias"] = torch.zeros(E, device=dev)   # a per-row logit shift: softmax cancels it exactly
+            dqp = scale * torch.einsum("hje,qhe->qhj", Wk.view(nh, hd, E), dqt).reshape(nq, E)
+        else:
+            dqp = _global_clip_backward(ff, pe, (t0i, y0i, x0i), scores, ds, R, nq, nh, hd, q32, Wq, bq, Wk, f32.get(A + "k_proj.bias"),
+                                        float(clip_g[0]), grads, P)
         grads[P + "attn_layer.q_proj.weight"] = dqp.t() @ q32
         grads[P + "attn_layer.q_proj.bias"] = _sum0(dqp)
         if gc.use_guide in (None, "off"):

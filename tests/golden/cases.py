@@ -83,6 +83,14 @@ CASES_EXTRA = {
     "G8h_clip_local_coarse": dict(cfg=dict(mm_projector_type="local43", use_guide="coarse"), T=4, h=6, w=9, logit=dict(local=(2.0, -3.0), glob=None)),
     "G8i_clip_local_fine": dict(cfg=dict(mm_projector_type="local43", use_guide="fine"), T=4, h=6, w=6, guide_len=9, logit=dict(local=(2.5, 1.0), glob=None)),
 }
+# clip-scale on the GLOBAL stage under autograd (golden_grad_v3.npz: clip_global_grads): global-only projectors, every injection mode
+CASES_CLIP_GLOBAL = {
+    "G8j_clip_global_direct": dict(cfg=dict(mm_projector_type="global32"), T=4, h=6, w=6, logit=dict(local=None, glob=(1.5, -2.0))),
+    "G8k_clip_global_off": dict(cfg=dict(mm_projector_type="global32", use_guide=None), T=4, h=6, w=6, logit=dict(local=None, glob=(2.0, 0.5))),
+    "G8l_clip_global_coarse": dict(cfg=dict(mm_projector_type="global32", use_guide="coarse"), T=3, h=6, w=5, logit=dict(local=None, glob=(1.0, -1.0))),
+    "G8m_clip_global_fine": dict(cfg=dict(mm_projector_type="global32", use_guide="fine"), T=4, h=6, w=6, guide_len=9, logit=dict(local=None, glob=(2.5, 1.0))),
+}
+CASES_EXTRA.update(CASES_CLIP_GLOBAL)
 
 DEFAULT_CFG = dict(mm_projector_type="local43_global32_coarse", use_guide="direct", use_clip_scale="",
                    mm_patch_merge_type="spatial_unpad", mm_newline_position="no_token",

@@ -75,7 +75,38 @@ def anyres_grads(proj, blobs2):
         print(name, "(anyres) params with grad:", sum(1 for _, gr in items if gr is not None), "/", len(items))
 
 
-CLIP_LOCAL_CASES = list(cases.CASES_EXTRA)               # clip-scale on the local stage under autograd, into golden_grad_v3.npz
+CLIP_LOCAL_CASES = [k for k in cases.CASES_EXTRA if k not in cases.CASES_CLIP_GLOBAL]     # clip-scale on the local stage under autograd, into golden_grad_v3.npz
+CLIP_GLOBAL_CASES = list(cases.CASES_CLIP_GLOBAL)
+
+
+def clip_global_grads(proj, blobs3):
+    """GlobalCompressor.forward(ff, fe, g, modal, logit_scale, logit_bias) of the reference with the two logits as leaf tensors (reference
+    projector.py:634-646 -> :184-191; HIComProjector.forward passes its `global_logit_scale` / `global_logit_bias` parameters there): gradients of
+    the compressor's parameters, of both logits and of guide_embed for loss = sum(out * R)."""
+    for name in CLIP_GLOBAL_CASES:
+        case = cases.build_case(name)
+        torch.manual_seed(0)
+        module = proj.build_vision_projector(case.cfg).float().train()
+        module.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd.items()}, strict=True)
+        t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))
+        ff, fe, g = t(case.ff), t(case.fe), t(case.g)
+        uses_guide = getattr(case.cfg, "use_guide", None) in ("direct", "coarse", "fine")
+        if uses_guide:
+            g = g.clone().requires_grad_(True)
+        ls = torch.tensor(float(case.logit["glob"][0]), requires_grad=True)
+        lb = torch.tensor(float(case.logit["glob"][1]), requires_grad=True)
+        out = module.global_compressor(ff, fe, g, case.modal, ls, lb)
+        out = out.reshape(-1, out.shape[-1])
+        R = torch.from_numpy(cotangent(name, out.shape))
+        (out * R).sum().backward()
+        items = [(k, p.grad) for k, p in module.named_parameters()]
+        items += [("global_logit_scale", ls.grad.reshape(1)), ("global_logit_bias", (lb.grad if lb.grad is not None else torch.zeros(())).reshape(1))]
+        if uses_guide:
+            items.append(("__guide_embed__", g.grad))
+        store(blobs3, name, items)
+        blobs3[f"{name}/out_shape"] = np.array(out.shape, dtype=np.int64)
+        blobs3[f"{name}/out"] = out.detach().numpy().astype(np.float32)
+        print(name, "(clip-scale global) d logit_scale", float(ls.grad), "params with grad:", sum(1 for _, gr in items if gr is not None), "/", len(items))
 
 
 def clip_local_grads(proj, blobs3):
@@ -146,6 +177,7 @@ def main():
     blobs3 = {}
     clip_local_grads(proj, blobs3)
     ff_grads(proj, blobs3)
+    clip_global_grads(proj, blobs3)
     blobs = {}
     blobs2 = {}     # golden_grad_v2.npz: d frames_embed of the recipes that do NOT inject the guide (guide off: frames_embed are the window
     #                 keys), and the parameter gradients of anyres dict inputs

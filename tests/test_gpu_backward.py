@@ -177,6 +177,45 @@ def test_clip_scale_local_gradients_match_reference_autograd(name):
     assert abs(float(m.local_logit_scale.grad)) > 1e-3                      # (a real number, not a placeholder)
 
 
+@pytest.mark.parametrize("name", ["G8j_clip_global_direct", "G8k_clip_global_off", "G8l_clip_global_coarse", "G8m_clip_global_fine"])
+def test_clip_scale_global_gradients_match_reference_autograd(name):
+    """Round 6 (verdict r5 #6a, the global half): clip-scale on the GLOBAL stage under autograd -- projected queries and keys L2-normalised over the
+    full width before the heads are split (reference projector.py:184-191), `global_logit_scale` / `global_logit_bias` trainable under `attn_scale`
+    (train.py:730-733).  Fixture: the reference's own autograd through direct GlobalCompressor calls with the logits as leaf tensors
+    (golden_grad_v3.npz, make_golden_grad.py: clip_global_grads); the build runs HIComProjector.forward of a global-only projector with
+    config.use_clip_scale = 'global'.  d k_proj.bias is no longer zero here: the key norm sees the bias."""
+    import make_golden_grad as mg
+    from hicom_amd import autograd as hag
+    z = np.load(os.path.join(ROOT, "tests", "golden", "golden_grad_v3.npz"))
+    gold = {k: z[k] for k in z.files}
+    case = cases.build_case(name)
+    case.cfg.use_clip_scale = "global"
+    m = build_module(case).train()
+    m.set_clip_logits(glob=case.logit["glob"])
+    for n, p in m.named_parameters():
+        if "logit_scale" in n or "logit_bias" in n:
+            p.requires_grad_(True)
+    ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
+    inputs = []
+    if f"{name}/__guide_embed__/samples" in gold:
+        g.requires_grad_(True)
+        inputs.append(("__guide_embed__", g))
+    with torch.no_grad():
+        want_out = m(ff, fe, g, case.modal, None).clone()
+    assert float((want_out.float().cpu() - torch.from_numpy(gold[f"{name}/out"])).abs().max()) <= 2e-3        # the forward, against the reference's
+    for step in range(2):                                                   # (twice: the second backward of a shape is where a graph would replay)
+        m.zero_grad(set_to_none=True)
+        if inputs:
+            g.grad = None
+        out = m(ff, fe, g, case.modal, None)
+        assert out.requires_grad and torch.equal(out.detach(), want_out) and tuple(out.shape) == tuple(gold[f"{name}/out_shape"])
+        (out * torch.from_numpy(mg.cotangent(name, out.shape)).cuda()).sum().backward()
+        items = [(k, p) for k, p in m.named_parameters()] + inputs
+        assert {"global_logit_scale", "global_logit_bias"} <= {k for k, _ in items}
+        assert _check_against_fixture(name, items, dict(hag.LAST_FP32_GRADS), gold) >= 10 + len(inputs)
+    assert abs(float(m.global_logit_scale.grad)) > 1e-4
+
+
 @pytest.mark.parametrize("name", ["G1_direct_T8", "G9_local_only", "G9_global_only", "G4_direct_T1", "G10_peaky_direct", "G12_clip768_direct",
                                   "G2_off_T8", "G2b_off_string", "G6_coarse", "G7_fine", "G7b_guide_override", "G12b_clip768_off",
                                   "G5_adaptkv", "G5b_adaptqkvg_off", "G3_direct_T7", "G9_local22"])
@@ -220,24 +259,24 @@ def test_frames_feature_gradient_matches_reference_autograd(name, with_fe):
 
 
 def test_unsupported_recipes_and_input_grads_refuse():
-    """clip-scale on the GLOBAL stage has no backward (the local stage's: round 6, test above); the k / v adaptors' backward over overlapping windows is not built
+    """The k / v adaptors' backward over overlapping windows is not built
     (input gradients over overlapping windows: round 6, tests above): all must raise, never return a detached tensor or a silent None.  (Guide off: d frames_embed exists since
     round 5 -- fixture golden_grad_v2 -- and d guide_embed is None, as in the reference: the guide does not enter that forward.)"""
-    import hicom_amd
-    case = cases.build_case("G8_clip_scale")
-    case.cfg.use_clip_scale = "local,global"
-    m = hicom_amd.build_vision_projector(case.cfg)
-    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd.items()}, strict=False)     # (the four logit parameters: set below)
-    m = m.to(torch.bfloat16).cuda().train()
-    m.set_clip_logits(local=case.logit["local"], glob=case.logit["glob"])
-    with pytest.raises(NotImplementedError):
-        m(dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g), case.modal, None)
     # k / v adaptors over a partition that does not divide the axes: the adaptor backward's per-token buffers are written once per token
     case = cases.build_case("G5_adaptkv")
     m = build_module(case).train()
     ff7 = torch.cat([dev_bf16(case.ff), dev_bf16(case.ff)[:3]]).contiguous()      # T = 7 under a temporal kernel of 4: windows [0, 4) and [3, 7)
     fe7 = torch.cat([dev_bf16(case.fe), dev_bf16(case.fe)[:3]]).contiguous()
     out = m(ff7, fe7, dev_bf16(case.g), case.modal, None)
+    with pytest.raises(NotImplementedError):
+        out.sum().backward()
+    # d frames_feature beside clip-scale
+    case = cases.build_case("G8f_clip_local_direct")
+    case.cfg.use_clip_scale = "local"
+    m = build_module(case).train()
+    m.set_clip_logits(local=case.logit["local"])
+    ffg = dev_bf16(case.ff).requires_grad_(True)
+    out = m(ffg, dev_bf16(case.fe), dev_bf16(case.g), case.modal, None)
     with pytest.raises(NotImplementedError):
         out.sum().backward()
     case = cases.build_case("G2_off_T8")
