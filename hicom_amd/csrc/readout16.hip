@@ -1086,7 +1086,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             return;
         }
         if constexpr (PRE == 1) {
-            // (the argument block sits behind the 14 preloaded dwords)
+            // (the argument block sits behind the 14 preloaded dwords: four pointers + six ints, and it is 8-byte aligned)
+            static_assert(4 * sizeof(void*) + 6 * sizeof(int) == 56 && alignof(R16Params) <= 8, "kernel-argument offset of the parameter block");
             r16_kernarg_ptr late = (r16_kernarg_ptr)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + 56);
             ChainNoMid none;
             if (p.aux.N > 1536) {
