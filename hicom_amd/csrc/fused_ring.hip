@@ -962,6 +962,9 @@ extern "C" int hicom_fused_stream_nparts(int32_t n_windows) {
     if (n_windows <= 0) return HICOM_EINVAL;
     const int slots = fused_num_cus();                           // one resident workgroup per CU
     int wpw = (n_windows + slots - 1) / slots;                   // equal windows per workgroup
+    // (HICOM_RING_WPW: dev -- more windows per workgroup = fewer streaming CUs: is the launch bound by the chip's HBM or by what one CU pulls?)
+    static const int wpw_env = getenv("HICOM_RING_WPW") ? atoi(getenv("HICOM_RING_WPW")) : 0;
+    if (wpw_env > wpw) wpw = wpw_env;
     if (wpw > kMaxWinPerWg) wpw = kMaxWinPerWg;
     return (n_windows + wpw - 1) / wpw;
 }
