@@ -584,6 +584,13 @@ __device__ __forceinline__ void merge_vproj_role(const R16Params& p, int ai, int
         merge_vproj_fixed_item<64, true>(p.mv, it % nslab, it / nslab, lds);
 }
 
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void r16_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        r16_static_for<N, I + 1>(f);
+    }
+}
 template <int N>
 __device__ __forceinline__ void r16_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -786,6 +793,48 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
 #pragma unroll
                 for (int i = 0; i < MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[ks][j], f.a[ks][i], acc[j][i], 0, 0, 0);
     };
+    // The stage's MFMAs with the NEXT ring stage's DMA pieces issued BETWEEN them.  A wave is alone on its SIMD: nothing but its own instruction
+    // stream overlaps anything, and a DMA instruction (64 lanes x 16 B) holds the CU's address unit for ~16 clocks -- with four waves issuing their
+    // pieces together right behind the barrier, a wave sat ~320-460 clocks in front of its MFMAs (tools/r16_hot_trace.py: 740 clocks per 64-deep
+    // step on cache-hot operands, the same as in the step: the K loop was bound by its own instruction order, not by memory).  Interleaved, the
+    // address unit works under the matrix pipe: GAP MFMAs, one piece, GAP MFMAs, one piece, ...  (sched_barrier pins the order: hipcc's
+    // scheduler would regroup them).
+    auto issue_piece = [&](auto I, int s_issue, char* base) {
+        constexpr int i = decltype(I)::value;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + 64 * s_issue),
+                                         (__attribute__((address_space(3))) void*)(base + dst_off[i]), 16, 0, i < AW ? kAuxA : 0);
+    };
+    // (The fragment reads of stage s + 1 stay in ONE group in front of the MFMAs.  tools/r16_hot_trace.py with the loop taken apart, cache-hot
+    // operands, clocks per 64-deep step of the 96 x 64 tile: barrier + 10 ds_read_b128 + their landing 440, + the 12 MFMAs 175, + the 5 DMA pieces
+    // 110 = 725.  One read per MFMA gap as well bought another 7-13 % of the K loop -- but with reads between the MFMAs hipcc rotates the
+    // accumulator blocks through the AGPRs from step to step (20 v_accvgpr moves per step), and the way around that, every MFMA as inline asm, takes
+    // the accumulators out of the hazard recogniser's sight: a compiler copy of an accumulator behind an MFMA in flight showed up at the loop exits
+    // and one parity case failed.  Not kept: profiles/r06_q_r16_loop.txt.)
+    auto compute_issue = [&](const Frags& f, Frags& nxt, int slot_rd, int s_issue, int ring_slot, bool do_issue) {
+        constexpr int NM = 2 * NJ * MI, GAP = NM / PW > 0 ? NM / PW : 1;
+        char* base = lds + ring_slot * STAGE;
+        read(slot_rd, nxt);                       // the reads of stage s+1 first: they fly under the MFMAs of stage s
+        __builtin_amdgcn_sched_barrier(0);
+        r16_static_for<NM>([&](auto M) {
+            constexpr int m = decltype(M)::value;
+            constexpr int ks = m / (NJ * MI), j = (m / MI) % NJ, i = m % MI;
+#ifndef HICOM_R16_DEV_NO_MFMA
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[ks][j], f.a[ks][i], acc[j][i], 0, 0, 0);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (m % GAP == GAP - 1 && m / GAP < PW) {
+#ifndef HICOM_R16_DEV_NO_DMA
+                if (do_issue) issue_piece(std::integral_constant<int, m / GAP>{}, s_issue, base);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // (pieces the MFMA count did not reach: none for the three tile shapes -- NM / GAP >= PW)
+        r16_static_for<PW>([&](auto I) {
+            if constexpr (decltype(I)::value >= NM / GAP)
+                if (do_issue) issue_piece(I, s_issue, base);
+        });
+    };
 
     // prologue: stages 0 .. kRRing-2 in flight, stage 0 landed, its fragments on the way
     const int npro = ns < kRRing - 1 ? ns : kRRing - 1;
@@ -856,6 +905,8 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
     int slot_next = 1;                 // ring slot of stage s+1
     int slot_issue = kRRing - 1;       // ring slot of stage s+kRRing-1 (= the slot of stage s-1)
     auto step = [&](auto steady, int s, const Frags& cur, Frags& nxt) {
+#ifdef HICOM_R16_SERIAL_ISSUE
+        // (round 2-6 form, dev A/B: every piece of the next ring stage right behind the barrier, then the reads, then the MFMAs)
         if constexpr (decltype(steady)::value) {
             r16_wait_vm<(kRRing - 3) * PW>();         // stage s+1 landed (this wave's pieces); s+2 .. s+kRRing-2 may fly
             __builtin_amdgcn_s_barrier();
@@ -873,6 +924,22 @@ __device__ __forceinline__ bool r16_tile(const R16Params& p, int tile, char* lds
         compute(cur);
         __builtin_amdgcn_sched_barrier(0);
         land(nxt);
+#else
+        bool do_issue = true;
+        if constexpr (decltype(steady)::value) {
+            r16_wait_vm<(kRRing - 3) * PW>();         // stage s+1 landed (this wave's pieces); s+2 .. s+kRRing-2 may fly
+        } else {
+            const int ahead = (ns - 1 < s + kRRing - 2 ? ns - 1 : s + kRRing - 2) - (s + 1);
+            wait_stages(ahead);
+            do_issue = s + kRRing - 1 < ns;
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        compute_issue(cur, nxt, slot_next, s + kRRing - 1, slot_issue, do_issue);      // MFMAs of stage s with the reads of s+1 and the pieces of s+kRRing-1 in their gaps
+        __builtin_amdgcn_sched_barrier(0);
+        land(nxt);
+#endif
         slot_next = slot_next + 1 == kRRing ? 0 : slot_next + 1;
         slot_issue = slot_issue + 1 == kRRing ? 0 : slot_issue + 1;
     };
