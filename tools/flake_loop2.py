@@ -16,6 +16,8 @@ def one(name, how):
     case = cases.build_case(name)
     ma, mb = build_module(case).train(), build_module(case).train()
     mb.graph_backward = False
+    if os.environ.get("FLAKE_ONE_STREAM", "0") == "1":
+        ma.overlap_stages = mb.overlap_stages = False               # the operator-by-operator forward on ONE stream
     ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
     gen = torch.Generator(device="cuda").manual_seed(11)
     R = None
@@ -62,4 +64,4 @@ for rep in range(reps):
                 if msg:
                     fails += 1
                     print(f"FAIL rep {rep} {name} {how}: {msg}", flush=True)
-print(f"FLAKE_LOOP2 sync={SYNC} only_b={ONLY_B} nofence={os.environ.get('HICOM_EVENT_NOFENCE', '1')}: failures={fails} of {runs} runs in {time.time() - t0:.0f} s", flush=True)
+print(f"FLAKE_LOOP2 one_stream={os.environ.get('FLAKE_ONE_STREAM', '0')} sync={SYNC} only_b={ONLY_B} nofence={os.environ.get('HICOM_EVENT_NOFENCE', '1')}: failures={fails} of {runs} runs in {time.time() - t0:.0f} s", flush=True)
