@@ -18,6 +18,10 @@ def one(name, how):
     mb.graph_backward = False
     if os.environ.get("FLAKE_ONE_STREAM", "0") == "1":
         ma.overlap_stages = mb.overlap_stages = False               # the operator-by-operator forward on ONE stream
+    if os.environ.get("FLAKE_NO_GSTORE", "0") == "1":
+        ma.share_global_state = mb.share_global_state = False       # the backward streams the tokens again instead of reading the forward's store
+    if os.environ.get("FLAKE_NO_CTX", "0") == "1":
+        ma.share_window_contexts = mb.share_window_contexts = False
     ff, fe, g = dev_bf16(case.ff), dev_bf16(case.fe), dev_bf16(case.g)
     gen = torch.Generator(device="cuda").manual_seed(11)
     R = None
@@ -64,4 +68,4 @@ for rep in range(reps):
                 if msg:
                     fails += 1
                     print(f"FAIL rep {rep} {name} {how}: {msg}", flush=True)
-print(f"FLAKE_LOOP2 one_stream={os.environ.get('FLAKE_ONE_STREAM', '0')} sync={SYNC} only_b={ONLY_B} nofence={os.environ.get('HICOM_EVENT_NOFENCE', '1')}: failures={fails} of {runs} runs in {time.time() - t0:.0f} s", flush=True)
+print(f"FLAKE_LOOP2 one_stream={os.environ.get('FLAKE_ONE_STREAM', '0')} no_gstore={os.environ.get('FLAKE_NO_GSTORE', '0')} no_ctx={os.environ.get('FLAKE_NO_CTX', '0')} sync={SYNC} only_b={ONLY_B} nofence={os.environ.get('HICOM_EVENT_NOFENCE', '1')}: failures={fails} of {runs} runs in {time.time() - t0:.0f} s", flush=True)
