@@ -167,14 +167,6 @@ def _global_store(proj, ff):
     streams the tokens again, as gradient checkpointing would)."""
     if proj.global_compressor is None or getattr(proj, "share_global_state", True) is False:
         return None
-    # The eager-backward opt-out (`graph_backward = False`) streams the tokens again instead of reading the forward's store.  With the store, about one
-    # training forward in 10^2-10^3 of the coarse / fine recipes (box-dependent) came out with global rows 3e-6..2e-4 off its own repeat -- the forward
-    # that WRITES the store at the addresses the previous eager backward had just READ, beside the local stage on the side stream.  On a box that
-    # showed it 4 times in 480 runs, neither the store-less form (0 of 240) nor the one-stream forward (0 of 240) did (profiles/r06_v_flake.txt);
-    # the mechanism behind that is not established.  The default (captured) backward keeps the store -- its graph reads it by address -- and has
-    # never shown the transient.
-    if getattr(proj, "graph_backward", None) is False:
-        return None
     stores = proj.__dict__.setdefault("_global_stores", {})
     key = (tuple(ff.shape), str(ff.device))
     st = stores.get(key)
