@@ -27,7 +27,8 @@ def one(name, how):
     R = None
     for stepno in range(5):
         outs = []
-        for m in ((mb,) if ONLY_B else (ma, mb)):
+        order = (mb,) if ONLY_B else ((mb, ma) if os.environ.get("FLAKE_ORDER", "ab") == "ba" else (ma, mb))
+        for m in order:
             m.zero_grad(set_to_none=True)
             out = m(ff, fe, g, case.modal, None)
             if SYNC == "after_fwd":
@@ -38,11 +39,12 @@ def one(name, how):
             if SYNC == "after_bwd":
                 torch.cuda.synchronize()
             outs.append(out.detach().clone())
-        with torch.no_grad():
-            rb = mb(ff, fe, g, case.modal, None)                    # the same weights, again: a forward that differs from its own repeat is the flake
-        if not torch.equal(rb, outs[-1]):
-            d = (outs[-1].float() - rb.float()).abs()
-            return f"step {stepno}: mb's training forward differs from its repeat by {float(d.max()):.3e}, rows {torch.nonzero(d.amax(1) > 0).flatten()[:6].tolist()}"
+        for which, m, o in zip(("ma" if m_ is ma else "mb" for m_ in order), order, outs):
+            with torch.no_grad():
+                r = m(ff, fe, g, case.modal, None)                  # the same weights, again: a forward that differs from its own repeat is the flake
+            if not torch.equal(r, o):
+                d = (o.float() - r.float()).abs()
+                return f"step {stepno}: {which}'s training forward differs from its repeat by {float(d.max()):.3e}, rows {torch.nonzero(d.amax(1) > 0).flatten()[:6].tolist()}"
         with torch.no_grad():
             for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
                 delta = (torch.randn(pa.shape, device="cuda", generator=gen) * 0.01).to(pa.dtype)
@@ -68,4 +70,4 @@ for rep in range(reps):
                 if msg:
                     fails += 1
                     print(f"FAIL rep {rep} {name} {how}: {msg}", flush=True)
-print(f"FLAKE_LOOP2 one_stream={os.environ.get('FLAKE_ONE_STREAM', '0')} no_gstore={os.environ.get('FLAKE_NO_GSTORE', '0')} no_ctx={os.environ.get('FLAKE_NO_CTX', '0')} sync={SYNC} only_b={ONLY_B} nofence={os.environ.get('HICOM_EVENT_NOFENCE', '1')}: failures={fails} of {runs} runs in {time.time() - t0:.0f} s", flush=True)
+print(f"FLAKE_LOOP2 order={os.environ.get('FLAKE_ORDER', 'ab')} one_stream={os.environ.get('FLAKE_ONE_STREAM', '0')} no_gstore={os.environ.get('FLAKE_NO_GSTORE', '0')} no_ctx={os.environ.get('FLAKE_NO_CTX', '0')} sync={SYNC} only_b={ONLY_B} nofence={os.environ.get('HICOM_EVENT_NOFENCE', '1')}: failures={fails} of {runs} runs in {time.time() - t0:.0f} s", flush=True)

@@ -5,8 +5,7 @@ export HICOM_EVENT_NOFENCE=0
 run() { env "$@" timeout 900 python3 tools/flake_loop2.py ${REPS:-8} 2>&1 | grep -E "FAIL|FLAKE_LOOP2" | cut -c1-260; }
 REPS=10 run A=1 | tee $O/base.txt
 if grep -q "^FAIL" $O/base.txt; then
-  REPS=20 run FLAKE_ONE_STREAM=1 | tee $O/one_stream.txt
-  REPS=20 run FLAKE_NO_GSTORE=1 | tee $O/no_gstore.txt
-  REPS=20 run FLAKE_NO_CTX=1 | tee $O/no_ctx.txt
-  REPS=10 run A=1 | tee $O/base2.txt
+  # (second hunt: does the victim follow the ORDER of the two modules?  ab: the eager module's forward runs right behind the graph module's replay)
+  REPS=24 run FLAKE_ORDER=ba | tee $O/order_ba.txt
+  REPS=12 run FLAKE_ORDER=ab | tee $O/order_ab.txt
 fi
