@@ -206,3 +206,21 @@ def test_data_alias_reads_do_not_move_the_weights_epoch_and_writes_do():
     assert nv.weights_epoch() == e0 + 3 and len(nv._DATA_ALIASES) == 0
     lin.weight.data = torch.ones(4, 4)
     assert nv.weights_epoch() == e0 + 4
+
+
+def test_device_event_factory_has_the_surface_the_callers_use():
+    """hicom_amd/events.py: a stream-to-stream event is either the raw HIP event (hipEventDisableSystemFence) or -- no HIP device, no library by that
+    name, HICOM_EVENT_NOFENCE=0 -- a torch event; both expose record / wait / cuda_event (engine._DeviceResources, dist._shard_plan,
+    projector._two_stream_forward)."""
+    import importlib
+    from hicom_amd import events
+    ev = events.device_event()
+    assert hasattr(ev, "record") and hasattr(ev, "wait")
+    os.environ["HICOM_EVENT_NOFENCE"] = "0"
+    try:
+        importlib.reload(events)
+        import torch
+        assert isinstance(events.device_event(), torch.cuda.Event)
+    finally:
+        os.environ.pop("HICOM_EVENT_NOFENCE", None)
+        importlib.reload(events)
